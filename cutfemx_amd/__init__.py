@@ -1,0 +1,20 @@
+"""cutfemx_amd: MI355X-native cut-FEM quadrature-and-assembly engine.
+
+Drop-in for the CutFEMx hot path (classification -> sub-triangulation ->
+runtime quadrature -> local tensors + ghost penalty -> CSR) with the reference's
+API names (python/cutfemx/__init__.py:19-48).  All compute runs in hand-written
+HIP kernels for gfx950 behind the C ABI of include/cutfemx_amd.h; importing the
+package needs no GPU, calling into it does.
+"""
+from . import fem
+from .cut import (CutData, FacetRows, RuntimeQuadratureRules, cut, full_cell_rules, ghost_penalty_facets,
+                  level_set_value, locate_entities, locate_entities_device, normal, runtime_quadrature,
+                  runtime_quadratures, update)
+from .mesh import Function, FunctionSpace, Mesh, box_mesh_arrays, lagrange_dofmap
+
+__all__ = [
+    "CutData", "FacetRows", "RuntimeQuadratureRules", "cut", "update", "locate_entities",
+    "locate_entities_device", "runtime_quadrature", "runtime_quadratures", "full_cell_rules",
+    "ghost_penalty_facets", "normal", "level_set_value", "Mesh", "FunctionSpace", "Function",
+    "box_mesh_arrays", "lagrange_dofmap", "fem",
+]

@@ -1,0 +1,171 @@
+"""ctypes binding of libcutfemx_amd.so (the C ABI in include/cutfemx_amd.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device is
+present when a compute entry point is called, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libcutfemx_amd.so"
+
+OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_OUT_OF_RANGE, ERR_HIP = 0, -1, -2, -3, -4
+
+INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
+CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
+K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
+L_SOURCE, L_NITSCHE_RHS = 101, 102
+F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
+
+
+class CutOptions(C.Structure):
+    _fields_ = [("cut_approximation_order", C.c_int32), ("max_refinement_iterations", C.c_int32),
+                ("edge_max_depth", C.c_int32), ("reserved", C.c_int32)]
+
+
+class RulesView(C.Structure):
+    _fields_ = [("tdim", C.c_int32), ("gdim", C.c_int32), ("nq", C.c_int64), ("nr", C.c_int64),
+                ("points", C.c_void_p), ("weights", C.c_void_p), ("offsets", C.c_void_p),
+                ("parent_map", C.c_void_p)]
+
+
+class Integral(C.Structure):
+    _fields_ = [("type", C.c_int32), ("kernel", C.c_int32), ("qdegree", C.c_int32),
+                ("point_stride", C.c_int32), ("entities", C.c_void_p), ("n_entities", C.c_int64),
+                ("rules", C.c_void_p), ("point_data", C.c_void_p), ("params", C.c_double * 8)]
+
+
+class PatternView(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("nnz", C.c_int64), ("indptr", C.c_void_p),
+                ("indices", C.c_void_p)]
+
+
+# every symbol declared in include/cutfemx_amd.h
+SYMBOLS = [
+    "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_copy",
+    "cfx_device_alloc", "cfx_device_free", "cfx_profile_enable", "cfx_profile_reset",
+    "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
+    "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box",
+    "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
+    "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
+    "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
+    "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
+    "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_cut_destroy", "cfx_space_create",
+    "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_create_sparsity",
+    "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_vector",
+    "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
+    "cfx_active_destroy",
+]
+
+_lib = None
+_initialised = False
+
+
+def load():
+    """dlopen the engine (no GPU needed for this step)."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). cutfemx_amd has no CPU fallback.")
+        _lib = C.CDLL(str(LIB_PATH))
+        _lib.cfx_last_error.restype = C.c_char_p
+        for name in SYMBOLS:
+            getattr(_lib, name)  # AttributeError if the ABI and the header diverge
+    return _lib
+
+
+def lib():
+    """Engine with an initialised HIP device (raises without one)."""
+    global _initialised
+    l = load()
+    if not _initialised:
+        check(l.cfx_init(_default_device()))
+        _initialised = True
+    return l
+
+
+def _default_device() -> int:
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("CFX_DEVICE") is None \
+        else int(os.environ["CFX_DEVICE"])
+
+
+def check(code: int):
+    if code == OK:
+        return
+    msg = (load().cfx_last_error() or b"").decode()
+    if code == ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    if code == ERR_OUT_OF_RANGE:
+        raise IndexError(msg)
+    raise RuntimeError(msg)
+
+
+class DeviceBuffer:
+    """Raw HBM allocation owned by Python (cfx_device_alloc / cfx_device_free)."""
+
+    def __init__(self, count: int, dtype, shape=None):
+        self.dtype = np.dtype(dtype)
+        self.size = int(count)
+        self.shape = shape if shape is not None else (self.size,)
+        self.ndim = len(self.shape)
+        p = C.c_void_p()
+        check(lib().cfx_device_alloc(C.byref(p), C.c_size_t(max(self.size, 1) * self.dtype.itemsize)))
+        self.ptr = p.value
+
+    def numpy(self) -> np.ndarray:
+        return download(self.ptr, self.size, self.dtype).reshape(self.shape)
+
+    def fill_from(self, host: np.ndarray):
+        host = np.ascontiguousarray(host, dtype=self.dtype)
+        check(lib().cfx_copy(C.c_void_p(self.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(host.nbytes)))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                load().cfx_device_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def is_torch(a) -> bool:
+    return type(a).__module__.startswith("torch")
+
+
+def is_device(a) -> bool:
+    return isinstance(a, DeviceBuffer) or (is_torch(a) and a.is_cuda)
+
+
+def as_ptr(a, dtype, keep: list):
+    """Pointer to a contiguous array of `dtype` (numpy host array or torch tensor)."""
+    if a is None:
+        return None
+    if isinstance(a, DeviceBuffer):
+        if a.dtype != np.dtype(dtype):
+            raise TypeError(f"device buffer has dtype {a.dtype}, expected {np.dtype(dtype)}")
+        keep.append(a)
+        return C.c_void_p(a.ptr)
+    if is_torch(a):
+        import torch
+        want = {np.float64: torch.float64, np.int32: torch.int32, np.int8: torch.int8}[dtype]
+        if a.dtype != want or not a.is_contiguous():
+            a = a.to(want).contiguous()
+        keep.append(a)
+        return C.c_void_p(a.data_ptr())
+    arr = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(arr)
+    return arr.ctypes.data_as(C.c_void_p)
+
+
+def download(ptr, n: int, dtype) -> np.ndarray:
+    out = np.empty(int(n), dtype=dtype)
+    if n > 0:
+        check(lib().cfx_copy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), C.c_size_t(out.nbytes)))
+    return out

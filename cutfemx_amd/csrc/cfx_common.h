@@ -1,0 +1,332 @@
+// cutfemx_amd: shared host/device plumbing for the HIP engine (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/cutfemx_amd.h"
+
+namespace cfx
+{
+
+// ---------------------------------------------------------------------------
+// errors: C++ exceptions inside, status code + thread-local message outside
+// ---------------------------------------------------------------------------
+struct Error : std::runtime_error
+{
+  int code;
+  Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+extern thread_local std::string g_last_error;
+
+#define CFX_HIP(expr)                                                                   \
+  do                                                                                    \
+  {                                                                                     \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess)                                                               \
+      throw ::cfx::Error(CFX_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+#define CFX_API_BEGIN try {
+#define CFX_API_END                                                   \
+  return CFX_OK;                                                      \
+  }                                                                   \
+  catch (const ::cfx::Error& e)                                       \
+  {                                                                   \
+    ::cfx::g_last_error = e.what();                                   \
+    return e.code;                                                    \
+  }                                                                   \
+  catch (const std::exception& e)                                     \
+  {                                                                   \
+    ::cfx::g_last_error = e.what();                                   \
+    return CFX_ERR_RUNTIME;                                           \
+  }
+
+inline void require(bool ok, int code, const char* msg)
+{
+  if (!ok) throw Error(code, msg);
+}
+
+// ---------------------------------------------------------------------------
+// context: device, stream, per-kernel profile
+// ---------------------------------------------------------------------------
+struct ProfileEntry
+{
+  std::string name;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+};
+
+struct Context
+{
+  int device = -1;
+  bool initialised = false;
+  hipStream_t stream = nullptr;
+  bool profile = false;
+  std::vector<ProfileEntry> entries;
+  std::map<std::string, int> entry_index;
+  struct Pending { int entry; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+
+  void ensure();
+  hipEvent_t get_event();
+  int entry(const char* name);
+  void flush_profile();
+};
+
+Context& ctx();
+
+// launch with optional HIP-event bracketing on the library stream
+template <typename K, typename... Args>
+inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shmem, Args... args)
+{
+  Context& c = ctx();
+  if (grid.x == 0) return;
+  if (c.profile)
+  {
+    hipEvent_t a = c.get_event(), b = c.get_event();
+    CFX_HIP(hipEventRecord(a, c.stream));
+    hipLaunchKernelGGL(kernel, grid, block, shmem, c.stream, args...);
+    CFX_HIP(hipEventRecord(b, c.stream));
+    c.pending.push_back({c.entry(name), a, b});
+  }
+  else
+  {
+    hipLaunchKernelGGL(kernel, grid, block, shmem, c.stream, args...);
+  }
+  CFX_HIP(hipGetLastError());
+}
+
+inline dim3 grid_for(int64_t n, int block = 256)
+{
+  int64_t g = (n + block - 1) / block;
+  if (g > 2147483647LL) throw Error(CFX_ERR_RUNTIME, "grid too large");
+  return dim3((unsigned)g);
+}
+
+// ---------------------------------------------------------------------------
+// device arrays: owning (stream-ordered allocation) or aliasing a caller pointer
+// ---------------------------------------------------------------------------
+template <typename T>
+struct DevArray
+{
+  T* p = nullptr;
+  int64_t n = 0;
+  bool owned = false;
+
+  DevArray() = default;
+  explicit DevArray(int64_t count) { alloc(count); }
+  DevArray(const DevArray&) = delete;
+  DevArray& operator=(const DevArray&) = delete;
+  DevArray(DevArray&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = false; }
+  DevArray& operator=(DevArray&& o) noexcept
+  {
+    if (this != &o)
+    {
+      release();
+      p = o.p; n = o.n; owned = o.owned;
+      o.p = nullptr; o.n = 0; o.owned = false;
+    }
+    return *this;
+  }
+  ~DevArray() { release(); }
+
+  void alloc(int64_t count)
+  {
+    release();
+    n = count;
+    owned = true;
+    // never hand out a null pointer for an empty array
+    CFX_HIP(hipMallocAsync((void**)&p, sizeof(T) * (size_t)(count > 0 ? count : 1), ctx().stream));
+  }
+  void release()
+  {
+    if (p && owned) (void)hipFreeAsync(p, ctx().stream);
+    p = nullptr; n = 0; owned = false;
+  }
+  void zero() { if (n > 0) CFX_HIP(hipMemsetAsync(p, 0, sizeof(T) * (size_t)n, ctx().stream)); }
+  T* get() const { return p; }
+};
+
+bool is_device_pointer(const void* p);
+
+// device copy of an input array: aliases device pointers, uploads host ones
+template <typename T>
+inline DevArray<T> to_device(const T* src, int64_t n)
+{
+  DevArray<T> a;
+  if (src == nullptr || n == 0) { a.alloc(0); return a; }
+  if (is_device_pointer(src))
+  {
+    a.p = const_cast<T*>(src); a.n = n; a.owned = false;
+    return a;
+  }
+  a.alloc(n);
+  CFX_HIP(hipMemcpyAsync(a.p, src, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
+  CFX_HIP(hipStreamSynchronize(ctx().stream)); // the host buffer may die right after the call
+  return a;
+}
+
+template <typename T>
+inline T read_scalar(const T* dev)
+{
+  T v;
+  CFX_HIP(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  return v;
+}
+
+template <typename T>
+inline std::vector<T> download(const T* dev, int64_t n)
+{
+  std::vector<T> v((size_t)n);
+  if (n > 0)
+  {
+    CFX_HIP(hipMemcpyAsync(v.data(), dev, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx().stream));
+    CFX_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  return v;
+}
+
+// an output pointer supplied by the caller: device pointers are written in
+// place, host pointers through a staging buffer copied back at the end
+template <typename T>
+struct OutArray
+{
+  T* user = nullptr;
+  DevArray<T> staging;
+  T* dev = nullptr;
+  int64_t n = 0;
+  OutArray(T* dst, int64_t count, bool copy_in) : user(dst), n(count)
+  {
+    if (is_device_pointer(dst)) { dev = dst; return; }
+    staging.alloc(count);
+    dev = staging.p;
+    if (copy_in && count > 0)
+      CFX_HIP(hipMemcpyAsync(dev, dst, sizeof(T) * (size_t)count, hipMemcpyHostToDevice, ctx().stream));
+  }
+  void finish()
+  {
+    if (dev != user && n > 0)
+    {
+      CFX_HIP(hipMemcpyAsync(user, dev, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx().stream));
+      CFX_HIP(hipStreamSynchronize(ctx().stream));
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// device primitives (cfx_primitives.hip)
+// ---------------------------------------------------------------------------
+// out[0..n] = exclusive scan of in[0..n-1]; out[n] = total
+void exclusive_scan(const int32_t* in, int64_t* out, int64_t n);
+void exclusive_scan(const int32_t* in, int32_t* out, int64_t n);
+void exclusive_scan(const int64_t* in, int64_t* out, int64_t n);
+
+// ---------------------------------------------------------------------------
+// handles
+// ---------------------------------------------------------------------------
+struct Adjacency
+{
+  // item -> cells incidence (CSR), cells ascending inside each segment
+  DevArray<int64_t> offsets; // [nitems+1]
+  DevArray<int32_t> cells;   // [ncells*width]
+  bool built = false;
+};
+
+void build_adjacency(const int32_t* map, int64_t ncells, int width, int64_t nitems, Adjacency& adj);
+
+} // namespace cfx
+
+struct cfx_mesh_s
+{
+  int tdim = 0, gdim = 0;
+  int64_t nnodes = 0, ncells = 0;
+  cfx::DevArray<double> x;     // [nnodes*3]
+  cfx::DevArray<int32_t> conn; // [ncells*(tdim+1)]
+  cfx::Adjacency v2c;          // vertex -> cells
+  const cfx::Adjacency& vertex_cells()
+  {
+    if (!v2c.built) cfx::build_adjacency(conn.p, ncells, tdim + 1, nnodes, v2c);
+    return v2c;
+  }
+};
+
+struct cfx_rules_s
+{
+  cfx_mesh_t mesh = nullptr;
+  int tdim = 0, gdim = 0;
+  int64_t nq = 0, nr = 0;
+  cfx::DevArray<double> points, weights;
+  cfx::DevArray<int32_t> offsets, parent_map;
+};
+
+struct cfx_cut_s
+{
+  cfx_mesh_t mesh = nullptr;
+  int nls = 0;
+  int ls_ndofs_cell = 0;
+  int64_t ls_ndofs = 0;
+  cfx_cut_options options{};
+  cfx::DevArray<int32_t> ls_dofmap;
+  std::vector<cfx::DevArray<double>> ls_values;
+  cfx::DevArray<int8_t> domain; // [nls*ncells]
+  std::map<std::string, cfx::DevArray<int32_t>> located;
+  std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
+};
+
+struct cfx_space_s
+{
+  cfx_mesh_t mesh = nullptr;
+  int degree = 1, bs = 1, ndofs_cell = 0;
+  int64_t ndofs = 0;
+  cfx::DevArray<int32_t> dofmap;
+  cfx::Adjacency d2c; // dof -> cells
+  const cfx::Adjacency& dof_cells()
+  {
+    if (!d2c.built) cfx::build_adjacency(dofmap.p, mesh->ncells, ndofs_cell, ndofs, d2c);
+    return d2c;
+  }
+};
+
+struct cfx_integral_dev
+{
+  int type = 0, kernel = 0, qdegree = 0, point_stride = 0;
+  cfx::DevArray<int32_t> entities;
+  int64_t n_entities = 0;
+  cfx_rules_t rules = nullptr;
+  cfx::DevArray<double> point_data;
+  double params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+struct cfx_form_s
+{
+  cfx_space_t V = nullptr;
+  int rank = 2;
+  std::vector<cfx_integral_dev> integrals;
+};
+
+struct cfx_pattern_s
+{
+  int64_t nrows = 0, nnz = 0;
+  cfx::DevArray<int64_t> indptr;
+  cfx::DevArray<int32_t> indices;
+};
+
+struct cfx_active_s
+{
+  cfx_space_t V = nullptr;
+  cfx::DevArray<int32_t> active_cells, inactive_dofs;
+  int64_t n_active = 0, n_inactive = 0;
+};

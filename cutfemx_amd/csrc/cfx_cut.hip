@@ -1,0 +1,1092 @@
+// cutfemx_amd: level-set classification, selector scan, cut-cell
+// sub-triangulation + runtime quadrature, per-point level-set evaluators and
+// ghost-penalty facet selection -- HIP kernels for gfx950 and their C ABI.
+//
+// Replaces (paths relative to the CutFEMx tree):
+//   cpp/cutfemx/cut/cut.cpp:845-868   update()  -> cutcells::cut        (a1, a2)
+//   cpp/cutfemx/cut/cut.cpp:877-924   locate_entities()                  (a4)
+//   cpp/cutfemx/cut/cut.cpp:1311-1335 runtime_quadrature()               (a3)
+//   cpp/cutfemx/level_set/normal.h:39-187, value.h:34-119                (a12)
+//   python/cutfemx/cut.py:340-380     ghost_penalty_facets()             (a7)
+#include <cctype>
+#include <cstdlib>
+
+#include "cfx_device.h"
+
+#define CFX_QUAD_TABLE_QUALIFIER static __device__ const
+#include "cfx_quadrature_tables.h"
+#undef CFX_QUAD_TABLE_QUALIFIER
+
+using namespace cfx;
+
+namespace cfx
+{
+// number of points of the reference rule of `degree` on a `dim`-simplex (cfx_quadhost.cpp)
+int quad_npoints(int dim, int degree);
+} // namespace cfx
+
+namespace
+{
+
+// ---------------------------------------------------------------------------
+// selector: DNF over (level set, relation) clauses.  relation -> set of
+// domains, cut.cpp:323-342.  bit0 inside, bit1 intersected, bit2 outside.
+// ---------------------------------------------------------------------------
+constexpr int kMaxClauses = 16;
+
+struct Selector
+{
+  int n = 0;
+  int ls[kMaxClauses];
+  int mask[kMaxClauses];
+  int term[kMaxClauses];
+};
+
+Selector parse_selector(const char* s, int nls)
+{
+  require(s != nullptr, CFX_ERR_INVALID_ARGUMENT, "selector is null");
+  Selector sel;
+  int term = 0;
+  const char* p = s;
+  auto fail = [&](const char* why)
+  { throw Error(CFX_ERR_INVALID_ARGUMENT, std::string("invalid selector '") + s + "': " + why); };
+  for (;;)
+  {
+    while (*p && isspace((unsigned char)*p)) ++p;
+    if (!*p) fail("expected a level-set name");
+    const char* b = p;
+    while (*p && (isalnum((unsigned char)*p) || *p == '_')) ++p;
+    if (p == b) fail("expected a level-set name");
+    const size_t len = (size_t)(p - b);
+    int ls = -1;
+    if (len >= 3 && strncmp(b, "phi", 3) == 0)
+    {
+      ls = 0;
+      for (size_t i = 3; i < len; ++i)
+      {
+        if (!isdigit((unsigned char)b[i])) { ls = -1; break; }
+        ls = 10 * ls + (b[i] - '0');
+      }
+    }
+    if (ls < 0 || ls >= nls) fail("unknown level-set name");
+    while (*p && isspace((unsigned char)*p)) ++p;
+    int mask = 0;
+    if (p[0] == '<' && p[1] == '=') { mask = 1 | 2; p += 2; }
+    else if (p[0] == '>' && p[1] == '=') { mask = 4 | 2; p += 2; }
+    else if (p[0] == '=' && p[1] == '=') { mask = 2; p += 2; }
+    else if (p[0] == '<') { mask = 1; p += 1; }
+    else if (p[0] == '>') { mask = 4; p += 1; }
+    else if (p[0] == '=') { mask = 2; p += 1; }
+    else fail("expected a relation (<, <=, =, >=, >)");
+    while (*p && isspace((unsigned char)*p)) ++p;
+    char* e = nullptr;
+    const double rhs = strtod(p, &e);
+    if (e == p || rhs != 0.0) fail("right-hand side must be 0");
+    p = e;
+    if (sel.n >= kMaxClauses) fail("too many clauses");
+    sel.ls[sel.n] = ls; sel.mask[sel.n] = mask; sel.term[sel.n] = term; ++sel.n;
+    while (*p && isspace((unsigned char)*p)) ++p;
+    if (!*p) break;
+    if (strncmp(p, "and", 3) == 0) p += 3;
+    else if (strncmp(p, "&&", 2) == 0) p += 2;
+    else if (*p == '&') p += 1;
+    else if (strncmp(p, "or", 2) == 0) { p += 2; ++term; }
+    else if (strncmp(p, "||", 2) == 0) { p += 2; ++term; }
+    else if (*p == '|') { p += 1; ++term; }
+    else fail("expected 'and' / 'or'");
+  }
+  return sel;
+}
+
+struct SelectorPred
+{
+  const int8_t* domain;
+  int64_t ncells;
+  Selector sel;
+  __device__ bool operator()(int64_t c) const
+  {
+    const int nterm = sel.term[sel.n - 1] + 1;
+    for (int t = 0; t < nterm; ++t)
+    {
+      bool ok = true, any = false;
+      for (int k = 0; k < sel.n; ++k)
+      {
+        if (sel.term[k] != t) continue;
+        any = true;
+        const int d = domain[(int64_t)sel.ls[k] * ncells + c];
+        if (!((sel.mask[k] >> (d + 1)) & 1)) { ok = false; break; }
+      }
+      if (any && ok) return true;
+    }
+    return false;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// a1 classification: one thread per cell, coalesced dofmap rows (16 B/lane for
+// tets), gathered level-set values (L2/MALL resident), 1 B/cell out.
+// ---------------------------------------------------------------------------
+template <int ND>
+__global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const int32_t* __restrict__ dofmap,
+                                                          const double* __restrict__ phi, int8_t* __restrict__ domain)
+{
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= ncells) return;
+  int32_t d[ND];
+  if constexpr (ND == 4)
+  {
+    const int4 v = *reinterpret_cast<const int4*>(dofmap + c * 4);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = dofmap[c * ND + i];
+  }
+  bool all_neg = true, all_pos = true;
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    const double v = phi[d[i]];
+    all_neg = all_neg && (v < 0.0);
+    all_pos = all_pos && (v > 0.0);
+  }
+  domain[c] = all_neg ? (int8_t)CFX_INSIDE : (all_pos ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+}
+
+// ---------------------------------------------------------------------------
+// a2 sub-triangulation tables.  A vertex is "negative" iff phi < 0 (zeros side
+// with the positive part).  Local point ids: 0..tdim parent vertices, then the
+// cut points on edges (a negative, b non-negative).  Built once on the host.
+// ---------------------------------------------------------------------------
+struct CutCase
+{
+  int8_t n_in, n_out, n_if, npts;
+  int8_t edge[4][2];
+  int8_t in[3][4];
+  int8_t out[3][4];
+  int8_t iface[2][3];
+};
+
+__constant__ CutCase c_cases[2][16];
+
+void prism(int8_t dst[3][4], int a0, int a1, int a2, int b0, int b1, int b2)
+{
+  const int t[3][4] = {{a0, a1, a2, b2}, {a0, a1, b1, b2}, {a0, b0, b1, b2}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) dst[i][j] = (int8_t)t[i][j];
+}
+
+CutCase make_case(int tdim, int mask)
+{
+  CutCase s;
+  memset(&s, 0, sizeof(s));
+  const int nv = tdim + 1;
+  int neg[4], pos[4], nn = 0, np = 0;
+  for (int v = 0; v < nv; ++v)
+    if ((mask >> v) & 1) neg[nn++] = v; else pos[np++] = v;
+  int npts = nv;
+  auto cutp = [&](int a, int b)
+  {
+    s.edge[npts - nv][0] = (int8_t)a; s.edge[npts - nv][1] = (int8_t)b;
+    return npts++;
+  };
+  auto set = [](int8_t* d, int a, int b, int c, int e = 0) { d[0] = (int8_t)a; d[1] = (int8_t)b; d[2] = (int8_t)c; d[3] = (int8_t)e; };
+  auto set3 = [](int8_t* d, int a, int b, int c) { d[0] = (int8_t)a; d[1] = (int8_t)b; d[2] = (int8_t)c; };
+  if (tdim == 2)
+  {
+    if (nn == 0) { s.n_out = 1; set(s.out[0], 0, 1, 2); }
+    else if (nn == 3) { s.n_in = 1; set(s.in[0], 0, 1, 2); }
+    else if (nn == 1)
+    {
+      const int a = neg[0], b0 = pos[0], b1 = pos[1];
+      const int q0 = cutp(a, b0), q1 = cutp(a, b1);
+      s.n_in = 1; set(s.in[0], a, q0, q1);
+      s.n_out = 2; set(s.out[0], q0, b0, b1); set(s.out[1], q0, b1, q1);
+      s.n_if = 1; set3(s.iface[0], q0, q1, 0);
+    }
+    else
+    {
+      const int a0 = neg[0], a1 = neg[1], b = pos[0];
+      const int q0 = cutp(a0, b), q1 = cutp(a1, b);
+      s.n_in = 2; set(s.in[0], a0, a1, q1); set(s.in[1], a0, q1, q0);
+      s.n_out = 1; set(s.out[0], b, q0, q1);
+      s.n_if = 1; set3(s.iface[0], q0, q1, 0);
+    }
+  }
+  else
+  {
+    if (nn == 0) { s.n_out = 1; set(s.out[0], 0, 1, 2, 3); }
+    else if (nn == 4) { s.n_in = 1; set(s.in[0], 0, 1, 2, 3); }
+    else if (nn == 1)
+    {
+      const int a = neg[0];
+      const int q0 = cutp(a, pos[0]), q1 = cutp(a, pos[1]), q2 = cutp(a, pos[2]);
+      s.n_in = 1; set(s.in[0], a, q0, q1, q2);
+      s.n_out = 3; prism(s.out, q0, q1, q2, pos[0], pos[1], pos[2]);
+      s.n_if = 1; set3(s.iface[0], q0, q1, q2);
+    }
+    else if (nn == 3)
+    {
+      const int b = pos[0];
+      const int q0 = cutp(neg[0], b), q1 = cutp(neg[1], b), q2 = cutp(neg[2], b);
+      s.n_in = 3; prism(s.in, q0, q1, q2, neg[0], neg[1], neg[2]);
+      s.n_out = 1; set(s.out[0], b, q0, q1, q2);
+      s.n_if = 1; set3(s.iface[0], q0, q1, q2);
+    }
+    else
+    {
+      const int a0 = neg[0], a1 = neg[1], b0 = pos[0], b1 = pos[1];
+      const int q00 = cutp(a0, b0), q01 = cutp(a0, b1), q10 = cutp(a1, b0), q11 = cutp(a1, b1);
+      s.n_in = 3; prism(s.in, a0, q00, q01, a1, q10, q11);
+      s.n_out = 3; prism(s.out, b0, q00, q10, b1, q01, q11);
+      s.n_if = 2; set3(s.iface[0], q00, q01, q11); set3(s.iface[1], q00, q11, q10);
+    }
+  }
+  s.npts = (int8_t)npts;
+  return s;
+}
+
+CutCase h_cases[2][16];
+bool g_cases_ready = false;
+
+void ensure_cases()
+{
+  if (g_cases_ready) return;
+  for (int t = 2; t <= 3; ++t)
+    for (int m = 0; m < 16; ++m) h_cases[t - 2][m] = make_case(t, m & ((1 << (t + 1)) - 1));
+  CFX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_cases), h_cases, sizeof(h_cases)));
+  g_cases_ready = true;
+}
+
+enum Part { PART_IN = 0, PART_OUT = 1, PART_IF = 2 };
+
+template <int TDIM>
+__device__ __forceinline__ int sign_mask(const double* phi)
+{
+  int m = 0;
+#pragma unroll
+  for (int v = 0; v <= TDIM; ++v) m |= (phi[v] < 0.0) ? (1 << v) : 0;
+  return m;
+}
+
+// per cut cell: number of rules and points it will emit for `part`
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) cut_count_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
+                                                           const int32_t* __restrict__ ls_dofmap,
+                                                           const double* __restrict__ phi_v, int part, int nref,
+                                                           int32_t* __restrict__ n_rules, int32_t* __restrict__ n_points)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncut) return;
+  const int64_t c = cut_cells[i];
+  double phi[TDIM + 1];
+#pragma unroll
+  for (int v = 0; v <= TDIM; ++v) phi[v] = phi_v[ls_dofmap[c * (TDIM + 1) + v]];
+  const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
+  const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
+  n_rules[i] = part == PART_IF ? ns : (ns > 0 ? 1 : 0);
+  n_points[i] = ns * nref;
+}
+
+// parent-reference coordinates of local point p of the cut case
+template <int TDIM>
+__device__ __forceinline__ void local_point(const CutCase& cs, int p, const double* phi, double* X)
+{
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) X[d] = 0.0;
+  if (p <= TDIM)
+  {
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) X[d] = (p == d + 1) ? 1.0 : 0.0;
+    return;
+  }
+  const int a = cs.edge[p - (TDIM + 1)][0], b = cs.edge[p - (TDIM + 1)][1];
+  double pa = 0.0, pb = 0.0;
+#pragma unroll
+  for (int v = 0; v <= TDIM; ++v)
+  {
+    pa = (v == a) ? phi[v] : pa;
+    pb = (v == b) ? phi[v] : pb;
+  }
+  const double t = pa / (pa - pb); // a negative, b non-negative: t in [0,1]
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    const double xa = (a == d + 1) ? 1.0 : 0.0, xb = (b == d + 1) ? 1.0 : 0.0;
+    X[d] = xa + t * (xb - xa);
+  }
+}
+
+template <int TDIM>
+__device__ __forceinline__ const double* ref_points(int dim, int degree, int& n, const double*& w)
+{
+  if (dim == 1)
+  {
+    n = cfx_quad_offset_1d[degree + 1] - cfx_quad_offset_1d[degree];
+    w = cfx_quad_weights_1d + cfx_quad_offset_1d[degree];
+    return cfx_quad_points_1d + cfx_quad_offset_1d[degree];
+  }
+  if (dim == 2)
+  {
+    n = cfx_quad_offset_2d[degree + 1] - cfx_quad_offset_2d[degree];
+    w = cfx_quad_weights_2d + cfx_quad_offset_2d[degree];
+    return cfx_quad_points_2d + 2 * cfx_quad_offset_2d[degree];
+  }
+  n = cfx_quad_offset_3d[degree + 1] - cfx_quad_offset_3d[degree];
+  w = cfx_quad_weights_3d + cfx_quad_offset_3d[degree];
+  return cfx_quad_points_3d + 3 * cfx_quad_offset_3d[degree];
+}
+
+// ---------------------------------------------------------------------------
+// a2+a3 emit: ONE WAVEFRONT PER CUT CELL.  Lanes 0..tdim stage the cell's
+// vertex coordinates and level-set values in LDS; every lane then owns one
+// (sub-simplex, reference point) pair, so the wave writes one contiguous run
+// of points/weights.  points = parent-reference coords; weights = physical
+// measure (w_ref |det sub->parent| |det parent->phys|, surface measure for the
+// interface).  Volume parts: one rule per cut cell; interface: one rule per
+// sub-facet (cut.cpp:1286-1294).
+// ---------------------------------------------------------------------------
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) cut_emit_kernel(
+    int64_t ncut, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
+    const int32_t* __restrict__ conn, const int32_t* __restrict__ ls_dofmap, const double* __restrict__ phi_v,
+    int part, int degree, const int32_t* __restrict__ rule_off, const int32_t* __restrict__ point_off,
+    double* __restrict__ points, double* __restrict__ weights, int32_t* __restrict__ offsets,
+    int32_t* __restrict__ parent_map)
+{
+  constexpr int NV = TDIM + 1;
+  __shared__ double s_phi[kBlock / 64][NV];
+  __shared__ double s_x[kBlock / 64][NV][TDIM];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + wave;
+  const bool live = i < ncut;
+  const int64_t c = live ? cut_cells[i] : 0;
+  if (live && lane < NV)
+  {
+    const int64_t v = conn[c * NV + lane];
+    s_phi[wave][lane] = phi_v[ls_dofmap[c * NV + lane]];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) s_x[wave][lane][d] = x[3 * v + d];
+  }
+  __syncthreads();
+  if (!live) return;
+
+  double phi[NV];
+  Geo<TDIM> g;
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+  {
+    phi[v] = s_phi[wave][v];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) g.x[v][d] = s_x[wave][v][d];
+  }
+  const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
+  const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
+  if (ns == 0) return;
+  int nref;
+  const double* wref;
+  const double* pref = ref_points<TDIM>(part == PART_IF ? TDIM - 1 : TDIM, degree, nref, wref);
+  const int npts = ns * nref;
+  const int32_t pbase = point_off[i], rbase = rule_off[i];
+
+  // J[d][t] = x_{t+1}[d] - x_0[d]
+  double J[TDIM][TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) J[d][t] = g.x[t + 1][d] - g.x[0][d];
+  double detJ;
+  if constexpr (TDIM == 2) detJ = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  else
+    detJ = J[0][0] * (J[1][1] * J[2][2] - J[1][2] * J[2][1]) + J[0][1] * (J[1][2] * J[2][0] - J[1][0] * J[2][2])
+           + J[0][2] * (J[1][0] * J[2][1] - J[1][1] * J[2][0]);
+  detJ = fabs(detJ);
+
+  for (int pt = lane; pt < npts; pt += 64)
+  {
+    const int k = pt / nref, q = pt - k * nref;
+    double V[NV][TDIM];
+    if (part == PART_IF)
+    {
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j) local_point<TDIM>(cs, cs.iface[k][j], phi, V[j]);
+      // physical sub-facet vertices -> surface measure
+      double xp[TDIM][TDIM];
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j)
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double v = g.x[0][d];
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t) v += J[d][t] * V[j][t];
+          xp[j][d] = v;
+        }
+      double scale;
+      if constexpr (TDIM == 2)
+      {
+        const double dx = xp[1][0] - xp[0][0], dy = xp[1][1] - xp[0][1];
+        scale = sqrt(dx * dx + dy * dy);
+      }
+      else
+      {
+        double a[3], b[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a[d] = xp[1][d] - xp[0][d]; b[d] = xp[2][d] - xp[0][d]; }
+        const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+        scale = sqrt(cx * cx + cy * cy + cz * cz);
+      }
+      const double* xi = pref + (TDIM - 1) * q;
+      double l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM - 1; ++t) l0 -= xi[t];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = l0 * V[0][d];
+#pragma unroll
+        for (int t = 0; t < TDIM - 1; ++t) v += xi[t] * V[t + 1][d];
+        points[(int64_t)(pbase + pt) * TDIM + d] = v;
+      }
+      weights[pbase + pt] = wref[q] * scale;
+    }
+    else
+    {
+      const int8_t* sx = part == PART_IN ? cs.in[k] : cs.out[k];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) local_point<TDIM>(cs, sx[j], phi, V[j]);
+      double dsub;
+      if constexpr (TDIM == 2)
+        dsub = (V[1][0] - V[0][0]) * (V[2][1] - V[0][1]) - (V[1][1] - V[0][1]) * (V[2][0] - V[0][0]);
+      else
+      {
+        double a[3], b[3], e[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { a[d] = V[1][d] - V[0][d]; b[d] = V[2][d] - V[0][d]; e[d] = V[3][d] - V[0][d]; }
+        dsub = a[0] * (b[1] * e[2] - b[2] * e[1]) - a[1] * (b[0] * e[2] - b[2] * e[0]) + a[2] * (b[0] * e[1] - b[1] * e[0]);
+      }
+      const double scale = fabs(dsub) * detJ;
+      const double* xi = pref + TDIM * q;
+      double l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) l0 -= xi[t];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = l0 * V[0][d];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v += xi[t] * V[t + 1][d];
+        points[(int64_t)(pbase + pt) * TDIM + d] = v;
+      }
+      weights[pbase + pt] = wref[q] * scale;
+    }
+  }
+  if (lane == 0)
+  {
+    if (part == PART_IF)
+    {
+      for (int f = 0; f < ns; ++f)
+      {
+        parent_map[rbase + f] = (int32_t)c;
+        offsets[rbase + f + 1] = pbase + (f + 1) * nref;
+      }
+    }
+    else
+    {
+      parent_map[rbase] = (int32_t)c;
+      offsets[rbase + 1] = pbase + npts;
+    }
+  }
+}
+
+// whole-cell rules: reference points, weights * |detJ|
+// (python/tests/quadrature_utils.py:40-61)
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) full_rules_kernel(int64_t n, const int32_t* __restrict__ cells,
+                                                            const double* __restrict__ x,
+                                                            const int32_t* __restrict__ conn, int degree,
+                                                            double* __restrict__ points, double* __restrict__ weights,
+                                                            int32_t* __restrict__ offsets, int32_t* __restrict__ parent_map)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  Geo<TDIM> g;
+  load_cell<TDIM>(x, conn, cells[i], g);
+  jacobian<TDIM>(g);
+  int nref;
+  const double* wref;
+  const double* pref = ref_points<TDIM>(TDIM, degree, nref, wref);
+  const double detJ = fabs(g.detJ);
+  for (int q = 0; q < nref; ++q)
+  {
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) points[(i * nref + q) * TDIM + d] = pref[q * TDIM + d];
+    weights[i * nref + q] = wref[q] * detJ;
+  }
+  parent_map[i] = cells[i];
+  offsets[i + 1] = (int32_t)((i + 1) * nref);
+  if (i == 0) offsets[0] = 0;
+}
+
+// rule index of point q: largest r with offsets[r] <= q
+__device__ __forceinline__ int64_t rule_of_point(const int32_t* __restrict__ offsets, int64_t nr, int64_t q)
+{
+  int64_t lo = 0, hi = nr; // offsets[lo] <= q < offsets[hi]
+  while (hi - lo > 1)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (offsets[mid] <= q) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------
+// a12 per-point evaluators (P1 level set over P1 geometry): one thread per
+// point.  normal = sign * K^T grad_ref(phi) / max(|.|, 1e-14)
+// (cpp/cutfemx/level_set/normal.h:150-186)
+// ---------------------------------------------------------------------------
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) normals_kernel(int64_t nq, int64_t nr, const int32_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ parent_map,
+                                                         const double* __restrict__ x, const int32_t* __restrict__ conn,
+                                                         const int32_t* __restrict__ ls_dofmap,
+                                                         const double* __restrict__ phi_v, double sign,
+                                                         double* __restrict__ out)
+{
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  const int64_t c = parent_map[rule_of_point(offsets, nr, q)];
+  Geo<TDIM> g;
+  load_cell<TDIM>(x, conn, c, g);
+  jacobian<TDIM>(g);
+  double phi[TDIM + 1];
+#pragma unroll
+  for (int v = 0; v <= TDIM; ++v) phi[v] = phi_v[ls_dofmap[c * (TDIM + 1) + v]];
+  double gref[TDIM], gp[TDIM];
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) gref[t] = phi[t + 1] - phi[0];
+  double norm = 0.0;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * gref[t];
+    gp[d] = v;
+    norm += v * v;
+  }
+  norm = sqrt(norm);
+  if (norm < 1.0e-14) norm = 1.0e-14;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) out[q * TDIM + d] = sign * gp[d] / norm;
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) values_kernel(int64_t nq, int64_t nr, const int32_t* __restrict__ offsets,
+                                                        const int32_t* __restrict__ parent_map,
+                                                        const double* __restrict__ points,
+                                                        const int32_t* __restrict__ ls_dofmap,
+                                                        const double* __restrict__ phi_v, double* __restrict__ out)
+{
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  const int64_t c = parent_map[rule_of_point(offsets, nr, q)];
+  double l0 = 1.0, v = 0.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t)
+  {
+    const double X = points[q * TDIM + t];
+    l0 -= X;
+    v += X * phi_v[ls_dofmap[c * (TDIM + 1) + t + 1]];
+  }
+  out[q] = v + l0 * phi_v[ls_dofmap[c * (TDIM + 1)]];
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) physical_points_kernel(int64_t nq, int64_t nr,
+                                                                 const int32_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ parent_map,
+                                                                 const double* __restrict__ points,
+                                                                 const double* __restrict__ x,
+                                                                 const int32_t* __restrict__ conn,
+                                                                 double* __restrict__ out)
+{
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  const int64_t c = parent_map[rule_of_point(offsets, nr, q)];
+  Geo<TDIM> g;
+  load_cell<TDIM>(x, conn, c, g);
+  double X[TDIM], l0 = 1.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) { X[t] = points[q * TDIM + t]; l0 -= X[t]; }
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = l0 * g.x[0][d];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) v += X[t] * g.x[t + 1][d];
+    out[q * TDIM + d] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// a7 ghost-penalty band.  For every cut cell c (ascending) and local facet lf:
+// the neighbour n across the facet is found through the vertex->cells
+// incidence; the facet is kept when n exists, n is in (cut U selected) and --
+// if n is itself cut -- c < n, so each facet is emitted once, by its smallest
+// cut cell.  Row = (c0, lf0, c1, lf1) with c0 < c1.
+// (python/cutfemx/cut.py:340-380, python/cutfemx/wrappers/cut.cpp:84-114)
+// ---------------------------------------------------------------------------
+template <int TDIM>
+__device__ __forceinline__ bool facet_neighbour(const int32_t* __restrict__ conn, const int64_t* __restrict__ v2c_off,
+                                                const int32_t* __restrict__ v2c, int64_t c, int lf, int32_t& nb,
+                                                int& nb_lf)
+{
+  constexpr int NV = TDIM + 1;
+  int32_t cv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) cv[i] = conn[c * NV + i];
+  // pivot = first facet vertex
+  int32_t pivot = -1;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if (i != lf && pivot < 0) pivot = cv[i];
+  for (int64_t k = v2c_off[pivot]; k < v2c_off[pivot + 1]; ++k)
+  {
+    const int32_t o = v2c[k];
+    if (o == c) continue;
+    int32_t ov[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ov[i] = conn[(int64_t)o * NV + i];
+    // o shares the facet iff all facet vertices of c are vertices of o
+    bool all = true;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+    {
+      if (i == lf) continue;
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) found = found || (ov[j] == cv[i]);
+      all = all && found;
+    }
+    if (!all) continue;
+    // local facet of o = its vertex that is not on the facet
+    int olf = 0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+    {
+      bool onf = false;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) onf = onf || (i != lf && cv[i] == ov[j]);
+      if (!onf) olf = j;
+    }
+    nb = o; nb_lf = olf;
+    return true;
+  }
+  return false;
+}
+
+template <int TDIM, bool WRITE>
+__global__ void __launch_bounds__(kBlock) ghost_facets_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
+                                                              const int32_t* __restrict__ conn,
+                                                              const int64_t* __restrict__ v2c_off,
+                                                              const int32_t* __restrict__ v2c,
+                                                              const int8_t* __restrict__ domain, SelectorPred sel,
+                                                              int32_t* __restrict__ counts,
+                                                              const int64_t* __restrict__ offs, int32_t* __restrict__ rows)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncut) return;
+  const int64_t c = cut_cells[i];
+  int n = 0;
+  int64_t o = WRITE ? offs[i] : 0;
+  for (int lf = 0; lf <= TDIM; ++lf)
+  {
+    int32_t nb; int nlf;
+    if (!facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf)) continue;
+    const bool nb_cut = domain[nb] == CFX_INTERSECTED;
+    if (!(nb_cut || sel(nb))) continue;
+    if (nb_cut && nb < c) continue;
+    if (WRITE)
+    {
+      int4 r = (c < nb) ? make_int4((int)c, lf, nb, nlf) : make_int4(nb, nlf, (int)c, lf);
+      *reinterpret_cast<int4*>(rows + 4 * o) = r;
+      ++o;
+    }
+    ++n;
+  }
+  if (!WRITE) counts[i] = n;
+}
+
+struct IsCut
+{
+  const int8_t* domain;
+  __device__ bool operator()(int64_t c) const { return domain[c] == CFX_INTERSECTED; }
+};
+
+void classify(cfx_cut_t cut)
+{
+  const int64_t nc = cut->mesh->ncells;
+  for (int k = 0; k < cut->nls; ++k)
+  {
+    int8_t* dom = cut->domain.p + (int64_t)k * nc;
+    const double* phi = cut->ls_values[k].p;
+    switch (cut->ls_ndofs_cell)
+    {
+    case 3: launch("classify", classify_kernel<3>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 4: launch("classify", classify_kernel<4>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 6: launch("classify", classify_kernel<6>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 10: launch("classify", classify_kernel<10>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported level-set element (dofs per cell must be 3, 4, 6 or 10)");
+    }
+  }
+  cut->located.clear();
+  cut->ghost_rows.clear();
+}
+
+const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
+{
+  auto it = cut->located.find(selector);
+  if (it != cut->located.end()) return it->second;
+  SelectorPred pred{cut->domain.p, cut->mesh->ncells, parse_selector(selector.c_str(), cut->nls)};
+  DevArray<int32_t> out;
+  compact("locate_entities", cut->mesh->ncells, pred, out);
+  auto res = cut->located.emplace(selector, std::move(out));
+  return res.first->second;
+}
+
+} // namespace
+
+extern "C" {
+
+int cfx_cut_options_default(cfx_cut_options* opt)
+{
+  CFX_API_BEGIN
+  require(opt != nullptr, CFX_ERR_INVALID_ARGUMENT, "null options");
+  opt->cut_approximation_order = 1;
+  opt->max_refinement_iterations = 8;
+  opt->edge_max_depth = 20;
+  opt->reserved = 0;
+  CFX_API_END
+}
+
+int cfx_cut_create(cfx_mesh_t mesh, int nls, const int32_t* ls_dofmap, int ls_ndofs_cell, int64_t ls_ndofs,
+                   const double* const* ls_values, const cfx_cut_options* opt, cfx_cut_t* out)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  require(mesh && out, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create: null mesh/output");
+  // cut.cpp:97-107: at least one level set
+  require(nls >= 1 && ls_values, CFX_ERR_INVALID_ARGUMENT, "cutfemx.cut requires at least one level-set function");
+  require(nls <= 8, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create: at most 8 level sets");
+  require(ls_dofmap && ls_ndofs > 0, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create: empty level-set dofmap");
+  ensure_cases();
+  auto cut = std::make_unique<cfx_cut_s>();
+  cut->mesh = mesh;
+  cut->nls = nls;
+  cut->ls_ndofs_cell = ls_ndofs_cell;
+  cut->ls_ndofs = ls_ndofs;
+  if (opt) cut->options = *opt; else cfx_cut_options_default(&cut->options);
+  require(cut->options.cut_approximation_order == 1, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_cut_create: only straight (order-1) cut approximation is implemented");
+  cut->ls_dofmap = to_device(ls_dofmap, mesh->ncells * (int64_t)ls_ndofs_cell);
+  for (int k = 0; k < nls; ++k)
+  {
+    require(ls_values[k] != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create: null level-set values");
+    cut->ls_values.push_back(to_device(ls_values[k], ls_ndofs));
+  }
+  cut->domain.alloc((int64_t)nls * mesh->ncells);
+  classify(cut.get());
+  *out = cut.release();
+  CFX_API_END
+}
+
+int cfx_cut_update(cfx_cut_t cut, const double* const* ls_values)
+{
+  CFX_API_BEGIN
+  require(cut != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_update: null handle");
+  if (ls_values)
+    for (int k = 0; k < cut->nls; ++k)
+      if (ls_values[k]) cut->ls_values[k] = to_device(ls_values[k], cut->ls_ndofs);
+  classify(cut);
+  CFX_API_END
+}
+
+int cfx_cut_info(cfx_cut_t cut, int* tdim, int* gdim, int64_t* ncells, int* nls)
+{
+  CFX_API_BEGIN
+  require(cut != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_info: null handle");
+  if (tdim) *tdim = cut->mesh->tdim;
+  if (gdim) *gdim = cut->mesh->gdim;
+  if (ncells) *ncells = cut->mesh->ncells;
+  if (nls) *nls = cut->nls;
+  CFX_API_END
+}
+
+int cfx_cut_domain(cfx_cut_t cut, int ls, const int8_t** domain)
+{
+  CFX_API_BEGIN
+  require(cut && domain, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_domain: null argument");
+  require(ls >= 0 && ls < cut->nls, CFX_ERR_OUT_OF_RANGE, "level-set index out of range");
+  *domain = cut->domain.p + (int64_t)ls * cut->mesh->ncells;
+  CFX_API_END
+}
+
+int cfx_locate_entities(cfx_cut_t cut, const char* selector, const int32_t** entities, int64_t* n)
+{
+  CFX_API_BEGIN
+  require(cut && selector && entities && n, CFX_ERR_INVALID_ARGUMENT, "cfx_locate_entities: null argument");
+  const DevArray<int32_t>& a = locate(cut, selector);
+  *entities = a.p;
+  *n = a.n;
+  CFX_API_END
+}
+
+int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const char* backend, cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(cut && selector && out, CFX_ERR_INVALID_ARGUMENT, "cfx_runtime_quadrature: null argument");
+  if (backend && strcmp(backend, "straight") != 0)
+    throw Error(CFX_ERR_INVALID_ARGUMENT, std::string("unsupported runtime quadrature backend '") + backend
+                                              + "' (only 'straight' is implemented)");
+  require(order >= 0, CFX_ERR_INVALID_ARGUMENT, "quadrature order must be non-negative");
+  require(order <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT, "quadrature order exceeds the built-in tables");
+  require(cut->nls == 1, CFX_ERR_INVALID_ARGUMENT,
+          "runtime quadrature for several level sets is not implemented");
+  cfx_mesh_t mesh = cut->mesh;
+  const int tdim = mesh->tdim;
+  require(cut->ls_ndofs_cell == tdim + 1, CFX_ERR_INVALID_ARGUMENT,
+          "runtime quadrature requires a P1 level set (straight cuts)");
+  const Selector sel = parse_selector(selector, cut->nls);
+  require(sel.n == 1, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature expects a single-clause selector");
+  const int m = sel.mask[0];
+  const int part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
+  const int nref = quad_npoints(part == PART_IF ? tdim - 1 : tdim, order);
+
+  const DevArray<int32_t>& cutc = locate(cut, "phi=0");
+  const int64_t ncut = cutc.n;
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim;
+  DevArray<int32_t> n_rules(ncut), n_points(ncut), rule_off(ncut + 1), point_off(ncut + 1);
+  const double* phi = cut->ls_values[0].p;
+  if (ncut > 0)
+  {
+    if (tdim == 2)
+      launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+             part, nref, n_rules.p, n_points.p);
+    else
+      launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+             part, nref, n_rules.p, n_points.p);
+  }
+  // int32 offsets are part of the RuntimeQuadrature contract; guard the total in 64 bit
+  DevArray<int64_t> point_off64(ncut + 1);
+  exclusive_scan(n_points.p, point_off64.p, ncut);
+  const int64_t nq = read_scalar(point_off64.p + ncut);
+  require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
+  exclusive_scan(n_points.p, point_off.p, ncut);
+  exclusive_scan(n_rules.p, rule_off.p, ncut);
+  const int64_t nr = read_scalar(rule_off.p + ncut);
+  r->nq = nq; r->nr = nr;
+  r->points.alloc(nq * tdim);
+  r->weights.alloc(nq);
+  r->offsets.alloc(nr + 1);
+  r->parent_map.alloc(nr);
+  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  if (ncut > 0)
+  {
+    const dim3 grid((unsigned)((ncut + kBlock / 64 - 1) / (kBlock / 64)));
+    if (tdim == 2)
+      launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+             cut->ls_dofmap.p, phi, part, order, rule_off.p, point_off.p, r->points.p, r->weights.p, r->offsets.p,
+             r->parent_map.p);
+    else
+      launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+             cut->ls_dofmap.p, phi, part, order, rule_off.p, point_off.p, r->points.p, r->weights.p, r->offsets.p,
+             r->parent_map.p);
+  }
+  *out = r.release();
+  CFX_API_END
+}
+
+int cfx_full_cell_rules(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int order, cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(mesh && out && (cells || n == 0), CFX_ERR_INVALID_ARGUMENT, "cfx_full_cell_rules: null argument");
+  require(order >= 0 && order <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT, "quadrature order out of range");
+  const int tdim = mesh->tdim;
+  const int nref = quad_npoints(tdim, order);
+  require(n * nref < 2147483647LL, CFX_ERR_RUNTIME, "too many points for int32 offsets");
+  DevArray<int32_t> dcells = to_device(cells, n);
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = n; r->nq = n * nref;
+  r->points.alloc(r->nq * tdim); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
+  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  if (n > 0)
+  {
+    if (tdim == 2)
+      launch("full_rules", full_rules_kernel<2>, grid_for(n), dim3(kBlock), 0, n, dcells.p, mesh->x.p, mesh->conn.p,
+             order, r->points.p, r->weights.p, r->offsets.p, r->parent_map.p);
+    else
+      launch("full_rules", full_rules_kernel<3>, grid_for(n), dim3(kBlock), 0, n, dcells.p, mesh->x.p, mesh->conn.p,
+             order, r->points.p, r->weights.p, r->offsets.p, r->parent_map.p);
+  }
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  *out = r.release();
+  CFX_API_END
+}
+
+int cfx_rules_create(cfx_mesh_t mesh, int tdim, int64_t nq, int64_t nr, const double* points, const double* weights,
+                     const int32_t* offsets, const int32_t* parent_map, cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(mesh && out, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_create: null argument");
+  require(tdim == mesh->tdim, CFX_ERR_INVALID_ARGUMENT, "rules tdim must match the mesh");
+  require(nq >= 0 && nr >= 0 && offsets, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_create: invalid sizes");
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nq = nq; r->nr = nr;
+  r->points = to_device(points, nq * tdim);
+  r->weights = to_device(weights, nq);
+  r->offsets = to_device(offsets, nr + 1);
+  r->parent_map = to_device(parent_map, nr);
+  *out = r.release();
+  CFX_API_END
+}
+
+int cfx_rules_view_get(cfx_rules_t r, cfx_rules_view* v)
+{
+  CFX_API_BEGIN
+  require(r && v, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_view_get: null argument");
+  v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq; v->nr = r->nr;
+  v->points = r->points.p; v->weights = r->weights.p; v->offsets = r->offsets.p; v->parent_map = r->parent_map.p;
+  CFX_API_END
+}
+
+int cfx_rules_physical_points(cfx_rules_t r, double* out)
+{
+  CFX_API_BEGIN
+  require(r && out, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_physical_points: null argument");
+  OutArray<double> o(out, r->nq * r->gdim, false);
+  if (r->nq > 0)
+  {
+    if (r->tdim == 2)
+      launch("physical_points", physical_points_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+             r->offsets.p, r->parent_map.p, r->points.p, r->mesh->x.p, r->mesh->conn.p, o.dev);
+    else
+      launch("physical_points", physical_points_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+             r->offsets.p, r->parent_map.p, r->points.p, r->mesh->x.p, r->mesh->conn.p, o.dev);
+  }
+  o.finish();
+  CFX_API_END
+}
+
+int cfx_rules_destroy(cfx_rules_t r)
+{
+  CFX_API_BEGIN
+  delete r;
+  CFX_API_END
+}
+
+int cfx_evaluate_normals(cfx_cut_t cut, int ls, cfx_rules_t r, double sign, double* out)
+{
+  CFX_API_BEGIN
+  require(cut && r && out, CFX_ERR_INVALID_ARGUMENT, "Cannot evaluate normals without a level set.");
+  require(ls >= 0 && ls < cut->nls, CFX_ERR_OUT_OF_RANGE, "level-set index out of range");
+  require(r->tdim == cut->mesh->tdim, CFX_ERR_RUNTIME, "Normal evaluation points must have cell reference dimension.");
+  require(cut->ls_ndofs_cell == cut->mesh->tdim + 1, CFX_ERR_INVALID_ARGUMENT,
+          "normal evaluation is implemented for P1 level sets");
+  OutArray<double> o(out, r->nq * r->gdim, false);
+  if (r->nq > 0)
+  {
+    if (r->tdim == 2)
+      launch("evaluate_normals", normals_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+             r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
+    else
+      launch("evaluate_normals", normals_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+             r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
+  }
+  o.finish();
+  CFX_API_END
+}
+
+int cfx_evaluate_values(cfx_cut_t cut, int ls, cfx_rules_t r, double* out)
+{
+  CFX_API_BEGIN
+  require(cut && r && out, CFX_ERR_INVALID_ARGUMENT, "Cannot evaluate values without a level set.");
+  require(ls >= 0 && ls < cut->nls, CFX_ERR_OUT_OF_RANGE, "level-set index out of range");
+  require(cut->ls_ndofs_cell == cut->mesh->tdim + 1, CFX_ERR_INVALID_ARGUMENT,
+          "value evaluation is implemented for P1 level sets");
+  OutArray<double> o(out, r->nq, false);
+  if (r->nq > 0)
+  {
+    if (r->tdim == 2)
+      launch("evaluate_values", values_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+             r->parent_map.p, r->points.p, cut->ls_dofmap.p, cut->ls_values[ls].p, o.dev);
+    else
+      launch("evaluate_values", values_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+             r->parent_map.p, r->points.p, cut->ls_dofmap.p, cut->ls_values[ls].p, o.dev);
+  }
+  o.finish();
+  CFX_API_END
+}
+
+int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t** rows, int64_t* n)
+{
+  CFX_API_BEGIN
+  require(cut && selector && rows && n, CFX_ERR_INVALID_ARGUMENT, "cfx_ghost_penalty_facets: null argument");
+  cfx_mesh_t mesh = cut->mesh;
+  {
+    auto it = cut->ghost_rows.find(selector);
+    if (it != cut->ghost_rows.end())
+    {
+      *rows = it->second.p;
+      *n = it->second.n / 4;
+      return CFX_OK;
+    }
+  }
+  SelectorPred pred{cut->domain.p, mesh->ncells, parse_selector(selector, cut->nls)};
+  const DevArray<int32_t>& cutc = locate(cut, "phi=0");
+  const int64_t ncut = cutc.n;
+  const Adjacency& adj = mesh->vertex_cells();
+  DevArray<int32_t> counts(ncut);
+  DevArray<int64_t> offs(ncut + 1);
+  int64_t total = 0;
+  if (ncut > 0)
+  {
+    if (mesh->tdim == 2)
+      launch("ghost_facets_count", ghost_facets_kernel<2, false>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, (const int64_t*)nullptr,
+             (int32_t*)nullptr);
+    else
+      launch("ghost_facets_count", ghost_facets_kernel<3, false>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, (const int64_t*)nullptr,
+             (int32_t*)nullptr);
+    exclusive_scan(counts.p, offs.p, ncut);
+    total = read_scalar(offs.p + ncut);
+  }
+  DevArray<int32_t>& grows = cut->ghost_rows[selector];
+  grows.alloc(total * 4);
+  if (total > 0)
+  {
+    if (mesh->tdim == 2)
+      launch("ghost_facets_write", ghost_facets_kernel<2, true>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, (int32_t*)nullptr, offs.p,
+             grows.p);
+    else
+      launch("ghost_facets_write", ghost_facets_kernel<3, true>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, (int32_t*)nullptr, offs.p,
+             grows.p);
+  }
+  *rows = grows.p;
+  *n = total;
+  CFX_API_END
+}
+
+int cfx_cut_destroy(cfx_cut_t cut)
+{
+  CFX_API_BEGIN
+  delete cut;
+  CFX_API_END
+}
+
+} // extern "C"

@@ -1,0 +1,185 @@
+// cutfemx_amd: device-side helpers shared by the HIP kernels (gfx950, wave64).
+#pragma once
+
+#include "cfx_common.h"
+
+namespace cfx
+{
+
+constexpr int kBlock = 256;      // 4 wavefronts
+constexpr int kScanItems = 8;    // items per thread in scan/compaction tiles
+constexpr int kTile = kBlock * kScanItems;
+
+// inclusive scan over the 64 lanes of a wavefront
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v)
+{
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1)
+  {
+    T up = __shfl_up(v, d, 64);
+    if (lane >= d) v += up;
+  }
+  return v;
+}
+
+// exclusive scan across a 256-thread block; returns the exclusive prefix of
+// `v`, writes the block total to `total` (all threads)
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T& total)
+{
+  __shared__ T wave_sums[kBlock / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  T incl = wave_inclusive_scan(v);
+  __syncthreads(); // protect wave_sums reuse across calls
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w)
+  {
+    T s = wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  total = tot;
+  return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------
+// stream compaction: indices i in [0,n) with pred(i), ascending.
+// Three launches: per-tile counts, scan, per-tile write.
+// ---------------------------------------------------------------------------
+template <typename Pred>
+__global__ void __launch_bounds__(kBlock) compact_count_kernel(int64_t n, Pred pred, int32_t* tile_counts)
+{
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+    if (i < n && pred(i)) ++c;
+  }
+  int total;
+  (void)block_exclusive_scan<int>(c, total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(kBlock) compact_write_kernel(int64_t n, Pred pred, const int64_t* tile_offsets,
+                                                               int32_t* out)
+{
+  // thread-major item order (thread t owns items t*kScanItems..) keeps output ascending
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  bool f[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + k;
+    f[k] = (i < n) && pred(i);
+    c += f[k] ? 1 : 0;
+  }
+  int total;
+  int off = block_exclusive_scan<int>(c, total);
+  int64_t o = tile_offsets[blockIdx.x] + off;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (f[k]) out[o++] = (int32_t)(base + k);
+}
+
+// returns count; `out` is allocated to exactly that size
+template <typename Pred>
+inline int64_t compact(const char* name, int64_t n, Pred pred, DevArray<int32_t>& out)
+{
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  if (ntiles == 0) { out.alloc(0); return 0; }
+  DevArray<int32_t> counts(ntiles);
+  DevArray<int64_t> offsets(ntiles + 1);
+  launch(name, compact_count_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, counts.p);
+  exclusive_scan(counts.p, offsets.p, ntiles);
+  const int64_t total = read_scalar(offsets.p + ntiles);
+  out.alloc(total);
+  launch(name, compact_write_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, offsets.p, out.p);
+  return total;
+}
+
+// ---------------------------------------------------------------------------
+// small geometry helpers (affine simplices, gdim == tdim)
+// ---------------------------------------------------------------------------
+template <int TDIM>
+struct Geo
+{
+  double x[TDIM + 1][TDIM]; // vertex coordinates
+  double K[TDIM][TDIM];     // K[t][d] = d xi_t / d x_d
+  double detJ;
+};
+
+template <int TDIM>
+__device__ __forceinline__ void load_cell(const double* __restrict__ x, const int32_t* __restrict__ conn,
+                                          int64_t cell, Geo<TDIM>& g)
+{
+#pragma unroll
+  for (int i = 0; i <= TDIM; ++i)
+  {
+    const int64_t v = conn[cell * (TDIM + 1) + i];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) g.x[i][d] = x[3 * v + d];
+  }
+}
+
+template <int TDIM>
+__device__ __forceinline__ void jacobian(Geo<TDIM>& g)
+{
+  double J[TDIM][TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) J[d][t] = g.x[t + 1][d] - g.x[0][d];
+  if constexpr (TDIM == 2)
+  {
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    g.K[0][0] = J[1][1] / det;  g.K[0][1] = -J[0][1] / det;
+    g.K[1][0] = -J[1][0] / det; g.K[1][1] = J[0][0] / det;
+    g.detJ = det;
+  }
+  else
+  {
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    g.K[0][0] = c00 / det;
+    g.K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+    g.K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+    g.K[1][0] = c01 / det;
+    g.K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+    g.K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+    g.K[2][0] = c02 / det;
+    g.K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+    g.K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    g.detJ = det;
+  }
+}
+
+// UFL CellDiameter: largest vertex-to-vertex distance
+template <int TDIM>
+__device__ __forceinline__ double cell_diameter(const Geo<TDIM>& g)
+{
+  double h2 = 0.0;
+#pragma unroll
+  for (int i = 0; i <= TDIM; ++i)
+#pragma unroll
+    for (int j = i + 1; j <= TDIM; ++j)
+    {
+      double d2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) d2 += (g.x[i][d] - g.x[j][d]) * (g.x[i][d] - g.x[j][d]);
+      h2 = d2 > h2 ? d2 : h2;
+    }
+  return sqrt(h2);
+}
+
+} // namespace cfx

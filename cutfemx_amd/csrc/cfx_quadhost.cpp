@@ -1,0 +1,16 @@
+// cutfemx_amd: host-side view of the generated quadrature tables (point counts).
+#include "cfx_quadrature_tables.h"
+
+namespace cfx
+{
+int quad_npoints(int dim, int degree)
+{
+  if (degree < 0) degree = 0;
+  if (degree > CFX_QUAD_MAX_DEGREE) degree = CFX_QUAD_MAX_DEGREE;
+  if (dim == 1) return cfx_quad_offset_1d[degree + 1] - cfx_quad_offset_1d[degree];
+  if (dim == 2) return cfx_quad_offset_2d[degree + 1] - cfx_quad_offset_2d[degree];
+  (void)cfx_quad_points_1d; (void)cfx_quad_points_2d; (void)cfx_quad_points_3d;
+  (void)cfx_quad_weights_1d; (void)cfx_quad_weights_2d; (void)cfx_quad_weights_3d;
+  return cfx_quad_offset_3d[degree + 1] - cfx_quad_offset_3d[degree];
+}
+} // namespace cfx

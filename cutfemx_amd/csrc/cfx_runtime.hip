@@ -1,0 +1,357 @@
+// cutfemx_amd: runtime (device/stream/profile), scans, incidence inversion.
+#include "cfx_device.h"
+
+namespace cfx
+{
+
+thread_local std::string g_last_error;
+
+Context& ctx()
+{
+  static Context c;
+  return c;
+}
+
+void Context::ensure()
+{
+  if (initialised) return;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    throw Error(CFX_ERR_HIP, "cutfemx_amd: no HIP device available (this engine has no CPU fallback)");
+  if (device < 0) device = 0;
+  if (device >= n) throw Error(CFX_ERR_HIP, "cutfemx_amd: device index out of range");
+  CFX_HIP(hipSetDevice(device));
+  initialised = true;
+}
+
+hipEvent_t Context::get_event()
+{
+  if (!event_pool.empty())
+  {
+    hipEvent_t e = event_pool.back();
+    event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  CFX_HIP(hipEventCreate(&e));
+  return e;
+}
+
+int Context::entry(const char* name)
+{
+  auto it = entry_index.find(name);
+  if (it != entry_index.end()) return it->second;
+  entries.push_back({name, 0.0, 0});
+  entry_index[name] = (int)entries.size() - 1;
+  return (int)entries.size() - 1;
+}
+
+void Context::flush_profile()
+{
+  if (pending.empty()) return;
+  CFX_HIP(hipStreamSynchronize(stream));
+  for (auto& p : pending)
+  {
+    float ms = 0.f;
+    CFX_HIP(hipEventElapsedTime(&ms, p.a, p.b));
+    entries[p.entry].total_ms += ms;
+    entries[p.entry].launches += 1;
+    event_pool.push_back(p.a);
+    event_pool.push_back(p.b);
+  }
+  pending.clear();
+}
+
+bool is_device_pointer(const void* p)
+{
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError(); // plain host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan: tile reduce -> (recursive) scan of tile sums -> tile scan
+// ---------------------------------------------------------------------------
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(kBlock) scan_reduce_kernel(const Tin* __restrict__ in, int64_t n, Tout* tile_sums)
+{
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  Tout s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) s += (Tout)in[base + k];
+  Tout total;
+  (void)block_exclusive_scan<Tout>(s, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restrict__ in, int64_t n,
+                                                            const Tout* __restrict__ tile_offsets, Tout* out)
+{
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  Tout v[kScanItems];
+  Tout s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    v[k] = (base + k < n) ? (Tout)in[base + k] : (Tout)0;
+    s += v[k];
+  }
+  Tout total;
+  Tout off = block_exclusive_scan<Tout>(s, total) + tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    if (base + k < n) out[base + k] = off;
+    off += v[k];
+  }
+  // the element one past the end receives the grand total
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = tile_offsets[blockIdx.x] + total;
+}
+
+template <typename Tout>
+__global__ void scan_small_kernel(const Tout* in, int64_t n, Tout* out)
+{
+  // single thread block, n <= kTile: used for the top of the recursion
+  const int64_t base = (int64_t)threadIdx.x * kScanItems;
+  Tout v[kScanItems];
+  Tout s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    v[k] = (base + k < n) ? in[base + k] : (Tout)0;
+    s += v[k];
+  }
+  Tout total;
+  Tout off = block_exclusive_scan<Tout>(s, total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    if (base + k < n) out[base + k] = off;
+    off += v[k];
+  }
+  if (threadIdx.x == 0) out[n] = total;
+}
+
+template <typename Tin, typename Tout>
+static void scan_impl(const Tin* in, Tout* out, int64_t n)
+{
+  if (n == 0)
+  {
+    CFX_HIP(hipMemsetAsync(out, 0, sizeof(Tout), ctx().stream));
+    return;
+  }
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  DevArray<Tout> sums(ntiles), offs(ntiles + 1);
+  launch("scan_reduce", scan_reduce_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, sums.p);
+  if (ntiles <= kTile)
+    launch("scan_top", scan_small_kernel<Tout>, dim3(1), dim3(kBlock), 0, sums.p, ntiles, offs.p);
+  else
+    scan_impl<Tout, Tout>(sums.p, offs.p, ntiles);
+  launch("scan_write", scan_write_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, offs.p, out);
+}
+
+void exclusive_scan(const int32_t* in, int64_t* out, int64_t n) { scan_impl<int32_t, int64_t>(in, out, n); }
+void exclusive_scan(const int32_t* in, int32_t* out, int64_t n) { scan_impl<int32_t, int32_t>(in, out, n); }
+void exclusive_scan(const int64_t* in, int64_t* out, int64_t n) { scan_impl<int64_t, int64_t>(in, out, n); }
+
+// ---------------------------------------------------------------------------
+// incidence inversion: map[ncells][width] (item ids) -> item -> cells (CSR).
+// Counting sort with integer atomics, then each segment is sorted so the
+// result does not depend on the atomic arrival order.
+// ---------------------------------------------------------------------------
+__global__ void adj_count_kernel(const int32_t* __restrict__ map, int64_t nentries, int32_t* counts)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nentries) atomicAdd(&counts[map[i]], 1);
+}
+
+__global__ void adj_fill_kernel(const int32_t* __restrict__ map, int64_t nentries, int width,
+                                const int64_t* __restrict__ offsets, int32_t* cursor, int32_t* cells)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nentries) return;
+  const int32_t item = map[i];
+  const int32_t pos = atomicAdd(&cursor[item], 1);
+  cells[offsets[item] + pos] = (int32_t)(i / width);
+}
+
+__global__ void adj_sort_kernel(int64_t nitems, const int64_t* __restrict__ offsets, int32_t* cells)
+{
+  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= nitems) return;
+  const int64_t b = offsets[it], e = offsets[it + 1];
+  for (int64_t i = b + 1; i < e; ++i) // insertion sort, segments are short (vertex valence)
+  {
+    const int32_t v = cells[i];
+    int64_t j = i - 1;
+    while (j >= b && cells[j] > v) { cells[j + 1] = cells[j]; --j; }
+    cells[j + 1] = v;
+  }
+}
+
+void build_adjacency(const int32_t* map, int64_t ncells, int width, int64_t nitems, Adjacency& adj)
+{
+  const int64_t nentries = ncells * width;
+  DevArray<int32_t> counts(nitems);
+  counts.zero();
+  launch("adj_count", adj_count_kernel, grid_for(nentries), dim3(kBlock), 0, map, nentries, counts.p);
+  adj.offsets.alloc(nitems + 1);
+  exclusive_scan(counts.p, adj.offsets.p, nitems);
+  adj.cells.alloc(nentries);
+  counts.zero();
+  launch("adj_fill", adj_fill_kernel, grid_for(nentries), dim3(kBlock), 0, map, nentries, width,
+         adj.offsets.p, counts.p, adj.cells.p);
+  launch("adj_sort", adj_sort_kernel, grid_for(nitems), dim3(kBlock), 0, nitems, adj.offsets.p, adj.cells.p);
+  adj.built = true;
+}
+
+} // namespace cfx
+
+using namespace cfx;
+
+// ---------------------------------------------------------------------------
+// C ABI: runtime
+// ---------------------------------------------------------------------------
+extern "C" {
+
+const char* cfx_last_error(void) { return g_last_error.c_str(); }
+
+int cfx_init(int device)
+{
+  CFX_API_BEGIN
+  Context& c = ctx();
+  if (c.initialised && c.device != device)
+  {
+    c.flush_profile();
+    c.initialised = false;
+  }
+  c.device = device;
+  c.ensure();
+  CFX_API_END
+}
+
+int cfx_set_stream(void* s)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  ctx().flush_profile();
+  ctx().stream = (hipStream_t)s;
+  CFX_API_END
+}
+
+int cfx_synchronize(void)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  CFX_API_END
+}
+
+int cfx_copy(void* dst, const void* src, size_t bytes)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  if (bytes > 0)
+  {
+    require(dst && src, CFX_ERR_INVALID_ARGUMENT, "cfx_copy: null pointer");
+    CFX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, ctx().stream));
+    CFX_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  CFX_API_END
+}
+
+int cfx_device_alloc(void** ptr, size_t bytes)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  CFX_HIP(hipMalloc(ptr, bytes > 0 ? bytes : 1));
+  CFX_API_END
+}
+
+int cfx_device_free(void* ptr)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  CFX_HIP(hipFree(ptr));
+  CFX_API_END
+}
+
+int cfx_profile_enable(int on)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  ctx().flush_profile();
+  ctx().profile = on != 0;
+  CFX_API_END
+}
+
+int cfx_profile_reset(void)
+{
+  CFX_API_BEGIN
+  ctx().flush_profile();
+  for (auto& e : ctx().entries) { e.total_ms = 0.0; e.launches = 0; }
+  CFX_API_END
+}
+
+int cfx_profile_count(void)
+{
+  try { ctx().flush_profile(); } catch (...) { return 0; }
+  return (int)ctx().entries.size();
+}
+
+int cfx_profile_get(int i, const char** name, double* total_ms, int64_t* launches)
+{
+  CFX_API_BEGIN
+  ctx().flush_profile();
+  require(i >= 0 && i < (int)ctx().entries.size(), CFX_ERR_OUT_OF_RANGE, "profile index out of range");
+  const ProfileEntry& e = ctx().entries[i];
+  if (name) *name = e.name.c_str();
+  if (total_ms) *total_ms = e.total_ms;
+  if (launches) *launches = e.launches;
+  CFX_API_END
+}
+
+int cfx_event_create(void** ev)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  hipEvent_t e;
+  CFX_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  CFX_API_END
+}
+
+int cfx_event_record(void* ev)
+{
+  CFX_API_BEGIN
+  CFX_HIP(hipEventRecord((hipEvent_t)ev, ctx().stream));
+  CFX_API_END
+}
+
+int cfx_event_elapsed_ms(void* a, void* b, double* ms)
+{
+  CFX_API_BEGIN
+  CFX_HIP(hipEventSynchronize((hipEvent_t)b));
+  float f = 0.f;
+  CFX_HIP(hipEventElapsedTime(&f, (hipEvent_t)a, (hipEvent_t)b));
+  *ms = f;
+  CFX_API_END
+}
+
+int cfx_event_destroy(void* ev)
+{
+  CFX_API_BEGIN
+  CFX_HIP(hipEventDestroy((hipEvent_t)ev));
+  CFX_API_END
+}
+
+} // extern "C"

@@ -1,0 +1,298 @@
+"""cut / update / locate_entities / runtime_quadrature / ghost_penalty_facets:
+the Python surface of python/cutfemx/cut.py backed by the HIP engine.
+
+Same names, argument meaning and error classes as the reference; array results
+keep the reference layouts (`RuntimeQuadratureRules`: points[nq,tdim] in parent
+reference coordinates, physical weights[nq], int32 offsets[nr+1],
+parent_map[nr], kind="per_entity").  Results live in HBM; numpy views are
+downloaded on first access.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections.abc import Sequence
+
+import numpy as np
+
+from . import _lib
+from .mesh import Function, Mesh
+
+
+class RuntimeQuadratureRules:
+    """runintgen.QuadratureRules(kind="per_entity") stand-in backed by HBM arrays
+    (python/cutfemx/cut.py:22-57, python/cutfemx/wrappers/cut.cpp:178-240)."""
+
+    kind = "per_entity"
+
+    def __init__(self, handle, mesh: Mesh):
+        self._h = handle
+        self.mesh = mesh
+        v = _lib.RulesView()
+        _lib.check(_lib.lib().cfx_rules_view_get(handle, C.byref(v)))
+        self._view = v
+        self.tdim, self.gdim = v.tdim, v.gdim
+        self.total_points = int(v.nq)
+        self.num_rules = int(v.nr)
+        self._cache: dict = {}
+
+    @classmethod
+    def from_arrays(cls, mesh: Mesh, points, weights, offsets, parent_map):
+        """Wrap caller-supplied per-entity rules (host or device arrays)."""
+        keep: list = []
+        nq, nr = len(weights), len(parent_map)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cfx_rules_create(
+            mesh._h, mesh.tdim, C.c_int64(nq), C.c_int64(nr), _lib.as_ptr(points, np.float64, keep),
+            _lib.as_ptr(weights, np.float64, keep), _lib.as_ptr(offsets, np.int32, keep),
+            _lib.as_ptr(parent_map, np.int32, keep), C.byref(h)))
+        r = cls(h, mesh)
+        r._keep = [k for k in keep if _lib.is_device(k)]
+        return r
+
+    def _get(self, name, ptr, n, dtype, shape=None):
+        if name not in self._cache:
+            a = _lib.download(ptr, n, dtype)
+            self._cache[name] = a if shape is None else a.reshape(shape)
+        return self._cache[name]
+
+    @property
+    def points(self):
+        return self._get("points", self._view.points, self.total_points * self.tdim, np.float64, (-1, self.tdim))
+
+    @property
+    def weights(self):
+        return self._get("weights", self._view.weights, self.total_points, np.float64)
+
+    @property
+    def offsets(self):
+        return self._get("offsets", self._view.offsets, self.num_rules + 1, np.int32)
+
+    @property
+    def parent_map(self):
+        return self._get("parent_map", self._view.parent_map, self.num_rules, np.int32)
+
+    @property
+    def physical_points(self):
+        """(gdim, total_nq), as python/cutfemx/cut.py:25-49."""
+        if "phys" not in self._cache:
+            out = np.empty((self.total_points, self.gdim))
+            _lib.check(_lib.lib().cfx_rules_physical_points(self._h, out.ctypes.data_as(C.c_void_p)))
+            self._cache["phys"] = np.ascontiguousarray(out.T)
+        return self._cache["phys"]
+
+    def with_physical_points(self):
+        _ = self.physical_points
+        return self
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cfx_rules_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+class CutData:
+    """Python handle for cut data (python/cutfemx/cut.py:94-146)."""
+
+    def __init__(self, handle, level_sets: Sequence[Function], keep=()):
+        self._h = handle
+        self._level_sets = tuple(level_sets)
+        self._keep = list(keep)
+
+    def update(self) -> None:
+        update(self)
+
+    @property
+    def mesh(self) -> Mesh:
+        return self._level_sets[0].function_space.mesh
+
+    @property
+    def tdim(self) -> int:
+        return self.mesh.tdim
+
+    @property
+    def gdim(self) -> int:
+        return self.mesh.gdim
+
+    @property
+    def num_local_cells(self) -> int:
+        return self.mesh.num_cells
+
+    @property
+    def level_set_names(self) -> tuple[str, ...]:
+        return tuple("phi" if i == 0 else f"phi{i}" for i in range(len(self._level_sets)))
+
+    @property
+    def level_sets(self) -> tuple[Function, ...]:
+        return self._level_sets
+
+    @property
+    def entity_dim(self):
+        return None
+
+    def domain(self, level_set: int = 0) -> np.ndarray:
+        """int8 classification per cell: -1 inside, 0 intersected, +1 outside."""
+        p = C.c_void_p()
+        _lib.check(_lib.lib().cfx_cut_domain(self._h, level_set, C.byref(p)))
+        return _lib.download(p.value, self.num_local_cells, np.int8)
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cfx_cut_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def _normalise_level_sets(level_set) -> list[Function]:
+    # python/cutfemx/cut.py:163-183
+    if isinstance(level_set, Function):
+        return [level_set]
+    if isinstance(level_set, (str, bytes)) or not isinstance(level_set, Sequence):
+        raise TypeError("cutfemx.cut expects a Function or a non-empty sequence of Functions")
+    level_sets = list(level_set)
+    if not level_sets:
+        raise ValueError("cutfemx.cut requires at least one level-set function")
+    for item in level_sets:
+        if not isinstance(item, Function):
+            raise TypeError("cutfemx.cut sequence entries must be Function objects")
+    return level_sets
+
+
+def _value_ptrs(level_sets, keep):
+    arr = (C.c_void_p * len(level_sets))()
+    for i, f in enumerate(level_sets):
+        arr[i] = _lib.as_ptr(f.values, np.float64, keep)
+    return arr
+
+
+def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "auto",
+        cut_approximation_order: int = 1, max_refinement_iterations: int = 8,
+        edge_max_depth: int = 20) -> CutData:
+    """Classify all cells against one or more level sets (python/cutfemx/cut.py:186-249)."""
+    level_sets = _normalise_level_sets(level_set)
+    if entities is not None or entity_dim is not None:
+        if entities is None:
+            raise ValueError("entity_dim is only valid when entities are supplied")
+        raise NotImplementedError("facet-hosted cuts are outside the accelerated path (SURVEY 8f-4)")
+    V = level_sets[0].function_space
+    for f in level_sets[1:]:
+        if f.function_space is not V:
+            raise ValueError("all level sets must share one function space")
+    if V.bs != 1:
+        raise ValueError("level-set function must be scalar")  # cut.cpp:445-460
+    opt = _lib.CutOptions(cut_approximation_order, max_refinement_iterations, edge_max_depth, 0)
+    keep: list = []
+    vals = _value_ptrs(level_sets, keep)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
+                                         C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
+    return CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V])
+
+
+def update(cut_data: CutData) -> None:
+    """Re-classify from the current level-set values (python/cutfemx/cut.py:252-254)."""
+    keep: list = []
+    vals = _value_ptrs(cut_data._level_sets, keep)
+    _lib.check(_lib.lib().cfx_cut_update(cut_data._h, vals))
+    cut_data._keep = [k for k in keep if _lib.is_device(k)] + [cut_data._level_sets[0].function_space]
+
+
+def locate_entities(cut_data: CutData, ls_part: str) -> np.ndarray:
+    """Background cells matched by a selector, ascending int32 (cut.cpp:877-924)."""
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, ls_part.encode(), C.byref(p), C.byref(n)))
+    return _lib.download(p.value, n.value, np.int32)
+
+
+def locate_entities_device(cut_data: CutData, ls_part: str):
+    """(device pointer, count) of the selector result; owned by `cut_data`."""
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, ls_part.encode(), C.byref(p), C.byref(n)))
+    return p.value, n.value
+
+
+def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: str = "straight"):
+    """Runtime quadrature on the cut entities of a selector (cut.cpp:1311-1335)."""
+    h = C.c_void_p()
+    _lib.check(_lib.lib().cfx_runtime_quadrature(cut_data._h, ls_part.encode(), int(order), backend.encode(),
+                                                 C.byref(h)))
+    return RuntimeQuadratureRules(h, cut_data.mesh)
+
+
+def runtime_quadratures(cut_data: CutData, ls_parts: Sequence[str], order: int, *, backend: str = "straight"):
+    return {str(p): runtime_quadrature(cut_data, str(p), order, backend=backend) for p in ls_parts}
+
+
+def full_cell_rules(mesh: Mesh, cells, order: int) -> RuntimeQuadratureRules:
+    """Whole-cell per-entity rules: reference points, weights*|detJ|
+    (python/tests/quadrature_utils.py:12-70)."""
+    keep: list = []
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    h = C.c_void_p()
+    _lib.check(_lib.lib().cfx_full_cell_rules(mesh._h, _lib.as_ptr(cells, np.int32, keep), C.c_int64(cells.size),
+                                              int(order), C.byref(h)))
+    return RuntimeQuadratureRules(h, mesh)
+
+
+class FacetRows:
+    """Interior-facet integration rows (cell0, local_facet0, cell1, local_facet1),
+    cell0 < cell1 -- what facet_integration_rows produces from raw facet ids
+    (python/cutfemx/wrappers/cut.cpp:54-115).  The engine has no global facet
+    numbering, so the rows ARE the facet identity."""
+
+    def __init__(self, ptr, n, owner):
+        self.ptr, self.size, self._owner = ptr, int(n), owner
+        self._rows = None
+
+    @property
+    def rows(self) -> np.ndarray:
+        if self._rows is None:
+            self._rows = _lib.download(self.ptr, 4 * self.size, np.int32).reshape(-1, 4)
+        return self._rows
+
+    def __len__(self):
+        return self.size
+
+
+def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, include_ghosts: bool = False):
+    """Interior facets of the cut-cell stabilisation band (python/cutfemx/cut.py:340-380)."""
+    if depth != 1:
+        raise NotImplementedError("ghost_penalty_facets currently supports depth=1.")
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, selector.encode(), C.byref(p), C.byref(n)))
+    rows = FacetRows(p.value, n.value, cut_data)
+    _ = rows.rows  # the device buffer is reused by the next call: snapshot now
+    return rows
+
+
+class QuadratureFunction:
+    """Per-point coefficient values aligned with a rule set (python/cutfemx/level_set.py)."""
+
+    def __init__(self, rules: RuntimeQuadratureRules, values: np.ndarray):
+        self.rules, self.values = rules, values
+
+
+def normal(cut_data: CutData, rules: RuntimeQuadratureRules, level_set: int = 0, sign: float = 1.0,
+           device: bool = False):
+    """Unit normals grad(phi)/|grad(phi)| at the rule points, (nq, gdim)
+    (cpp/cutfemx/level_set/normal.h:39-187).  device=True keeps them in HBM."""
+    if device:
+        buf = _lib.DeviceBuffer(rules.total_points * rules.gdim, np.float64, (rules.total_points, rules.gdim))
+        _lib.check(_lib.lib().cfx_evaluate_normals(cut_data._h, level_set, rules._h, C.c_double(sign),
+                                                   C.c_void_p(buf.ptr)))
+        return buf
+    out = np.empty((rules.total_points, rules.gdim))
+    _lib.check(_lib.lib().cfx_evaluate_normals(cut_data._h, level_set, rules._h, C.c_double(sign),
+                                               out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def level_set_value(cut_data: CutData, rules: RuntimeQuadratureRules, level_set: int = 0) -> np.ndarray:
+    """phi at the rule points (cpp/cutfemx/level_set/value.h:34-119)."""
+    out = np.empty(rules.total_points)
+    _lib.check(_lib.lib().cfx_evaluate_values(cut_data._h, level_set, rules._h, out.ctypes.data_as(C.c_void_p)))
+    return out

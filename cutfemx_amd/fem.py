@@ -1,0 +1,253 @@
+"""form / create_matrix / assemble_matrix / assemble_vector / active_domain /
+deactivate_outside: the Python surface of python/cutfemx/fem.py backed by the
+HIP engine.
+
+The reference compiles UFL forms to JIT kernels (runintgen/FFCx); a GPU engine
+cannot call a CPU function pointer per entity, so a form here is a list of
+`Integral` descriptors -- an integrand id + parameters + the same integration
+domain data the reference puts in `ufl.Measure(subdomain_data=...)`:
+
+    dx(subdomain_data=[inside_cells, rules]) -> Integral(..., cells=inside_cells, rules=rules)
+    dx(subdomain_data=interface_rules)       -> Integral(..., rules=interface_rules, point_data=normals)
+    dS(subdomain_data=ghost_facets)          -> Integral(..., facets=ghost_facets)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib
+from .cut import FacetRows, RuntimeQuadratureRules
+from .mesh import FunctionSpace
+
+MASS, STIFFNESS, NITSCHE, GHOST_GRADJUMP, ELASTICITY = (_lib.K_MASS, _lib.K_STIFFNESS, _lib.K_NITSCHE,
+                                                        _lib.K_GHOST_GRADJUMP, _lib.K_ELASTICITY)
+SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
+F_ONE, F_SINPROD, F_POISSON_RHS = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS
+
+
+@dataclass
+class Integral:
+    """One integral of a form (the per-integral tuple of python/cutfemx/fem.py:346-351)."""
+    kernel: int
+    cells: object = None                      # standard (uncut) cells: ids, numpy/torch/(ptr, n)
+    rules: RuntimeQuadratureRules | None = None  # runtime quadrature on the cut cells
+    facets: FacetRows | np.ndarray | None = None  # interior facets (c0,lf0,c1,lf1)
+    point_data: object = None                 # per-point coefficients aligned with `rules`
+    params: tuple = ()
+    qdegree: int = 2                          # quadrature degree on the standard entities
+    _keep: list = field(default_factory=list, repr=False)
+
+    def _cstruct(self) -> _lib.Integral:
+        keep = self._keep = []
+        itype = _lib.CELL
+        ent_ptr, n_ent = None, 0
+        if self.facets is not None:
+            itype = _lib.INTERIOR_FACET
+            if isinstance(self.facets, FacetRows):
+                ent_ptr, n_ent = C.c_void_p(self.facets.ptr), self.facets.size
+                keep.append(self.facets)
+            else:
+                rows = np.ascontiguousarray(self.facets, dtype=np.int32).reshape(-1, 4)
+                ent_ptr, n_ent = _lib.as_ptr(rows, np.int32, keep), rows.shape[0]
+        elif self.cells is not None:
+            if isinstance(self.cells, tuple):  # (device pointer, count)
+                ent_ptr, n_ent = C.c_void_p(self.cells[0]), int(self.cells[1])
+            else:
+                ent_ptr = _lib.as_ptr(self.cells, np.int32, keep)
+                n_ent = int(keep[-1].numel() if _lib.is_torch(keep[-1]) else keep[-1].size)
+        pd, stride = None, 0
+        if self.point_data is not None:
+            pdata = self.point_data
+            stride = 1 if pdata.ndim == 1 else int(pdata.shape[1])
+            pd = _lib.as_ptr(pdata, np.float64, keep)
+        params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
+        return _lib.Integral(itype, self.kernel, int(self.qdegree), stride, ent_ptr, n_ent,
+                             self.rules._h if self.rules is not None else None, pd, params)
+
+
+class CutForm:
+    """Compiled form handle (python/cutfemx/fem.py CutForm)."""
+
+    def __init__(self, V: FunctionSpace, integrals, rank: int):
+        self.function_space, self.rank = V, rank
+        self.integrals = list(integrals)
+        arr = (_lib.Integral * len(self.integrals))(*[i._cstruct() for i in self.integrals])
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(self._h)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cfx_form_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def form(integrals, V: FunctionSpace, rank: int | None = None) -> CutForm:
+    """Create a form from integral descriptors (stands in for cutfemx.fem.form)."""
+    integrals = list(integrals)
+    if rank is None:
+        ranks = {2 if i.kernel < 100 else 1 for i in integrals}
+        if len(ranks) != 1:
+            raise ValueError("all integrals of a form must have the same rank")
+        rank = ranks.pop()
+    return CutForm(V, integrals, rank)
+
+
+class MatrixCSR:
+    """dolfinx.la.MatrixCSR stand-in: indptr (int64), indices (int32), data in HBM."""
+
+    def __init__(self, pattern_handle, V: FunctionSpace, values=None):
+        self._p = pattern_handle
+        self.function_space = V
+        v = _lib.PatternView()
+        _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
+        self._view = v
+        self.nrows, self.nnz = int(v.nrows), int(v.nnz)
+        self._owns_values = values is None
+        if values is None:
+            p = C.c_void_p()
+            _lib.check(_lib.lib().cfx_device_alloc(C.byref(p), C.c_size_t(8 * max(self.nnz, 1))))
+            self.values_ptr = p.value
+            self.set_value(0.0)
+        else:  # torch tensor on the device
+            self._values_keep = values
+            self.values_ptr = values.data_ptr()
+
+    def set_value(self, v: float):
+        z = np.full(self.nnz, float(v))
+        _lib.check(_lib.lib().cfx_copy(C.c_void_p(self.values_ptr), z.ctypes.data_as(C.c_void_p),
+                                       C.c_size_t(z.nbytes)))
+
+    @property
+    def indptr(self):
+        return _lib.download(self._view.indptr, self.nrows + 1, np.int64)
+
+    @property
+    def indices(self):
+        return _lib.download(self._view.indices, self.nnz, np.int32)
+
+    @property
+    def data(self):
+        return _lib.download(self.values_ptr, self.nnz, np.float64)
+
+    def scatter_reverse(self):
+        """Serial: nothing to reduce (multi-GPU reduction lives in cutfemx_amd.dist)."""
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.data, self.indices, self.indptr), shape=(self.nrows, self.nrows))
+
+    def to_dense(self):
+        return self.to_scipy().toarray()
+
+    def __del__(self):
+        try:
+            l = _lib.load()
+            if getattr(self, "_owns_values", False) and self.values_ptr:
+                l.cfx_device_free(C.c_void_p(self.values_ptr))
+                self.values_ptr = None
+            if self._p:
+                l.cfx_pattern_destroy(self._p)
+                self._p = None
+        except Exception:
+            pass
+
+
+def create_matrix(a: CutForm, values=None) -> MatrixCSR:
+    """Sparsity of a bilinear form incl. the all-rows diagonal
+    (python/cutfemx/fem.py:810-848 -> assembler.h:567-592)."""
+    p = C.c_void_p()
+    _lib.check(_lib.lib().cfx_create_sparsity(a._h, C.byref(p)))
+    return MatrixCSR(p, a.function_space, values)
+
+
+def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixCSR:
+    """Assemble a bilinear form into CSR (python/cutfemx/fem.py:886-942).
+    `bcs` is an int8 dof marker applied to rows and columns, or (bc0, bc1)."""
+    if A is None:
+        A = create_matrix(a)
+    keep: list = []
+    bc0 = bc1 = None
+    if bcs is not None:
+        b0, b1 = bcs if isinstance(bcs, tuple) else (bcs, bcs)
+        bc0, bc1 = _lib.as_ptr(b0, np.int8, keep), _lib.as_ptr(b1, np.int8, keep)
+    _lib.check(_lib.lib().cfx_assemble_matrix(a._h, A._p, bc0, bc1, C.c_void_p(A.values_ptr)))
+    return A
+
+
+def assemble_vector(L: CutForm, b=None):
+    """Assemble a linear form (python/cutfemx/fem.py:851-883).  Returns a numpy
+    vector, or accumulates into `b` (numpy array or device torch tensor)."""
+    V = L.function_space
+    if b is None:
+        b = np.zeros(V.ndofs * V.bs)
+    if _lib.is_torch(b):
+        _lib.check(_lib.lib().cfx_assemble_vector(L._h, C.c_void_p(b.data_ptr())))
+    else:
+        _lib.check(_lib.lib().cfx_assemble_vector(L._h, b.ctypes.data_as(C.c_void_p)))
+    return b
+
+
+def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np.ndarray:
+    """Local tensor of one entity (for local-entry parity checks)."""
+    V = a.function_space
+    I = a.integrals[integral]
+    nloc = V.ndofs_cell * V.bs * (2 if I.facets is not None else 1)
+    Ae = np.zeros((nloc, nloc) if a.rank == 2 else (nloc,))
+    _lib.check(_lib.lib().cfx_tabulate_entity(a._h, integral, C.c_int64(index), int(use_rule),
+                                              Ae.ctypes.data_as(C.c_void_p)))
+    return Ae
+
+
+class ActiveDomain:
+    """cutfemx.fem.ActiveDomain (cpp/cutfemx/fem/deactivate.h:387-400)."""
+
+    def __init__(self, handle, V):
+        self._h, self.function_space = handle, V
+        ac, na, idf, ni = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
+        _lib.check(_lib.lib().cfx_active_view(handle, C.byref(ac), C.byref(na), C.byref(idf), C.byref(ni)))
+        self._ac, self._na, self._id, self._ni = ac.value, na.value, idf.value, ni.value
+
+    @property
+    def active_cells(self):
+        return _lib.download(self._ac, self._na, np.int32)
+
+    @property
+    def inactive_dofs(self):
+        return _lib.download(self._id, self._ni, np.int32)
+
+    @property
+    def num_active_dofs(self):
+        V = self.function_space
+        return V.ndofs * V.bs - self._ni
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().cfx_active_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def active_domain(a: CutForm) -> ActiveDomain:
+    h = C.c_void_p()
+    _lib.check(_lib.lib().cfx_active_domain(a._h, C.byref(h)))
+    return ActiveDomain(h, a.function_space)
+
+
+def deactivate_outside(A: MatrixCSR | None, b, domain: ActiveDomain, diagonal: float = 1.0,
+                       rhs_value: float = 0.0) -> ActiveDomain:
+    """diag=1 / rhs=0 on dofs outside the active domain (deactivate.h:402-418)."""
+    bp = None
+    if b is not None:
+        bp = C.c_void_p(b.data_ptr()) if _lib.is_torch(b) else b.ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.lib().cfx_deactivate_outside(domain._h, A._p if A is not None else None,
+                                                 C.c_void_p(A.values_ptr) if A is not None else None, bp,
+                                                 C.c_double(diagonal), C.c_double(rhs_value)))
+    return domain

@@ -1,0 +1,237 @@
+/* cutfemx_amd -- C ABI of the MI355X-native cut-FEM quadrature-and-assembly
+ * engine (libcutfemx_amd.so).
+ *
+ * Drop-in boundary for the CutFEMx hot path.  Every entry point
+ * names the reference interface it replaces (paths relative to the CutFEMx
+ * source tree).  Conventions:
+ *   - plain C types only; handles are opaque pointers;
+ *   - every function returns 0 on success, a negative CFX_ERR_* otherwise, and
+ *     cfx_last_error() returns the thread-local message (the reference throws
+ *     std::invalid_argument / runtime_error / out_of_range; the code says which);
+ *   - INPUT array pointers may be host or device (HIP) pointers: the library
+ *     detects the memory space and copies host data to HBM once;
+ *   - OUTPUT arrays live in HBM and are owned by their handle; `*_view`
+ *     functions expose the device pointers, cfx_copy() moves bytes to a host
+ *     or device destination;
+ *   - the caller keeps ownership of inputs; a handle that was given a DEVICE
+ *     pointer aliases it (zero copy) and the caller must keep it alive;
+ *   - calls on one device are issued on one HIP stream (cfx_set_stream) and
+ *     are not thread-safe.
+ * Scalar/geometry type: float64/float64 (north_star); other instantiations of
+ * python/cutfemx/wrappers/fem.cpp:490-500 are not provided.
+ */
+#ifndef CUTFEMX_AMD_H
+#define CUTFEMX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes (exception classes of the reference) ------------------- */
+#define CFX_OK 0
+#define CFX_ERR_INVALID_ARGUMENT (-1) /* std::invalid_argument -> ValueError  */
+#define CFX_ERR_RUNTIME (-2)          /* std::runtime_error   -> RuntimeError */
+#define CFX_ERR_OUT_OF_RANGE (-3)     /* std::out_of_range    -> IndexError   */
+#define CFX_ERR_HIP (-4)              /* HIP runtime failure / no device      */
+
+/* ---- classification codes: cutcells::cell::domain as used by
+ *      cpp/cutfemx/cut/cut.cpp:292-321 ---------------------------------------- */
+#define CFX_INSIDE (-1)     /* all level-set dof values < 0 */
+#define CFX_INTERSECTED 0   /* anything else, incl. a value == 0 */
+#define CFX_OUTSIDE 1       /* all level-set dof values > 0 */
+
+/* ---- integral types, order of python/cutfemx/fem.py:261-267 --------------- */
+#define CFX_CELL 0
+#define CFX_EXTERIOR_FACET 1
+#define CFX_INTERIOR_FACET 2
+
+/* ---- integrand ids: replace the JIT kernel pointer of
+ *      cpp/dolfinx_custom_data/fem/Form.h:59-75 (a GPU engine cannot call a
+ *      CPU function pointer per entity) ---------------------- */
+#define CFX_K_MASS 1            /* u v                                         */
+#define CFX_K_STIFFNESS 2       /* grad u . grad v                             */
+#define CFX_K_NITSCHE 3         /* -dn(u) v - dn(v) u + gamma/h u v; params[0]=gamma;
+                                   point_data = unit normals (gdim per point)  */
+#define CFX_K_GHOST_GRADJUMP 4  /* gamma_g h_avg [dn u][dn v]; params[0]=gamma_g */
+#define CFX_K_ELASTICITY 5      /* sigma(u):eps(v); params[0]=E, params[1]=nu  */
+#define CFX_L_SOURCE 101        /* f v; params[0]=field id, params[1]=scale    */
+#define CFX_L_NITSCHE_RHS 102   /* -dn(v) g + gamma/h g v; params[0]=gamma,
+                                   params[1]=field id of g, params[2]=scale    */
+/* analytic fields evaluated at physical quadrature points */
+#define CFX_F_ONE 0             /* 1 */
+#define CFX_F_SINPROD 1         /* prod_i sin(pi x_i) */
+#define CFX_F_POISSON_RHS 2     /* gdim pi^2 prod_i sin(pi x_i) */
+
+typedef struct cfx_mesh_s* cfx_mesh_t;
+typedef struct cfx_cut_s* cfx_cut_t;
+typedef struct cfx_rules_s* cfx_rules_t;
+typedef struct cfx_space_s* cfx_space_t;
+typedef struct cfx_form_s* cfx_form_t;
+typedef struct cfx_pattern_s* cfx_pattern_t;
+typedef struct cfx_active_s* cfx_active_t;
+
+/* Options of cutfemx.cut(); defaults of python/cutfemx/wrappers/cut.cpp:117-140 */
+typedef struct
+{
+  int32_t cut_approximation_order;   /* 1 */
+  int32_t max_refinement_iterations; /* 8  (unused for P1 level sets) */
+  int32_t edge_max_depth;            /* 20 (unused for P1 level sets) */
+  int32_t reserved;
+} cfx_cut_options;
+
+/* Device view of cutfemx::RuntimeQuadrature
+ * (cpp/cutfemx/cut/runtime_quadrature.h:223-231, python/cutfemx/wrappers/cut.cpp:181-240) */
+typedef struct
+{
+  int32_t tdim;              /* columns of points                              */
+  int32_t gdim;
+  int64_t nq;                /* total points = offsets[nr]                     */
+  int64_t nr;                /* number of rules = len(parent_map)              */
+  const double* points;      /* [nq*tdim] parent-reference coordinates (HBM)   */
+  const double* weights;     /* [nq] physical-measure weights (HBM)            */
+  const int32_t* offsets;    /* [nr+1] (HBM)                                   */
+  const int32_t* parent_map; /* [nr] parent background cell (HBM)              */
+} cfx_rules_view;
+
+/* One integral of a form: the (kernel_ptr, entities, active_coeffs, custom_data)
+ * tuple of python/cutfemx/fem.py:346-351 with the kernel selected by id.
+ * `entities` are the standard (uncut) entities, `rules` the runtime (cut)
+ * entities of the same measure -- the [inside_cells, rules] measure of
+ * python/demo/demo_poisson.py:143-147. */
+typedef struct
+{
+  int32_t type;            /* CFX_CELL | CFX_INTERIOR_FACET                    */
+  int32_t kernel;          /* CFX_K_* (rank 2) or CFX_L_* (rank 1)             */
+  int32_t qdegree;         /* standard quadrature degree for uncut entities    */
+  int32_t point_stride;    /* doubles per point in point_data                  */
+  const int32_t* entities; /* cells: ids; interior facets: (c0,lf0,c1,lf1)     */
+  int64_t n_entities;
+  cfx_rules_t rules;       /* or NULL                                          */
+  const double* point_data;/* per-point coefficients aligned with rules, or NULL */
+  double params[8];
+} cfx_integral;
+
+typedef struct
+{
+  int64_t nrows;
+  int64_t nnz;
+  const int64_t* indptr;  /* [nrows+1] (HBM), DOLFINx MatrixCSR row_ptr type */
+  const int32_t* indices; /* [nnz] sorted per row (HBM)                       */
+} cfx_pattern_view;
+
+/* ---- runtime ------------------------------------------------------------- */
+int cfx_init(int device);              /* select the HIP device; fails loudly without one */
+const char* cfx_last_error(void);
+int cfx_set_stream(void* hip_stream);  /* all later launches go to this stream */
+int cfx_synchronize(void);
+int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
+int cfx_device_alloc(void** ptr, size_t bytes);
+int cfx_device_free(void* ptr);
+/* per-kernel HIP-event timing of the launches made by this library */
+int cfx_profile_enable(int on);
+int cfx_profile_reset(void);
+int cfx_profile_count(void);
+int cfx_profile_get(int i, const char** name, double* total_ms, int64_t* launches);
+/* HIP events on the library stream (bench.py timing) */
+int cfx_event_create(void** ev);
+int cfx_event_record(void* ev);
+int cfx_event_elapsed_ms(void* start, void* stop, double* ms); /* synchronises on stop */
+int cfx_event_destroy(void* ev);
+
+/* ---- mesh: cutcells::MeshView built by build_mesh_view,
+ *      cpp/cutfemx/cut/cut.cpp:500-538 (x stride 3, int32 connectivity) ------ */
+int cfx_mesh_create(int tdim, int gdim, int64_t nnodes, const double* x,
+                    int64_t ncells, const int32_t* conn, int cell_stride,
+                    cfx_mesh_t* out);
+/* synthetic box mesh generated in HBM (Kuhn split of
+ * cpp/cutfemx/distance/fast_iterative.h:93-108) */
+int cfx_mesh_create_box(int tdim, int n, cfx_mesh_t* out);
+int cfx_mesh_info(cfx_mesh_t m, int* tdim, int* gdim, int64_t* nnodes, int64_t* ncells,
+                  const double** x, const int32_t** conn);
+int cfx_mesh_destroy(cfx_mesh_t m);
+
+/* ---- cut: cutfemx::cut / update / locate_entities / runtime_quadrature,
+ *      cpp/cutfemx/cut/cut.h:104-181 ------------------------------------------ */
+int cfx_cut_options_default(cfx_cut_options* opt);
+/* cut(): cut.cpp:743-786 + update :845-868.  ls_values[k] = dof values of level
+ * set k; one shared P1 dofmap [ncells*ls_ndofs_cell]. */
+int cfx_cut_create(cfx_mesh_t mesh, int n_level_sets, const int32_t* ls_dofmap,
+                   int ls_ndofs_cell, int64_t ls_ndofs, const double* const* ls_values,
+                   const cfx_cut_options* opt, cfx_cut_t* out);
+/* update(): cut.cpp:845-868 -- re-classify from new values (same pointers if NULL) */
+int cfx_cut_update(cfx_cut_t cut, const double* const* ls_values);
+int cfx_cut_info(cfx_cut_t cut, int* tdim, int* gdim, int64_t* num_local_cells,
+                 int* n_level_sets);
+/* ParentCellClassification::domain(ls, cell) for all cells: device int8 [ncells] */
+int cfx_cut_domain(cfx_cut_t cut, int level_set, const int8_t** domain);
+/* locate_entities(): cut.cpp:877-924.  *entities is owned by `cut` until the
+ * next locate call with the same selector or cfx_cut_destroy. */
+int cfx_locate_entities(cfx_cut_t cut, const char* selector,
+                        const int32_t** entities, int64_t* n);
+/* runtime_quadrature(): cut.cpp:1311-1335 (backend "straight" only) */
+int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order,
+                           const char* backend, cfx_rules_t* out);
+/* rules over whole cells (reference points, weights*|detJ|): the test helper
+ * python/tests/quadrature_utils.py:12-70 */
+int cfx_full_cell_rules(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int order,
+                        cfx_rules_t* out);
+/* wrap caller-provided rule arrays (runintgen.QuadratureRules(kind="per_entity")) */
+int cfx_rules_create(cfx_mesh_t mesh, int tdim, int64_t nq, int64_t nr, const double* points,
+                     const double* weights, const int32_t* offsets,
+                     const int32_t* parent_map, cfx_rules_t* out);
+int cfx_rules_view_get(cfx_rules_t r, cfx_rules_view* view);
+/* RuntimeQuadrature::physical_points(): runtime_quadrature.h:102-221; out [nq*gdim] */
+int cfx_rules_physical_points(cfx_rules_t r, double* out);
+int cfx_rules_destroy(cfx_rules_t r);
+/* level_set::evaluate_normals / evaluate_values:
+ * cpp/cutfemx/level_set/normal.h:39-187, value.h:34-119; out in HBM or host */
+int cfx_evaluate_normals(cfx_cut_t cut, int level_set, cfx_rules_t rules, double sign,
+                         double* out /* [nq*gdim] */);
+int cfx_evaluate_values(cfx_cut_t cut, int level_set, cfx_rules_t rules,
+                        double* out /* [nq] */);
+/* ghost_penalty_facets(): python/cutfemx/cut.py:340-380 fused with
+ * facet_integration_rows(): python/cutfemx/wrappers/cut.cpp:54-115.
+ * rows = (cell0, local_facet0, cell1, local_facet1), cell0 < cell1. */
+int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector,
+                             const int32_t** rows, int64_t* n);
+int cfx_cut_destroy(cfx_cut_t cut);
+
+/* ---- function space: dolfinx DofMap as read by
+ *      cpp/dolfinx_custom_data/fem/assemble_matrix_impl.h:97-116 ------------- */
+int cfx_space_create(cfx_mesh_t mesh, int degree, int bs, int64_t ndofs,
+                     const int32_t* dofmap, int ndofs_cell, cfx_space_t* out);
+int cfx_space_destroy(cfx_space_t V);
+
+/* ---- forms: dolfinx_custom_data::fem::Form, Form.h:119-178, built as in
+ *      python/cutfemx/wrappers/fem.cpp:124-172 ------------------------------- */
+int cfx_form_create(cfx_space_t V, int rank, int n_integrals,
+                    const cfx_integral* integrals, cfx_form_t* out);
+int cfx_form_destroy(cfx_form_t a);
+/* create_sparsity_pattern(): assembler.h:567-592 (+ :442-529, :538-560) */
+int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out);
+int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* view);
+int cfx_pattern_destroy(cfx_pattern_t p);
+/* assemble_matrix(): assembler.h:690-703 -> assemble_matrix_impl.h:629-810.
+ * Accumulates into values[nnz] (HBM); bc0/bc1 int8 markers or NULL. */
+int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0,
+                        const int8_t* bc1, double* values);
+/* assemble_vector(): assembler.h:252-262 -> assemble_vector_impl.h:573-767 */
+int cfx_assemble_vector(cfx_form_t L, double* b);
+/* local tensor of one entity (parity tests of local entries) */
+int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
+
+/* ---- deactivation: cpp/cutfemx/fem/deactivate.h:387-418 ------------------- */
+int cfx_active_domain(cfx_form_t a, cfx_active_t* out);
+int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_active,
+                    const int32_t** inactive_dofs, int64_t* n_inactive);
+int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t pattern, double* values,
+                           double* b /* or NULL */, double diagonal, double rhs_value);
+int cfx_active_destroy(cfx_active_t d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUTFEMX_AMD_H */

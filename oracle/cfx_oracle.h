@@ -1,0 +1,156 @@
+/* CPU ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C restatement of the CutFEMx hot path (level-set classification ->
+ * sub-triangulation -> runtime quadrature -> local tensors -> CSR scatter ->
+ * deactivation).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (cutfemx_amd/) never
+ * does.
+ *
+ * PARITY STATUS (see DESIGN.md "Oracle"):
+ *   - loop structure, argument order, Ae layouts, BC zeroing, sparsity with the
+ *     all-rows diagonal, selector semantics, classification rule, normal
+ *     evaluator, deactivation: restated from the reference files cited on each
+ *     function (paths relative to /root/reference).
+ *   - classification, selector algebra, rule-array contracts, area/perimeter,
+ *     sum(b)==area, active-domain and runtime-vs-standard matrix parity are
+ *     pinned by the reference's own test invariants (tests/test_oracle_*.py).
+ *   - per-point quadrature coordinates/weights and the sub-triangulation
+ *     topology live in CutCells (third party, >=0.4.0,<0.5.0, not vendored) and
+ *     the reference holds no fixture for them: PARITY UNPINNED at that level.
+ *     Integrals of polynomial integrands do not depend on that choice.
+ */
+#ifndef CFX_ORACLE_H
+#define CFX_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* domain codes (sign of the level set on the cell) */
+enum { ORC_INSIDE = -1, ORC_INTERSECTED = 0, ORC_OUTSIDE = 1 };
+
+/* integral types, order of python/cutfemx/fem.py:261-267 */
+enum { ORC_CELL = 0, ORC_EXTERIOR_FACET = 1, ORC_INTERIOR_FACET = 2 };
+
+/* integrand ids (stand in for the JIT kernel pointer) */
+enum {
+  ORC_K_MASS = 1,           /* u v                                         */
+  ORC_K_STIFFNESS = 2,      /* grad u . grad v                             */
+  ORC_K_NITSCHE = 3,        /* -dn(u) v - dn(v) u + gamma/h u v  (params[0]=gamma) */
+  ORC_K_GHOST_GRADJUMP = 4, /* gamma_g h_avg [dn u][dn v]  (params[0]=gamma_g)     */
+  ORC_K_ELASTICITY = 5,     /* sigma(u):eps(v), params[0]=E, params[1]=nu  */
+  ORC_K_NITSCHE_ELASTICITY = 6,
+  ORC_K_GHOST_GRADJUMP_VEC = 7,
+  ORC_L_SOURCE = 101,       /* f v, f = analytic id params[0], scale params[1] */
+  ORC_L_NITSCHE_RHS = 102   /* -dn(v) g + gamma/h g v, gamma=params[0], g id params[1], scale params[2] */
+};
+
+/* analytic scalar fields evaluated at physical points */
+enum {
+  ORC_F_ONE = 0,           /* 1                                    */
+  ORC_F_SINPROD = 1,       /* prod_i sin(pi x_i)                   */
+  ORC_F_POISSON_RHS = 2    /* gdim pi^2 prod_i sin(pi x_i)         */
+};
+
+typedef struct {
+  int32_t tdim;        /* dimension of the reference points (parent cell) */
+  int64_t nq;          /* total points */
+  int64_t nr;          /* number of rules */
+  double* points;      /* [nq*tdim] parent-reference coordinates */
+  double* weights;     /* [nq] physical measure weights          */
+  int32_t* offsets;    /* [nr+1]                                 */
+  int32_t* parent_map; /* [nr] parent cell of each rule          */
+} orc_rules;
+
+typedef struct {
+  int32_t type;          /* ORC_CELL / ORC_INTERIOR_FACET                      */
+  int32_t kernel;        /* ORC_K_* or ORC_L_*                                  */
+  int32_t qdegree;       /* standard-quadrature degree for uncut entities       */
+  int32_t point_stride;  /* doubles per point in point_data                     */
+  const int32_t* entities; /* cells: ids; interior facets: (c0,lf0,c1,lf1) rows */
+  int64_t n_entities;
+  const orc_rules* rules;  /* runtime rules for the cut entities, or NULL       */
+  const double* point_data;/* per-point coefficients aligned with rules points  */
+  double params[8];
+} orc_integral;
+
+typedef struct {
+  int32_t tdim, gdim;
+  int64_t nnodes, ncells;
+  const double* x;        /* [nnodes*3], stride 3 (cut.cpp:528-529)          */
+  const int32_t* conn;    /* [ncells*(tdim+1)] geometry dofmap, P1           */
+} orc_mesh;
+
+typedef struct {
+  int32_t degree;         /* Lagrange degree 1 or 2                          */
+  int32_t bs;             /* block size (1 scalar, gdim vector)              */
+  int32_t ndofs_cell;     /* scalar dofs per cell                            */
+  int64_t ndofs;          /* scalar dofs in the space                        */
+  const int32_t* dofmap;  /* [ncells*ndofs_cell]                             */
+} orc_space;
+
+void orc_free(void* p);
+void orc_rules_free(orc_rules* r);
+
+/* synthetic inputs: box [0,1]^d, N^d cubes, Kuhn split */
+void orc_mesh_box(int tdim, int N, double* x, int32_t* conn);
+
+/* a1 */
+void orc_classify(int64_t ncells, int ndofs_cell, const int32_t* ls_dofmap,
+                  const double* ls_values, int8_t* domain);
+/* a4: returns count, fills out (capacity ncells); -1 on selector error */
+int64_t orc_locate_entities(int64_t ncells, int nls, const int8_t* domain,
+                            const char* selector, int32_t* out);
+/* a2+a3 */
+int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
+                           const double* ls_values, const int8_t* domain,
+                           const char* selector, int order, orc_rules* out);
+/* rule for a whole reference simplex of each listed cell (test helper that
+   mirrors python/tests/quadrature_utils.py:12-70) */
+int orc_full_cell_rules(const orc_mesh* mesh, const int32_t* cells, int64_t n,
+                        int order, orc_rules* out);
+/* a12 */
+void orc_evaluate_normals(const orc_mesh* mesh, const int32_t* ls_dofmap,
+                          const double* ls_values, const orc_rules* rules,
+                          double sign, double* out);
+void orc_evaluate_values(const orc_mesh* mesh, const int32_t* ls_dofmap,
+                         const double* ls_values, const orc_rules* rules,
+                         double* out);
+void orc_physical_points(const orc_mesh* mesh, const orc_rules* rules, double* out);
+/* a7 facet selection: rows (c0,lf0,c1,lf1), c0<c1, sorted; returns count */
+int64_t orc_ghost_penalty_facets(const orc_mesh* mesh, const int8_t* domain,
+                                 const char* selector, int32_t** rows_out);
+int64_t orc_interior_facets_for_cells(const orc_mesh* mesh, const int32_t* cells,
+                                      int64_t ncells_sel, int32_t** rows_out);
+/* a9 */
+int orc_create_sparsity(const orc_mesh* mesh, const orc_space* V,
+                        const orc_integral* integrals, int n_integrals,
+                        int64_t** indptr, int32_t** indices);
+/* a5/a6/a7 */
+int orc_assemble_matrix(const orc_mesh* mesh, const orc_space* V,
+                        const orc_integral* integrals, int n_integrals,
+                        const int8_t* bc0, const int8_t* bc1,
+                        const int64_t* indptr, const int32_t* indices,
+                        double* values);
+/* a8 */
+int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
+                        const orc_integral* integrals, int n_integrals,
+                        double* b);
+/* local tensor of one entity (for local-entry parity tests) */
+int orc_tabulate_entity(const orc_mesh* mesh, const orc_space* V,
+                        const orc_integral* integral, int64_t entity_or_rule,
+                        int use_rule, double* Ae);
+/* a11 */
+int64_t orc_active_cells(const orc_integral* integrals, int n_integrals,
+                         int64_t ncells, int32_t* out);
+int64_t orc_inactive_dofs(const orc_space* V, const int32_t* active_cells,
+                          int64_t n_active, int32_t* out);
+void orc_deactivate(const int32_t* inactive, int64_t n, int bs_unused,
+                    const int64_t* indptr, const int32_t* indices,
+                    double* values, double* b, double diagonal, double rhs_value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,337 @@
+"""ctypes front-end of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (cutfemx_amd/) never imports
+this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from dataclasses import dataclass, field
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB = None
+
+INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
+CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
+K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
+L_SOURCE, L_NITSCHE_RHS = 101, 102
+F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
+
+
+class _Rules(C.Structure):
+    _fields_ = [("tdim", C.c_int32), ("nq", C.c_int64), ("nr", C.c_int64),
+                ("points", C.c_void_p), ("weights", C.c_void_p),
+                ("offsets", C.c_void_p), ("parent_map", C.c_void_p)]
+
+
+class _Integral(C.Structure):
+    _fields_ = [("type", C.c_int32), ("kernel", C.c_int32), ("qdegree", C.c_int32),
+                ("point_stride", C.c_int32), ("entities", C.c_void_p),
+                ("n_entities", C.c_int64), ("rules", C.c_void_p),
+                ("point_data", C.c_void_p), ("params", C.c_double * 8)]
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("tdim", C.c_int32), ("gdim", C.c_int32), ("nnodes", C.c_int64),
+                ("ncells", C.c_int64), ("x", C.c_void_p), ("conn", C.c_void_p)]
+
+
+class _Space(C.Structure):
+    _fields_ = [("degree", C.c_int32), ("bs", C.c_int32), ("ndofs_cell", C.c_int32),
+                ("ndofs", C.c_int64), ("dofmap", C.c_void_p)]
+
+
+def build(force: bool = False) -> Path:
+    so = _HERE / "liboracle.so"
+    srcs = [_HERE / "cfx_oracle.c", _HERE / "cfx_oracle.h", _HERE / "cfx_quadrature_tables.h"]
+    if force or not so.exists() or any(s.stat().st_mtime > so.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(_HERE), "-B", "liboracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(str(build()))
+        _LIB.orc_locate_entities.restype = C.c_int64
+        _LIB.orc_ghost_penalty_facets.restype = C.c_int64
+        _LIB.orc_interior_facets_for_cells.restype = C.c_int64
+        _LIB.orc_active_cells.restype = C.c_int64
+        _LIB.orc_inactive_dofs.restype = C.c_int64
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclass
+class Mesh:
+    tdim: int
+    x: np.ndarray      # (nnodes, 3) float64
+    conn: np.ndarray   # (ncells, tdim+1) int32
+
+    def __post_init__(self):
+        self.x = np.ascontiguousarray(self.x, dtype=np.float64)
+        self.conn = np.ascontiguousarray(self.conn, dtype=np.int32)
+        self.gdim = self.tdim
+        self.c = _Mesh(self.tdim, self.gdim, self.x.shape[0], self.conn.shape[0],
+                       _p(self.x), _p(self.conn))
+
+    @property
+    def ncells(self):
+        return self.conn.shape[0]
+
+    @property
+    def nnodes(self):
+        return self.x.shape[0]
+
+
+@dataclass
+class Space:
+    dofmap: np.ndarray
+    ndofs: int
+    degree: int = 1
+    bs: int = 1
+
+    def __post_init__(self):
+        self.dofmap = np.ascontiguousarray(self.dofmap, dtype=np.int32)
+        self.c = _Space(self.degree, self.bs, self.dofmap.shape[1], self.ndofs, _p(self.dofmap))
+
+
+@dataclass
+class Rules:
+    tdim: int
+    points: np.ndarray
+    weights: np.ndarray
+    offsets: np.ndarray
+    parent_map: np.ndarray
+    kind: str = "per_entity"
+
+    def cstruct(self):
+        self.points = np.ascontiguousarray(self.points, dtype=np.float64)
+        self.weights = np.ascontiguousarray(self.weights, dtype=np.float64)
+        self.offsets = np.ascontiguousarray(self.offsets, dtype=np.int32)
+        self.parent_map = np.ascontiguousarray(self.parent_map, dtype=np.int32)
+        return _Rules(self.tdim, self.weights.size, self.parent_map.size, _p(self.points),
+                      _p(self.weights), _p(self.offsets), _p(self.parent_map))
+
+
+def _rules_from_c(r: _Rules) -> Rules:
+    nq, nr, tdim = r.nq, r.nr, r.tdim
+
+    def arr(ptr, n, dt):
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dt))),
+                                     shape=(n,)).copy()
+    out = Rules(tdim, arr(r.points, nq * tdim, np.float64).reshape(nq, tdim),
+                arr(r.weights, nq, np.float64), arr(r.offsets, nr + 1, np.int32),
+                arr(r.parent_map, nr, np.int32))
+    lib().orc_rules_free(C.byref(r))
+    return out
+
+
+def mesh_box(tdim: int, n: int) -> Mesh:
+    nn = (n + 1) ** tdim
+    nc = (2 if tdim == 2 else 6) * n ** tdim
+    x = np.zeros((nn, 3))
+    conn = np.zeros((nc, tdim + 1), dtype=np.int32)
+    lib().orc_mesh_box(tdim, n, _p(x), _p(conn))
+    return Mesh(tdim, x, conn)
+
+
+def classify(ls_dofmap, ls_values):
+    ls_dofmap = np.ascontiguousarray(ls_dofmap, dtype=np.int32)
+    ls_values = np.ascontiguousarray(ls_values, dtype=np.float64)
+    dom = np.zeros(ls_dofmap.shape[0], dtype=np.int8)
+    lib().orc_classify(C.c_int64(ls_dofmap.shape[0]), ls_dofmap.shape[1], _p(ls_dofmap),
+                       _p(ls_values), _p(dom))
+    return dom
+
+
+def locate_entities(domain, selector: str):
+    domain = np.ascontiguousarray(domain, dtype=np.int8)
+    dom2 = domain.reshape(-1, domain.shape[-1]) if domain.ndim > 1 else domain.reshape(1, -1)
+    nls, nc = dom2.shape
+    out = np.zeros(nc, dtype=np.int32)
+    n = lib().orc_locate_entities(C.c_int64(nc), nls, _p(dom2), selector.encode(), _p(out))
+    if n < 0:
+        raise ValueError(f"invalid selector {selector!r}")
+    return out[:n].copy()
+
+
+def runtime_quadrature(mesh: Mesh, ls_dofmap, ls_values, domain, selector: str, order: int):
+    ls_dofmap = np.ascontiguousarray(ls_dofmap, dtype=np.int32)
+    ls_values = np.ascontiguousarray(ls_values, dtype=np.float64)
+    domain = np.ascontiguousarray(domain, dtype=np.int8)
+    r = _Rules()
+    rc = lib().orc_runtime_quadrature(C.byref(mesh.c), _p(ls_dofmap), _p(ls_values), _p(domain),
+                                      selector.encode(), order, C.byref(r))
+    if rc != 0:
+        raise ValueError(f"invalid runtime-quadrature selector {selector!r}")
+    return _rules_from_c(r)
+
+
+def full_cell_rules(mesh: Mesh, cells, order: int):
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    r = _Rules()
+    lib().orc_full_cell_rules(C.byref(mesh.c), _p(cells), C.c_int64(cells.size), order, C.byref(r))
+    return _rules_from_c(r)
+
+
+def evaluate_normals(mesh, ls_dofmap, ls_values, rules: Rules, sign=1.0):
+    ls_dofmap = np.ascontiguousarray(ls_dofmap, dtype=np.int32)
+    ls_values = np.ascontiguousarray(ls_values, dtype=np.float64)
+    rc = rules.cstruct()
+    out = np.zeros((rules.weights.size, mesh.gdim))
+    lib().orc_evaluate_normals(C.byref(mesh.c), _p(ls_dofmap), _p(ls_values), C.byref(rc),
+                               C.c_double(sign), _p(out))
+    return out
+
+
+def evaluate_values(mesh, ls_dofmap, ls_values, rules: Rules):
+    ls_dofmap = np.ascontiguousarray(ls_dofmap, dtype=np.int32)
+    ls_values = np.ascontiguousarray(ls_values, dtype=np.float64)
+    rc = rules.cstruct()
+    out = np.zeros(rules.weights.size)
+    lib().orc_evaluate_values(C.byref(mesh.c), _p(ls_dofmap), _p(ls_values), C.byref(rc), _p(out))
+    return out
+
+
+def physical_points(mesh, rules: Rules):
+    rc = rules.cstruct()
+    out = np.zeros((rules.weights.size, mesh.gdim))
+    lib().orc_physical_points(C.byref(mesh.c), C.byref(rc), _p(out))
+    return out
+
+
+def _rows_out(n, ptr):
+    if n < 0:
+        raise ValueError("invalid selector")
+    if n == 0:
+        rows = np.zeros((0, 4), dtype=np.int32)
+    else:
+        rows = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)), shape=(n, 4)).copy()
+    lib().orc_free(ptr)
+    return rows
+
+
+def ghost_penalty_facets(mesh, domain, selector: str):
+    domain = np.ascontiguousarray(domain, dtype=np.int8)
+    ptr = C.c_void_p()
+    n = lib().orc_ghost_penalty_facets(C.byref(mesh.c), _p(domain), selector.encode(), C.byref(ptr))
+    return _rows_out(n, ptr)
+
+
+def interior_facets_for_cells(mesh, cells):
+    cells = np.ascontiguousarray(cells, dtype=np.int32)
+    ptr = C.c_void_p()
+    n = lib().orc_interior_facets_for_cells(C.byref(mesh.c), _p(cells), C.c_int64(cells.size),
+                                            C.byref(ptr))
+    return _rows_out(n, ptr)
+
+
+@dataclass
+class Integral:
+    type: int
+    kernel: int
+    entities: np.ndarray | None = None
+    rules: Rules | None = None
+    point_data: np.ndarray | None = None
+    params: tuple = ()
+    qdegree: int = 2
+    _keep: list = field(default_factory=list)
+
+    def cstruct(self):
+        ent = np.zeros(0, dtype=np.int32) if self.entities is None else \
+            np.ascontiguousarray(self.entities, dtype=np.int32)
+        n_ent = ent.size // 4 if self.type == INTERIOR_FACET else ent.size
+        self._keep = [ent]
+        rptr = None
+        if self.rules is not None:
+            rc = self.rules.cstruct()
+            self._keep.append(rc)
+            rptr = C.cast(C.pointer(rc), C.c_void_p)
+        pd, stride = None, 0
+        if self.point_data is not None:
+            pdarr = np.ascontiguousarray(self.point_data, dtype=np.float64)
+            self._keep.append(pdarr)
+            pd = _p(pdarr)
+            stride = 1 if pdarr.ndim == 1 else pdarr.shape[1]
+        params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
+        return _Integral(self.type, self.kernel, self.qdegree, stride, _p(ent), n_ent, rptr, pd, params)
+
+
+def _integral_array(integrals):
+    arr = (_Integral * len(integrals))(*[i.cstruct() for i in integrals])
+    return arr
+
+
+def create_sparsity(mesh, V: Space, integrals):
+    arr = _integral_array(integrals)
+    ip, ix = C.c_void_p(), C.c_void_p()
+    lib().orc_create_sparsity(C.byref(mesh.c), C.byref(V.c), arr, len(integrals),
+                              C.byref(ip), C.byref(ix))
+    nrows = V.ndofs * V.bs
+    indptr = np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_int64)), shape=(nrows + 1,)).copy()
+    nnz = int(indptr[-1])
+    indices = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_int32)), shape=(nnz,)).copy()
+    lib().orc_free(ip)
+    lib().orc_free(ix)
+    return indptr, indices
+
+
+def assemble_matrix(mesh, V: Space, integrals, indptr, indices, bc0=None, bc1=None):
+    arr = _integral_array(integrals)
+    values = np.zeros(indices.size)
+    b0 = None if bc0 is None else np.ascontiguousarray(bc0, dtype=np.int8)
+    b1 = None if bc1 is None else np.ascontiguousarray(bc1, dtype=np.int8)
+    rc = lib().orc_assemble_matrix(C.byref(mesh.c), C.byref(V.c), arr, len(integrals), _p(b0),
+                                   _p(b1), _p(indptr), _p(indices), _p(values))
+    if rc != 0:
+        raise RuntimeError("entry not in sparsity pattern")
+    return values
+
+
+def assemble_vector(mesh, V: Space, integrals):
+    arr = _integral_array(integrals)
+    b = np.zeros(V.ndofs * V.bs)
+    lib().orc_assemble_vector(C.byref(mesh.c), C.byref(V.c), arr, len(integrals), _p(b))
+    return b
+
+
+def tabulate_entity(mesh, V: Space, integral: Integral, idx: int, use_rule: bool):
+    ic = integral.cstruct()
+    nloc = V.dofmap.shape[1] * V.bs * (2 if integral.type == INTERIOR_FACET else 1)
+    rank2 = integral.kernel < 100
+    Ae = np.zeros((nloc, nloc) if rank2 else (nloc,))
+    lib().orc_tabulate_entity(C.byref(mesh.c), C.byref(V.c), C.byref(ic), C.c_int64(idx),
+                              int(use_rule), _p(Ae))
+    return Ae
+
+
+def active_cells(integrals, ncells):
+    arr = _integral_array(integrals)
+    out = np.zeros(ncells, dtype=np.int32)
+    n = lib().orc_active_cells(arr, len(integrals), C.c_int64(ncells), _p(out))
+    return out[:n].copy()
+
+
+def inactive_dofs(V: Space, active):
+    active = np.ascontiguousarray(active, dtype=np.int32)
+    out = np.zeros(V.ndofs * V.bs, dtype=np.int32)
+    n = lib().orc_inactive_dofs(C.byref(V.c), _p(active), C.c_int64(active.size), _p(out))
+    return out[:n].copy()
+
+
+def deactivate(inactive, indptr, indices, values, b=None, diagonal=1.0, rhs_value=0.0):
+    inactive = np.ascontiguousarray(inactive, dtype=np.int32)
+    lib().orc_deactivate(_p(inactive), C.c_int64(inactive.size), 1, _p(indptr), _p(indices),
+                         _p(values), _p(b), C.c_double(diagonal), C.c_double(rhs_value))

@@ -1,0 +1,54 @@
+"""Shared problem builders for the parity tests: the same synthetic inputs
+ fed to the CPU oracle and to the HIP engine."""
+from __future__ import annotations
+
+import numpy as np
+
+CIRCLE = (np.array([0.47, 0.43]), 0.31)           # python/tests/test_cut_api.py:36-38
+SPHERE = (np.array([0.47, 0.43, 0.41]), 0.31)     # python/tests/test_cut_api.py:50-52
+
+
+def level_set_values(x: np.ndarray, tdim: int, kind: str = "sphere") -> np.ndarray:
+    if kind == "sphere":
+        c, r = CIRCLE if tdim == 2 else SPHERE
+        return np.linalg.norm(x[:, :tdim] - c, axis=1) - r
+    if kind == "gyroid":
+        k = 2.0 * np.pi * 4.0 if tdim == 3 else 2.0 * np.pi * 2.0
+        X, Y = x[:, 0], x[:, 1]
+        Z = x[:, 2] if tdim == 3 else 0.3 * np.ones_like(X)
+        return (np.sin(k * X) * np.cos(k * Y) + np.sin(k * Y) * np.cos(k * Z)
+                + np.sin(k * Z) * np.cos(k * X)) + 0.0137
+    if kind == "plane":
+        return x[:, 0] - 0.51
+    raise ValueError(kind)
+
+
+def oracle_poisson(O, mesh, phi, order=4, gamma=40.0, gamma_g=0.1, degree=1, dofmap=None, ndofs=None):
+    """Oracle restatement of the demo_poisson.py system on `mesh`."""
+    dom = O.classify(mesh.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    vol = O.runtime_quadrature(mesh, mesh.conn, phi, dom, "phi<0", order)
+    itf = O.runtime_quadrature(mesh, mesh.conn, phi, dom, "phi=0", order)
+    normals = O.evaluate_normals(mesh, mesh.conn, phi, itf)
+    ghost = O.ghost_penalty_facets(mesh, dom, "phi<0")
+    V = O.Space(mesh.conn if dofmap is None else dofmap, mesh.nnodes if ndofs is None else ndofs, degree)
+    a = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=vol, qdegree=2 * (degree - 1)),
+         O.Integral(O.CELL, O.K_NITSCHE, rules=itf, point_data=normals, params=(gamma,))]
+    if len(ghost):
+        a.append(O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=ghost, params=(gamma_g,),
+                            qdegree=2 * (degree - 1)))
+    L = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=vol, params=(O.F_POISSON_RHS, 1.0), qdegree=4),
+         O.Integral(O.CELL, O.L_NITSCHE_RHS, rules=itf, point_data=normals, params=(gamma, O.F_SINPROD, 1.0))]
+    indptr, indices = O.create_sparsity(mesh, V, a)
+    values = O.assemble_matrix(mesh, V, a, indptr, indices)
+    b = O.assemble_vector(mesh, V, L)
+    active = O.active_cells(a, mesh.ncells)
+    inactive = O.inactive_dofs(V, active)
+    return dict(domain=dom, inside=inside, vol=vol, itf=itf, normals=normals, ghost=ghost, V=V, a=a, L=L,
+                indptr=indptr, indices=indices, values=values, b=b, active=active, inactive=inactive)
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = max(np.max(np.abs(b)) if b.size else 0.0, 1e-300)
+    return float(np.max(np.abs(a - b)) / scale) if a.size else 0.0

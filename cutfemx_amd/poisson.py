@@ -11,8 +11,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
-from . import cut as _cut
 from . import fem
+from .cut import ghost_penalty_facets, locate_entities_device, normal, runtime_quadrature
 
 
 @dataclass
@@ -30,11 +30,11 @@ class PoissonSystem:
 def build_forms(V, cut_data, *, order: int = 4, gamma: float = 40.0, gamma_g: float = 0.1,
                 ghost_penalty: bool = True, source_degree: int = 4) -> PoissonSystem:
     """locate -> runtime rules -> normals -> forms; everything stays in HBM."""
-    inside = _cut.locate_entities_device(cut_data, "phi<0")
-    volume_rules = _cut.runtime_quadrature(cut_data, "phi<0", order)
-    interface_rules = _cut.runtime_quadrature(cut_data, "phi=0", order)
-    normals = _cut.normal(cut_data, interface_rules, device=True)
-    ghost = _cut.ghost_penalty_facets(cut_data, "phi<0") if ghost_penalty else None
+    inside = locate_entities_device(cut_data, "phi<0")
+    volume_rules = runtime_quadrature(cut_data, "phi<0", order)
+    interface_rules = runtime_quadrature(cut_data, "phi=0", order)
+    normals = normal(cut_data, interface_rules, device=True)
+    ghost = ghost_penalty_facets(cut_data, "phi<0") if ghost_penalty else None
     P = V.degree
     a_int = [
         fem.Integral(fem.STIFFNESS, cells=inside, rules=volume_rules, qdegree=2 * (P - 1)),

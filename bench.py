@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Benchmark of the cut-FEM hot path on MI355X.
+
+One "step" = one full pass of the hot path on a synthetic level-set mesh whose
+inputs (mesh connectivity, coordinates, level-set dof values) are already in
+HBM:  classify -> locate -> sub-triangulate + runtime quadrature (phi<0, phi=0)
+-> normals -> ghost-penalty facets -> forms -> CSR sparsity -> assemble_matrix
+-> assemble_vector -> active domain + deactivation.  This is the per-time-step
+work of a moving-domain CutFEM solve (python/demo/demo_moving_poisson.py:53-67);
+only the mesh-static incidence tables are reused between steps.
+
+metric (BASELINE.json): assembled DOFs/s = active dofs / step time; the
+cut-quadrature points/s and the per-phase times are reported beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 128] [--order 4]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+# ALGORITHMIC bytes per unit (explicit-connectivity variant)
+B_CLASSIFY_PER_CELL = 18.3      # 16 B dofmap row + 8 B*V/C phi + 1 B domain
+B_UNCUT_CELL = 60.0             # id 4 + geometry dofmap 16 + dofmap 16 + coords 4 + CSR write 20
+B_QUAD_PER_POINT = 32.0         # (tdim+1)*8 written per emitted point (3-D)
+B_QUAD_PER_CUT_CELL = 152.0     # dofmap 16 + coords 96 + phi 32 + offsets/parent 8
+B_GHOST_FACET = 600.0           # row ids 16 + 2x(16+16) maps + 64 values x 8 B
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--n", type=int, default=128, help="background mesh n^3 cubes (x6 tets)")
+    p.add_argument("--order", type=int, default=4, help="runtime quadrature order (demo_poisson.py:139)")
+    p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    p.add_argument("--cpu-n", type=int, default=0, help="mesh size of the CPU sample (default: min(n, 128))")
+    return p.parse_args()
+
+
+def sphere_level_set(torch, n, device, z0=0, z1=None):
+    """phi = |x - c| - R sampled at the vertices, vertex id ix+(n+1)(iy+(n+1)iz)."""
+    z1 = n if z1 is None else z1
+    ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
+    az = torch.arange(z0, z1 + 1, device=device, dtype=torch.float64) / n
+    cx, cy, cz, R = 0.47, 0.43, 0.41, 0.31
+    d2 = (az[:, None, None] - cz) ** 2 + (ax[None, :, None] - cy) ** 2 + (ax[None, None, :] - cx) ** 2
+    return (torch.sqrt(d2) - R).reshape(-1).contiguous()
+
+
+class Timer:
+    def __init__(self, torch):
+        self.torch, self.t = torch, {}
+
+    def run(self, name, fn):
+        self.torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        self.torch.cuda.synchronize()
+        self.t[name] = self.t.get(name, 0.0) + (time.perf_counter() - t0)
+        return out
+
+
+def hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer=None):
+    """One full pass; returns counters.  `timer` splits the phases (extra syncs)."""
+    run = (lambda name, fn: fn()) if timer is None else timer.run
+    cd = run("cut", lambda: cfx.cut(phi_fn))
+    system = run("rules+facets+forms", lambda: poisson.build_forms(V, cd, order=order))
+    b_buf.zero_()
+    A = run("sparsity", lambda: cfx.fem.create_matrix(system.a, values=values_buf))
+    if A.nnz > values_buf.numel():
+        raise RuntimeError("values buffer too small")
+    values_buf[: A.nnz].zero_()
+    run("assemble_matrix", lambda: cfx.fem.assemble_matrix(system.a, A=A))
+    run("assemble_vector", lambda: cfx.fem.assemble_vector(system.L, b_buf))
+    dom = run("deactivate", lambda: cfx.fem.deactivate_outside(A, b_buf, cfx.fem.active_domain(system.a)))
+    return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz,
+                n_inside=system.inside_cells[1], n_cut=system.interface_rules.num_rules,
+                nq_volume=system.volume_rules.total_points, nq_interface=system.interface_rules.total_points,
+                n_vol_rules=system.volume_rules.num_rules,
+                n_ghost=0 if system.ghost_facets is None else system.ghost_facets.size)
+
+
+def cpu_baseline(n, order):
+    """The CPU oracle (restatement of the reference loops, single thread) on the
+    same workload; kind='port' because the reference itself cannot be built here."""
+    import numpy as np
+    from helpers import level_set_values
+    from oracle import pyoracle as O
+    O.build()
+    om = O.mesh_box(3, n)
+    phi = level_set_values(om.x, 3)
+    t = {}
+
+    def run(name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        t[name] = time.perf_counter() - t0
+        return out
+
+    dom = run("cut", lambda: O.classify(om.conn, phi))
+    inside = run("locate", lambda: O.locate_entities(dom, "phi<0"))
+    vol = run("rules_volume", lambda: O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", order))
+    itf = run("rules_interface", lambda: O.runtime_quadrature(om, om.conn, phi, dom, "phi=0", order))
+    normals = run("normals", lambda: O.evaluate_normals(om, om.conn, phi, itf))
+    ghost = run("ghost_facets", lambda: O.ghost_penalty_facets(om, dom, "phi<0"))
+    V = O.Space(om.conn, om.nnodes, 1)
+    a = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=vol, qdegree=0),
+         O.Integral(O.CELL, O.K_NITSCHE, rules=itf, point_data=normals, params=(40.0,)),
+         O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=ghost, params=(0.1,), qdegree=0)]
+    L = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=vol, params=(O.F_POISSON_RHS, 1.0), qdegree=4),
+         O.Integral(O.CELL, O.L_NITSCHE_RHS, rules=itf, point_data=normals, params=(40.0, O.F_SINPROD, 1.0))]
+    indptr, indices = run("sparsity", lambda: O.create_sparsity(om, V, a))
+    values = run("assemble_matrix", lambda: O.assemble_matrix(om, V, a, indptr, indices))
+    b = run("assemble_vector", lambda: O.assemble_vector(om, V, L))
+
+    def deact():
+        act = O.active_cells(a, om.ncells)
+        ina = O.inactive_dofs(V, act)
+        O.deactivate(ina, indptr, indices, values, b)
+        return ina
+    ina = run("deactivate", deact)
+    total = sum(t.values())
+    active = om.nnodes - ina.size
+    return dict(value=active / total, unit="DOF/s", cores=1, kind="port",
+                sample=f"full hot path on the {n}^3 sphere workload (oracle/cfx_oracle.c, gcc -O2, 1 thread), "
+                       f"{total:.2f} s",
+                seconds=total, active_dofs=int(active),
+                assemble_matrix_dofs_per_s=active / t["assemble_matrix"],
+                cut_qp_per_s=(vol.weights.size + itf.weights.size)
+                / (t["cut"] + t["rules_volume"] + t["rules_interface"]),
+                phases_s={k: round(v, 4) for k, v in t.items()})
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: cutfemx_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+    os.environ["CFX_DEVICE"] = str(local_rank)
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import _lib, poisson
+
+    n = args.n
+    # ---- inputs resident in HBM before the timed region -----------------------
+    if world == 1:
+        mesh = cfx.Mesh.create_box(3, n)
+        phi_vals = sphere_level_set(torch, n, device)
+    else:
+        from cutfemx_amd import dist as cdist
+        part = cdist.SlabPartition(n, world, rank)
+        mesh, phi_vals = part.local_mesh_and_level_set(torch, device)
+    V = cfx.FunctionSpace(mesh, 1)
+    phi_fn = cfx.Function(V, phi_vals)
+    # generous CSR value buffer (<= 27 entries per P1 row on a Kuhn mesh + ghost couplings)
+    nnz_cap = int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000)
+    values_buf = torch.zeros(nnz_cap, device=device, dtype=torch.float64)
+    b_buf = torch.zeros(mesh.num_nodes, device=device, dtype=torch.float64)
+
+    def step(timer=None):
+        return hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, args.order, timer)
+
+    for _ in range(args.warmup):
+        info = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(info["active_dofs_owned"] if "active_dofs_owned" in info else info["active_dofs"]),
+                          float(info["nq_volume"] + info["nq_interface"])], device=device, dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        active_total, nq_total = float(c[0].item()), float(c[1].item())
+    else:
+        active_total = float(info["active_dofs"])
+        nq_total = float(info["nq_volume"] + info["nq_interface"])
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- phase split + per-kernel HIP-event profile (extra steps, same work) ---
+    timer = Timer(torch)
+    psteps = max(2, min(args.steps, 5))
+    for _ in range(psteps):
+        step(timer)
+    phases_ms = {k: round(1e3 * v / psteps, 4) for k, v in timer.t.items()}
+    _lib.check(_lib.lib().cfx_profile_enable(1))
+    _lib.check(_lib.lib().cfx_profile_reset())
+    for _ in range(psteps):
+        step()
+    torch.cuda.synchronize()
+    import ctypes as C
+    kernels = {}
+    for i in range(_lib.lib().cfx_profile_count()):
+        name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            kernels[name.value.decode()] = dict(total_ms=ms.value / psteps, launches=cnt.value / psteps,
+                                                avg_us=1e3 * ms.value / cnt.value)
+    _lib.check(_lib.lib().cfx_profile_enable(0))
+
+    ncells = mesh.num_cells
+    alg_bytes = {
+        "classify": B_CLASSIFY_PER_CELL * ncells,
+        "assemble_cells_std": B_UNCUT_CELL * info["n_inside"],
+        "cut_emit": B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"]) / 2
+        + B_QUAD_PER_CUT_CELL * info["n_vol_rules"],
+        "assemble_facets": B_GHOST_FACET * info["n_ghost"],
+    }
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    roofline = None
+    if dominant is not None:
+        ab = alg_bytes.get(dominant)
+        k = kernels[dominant]
+        ach = None if ab is None else ab / (k["avg_us"] * 1e-6) / 1e9
+        roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=None,
+                        avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,
+                        measured="HIP events on the launch stream, %d profiled steps after the timed region" % psteps)
+    # also report the roofline of every kernel with a SURVEY byte model
+    roof_all = {}
+    for name, ab in alg_bytes.items():
+        if name in kernels and ab:
+            roof_all[name] = dict(avg_us=round(kernels[name]["avg_us"], 2),
+                                  achieved_GBs=round(ab / (kernels[name]["avg_us"] * 1e-6) / 1e9, 1),
+                                  frac=round(ab / (kernels[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
+
+    out = {
+        "metric": "assembled DOFs/sec (active dofs / full hot-path step), Poisson P1 sphere level-set",
+        "value": active_total / (elapsed / args.steps),
+        "unit": "DOF/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"3D Poisson P1, sphere level set on {n}^3 background mesh "
+                               f"({6 * n ** 3} tets), Nitsche + ghost penalty, order {args.order}",
+                   "cells": 6 * n ** 3, "parallelism": "1 gpu" if world == 1 else f"z-slabs x{world}"},
+        "cut_quadrature_points_per_s": nq_total / (1e-3 * (phases_ms.get("cut", 0) + phases_ms.get("rules+facets+forms", 0)))
+        if phases_ms.get("cut") else None,
+        "assemble_matrix_dofs_per_s": active_total / (1e-3 * phases_ms["assemble_matrix"]) if phases_ms.get("assemble_matrix") else None,
+        "counts": {k: int(v) for k, v in info.items()},
+        "phases_ms": phases_ms,
+        "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
+        "roofline": roofline,
+        "roofline_by_kernel": roof_all,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cn = args.cpu_n or min(n, 128)
+        cb = cpu_baseline(cn, args.order)
+        cb["host_cores_available"] = os.cpu_count()
+        out["cpu_baseline"] = cb
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,15 @@ void Context::ensure()
   if (device < 0) device = 0;
   if (device >= n) throw Error(CFX_ERR_HIP, "cutfemx_amd: device index out of range");
   CFX_HIP(hipSetDevice(device));
+  // keep freed temporaries in the stream-ordered pool instead of returning them
+  // to the driver at every synchronisation
+  hipMemPool_t pool;
+  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess)
+  {
+    uint64_t threshold = UINT64_MAX;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+  }
+  (void)hipGetLastError();
   initialised = true;
 }
 

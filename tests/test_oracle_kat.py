@@ -1,0 +1,307 @@
+"""Known-answer tests that pin the CPU oracle: every integral-level / set-level
+invariant the reference's own tests hold for the hot path (SURVEY.md section 4
+and 8c), plus closed-form checks.  Citations: python/tests/*.py of CutFEMx."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import level_set_values, oracle_poisson
+
+
+def tri_mesh(O, nx, ny, lo=(0.0, 0.0), hi=(1.0, 1.0)):
+    """nx x ny rectangles, right diagonal (dolfinx create_rectangle default)."""
+    xs = np.linspace(lo[0], hi[0], nx + 1)
+    ys = np.linspace(lo[1], hi[1], ny + 1)
+    x = np.zeros(((nx + 1) * (ny + 1), 3))
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    x[:, 0], x[:, 1] = X.ravel(), Y.ravel()
+    conn = []
+    for j in range(ny):
+        for i in range(nx):
+            v = [i + (nx + 1) * j, i + 1 + (nx + 1) * j, i + (nx + 1) * (j + 1), i + 1 + (nx + 1) * (j + 1)]
+            conn += [[v[0], v[1], v[3]], [v[0], v[3], v[2]]]
+    return O.Mesh(2, x, np.array(conn, dtype=np.int32))
+
+
+def test_plane_cut_cells_3x3(oracle):
+    # test_cut_api.py:95-103 / test_locate_entities.py:13-35: phi = x - 0.51 on a 3x3
+    # right-diagonal mesh cuts exactly the 6 triangles of the middle column
+    O = oracle
+    m = tri_mesh(O, 3, 3)
+    phi = m.x[:, 0] - 0.51
+    dom = O.classify(m.conn, phi)
+    cut = O.locate_entities(dom, "phi=0")
+    assert cut.size == 6
+    xc = m.x[m.conn][:, :, 0]
+    assert np.all(xc[cut].min(axis=1) < 0.51) and np.all(xc[cut].max(axis=1) > 0.51)
+    inside = O.locate_entities(dom, "phi<0")
+    assert np.all(xc[inside].max(axis=1) < 0.51) and inside.size == 6
+    assert O.locate_entities(dom, "phi>0").size == 6
+
+
+def test_zero_vertex_values_are_intersected(oracle):
+    # test_cut_api.py:191-208, docs/user-guide/level-sets.md:84-88
+    O = oracle
+    m = tri_mesh(O, 2, 1)
+    phi = m.x[:, 0] - 0.5
+    dom = O.classify(m.conn, phi)
+    assert np.array_equal(O.locate_entities(dom, "phi=0"), np.arange(m.ncells))
+    assert O.locate_entities(dom, "phi<0").size == 0 and O.locate_entities(dom, "phi>0").size == 0
+    # degenerate cuts must not produce NaN / negative weights, and must tile the cells
+    r_in = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 2)
+    r_out = O.runtime_quadrature(m, m.conn, phi, dom, "phi>0", 2)
+    for r in (r_in, r_out):
+        assert np.all(np.isfinite(r.weights)) and np.all(r.weights >= 0)
+    assert abs(r_in.weights.sum() - 0.5) < 1e-14 and abs(r_out.weights.sum() - 0.5) < 1e-14
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 12), (3, 6)])
+def test_selector_algebra(oracle, tdim, n):
+    # test_cut_api.py:142-157,702-710
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    le = O.locate_entities(dom, "phi<=0")
+    lt, eq = O.locate_entities(dom, "phi<0"), O.locate_entities(dom, "phi=0")
+    assert np.array_equal(le, np.union1d(lt, eq))
+    assert np.array_equal(O.locate_entities(dom, "phi<0 or phi=0"), le)
+    assert O.locate_entities(dom, "phi<0 and phi>0").size == 0
+    assert np.array_equal(O.locate_entities(dom, "phi>=0"), np.union1d(O.locate_entities(dom, "phi>0"), eq))
+    a = O.runtime_quadrature(m, m.conn, phi, dom, "phi<=0", 2)
+    b = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 2)
+    for f in ("points", "weights", "offsets", "parent_map"):
+        assert np.array_equal(getattr(a, f), getattr(b, f))
+    with pytest.raises(ValueError):
+        O.locate_entities(dom, "psi<0")
+    with pytest.raises(ValueError):
+        O.locate_entities(dom, "phi<1")
+    # two level sets: "phi<0 and phi1>0" (docs/user-guide/element-classification.md:145-160)
+    phi1 = m.x[:, 0] - 0.5
+    dom2 = np.stack([dom, O.classify(m.conn, phi1)])
+    both = O.locate_entities(dom2, "phi<0 and phi1>0")
+    assert np.array_equal(both, np.intersect1d(lt, O.locate_entities(dom2[1], "phi>0")))
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 12), (3, 6)])
+def test_rule_array_contracts(oracle, tdim, n):
+    # test_cut_api.py:405-421
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    cut = O.locate_entities(dom, "phi=0")
+    for sel in ("phi<0", "phi>0", "phi=0"):
+        r = O.runtime_quadrature(m, m.conn, phi, dom, sel, 4)
+        assert r.kind == "per_entity" and r.tdim == tdim
+        assert r.offsets.dtype == np.int32 and r.parent_map.dtype == np.int32
+        assert r.offsets[0] == 0 and r.offsets[-1] == r.weights.size
+        assert len(r.parent_map) == len(r.offsets) - 1
+        assert np.all(np.isin(r.parent_map, cut))
+        assert r.points.shape == (r.weights.size, tdim)
+        assert np.all(np.diff(r.offsets) > 0) and np.all(r.weights > 0)
+        assert r.points.min() > -1e-14 and r.points.sum(axis=1).max() < 1 + 1e-14
+
+
+def test_circle_area_and_perimeter(oracle):
+    # test_cut_api.py:1268-1300: R = 0.5 on a 21x21 triangle mesh of [-1,1]^2, order 4
+    O = oracle
+    m = tri_mesh(O, 21, 21, (-1.0, -1.0), (1.0, 1.0))
+    phi = np.sqrt(m.x[:, 0] ** 2 + m.x[:, 1] ** 2) - 0.5
+    dom = O.classify(m.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    vol = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 4)
+    itf = O.runtime_quadrature(m, m.conn, phi, dom, "phi=0", 4)
+    area = vol.weights.sum() + O.full_cell_rules(m, inside, 1).weights.sum()
+    assert abs(area - np.pi * 0.25) < 1e-2
+    assert abs(itf.weights.sum() - np.pi) < 1e-2
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_load_vector_sum_equals_measure(oracle, tdim, n):
+    # test_cut_api.py:813-869: sum_i b_i (L = int 1*v) == cut area, rtol = atol = 1e-12,
+    # with the mixed [inside_cells, rules] measure; active cells = inside U parent_map
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    vol = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 2)
+    V = O.Space(m.conn, m.nnodes, 1)
+    L = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=vol, params=(O.F_ONE, 1.0), qdegree=1)]
+    b = O.assemble_vector(m, V, L)
+    area = vol.weights.sum() + O.full_cell_rules(m, inside, 1).weights.sum()
+    assert np.isclose(b.sum(), area, rtol=1e-12, atol=1e-12)
+    active = O.active_cells([O.Integral(O.CELL, O.K_MASS, entities=inside, rules=vol)], m.ncells)
+    assert np.array_equal(active, np.unique(np.concatenate([inside, vol.parent_map])))
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_deactivation(oracle, tdim, n):
+    # test_cut_api.py:840-846,876,949-952: inactive dofs -> diag = 1, rhs = 0
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    ref = oracle_poisson(O, m, level_set_values(m.x, tdim))
+    touched = np.unique(m.conn[ref["active"]])
+    assert np.array_equal(ref["inactive"], np.setdiff1d(np.arange(m.nnodes), touched))
+    vals, b = ref["values"].copy(), ref["b"].copy()
+    O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, b)
+    A = sp.csr_matrix((vals, ref["indices"], ref["indptr"]), shape=(m.nnodes, m.nnodes))
+    assert np.all(A.diagonal()[ref["inactive"]] == 1.0) and np.all(b[ref["inactive"]] == 0.0)
+    # inactive rows hold nothing but the diagonal
+    assert abs(A[ref["inactive"]]).sum() == len(ref["inactive"])
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_ghost_penalty_facets(oracle, tdim, n):
+    # test_cut_api.py:1158-1173: unique, exactly two adjacent cells, band semantics of cut.py:340-380
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    rows = O.ghost_penalty_facets(m, dom, "phi<0")
+    assert len(np.unique(rows[:, [0, 2]], axis=0)) == len(rows)
+    assert np.all(rows[:, 0] < rows[:, 2])
+    active = set(O.locate_entities(dom, "phi<=0").tolist())
+    nv = tdim + 1
+    for c0, l0, c1, l1 in rows[:: max(1, len(rows) // 50)]:
+        assert c0 in active and c1 in active and (dom[c0] == 0 or dom[c1] == 0)
+        f0 = set(np.delete(m.conn[c0], l0).tolist())
+        f1 = set(np.delete(m.conn[c1], l1).tolist())
+        assert f0 == f1 and len(f0) == nv - 1
+    # brute force: every interior facet between active cells touching a cut cell is present
+    allf = O.interior_facets_for_cells(m, np.array(sorted(active), dtype=np.int32))
+    want = allf[(dom[allf[:, 0]] == 0) | (dom[allf[:, 2]] == 0)]
+    assert {tuple(r) for r in want} == {tuple(r) for r in rows}
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_interface_normal_identity(oracle, tdim, n):
+    # test_cut_api.py:989-1026: int_Gamma n_h . n_h == meas(Gamma) (1e-12)
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    itf = O.runtime_quadrature(m, m.conn, phi, dom, "phi=0", 2)
+    nrm = O.evaluate_normals(m, m.conn, phi, itf)
+    assert np.isclose((itf.weights * (nrm * nrm).sum(axis=1)).sum(), itf.weights.sum(), rtol=1e-12)
+    # the normals point along grad(phi): radially outward for a signed-distance sphere
+    xp = O.physical_points(m, itf)
+    c = np.array([0.47, 0.43, 0.41])[:tdim]
+    radial = (xp - c) / np.linalg.norm(xp - c, axis=1)[:, None]
+    assert np.min((radial * nrm).sum(axis=1)) > 0.9
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_volume_fraction_complement(oracle, tdim, n):
+    # test_extensions_cell_aggregation.py:74-98: opposite-phase fractions sum to 1 (atol 1e-12)
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = level_set_values(m.x, tdim)
+    dom = O.classify(m.conn, phi)
+    a = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 1)
+    b = O.runtime_quadrature(m, m.conn, phi, dom, "phi>0", 1)
+    cut = O.locate_entities(dom, "phi=0")
+    vol = O.full_cell_rules(m, cut, 1).weights
+    fa = np.zeros(m.ncells); fb = np.zeros(m.ncells)
+    np.add.at(fa, np.repeat(a.parent_map, np.diff(a.offsets)), a.weights)
+    np.add.at(fb, np.repeat(b.parent_map, np.diff(b.offsets)), b.weights)
+    assert np.allclose((fa[cut] + fb[cut]) / vol, 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("kernel,order,tol", [("stiffness", 2, 1e-12), ("mass", 2, 1e-12), ("elasticity", 2, 1e-9)])
+def test_runtime_vs_standard_matrix(oracle, kernel, order, tol):
+    # test_assembly_poisson.py:18-59 (||A_cut - A_ref||_F < 1e-12, unit square 4x4, full-cell
+    # rules of order 2), test_assembly_elasticity.py:18-68 (< 1e-9)
+    O = oracle
+    m = tri_mesh(O, 4, 4)
+    cells = np.arange(m.ncells, dtype=np.int32)
+    rules = O.full_cell_rules(m, cells, order)
+    if kernel == "elasticity":
+        V = O.Space(m.conn, m.nnodes, 1, bs=2)
+        k, params = O.K_ELASTICITY, (1.0e3, 0.3)
+    else:
+        V = O.Space(m.conn, m.nnodes, 1)
+        k, params = (O.K_STIFFNESS if kernel == "stiffness" else O.K_MASS), ()
+    a_std = [O.Integral(O.CELL, k, entities=cells, params=params, qdegree=order)]
+    a_run = [O.Integral(O.CELL, k, rules=rules, params=params)]
+    ip, ix = O.create_sparsity(m, V, a_std)
+    ip2, ix2 = O.create_sparsity(m, V, a_run)
+    assert np.array_equal(ip, ip2) and np.array_equal(ix, ix2)
+    A = O.assemble_matrix(m, V, a_std, ip, ix)
+    B = O.assemble_matrix(m, V, a_run, ip, ix)
+    assert np.linalg.norm(A - B) < tol
+    # closed form: the P1 stiffness matrix of the right-diagonal unit-square mesh is the
+    # 5-point Laplacian; constants are in its null space
+    if kernel == "stiffness":
+        M = sp.csr_matrix((A, ix, ip), shape=(m.nnodes, m.nnodes))
+        assert np.abs(M @ np.ones(m.nnodes)).max() < 1e-13
+        interior = 2 * 5 + 2
+        assert np.isclose(M[interior, interior], 4.0) and np.isclose(M[interior, interior + 1], -1.0)
+    if kernel == "mass":
+        assert np.isclose(A.sum(), 1.0, rtol=1e-13)
+
+
+def test_dirichlet_rows_and_columns_are_zeroed(oracle):
+    # assemble_matrix_impl.h:151-185
+    O = oracle
+    m = tri_mesh(O, 4, 4)
+    V = O.Space(m.conn, m.nnodes, 1)
+    cells = np.arange(m.ncells, dtype=np.int32)
+    a = [O.Integral(O.CELL, O.K_STIFFNESS, entities=cells, qdegree=0)]
+    ip, ix = O.create_sparsity(m, V, a)
+    bc = np.zeros(m.nnodes, dtype=np.int8)
+    bc[[0, 7, 12]] = 1
+    A = sp.csr_matrix((O.assemble_matrix(m, V, a, ip, ix, bc, bc), ix, ip), shape=(m.nnodes,) * 2).toarray()
+    F = sp.csr_matrix((O.assemble_matrix(m, V, a, ip, ix), ix, ip), shape=(m.nnodes,) * 2).toarray()
+    assert np.all(A[[0, 7, 12], :] == 0) and np.all(A[:, [0, 7, 12]] == 0)
+    keep = np.setdiff1d(np.arange(m.nnodes), [0, 7, 12])
+    assert np.array_equal(A[np.ix_(keep, keep)], F[np.ix_(keep, keep)])
+
+
+def test_sparsity_has_all_rows_diagonal(oracle):
+    # assembler.h:538-560
+    O = oracle
+    m = O.mesh_box(3, 6)
+    ref = oracle_poisson(O, m, level_set_values(m.x, 3))
+    ip, ix = ref["indptr"], ref["indices"]
+    assert ip.dtype == np.int64 and ix.dtype == np.int32
+    for r in range(m.nnodes):
+        row = ix[ip[r]:ip[r + 1]]
+        assert r in row and np.all(np.diff(row) > 0)
+    assert np.all(np.diff(ip)[ref["inactive"]] == 1)
+
+
+def test_sphere_volume_and_area_convergence(oracle):
+    O = oracle
+    R = 0.31
+    errs = []
+    for n in (8, 16, 32):
+        m = O.mesh_box(3, n)
+        phi = level_set_values(m.x, 3)
+        dom = O.classify(m.conn, phi)
+        inside = O.locate_entities(dom, "phi<0")
+        vol = O.runtime_quadrature(m, m.conn, phi, dom, "phi<0", 1).weights.sum() \
+            + O.full_cell_rules(m, inside, 1).weights.sum()
+        area = O.runtime_quadrature(m, m.conn, phi, dom, "phi=0", 1).weights.sum()
+        errs.append((abs(vol - 4 / 3 * np.pi * R ** 3), abs(area - 4 * np.pi * R ** 2)))
+    for k in range(2):  # second-order convergence of the piecewise-linear interface
+        assert errs[1][k] < errs[0][k] / 3 and errs[2][k] < errs[1][k] / 3
+
+
+def test_cut_poisson_solution_converges(oracle):
+    # end-to-end sanity of the weak form (demo_poisson.py:183-201): O(h^2) nodal error
+    import scipy.sparse.linalg as spl
+    O = oracle
+    errs = []
+    for n in (16, 32):
+        m = O.mesh_box(2, n)
+        ref = oracle_poisson(O, m, level_set_values(m.x, 2))
+        vals, b = ref["values"].copy(), ref["b"].copy()
+        O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, b)
+        A = sp.csr_matrix((vals, ref["indices"], ref["indptr"]), shape=(m.nnodes,) * 2)
+        u = spl.spsolve(A.tocsc(), b)
+        uex = np.prod(np.sin(np.pi * m.x[:, :2]), axis=1)
+        act = np.setdiff1d(np.arange(m.nnodes), ref["inactive"])
+        errs.append(np.abs(u - uex)[act].max())
+    assert errs[1] < errs[0] / 3

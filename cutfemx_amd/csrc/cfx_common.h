@@ -310,16 +310,48 @@ struct cfx_integral_dev
   double params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+// Row plan of a form: everything the row-centric kernels (sparsity, gather
+// assembly, active domain) need that depends on the form's entity lists.
+struct cfx_row_plan
+{
+  bool built = false;
+  bool usable = false;             // row-gather assembly is legal for this form
+  cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
+  cfx::DevArray<uint8_t> rowmark;  // dof touched by any entity of the form
+  cfx::DevArray<int32_t> active_rows;
+  int64_t n_active_rows = 0;
+  bool any_cells = false;
+  // interior facets of all facet integrals, concatenated
+  int64_t nfacets = 0;
+  cfx::DevArray<int32_t> facet_rows;  // [nfacets*4]
+  cfx::DevArray<uint8_t> facet_slot;  // facet integral slot of each row
+  cfx::DevArray<int64_t> d2f_offsets; // dof -> facets incidence
+  cfx::DevArray<int32_t> d2f;
+  int n_cell_slots = 0, n_facet_slots = 0;
+  int cell_slot_integral[4] = {0, 0, 0, 0};
+  int facet_slot_integral[2] = {0, 0};
+};
+
 struct cfx_form_s
 {
   cfx_space_t V = nullptr;
   int rank = 2;
   std::vector<cfx_integral_dev> integrals;
+  cfx_row_plan plan;
 };
+
+namespace cfx
+{
+cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
+void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
+bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values);
+bool assemble_vector_rows(cfx_form_s* L, double* b);
+} // namespace cfx
 
 struct cfx_pattern_s
 {
   int64_t nrows = 0, nnz = 0;
+  int max_row_len = 0; // upper bound on the scalar-dof row length
   cfx::DevArray<int64_t> indptr;
   cfx::DevArray<int32_t> indices;
 };

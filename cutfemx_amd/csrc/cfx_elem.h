@@ -1,0 +1,390 @@
+// cutfemx_amd: element mathematics shared by the assembly kernels -- Lagrange
+// tabulation, reference rules, analytic fields and the per-entity "local row"
+// of every supported integrand.  These device functions stand in for the
+// runintgen/FFCx generated tabulate_tensor kernels (third party):
+//   void k(T* A, const T* w, const T* c, const U* coordinate_dofs,
+//          const int* entity_local_index, const uint8_t* perm, void* custom_data)
+// (cpp/dolfinx_custom_data/fem/Form.h:59-75).  A cut entity integrates over its
+// runtime rule slice (points = parent reference coords, weights = physical
+// measure, no detJ factor); an uncut entity uses the reference rule of degree
+// qdegree times |detJ|.
+#pragma once
+
+#include "cfx_device.h"
+
+#define CFX_QUAD_TABLE_QUALIFIER static __device__ const
+#include "cfx_quadrature_tables.h"
+#undef CFX_QUAD_TABLE_QUALIFIER
+
+namespace cfx
+{
+
+constexpr double kPi = 3.14159265358979323846;
+
+template <int TDIM, int DEG>
+struct Elem
+{
+  static constexpr int ND = DEG == 1 ? TDIM + 1 : (TDIM == 2 ? 6 : 10);
+};
+
+// Lagrange tabulation; dof order = Basix (vertices, then edges
+// tri: (1,2),(0,2),(0,1); tet: (2,3),(1,3),(1,2),(0,3),(0,2),(0,1))
+template <int TDIM, int DEG>
+__device__ __forceinline__ void tabulate(const double* X, double* N, double (*dN)[TDIM])
+{
+  double lam[TDIM + 1];
+  lam[0] = 1.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) { lam[0] -= X[t]; lam[t + 1] = X[t]; }
+  if constexpr (DEG == 1)
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      N[i] = lam[i];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) dN[i][t] = (i == 0) ? -1.0 : ((i - 1 == t) ? 1.0 : 0.0);
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      N[i] = lam[i] * (2.0 * lam[i] - 1.0);
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+        dN[i][t] = (4.0 * lam[i] - 1.0) * ((i == 0) ? -1.0 : ((i - 1 == t) ? 1.0 : 0.0));
+    }
+    constexpr int NE = TDIM == 2 ? 3 : 6;
+    constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+    constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+    {
+      const int a = TDIM == 2 ? ea2[e % 3] : ea3[e], b = TDIM == 2 ? eb2[e % 3] : eb3[e];
+      N[TDIM + 1 + e] = 4.0 * lam[a] * lam[b];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        const double da = (a == 0) ? -1.0 : ((a - 1 == t) ? 1.0 : 0.0);
+        const double db = (b == 0) ? -1.0 : ((b - 1 == t) ? 1.0 : 0.0);
+        dN[TDIM + 1 + e][t] = 4.0 * (lam[a] * db + da * lam[b]);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ const double* ref_rule(int dim, int degree, int& n, const double*& w)
+{
+  if (dim == 1)
+  {
+    n = cfx_quad_offset_1d[degree + 1] - cfx_quad_offset_1d[degree];
+    w = cfx_quad_weights_1d + cfx_quad_offset_1d[degree];
+    return cfx_quad_points_1d + cfx_quad_offset_1d[degree];
+  }
+  if (dim == 2)
+  {
+    n = cfx_quad_offset_2d[degree + 1] - cfx_quad_offset_2d[degree];
+    w = cfx_quad_weights_2d + cfx_quad_offset_2d[degree];
+    return cfx_quad_points_2d + 2 * cfx_quad_offset_2d[degree];
+  }
+  n = cfx_quad_offset_3d[degree + 1] - cfx_quad_offset_3d[degree];
+  w = cfx_quad_weights_3d + cfx_quad_offset_3d[degree];
+  return cfx_quad_points_3d + 3 * cfx_quad_offset_3d[degree];
+}
+
+template <int GDIM>
+__device__ __forceinline__ double field_eval(int id, const double* x)
+{
+  if (id == CFX_F_ONE) return 1.0;
+  double p = 1.0;
+#pragma unroll
+  for (int d = 0; d < GDIM; ++d) p *= sin(kPi * x[d]);
+  if (id == CFX_F_SINPROD) return p;
+  return (double)GDIM * kPi * kPi * p;
+}
+
+// position of column `col` in CSR row [b,e); -1 if absent
+__device__ __forceinline__ int64_t csr_find(const int32_t* __restrict__ indices, int64_t b, int64_t e, int32_t col)
+{
+  int64_t lo = b, hi = e;
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (indices[mid] < col) lo = mid + 1; else hi = mid;
+  }
+  return (lo < e && indices[lo] == col) ? lo : -1;
+}
+
+// ---------------------------------------------------------------------------
+// Row (ia, ik) of a CELL integral's element tensor, accumulated into acc:
+// RANK 2: acc[j*BS + b] over all trial dofs; RANK 1: acc[0].
+// `g` must hold the vertex coordinates and K/detJ (jacobian() already called).
+// ---------------------------------------------------------------------------
+template <int TDIM, int DEG, int BS, int RANK>
+__device__ __forceinline__ void cell_local_row(int kernel, const double* __restrict__ params, int point_stride,
+                                               const Geo<TDIM>& g, double h, int npts,
+                                               const double* __restrict__ pts, const double* __restrict__ wts,
+                                               double wscale, const double* __restrict__ pdata, int ia, int ik,
+                                               double* acc)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  for (int q = 0; q < npts; ++q)
+  {
+    double X[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
+    const double w = wts[q] * wscale;
+    double N[ND], dN[ND][TDIM], G[ND][TDIM];
+    tabulate<TDIM, DEG>(X, N, dN);
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
+        G[j][d] = v;
+      }
+    // row basis function (static indexing through a select chain)
+    double Ni = 0.0, Gi[TDIM];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) Gi[d] = 0.0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+      if (j == ia)
+      {
+        Ni = N[j];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) Gi[d] = G[j][d];
+      }
+
+    if constexpr (RANK == 2)
+    {
+      switch (kernel)
+      {
+      case CFX_K_MASS:
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * Ni * N[j] : 0.0;
+        break;
+      case CFX_K_STIFFNESS:
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) s += Gi[d] * G[j][d];
+#pragma unroll
+          for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * s : 0.0;
+        }
+        break;
+      case CFX_K_NITSCHE:
+        if constexpr (BS == 1)
+        {
+          const double* nrm = pdata + (int64_t)q * point_stride;
+          const double gam = params[0] / h;
+          double dni = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) dni += Gi[d] * nrm[d];
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            double dnj = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d) dnj += G[j][d] * nrm[d];
+            acc[j] += w * (-dnj * Ni - dni * N[j] + gam * N[j] * Ni);
+          }
+        }
+        break;
+      case CFX_K_ELASTICITY:
+        if constexpr (BS == TDIM)
+        {
+          // sigma(u):eps(v), sigma = 2 mu eps + lambda tr(eps) I  (python/demo/demo_elasticity.py:167-238)
+          const double E = params[0], nu = params[1];
+          const double mu = E / (2.0 * (1.0 + nu));
+          const double lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+          double Gia = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) Gia = (d == ik) ? Gi[d] : Gia;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            double gg = 0.0, Gja = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d) { gg += Gi[d] * G[j][d]; Gja = (d == ik) ? G[j][d] : Gja; }
+#pragma unroll
+            for (int b = 0; b < BS; ++b)
+              acc[j * BS + b] += w * (mu * ((b == ik ? gg : 0.0) + Gi[b] * Gja) + lmbda * Gia * G[j][b]);
+          }
+        }
+        break;
+      default: break;
+      }
+    }
+    else
+    {
+      double xq[TDIM], l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) l0 -= X[t];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = l0 * g.x[0][d];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v += X[t] * g.x[t + 1][d];
+        xq[d] = v;
+      }
+      if (kernel == CFX_L_SOURCE)
+      {
+        const double f = params[1] * field_eval<TDIM>((int)params[0], xq);
+        acc[0] += w * f * Ni;
+      }
+      else if (kernel == CFX_L_NITSCHE_RHS)
+      {
+        const double* nrm = pdata + (int64_t)q * point_stride;
+        const double gam = params[0] / h;
+        const double gv = params[2] * field_eval<TDIM>((int)params[1], xq);
+        double dni = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) dni += Gi[d] * nrm[d];
+        acc[0] += w * (-dni * gv + gam * gv * Ni);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Row (ia, ik) of an INTERIOR-FACET integral's macro element tensor.
+// Macro element = [cell0 dofs, cell1 dofs]; Ae block layout [[00,01],[10,11]]
+// (assemble_matrix_impl.h:537-542); ia in [0, 2 ND).  The facet quadrature
+// points are pushed to physical space from cell0's facet lf0 and pulled back
+// to both reference cells.  acc[j*BS + b], j in [0, 2 ND).
+// ---------------------------------------------------------------------------
+template <int TDIM, int DEG, int BS>
+__device__ __forceinline__ void facet_local_row(int kernel, const double* __restrict__ params, int qdegree,
+                                                const Geo<TDIM>& g0, const Geo<TDIM>& g1, int lf0, int ia, int ik,
+                                                double* acc)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
+  // outward unit normal of cell0 on facet lf0: -grad(lambda_lf0)/|.|
+  double nrm[TDIM];
+  {
+    double nn = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double v = 0.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        const double dl = (lf0 == 0) ? -1.0 : ((lf0 - 1 == t) ? 1.0 : 0.0);
+        v -= g0.K[t][d] * dl;
+      }
+      nrm[d] = v;
+      nn += v * v;
+    }
+    nn = sqrt(nn);
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) nrm[d] /= nn;
+  }
+  // facet vertices (cell0 vertices except lf0, ascending local index)
+  double xf[TDIM][TDIM];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      if (i == lf0) continue;
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j)
+        if (j == k)
+        {
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) xf[j][d] = g0.x[i][d];
+        }
+      ++k;
+    }
+  }
+  double scale;
+  if constexpr (TDIM == 2)
+  {
+    const double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
+    scale = sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    scale = sqrt(cx * cx + cy * cy + cz * cz);
+  }
+
+  int nref;
+  const double* wref;
+  const double* pref = ref_rule(TDIM - 1, qdegree, nref, wref);
+  for (int q = 0; q < nref; ++q)
+  {
+    double l0 = 1.0, xq[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM - 1; ++t) l0 -= pref[q * (TDIM - 1) + t];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double v = l0 * xf[0][d];
+#pragma unroll
+      for (int t = 0; t < TDIM - 1; ++t) v += pref[q * (TDIM - 1) + t] * xf[t + 1][d];
+      xq[d] = v;
+    }
+    double X0[TDIM], X1[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t)
+    {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        a += g0.K[t][d] * (xq[d] - g0.x[0][d]);
+        b += g1.K[t][d] * (xq[d] - g1.x[0][d]);
+      }
+      X0[t] = a; X1[t] = b;
+    }
+    double N0[ND], dN0[ND][TDIM], N1[ND], dN1[ND][TDIM];
+    tabulate<TDIM, DEG>(X0, N0, dN0);
+    tabulate<TDIM, DEG>(X1, N1, dN1);
+    const double w = wref[q] * scale * params[0] * havg;
+    // normal-derivative jump of every macro basis function
+    double jn[2 * ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+    {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+        {
+          a += g0.K[t][d] * dN0[j][t] * nrm[d];
+          b += g1.K[t][d] * dN1[j][t] * nrm[d];
+        }
+      jn[j] = a; jn[ND + j] = -b;
+    }
+    double ji = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2 * ND; ++j) ji = (j == ia) ? jn[j] : ji;
+    if (kernel == CFX_K_GHOST_GRADJUMP)
+    {
+#pragma unroll
+      for (int j = 0; j < 2 * ND; ++j)
+#pragma unroll
+        for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * ji * jn[j] : 0.0;
+    }
+  }
+}
+
+} // namespace cfx

@@ -8,107 +8,14 @@
 //   cpp/dolfinx_custom_data/fem/assemble_vector_impl.h:62-122   vector loop   (a8)
 //   runintgen/FFCx generated tabulate_tensor kernels (third party)            (a6)
 //   cpp/cutfemx/fem/deactivate.h:387-418                                      (a11)
-#include "cfx_device.h"
+#include <cstdlib>
 
-#define CFX_QUAD_TABLE_QUALIFIER static __device__ const
-#include "cfx_quadrature_tables.h"
-#undef CFX_QUAD_TABLE_QUALIFIER
+#include "cfx_elem.h"
 
 using namespace cfx;
 
-namespace cfx
-{
-int quad_npoints(int dim, int degree);
-}
-
 namespace
 {
-
-constexpr double kPi = 3.14159265358979323846;
-
-template <int TDIM, int DEG>
-struct Elem
-{
-  static constexpr int ND = DEG == 1 ? TDIM + 1 : (TDIM == 2 ? 6 : 10);
-};
-
-// Lagrange tabulation; dof order = Basix (vertices, then edges
-// tri: (1,2),(0,2),(0,1); tet: (2,3),(1,3),(1,2),(0,3),(0,2),(0,1))
-template <int TDIM, int DEG>
-__device__ __forceinline__ void tabulate(const double* X, double* N, double (*dN)[TDIM])
-{
-  double lam[TDIM + 1];
-  lam[0] = 1.0;
-#pragma unroll
-  for (int t = 0; t < TDIM; ++t) { lam[0] -= X[t]; lam[t + 1] = X[t]; }
-  if constexpr (DEG == 1)
-  {
-#pragma unroll
-    for (int i = 0; i <= TDIM; ++i)
-    {
-      N[i] = lam[i];
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t) dN[i][t] = (i == 0) ? -1.0 : ((i - 1 == t) ? 1.0 : 0.0);
-    }
-  }
-  else
-  {
-#pragma unroll
-    for (int i = 0; i <= TDIM; ++i)
-    {
-      N[i] = lam[i] * (2.0 * lam[i] - 1.0);
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t)
-        dN[i][t] = (4.0 * lam[i] - 1.0) * ((i == 0) ? -1.0 : ((i - 1 == t) ? 1.0 : 0.0));
-    }
-    constexpr int NE = TDIM == 2 ? 3 : 6;
-    constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
-    constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
-#pragma unroll
-    for (int e = 0; e < NE; ++e)
-    {
-      const int a = TDIM == 2 ? ea2[e % 3] : ea3[e], b = TDIM == 2 ? eb2[e % 3] : eb3[e];
-      N[TDIM + 1 + e] = 4.0 * lam[a] * lam[b];
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t)
-      {
-        const double da = (a == 0) ? -1.0 : ((a - 1 == t) ? 1.0 : 0.0);
-        const double db = (b == 0) ? -1.0 : ((b - 1 == t) ? 1.0 : 0.0);
-        dN[TDIM + 1 + e][t] = 4.0 * (lam[a] * db + da * lam[b]);
-      }
-    }
-  }
-}
-
-__device__ __forceinline__ const double* ref_rule(int dim, int degree, int& n, const double*& w)
-{
-  if (dim == 1)
-  {
-    n = cfx_quad_offset_1d[degree + 1] - cfx_quad_offset_1d[degree];
-    w = cfx_quad_weights_1d + cfx_quad_offset_1d[degree];
-    return cfx_quad_points_1d + cfx_quad_offset_1d[degree];
-  }
-  if (dim == 2)
-  {
-    n = cfx_quad_offset_2d[degree + 1] - cfx_quad_offset_2d[degree];
-    w = cfx_quad_weights_2d + cfx_quad_offset_2d[degree];
-    return cfx_quad_points_2d + 2 * cfx_quad_offset_2d[degree];
-  }
-  n = cfx_quad_offset_3d[degree + 1] - cfx_quad_offset_3d[degree];
-  w = cfx_quad_weights_3d + cfx_quad_offset_3d[degree];
-  return cfx_quad_points_3d + 3 * cfx_quad_offset_3d[degree];
-}
-
-template <int GDIM>
-__device__ __forceinline__ double field_eval(int id, const double* x)
-{
-  if (id == CFX_F_ONE) return 1.0;
-  double p = 1.0;
-#pragma unroll
-  for (int d = 0; d < GDIM; ++d) p *= sin(kPi * x[d]);
-  if (id == CFX_F_SINPROD) return p;
-  return (double)GDIM * kPi * kPi * p;
-}
 
 // arguments shared by the assembly kernels
 struct AsmArgs
@@ -137,18 +44,6 @@ struct AsmArgs
   double* dump;   // if set: write the local tensor here instead of scattering
   int* error;
 };
-
-// position of column `col` in CSR row [b,e); -1 if absent
-__device__ __forceinline__ int64_t csr_find(const int32_t* __restrict__ indices, int64_t b, int64_t e, int32_t col)
-{
-  int64_t lo = b, hi = e;
-  while (lo < hi)
-  {
-    const int64_t mid = (lo + hi) >> 1;
-    if (indices[mid] < col) lo = mid + 1; else hi = mid;
-  }
-  return (lo < e && indices[lo] == col) ? lo : -1;
-}
 
 // ---------------------------------------------------------------------------
 // a5/a6/a8 cell integrals.  One thread per (entity, local row): the thread
@@ -198,127 +93,7 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
 #pragma unroll
   for (int j = 0; j < (RANK == 2 ? NLOC : 1); ++j) acc[j] = 0.0;
 
-  for (int q = 0; q < npts; ++q)
-  {
-    double X[TDIM];
-#pragma unroll
-    for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
-    const double w = wts[q] * wscale;
-    double N[ND], dN[ND][TDIM], G[ND][TDIM];
-    tabulate<TDIM, DEG>(X, N, dN);
-#pragma unroll
-    for (int j = 0; j < ND; ++j)
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d)
-      {
-        double v = 0.0;
-#pragma unroll
-        for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
-        G[j][d] = v;
-      }
-    // row basis function (static indexing through a select chain)
-    double Ni = 0.0, Gi[TDIM];
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d) Gi[d] = 0.0;
-#pragma unroll
-    for (int j = 0; j < ND; ++j)
-      if (j == ia)
-      {
-        Ni = N[j];
-#pragma unroll
-        for (int d = 0; d < TDIM; ++d) Gi[d] = G[j][d];
-      }
-
-    if constexpr (RANK == 2)
-    {
-      switch (A.kernel)
-      {
-      case CFX_K_MASS:
-#pragma unroll
-        for (int j = 0; j < ND; ++j) acc[j * BS + ik] += w * Ni * N[j];
-        break;
-      case CFX_K_STIFFNESS:
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-        {
-          double s = 0.0;
-#pragma unroll
-          for (int d = 0; d < TDIM; ++d) s += Gi[d] * G[j][d];
-          acc[j * BS + ik] += w * s;
-        }
-        break;
-      case CFX_K_NITSCHE:
-        if constexpr (BS == 1)
-        {
-          const double* nrm = pdata + (int64_t)q * A.point_stride;
-          const double gam = A.params[0] / h;
-          double dni = 0.0;
-#pragma unroll
-          for (int d = 0; d < TDIM; ++d) dni += Gi[d] * nrm[d];
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            double dnj = 0.0;
-#pragma unroll
-            for (int d = 0; d < TDIM; ++d) dnj += G[j][d] * nrm[d];
-            acc[j] += w * (-dnj * Ni - dni * N[j] + gam * N[j] * Ni);
-          }
-        }
-        break;
-      case CFX_K_ELASTICITY:
-        if constexpr (BS == TDIM)
-        {
-          const double E = A.params[0], nu = A.params[1];
-          const double mu = E / (2.0 * (1.0 + nu));
-          const double lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
-          double Gia = 0.0;
-#pragma unroll
-          for (int d = 0; d < TDIM; ++d) Gia = (d == ik) ? Gi[d] : Gia;
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            double gg = 0.0, Gja = 0.0;
-#pragma unroll
-            for (int d = 0; d < TDIM; ++d) { gg += Gi[d] * G[j][d]; Gja = (d == ik) ? G[j][d] : Gja; }
-#pragma unroll
-            for (int b = 0; b < BS; ++b)
-              acc[j * BS + b] += w * (mu * ((b == ik ? gg : 0.0) + Gi[b] * Gja) + lmbda * Gia * G[j][b]);
-          }
-        }
-        break;
-      default: break;
-      }
-    }
-    else
-    {
-      double xq[TDIM], l0 = 1.0;
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t) l0 -= X[t];
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d)
-      {
-        double v = l0 * g.x[0][d];
-#pragma unroll
-        for (int t = 0; t < TDIM; ++t) v += X[t] * g.x[t + 1][d];
-        xq[d] = v;
-      }
-      if (A.kernel == CFX_L_SOURCE)
-      {
-        const double f = A.params[1] * field_eval<TDIM>((int)A.params[0], xq);
-        acc[0] += w * f * Ni;
-      }
-      else if (A.kernel == CFX_L_NITSCHE_RHS)
-      {
-        const double* nrm = pdata + (int64_t)q * A.point_stride;
-        const double gam = A.params[0] / h;
-        const double gv = A.params[2] * field_eval<TDIM>((int)A.params[1], xq);
-        double dni = 0.0;
-#pragma unroll
-        for (int d = 0; d < TDIM; ++d) dni += Gi[d] * nrm[d];
-        acc[0] += w * (-dni * gv + gam * gv * Ni);
-      }
-    }
-  }
+  cell_local_row<TDIM, DEG, BS, RANK>(A.kernel, A.params, A.point_stride, g, h, npts, pts, wts, wscale, pdata, ia, ik, acc);
 
   if (A.dump)
   {
@@ -386,124 +161,10 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   load_cell<TDIM>(A.x, A.conn, c1, g1);
   jacobian<TDIM>(g0);
   jacobian<TDIM>(g1);
-  const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
-
-  // outward unit normal of cell0 on facet lf0: -grad(lambda_lf0)/|.|
-  double nrm[TDIM];
-  {
-    double nn = 0.0;
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d)
-    {
-      double v = 0.0;
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t)
-      {
-        const double dl = (lf0 == 0) ? -1.0 : ((lf0 - 1 == t) ? 1.0 : 0.0);
-        v -= g0.K[t][d] * dl;
-      }
-      nrm[d] = v;
-      nn += v * v;
-    }
-    nn = sqrt(nn);
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d) nrm[d] /= nn;
-  }
-  // facet vertices (cell0 vertices except lf0, ascending local index)
-  double xf[TDIM][TDIM];
-  {
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i <= TDIM; ++i)
-    {
-      if (i == lf0) continue;
-#pragma unroll
-      for (int j = 0; j < TDIM; ++j)
-        if (j == k)
-        {
-#pragma unroll
-          for (int d = 0; d < TDIM; ++d) xf[j][d] = g0.x[i][d];
-        }
-      ++k;
-    }
-  }
-  double scale;
-  if constexpr (TDIM == 2)
-  {
-    const double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
-    scale = sqrt(dx * dx + dy * dy);
-  }
-  else
-  {
-    double a[3], b[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
-    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
-    scale = sqrt(cx * cx + cy * cy + cz * cz);
-  }
-
   double acc[NLOC];
 #pragma unroll
   for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
-
-  int nref;
-  const double* wref;
-  const double* pref = ref_rule(TDIM - 1, A.qdegree, nref, wref);
-  for (int q = 0; q < nref; ++q)
-  {
-    double l0 = 1.0, xq[TDIM];
-#pragma unroll
-    for (int t = 0; t < TDIM - 1; ++t) l0 -= pref[q * (TDIM - 1) + t];
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d)
-    {
-      double v = l0 * xf[0][d];
-#pragma unroll
-      for (int t = 0; t < TDIM - 1; ++t) v += pref[q * (TDIM - 1) + t] * xf[t + 1][d];
-      xq[d] = v;
-    }
-    double X0[TDIM], X1[TDIM];
-#pragma unroll
-    for (int t = 0; t < TDIM; ++t)
-    {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d)
-      {
-        a += g0.K[t][d] * (xq[d] - g0.x[0][d]);
-        b += g1.K[t][d] * (xq[d] - g1.x[0][d]);
-      }
-      X0[t] = a; X1[t] = b;
-    }
-    double N0[ND], dN0[ND][TDIM], N1[ND], dN1[ND][TDIM];
-    tabulate<TDIM, DEG>(X0, N0, dN0);
-    tabulate<TDIM, DEG>(X1, N1, dN1);
-    const double w = wref[q] * scale * A.params[0] * havg;
-    // normal-derivative jump of every macro basis function
-    double jn[2 * ND];
-#pragma unroll
-    for (int j = 0; j < ND; ++j)
-    {
-      double a = 0.0, b = 0.0;
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d)
-#pragma unroll
-        for (int t = 0; t < TDIM; ++t)
-        {
-          a += g0.K[t][d] * dN0[j][t] * nrm[d];
-          b += g1.K[t][d] * dN1[j][t] * nrm[d];
-        }
-      jn[j] = a; jn[ND + j] = -b;
-    }
-    double ji = 0.0;
-#pragma unroll
-    for (int j = 0; j < 2 * ND; ++j) ji = (j == ia) ? jn[j] : ji;
-    if (A.kernel == CFX_K_GHOST_GRADJUMP)
-    {
-#pragma unroll
-      for (int j = 0; j < 2 * ND; ++j) acc[j * BS + ik] += w * ji * jn[j];
-    }
-  }
+  facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
 
   if (A.dump)
   {
@@ -605,119 +266,10 @@ void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, 
   }
 }
 
-// ---------------------------------------------------------------------------
-// a9 sparsity, row-centric.  A cell integral contributes, to row r, the dofs of
-// every marked cell incident to r (static dof->cells incidence of the space);
-// a facet integral contributes the dofs of both cells of every incident facet
-// (dof->facets incidence rebuilt per pattern, the facet band is O(N^2)).
-// Every row also holds its diagonal (assembler.h:538-560).
-// Each thread keeps its row as a sorted list in LDS; two passes (count, fill).
-// ---------------------------------------------------------------------------
 __global__ void mark_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride, uint8_t* mark)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) mark[cells[i * stride]] = 1;
-}
-
-__global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                       int nd, int32_t* counts)
-{
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * 2 * nd) return;
-  const int64_t f = i / (2 * nd);
-  const int k = (int)(i - f * 2 * nd);
-  const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
-  atomicAdd(&counts[dofmap[c * nd + (k < nd ? k : k - nd)]], 1);
-}
-
-__global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                      int nd, const int64_t* __restrict__ offs, int32_t* cursor, int32_t* facets)
-{
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * 2 * nd) return;
-  const int64_t f = i / (2 * nd);
-  const int k = (int)(i - f * 2 * nd);
-  const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
-  const int32_t dof = dofmap[c * nd + (k < nd ? k : k - nd)];
-  facets[offs[dof] + atomicAdd(&cursor[dof], 1)] = (int32_t)f;
-}
-
-template <int CAP>
-__device__ __forceinline__ bool list_insert(int32_t* list, int& len, int32_t v)
-{
-  int lo = 0, hi = len;
-  while (lo < hi)
-  {
-    const int mid = (lo + hi) >> 1;
-    if (list[mid] < v) lo = mid + 1; else hi = mid;
-  }
-  if (lo < len && list[lo] == v) return true;
-  if (len >= CAP) return false;
-  for (int k = len; k > lo; --k) list[k] = list[k - 1];
-  list[lo] = v;
-  ++len;
-  return true;
-}
-
-struct SparsityArgs
-{
-  int64_t ndofs;
-  int nd, bs;
-  const int32_t* dofmap;
-  const int64_t* d2c_off;
-  const int32_t* d2c;
-  const uint8_t* cellmark; // or null
-  int64_t nfacets;
-  const int32_t* facet_rows;
-  const int64_t* d2f_off;  // or null
-  const int32_t* d2f;
-  int32_t* counts;         // pass 0: [ndofs*bs] expanded row lengths
-  const int64_t* indptr;   // pass 1
-  int32_t* indices;
-  int* overflow;
-};
-
-template <int THREADS, int CAP, bool FILL>
-__global__ void __launch_bounds__(THREADS) sparsity_rows_kernel(SparsityArgs S)
-{
-  __shared__ int32_t s_list[THREADS][CAP + 1];
-  const int64_t r = (int64_t)blockIdx.x * THREADS + threadIdx.x;
-  if (r >= S.ndofs) return;
-  int32_t* list = s_list[threadIdx.x];
-  int len = 1;
-  list[0] = (int32_t)r; // diagonal of every row
-  bool ok = true;
-  if (S.cellmark)
-    for (int64_t k = S.d2c_off[r]; k < S.d2c_off[r + 1]; ++k)
-    {
-      const int64_t c = S.d2c[k];
-      if (!S.cellmark[c]) continue;
-      for (int j = 0; j < S.nd; ++j) ok = list_insert<CAP>(list, len, S.dofmap[c * S.nd + j]) && ok;
-    }
-  if (S.d2f_off)
-    for (int64_t k = S.d2f_off[r]; k < S.d2f_off[r + 1]; ++k)
-    {
-      const int64_t f = S.d2f[k];
-      for (int s = 0; s < 2; ++s)
-      {
-        const int64_t c = S.facet_rows[4 * f + 2 * s];
-        for (int j = 0; j < S.nd; ++j) ok = list_insert<CAP>(list, len, S.dofmap[c * S.nd + j]) && ok;
-      }
-    }
-  if (!ok) { *S.overflow = 1; return; }
-  if constexpr (!FILL)
-  {
-    for (int a = 0; a < S.bs; ++a) S.counts[r * S.bs + a] = len * S.bs;
-  }
-  else
-  {
-    for (int a = 0; a < S.bs; ++a)
-    {
-      int64_t o = S.indptr[r * S.bs + a];
-      for (int k = 0; k < len; ++k)
-        for (int b = 0; b < S.bs; ++b) S.indices[o++] = list[k] * S.bs + b;
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -731,6 +283,13 @@ __global__ void mark_dofs_kernel(int64_t ncells_active, const int32_t* __restric
   const int64_t c = cells[i / nd];
   const int32_t dof = dofmap[c * nd + (int)(i % nd)];
   for (int k = 0; k < bs; ++k) indicator[(int64_t)dof * bs + k] = 1;
+}
+
+// CFX_ASSEMBLY=atomic selects the entity-parallel FP64-atomic kernels (tests cover both paths)
+bool force_atomic()
+{
+  const char* e = getenv("CFX_ASSEMBLY");
+  return e && strcmp(e, "atomic") == 0;
 }
 
 struct FlagSet
@@ -887,73 +446,8 @@ int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out)
   require(a && out, CFX_ERR_INVALID_ARGUMENT, "cfx_create_sparsity: null argument");
   // assembler.h:570-574
   require(a->rank == 2, CFX_ERR_RUNTIME, "Cannot create sparsity pattern. Form is not a bilinear.");
-  cfx_space_s* V = a->V;
-  const int nd = V->ndofs_cell;
-  SparsityArgs S{};
-  S.ndofs = V->ndofs; S.nd = nd; S.bs = V->bs; S.dofmap = V->dofmap.p;
-
-  DevArray<uint8_t> mark;
-  bool any_cells = false;
-  collect_cell_marks(a, false, mark, any_cells);
-  if (any_cells)
-  {
-    const Adjacency& adj = V->dof_cells();
-    S.d2c_off = adj.offsets.p; S.d2c = adj.cells.p; S.cellmark = mark.p;
-  }
-  // concatenate the facet rows of all interior-facet integrals
-  int64_t nf = 0;
-  for (const auto& I : a->integrals)
-    if (I.type == CFX_INTERIOR_FACET) nf += I.n_entities;
-  DevArray<int32_t> frows, fcount, d2f;
-  DevArray<int64_t> d2f_off;
-  if (nf > 0)
-  {
-    frows.alloc(nf * 4);
-    int64_t o = 0;
-    for (const auto& I : a->integrals)
-      if (I.type == CFX_INTERIOR_FACET && I.n_entities > 0)
-      {
-        CFX_HIP(hipMemcpyAsync(frows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)I.n_entities,
-                               hipMemcpyDeviceToDevice, ctx().stream));
-        o += I.n_entities;
-      }
-    fcount.alloc(V->ndofs);
-    fcount.zero();
-    launch("facet_dof_count", facet_dof_count_kernel, grid_for(nf * 2 * nd), dim3(kBlock), 0, nf, frows.p,
-           V->dofmap.p, nd, fcount.p);
-    d2f_off.alloc(V->ndofs + 1);
-    exclusive_scan(fcount.p, d2f_off.p, V->ndofs);
-    d2f.alloc(nf * 2 * nd);
-    fcount.zero();
-    launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(nf * 2 * nd), dim3(kBlock), 0, nf, frows.p, V->dofmap.p,
-           nd, d2f_off.p, fcount.p, d2f.p);
-    S.nfacets = nf; S.facet_rows = frows.p; S.d2f_off = d2f_off.p; S.d2f = d2f.p;
-  }
-
   auto P = std::make_unique<cfx_pattern_s>();
-  P->nrows = V->ndofs * V->bs;
-  DevArray<int32_t> counts(P->nrows);
-  DevArray<int> overflow(1);
-  overflow.zero();
-  S.counts = counts.p; S.overflow = overflow.p;
-  bool big = false;
-  launch("sparsity_count", sparsity_rows_kernel<128, 96, false>, grid_for(V->ndofs, 128), dim3(128), 0, S);
-  if (read_scalar(overflow.p))
-  {
-    big = true;
-    overflow.zero();
-    launch("sparsity_count_big", sparsity_rows_kernel<64, 480, false>, grid_for(V->ndofs, 64), dim3(64), 0, S);
-    require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 480 dofs");
-  }
-  P->indptr.alloc(P->nrows + 1);
-  exclusive_scan(counts.p, P->indptr.p, P->nrows);
-  P->nnz = read_scalar(P->indptr.p + P->nrows);
-  P->indices.alloc(P->nnz);
-  S.indptr = P->indptr.p; S.indices = P->indices.p;
-  if (!big)
-    launch("sparsity_fill", sparsity_rows_kernel<128, 96, true>, grid_for(V->ndofs, 128), dim3(128), 0, S);
-  else
-    launch("sparsity_fill_big", sparsity_rows_kernel<64, 480, true>, grid_for(V->ndofs, 64), dim3(64), 0, S);
+  build_pattern(a, P.get());
   CFX_HIP(hipStreamSynchronize(ctx().stream));
   *out = P.release();
   CFX_API_END
@@ -989,6 +483,9 @@ int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const 
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.bc0 = bc0 ? dbc0.p : nullptr; A.bc1 = bc1 ? dbc1.p : nullptr;
   A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = out.dev; A.dump = nullptr; A.error = err.p;
+  // row-gather path (deterministic, no global atomics) when the form allows it;
+  // otherwise the entity-parallel kernels with FP64 atomics
+  if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev)) { out.finish(); return CFX_OK; }
   for (const auto& I : a->integrals) launch_integral(a, I, A);
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   out.finish();
@@ -1007,7 +504,8 @@ int cfx_assemble_vector(cfx_form_t L, double* b)
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.values = out.dev; A.error = err.p;
-  for (const auto& I : L->integrals) launch_integral(L, I, A);
+  if (force_atomic() || !assemble_vector_rows(L, out.dev))
+    for (const auto& I : L->integrals) launch_integral(L, I, A);
   out.finish();
   if (out.dev == b) { /* device output: leave the stream running */ }
   CFX_API_END

@@ -100,7 +100,7 @@ __device__ __forceinline__ double field_eval(int id, const double* x)
   if (id == CFX_F_ONE) return 1.0;
   double p = 1.0;
 #pragma unroll
-  for (int d = 0; d < GDIM; ++d) p *= sin(kPi * x[d]);
+  for (int d = 0; d < GDIM; ++d) p *= sinpi(x[d]); // sin(pi x) without the range reduction by pi
   if (id == CFX_F_SINPROD) return p;
   return (double)GDIM * kPi * kPi * p;
 }

@@ -197,7 +197,8 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 }
 
 template <int TDIM, int DEG, int BS>
-void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule)
+void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule,
+                       int parts)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   const bool single = only_index >= 0;
@@ -209,7 +210,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
     return;
   }
-  if (!single || !use_rule)
+  if ((parts & 1) && (!single || !use_rule))
   {
     A.n = single ? 1 : I.n_entities;
     A.entities = I.entities.p + (single ? only_index : 0);
@@ -223,7 +224,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
                dim3(kBlock), 0, A);
     }
   }
-  if (I.rules && (!single || use_rule))
+  if ((parts & 2) && I.rules && (!single || use_rule))
   {
     const cfx_rules_s* R = I.rules;
     A.n = single ? 1 : R->nr;
@@ -245,7 +246,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
 }
 
 void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index = -1,
-                     int use_rule = 0)
+                     int use_rule = 0, int parts = 3)
 {
   const cfx_space_s* V = a->V;
   const int tdim = V->mesh->tdim;
@@ -254,14 +255,14 @@ void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, 
   const int key = tdim * 100 + V->degree * 10 + V->bs;
   switch (key)
   {
-  case 211: launch_integral_t<2, 1, 1>(a, I, A, only_index, use_rule); break;
-  case 221: launch_integral_t<2, 2, 1>(a, I, A, only_index, use_rule); break;
-  case 212: launch_integral_t<2, 1, 2>(a, I, A, only_index, use_rule); break;
-  case 222: launch_integral_t<2, 2, 2>(a, I, A, only_index, use_rule); break;
-  case 311: launch_integral_t<3, 1, 1>(a, I, A, only_index, use_rule); break;
-  case 321: launch_integral_t<3, 2, 1>(a, I, A, only_index, use_rule); break;
-  case 313: launch_integral_t<3, 1, 3>(a, I, A, only_index, use_rule); break;
-  case 323: launch_integral_t<3, 2, 3>(a, I, A, only_index, use_rule); break;
+  case 211: launch_integral_t<2, 1, 1>(a, I, A, only_index, use_rule, parts); break;
+  case 221: launch_integral_t<2, 2, 1>(a, I, A, only_index, use_rule, parts); break;
+  case 212: launch_integral_t<2, 1, 2>(a, I, A, only_index, use_rule, parts); break;
+  case 222: launch_integral_t<2, 2, 2>(a, I, A, only_index, use_rule, parts); break;
+  case 311: launch_integral_t<3, 1, 1>(a, I, A, only_index, use_rule, parts); break;
+  case 321: launch_integral_t<3, 2, 1>(a, I, A, only_index, use_rule, parts); break;
+  case 313: launch_integral_t<3, 1, 3>(a, I, A, only_index, use_rule, parts); break;
+  case 323: launch_integral_t<3, 2, 3>(a, I, A, only_index, use_rule, parts); break;
   default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported (tdim, degree, block size) combination");
   }
 }
@@ -353,6 +354,22 @@ void collect_cell_marks(const cfx_form_s* a, bool include_facets, DevArray<uint8
 }
 
 } // namespace
+
+namespace cfx
+{
+// local tensors of all standard (parts=1) or runtime (parts=2) entities of one
+// integral, written entity-major to `out` (used by the row-gather assembly)
+void dump_integral(cfx_form_s* a, int integral, int parts, double* out)
+{
+  cfx_space_s* V = a->V;
+  DevArray<int> err(1);
+  err.zero();
+  AsmArgs A{};
+  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
+  A.dump = out; A.error = err.p;
+  launch_integral(a, a->integrals[integral], A, -1, 0, parts);
+}
+} // namespace cfx
 
 extern "C" {
 

@@ -1,0 +1,538 @@
+// cutfemx_amd: row-centric kernels, part 2 -- gather assembly of matrices and
+// vectors without global atomics.
+//
+// Two stages, both uniform in work per lane:
+//  1. "tensor" kernels: the expensive local tensors -- cut cells (runtime rules,
+//     10-40 points each), ghost-penalty facets, and rank-1 source terms (a few
+//     transcendental evaluations per point) -- are formed entity-parallel and
+//     stored entity-major in HBM (one 128 B line per P1 tet tensor).
+//  2. "rows" kernels: a group of G lanes owns one matrix row r.  Its items are
+//     the marked cells incident to r (dof->cells incidence of the space) and the
+//     facets incident to r (dof->facets incidence of the form).  A lane either
+//     computes the item's local row inline (uncut P1 stiffness: one point) or
+//     reads it from the stage-1 tensors, then adds it to the row's CSR slots held
+//     in LDS.  One coalesced `values[row] += ...` per row at the end.
+// This is the reference's cell loop + mat_add (assemble_matrix_impl.h:103-188,
+// :462-606) re-ordered by row.  The LDS reduction is either LDS FP64 atomics
+// (default) or a lane-ordered, bitwise-reproducible sequence
+// (CFX_DETERMINISTIC=1).
+#include <cstdlib>
+
+#include "cfx_elem.h"
+
+using namespace cfx;
+
+namespace cfx
+{
+void dump_integral(cfx_form_s* a, int integral, int parts, double* out); // cfx_fem.hip
+}
+
+namespace
+{
+
+constexpr int kWave = 64;
+
+struct RowIntegral
+{
+  int kernel, qdegree, point_stride;
+  int std_inline;            // uncut entities: compute inline (1) or read std_tensors (0)
+  const int32_t* entities;   // sorted uncut entities (lookup of std_tensors)
+  int64_t n_entities;
+  const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [n_entities][ND] (rank 1)
+  const int32_t* parent_map; // sorted rule parents
+  int64_t nr;
+  const double* rule_tensors; // [nr][ND*ND] or [nr][ND]
+  double params[8];
+};
+
+struct RowArgs
+{
+  const double* x;
+  const int32_t* conn;
+  const int32_t* dofmap;
+  int64_t n_active;
+  const int32_t* active_rows;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint8_t* cellmark;
+  const int64_t* d2f_off;
+  const int32_t* d2f;
+  const int32_t* facet_rows;
+  const double* facet_tensors; // [nfacets][(2ND)^2]
+  int n_cell;
+  RowIntegral cell[4];
+  const int8_t* bc0;
+  const int8_t* bc1;
+  const int64_t* indptr;
+  const int32_t* indices;
+  double* values;
+  int* error;
+};
+
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int32_t v)
+{
+  int64_t lo = 0, hi = n;
+  while (lo < hi)
+  {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < v) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// ---------------------------------------------------------------------------
+// stage 1 for linear forms: all ND entries of be per entity, the source /
+// boundary datum evaluated once per point.  One thread per entity.
+// ---------------------------------------------------------------------------
+struct VecArgs
+{
+  const double* x;
+  const int32_t* conn;
+  int64_t n;
+  const int32_t* entities;   // uncut: cells
+  const int32_t* offsets;    // runtime
+  const int32_t* parent_map;
+  const double* points;
+  const double* weights;
+  const double* point_data;
+  int point_stride, kernel, qdegree;
+  double params[8];
+  double* out; // [n][ND]
+};
+
+template <int TDIM, int DEG, bool RUNTIME>
+__global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= A.n) return;
+  const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
+  Geo<TDIM> g;
+  load_cell<TDIM>(A.x, A.conn, cell, g);
+  jacobian<TDIM>(g);
+  const double h = cell_diameter<TDIM>(g);
+  int npts;
+  const double *pts, *wts, *pdata = nullptr;
+  double wscale = 1.0;
+  if constexpr (RUNTIME)
+  {
+    const int32_t q0 = A.offsets[e], q1 = A.offsets[e + 1];
+    npts = q1 - q0;
+    pts = A.points + (int64_t)q0 * TDIM;
+    wts = A.weights + q0;
+    if (A.point_data) pdata = A.point_data + (int64_t)q0 * A.point_stride;
+  }
+  else
+  {
+    pts = ref_rule(TDIM, A.qdegree, npts, wts);
+    wscale = fabs(g.detJ);
+  }
+  double be[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) be[i] = 0.0;
+  for (int q = 0; q < npts; ++q)
+  {
+    double X[TDIM], xq[TDIM], l0 = 1.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) { X[t] = pts[(int64_t)q * TDIM + t]; l0 -= X[t]; }
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double v = l0 * g.x[0][d];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) v += X[t] * g.x[t + 1][d];
+      xq[d] = v;
+    }
+    const double w = wts[q] * wscale;
+    double N[ND], dN[ND][TDIM];
+    tabulate<TDIM, DEG>(X, N, dN);
+    if (A.kernel == CFX_L_SOURCE)
+    {
+      const double f = w * A.params[1] * field_eval<TDIM>((int)A.params[0], xq);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) be[i] += f * N[i];
+    }
+    else if (A.kernel == CFX_L_NITSCHE_RHS)
+    {
+      const double* nrm = pdata + (int64_t)q * A.point_stride;
+      const double gam = A.params[0] / h;
+      const double gv = A.params[2] * field_eval<TDIM>((int)A.params[1], xq);
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        double dni = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double G = 0.0;
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t) G += g.K[t][d] * dN[i][t];
+          dni += G * nrm[d];
+        }
+        be[i] += w * (-dni * gv + gam * gv * N[i]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < ND; ++i) A.out[e * ND + i] = be[i];
+}
+
+// ---------------------------------------------------------------------------
+// stage 2, bilinear forms
+// ---------------------------------------------------------------------------
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave) assemble_rows_kernel(RowArgs A)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  constexpr int W = 2 * ND; // widest item: a facet's macro row
+  constexpr int RPW = kWave / G;
+  __shared__ int32_t s_col[RPW][CAP];
+  __shared__ double s_val[RPW][CAP];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
+  const bool live = ri < A.n_active;
+  const int64_t r = live ? A.active_rows[ri] : 0;
+  const int64_t rb = live ? A.indptr[r] : 0;
+  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+  for (int k = gl; k < len; k += G)
+  {
+    s_col[grp][k] = A.indices[rb + k];
+    s_val[grp][k] = 0.0;
+  }
+  __syncthreads();
+  const bool cells = live && A.cellmark != nullptr;
+  const int64_t cb = cells ? A.d2c_off[r] : 0;
+  const int nc = cells ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  const bool facets = live && A.d2f_off != nullptr;
+  const int64_t fb = facets ? A.d2f_off[r] : 0;
+  const int nf = facets ? (int)(A.d2f_off[r + 1] - fb) : 0;
+  const int nitems = len > 0 ? nc + nf : 0;
+  const bool row_bc = live && A.bc0 && A.bc0[r];
+
+  for (int base = 0;; base += G)
+  {
+    const int t = base + gl;
+    const bool has = t < nitems;
+    if (__ballot(has) == 0) break;
+    double acc[W];
+    int32_t cols[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { acc[j] = 0.0; cols[j] = -1; }
+    int ncols = 0;
+    if (has)
+    {
+      if (t < nc)
+      {
+        const int64_t c = A.d2c[cb + t];
+        const uint8_t mark = A.cellmark[c];
+        if (mark)
+        {
+          int lr = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            cols[j] = A.dofmap[c * ND + j];
+            lr = (cols[j] == (int32_t)r) ? j : lr;
+          }
+          ncols = ND;
+          for (int i = 0; i < A.n_cell; ++i)
+          {
+            const RowIntegral& I = A.cell[i];
+            if (mark & (1u << i))
+            {
+              if (I.std_inline)
+              {
+                Geo<TDIM> g;
+                load_cell<TDIM>(A.x, A.conn, c, g);
+                jacobian<TDIM>(g);
+                int npts;
+                const double* wts;
+                const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+                cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
+                                                fabs(g.detJ), nullptr, lr, 0, acc);
+              }
+              else
+              {
+                const int64_t e = lower_bound_i32(I.entities, I.n_entities, (int32_t)c);
+                const double* T = I.std_tensors + (e * ND + lr) * ND;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] += T[j];
+              }
+            }
+            if (mark & (16u << i))
+            {
+              // an interface cell may own several consecutive rules (cut.cpp:1286-1294)
+              for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+              {
+                const double* T = I.rule_tensors + (e * ND + lr) * ND;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] += T[j];
+              }
+            }
+          }
+        }
+      }
+      else
+      {
+        const int64_t f = A.d2f[fb + (t - nc)];
+        const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          cols[j] = A.dofmap[(int64_t)row4.x * ND + j];
+          cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
+        }
+        ncols = W;
+        // r may be a dof of both cells: both macro rows land in global row r
+        const double* T = A.facet_tensors + f * (W * W);
+#pragma unroll
+        for (int i = 0; i < W; ++i)
+          if (cols[i] == (int32_t)r)
+          {
+#pragma unroll
+            for (int j = 0; j < W; ++j) acc[j] += T[i * W + j];
+          }
+      }
+    }
+    // CSR slot of every column of the item
+    int sl[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j)
+    {
+      sl[j] = -1;
+      if (j < ncols)
+      {
+        int lo = 0, hi = len;
+        while (lo < hi)
+        {
+          const int mid = (lo + hi) >> 1;
+          if (s_col[grp][mid] < cols[j]) lo = mid + 1; else hi = mid;
+        }
+        if (lo < len && s_col[grp][lo] == cols[j]) sl[j] = lo; else *A.error = 1;
+        // zero BC rows / columns: assemble_matrix_impl.h:151-185
+        if (row_bc || (A.bc1 && A.bc1[cols[j]])) acc[j] = 0.0;
+      }
+    }
+    if constexpr (ORDERED)
+    {
+      // item order: one lane of each group at a time
+      volatile double* val = s_val[grp];
+      for (int turn = 0; turn < G; ++turn)
+      {
+        if (__ballot(has && gl == turn) == 0) continue;
+        if (has && gl == turn)
+        {
+#pragma unroll
+          for (int j = 0; j < W; ++j)
+            if (sl[j] >= 0) val[sl[j]] += acc[j];
+        }
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
+    }
+  }
+  __syncthreads();
+  for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k];
+}
+
+// stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
+template <int TDIM, int DEG, int G>
+__global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  constexpr int RPW = kWave / G;
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
+  const bool live = ri < A.n_active && A.cellmark != nullptr;
+  const int64_t r = live ? A.active_rows[ri] : 0;
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  double part = 0.0; // items gl, gl+G, ... in ascending order
+  for (int t = gl; t < nc; t += G)
+  {
+    const int64_t c = A.d2c[cb + t];
+    const uint8_t mark = A.cellmark[c];
+    if (!mark) continue;
+    int lr = 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) lr = (A.dofmap[c * ND + j] == (int32_t)r) ? j : lr;
+    for (int i = 0; i < A.n_cell; ++i)
+    {
+      const RowIntegral& I = A.cell[i];
+      if (mark & (1u << i))
+        part += I.std_tensors[lower_bound_i32(I.entities, I.n_entities, (int32_t)c) * ND + lr];
+      if (mark & (16u << i))
+        for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+          part += I.rule_tensors[e * ND + lr];
+    }
+  }
+  // fixed-shape tree over the group's lanes: bitwise reproducible
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1) part += __shfl_xor(part, d, G);
+  if (live && gl == 0) A.values[r] += part;
+}
+
+bool deterministic()
+{
+  const char* e = getenv("CFX_DETERMINISTIC");
+  return e && e[0] == '1';
+}
+
+struct Stage1
+{
+  std::vector<DevArray<double>> buffers;
+};
+
+template <int TDIM, int DEG>
+void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out)
+{
+  cfx_space_s* V = L->V;
+  VecArgs A{};
+  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p;
+  A.kernel = I.kernel; A.qdegree = I.qdegree; A.point_stride = I.point_stride;
+  for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
+  A.out = out;
+  if (!runtime)
+  {
+    A.n = I.n_entities; A.entities = I.entities.p;
+    launch("vec_tensors_std", vec_tensors_kernel<TDIM, DEG, false>, grid_for(A.n), dim3(kBlock), 0, A);
+  }
+  else
+  {
+    const cfx_rules_s* R = I.rules;
+    A.n = R->nr; A.offsets = R->offsets.p; A.parent_map = R->parent_map.p; A.points = R->points.p;
+    A.weights = R->weights.p; A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
+    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true>, grid_for(A.n), dim3(kBlock), 0, A);
+  }
+}
+
+// stage 1 + RowArgs for a form
+template <int TDIM, int DEG>
+RowArgs prepare(cfx_form_s* a, Stage1& st)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  cfx_row_plan& plan = row_plan(a);
+  cfx_space_s* V = a->V;
+  RowArgs A{};
+  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
+  A.n_active = plan.n_active_rows; A.active_rows = plan.active_rows.p;
+  if (plan.any_cells)
+  {
+    const Adjacency& adj = V->dof_cells();
+    A.d2c_off = adj.offsets.p; A.d2c = adj.cells.p; A.cellmark = plan.cellmark.p;
+  }
+  const int64_t tsize = a->rank == 2 ? ND * ND : ND;
+  A.n_cell = plan.n_cell_slots;
+  for (int s = 0; s < plan.n_cell_slots; ++s)
+  {
+    const int ii = plan.cell_slot_integral[s];
+    const cfx_integral_dev& I = a->integrals[ii];
+    RowIntegral& R = A.cell[s];
+    R.kernel = I.kernel; R.qdegree = I.qdegree; R.point_stride = I.point_stride;
+    for (int k = 0; k < 8; ++k) R.params[k] = I.params[k];
+    R.entities = I.entities.p; R.n_entities = I.n_entities;
+    // uncut P1 stiffness is one point: cheaper to recompute than to stage
+    R.std_inline = (a->rank == 2 && I.kernel == CFX_K_STIFFNESS && DEG == 1) ? 1 : 0;
+    if (!R.std_inline && I.n_entities > 0)
+    {
+      st.buffers.emplace_back(I.n_entities * tsize);
+      R.std_tensors = st.buffers.back().p;
+      if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
+      else vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p);
+    }
+    if (I.rules && I.rules->nr > 0)
+    {
+      R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
+      st.buffers.emplace_back(I.rules->nr * tsize);
+      R.rule_tensors = st.buffers.back().p;
+      if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
+      else vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
+    }
+  }
+  if (plan.nfacets > 0)
+  {
+    A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
+    st.buffers.emplace_back(plan.nfacets * (int64_t)(4 * ND * ND));
+    A.facet_tensors = st.buffers.back().p;
+    int64_t o = 0;
+    for (int s = 0; s < plan.n_facet_slots; ++s)
+    {
+      const int ii = plan.facet_slot_integral[s];
+      dump_integral(a, ii, 1, st.buffers.back().p + o * (4 * ND * ND));
+      o += a->integrals[ii].n_entities;
+    }
+  }
+  return A;
+}
+
+template <int TDIM, int DEG>
+int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+{
+  Stage1 st;
+  RowArgs A = prepare<TDIM, DEG>(a, st);
+  A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
+  DevArray<int> err(1);
+  err.zero();
+  A.error = err.p;
+  if (A.n_active > 0)
+  {
+    const bool det = deterministic();
+    if (P->max_row_len < 64)
+    {
+      const dim3 grid((unsigned)((A.n_active + 7) / 8));
+      if (det) launch("assemble_rows", assemble_rows_kernel<TDIM, DEG, 8, 64, true>, grid, dim3(kWave), 0, A);
+      else launch("assemble_rows", assemble_rows_kernel<TDIM, DEG, 8, 64, false>, grid, dim3(kWave), 0, A);
+    }
+    else
+    {
+      const dim3 grid((unsigned)A.n_active);
+      if (det) launch("assemble_rows_wide", assemble_rows_kernel<TDIM, DEG, 64, 512, true>, grid, dim3(kWave), 0, A);
+      else launch("assemble_rows_wide", assemble_rows_kernel<TDIM, DEG, 64, 512, false>, grid, dim3(kWave), 0, A);
+    }
+  }
+  return read_scalar(err.p);
+}
+
+template <int TDIM, int DEG>
+void run_vector(cfx_form_s* L, double* b)
+{
+  Stage1 st;
+  RowArgs A = prepare<TDIM, DEG>(L, st);
+  A.values = b;
+  if (A.n_active > 0)
+    launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 8>, dim3((unsigned)((A.n_active + 7) / 8)),
+           dim3(kWave), 0, A);
+}
+
+} // namespace
+
+namespace cfx
+{
+
+bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+{
+  cfx_row_plan& plan = row_plan(a);
+  cfx_space_s* V = a->V;
+  if (!plan.usable || V->degree != 1 || V->bs != 1 || P->max_row_len >= 512) return false;
+  const int err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values)
+                                     : run_matrix<3, 1>(a, P, bc0, bc1, values);
+  require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
+  require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
+  return true;
+}
+
+bool assemble_vector_rows(cfx_form_s* L, double* b)
+{
+  cfx_row_plan& plan = row_plan(L);
+  cfx_space_s* V = L->V;
+  if (!plan.usable || V->degree != 1 || V->bs != 1 || plan.nfacets > 0) return false;
+  if (V->mesh->tdim == 2) run_vector<2, 1>(L, b); else run_vector<3, 1>(L, b);
+  return true;
+}
+
+} // namespace cfx

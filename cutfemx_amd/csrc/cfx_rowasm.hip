@@ -1,5 +1,5 @@
-// cutfemx_amd: row-centric kernels -- the form's row plan, CSR sparsity and the
-// atomic-free, bitwise-reproducible gather assembly.
+// cutfemx_amd: row-centric kernels, part 1 -- the form's row plan and the CSR
+// sparsity (the gather assembly that uses them is in cfx_gather.hip).
 //
 // Decomposition: a group of G lanes owns one matrix row (one dof r).  The
 // "items" of the row are the marked cells incident to r (static dof->cells
@@ -40,10 +40,11 @@ __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict
   rowmark[dofmap[c * nd + (int)(i % nd)]] = 1;
 }
 
-__global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ a, int* flag)
+// flags a list that is not ascending (strict: not strictly ascending)
+__global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ a, int strict, int* flag)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 < n && a[i] > a[i + 1]) *flag = 1;
+  if (i + 1 < n && (a[i] > a[i + 1] || (strict && a[i] == a[i + 1]))) *flag = 1;
 }
 
 __global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
@@ -83,11 +84,13 @@ __global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ ro
   facets[offs[dof] + atomicAdd(&cursor[dof], 1)] = (int32_t)f;
 }
 
-// sort each dof's facet list so the gather order is reproducible
-__global__ void seg_sort_kernel(int64_t nitems, const int64_t* __restrict__ offsets, int32_t* vals)
+// sort each listed dof's facet list so the gather order is reproducible
+__global__ void seg_sort_kernel(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ offsets,
+                                int32_t* vals)
 {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= nitems) return;
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i0 >= nrows) return;
+  const int64_t it = rows[i0];
   const int64_t b = offsets[it], e = offsets[it + 1];
   for (int64_t i = b + 1; i < e; ++i)
   {
@@ -237,295 +240,6 @@ __global__ void pattern_write_kernel(int64_t n_active, const int32_t* __restrict
     for (int b = 0; b < bs; ++b) indices[indptr[r * bs + a] + (int64_t)k * bs + b] = col * bs + b;
 }
 
-// ---------------------------------------------------------------------------
-// gather assembly
-// ---------------------------------------------------------------------------
-struct RowIntegral
-{
-  int kernel, qdegree, point_stride, has_rules;
-  const int32_t* offsets;
-  const int32_t* parent_map;
-  int64_t nr;
-  const double* points;
-  const double* weights;
-  const double* point_data;
-  double params[8];
-};
-
-struct RowArgs
-{
-  const double* x;
-  const int32_t* conn;
-  const int32_t* dofmap;
-  int64_t n_active;
-  const int32_t* active_rows;
-  const int64_t* d2c_off;
-  const int32_t* d2c;
-  const uint8_t* cellmark;
-  const int64_t* d2f_off;
-  const int32_t* d2f;
-  const int32_t* facet_rows;
-  const uint8_t* facet_slot;
-  int n_cell, n_facet;
-  RowIntegral cell[4];
-  RowIntegral facet[2];
-  const int8_t* bc0;
-  const int8_t* bc1;
-  const int64_t* indptr;
-  const int32_t* indices;
-  double* values;
-  int* error;
-};
-
-__device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int32_t v)
-{
-  int64_t lo = 0, hi = n;
-  while (lo < hi)
-  {
-    const int64_t mid = (lo + hi) >> 1;
-    if (a[mid] < v) lo = mid + 1; else hi = mid;
-  }
-  return lo;
-}
-
-// local row `lr` of every cell integral living on cell c, summed into acc[ND]
-template <int TDIM, int DEG, int RANK>
-__device__ __forceinline__ void cell_item(const RowArgs& A, int64_t c, uint8_t mark, int lr, double* acc)
-{
-  Geo<TDIM> g;
-  load_cell<TDIM>(A.x, A.conn, c, g);
-  jacobian<TDIM>(g);
-  const double h = cell_diameter<TDIM>(g);
-  for (int i = 0; i < A.n_cell; ++i)
-  {
-    const RowIntegral& I = A.cell[i];
-    if (mark & (1u << i))
-    {
-      int npts;
-      const double* wts;
-      const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
-      cell_local_row<TDIM, DEG, 1, RANK>(I.kernel, I.params, I.point_stride, g, h, npts, pts, wts, fabs(g.detJ),
-                                         nullptr, lr, 0, acc);
-    }
-    if (mark & (16u << i))
-    {
-      // rules are sorted by parent (checked when the plan is built); an interface
-      // cell may own several consecutive rules (cut.cpp:1286-1294)
-      for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
-      {
-        const int32_t q0 = I.offsets[e], q1 = I.offsets[e + 1];
-        cell_local_row<TDIM, DEG, 1, RANK>(I.kernel, I.params, I.point_stride, g, h, q1 - q0,
-                                           I.points + (int64_t)q0 * TDIM, I.weights + q0, 1.0,
-                                           I.point_data ? I.point_data + (int64_t)q0 * I.point_stride : nullptr,
-                                           lr, 0, acc);
-      }
-    }
-  }
-}
-
-template <int TDIM, int DEG, int G, int CAP>
-__global__ void __launch_bounds__(kWave) assemble_rows_kernel(RowArgs A)
-{
-  constexpr int ND = Elem<TDIM, DEG>::ND;
-  constexpr int W = 2 * ND; // widest item: a facet's macro row
-  constexpr int RPW = kWave / G;
-  __shared__ int32_t s_col[RPW][CAP];
-  __shared__ double s_val[RPW][CAP];
-  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
-  const bool live = ri < A.n_active;
-  const int64_t r = live ? A.active_rows[ri] : 0;
-  const int64_t rb = live ? A.indptr[r] : 0;
-  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
-  if (len > CAP) { *A.error = 2; len = 0; }
-  for (int k = gl; k < len; k += G)
-  {
-    s_col[grp][k] = A.indices[rb + k];
-    s_val[grp][k] = 0.0;
-  }
-  __syncthreads();
-  const int64_t cb = (live && A.cellmark) ? A.d2c_off[r] : 0;
-  const int nc = (live && A.cellmark) ? (int)(A.d2c_off[r + 1] - cb) : 0;
-  const int64_t fb = (live && A.d2f_off) ? A.d2f_off[r] : 0;
-  const int nf = (live && A.d2f_off) ? (int)(A.d2f_off[r + 1] - fb) : 0;
-  const int nitems = len > 0 ? nc + nf : 0;
-  const bool row_bc = live && A.bc0 && A.bc0[r];
-  volatile double* val = s_val[grp];
-
-  for (int base = 0;; base += G)
-  {
-    const int t = base + gl;
-    const bool has = t < nitems;
-    if (__ballot(has) == 0) break;
-    double acc[W];
-    int sl[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) { acc[j] = 0.0; sl[j] = -1; }
-    int ncols = 0;
-    if (has)
-    {
-      if (t < nc)
-      {
-        const int64_t c = A.d2c[cb + t];
-        const uint8_t mark = A.cellmark[c];
-        if (mark)
-        {
-          int32_t cols[ND];
-          int lr = 0;
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            cols[j] = A.dofmap[c * ND + j];
-            lr = (cols[j] == (int32_t)r) ? j : lr;
-          }
-          cell_item<TDIM, DEG, 2>(A, c, mark, lr, acc);
-          ncols = ND;
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            int lo = 0, hi = len;
-            while (lo < hi)
-            {
-              const int mid = (lo + hi) >> 1;
-              if (s_col[grp][mid] < cols[j]) lo = mid + 1; else hi = mid;
-            }
-            sl[j] = (lo < len && s_col[grp][lo] == cols[j]) ? lo : -2;
-            if (row_bc || (A.bc1 && A.bc1[cols[j]])) acc[j] = 0.0;
-          }
-        }
-      }
-      else
-      {
-        const int64_t f = A.d2f[fb + (t - nc)];
-        const RowIntegral& I = A.facet[A.facet_slot[f]];
-        const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
-        const int64_t c0 = row4.x, c1 = row4.z;
-        Geo<TDIM> g0, g1;
-        load_cell<TDIM>(A.x, A.conn, c0, g0);
-        load_cell<TDIM>(A.x, A.conn, c1, g1);
-        jacobian<TDIM>(g0);
-        jacobian<TDIM>(g1);
-        int32_t cols[W];
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-        {
-          cols[j] = A.dofmap[c0 * ND + j];
-          cols[ND + j] = A.dofmap[c1 * ND + j];
-        }
-        // r may be a dof of both cells: both macro rows land in global row r
-        int ia0 = -1, ia1 = -1;
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-        {
-          ia0 = (cols[j] == (int32_t)r) ? j : ia0;
-          ia1 = (cols[ND + j] == (int32_t)r) ? ND + j : ia1;
-        }
-        if (ia0 >= 0) facet_local_row<TDIM, DEG, 1>(I.kernel, I.params, I.qdegree, g0, g1, row4.y, ia0, 0, acc);
-        if (ia1 >= 0) facet_local_row<TDIM, DEG, 1>(I.kernel, I.params, I.qdegree, g0, g1, row4.y, ia1, 0, acc);
-        ncols = W;
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-        {
-          int lo = 0, hi = len;
-          while (lo < hi)
-          {
-            const int mid = (lo + hi) >> 1;
-            if (s_col[grp][mid] < cols[j]) lo = mid + 1; else hi = mid;
-          }
-          sl[j] = (lo < len && s_col[grp][lo] == cols[j]) ? lo : -2;
-          if (row_bc || (A.bc1 && A.bc1[cols[j]])) acc[j] = 0.0;
-        }
-      }
-    }
-    // reduce the round's items into the row in item order: one lane of the group at a time
-    for (int turn = 0; turn < G; ++turn)
-    {
-      if (__ballot(has && gl == turn) == 0) continue;
-      if (has && gl == turn)
-      {
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-          if (j < ncols)
-          {
-            if (sl[j] >= 0) val[sl[j]] += acc[j];
-            else *A.error = 1;
-          }
-      }
-    }
-  }
-  __syncthreads();
-  for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k];
-}
-
-// vector assembly: b[r] += sum over the marked incident cells of be[local row]
-template <int TDIM, int DEG, int G>
-__global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
-{
-  constexpr int ND = Elem<TDIM, DEG>::ND;
-  constexpr int RPW = kWave / G;
-  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
-  const bool live = ri < A.n_active;
-  const int64_t r = live ? A.active_rows[ri] : 0;
-  const int64_t cb = (live && A.cellmark) ? A.d2c_off[r] : 0;
-  const int nc = (live && A.cellmark) ? (int)(A.d2c_off[r + 1] - cb) : 0;
-  double part = 0.0; // items gl, gl+G, ... in ascending order
-  for (int t = gl; t < nc; t += G)
-  {
-    const int64_t c = A.d2c[cb + t];
-    const uint8_t mark = A.cellmark[c];
-    if (!mark) continue;
-    int lr = 0;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) lr = (A.dofmap[c * ND + j] == (int32_t)r) ? j : lr;
-    double acc[1] = {0.0};
-    cell_item<TDIM, DEG, 1>(A, c, mark, lr, acc);
-    part += acc[0];
-  }
-  // fixed-shape tree over the group's lanes
-#pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) part += __shfl_xor(part, d, G);
-  if (live && gl == 0) A.values[r] += part;
-}
-
-RowIntegral make_row_integral(const cfx_integral_dev& I)
-{
-  RowIntegral R{};
-  R.kernel = I.kernel; R.qdegree = I.qdegree; R.point_stride = I.point_stride;
-  R.has_rules = I.rules != nullptr;
-  if (I.rules)
-  {
-    R.offsets = I.rules->offsets.p; R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
-    R.points = I.rules->points.p; R.weights = I.rules->weights.p;
-    R.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-  }
-  for (int k = 0; k < 8; ++k) R.params[k] = I.params[k];
-  return R;
-}
-
-RowArgs make_row_args(cfx_form_s* a)
-{
-  cfx_row_plan& plan = row_plan(a);
-  cfx_space_s* V = a->V;
-  RowArgs A{};
-  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
-  A.n_active = plan.n_active_rows; A.active_rows = plan.active_rows.p;
-  if (plan.any_cells)
-  {
-    const Adjacency& adj = V->dof_cells();
-    A.d2c_off = adj.offsets.p; A.d2c = adj.cells.p; A.cellmark = plan.cellmark.p;
-  }
-  if (plan.nfacets > 0)
-  {
-    A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
-    A.facet_slot = plan.facet_slot.p;
-  }
-  A.n_cell = plan.n_cell_slots; A.n_facet = plan.n_facet_slots;
-  for (int i = 0; i < plan.n_cell_slots; ++i) A.cell[i] = make_row_integral(a->integrals[plan.cell_slot_integral[i]]);
-  for (int i = 0; i < plan.n_facet_slots; ++i) A.facet[i] = make_row_integral(a->integrals[plan.facet_slot_integral[i]]);
-  return A;
-}
-
 } // namespace
 
 namespace cfx
@@ -560,6 +274,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
                I.entities.p, 1, (uint8_t)(1u << slot), P.cellmark.p);
         launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
                I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p);
+        launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+               I.entities.p, 1, flag.p);
         P.any_cells = true;
       }
       if (I.rules && I.rules->nr > 0)
@@ -569,7 +285,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.rules->nr * nd), dim3(kBlock), 0,
                I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p);
         launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
-               I.rules->parent_map.p, flag.p);
+               I.rules->parent_map.p, 0, flag.p);
         P.any_cells = true;
       }
     }
@@ -614,9 +330,11 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   if (P.nfacets > 0)
   {
     // only active rows have facets: sort their (short) lists
-    launch("plan_sort_d2f", seg_sort_kernel, grid_for(V->ndofs), dim3(kBlock), 0, V->ndofs, P.d2f_offsets.p, P.d2f.p);
+    launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_active_rows), dim3(kBlock), 0, P.n_active_rows,
+           P.active_rows.p, P.d2f_offsets.p, P.d2f.p);
   }
-  if (read_scalar(flag.p)) P.usable = false; // unsorted caller-supplied rules: gather path cannot look them up
+  // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
+  if (read_scalar(flag.p)) P.usable = false;
   if (V->bs != 1) P.usable = false;
   P.built = true;
   return P;
@@ -677,54 +395,6 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       launch("pattern_write", pattern_write_kernel<512>, grid_for(plan.n_active_rows * 512), dim3(kBlock), 0,
              plan.n_active_rows, plan.active_rows.p, V->bs, tmp.p, len.p, P->indptr.p, P->indices.p);
   }
-}
-
-template <int TDIM, int DEG>
-static void launch_rows(cfx_form_s* a, RowArgs& A, int* err_host, int max_row_len = 0)
-{
-  DevArray<int> err(1);
-  err.zero();
-  A.error = err.p;
-  if (A.n_active > 0)
-  {
-    if (a->rank == 2 && max_row_len < 64)
-      launch("assemble_rows", assemble_rows_kernel<TDIM, DEG, 16, 64>, dim3((unsigned)((A.n_active + 3) / 4)),
-             dim3(kWave), 0, A);
-    else if (a->rank == 2)
-      launch("assemble_rows_wide", assemble_rows_kernel<TDIM, DEG, 64, 512>, dim3((unsigned)A.n_active), dim3(kWave),
-             0, A);
-    else
-      launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 16>, dim3((unsigned)((A.n_active + 3) / 4)),
-             dim3(kWave), 0, A);
-  }
-  *err_host = a->rank == 2 ? read_scalar(err.p) : 0;
-}
-
-bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
-{
-  cfx_row_plan& plan = row_plan(a);
-  cfx_space_s* V = a->V;
-  if (!plan.usable || V->degree != 1) return false;
-  RowArgs A = make_row_args(a);
-  A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
-  int err = 0;
-  if (P->max_row_len >= 512) return false;
-  if (V->mesh->tdim == 2) launch_rows<2, 1>(a, A, &err, P->max_row_len); else launch_rows<3, 1>(a, A, &err, P->max_row_len);
-  require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
-  require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
-  return true;
-}
-
-bool assemble_vector_rows(cfx_form_s* L, double* b)
-{
-  cfx_row_plan& plan = row_plan(L);
-  cfx_space_s* V = L->V;
-  if (!plan.usable || V->degree != 1 || plan.nfacets > 0) return false;
-  RowArgs A = make_row_args(L);
-  A.values = b;
-  int err = 0;
-  if (V->mesh->tdim == 2) launch_rows<2, 1>(L, A, &err); else launch_rows<3, 1>(L, A, &err);
-  return true;
 }
 
 } // namespace cfx

@@ -328,6 +328,9 @@ struct cfx_row_plan
   cfx::DevArray<int64_t> d2f_offsets; // dof -> facets incidence
   cfx::DevArray<int32_t> d2f;
   int n_cell_slots = 0, n_facet_slots = 0;
+  // per cell slot: bitset of its uncut entities + exclusive popcount ranks (entity index lookup)
+  cfx::DevArray<int64_t> std_bits[4];
+  cfx::DevArray<int32_t> std_rank[4];
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};
 };

@@ -751,7 +751,11 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
   if (it != cut->located.end()) return it->second;
   SelectorPred pred{cut->domain.p, cut->mesh->ncells, parse_selector(selector.c_str(), cut->nls)};
   DevArray<int32_t> out;
-  compact("locate_entities", cut->mesh->ncells, pred, out);
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(cut->domain.p) + (int64_t)pred.sel.ls[0] * cut->mesh->ncells;
+  if (pred.sel.n == 1 && (reinterpret_cast<uintptr_t>(bytes) & 15) == 0)
+    compact_bytes("locate_entities", cut->mesh->ncells, bytes, DomainMask{pred.sel.mask[0]}, out); // 1 B/cell stream
+  else
+    compact("locate_entities", cut->mesh->ncells, pred, out);
   auto res = cut->located.emplace(selector, std::move(out));
   return res.first->second;
 }

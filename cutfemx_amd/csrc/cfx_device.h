@@ -10,6 +10,23 @@ constexpr int kBlock = 256;      // 4 wavefronts
 constexpr int kScanItems = 8;    // items per thread in scan/compaction tiles
 constexpr int kTile = kBlock * kScanItems;
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Row-ordered kernels remap the block id so that every XCD walks one
+// contiguous chunk of the rows and neighbouring rows meet in the same L2.
+// Launch with xcd_grid(); placement only affects speed, never results.
+__device__ __forceinline__ int64_t xcd_block_id()
+{
+  const int64_t per = gridDim.x >> 3; // gridDim.x is a multiple of 8
+  return (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+}
+
+inline dim3 xcd_grid(int64_t nblocks)
+{
+  const int64_t g = (nblocks + 7) / 8 * 8;
+  if (g > 2147483647LL) throw Error(CFX_ERR_RUNTIME, "grid too large");
+  return dim3((unsigned)g);
+}
+
 // inclusive scan over the 64 lanes of a wavefront
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v)
@@ -107,6 +124,92 @@ inline int64_t compact(const char* name, int64_t n, Pred pred, DevArray<int32_t>
 }
 
 // ---------------------------------------------------------------------------
+// compaction of a byte array (classification codes, flags): 16 B per lane per
+// load, so a wave streams 1 KiB per instruction instead of 64 B.
+// ---------------------------------------------------------------------------
+constexpr int kByteItems = 16;
+constexpr int kByteTile = kBlock * kByteItems;
+
+template <typename ByteTest>
+__device__ __forceinline__ unsigned byte_flags(const uint8_t* __restrict__ bytes, int64_t base, int64_t n, ByteTest test)
+{
+  unsigned f = 0;
+  if (base + kByteItems <= n)
+  {
+    const uint4 v = *reinterpret_cast<const uint4*>(bytes + base);
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < kByteItems; ++k) f |= test((uint8_t)(w[k >> 2] >> (8 * (k & 3)))) ? (1u << k) : 0u;
+  }
+  else
+  {
+    for (int k = 0; k < kByteItems; ++k)
+      if (base + k < n && test(bytes[base + k])) f |= 1u << k;
+  }
+  return f;
+}
+
+template <typename ByteTest>
+__global__ void __launch_bounds__(kBlock) compact_bytes_count_kernel(int64_t n, const uint8_t* __restrict__ bytes,
+                                                                     ByteTest test, int32_t* tile_counts)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  const int c = base < n ? __popc(byte_flags(bytes, base, n, test)) : 0;
+  int total;
+  (void)block_exclusive_scan<int>(c, total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+template <typename ByteTest>
+__global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, const uint8_t* __restrict__ bytes,
+                                                                     ByteTest test,
+                                                                     const int64_t* __restrict__ tile_offsets,
+                                                                     int32_t* __restrict__ out)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  const unsigned f = base < n ? byte_flags(bytes, base, n, test) : 0u;
+  int total;
+  const int off = block_exclusive_scan<int>(__popc(f), total);
+  int64_t o = tile_offsets[blockIdx.x] + off;
+#pragma unroll
+  for (int k = 0; k < kByteItems; ++k)
+    if (f & (1u << k)) out[o++] = (int32_t)(base + k);
+}
+
+// `bytes` must be 16-byte aligned
+template <typename ByteTest>
+inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, ByteTest test, DevArray<int32_t>& out)
+{
+  const int64_t ntiles = (n + kByteTile - 1) / kByteTile;
+  if (ntiles == 0) { out.alloc(0); return 0; }
+  DevArray<int32_t> counts(ntiles);
+  DevArray<int64_t> offsets(ntiles + 1);
+  launch(name, compact_bytes_count_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
+         counts.p);
+  exclusive_scan(counts.p, offsets.p, ntiles);
+  const int64_t total = read_scalar(offsets.p + ntiles);
+  out.alloc(total);
+  launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
+         offsets.p, out.p);
+  return total;
+}
+
+struct ByteNonZero
+{
+  __device__ bool operator()(uint8_t v) const { return v != 0; }
+};
+struct ByteZero
+{
+  __device__ bool operator()(uint8_t v) const { return v == 0; }
+};
+// classification code (-1, 0, 1) against a selector mask: bit0 inside, bit1 cut, bit2 outside
+struct DomainMask
+{
+  int mask;
+  __device__ bool operator()(uint8_t v) const { return (mask >> ((int)(int8_t)v + 1)) & 1; }
+};
+
+// ---------------------------------------------------------------------------
 // small geometry helpers (affine simplices, gdim == tdim)
 // ---------------------------------------------------------------------------
 template <int TDIM>
@@ -141,8 +244,9 @@ __device__ __forceinline__ void jacobian(Geo<TDIM>& g)
   if constexpr (TDIM == 2)
   {
     const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-    g.K[0][0] = J[1][1] / det;  g.K[0][1] = -J[0][1] / det;
-    g.K[1][0] = -J[1][0] / det; g.K[1][1] = J[0][0] / det;
+    const double inv = 1.0 / det; // one FP64 division per cell instead of four
+    g.K[0][0] = J[1][1] * inv;  g.K[0][1] = -J[0][1] * inv;
+    g.K[1][0] = -J[1][0] * inv; g.K[1][1] = J[0][0] * inv;
     g.detJ = det;
   }
   else
@@ -151,15 +255,16 @@ __device__ __forceinline__ void jacobian(Geo<TDIM>& g)
     const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
     const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
     const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-    g.K[0][0] = c00 / det;
-    g.K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
-    g.K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
-    g.K[1][0] = c01 / det;
-    g.K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
-    g.K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
-    g.K[2][0] = c02 / det;
-    g.K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
-    g.K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+    const double inv = 1.0 / det; // one FP64 division per cell instead of nine
+    g.K[0][0] = c00 * inv;
+    g.K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * inv;
+    g.K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * inv;
+    g.K[1][0] = c01 * inv;
+    g.K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * inv;
+    g.K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * inv;
+    g.K[2][0] = c02 * inv;
+    g.K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * inv;
+    g.K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * inv;
     g.detJ = det;
   }
 }

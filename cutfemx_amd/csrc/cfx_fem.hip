@@ -562,7 +562,7 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   collect_cell_marks(a, true, mark, any);
   auto d = std::make_unique<cfx_active_s>();
   d->V = V;
-  d->n_active = compact("active_cells", V->mesh->ncells, FlagSet{mark.p}, d->active_cells);
+  d->n_active = compact_bytes("active_cells", V->mesh->ncells, mark.p, ByteNonZero{}, d->active_cells);
   // deactivate.h:155-160
   require(d->n_active > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
   const int64_t nrows = V->ndofs * V->bs;
@@ -570,7 +570,7 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   ind.zero();
   launch("mark_dofs", mark_dofs_kernel, grid_for(d->n_active * V->ndofs_cell), dim3(kBlock), 0, d->n_active,
          d->active_cells.p, V->dofmap.p, V->ndofs_cell, V->bs, ind.p);
-  d->n_inactive = compact("inactive_dofs", nrows, FlagClear{ind.p}, d->inactive_dofs);
+  d->n_inactive = compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs);
   CFX_HIP(hipStreamSynchronize(ctx().stream));
   *out = d.release();
   CFX_API_END

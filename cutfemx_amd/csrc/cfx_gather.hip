@@ -17,6 +17,7 @@
 // (default) or a lane-ordered, bitwise-reproducible sequence
 // (CFX_DETERMINISTIC=1).
 #include <cstdlib>
+#include <type_traits>
 
 #include "cfx_elem.h"
 
@@ -31,13 +32,16 @@ namespace
 {
 
 constexpr int kWave = 64;
+#ifndef CFX_ROWS_WAVES
+#define CFX_ROWS_WAVES 5 // waves per SIMD the gather kernel is compiled for (measured: 4 -> 2.27, 5 -> 2.09, 6 -> 2.58 ms at 256^3)
+#endif
 
 struct RowIntegral
 {
   int kernel, qdegree, point_stride;
   int std_inline;            // uncut entities: compute inline (1) or read std_tensors (0)
-  const int32_t* entities;   // sorted uncut entities (lookup of std_tensors)
-  int64_t n_entities;
+  const unsigned long long* std_bits; // bitset of the uncut entities
+  const int32_t* std_rank;            // entities before each 64-cell word
   const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [n_entities][ND] (rank 1)
   const int32_t* parent_map; // sorted rule parents
   int64_t nr;
@@ -67,7 +71,16 @@ struct RowArgs
   const int32_t* indices;
   double* values;
   int* error;
+  int debug; // ablation switches (CFX_DEBUG_ROWS), 0 in production
 };
+
+// index of cell c in the sorted entity list described by (bits, rank)
+__device__ __forceinline__ int64_t entity_index(const unsigned long long* __restrict__ bits,
+                                                const int32_t* __restrict__ rank, int64_t c)
+{
+  const int64_t w = c >> 6;
+  return (int64_t)rank[w] + __popcll(bits[w] & ((1ull << (c & 63)) - 1ull));
+}
 
 __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int32_t v)
 {
@@ -180,14 +193,19 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 // ---------------------------------------------------------------------------
 // stage 2, bilinear forms
 // ---------------------------------------------------------------------------
-template <int TDIM, int DEG, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave) assemble_rows_kernel(RowArgs A)
+// ISO: the space is P1 and its dofmap IS the geometry dofmap, so the columns of
+// row r are exactly the vertices of its incident cells: their coordinates are
+// staged once per row in LDS (~15-30 coalesced 24 B reads) instead of being
+// gathered again for every (row, cell) pair (~100 scattered reads per row).
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool ISO>
+__global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row
   constexpr int RPW = kWave / G;
   __shared__ int32_t s_col[RPW][CAP];
   __shared__ double s_val[RPW][CAP];
+  __shared__ double s_x[ISO ? RPW : 1][ISO ? CAP : 1][TDIM];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
   const bool live = ri < A.n_active;
@@ -195,10 +213,29 @@ __global__ void __launch_bounds__(kWave) assemble_rows_kernel(RowArgs A)
   const int64_t rb = live ? A.indptr[r] : 0;
   int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
   if (len > CAP) { *A.error = 2; len = 0; }
-  for (int k = gl; k < len; k += G)
+  // Row prologue: this lane's slice of the row's columns, requested in one batch
+  constexpr int KMAX = CAP / G;
+  int32_t mycol[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
   {
-    s_col[grp][k] = A.indices[rb + k];
-    s_val[grp][k] = 0.0;
+    const int k = gl + q * G;
+    mycol[q] = k < len ? A.indices[rb + k] : -1;
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len)
+    {
+      s_col[grp][k] = mycol[q];
+      s_val[grp][k] = 0.0;
+      if constexpr (ISO)
+      {
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) s_x[grp][k][d] = A.x[3 * (int64_t)mycol[q] + d];
+      }
+    }
   }
   __syncthreads();
   const bool cells = live && A.cellmark != nullptr;
@@ -207,137 +244,211 @@ __global__ void __launch_bounds__(kWave) assemble_rows_kernel(RowArgs A)
   const bool facets = live && A.d2f_off != nullptr;
   const int64_t fb = facets ? A.d2f_off[r] : 0;
   const int nf = facets ? (int)(A.d2f_off[r + 1] - fb) : 0;
-  const int nitems = len > 0 ? nc + nf : 0;
   const bool row_bc = live && A.bc0 && A.bc0[r];
 
-  for (int base = 0;; base += G)
+  // add one item (ncols columns) of every group to its row; ORDERED keeps item order
+  // CSR slot of column `col` of this row (-1 and the error flag if absent)
+  auto find_slot = [&](int32_t col) -> int
   {
-    const int t = base + gl;
-    const bool has = t < nitems;
-    if (__ballot(has) == 0) break;
-    double acc[W];
-    int32_t cols[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) { acc[j] = 0.0; cols[j] = -1; }
-    int ncols = 0;
+    int lo = 0, hi = len;
+    while (lo < hi)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (s_col[grp][mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (lo < len && s_col[grp][lo] == col) return lo;
+    *A.error = 1;
+    return -1;
+  };
+  // add one item of NC columns to the row; `sl` holds the CSR slot of each column
+  auto add_item = [&](auto nc_tag, bool has, const int32_t* cols, double* acc, const int* sl)
+  {
+    constexpr int NC = decltype(nc_tag)::value;
+    if (A.debug & 1) { if (has && acc[0] == 1.2345e300) *A.error = 3; return; } // ablation: no reduction
     if (has)
     {
-      if (t < nc)
-      {
-        const int64_t c = A.d2c[cb + t];
-        const uint8_t mark = A.cellmark[c];
-        if (mark)
-        {
-          int lr = 0;
+      // zero BC rows / columns: assemble_matrix_impl.h:151-185
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            cols[j] = A.dofmap[c * ND + j];
-            lr = (cols[j] == (int32_t)r) ? j : lr;
-          }
-          ncols = ND;
-          for (int i = 0; i < A.n_cell; ++i)
-          {
-            const RowIntegral& I = A.cell[i];
-            if (mark & (1u << i))
-            {
-              if (I.std_inline)
-              {
-                Geo<TDIM> g;
-                load_cell<TDIM>(A.x, A.conn, c, g);
-                jacobian<TDIM>(g);
-                int npts;
-                const double* wts;
-                const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
-                cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
-                                                fabs(g.detJ), nullptr, lr, 0, acc);
-              }
-              else
-              {
-                const int64_t e = lower_bound_i32(I.entities, I.n_entities, (int32_t)c);
-                const double* T = I.std_tensors + (e * ND + lr) * ND;
-#pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] += T[j];
-              }
-            }
-            if (mark & (16u << i))
-            {
-              // an interface cell may own several consecutive rules (cut.cpp:1286-1294)
-              for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
-              {
-                const double* T = I.rule_tensors + (e * ND + lr) * ND;
-#pragma unroll
-                for (int j = 0; j < ND; ++j) acc[j] += T[j];
-              }
-            }
-          }
-        }
-      }
-      else
-      {
-        const int64_t f = A.d2f[fb + (t - nc)];
-        const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
-#pragma unroll
-        for (int j = 0; j < ND; ++j)
-        {
-          cols[j] = A.dofmap[(int64_t)row4.x * ND + j];
-          cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
-        }
-        ncols = W;
-        // r may be a dof of both cells: both macro rows land in global row r
-        const double* T = A.facet_tensors + f * (W * W);
-#pragma unroll
-        for (int i = 0; i < W; ++i)
-          if (cols[i] == (int32_t)r)
-          {
-#pragma unroll
-            for (int j = 0; j < W; ++j) acc[j] += T[i * W + j];
-          }
-      }
-    }
-    // CSR slot of every column of the item
-    int sl[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j)
-    {
-      sl[j] = -1;
-      if (j < ncols)
-      {
-        int lo = 0, hi = len;
-        while (lo < hi)
-        {
-          const int mid = (lo + hi) >> 1;
-          if (s_col[grp][mid] < cols[j]) lo = mid + 1; else hi = mid;
-        }
-        if (lo < len && s_col[grp][lo] == cols[j]) sl[j] = lo; else *A.error = 1;
-        // zero BC rows / columns: assemble_matrix_impl.h:151-185
+      for (int j = 0; j < NC; ++j)
         if (row_bc || (A.bc1 && A.bc1[cols[j]])) acc[j] = 0.0;
-      }
     }
     if constexpr (ORDERED)
     {
-      // item order: one lane of each group at a time
       volatile double* val = s_val[grp];
-      for (int turn = 0; turn < G; ++turn)
+      for (int turn = 0; turn < G; ++turn) // one lane of each group at a time
       {
         if (__ballot(has && gl == turn) == 0) continue;
         if (has && gl == turn)
         {
 #pragma unroll
-          for (int j = 0; j < W; ++j)
+          for (int j = 0; j < NC; ++j)
             if (sl[j] >= 0) val[sl[j]] += acc[j];
         }
       }
     }
     else
     {
+      if (has)
+      {
 #pragma unroll
-      for (int j = 0; j < W; ++j)
-        if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
+        for (int j = 0; j < NC; ++j)
+          if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
+      }
+    }
+  };
+
+  // ---- cell items, R per lane per pass.  The index loads of a pass (incidence
+  // list, marks, dof rows) are issued together so that their latencies overlap:
+  // the kernel is bound by dependent gathers, not by bandwidth or flops.
+  constexpr int R = G <= 4 ? 6 : 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  const int ncl = len > 0 ? nc : 0;
+  for (int base = 0;; base += R * G)
+  {
+    if (__ballot(base + gl < ncl) == 0) break;
+    int32_t cell[R];
+    uint8_t mk[R];
+    int32_t cd[R][ND];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      const int t = base + k * G + gl;
+      cell[k] = t < ncl ? A.d2c[cb + t] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (!mk[k]) continue;
+      if constexpr (ND == 4)
+      {
+        const int4 v = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)cell[k] * 4);
+        cd[k][0] = v.x; cd[k][1] = v.y; cd[k][2] = v.z; cd[k][3] = v.w;
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) cd[k][j] = A.dofmap[(int64_t)cell[k] * ND + j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (__ballot(mk[k] != 0) == 0) continue;
+      double acc[ND];
+      int csl[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { acc[j] = 0.0; csl[j] = -1; }
+      if (mk[k])
+      {
+        const int64_t c = cell[k];
+        const uint8_t mark = mk[k];
+        int lr = 0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          lr = (cd[k][j] == (int32_t)r) ? j : lr;
+          csl[j] = (A.debug & 4) ? j : find_slot(cd[k][j]);
+        }
+        for (int i = 0; i < ((A.debug & 2) ? 0 : A.n_cell); ++i)
+        {
+          const RowIntegral& I = A.cell[i];
+          if (mark & (1u << i))
+          {
+            if (I.std_inline)
+            {
+              Geo<TDIM> g;
+              if constexpr (ISO)
+              {
+#pragma unroll
+                for (int j = 0; j < ND; ++j)
+#pragma unroll
+                  for (int d = 0; d < TDIM; ++d) g.x[j][d] = s_x[grp][csl[j] < 0 ? 0 : csl[j]][d];
+              }
+              else
+                load_cell<TDIM>(A.x, A.conn, c, g);
+              jacobian<TDIM>(g);
+              int npts;
+              const double* wts;
+              const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+              cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
+                                              fabs(g.detJ), nullptr, lr, 0, acc);
+            }
+            else
+            {
+              const int64_t e = entity_index(I.std_bits, I.std_rank, c);
+              const double* T = I.std_tensors + (e * ND + lr) * ND;
+#pragma unroll
+              for (int j = 0; j < ND; ++j) acc[j] += T[j];
+            }
+          }
+          if (mark & (16u << i))
+          {
+            // an interface cell may own several consecutive rules (cut.cpp:1286-1294)
+            for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+            {
+              const double* T = I.rule_tensors + (e * ND + lr) * ND;
+#pragma unroll
+              for (int j = 0; j < ND; ++j) acc[j] += T[j];
+            }
+          }
+        }
+      }
+      add_item(std::integral_constant<int, ND>{}, mk[k] != 0, cd[k], acc, csl);
     }
   }
+
+  // ---- facet items (rows next to the interface only)
+  const int nfl = len > 0 ? nf : 0;
+  for (int base = 0;; base += G)
+  {
+    const int t = base + gl;
+    const bool has = t < nfl;
+    if (__ballot(has) == 0) break;
+    double acc[W];
+    int32_t cols[W];
+    int fsl[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) { acc[j] = 0.0; cols[j] = -1; fsl[j] = -1; }
+    if (has)
+    {
+      const int64_t f = A.d2f[fb + t];
+      const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        cols[j] = A.dofmap[(int64_t)row4.x * ND + j];
+        cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
+      }
+      // r may be a dof of both cells: both macro rows land in global row r
+      const double* T = A.facet_tensors + f * (W * W);
+#pragma unroll
+      for (int i = 0; i < W; ++i)
+        if (cols[i] == (int32_t)r)
+        {
+#pragma unroll
+          for (int j = 0; j < W; ++j) acc[j] += T[i * W + j];
+        }
+#pragma unroll
+      for (int j = 0; j < W; ++j) fsl[j] = find_slot(cols[j]);
+    }
+    add_item(std::integral_constant<int, W>{}, has, cols, acc, fsl);
+  }
   __syncthreads();
-  for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k];
+  // Row epilogue: values[row] += reduced row, loads batched
+  double myval[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    myval[q] = k < len ? A.values[rb + k] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len) A.values[rb + k] = myval[q] + s_val[grp][k];
+  }
 }
 
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
@@ -353,22 +464,43 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   const int64_t cb = live ? A.d2c_off[r] : 0;
   const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
   double part = 0.0; // items gl, gl+G, ... in ascending order
-  for (int t = gl; t < nc; t += G)
+  constexpr int R = G <= 4 ? 6 : 4;
+  for (int base = 0;; base += R * G)
   {
-    const int64_t c = A.d2c[cb + t];
-    const uint8_t mark = A.cellmark[c];
-    if (!mark) continue;
-    int lr = 0;
+    if (__ballot(base + gl < nc) == 0) break;
+    int64_t cell[R];
+    uint8_t mk[R];
+    int lr[R];
 #pragma unroll
-    for (int j = 0; j < ND; ++j) lr = (A.dofmap[c * ND + j] == (int32_t)r) ? j : lr;
-    for (int i = 0; i < A.n_cell; ++i)
+    for (int k = 0; k < R; ++k)
     {
-      const RowIntegral& I = A.cell[i];
-      if (mark & (1u << i))
-        part += I.std_tensors[lower_bound_i32(I.entities, I.n_entities, (int32_t)c) * ND + lr];
-      if (mark & (16u << i))
-        for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
-          part += I.rule_tensors[e * ND + lr];
+      const int t = base + k * G + gl;
+      cell[k] = t < nc ? (int64_t)A.d2c[cb + t] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      lr[k] = 0;
+      if (!mk[k]) continue;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) lr[k] = (A.dofmap[cell[k] * ND + j] == (int32_t)r) ? j : lr[k];
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (!mk[k]) continue;
+      const int64_t c = cell[k];
+      for (int i = 0; i < A.n_cell; ++i)
+      {
+        const RowIntegral& I = A.cell[i];
+        if (mk[k] & (1u << i))
+          part += I.std_tensors[entity_index(I.std_bits, I.std_rank, c) * ND + lr[k]];
+        if (mk[k] & (16u << i))
+          for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+            part += I.rule_tensors[e * ND + lr[k]];
+      }
     }
   }
   // fixed-shape tree over the group's lanes: bitwise reproducible
@@ -435,9 +567,14 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     RowIntegral& R = A.cell[s];
     R.kernel = I.kernel; R.qdegree = I.qdegree; R.point_stride = I.point_stride;
     for (int k = 0; k < 8; ++k) R.params[k] = I.params[k];
-    R.entities = I.entities.p; R.n_entities = I.n_entities;
+    if (I.n_entities > 0)
+    {
+      R.std_bits = reinterpret_cast<const unsigned long long*>(plan.std_bits[s].p);
+      R.std_rank = plan.std_rank[s].p;
+    }
     // uncut P1 stiffness is one point: cheaper to recompute than to stage
-    R.std_inline = (a->rank == 2 && I.kernel == CFX_K_STIFFNESS && DEG == 1) ? 1 : 0;
+    const char* inl = getenv("CFX_STD_INLINE");
+    R.std_inline = (a->rank == 2 && I.kernel == CFX_K_STIFFNESS && DEG == 1 && !(inl && inl[0] == '0')) ? 1 : 0;
     if (!R.std_inline && I.n_entities > 0)
     {
       st.buffers.emplace_back(I.n_entities * tsize);
@@ -479,21 +616,28 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   DevArray<int> err(1);
   err.zero();
   A.error = err.p;
+  if (const char* dbg = getenv("CFX_DEBUG_ROWS")) A.debug = atoi(dbg);
   if (A.n_active > 0)
   {
     const bool det = deterministic();
-    if (P->max_row_len < 64)
-    {
-      const dim3 grid((unsigned)((A.n_active + 7) / 8));
-      if (det) launch("assemble_rows", assemble_rows_kernel<TDIM, DEG, 8, 64, true>, grid, dim3(kWave), 0, A);
-      else launch("assemble_rows", assemble_rows_kernel<TDIM, DEG, 8, 64, false>, grid, dim3(kWave), 0, A);
-    }
-    else
-    {
-      const dim3 grid((unsigned)A.n_active);
-      if (det) launch("assemble_rows_wide", assemble_rows_kernel<TDIM, DEG, 64, 512, true>, grid, dim3(kWave), 0, A);
-      else launch("assemble_rows_wide", assemble_rows_kernel<TDIM, DEG, 64, 512, false>, grid, dim3(kWave), 0, A);
-    }
+    // P1 space whose dofmap aliases the geometry dofmap: vertex coordinates via LDS
+    // (measured: no gain -- the kernel is bound by the dependent index chain; CFX_ISO=1 enables it)
+    const char* iso_env = getenv("CFX_ISO");
+    const bool iso = DEG == 1 && a->V->dofmap.p == a->V->mesh->conn.p && iso_env && iso_env[0] == '1';
+    const int mr = P->max_row_len;
+#define CFX_ROWS(GG, CAPP, NAME)                                                                          \
+  do                                                                                                      \
+  {                                                                                                       \
+    const dim3 grid = xcd_grid((A.n_active + (kWave / GG) - 1) / (kWave / GG));                           \
+    if (det && iso) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, true>, grid, dim3(kWave), 0, A);   \
+    else if (det) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, false>, grid, dim3(kWave), 0, A);    \
+    else if (iso) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, true>, grid, dim3(kWave), 0, A);    \
+    else launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, A);            \
+  } while (0)
+    if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows");
+    else if (mr <= 64) CFX_ROWS(8, 64, "assemble_rows");
+    else CFX_ROWS(64, 512, "assemble_rows_wide");
+#undef CFX_ROWS
   }
   return read_scalar(err.p);
 }
@@ -505,8 +649,8 @@ void run_vector(cfx_form_s* L, double* b)
   RowArgs A = prepare<TDIM, DEG>(L, st);
   A.values = b;
   if (A.n_active > 0)
-    launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 8>, dim3((unsigned)((A.n_active + 7) / 8)),
-           dim3(kWave), 0, A);
+    launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 4>, xcd_grid((A.n_active + 15) / 16), dim3(kWave), 0,
+           A);
 }
 
 } // namespace
@@ -518,7 +662,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
 {
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
-  if (!plan.usable || V->degree != 1 || V->bs != 1 || P->max_row_len >= 512) return false;
+  if (!plan.usable || V->degree != 1 || V->bs != 1 || P->max_row_len > 512) return false;
   const int err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values)
                                      : run_matrix<3, 1>(a, P, bc0, bc1, values);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");

@@ -9,6 +9,8 @@
 // produces one after the other (assemble_matrix_impl.h:103-188, :462-606) --
 // and the group reduces the items into the row's CSR slots in LDS in item
 // order, so no global atomics are issued and the sums do not depend on timing.
+#include <cstdlib>
+
 #include "cfx_elem.h"
 
 using namespace cfx;
@@ -26,9 +28,38 @@ __global__ void plan_mark_cells_kernel(int64_t n, const int32_t* __restrict__ ce
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  // byte-wide OR: concurrent writers may set different bits of one byte
-  unsigned int* word = reinterpret_cast<unsigned int*>(mark + ((int64_t)cells[i * stride] & ~3LL));
-  atomicOr(word, (unsigned int)bit << (8 * (cells[i * stride] & 3)));
+  // Launches are serialised on the stream and every thread of one launch ORs the
+  // same bit, so a repeated cell (interface rules) is a benign same-value race.
+  const int64_t c = cells[i * stride];
+  mark[c] = mark[c] | bit;
+}
+
+// bit `bit` of 64 consecutive cell marks -> one word; its popcount for the rank scan
+__global__ void plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict__ mark, uint8_t bit,
+                                      unsigned long long* __restrict__ words, int32_t* __restrict__ pop)
+{
+  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w * 64 >= ncells) return;
+  unsigned long long v = 0;
+  const int64_t base = w * 64;
+  if (base + 64 <= ncells)
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(mark + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+      const uint4 u = p[q];
+      const unsigned x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if ((x[k >> 2] >> (8 * (k & 3))) & bit) v |= 1ull << (16 * q + k);
+    }
+  }
+  else
+    for (int k = 0; base + k < ncells; ++k)
+      if (mark[base + k] & bit) v |= 1ull << k;
+  words[w] = v;
+  pop[w] = __popcll(v);
 }
 
 __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride,
@@ -130,6 +161,7 @@ struct PatArgs
   int32_t* len;     // [n_active]
   int32_t* counts;  // [ndofs*bs] expanded row lengths
   int* overflow;
+  int* maxlen;      // longest scalar-dof row
 };
 
 template <int T>
@@ -139,8 +171,14 @@ __device__ __forceinline__ bool hash_insert(int32_t* tab, int32_t v)
   for (int probe = 0; probe < T; ++probe)
   {
     slot &= (T - 1);
-    const int32_t old = atomicCAS(&tab[slot], -1, v);
-    if (old == -1 || old == v) return true;
+    // most candidates are duplicates: a plain read settles them without an LDS atomic
+    int32_t old = tab[slot];
+    if (old == v) return true;
+    if (old == -1)
+    {
+      old = atomicCAS(&tab[slot], -1, v);
+      if (old == -1 || old == v) return true;
+    }
     ++slot;
   }
   return false;
@@ -151,11 +189,14 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
 {
   constexpr int RPW = kWave / G;
   __shared__ int32_t s_tab[RPW][T];
+  __shared__ int32_t s_list[RPW][T];
+  __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
+  const int64_t ri = xcd_block_id() * RPW + grp;
   const bool live = ri < P.n_active;
   const int64_t r = live ? P.active_rows[ri] : 0;
   for (int k = gl; k < T; k += G) s_tab[grp][k] = -1;
+  if (gl == 0) s_cnt[grp] = 0;
   __syncthreads();
   bool ok = true;
   if (live)
@@ -163,12 +204,49 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
     int32_t* tab = s_tab[grp];
     if (gl == 0) ok = hash_insert<T>(tab, (int32_t)r);
     if (P.cellmark)
-      for (int64_t k = P.d2c_off[r] + gl; k < P.d2c_off[r + 1]; k += G)
+    {
+      // R incident cells per lane per pass; incidence, marks and dof rows of a pass
+      // are requested together so that the three dependent levels overlap
+      constexpr int R = G <= 4 ? 6 : (G <= 8 ? 4 : 2);
+      const int64_t cb = P.d2c_off[r];
+      const int nc = (int)(P.d2c_off[r + 1] - cb);
+      for (int base = 0; base < nc; base += R * G)
       {
-        const int64_t c = P.d2c[k];
-        if (!P.cellmark[c]) continue;
-        for (int j = 0; j < P.nd; ++j) ok = hash_insert<T>(tab, P.dofmap[c * P.nd + j]) && ok;
+        int64_t cell[R];
+        uint8_t mk[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+        {
+          const int t = base + k * G + gl;
+          cell[k] = t < nc ? (int64_t)P.d2c[cb + t] : -1;
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? P.cellmark[cell[k]] : (uint8_t)0;
+        if (P.nd == 4)
+        {
+          int4 dr[R];
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            dr[k] = mk[k] ? *reinterpret_cast<const int4*>(P.dofmap + cell[k] * 4) : make_int4(-1, -1, -1, -1);
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (mk[k])
+            {
+              ok = hash_insert<T>(tab, dr[k].x) && ok;
+              ok = hash_insert<T>(tab, dr[k].y) && ok;
+              ok = hash_insert<T>(tab, dr[k].z) && ok;
+              ok = hash_insert<T>(tab, dr[k].w) && ok;
+            }
+        }
+        else
+        {
+#pragma unroll
+          for (int k = 0; k < R; ++k)
+            if (mk[k])
+              for (int j = 0; j < P.nd; ++j) ok = hash_insert<T>(tab, P.dofmap[cell[k] * P.nd + j]) && ok;
+        }
       }
+    }
     if (P.d2f_off)
       for (int64_t k = P.d2f_off[r] + gl; k < P.d2f_off[r + 1]; k += G)
       {
@@ -182,27 +260,27 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   }
   __syncthreads();
   if (!ok) *P.overflow = 1;
-  if (!live) return;
-  // a full table cannot be told from an overflowing one: keep one slot free
-  int cnt = 0;
+  // compact the set, then rank inside the compact list (cnt^2/G reads instead of T^2/G)
   for (int k = gl; k < T; k += G)
   {
     const int32_t v = s_tab[grp][k];
-    if (v < 0) continue;
-    ++cnt;
+    if (v >= 0) s_list[grp][atomicAdd(&s_cnt[grp], 1)] = v;
+  }
+  __syncthreads();
+  const int cnt = s_cnt[grp];
+  for (int k = gl; k < cnt; k += G)
+  {
+    const int32_t v = s_list[grp][k];
     int rank = 0;
-    for (int m = 0; m < T; ++m)
-    {
-      const int32_t u = s_tab[grp][m];
-      rank += (u >= 0 && u < v) ? 1 : 0;
-    }
+    for (int m = 0; m < cnt; ++m) rank += (s_list[grp][m] < v) ? 1 : 0;
     P.tmp[ri * T + rank] = v;
   }
-#pragma unroll
-  for (int d = G / 2; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d, G);
+  // a full table cannot be told from an overflowing one: keep one slot free
   if (cnt >= T) *P.overflow = 1;
-  if (gl == 0)
+  if (live && gl == 0)
   {
+    // a racy pre-check keeps 10^7 rows from serialising on one address
+    if (cnt > *reinterpret_cast<volatile int*>(P.maxlen)) atomicMax(P.maxlen, cnt);
     P.len[ri] = cnt;
     for (int a = 0; a < P.bs; ++a) P.counts[r * P.bs + a] = cnt * P.bs;
   }
@@ -230,14 +308,16 @@ __global__ void pattern_write_kernel(int64_t n_active, const int32_t* __restrict
                                      const int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t ri = i / T;
+  const int64_t ri = i / 8;
   if (ri >= n_active) return;
-  const int k = (int)(i - ri * T);
-  if (k >= len[ri]) return;
+  const int n = len[ri];
   const int64_t r = active_rows[ri];
-  const int32_t col = tmp[i];
-  for (int a = 0; a < bs; ++a)
-    for (int b = 0; b < bs; ++b) indices[indptr[r * bs + a] + (int64_t)k * bs + b] = col * bs + b;
+  for (int k = (int)(i - ri * 8); k < n; k += 8)
+  {
+    const int32_t col = tmp[ri * T + k];
+    for (int a = 0; a < bs; ++a)
+      for (int b = 0; b < bs; ++b) indices[indptr[r * bs + a] + (int64_t)k * bs + b] = col * bs + b;
+  }
 }
 
 } // namespace
@@ -326,10 +406,26 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
            P.facet_rows.p, V->dofmap.p, nd, P.d2f_offsets.p, fcount.p, P.d2f.p);
   }
-  P.n_active_rows = compact("plan_active_rows", V->ndofs, FlagSetU8{P.rowmark.p}, P.active_rows);
-  if (P.nfacets > 0)
+  P.n_active_rows = compact_bytes("plan_active_rows", V->ndofs, P.rowmark.p, ByteNonZero{}, P.active_rows);
+  // rank structure of every uncut entity list: entity index of cell c =
+  // rank[c/64] + popcount(bits[c/64] below c), two cached loads instead of a
+  // binary search over the (10^8-entry) list
+  const int64_t nwords = (nc + 63) / 64;
+  for (int slot = 0; slot < P.n_cell_slots; ++slot)
   {
-    // only active rows have facets: sort their (short) lists
+    const cfx_integral_dev& I = a->integrals[P.cell_slot_integral[slot]];
+    if (I.n_entities == 0) continue;
+    P.std_bits[slot].alloc(nwords);
+    P.std_rank[slot].alloc(nwords + 1);
+    DevArray<int32_t> pop(nwords);
+    launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, P.cellmark.p,
+           (uint8_t)(1u << slot), reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p);
+    exclusive_scan(pop.p, P.std_rank[slot].p, nwords);
+  }
+  const char* det = getenv("CFX_DETERMINISTIC");
+  if (P.nfacets > 0 && det && det[0] == '1')
+  {
+    // reproducible gather order (the lists were filled through an atomic cursor)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_active_rows), dim3(kBlock), 0, P.n_active_rows,
            P.active_rows.p, P.d2f_offsets.p, P.d2f.p);
   }
@@ -358,28 +454,30 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   P->nrows = V->ndofs * V->bs;
   DevArray<int32_t> counts(P->nrows), len(plan.n_active_rows), tmp;
-  DevArray<int> overflow(1);
+  DevArray<int> overflow(1), maxlen(1);
   overflow.zero();
+  maxlen.zero();
   launch("pattern_init", fill_i32_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, (int32_t)V->bs, counts.p);
-  S.len = len.p; S.counts = counts.p; S.overflow = overflow.p;
+  S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
   int T = 64;
   if (plan.n_active_rows > 0)
   {
     tmp.alloc(plan.n_active_rows * 64);
     S.tmp = tmp.p;
-    launch("pattern_rows", pattern_rows_kernel<16, 64>, dim3((unsigned)((plan.n_active_rows + 3) / 4)), dim3(kWave),
+    launch("pattern_rows", pattern_rows_kernel<4, 64>, xcd_grid((plan.n_active_rows + 15) / 16), dim3(kWave),
            0, S);
     if (read_scalar(overflow.p))
     {
       T = 512;
       overflow.zero();
+      maxlen.zero();
       tmp.alloc(plan.n_active_rows * 512);
       S.tmp = tmp.p;
-      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, dim3((unsigned)plan.n_active_rows), dim3(kWave), 0, S);
+      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, xcd_grid(plan.n_active_rows), dim3(kWave), 0, S);
       require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 511 dofs");
     }
   }
-  P->max_row_len = T - 1;
+  P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
   P->indptr.alloc(P->nrows + 1);
   exclusive_scan(counts.p, P->indptr.p, P->nrows);
   P->nnz = read_scalar(P->indptr.p + P->nrows);
@@ -389,10 +487,10 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   if (plan.n_active_rows > 0)
   {
     if (T == 64)
-      launch("pattern_write", pattern_write_kernel<64>, grid_for(plan.n_active_rows * 64), dim3(kBlock), 0,
+      launch("pattern_write", pattern_write_kernel<64>, grid_for(plan.n_active_rows * 8), dim3(kBlock), 0,
              plan.n_active_rows, plan.active_rows.p, V->bs, tmp.p, len.p, P->indptr.p, P->indices.p);
     else
-      launch("pattern_write", pattern_write_kernel<512>, grid_for(plan.n_active_rows * 512), dim3(kBlock), 0,
+      launch("pattern_write", pattern_write_kernel<512>, grid_for(plan.n_active_rows * 8), dim3(kBlock), 0,
              plan.n_active_rows, plan.active_rows.p, V->bs, tmp.p, len.p, P->indptr.p, P->indices.p);
   }
 }

@@ -49,7 +49,7 @@ SYMBOLS = [
     "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_copy",
     "cfx_device_alloc", "cfx_device_free", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
-    "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box",
+    "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
     "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
     "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",

@@ -18,7 +18,7 @@ __global__ void compact_conn_kernel(const int32_t* __restrict__ in, int64_t ncel
 }
 
 // box [0,1]^d, n^d cubes; vertex id ix+(n+1)(iy+(n+1)iz)
-__global__ void box_nodes_kernel(int tdim, int n, int64_t nnodes, double* __restrict__ x)
+__global__ void box_nodes_kernel(int tdim, int n, int z0, int64_t nnodes, double* __restrict__ x)
 {
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= nnodes) return;
@@ -26,7 +26,7 @@ __global__ void box_nodes_kernel(int tdim, int n, int64_t nnodes, double* __rest
   const int64_t ix = v % n1, iy = (v / n1) % n1, iz = tdim == 3 ? v / (n1 * n1) : 0;
   x[3 * v + 0] = (double)ix / (double)n;
   x[3 * v + 1] = (double)iy / (double)n;
-  x[3 * v + 2] = tdim == 3 ? (double)iz / (double)n : 0.0;
+  x[3 * v + 2] = tdim == 3 ? (double)(iz + z0) / (double)n : 0.0;
 }
 
 // Kuhn split; local corner i = bx + 2 by + 4 bz
@@ -114,8 +114,29 @@ int cfx_mesh_create_box(int tdim, int n, cfx_mesh_t* out)
   m->tdim = tdim; m->gdim = tdim; m->nnodes = nnodes; m->ncells = ncells;
   m->x.alloc(nnodes * 3);
   m->conn.alloc(ncells * (tdim + 1));
-  launch("box_nodes", box_nodes_kernel, grid_for(nnodes), dim3(kBlock), 0, tdim, n, nnodes, m->x.p);
+  launch("box_nodes", box_nodes_kernel, grid_for(nnodes), dim3(kBlock), 0, tdim, n, 0, nnodes, m->x.p);
   launch("box_cells", box_cells_kernel, grid_for(ncells), dim3(kBlock), 0, tdim, n, ncells, m->conn.p);
+  *out = m.release();
+  CFX_API_END
+}
+
+int cfx_mesh_create_slab(int n, int z0, int nz, cfx_mesh_t* out)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  require(out != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_mesh_create_slab: null output");
+  require(n >= 1 && z0 >= 0 && nz >= 1 && z0 + nz <= n, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_mesh_create_slab: need 0 <= z0, 1 <= nz, z0 + nz <= n");
+  const int64_t n1 = n + 1;
+  const int64_t nnodes = n1 * n1 * (nz + 1), ncells = 6LL * n * n * nz;
+  require(ncells < 2147483647LL, CFX_ERR_INVALID_ARGUMENT, "cfx_mesh_create_slab: too many cells for int32 ids");
+  auto m = std::make_unique<cfx_mesh_s>();
+  m->tdim = 3; m->gdim = 3; m->nnodes = nnodes; m->ncells = ncells;
+  m->x.alloc(nnodes * 3);
+  m->conn.alloc(ncells * 4);
+  // the same generators as the full box: local ids = global ids minus the slab offset
+  launch("box_nodes", box_nodes_kernel, grid_for(nnodes), dim3(kBlock), 0, 3, n, z0, nnodes, m->x.p);
+  launch("box_cells", box_cells_kernel, grid_for(ncells), dim3(kBlock), 0, 3, n, ncells, m->conn.p);
   *out = m.release();
   CFX_API_END
 }

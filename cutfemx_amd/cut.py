@@ -84,6 +84,28 @@ class RuntimeQuadratureRules:
         _ = self.physical_points
         return self
 
+    def slice_by_parent(self, cell_lo: int, cell_hi: int, device):
+        """Zero-copy sub-rule-set of the rules whose parent cell lies in
+        [cell_lo, cell_hi) (parents are ascending): `offsets` / `parent_map` are
+        aliased with a shift, points / weights / per-point data keep their absolute
+        indices.  Used to restrict a form to a rank's owned cells."""
+        import torch
+
+        from .dist import as_torch
+        parents = as_torch(self._view.parent_map, self.num_rules, "int32", device)
+        r0, r1 = (int(v) for v in torch.searchsorted(
+            parents, torch.tensor([cell_lo, cell_hi], device=device, dtype=torch.int32)))
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cfx_rules_create(
+            self.mesh._h, self.tdim, C.c_int64(self.total_points), C.c_int64(r1 - r0),
+            C.c_void_p(self._view.points), C.c_void_p(self._view.weights),
+            C.c_void_p(self._view.offsets + 4 * r0), C.c_void_p(self._view.parent_map + 4 * r0), C.byref(h)))
+        sub = RuntimeQuadratureRules(h, self.mesh)
+        sub._keep = [self]
+        offs = as_torch(self._view.offsets, self.num_rules + 1, "int32", device)
+        sub.total_points_owned = int(offs[r1] - offs[r0]) if r1 > r0 else 0
+        return sub
+
     def __del__(self):
         try:
             if self._h:

@@ -49,6 +49,8 @@ class Integral:
             if isinstance(self.facets, FacetRows):
                 ent_ptr, n_ent = C.c_void_p(self.facets.ptr), self.facets.size
                 keep.append(self.facets)
+            elif _lib.is_torch(self.facets):  # (nf, 4) int32 tensor, host or device
+                ent_ptr, n_ent = _lib.as_ptr(self.facets, np.int32, keep), int(self.facets.numel() // 4)
             else:
                 rows = np.ascontiguousarray(self.facets, dtype=np.int32).reshape(-1, 4)
                 ent_ptr, n_ent = _lib.as_ptr(rows, np.int32, keep), rows.shape[0]

@@ -75,6 +75,15 @@ class Mesh:
         _lib.check(_lib.lib().cfx_mesh_info(h, None, None, C.byref(nn), C.byref(nc), None, None))
         return cls(h, tdim, tdim, nn.value, nc.value)
 
+    @classmethod
+    def create_slab(cls, n: int, z0: int, nz: int) -> "Mesh":
+        """Hex layers z0..z0+nz-1 of the n^3 unit-box mesh, generated in HBM."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cfx_mesh_create_slab(n, z0, nz, C.byref(h)))
+        nn, nc = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().cfx_mesh_info(h, None, None, C.byref(nn), C.byref(nc), None, None))
+        return cls(h, 3, 3, nn.value, nc.value)
+
     def _info(self):
         x, conn = C.c_void_p(), C.c_void_p()
         _lib.check(_lib.lib().cfx_mesh_info(self._h, None, None, None, None, C.byref(x), C.byref(conn)))

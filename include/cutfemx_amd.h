@@ -149,6 +149,9 @@ int cfx_mesh_create(int tdim, int gdim, int64_t nnodes, const double* x,
 /* synthetic box mesh generated in HBM (Kuhn split of
  * cpp/cutfemx/distance/fast_iterative.h:93-108) */
 int cfx_mesh_create_box(int tdim, int n, cfx_mesh_t* out);
+/* hex layers z0 .. z0+nz-1 of the n^3 box mesh (one rank's slab + halo): local
+ * vertex / cell ids are the global ids minus (n+1)^2 z0 / 6 n^2 z0 */
+int cfx_mesh_create_slab(int n, int z0, int nz, cfx_mesh_t* out);
 int cfx_mesh_info(cfx_mesh_t m, int* tdim, int* gdim, int64_t* nnodes, int64_t* ncells,
                   const double** x, const int32_t** conn);
 int cfx_mesh_destroy(cfx_mesh_t m);

@@ -5,18 +5,27 @@ One "step" = one full pass of the hot path on a synthetic level-set mesh whose
 inputs (mesh connectivity, coordinates, level-set dof values) are already in
 HBM:  classify -> locate -> sub-triangulate + runtime quadrature (phi<0, phi=0)
 -> normals -> ghost-penalty facets -> forms -> CSR sparsity -> assemble_matrix
--> assemble_vector -> active domain + deactivation.  This is the per-time-step
-work of a moving-domain CutFEM solve (python/demo/demo_moving_poisson.py:53-67);
-only the mesh-static incidence tables are reused between steps.
+-> assemble_vector -> (N>1: RCCL row reduction) -> active domain + deactivation.
+This is the per-time-step work of a moving-domain CutFEM solve
+(python/demo/demo_moving_poisson.py:53-67); only the mesh-static incidence
+tables (vertex->cells) are reused between steps.
 
-metric (BASELINE.json): assembled DOFs/s = active dofs / step time; the
-cut-quadrature points/s and the per-phase times are reported beside it.
+Workload: BASELINE.json configs[2], the configuration its north-star target is
+quoted on -- 3-D Poisson P1, sphere level set on the 512^3 background mesh
+(805 M tets), Nitsche + ghost penalty, runtime quadrature order 4.  It fits one
+MI355X (~60 GB), so N=1 runs it whole and N>1 strong-scales it over z-slabs.
+`--n 128` runs configs[1]; the default N=1 run also reports it under
+"config_128".
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 128] [--order 4]
+metric (BASELINE.json): assembled DOFs/s = active dofs / step time (whole job);
+cut-quadrature points/s and per-phase times are reported beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--order 4]
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -27,7 +36,7 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s measured copy)
 
 # ALGORITHMIC bytes per unit (explicit-connectivity variant)
 B_CLASSIFY_PER_CELL = 18.3      # 16 B dofmap row + 8 B*V/C phi + 1 B domain
@@ -40,22 +49,21 @@ B_GHOST_FACET = 600.0           # row ids 16 + 2x(16+16) maps + 64 values x 8 B
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--n", type=int, default=128, help="background mesh n^3 cubes (x6 tets)")
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=2)
+    p.add_argument("--n", type=int, default=512, help="background mesh n^3 cubes (x6 tets)")
     p.add_argument("--order", type=int, default=4, help="runtime quadrature order (demo_poisson.py:139)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    p.add_argument("--cpu-n", type=int, default=0, help="mesh size of the CPU sample (default: min(n, 128))")
+    p.add_argument("--cpu-n", type=int, default=160, help="mesh size of the bounded CPU sample")
+    p.add_argument("--no-secondary", action="store_true", help="skip the 128^3 (configs[1]) line")
     return p.parse_args()
 
 
-def sphere_level_set(torch, n, device, z0=0, z1=None):
+def sphere_level_set(torch, n, device):
     """phi = |x - c| - R sampled at the vertices, vertex id ix+(n+1)(iy+(n+1)iz)."""
-    z1 = n if z1 is None else z1
     ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
-    az = torch.arange(z0, z1 + 1, device=device, dtype=torch.float64) / n
     cx, cy, cz, R = 0.47, 0.43, 0.41, 0.31
-    d2 = (az[:, None, None] - cz) ** 2 + (ax[None, :, None] - cy) ** 2 + (ax[None, None, :] - cx) ** 2
+    d2 = (ax[:, None, None] - cz) ** 2 + (ax[None, :, None] - cy) ** 2 + (ax[None, None, :] - cx) ** 2
     return (torch.sqrt(d2) - R).reshape(-1).contiguous()
 
 
@@ -73,7 +81,7 @@ class Timer:
 
 
 def hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer=None):
-    """One full pass; returns counters.  `timer` splits the phases (extra syncs)."""
+    """One full pass on one GPU; returns counters.  `timer` splits the phases (extra syncs)."""
     run = (lambda name, fn: fn()) if timer is None else timer.run
     cd = run("cut", lambda: cfx.cut(phi_fn))
     system = run("rules+facets+forms", lambda: poisson.build_forms(V, cd, order=order))
@@ -94,8 +102,8 @@ def hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer=None)
 
 def cpu_baseline(n, order):
     """The CPU oracle (restatement of the reference loops, single thread) on the
-    same workload; kind='port' because the reference itself cannot be built here."""
-    import numpy as np
+    same workload at a bounded size; kind='port' because the reference itself
+    cannot be built here.  The reference is serial per rank."""
     from helpers import level_set_values
     from oracle import pyoracle as O
     O.build()
@@ -134,13 +142,134 @@ def cpu_baseline(n, order):
     total = sum(t.values())
     active = om.nnodes - ina.size
     return dict(value=active / total, unit="DOF/s", cores=1, kind="port",
-                sample=f"full hot path on the {n}^3 sphere workload (oracle/cfx_oracle.c, gcc -O2, 1 thread), "
-                       f"{total:.2f} s",
+                sample=f"full hot path on the {n}^3 sphere workload ({6 * n ** 3} tets; oracle/cfx_oracle.c, "
+                       f"gcc -O2, 1 thread), {total:.1f} s",
                 seconds=total, active_dofs=int(active),
                 assemble_matrix_dofs_per_s=active / t["assemble_matrix"],
                 cut_qp_per_s=(vol.weights.size + itf.weights.size)
                 / (t["cut"] + t["rules_volume"] + t["rules_interface"]),
-                phases_s={k: round(v, 4) for k, v in t.items()})
+                phases_s={k: round(v, 4) for k, v in t.items()},
+                host_cores_available=os.cpu_count())
+
+
+def kernel_profile(_lib, step, psteps):
+    """Per-kernel HIP-event times (events on the launch stream) over psteps steps."""
+    _lib.check(_lib.lib().cfx_profile_enable(1))
+    _lib.check(_lib.lib().cfx_profile_reset())
+    for _ in range(psteps):
+        step()
+    kernels = {}
+    for i in range(_lib.lib().cfx_profile_count()):
+        name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
+        if cnt.value:
+            kernels[name.value.decode()] = dict(total_ms=ms.value / psteps, launches=cnt.value / psteps,
+                                                avg_us=1e3 * ms.value / cnt.value)
+    _lib.check(_lib.lib().cfx_profile_enable(0))
+    return kernels
+
+
+def measure(n, steps, warmup, order, world, rank, device, profile=True):
+    import torch
+    import torch.distributed as dist
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import _lib, poisson
+
+    # ---- inputs resident in HBM before the timed region -----------------------
+    if world == 1:
+        mesh = cfx.Mesh.create_box(3, n)
+        V = cfx.FunctionSpace(mesh, 1)
+        phi_fn = cfx.Function(V, sphere_level_set(torch, n, device))
+        # CSR value buffer: <= 15 (27 with ghost couplings) entries per active P1 row + 1 per inactive row
+        nnz_cap = int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000)
+        values_buf = torch.zeros(nnz_cap, device=device, dtype=torch.float64)
+        b_buf = torch.zeros(mesh.num_nodes, device=device, dtype=torch.float64)
+
+        def step(timer=None):
+            return hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer)
+    else:
+        # z-slabs weighted by active cells, one rank per GPU, RCCL point-to-point row reduction
+        from cutfemx_amd import dist as cdist
+        part = cdist.SlabPartition.create(n, world, rank)
+        dp = cdist.DistributedPoisson(part, device, order=order)
+        mesh = dp.mesh
+
+        def step(timer=None):
+            return dp.step() if timer is None else timer.run("step", dp.step)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        info = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        c = torch.tensor([float(info["active_dofs_owned"]), float(info["nq_volume"] + info["nq_interface"])],
+                         device=device, dtype=torch.float64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        active_total, nq_total = float(c[0].item()), float(c[1].item())
+    else:
+        active_total = float(info["active_dofs"])
+        nq_total = float(info["nq_volume"] + info["nq_interface"])
+    out = dict(value=active_total / (elapsed / steps), ms_per_step=1e3 * elapsed / steps,
+               active_dofs=int(active_total), counts={k: int(v) for k, v in info.items()})
+    if not profile:
+        return out
+
+    # ---- phase split + per-kernel HIP-event profile: extra steps, same work -----
+    psteps = max(2, min(steps, 5))
+    timer = Timer(torch)
+    for _ in range(psteps):
+        step(timer)
+    phases_ms = {k: round(1e3 * v / psteps, 4) for k, v in timer.t.items()}
+    kernels = kernel_profile(_lib, step, psteps)
+    torch.cuda.synchronize()
+    alg_bytes = {
+        "classify": B_CLASSIFY_PER_CELL * mesh.num_cells,
+        "assemble_rows": B_UNCUT_CELL * info["n_inside"],
+        "cut_emit": (B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])
+                     + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])) / 2,   # two launches per step
+        "assemble_facets": B_GHOST_FACET * info["n_ghost"],
+    }
+    roof = {}
+    for name, ab in alg_bytes.items():
+        if name in kernels and ab:
+            ach = ab / (kernels[name]["avg_us"] * 1e-6) / 1e9
+            roof[name] = dict(avg_us=round(kernels[name]["avg_us"], 2), algorithmic_bytes=ab,
+                              achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
+    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    roofline = None
+    if dominant is not None:
+        k = kernels[dominant]
+        ab = alg_bytes.get(dominant)
+        ach = None if ab is None else ab / (k["avg_us"] * 1e-6) / 1e9
+        roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=None,
+                        avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,
+                        note="achieved = SURVEY 8d bytes/unit x units of the launch / HIP-event duration on the "
+                             f"launch stream, {psteps} profiled steps right after the timed region; traffic (PMC) "
+                             "is in profiles/ (rocprofv3 --pmc passes), not re-collected per run")
+    out.update(phases_ms=phases_ms,
+               cut_quadrature_points_per_s=(nq_total / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
+                                            if "cut" in phases_ms else None),
+               assemble_matrix_dofs_per_s=(active_total / (1e-3 * phases_ms["assemble_matrix"])
+                                           if "assemble_matrix" in phases_ms else None),
+               kernels={k: {kk: round(vv, 3) for kk, vv in v.items()}
+                        for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
+               roofline=roofline, roofline_by_kernel=roof)
+    return out
 
 
 def main():
@@ -159,138 +288,35 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     os.environ["CFX_DEVICE"] = str(local_rank)
 
-    import cutfemx_amd as cfx
-    from cutfemx_amd import _lib, poisson
-
     n = args.n
-    # ---- inputs resident in HBM before the timed region -----------------------
-    if world == 1:
-        mesh = cfx.Mesh.create_box(3, n)
-        phi_vals = sphere_level_set(torch, n, device)
-        V = cfx.FunctionSpace(mesh, 1)
-        phi_fn = cfx.Function(V, phi_vals)
-        # generous CSR value buffer (<= 27 entries per P1 row on a Kuhn mesh + ghost couplings)
-        nnz_cap = int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000)
-        values_buf = torch.zeros(nnz_cap, device=device, dtype=torch.float64)
-        b_buf = torch.zeros(mesh.num_nodes, device=device, dtype=torch.float64)
-
-        def step(timer=None):
-            return hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, args.order, timer)
-    else:
-        # z-slabs weighted by active cells, one rank per GPU, RCCL row reduction
-        from cutfemx_amd import dist as cdist
-        part = cdist.SlabPartition.create(n, world, rank)
-        dp = cdist.DistributedPoisson(part, device, order=args.order)
-        mesh = dp.mesh
-
-        def step(timer=None):
-            if timer is not None:
-                return timer.run("step", dp.step)
-            return dp.step()
-
-    for _ in range(args.warmup):
-        info = step()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        info = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        c = torch.tensor([float(info["active_dofs_owned"] if "active_dofs_owned" in info else info["active_dofs"]),
-                          float(info["nq_volume"] + info["nq_interface"])], device=device, dtype=torch.float64)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        active_total, nq_total = float(c[0].item()), float(c[1].item())
-    else:
-        active_total = float(info["active_dofs"])
-        nq_total = float(info["nq_volume"] + info["nq_interface"])
-    ms_per_step = 1e3 * elapsed / args.steps
-
-    # ---- phase split + per-kernel HIP-event profile (extra steps, same work) ---
-    timer = Timer(torch)
-    psteps = max(2, min(args.steps, 5))
-    for _ in range(psteps):
-        step(timer)
-    phases_ms = {k: round(1e3 * v / psteps, 4) for k, v in timer.t.items()}
-    _lib.check(_lib.lib().cfx_profile_enable(1))
-    _lib.check(_lib.lib().cfx_profile_reset())
-    for _ in range(psteps):
-        step()
-    torch.cuda.synchronize()
-    import ctypes as C
-    kernels = {}
-    for i in range(_lib.lib().cfx_profile_count()):
-        name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
-        _lib.check(_lib.lib().cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
-        if cnt.value:
-            kernels[name.value.decode()] = dict(total_ms=ms.value / psteps, launches=cnt.value / psteps,
-                                                avg_us=1e3 * ms.value / cnt.value)
-    _lib.check(_lib.lib().cfx_profile_enable(0))
-
-    ncells = mesh.num_cells
-    info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
-    alg_bytes = {
-        "classify": B_CLASSIFY_PER_CELL * ncells,
-        "assemble_cells_std": B_UNCUT_CELL * info["n_inside"],
-        "cut_emit": B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"]) / 2
-        + B_QUAD_PER_CUT_CELL * info["n_vol_rules"],
-        "assemble_facets": B_GHOST_FACET * info["n_ghost"],
-    }
-    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
-    roofline = None
-    if dominant is not None:
-        ab = alg_bytes.get(dominant)
-        k = kernels[dominant]
-        ach = None if ab is None else ab / (k["avg_us"] * 1e-6) / 1e9
-        roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=None,
-                        avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,
-                        measured="HIP events on the launch stream, %d profiled steps after the timed region" % psteps)
-    # also report the roofline of every kernel with a SURVEY byte model
-    roof_all = {}
-    for name, ab in alg_bytes.items():
-        if name in kernels and ab:
-            roof_all[name] = dict(avg_us=round(kernels[name]["avg_us"], 2),
-                                  achieved_GBs=round(ab / (kernels[name]["avg_us"] * 1e-6) / 1e9, 1),
-                                  frac=round(ab / (kernels[name]["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4))
-
+    m = measure(n, args.steps, args.warmup, args.order, world, rank, device)
     out = {
-        "metric": "assembled DOFs/sec (active dofs / full hot-path step), Poisson P1 sphere level-set",
-        "value": active_total / (elapsed / args.steps),
-        "unit": "DOF/s",
+        "metric": "assembled DOFs/sec (active dofs / full hot-path step) + cut-quadrature points/sec, "
+                  "Poisson P1 sphere level-set",
+        "value": m["value"], "unit": "DOF/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
+        "ms_per_step": m["ms_per_step"],
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"3D Poisson P1, sphere level set on {n}^3 background mesh "
-                               f"({6 * n ** 3} tets), Nitsche + ghost penalty, order {args.order}",
-                   "cells": 6 * n ** 3, "parallelism": "1 gpu" if world == 1 else f"z-slabs x{world}, halo 3 layers, RCCL p2p row reduction"},
-        "cut_quadrature_points_per_s": nq_total / (1e-3 * (phases_ms.get("cut", 0) + phases_ms.get("rules+facets+forms", 0)))
-        if phases_ms.get("cut") else None,
-        "assemble_matrix_dofs_per_s": active_total / (1e-3 * phases_ms["assemble_matrix"]) if phases_ms.get("assemble_matrix") else None,
-        "counts": {k: int(v) for k, v in info.items()},
-        "phases_ms": phases_ms,
-        "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
-        "roofline": roofline,
-        "roofline_by_kernel": roof_all,
+        "config": {"workload": f"3D Poisson P1, sphere level set on {n}^3 background mesh ({6 * n ** 3} tets), "
+                               f"Nitsche + ghost penalty, runtime quadrature order {args.order}; one step = cut + "
+                               "rules + sparsity + assemble_matrix + assemble_vector + deactivation",
+                   "cells": 6 * n ** 3, "active_dofs": m["active_dofs"],
+                   "parallelism": "1 gpu" if world == 1 else f"z-slabs x{world}, halo 3 layers, RCCL p2p row "
+                                                             "reduction"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cn = args.cpu_n or min(n, 128)
-        cb = cpu_baseline(cn, args.order)
-        cb["host_cores_available"] = os.cpu_count()
-        out["cpu_baseline"] = cb
+    for k in ("cut_quadrature_points_per_s", "assemble_matrix_dofs_per_s", "counts", "phases_ms", "kernels",
+              "roofline", "roofline_by_kernel"):
+        out[k] = m.get(k)
+    if rank == 0 and world == 1:
+        if not args.no_secondary and n != 128:
+            s = measure(128, 20, 3, args.order, 1, 0, device, profile=False)
+            out["config_128"] = {"workload": "configs[1]: 128^3 background mesh, same form", "value": s["value"],
+                                 "unit": "DOF/s", "ms_per_step": s["ms_per_step"], "active_dofs": s["active_dofs"]}
+        out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

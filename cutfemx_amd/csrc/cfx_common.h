@@ -295,6 +295,8 @@ struct cfx_space_s
   cfx::Adjacency d2c; // dof -> cells
   const cfx::Adjacency& dof_cells()
   {
+    // a P1 space whose dofmap aliases the geometry dofmap shares the mesh's vertex->cells table
+    if (dofmap.p == mesh->conn.p && ndofs == mesh->nnodes) return mesh->vertex_cells();
     if (!d2c.built) cfx::build_adjacency(dofmap.p, mesh->ncells, ndofs_cell, ndofs, d2c);
     return d2c;
   }

@@ -286,9 +286,8 @@ def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, in
         raise NotImplementedError("ghost_penalty_facets currently supports depth=1.")
     p, n = C.c_void_p(), C.c_int64()
     _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, selector.encode(), C.byref(p), C.byref(n)))
-    rows = FacetRows(p.value, n.value, cut_data)
-    _ = rows.rows  # the device buffer is reused by the next call: snapshot now
-    return rows
+    # the rows stay in HBM (owned by cut_data until update()/destruction); .rows downloads on demand
+    return FacetRows(p.value, n.value, cut_data)
 
 
 class QuadratureFunction:

@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <array>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -116,7 +117,18 @@ inline dim3 grid_for(int64_t n, int block = 256)
 }
 
 // ---------------------------------------------------------------------------
-// device arrays: owning (stream-ordered allocation) or aliasing a caller pointer
+// HBM block cache.  All work is issued in order on one stream, so a block
+// released on the host can be handed to a later launch without an event.
+// (ROCm 7.2's stream-ordered pool gives memory back at every synchronisation
+// even with the release threshold at its maximum: measured 1.2 ms per 1.6 GB
+// of hipMallocAsync/hipFreeAsync per step, hence this cache.)
+// ---------------------------------------------------------------------------
+void* dev_alloc(size_t bytes);
+void dev_free(void* p);
+void dev_cache_release(); // hipFree every cached block
+
+// ---------------------------------------------------------------------------
+// device arrays: owning (cached blocks) or aliasing a caller pointer
 // ---------------------------------------------------------------------------
 template <typename T>
 struct DevArray
@@ -148,11 +160,11 @@ struct DevArray
     n = count;
     owned = true;
     // never hand out a null pointer for an empty array
-    CFX_HIP(hipMallocAsync((void**)&p, sizeof(T) * (size_t)(count > 0 ? count : 1), ctx().stream));
+    p = static_cast<T*>(dev_alloc(sizeof(T) * (size_t)(count > 0 ? count : 1)));
   }
   void release()
   {
-    if (p && owned) (void)hipFreeAsync(p, ctx().stream);
+    if (p && owned) dev_free(p);
     p = nullptr; n = 0; owned = false;
   }
   void zero() { if (n > 0) CFX_HIP(hipMemsetAsync(p, 0, sizeof(T) * (size_t)n, ctx().stream)); }
@@ -293,6 +305,7 @@ struct cfx_space_s
   int64_t ndofs = 0;
   cfx::DevArray<int32_t> dofmap;
   cfx::Adjacency d2c; // dof -> cells
+  std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   const cfx::Adjacency& dof_cells()
   {
     // a P1 space whose dofmap aliases the geometry dofmap shares the mesh's vertex->cells table
@@ -335,6 +348,10 @@ struct cfx_row_plan
   cfx::DevArray<int32_t> std_rank[4];
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};
+  // identity of the entity lists the plan was built from: (integral index, entities ptr, count,
+  // rules handle, rules count) per integral.  Forms of one space whose cell integrals have the same
+  // identity share the plan (e.g. the bilinear and the linear form of one problem).
+  std::vector<std::array<int64_t, 5>> key_cells, key_facets;
 };
 
 struct cfx_form_s
@@ -342,7 +359,7 @@ struct cfx_form_s
   cfx_space_t V = nullptr;
   int rank = 2;
   std::vector<cfx_integral_dev> integrals;
-  cfx_row_plan plan;
+  std::shared_ptr<cfx_row_plan> plan; // built lazily, possibly shared with another live form
 };
 
 namespace cfx

@@ -591,7 +591,9 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       else vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
     }
   }
-  if (plan.nfacets > 0)
+  bool has_facets = false;
+  for (const auto& I : a->integrals) has_facets = has_facets || I.type == CFX_INTERIOR_FACET;
+  if (has_facets && plan.nfacets > 0)
   {
     A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
     st.buffers.emplace_back(plan.nfacets * (int64_t)(4 * ND * ND));
@@ -674,7 +676,9 @@ bool assemble_vector_rows(cfx_form_s* L, double* b)
 {
   cfx_row_plan& plan = row_plan(L);
   cfx_space_s* V = L->V;
-  if (!plan.usable || V->degree != 1 || V->bs != 1 || plan.nfacets > 0) return false;
+  for (const auto& I : L->integrals)
+    if (I.type == CFX_INTERIOR_FACET) return false;
+  if (!plan.usable || V->degree != 1 || V->bs != 1) return false;
   if (V->mesh->tdim == 2) run_vector<2, 1>(L, b); else run_vector<3, 1>(L, b);
   return true;
 }

@@ -327,9 +327,38 @@ namespace cfx
 
 cfx_row_plan& row_plan(cfx_form_s* a)
 {
-  cfx_row_plan& P = a->plan;
-  if (P.built) return P;
+  if (a->plan) return *a->plan;
   cfx_space_s* V = a->V;
+  // identity of this form's entity lists
+  std::vector<std::array<int64_t, 5>> key_cells, key_facets;
+  for (size_t ii = 0; ii < a->integrals.size(); ++ii)
+  {
+    const cfx_integral_dev& I = a->integrals[ii];
+    const std::array<int64_t, 5> k{(int64_t)ii, I.n_entities > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, I.n_entities,
+                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr : 0};
+    (I.type == CFX_CELL ? key_cells : key_facets).push_back(k);
+  }
+  // Share the plan of another LIVE form of this space built from the same lists
+  // (entity arrays must not change while a form that references them is alive,
+  // so pointer identity implies content identity).  A form without facet
+  // integrals may use a plan that has some: the extra active rows receive zeros.
+  for (auto it = V->plans.begin(); it != V->plans.end();)
+  {
+    std::shared_ptr<cfx_row_plan> p = it->lock();
+    if (!p) { it = V->plans.erase(it); continue; }
+    if (p->key_cells == key_cells && (key_facets.empty() || p->key_facets == key_facets)
+        && (a->rank == 1 || p->key_facets == key_facets))
+    {
+      a->plan = p;
+      return *a->plan;
+    }
+    ++it;
+  }
+  a->plan = std::make_shared<cfx_row_plan>();
+  cfx_row_plan& P = *a->plan;
+  P.key_cells = key_cells;
+  P.key_facets = key_facets;
+  V->plans.push_back(a->plan);
   const int nd = V->ndofs_cell;
   const int64_t nc = V->mesh->ncells;
   P.usable = true;

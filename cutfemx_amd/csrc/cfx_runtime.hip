@@ -22,15 +22,6 @@ void Context::ensure()
   if (device < 0) device = 0;
   if (device >= n) throw Error(CFX_ERR_HIP, "cutfemx_amd: device index out of range");
   CFX_HIP(hipSetDevice(device));
-  // keep freed temporaries in the stream-ordered pool instead of returning them
-  // to the driver at every synchronisation
-  hipMemPool_t pool;
-  if (hipDeviceGetDefaultMemPool(&pool, device) == hipSuccess)
-  {
-    uint64_t threshold = UINT64_MAX;
-    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
-  }
-  (void)hipGetLastError();
   initialised = true;
 }
 
@@ -70,6 +61,77 @@ void Context::flush_profile()
     event_pool.push_back(p.b);
   }
   pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+// HBM block cache (see cfx_common.h)
+// ---------------------------------------------------------------------------
+namespace
+{
+struct BlockCache
+{
+  std::multimap<size_t, void*> free_blocks; // size -> block
+  std::map<void*, size_t> live;             // block -> size
+  size_t cached = 0;
+};
+BlockCache& cache()
+{
+  static BlockCache c;
+  return c;
+}
+size_t round_size(size_t bytes)
+{
+  const size_t g = bytes < (1u << 20) ? 4096 : (size_t)2 << 20; // 4 KiB / 2 MiB granules
+  return (bytes + g - 1) / g * g;
+}
+} // namespace
+
+void* dev_alloc(size_t bytes)
+{
+  BlockCache& c = cache();
+  const size_t want = round_size(bytes > 0 ? bytes : 1);
+  // best fit that does not waste more than half of the block
+  auto it = c.free_blocks.lower_bound(want);
+  if (it != c.free_blocks.end() && it->first <= want + want / 2 + ((size_t)4 << 20))
+  {
+    void* p = it->second;
+    c.live[p] = it->first;
+    c.cached -= it->first;
+    c.free_blocks.erase(it);
+    return p;
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess)
+  {
+    (void)hipGetLastError();
+    dev_cache_release(); // out of memory: give the cached blocks back and retry once
+    e = hipMalloc(&p, want);
+    if (e != hipSuccess) throw Error(CFX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+  }
+  c.live[p] = want;
+  return p;
+}
+
+void dev_free(void* p)
+{
+  if (!p) return;
+  BlockCache& c = cache();
+  auto it = c.live.find(p);
+  if (it == c.live.end()) return; // not ours
+  c.free_blocks.emplace(it->second, p);
+  c.cached += it->second;
+  c.live.erase(it);
+}
+
+void dev_cache_release()
+{
+  BlockCache& c = cache();
+  if (c.free_blocks.empty()) return;
+  (void)hipStreamSynchronize(ctx().stream); // a cached block may still be in use by queued work
+  for (auto& kv : c.free_blocks) (void)hipFree(kv.second);
+  c.free_blocks.clear();
+  c.cached = 0;
 }
 
 bool is_device_pointer(const void* p)
@@ -282,7 +344,7 @@ int cfx_device_alloc(void** ptr, size_t bytes)
 {
   CFX_API_BEGIN
   ctx().ensure();
-  CFX_HIP(hipMalloc(ptr, bytes > 0 ? bytes : 1));
+  *ptr = dev_alloc(bytes); // cached blocks: a real hipMalloc/hipFree pair per step costs milliseconds
   CFX_API_END
 }
 
@@ -290,7 +352,7 @@ int cfx_device_free(void* ptr)
 {
   CFX_API_BEGIN
   ctx().ensure();
-  CFX_HIP(hipFree(ptr));
+  dev_free(ptr);
   CFX_API_END
 }
 

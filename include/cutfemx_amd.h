@@ -100,7 +100,10 @@ typedef struct
  * tuple of python/cutfemx/fem.py:346-351 with the kernel selected by id.
  * `entities` are the standard (uncut) entities, `rules` the runtime (cut)
  * entities of the same measure -- the [inside_cells, rules] measure of
- * python/demo/demo_poisson.py:143-147. */
+ * python/demo/demo_poisson.py:143-147.
+ * Entity / rule / point_data arrays given as DEVICE pointers are aliased: they
+ * must stay allocated and unchanged while any form created from them is alive
+ * (forms of one space that reference the same arrays share derived tables). */
 typedef struct
 {
   int32_t type;            /* CFX_CELL | CFX_INTERIOR_FACET                    */

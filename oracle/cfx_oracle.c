@@ -1136,10 +1136,17 @@ int orc_create_sparsity(const orc_mesh* mesh, const orc_space* V,
     {
       ptr = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nrows + 1));
       ptr[0] = 0;
-      for (int64_t r = 0; r < nrows; ++r) ptr[r + 1] = ptr[r] + cnt[r] + 1;
+      /* the all-rows diagonal is a bs x bs BLOCK: DOLFINx patterns are in block-index space
+         (insert_diagonal on the blocked index map, assembler.h:538-560) */
+      for (int64_t r = 0; r < nrows; ++r) ptr[r + 1] = ptr[r] + cnt[r] + V->bs;
       cols = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ptr[nrows] + 1));
       fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nrows + 1));
-      for (int64_t r = 0; r < nrows; ++r) { cols[ptr[r]] = (int32_t)r; fill[r] = ptr[r] + 1; }
+      for (int64_t r = 0; r < nrows; ++r)
+      {
+        const int64_t dof = r / V->bs;
+        for (int b = 0; b < V->bs; ++b) cols[ptr[r] + b] = (int32_t)(dof * V->bs + b);
+        fill[r] = ptr[r] + V->bs;
+      }
     }
     for (int ii = 0; ii < n_integrals; ++ii)
     {

@@ -1,0 +1,224 @@
+"""GPU parity beyond scalar P1: P2 spaces over a P1 level set (BASELINE configs
+4/5 as parity cases), vector-valued elasticity, Dirichlet markers, runtime-vs-
+standard assembly on whole-cell rules, and the reference's error classes."""
+import numpy as np
+import pytest
+
+from helpers import level_set_values, rel_err
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+
+
+def setup(oracle, tdim, n, degree, bs, kind="sphere"):
+    import cutfemx_amd as cfx
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim, kind)
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, degree)
+    oV = O.Space(dofmap, ndofs, degree, bs)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, degree, dofmap=None if degree == 1 else dofmap, ndofs=ndofs, bs=bs)
+    Vphi = V if (degree == 1 and bs == 1) else cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(Vphi, phi))
+    dom = O.classify(om.conn, phi)
+    return dict(O=O, om=om, phi=phi, oV=oV, mesh=mesh, V=V, cd=cd, dom=dom)
+
+
+def compare_forms(s, o_integrals, g_integrals, rank=2):
+    import cutfemx_amd as cfx
+    O, om, oV = s["O"], s["om"], s["oV"]
+    a = cfx.fem.form(g_integrals, s["V"])
+    if rank == 2:
+        ip, ix = O.create_sparsity(om, oV, o_integrals)
+        want = O.assemble_matrix(om, oV, o_integrals, ip, ix)
+        A = cfx.fem.assemble_matrix(a)
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
+        assert rel_err(A.data, want) < RTOL
+        return A
+    want = O.assemble_vector(om, oV, o_integrals)
+    b = cfx.fem.assemble_vector(a)
+    assert rel_err(b, want) < RTOL
+    return b
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 12), (3, 6)])
+def test_p2_scalar_poisson_with_ghost_penalty(oracle, tdim, n):
+    import cutfemx_amd as cfx
+    s = setup(oracle, tdim, n, 2, 1)
+    O, om, dom, cd = s["O"], s["om"], s["dom"], s["cd"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 4)
+    oitf = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi=0", 4)
+    onrm = O.evaluate_normals(om, om.conn, s["phi"], oitf)
+    oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    itf = cfx.runtime_quadrature(cd, "phi=0", 4)
+    nrm = cfx.normal(cd, itf)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    oa = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=ovol, qdegree=2),
+          O.Integral(O.CELL, O.K_MASS, entities=inside, rules=ovol, qdegree=4),
+          O.Integral(O.CELL, O.K_NITSCHE, rules=oitf, point_data=onrm, params=(40.0,)),
+          O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.1,), qdegree=2)]
+    ga = [cfx.fem.Integral(cfx.fem.STIFFNESS, cells=inside, rules=vol, qdegree=2),
+          cfx.fem.Integral(cfx.fem.MASS, cells=inside, rules=vol, qdegree=4),
+          cfx.fem.Integral(cfx.fem.NITSCHE, rules=itf, point_data=nrm, params=(40.0,)),
+          cfx.fem.Integral(cfx.fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)]
+    A = compare_forms(s, oa, ga)
+    M = A.to_scipy()
+    assert abs(M - M.T).max() < 1e-10 * abs(M).max()
+    oL = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=ovol, params=(O.F_POISSON_RHS, 1.0), qdegree=4),
+          O.Integral(O.CELL, O.L_NITSCHE_RHS, rules=oitf, point_data=onrm, params=(40.0, O.F_SINPROD, 1.0))]
+    gL = [cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, rules=vol, params=(cfx.fem.F_POISSON_RHS, 1.0), qdegree=4),
+          cfx.fem.Integral(cfx.fem.NITSCHE_RHS, rules=itf, point_data=nrm, params=(40.0, cfx.fem.F_SINPROD, 1.0))]
+    compare_forms(s, oL, gL, rank=1)
+    # local tensors of a cut P2 cell and of a facet
+    a = cfx.fem.form(ga, s["V"])
+    for integral, idx, use_rule in [(0, 0, True), (1, ovol.parent_map.size // 2, True), (0, len(inside) // 2, False),
+                                    (3, len(oghost) // 2, False)]:
+        got = cfx.fem.tabulate_entity(a, integral, idx, use_rule)
+        want = O.tabulate_entity(om, s["oV"], oa[integral], idx, use_rule)
+        assert rel_err(got, want) < RTOL
+
+
+@pytest.mark.parametrize("tdim,n,degree", [(2, 10, 1), (3, 6, 1), (3, 4, 2)])
+def test_vector_elasticity(oracle, tdim, n, degree):
+    # python/demo/demo_elasticity.py:167-238 (E = 1e3, nu = 0.3), vector space bs = gdim
+    import cutfemx_amd as cfx
+    s = setup(oracle, tdim, n, degree, tdim)
+    O, om, dom, cd = s["O"], s["om"], s["dom"], s["cd"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 2)
+    vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+    q = 2 * (degree - 1)
+    oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=inside, rules=ovol, params=(1.0e3, 0.3), qdegree=q),
+          O.Integral(O.CELL, O.K_MASS, entities=inside, rules=ovol, qdegree=2 * degree)]
+    ga = [cfx.fem.Integral(cfx.fem.ELASTICITY, cells=inside, rules=vol, params=(1.0e3, 0.3), qdegree=q),
+          cfx.fem.Integral(cfx.fem.MASS, cells=inside, rules=vol, qdegree=2 * degree)]
+    A = compare_forms(s, oa, ga)
+    M = A.to_scipy()
+    assert abs(M - M.T).max() < 1e-10 * abs(M).max()
+    # rigid translations lie in the null space of the elasticity block alone
+    a_el = cfx.fem.form(ga[:1], s["V"])
+    K = cfx.fem.assemble_matrix(a_el).to_scipy()
+    t = np.zeros(K.shape[0]); t[0::tdim] = 1.0
+    assert np.abs(K @ t).max() < 1e-9 * abs(K).max()
+    dom_a = cfx.fem.active_domain(a_el)
+    active = O.active_cells(oa[:1], om.ncells)
+    assert np.array_equal(dom_a.active_cells, active)
+    assert np.array_equal(dom_a.inactive_dofs, O.inactive_dofs(s["oV"], active))
+
+
+@pytest.mark.parametrize("mode", ["rows", "atomic"])
+def test_dirichlet_markers_zero_rows_and_columns(oracle, mode, monkeypatch):
+    # assemble_matrix_impl.h:151-185
+    import cutfemx_amd as cfx
+    if mode == "atomic":
+        monkeypatch.setenv("CFX_ASSEMBLY", "atomic")
+    s = setup(oracle, 3, 6, 1, 1)
+    O, om, dom, cd = s["O"], s["om"], s["dom"], s["cd"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 2)
+    oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    oa = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=ovol, qdegree=0),
+          O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.1,), qdegree=0)]
+    ga = [cfx.fem.Integral(cfx.fem.STIFFNESS, cells=inside, rules=vol, qdegree=0),
+          cfx.fem.Integral(cfx.fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=0)]
+    bc = np.zeros(om.nnodes, dtype=np.int8)
+    touched = np.unique(om.conn[inside])
+    bc[touched[::7]] = 1
+    ip, ix = O.create_sparsity(om, s["oV"], oa)
+    want = O.assemble_matrix(om, s["oV"], oa, ip, ix, bc, bc)
+    A = cfx.fem.assemble_matrix(cfx.fem.form(ga, s["V"]), bcs=bc)
+    assert rel_err(A.data, want) < RTOL
+    M = A.to_scipy().toarray()
+    assert np.all(M[bc == 1, :] == 0) and np.all(M[:, bc == 1] == 0)
+
+
+@pytest.mark.parametrize("kernel,order,tol", [("stiffness", 2, 1e-12), ("mass", 2, 1e-12), ("elasticity", 2, 1e-9)])
+def test_runtime_vs_standard_matrix_on_gpu(oracle, kernel, order, tol):
+    # test_assembly_poisson.py:18-59, test_assembly_elasticity.py:18-68: whole-cell runtime
+    # rules (reference points, weights*|detJ|) reproduce the standard assembly
+    import cutfemx_amd as cfx
+    tdim, n = 2, 4
+    om = oracle.mesh_box(tdim, n)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    bs = 2 if kernel == "elasticity" else 1
+    V = cfx.FunctionSpace(mesh, 1, bs=bs)
+    cells = np.arange(om.ncells, dtype=np.int32)
+    rules = cfx.full_cell_rules(mesh, cells, order)
+    k, params = {"stiffness": (cfx.fem.STIFFNESS, ()), "mass": (cfx.fem.MASS, ()),
+                 "elasticity": (cfx.fem.ELASTICITY, (1.0e3, 0.3))}[kernel]
+    A = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(k, cells=cells, params=params, qdegree=order)], V))
+    B = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(k, rules=rules, params=params)], V))
+    assert np.array_equal(A.indptr, B.indptr) and np.array_equal(A.indices, B.indices)
+    assert np.linalg.norm(A.data - B.data) < tol
+    # unsorted caller-supplied rules go through the entity-parallel path and agree too
+    perm = np.random.default_rng(20260630).permutation(om.ncells)
+    r2 = cfx.RuntimeQuadratureRules.from_arrays(
+        mesh, rules.points.reshape(om.ncells, -1, tdim)[perm].reshape(-1, tdim),
+        rules.weights.reshape(om.ncells, -1)[perm].ravel(), rules.offsets, rules.parent_map[perm])
+    Cm = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(k, rules=r2, params=params)], V))
+    assert rel_err(Cm.data, A.data) < 1e-12
+
+
+def test_reference_error_classes(oracle):
+    # test_cut_api.py:214-233,252,1321-1333: ValueError / RuntimeError / IndexError surface
+    import cutfemx_amd as cfx
+    om = oracle.mesh_box(2, 4)
+    mesh = cfx.Mesh.from_arrays(2, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    f = cfx.Function(V, level_set_values(om.x, 2))
+    cd = cfx.cut(f)
+    with pytest.raises(ValueError):
+        cfx.locate_entities(cd, "psi<0")
+    with pytest.raises(ValueError):
+        cfx.locate_entities(cd, "phi<")
+    with pytest.raises(ValueError):
+        cfx.locate_entities(cd, "phi1<0")          # only one level set was cut
+    with pytest.raises(ValueError):
+        cfx.runtime_quadrature(cd, "phi<0", 4, backend="algoim")
+    with pytest.raises(ValueError):
+        cfx.runtime_quadrature(cd, "phi<0", -1)
+    with pytest.raises(ValueError):
+        cfx.cut([])
+    with pytest.raises(TypeError):
+        cfx.cut("phi")
+    with pytest.raises(NotImplementedError):
+        cfx.ghost_penalty_facets(cd, "phi<0", depth=2)
+    L = cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=np.arange(4, dtype=np.int32), params=(0, 1.0))], V)
+    with pytest.raises(RuntimeError):
+        cfx.fem.create_matrix(L)                   # "Form is not a bilinear" (assembler.h:570-574)
+    with pytest.raises(ValueError):
+        cfx.fem.active_domain(L)                   # rank-2 required (deactivate.h:80-85)
+    a = cfx.fem.form([cfx.fem.Integral(cfx.fem.MASS, cells=np.arange(4, dtype=np.int32))], V)
+    with pytest.raises(IndexError):
+        cfx.fem.tabulate_entity(a, 0, 99, False)
+    # two level sets: selector algebra on the device
+    f1 = cfx.Function(V, om.x[:, 0] - 0.5)
+    cd2 = cfx.cut([f, f1])
+    dom = np.stack([cd2.domain(0), cd2.domain(1)])
+    assert np.array_equal(cfx.locate_entities(cd2, "phi<0 and phi1>0"),
+                          oracle.locate_entities(dom, "phi<0 and phi1>0"))
+
+
+def test_update_reclassifies(oracle):
+    # cutfemx.update(): cut.cpp:845-868, python/demo/demo_moving_poisson.py:53-67
+    import cutfemx_amd as cfx
+    om = oracle.mesh_box(3, 8)
+    mesh = cfx.Mesh.from_arrays(3, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    f = cfx.Function(V, level_set_values(om.x, 3))
+    cd = cfx.cut(f)
+    before = cfx.locate_entities(cd, "phi=0")
+    f.values = np.linalg.norm(om.x - np.array([0.55, 0.5, 0.45]), axis=1) - 0.27
+    cfx.update(cd)
+    dom = oracle.classify(om.conn, f.values)
+    assert np.array_equal(cd.domain(), dom)
+    after = cfx.locate_entities(cd, "phi=0")
+    assert np.array_equal(after, oracle.locate_entities(dom, "phi=0")) and not np.array_equal(before, after)
+    r = cfx.runtime_quadrature(cd, "phi<0", 2)
+    want = oracle.runtime_quadrature(om, om.conn, f.values, dom, "phi<0", 2)
+    assert np.array_equal(r.parent_map, want.parent_map) and rel_err(r.weights, want.weights) < RTOL

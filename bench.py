@@ -20,7 +20,7 @@ MI355X (~60 GB), so N=1 runs it whole and N>1 strong-scales it over z-slabs.
 metric (BASELINE.json): assembled DOFs/s = active dofs / step time (whole job);
 cut-quadrature points/s and per-phase times are reported beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 512] [--order 4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mesh 512] [--order 4]
 """
 from __future__ import annotations
 
@@ -51,7 +51,8 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=10)
     p.add_argument("--warmup", type=int, default=2)
-    p.add_argument("--n", type=int, default=512, help="background mesh n^3 cubes (x6 tets)")
+    p.add_argument("--mesh", "--n", dest="n", type=int, default=512,
+                   help="background mesh n^3 cubes (x6 tets); use --mesh under torchrun (--n is ambiguous there)")
     p.add_argument("--order", type=int, default=4, help="runtime quadrature order (demo_poisson.py:139)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-n", type=int, default=160, help="mesh size of the bounded CPU sample")
@@ -199,6 +200,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
             return dp.step() if timer is None else timer.run("step", dp.step)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -213,11 +215,12 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     elapsed = time.perf_counter() - t0
     info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        cdev = device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         c = torch.tensor([float(info["active_dofs_owned"]), float(info["nq_volume"] + info["nq_interface"])],
-                         device=device, dtype=torch.float64)
+                         device=cdev, dtype=torch.float64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         active_total, nq_total = float(c[0].item()), float(c[1].item())
     else:
@@ -282,10 +285,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: cutfemx_amd has no CPU fallback")
+    # rehearsal on a one-GPU box: CFX_REHEARSE=1 puts every rank on cuda:0 and uses gloo
+    # (RCCL cannot place two ranks on one device); never set on the real multi-GPU run
+    rehearse = os.environ.get("CFX_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     os.environ["CFX_DEVICE"] = str(local_rank)
 
     n = args.n

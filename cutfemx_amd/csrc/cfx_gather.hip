@@ -32,6 +32,9 @@ namespace
 {
 
 constexpr int kWave = 64;
+#ifndef CFX_ROW_BLOCK
+#define CFX_ROW_BLOCK (int64_t) blockIdx.x // xcd_block_id(): XCD-contiguous row chunks
+#endif
 #ifndef CFX_ROWS_WAVES
 #define CFX_ROWS_WAVES 5 // waves per SIMD the gather kernel is compiled for (measured: 4 -> 2.27, 5 -> 2.09, 6 -> 2.58 ms at 256^3)
 #endif
@@ -207,7 +210,7 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
   __shared__ double s_val[RPW][CAP];
   __shared__ double s_x[ISO ? RPW : 1][ISO ? CAP : 1][TDIM];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
   const bool live = ri < A.n_active;
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t rb = live ? A.indptr[r] : 0;
@@ -265,35 +268,35 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
   {
     constexpr int NC = decltype(nc_tag)::value;
     if (A.debug & 1) { if (has && acc[0] == 1.2345e300) *A.error = 3; return; } // ablation: no reduction
-    if (has)
-    {
-      // zero BC rows / columns: assemble_matrix_impl.h:151-185
+    // (slot, value) pairs of this lane's item; BC rows / columns are zeroed here
+    // (assemble_matrix_impl.h:151-185)
+    double v[NC];
+    int s[NC];
 #pragma unroll
-      for (int j = 0; j < NC; ++j)
-        if (row_bc || (A.bc1 && A.bc1[cols[j]])) acc[j] = 0.0;
+    for (int j = 0; j < NC; ++j)
+    {
+      s[j] = has ? sl[j] : -1;
+      const bool bc = has && (row_bc || (A.bc1 != nullptr && A.bc1[cols[j]] != 0));
+      v[j] = bc ? 0.0 : acc[j];
     }
     if constexpr (ORDERED)
     {
-      volatile double* val = s_val[grp];
-      for (int turn = 0; turn < G; ++turn) // one lane of each group at a time
+      for (int turn = 0; turn < G; ++turn) // one lane of each group at a time: item order
       {
-        if (__ballot(has && gl == turn) == 0) continue;
-        if (has && gl == turn)
+        if (gl == turn)
         {
 #pragma unroll
           for (int j = 0; j < NC; ++j)
-            if (sl[j] >= 0) val[sl[j]] += acc[j];
+            if (s[j] >= 0) s_val[grp][s[j]] += v[j];
         }
+        __syncthreads(); // block = one wavefront: orders the LDS read-modify-writes of successive turns
       }
     }
     else
     {
-      if (has)
-      {
 #pragma unroll
-        for (int j = 0; j < NC; ++j)
-          if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
-      }
+      for (int j = 0; j < NC; ++j)
+        if (s[j] >= 0) atomicAdd(&s_val[grp][s[j]], v[j]);
     }
   };
 
@@ -458,7 +461,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int RPW = kWave / G;
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
   const bool live = ri < A.n_active && A.cellmark != nullptr;
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t cb = live ? A.d2c_off[r] : 0;

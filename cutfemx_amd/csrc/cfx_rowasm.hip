@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   __shared__ int32_t s_list[RPW][T];
   __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = xcd_block_id() * RPW + grp;
+  const int64_t ri = (int64_t)blockIdx.x * RPW + grp; // (XCD-contiguous chunks measured slower: 5.95 vs 6.0 ms here, 12.6 vs 14.5 ms in the gather)
   const bool live = ri < P.n_active;
   const int64_t r = live ? P.active_rows[ri] : 0;
   for (int k = gl; k < T; k += G) s_tab[grp][k] = -1;

@@ -222,3 +222,24 @@ def test_update_reclassifies(oracle):
     r = cfx.runtime_quadrature(cd, "phi<0", 2)
     want = oracle.runtime_quadrature(om, om.conn, f.values, dom, "phi<0", 2)
     assert np.array_equal(r.parent_map, want.parent_map) and rel_err(r.weights, want.weights) < RTOL
+
+
+def test_deterministic_mode_is_bitwise_reproducible(oracle, monkeypatch):
+    # CFX_DETERMINISTIC=1: lane-ordered LDS reduction + sorted facet lists; two assemblies of
+    # the same system must agree bit for bit (the default LDS-atomic reduction only to round-off)
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    monkeypatch.setenv("CFX_DETERMINISTIC", "1")
+    om = oracle.mesh_box(3, 14)
+    mesh = cfx.Mesh.from_arrays(3, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    phi = level_set_values(om.x, 3)
+    runs = []
+    for _ in range(3):
+        cd = cfx.cut(cfx.Function(V, phi))
+        s = poisson.build_forms(V, cd)
+        A = cfx.fem.assemble_matrix(s.a)
+        b = cfx.fem.assemble_vector(s.L)
+        runs.append((A.data.copy(), b.copy()))
+    for vals, b in runs[1:]:
+        assert np.array_equal(vals, runs[0][0]) and np.array_equal(b, runs[0][1])

@@ -557,20 +557,39 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   // deactivate.h:80-85
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain requires a rank-2 bilinear CutForm");
   cfx_space_s* V = a->V;
-  DevArray<uint8_t> mark;
-  bool any = false;
-  collect_cell_marks(a, true, mark, any);
   auto d = std::make_unique<cfx_active_s>();
   d->V = V;
-  d->n_active = compact_bytes("active_cells", V->mesh->ncells, mark.p, ByteNonZero{}, d->active_cells);
+  // The row plan of the form already holds both indicators: cellmark (cells of
+  // every cell integral, standard or runtime) and rowmark (dofs touched by any
+  // entity) -- collect_active_cells / build_active_indicator of deactivate.h:103-183.
+  cfx_row_plan& plan = row_plan(a);
+  const int64_t nc = V->mesh->ncells;
+  if (plan.nfacets == 0)
+    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells);
+  else
+  {
+    // facet integrals contribute both of their cells (deactivate.h:138-146)
+    DevArray<uint8_t> mark((nc + 3) & ~3LL);
+    CFX_HIP(hipMemcpyAsync(mark.p, plan.cellmark.p, (size_t)nc, hipMemcpyDeviceToDevice, ctx().stream));
+    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets), dim3(kBlock), 0, plan.nfacets, plan.facet_rows.p, 4,
+           mark.p);
+    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets), dim3(kBlock), 0, plan.nfacets,
+           plan.facet_rows.p + 2, 4, mark.p);
+    d->n_active = compact_bytes("active_cells", nc, mark.p, ByteNonZero{}, d->active_cells);
+  }
   // deactivate.h:155-160
   require(d->n_active > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
   const int64_t nrows = V->ndofs * V->bs;
-  DevArray<uint8_t> ind(nrows);
-  ind.zero();
-  launch("mark_dofs", mark_dofs_kernel, grid_for(d->n_active * V->ndofs_cell), dim3(kBlock), 0, d->n_active,
-         d->active_cells.p, V->dofmap.p, V->ndofs_cell, V->bs, ind.p);
-  d->n_inactive = compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs);
+  if (V->bs == 1)
+    d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs);
+  else
+  {
+    DevArray<uint8_t> ind(nrows);
+    ind.zero();
+    launch("mark_dofs", mark_dofs_kernel, grid_for(d->n_active * V->ndofs_cell), dim3(kBlock), 0, d->n_active,
+           d->active_cells.p, V->dofmap.p, V->ndofs_cell, V->bs, ind.p);
+    d->n_inactive = compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs);
+  }
   CFX_HIP(hipStreamSynchronize(ctx().stream));
   *out = d.release();
   CFX_API_END

@@ -227,8 +227,12 @@ def test_update_reclassifies(oracle):
 def test_deterministic_mode_is_bitwise_reproducible(oracle, monkeypatch):
     # CFX_DETERMINISTIC=1: lane-ordered LDS reduction + sorted facet lists; two assemblies of
     # the same system must agree bit for bit (the default LDS-atomic reduction only to round-off)
+    import os
+
     import cutfemx_amd as cfx
     from cutfemx_amd import poisson
+    if os.environ.get("CFX_ASSEMBLY") == "atomic":
+        pytest.skip("global FP64 atomics are order dependent by construction")
     monkeypatch.setenv("CFX_DETERMINISTIC", "1")
     om = oracle.mesh_box(3, 14)
     mesh = cfx.Mesh.from_arrays(3, om.x, om.conn)

@@ -1,0 +1,377 @@
+// cutfemx_amd.hpp -- header-only C++ facade over the C ABI (cutfemx_amd.h).
+//
+// Mirrors the C++ surface of the reference for the hot path with the same
+// names, argument meaning and exception classes:
+//   cutfemx::cut / update / locate_entities / runtime_quadrature
+//                                   cpp/cutfemx/cut/cut.h:104-181
+//   cutfemx::RuntimeQuadrature      cpp/cutfemx/cut/runtime_quadrature.h:43-232
+//   dolfinx_custom_data::fem::create_sparsity_pattern / assemble_matrix /
+//   assemble_vector                 cpp/dolfinx_custom_data/fem/assembler.h:252-262,567-592,690-703
+//   cutfemx::fem::active_domain / deactivate_outside
+//                                   cpp/cutfemx/fem/deactivate.h:387-418
+// DOLFINx objects are replaced by the flat arrays the reference reads from them
+// (geometry.x stride 3, int32 dofmaps, dof values); JIT kernel pointers by
+// integrand ids.  Status codes become the exceptions the reference throws:
+// std::invalid_argument, std::runtime_error, std::out_of_range.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <span>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <vector>
+
+#include "cutfemx_amd.h"
+
+namespace cutfemx_amd
+{
+
+inline void check(int rc)
+{
+  if (rc == CFX_OK) return;
+  const std::string msg = cfx_last_error();
+  if (rc == CFX_ERR_INVALID_ARGUMENT) throw std::invalid_argument(msg);
+  if (rc == CFX_ERR_OUT_OF_RANGE) throw std::out_of_range(msg);
+  throw std::runtime_error(msg);
+}
+
+template <typename T>
+inline std::vector<T> download(const T* dev, std::int64_t n)
+{
+  std::vector<T> v(static_cast<std::size_t>(n));
+  if (n > 0) check(cfx_copy(v.data(), dev, sizeof(T) * static_cast<std::size_t>(n)));
+  return v;
+}
+
+namespace detail
+{
+template <typename H, int (*Destroy)(H)>
+struct Handle
+{
+  H h = nullptr;
+  Handle() = default;
+  explicit Handle(H handle) : h(handle) {}
+  Handle(const Handle&) = delete;
+  Handle& operator=(const Handle&) = delete;
+  Handle(Handle&& o) noexcept : h(std::exchange(o.h, nullptr)) {}
+  Handle& operator=(Handle&& o) noexcept
+  {
+    if (this != &o) { reset(); h = std::exchange(o.h, nullptr); }
+    return *this;
+  }
+  ~Handle() { reset(); }
+  void reset() { if (h) { Destroy(h); h = nullptr; } }
+};
+} // namespace detail
+
+/// Background simplex mesh: the cutcells::MeshView of cut.cpp:500-538.
+struct Mesh
+{
+  detail::Handle<cfx_mesh_t, cfx_mesh_destroy> handle;
+  int tdim = 0, gdim = 0;
+  std::int64_t num_nodes = 0, num_cells = 0;
+
+  /// x: geometry.x (stride 3); connectivity: geometry dofmap [ncells x cell_stride]
+  static Mesh create(int tdim, std::span<const double> x, std::span<const std::int32_t> connectivity,
+                     int cell_stride)
+  {
+    Mesh m;
+    cfx_mesh_t h = nullptr;
+    const std::int64_t ncells = static_cast<std::int64_t>(connectivity.size()) / cell_stride;
+    check(cfx_mesh_create(tdim, tdim, static_cast<std::int64_t>(x.size()) / 3, x.data(), ncells,
+                          connectivity.data(), cell_stride, &h));
+    m.handle = detail::Handle<cfx_mesh_t, cfx_mesh_destroy>(h);
+    check(cfx_mesh_info(h, &m.tdim, &m.gdim, &m.num_nodes, &m.num_cells, nullptr, nullptr));
+    return m;
+  }
+  static Mesh create_box(int tdim, int n)
+  {
+    Mesh m;
+    cfx_mesh_t h = nullptr;
+    check(cfx_mesh_create_box(tdim, n, &h));
+    m.handle = detail::Handle<cfx_mesh_t, cfx_mesh_destroy>(h);
+    check(cfx_mesh_info(h, &m.tdim, &m.gdim, &m.num_nodes, &m.num_cells, nullptr, nullptr));
+    return m;
+  }
+  std::vector<double> x() const
+  {
+    const double* p;
+    check(cfx_mesh_info(handle.h, nullptr, nullptr, nullptr, nullptr, &p, nullptr));
+    return download(p, num_nodes * 3);
+  }
+  std::vector<std::int32_t> connectivity() const
+  {
+    const std::int32_t* p;
+    check(cfx_mesh_info(handle.h, nullptr, nullptr, nullptr, nullptr, nullptr, &p));
+    return download(p, num_cells * (tdim + 1));
+  }
+};
+
+/// cutcells::CutOptions as filled by make_cut_options (wrappers/cut.cpp:117-140)
+struct CutOptions
+{
+  int cut_approximation_order = 1;
+  int max_refinement_iterations = 8;
+  int edge_max_depth = 20;
+};
+
+/// cutfemx::CutData<T> (cut.h:31-102): move-only, owns the classification.
+struct CutData
+{
+  detail::Handle<cfx_cut_t, cfx_cut_destroy> handle;
+  int gdim = 0, tdim = 0;
+  std::int32_t num_local_cells = 0;
+  std::vector<std::string> level_set_names;
+
+  /// ParentCellClassification::domain(level_set, cell) for every cell
+  std::vector<std::int8_t> domain(int level_set = 0) const
+  {
+    const std::int8_t* p;
+    check(cfx_cut_domain(handle.h, level_set, &p));
+    return download(p, num_local_cells);
+  }
+};
+
+/// cut(): cut.cpp:743-786.  One P1/P2 Lagrange dofmap shared by the level sets;
+/// level_set_values[k] are the dof values of level set k (host or device pointers).
+inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, int ls_ndofs_cell,
+                   std::int64_t ls_ndofs, std::span<const double* const> level_set_values,
+                   const CutOptions& options = CutOptions{})
+{
+  if (level_set_values.empty())
+    throw std::invalid_argument("cutfemx.cut requires at least one level-set function"); // cut.cpp:97-107
+  cfx_cut_options opt{options.cut_approximation_order, options.max_refinement_iterations, options.edge_max_depth, 0};
+  cfx_cut_t h = nullptr;
+  check(cfx_cut_create(mesh.handle.h, static_cast<int>(level_set_values.size()), ls_dofmap.data(), ls_ndofs_cell,
+                       ls_ndofs, level_set_values.data(), &opt, &h));
+  CutData cd;
+  cd.handle = detail::Handle<cfx_cut_t, cfx_cut_destroy>(h);
+  std::int64_t nc = 0;
+  int nls = 0;
+  check(cfx_cut_info(h, &cd.tdim, &cd.gdim, &nc, &nls));
+  cd.num_local_cells = static_cast<std::int32_t>(nc);
+  for (int k = 0; k < nls; ++k) cd.level_set_names.push_back(k == 0 ? "phi" : "phi" + std::to_string(k));
+  return cd;
+}
+
+/// update(): cut.cpp:845-868 -- re-classify from the current values (same pointers when empty)
+inline void update(CutData& cut_data, std::span<const double* const> level_set_values = {})
+{
+  check(cfx_cut_update(cut_data.handle.h, level_set_values.empty() ? nullptr : level_set_values.data()));
+}
+
+/// locate_entities(): cut.cpp:877-924 -- ascending background cell ids
+inline std::vector<std::int32_t> locate_entities(const CutData& cut_data, std::string_view ls_part)
+{
+  const std::int32_t* p;
+  std::int64_t n;
+  check(cfx_locate_entities(cut_data.handle.h, std::string(ls_part).c_str(), &p, &n));
+  return download(p, n);
+}
+
+/// cutfemx::RuntimeQuadrature<T> (runtime_quadrature.h:43-232).  Arrays stay in HBM;
+/// the accessors download them.
+struct RuntimeQuadrature
+{
+  detail::Handle<cfx_rules_t, cfx_rules_destroy> handle;
+  cfx_rules_view view{};
+
+  int tdim() const { return view.tdim; }
+  int gdim() const { return view.gdim; }
+  std::size_t num_points() const { return static_cast<std::size_t>(view.nq); }
+  std::size_t num_rules() const { return static_cast<std::size_t>(view.nr); }
+  std::vector<double> points() const { return download(view.points, view.nq * view.tdim); }
+  std::vector<double> weights() const { return download(view.weights, view.nq); }
+  std::vector<std::int32_t> offsets() const { return download(view.offsets, view.nr + 1); }
+  std::vector<std::int32_t> parent_map() const { return download(view.parent_map, view.nr); }
+  /// physical_points(): runtime_quadrature.h:102-221, row-major (nq, gdim)
+  std::vector<double> physical_points() const
+  {
+    std::vector<double> out(static_cast<std::size_t>(view.nq * view.gdim));
+    check(cfx_rules_physical_points(handle.h, out.data()));
+    return out;
+  }
+};
+
+/// runtime_quadrature(): cut.cpp:1311-1335
+inline RuntimeQuadrature runtime_quadrature(const CutData& cut_data, std::string_view ls_part, int order,
+                                            std::string_view backend = "straight")
+{
+  cfx_rules_t h = nullptr;
+  check(cfx_runtime_quadrature(cut_data.handle.h, std::string(ls_part).c_str(), order, std::string(backend).c_str(),
+                               &h));
+  RuntimeQuadrature r;
+  r.handle = detail::Handle<cfx_rules_t, cfx_rules_destroy>(h);
+  check(cfx_rules_view_get(h, &r.view));
+  return r;
+}
+
+/// runtime_quadratures(): cut.cpp:1357-1406
+inline std::vector<std::pair<std::string, RuntimeQuadrature>>
+runtime_quadratures(const CutData& cut_data, std::span<const std::string> ls_parts, int order,
+                    std::string_view backend = "straight")
+{
+  std::vector<std::pair<std::string, RuntimeQuadrature>> out;
+  for (const std::string& p : ls_parts) out.emplace_back(p, runtime_quadrature(cut_data, p, order, backend));
+  return out;
+}
+
+/// ghost_penalty_facets() + facet_integration_rows(): python/cutfemx/cut.py:340-380,
+/// wrappers/cut.cpp:54-115 -- rows (cell0, lf0, cell1, lf1), cell0 < cell1
+inline std::vector<std::int32_t> ghost_penalty_facets(const CutData& cut_data, std::string_view selector)
+{
+  const std::int32_t* p;
+  std::int64_t n;
+  check(cfx_ghost_penalty_facets(cut_data.handle.h, std::string(selector).c_str(), &p, &n));
+  return download(p, 4 * n);
+}
+
+namespace level_set
+{
+/// evaluate_normals(): level_set/normal.h:39-187 -- row-major (nq, gdim), always double
+inline std::vector<double> evaluate_normals(const CutData& cut_data, int level_set, const RuntimeQuadrature& rules,
+                                            double sign = 1.0)
+{
+  std::vector<double> out(rules.num_points() * static_cast<std::size_t>(rules.gdim()));
+  check(cfx_evaluate_normals(cut_data.handle.h, level_set, rules.handle.h, sign, out.data()));
+  return out;
+}
+/// evaluate_values(): level_set/value.h:34-119
+inline std::vector<double> evaluate_values(const CutData& cut_data, int level_set, const RuntimeQuadrature& rules)
+{
+  std::vector<double> out(rules.num_points());
+  check(cfx_evaluate_values(cut_data.handle.h, level_set, rules.handle.h, out.data()));
+  return out;
+}
+} // namespace level_set
+
+namespace fem
+{
+
+struct FunctionSpace
+{
+  detail::Handle<cfx_space_t, cfx_space_destroy> handle;
+  int degree = 1, bs = 1, ndofs_cell = 0;
+  std::int64_t ndofs = 0;
+  static FunctionSpace create(const Mesh& mesh, int degree, int bs, std::int64_t ndofs,
+                              std::span<const std::int32_t> dofmap, int ndofs_cell)
+  {
+    cfx_space_t h = nullptr;
+    check(cfx_space_create(mesh.handle.h, degree, bs, ndofs, dofmap.data(), ndofs_cell, &h));
+    FunctionSpace V;
+    V.handle = detail::Handle<cfx_space_t, cfx_space_destroy>(h);
+    V.degree = degree; V.bs = bs; V.ndofs = ndofs; V.ndofs_cell = ndofs_cell;
+    return V;
+  }
+};
+
+/// One integral: the integral_data of Form.h:46-89 with the kernel chosen by id.
+struct Integral
+{
+  int type = CFX_CELL;
+  int kernel = CFX_K_STIFFNESS;
+  std::span<const std::int32_t> entities{};    // cells, or (c0,lf0,c1,lf1) rows
+  const RuntimeQuadrature* rules = nullptr;    // runtime entities of the same measure
+  std::span<const double> point_data{};        // per-point coefficients, row-major
+  int point_stride = 0;
+  std::vector<double> params{};
+  int quadrature_degree = 2;
+};
+
+struct Form
+{
+  detail::Handle<cfx_form_t, cfx_form_destroy> handle;
+  int rank = 2;
+  static Form create(const FunctionSpace& V, int rank, std::span<const Integral> integrals)
+  {
+    std::vector<cfx_integral> raw(integrals.size());
+    for (std::size_t i = 0; i < integrals.size(); ++i)
+    {
+      const Integral& in = integrals[i];
+      cfx_integral& r = raw[i];
+      r = cfx_integral{};
+      r.type = in.type; r.kernel = in.kernel; r.qdegree = in.quadrature_degree; r.point_stride = in.point_stride;
+      r.entities = in.entities.data();
+      r.n_entities = static_cast<std::int64_t>(in.entities.size()) / (in.type == CFX_INTERIOR_FACET ? 4 : 1);
+      r.rules = in.rules ? in.rules->handle.h : nullptr;
+      r.point_data = in.point_data.empty() ? nullptr : in.point_data.data();
+      for (std::size_t k = 0; k < in.params.size() && k < 8; ++k) r.params[k] = in.params[k];
+    }
+    cfx_form_t h = nullptr;
+    check(cfx_form_create(V.handle.h, rank, static_cast<int>(raw.size()), raw.data(), &h));
+    Form a;
+    a.handle = detail::Handle<cfx_form_t, cfx_form_destroy>(h);
+    a.rank = rank;
+    return a;
+  }
+};
+
+/// la::SparsityPattern after finalize(): row_ptr (int64) / cols (int32)
+struct SparsityPattern
+{
+  detail::Handle<cfx_pattern_t, cfx_pattern_destroy> handle;
+  cfx_pattern_view view{};
+  std::int64_t num_rows() const { return view.nrows; }
+  std::int64_t num_nonzeros() const { return view.nnz; }
+  std::vector<std::int64_t> row_ptr() const { return download(view.indptr, view.nrows + 1); }
+  std::vector<std::int32_t> cols() const { return download(view.indices, view.nnz); }
+};
+
+/// create_sparsity_pattern(): assembler.h:567-592 (incl. the all-rows diagonal :538-560)
+inline SparsityPattern create_sparsity_pattern(const Form& a)
+{
+  cfx_pattern_t h = nullptr;
+  check(cfx_create_sparsity(a.handle.h, &h));
+  SparsityPattern p;
+  p.handle = detail::Handle<cfx_pattern_t, cfx_pattern_destroy>(h);
+  check(cfx_pattern_view_get(h, &p.view));
+  return p;
+}
+
+/// assemble_matrix(): assembler.h:690-703 -- accumulates into `values` (host or device,
+/// length nnz); bc0/bc1 are the int8 dof markers of assembler.h:643-683 (may be empty)
+inline void assemble_matrix(std::span<double> values, const Form& a, const SparsityPattern& pattern,
+                            std::span<const std::int8_t> bc0 = {}, std::span<const std::int8_t> bc1 = {})
+{
+  check(cfx_assemble_matrix(a.handle.h, pattern.handle.h, bc0.empty() ? nullptr : bc0.data(),
+                            bc1.empty() ? nullptr : bc1.data(), values.data()));
+}
+
+/// assemble_vector(): assembler.h:252-262
+inline void assemble_vector(std::span<double> b, const Form& L) { check(cfx_assemble_vector(L.handle.h, b.data())); }
+
+/// cutfemx::fem::ActiveDomain (deactivate.h:387-400)
+struct ActiveDomain
+{
+  detail::Handle<cfx_active_t, cfx_active_destroy> handle;
+  std::vector<std::int32_t> active_cells, inactive_dofs;
+};
+
+inline ActiveDomain active_domain(const Form& a)
+{
+  cfx_active_t h = nullptr;
+  check(cfx_active_domain(a.handle.h, &h));
+  ActiveDomain d;
+  d.handle = detail::Handle<cfx_active_t, cfx_active_destroy>(h);
+  const std::int32_t *ac, *id;
+  std::int64_t na, ni;
+  check(cfx_active_view(h, &ac, &na, &id, &ni));
+  d.active_cells = download(ac, na);
+  d.inactive_dofs = download(id, ni);
+  return d;
+}
+
+/// deactivate_outside(): deactivate.h:402-418 -- diag = 1, rhs = 0 on the inactive dofs
+inline ActiveDomain& deactivate_outside(std::span<double> values, const SparsityPattern& pattern, std::span<double> b,
+                                        ActiveDomain& domain, double diagonal = 1.0, double rhs_value = 0.0)
+{
+  check(cfx_deactivate_outside(domain.handle.h, pattern.handle.h, values.empty() ? nullptr : values.data(),
+                               b.empty() ? nullptr : b.data(), diagonal, rhs_value));
+  return domain;
+}
+
+} // namespace fem
+} // namespace cutfemx_amd

@@ -10,11 +10,11 @@ from . import fem
 from .cut import (CutData, FacetRows, RuntimeQuadratureRules, cut, full_cell_rules, ghost_penalty_facets,
                   level_set_value, locate_entities, locate_entities_device, normal, runtime_quadrature,
                   runtime_quadratures, update)
-from .mesh import Function, FunctionSpace, Mesh, box_mesh_arrays, lagrange_dofmap
+from .mesh import Function, FunctionSpace, Mesh, box_lagrange2_dofmap, box_mesh_arrays, lagrange_dofmap
 
 __all__ = [
     "CutData", "FacetRows", "RuntimeQuadratureRules", "cut", "update", "locate_entities",
     "locate_entities_device", "runtime_quadrature", "runtime_quadratures", "full_cell_rules",
     "ghost_penalty_facets", "normal", "level_set_value", "Mesh", "FunctionSpace", "Function",
-    "box_mesh_arrays", "lagrange_dofmap", "fem",
+    "box_mesh_arrays", "box_lagrange2_dofmap", "lagrange_dofmap", "fem",
 ]

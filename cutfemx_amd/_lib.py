@@ -47,7 +47,7 @@ class PatternView(C.Structure):
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
     "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_copy",
-    "cfx_device_alloc", "cfx_device_free", "cfx_profile_enable", "cfx_profile_reset",
+    "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
@@ -73,6 +73,14 @@ def load():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). cutfemx_amd has no CPU fallback.")
+        # A PyTorch-ROCm wheel bundles its own libamdhip64.so.7 / libhsa-runtime64.  Loaded after
+        # ours it becomes a second runtime in the process and torch then finds "No HIP GPUs";
+        # loaded before, the dynamic loader hands the same copy to both.  So when torch is
+        # installed it is imported first (dist.py and bench.py need it anyway).
+        import importlib.util
+        import sys
+        if "torch" not in sys.modules and importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
         _lib = C.CDLL(str(LIB_PATH))
         _lib.cfx_last_error.restype = C.c_char_p
         for name in SYMBOLS:

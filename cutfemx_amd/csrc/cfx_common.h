@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
@@ -94,6 +95,9 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shm
 {
   Context& c = ctx();
   if (grid.x == 0) return;
+  // HIP launches at most 2^32 - 1 work-items per dimension; a larger grid is cut short silently
+  if ((uint64_t)grid.x * block.x > 0xffffffffull)
+    throw Error(CFX_ERR_RUNTIME, std::string(name) + ": launch exceeds 2^32 threads");
   if (c.profile)
   {
     hipEvent_t a = c.get_event(), b = c.get_event();
@@ -107,6 +111,13 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shm
     hipLaunchKernelGGL(kernel, grid, block, shmem, c.stream, args...);
   }
   CFX_HIP(hipGetLastError());
+}
+
+// grid of one-wavefront blocks whose kernel loops `for (blk = blockIdx.x; ...; blk += gridDim.x)`
+inline dim3 wave_grid(int64_t nblocks)
+{
+  const int64_t cap = (0xffffffffll / 64) / 8 * 8;
+  return dim3((unsigned)std::min<int64_t>(std::max<int64_t>(nblocks, 1), cap));
 }
 
 inline dim3 grid_for(int64_t n, int block = 256)

@@ -157,7 +157,9 @@ struct PatArgs
   const int64_t* d2f_off; // or null
   const int32_t* d2f;
   const int32_t* facet_rows;
-  int32_t* tmp;     // [n_active * T] sorted unique columns of each active row
+  int32_t* tmp;     // [n_active * T] sorted unique columns of each active row (narrow path), or null
+  const int64_t* indptr; // wide path, second pass: write rows directly
+  int32_t* indices;
   int32_t* len;     // [n_active]
   int32_t* counts;  // [ndofs*bs] expanded row lengths
   int* overflow;
@@ -192,7 +194,10 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   __shared__ int32_t s_list[RPW][T];
   __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
-  const int64_t ri = (int64_t)blockIdx.x * RPW + grp; // (XCD-contiguous chunks measured slower: 5.95 vs 6.0 ms here, 12.6 vs 14.5 ms in the gather)
+  // one pass for every launch that fits HIP's 2^32-thread limit; the grid is capped beyond it
+  for (int64_t blk = blockIdx.x; blk * RPW < P.n_active; blk += gridDim.x)
+  {
+  const int64_t ri = blk * RPW + grp; // (XCD-contiguous chunks measured slower: 5.95 vs 6.0 ms here, 12.6 vs 14.5 ms in the gather)
   const bool live = ri < P.n_active;
   const int64_t r = live ? P.active_rows[ri] : 0;
   for (int k = gl; k < T; k += G) s_tab[grp][k] = -1;
@@ -268,21 +273,32 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   }
   __syncthreads();
   const int cnt = s_cnt[grp];
-  for (int k = gl; k < cnt; k += G)
-  {
-    const int32_t v = s_list[grp][k];
-    int rank = 0;
-    for (int m = 0; m < cnt; ++m) rank += (s_list[grp][m] < v) ? 1 : 0;
-    P.tmp[ri * T + rank] = v;
-  }
+  if (P.tmp || P.indices)
+    for (int k = gl; k < cnt; k += G)
+    {
+      const int32_t v = s_list[grp][k];
+      int rank = 0;
+      for (int m = 0; m < cnt; ++m) rank += (s_list[grp][m] < v) ? 1 : 0;
+      if (P.indices)
+      {
+        // second pass of the wide path: the row goes straight into the CSR arrays
+        for (int a = 0; a < P.bs; ++a)
+          for (int b = 0; b < P.bs; ++b)
+            P.indices[P.indptr[r * P.bs + a] + (int64_t)rank * P.bs + b] = v * P.bs + b;
+      }
+      else
+        P.tmp[ri * T + rank] = v;
+    }
   // a full table cannot be told from an overflowing one: keep one slot free
   if (cnt >= T) *P.overflow = 1;
-  if (live && gl == 0)
+  if (live && gl == 0 && !P.indices)
   {
     // a racy pre-check keeps 10^7 rows from serialising on one address
     if (cnt > *reinterpret_cast<volatile int*>(P.maxlen)) atomicMax(P.maxlen, cnt);
     P.len[ri] = cnt;
     for (int a = 0; a < P.bs; ++a) P.counts[r * P.bs + a] = cnt * P.bs;
+  }
+  __syncthreads(); // the LDS tables are reused by the next pass
   }
 }
 
@@ -493,16 +509,19 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   {
     tmp.alloc(plan.n_active_rows * 64);
     S.tmp = tmp.p;
-    launch("pattern_rows", pattern_rows_kernel<4, 64>, xcd_grid((plan.n_active_rows + 15) / 16), dim3(kWave),
+    launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((plan.n_active_rows + 15) / 16), dim3(kWave),
            0, S);
     if (read_scalar(overflow.p))
     {
+      // long rows (P2, vector spaces, many facet couplings): one wavefront per row with a
+      // 512-slot set.  n_active * 512 staged columns would be ~150 GB for config 4, so the
+      // wide path counts first and builds each set again to write it in place.
       T = 512;
       overflow.zero();
       maxlen.zero();
-      tmp.alloc(plan.n_active_rows * 512);
-      S.tmp = tmp.p;
-      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, xcd_grid(plan.n_active_rows), dim3(kWave), 0, S);
+      tmp.release();
+      S.tmp = nullptr;
+      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(plan.n_active_rows), dim3(kWave), 0, S);
       require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 511 dofs");
     }
   }
@@ -519,8 +538,11 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       launch("pattern_write", pattern_write_kernel<64>, grid_for(plan.n_active_rows * 8), dim3(kBlock), 0,
              plan.n_active_rows, plan.active_rows.p, V->bs, tmp.p, len.p, P->indptr.p, P->indices.p);
     else
-      launch("pattern_write", pattern_write_kernel<512>, grid_for(plan.n_active_rows * 8), dim3(kBlock), 0,
-             plan.n_active_rows, plan.active_rows.p, V->bs, tmp.p, len.p, P->indptr.p, P->indices.p);
+    {
+      S.indptr = P->indptr.p; S.indices = P->indices.p;
+      launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(plan.n_active_rows), dim3(kWave), 0,
+             S);
+    }
   }
 }
 

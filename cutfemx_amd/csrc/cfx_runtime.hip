@@ -356,6 +356,15 @@ int cfx_device_free(void* ptr)
   CFX_API_END
 }
 
+int cfx_device_memset(void* ptr, int byte, size_t bytes)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  if (bytes && !ptr) throw Error(CFX_ERR_INVALID_ARGUMENT, "cfx_device_memset: null pointer");
+  if (bytes) CFX_HIP(hipMemsetAsync(ptr, byte, bytes, ctx().stream));
+  CFX_API_END
+}
+
 int cfx_profile_enable(int on)
 {
   CFX_API_BEGIN

@@ -121,9 +121,27 @@ class MatrixCSR:
             self.values_ptr = values.data_ptr()
 
     def set_value(self, v: float):
+        if float(v) == 0.0:
+            _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(self.values_ptr), 0, C.c_size_t(8 * self.nnz)))
+            return
         z = np.full(self.nnz, float(v))
         _lib.check(_lib.lib().cfx_copy(C.c_void_p(self.values_ptr), z.ctypes.data_as(C.c_void_p),
                                        C.c_size_t(z.nbytes)))
+
+    def row_block(self, lo: int, hi: int):
+        """(indptr - indptr[lo], indices, data) of rows lo..hi-1, downloading only those rows."""
+        ip = _lib.download(self._view.indptr + 8 * lo, hi - lo + 1, np.int64)
+        e0, e1 = int(ip[0]), int(ip[-1])
+        ix = _lib.download(self._view.indices + 4 * e0, e1 - e0, np.int32)
+        va = _lib.download(self.values_ptr + 8 * e0, e1 - e0, np.float64)
+        return ip - e0, ix, va
+
+    def torch_views(self, device):
+        """Zero-copy torch tensors (indptr int64, indices int32, values f64) over the HBM arrays."""
+        from .dist import as_torch
+        return (as_torch(self._view.indptr, self.nrows + 1, "int64", device),
+                as_torch(self._view.indices, self.nnz, "int32", device),
+                as_torch(self.values_ptr, self.nnz, "float64", device))
 
     @property
     def indptr(self):

@@ -133,6 +133,35 @@ def lagrange_dofmap(tdim: int, conn: np.ndarray, num_nodes: int, degree: int):
     return np.ascontiguousarray(dofmap, dtype=np.int32), int(num_nodes + uniq.size)
 
 
+def box_lagrange2_dofmap(mesh: "Mesh", n: int, device=None, chunk: int = 1 << 24):
+    """P2 dofmap of a Kuhn box / slab mesh built in HBM with torch (no host pass).
+
+    Closed form for the generator's vertex numbering (stride s = n+1): every edge
+    joins a vertex `a` to `a + d` with d one of the 7 Kuhn directions
+    {x, y, z, xy, xz, yz, xyz}; edge dof = nnodes + 7*a + direction.  Ids of
+    directions that leave the box are never referenced by a cell; those rows stay
+    inactive (identity after deactivation).  Returns (torch int32 (ncells, 10), ndofs).
+    """
+    import torch
+
+    from .dist import as_torch
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    s = n + 1
+    nn, nc = mesh.num_nodes, mesh.num_cells
+    conn = as_torch(mesh.conn_ptr, nc * 4, "int32", device).view(nc, 4)
+    table = torch.tensor([1, s, s * s, 1 + s, 1 + s * s, s + s * s, 1 + s + s * s], device=device, dtype=torch.int32)
+    out = torch.empty((nc, 10), device=device, dtype=torch.int32)
+    out[:, :4] = conn
+    for lo in range(0, nc, chunk):
+        c = conn[lo:lo + chunk]
+        for k, (p, q) in enumerate(_EDGES[3]):
+            a = torch.minimum(c[:, p], c[:, q])
+            d = (c[:, p] - c[:, q]).abs()
+            direction = (d[:, None] == table[None, :]).to(torch.int32).argmax(dim=1).to(torch.int32)
+            out[lo:lo + chunk, 4 + k] = nn + 7 * a + direction
+    return out, 8 * nn
+
+
 class FunctionSpace:
     """Continuous Lagrange space (degree 1 or 2, scalar or gdim-vector)."""
 

@@ -346,6 +346,8 @@ struct cfx_row_plan
   cfx::DevArray<uint8_t> rowmark;  // dof touched by any entity of the form
   cfx::DevArray<int32_t> active_rows;
   int64_t n_active_rows = 0;
+  cfx::DevArray<int32_t> special_rows; // active rows next to the interface: touched by a runtime-rule cell or a facet
+  int64_t n_special_rows = 0;
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
@@ -357,6 +359,10 @@ struct cfx_row_plan
   // per cell slot: bitset of its uncut entities + exclusive popcount ranks (entity index lookup)
   cfx::DevArray<int64_t> std_bits[4];
   cfx::DevArray<int32_t> std_rank[4];
+  // per cell slot: open-addressing map parent cell -> first rule of the cell (rules of a cell are
+  // consecutive); keys -1 = empty, size = mask + 1 >= 2 * distinct parents
+  cfx::DevArray<int32_t> rule_keys[4], rule_first[4];
+  uint32_t rule_mask[4] = {0, 0, 0, 0};
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};
   // identity of the entity lists the plan was built from: (integral index, entities ptr, count,

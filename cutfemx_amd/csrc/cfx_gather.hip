@@ -42,13 +42,16 @@ constexpr int kWave = 64;
 struct RowIntegral
 {
   int kernel, qdegree, point_stride;
-  int std_inline;            // uncut entities: compute inline (1) or read std_tensors (0)
+  int std_inline;            // uncut entities: read std_tensors (0), generic inline row (1), P1 stiffness row from vertex coordinates (2)
   const unsigned long long* std_bits; // bitset of the uncut entities
   const int32_t* std_rank;            // entities before each 64-cell word
   const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [n_entities][ND] (rank 1)
   const int32_t* parent_map; // sorted rule parents
   int64_t nr;
   const double* rule_tensors; // [nr][ND*ND] or [nr][ND]
+  const int32_t* rule_keys;   // parent cell -> first rule (open addressing, plan.rule_keys / rule_first)
+  const int32_t* rule_first;
+  unsigned rule_mask;
   double params[8];
 };
 
@@ -75,6 +78,9 @@ struct RowArgs
   double* values;
   int* error;
   int debug; // ablation switches (CFX_DEBUG_ROWS), 0 in production
+  int iso_geometry; // the space's dofmap is the geometry dofmap (P1): dofs are vertex ids
+  unsigned mark_mask;   // cell-mark bits this launch handles: 0x0F uncut entities, 0xF0 runtime rules (+ facets)
+  unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -83,6 +89,21 @@ __device__ __forceinline__ int64_t entity_index(const unsigned long long* __rest
 {
   const int64_t w = c >> 6;
   return (int64_t)rank[w] + __popcll(bits[w] & ((1ull << (c & 63)) - 1ull));
+}
+
+// first rule hosted by cut cell c (the cell is known to host at least one)
+__device__ __forceinline__ int64_t first_rule(const int32_t* __restrict__ keys, const int32_t* __restrict__ first,
+                                              unsigned mask, int32_t c)
+{
+  unsigned h = ((unsigned)c * 2654435761u) & mask;
+  for (unsigned probe = 0; probe <= mask; ++probe)
+  {
+    const int32_t k = keys[h];
+    if (k == c) return first[h];
+    if (k == -1) break;
+    h = (h + 1) & mask;
+  }
+  return 0x7fffffff; // absent: the caller's range loop ends immediately
 }
 
 __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a, int64_t n, int32_t v)
@@ -94,6 +115,73 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t* __restrict__ a
     if (a[mid] < v) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+// 24 B vertex record (stride 3 doubles, 8 B aligned): one 16 B + one 8 B load
+typedef double cfx_d2u __attribute__((ext_vector_type(2), aligned(8)));
+
+template <int TDIM>
+__device__ __forceinline__ void load_vertex(const double* __restrict__ x, int64_t v, double* out)
+{
+  const cfx_d2u a = *reinterpret_cast<const cfx_d2u*>(x + 3 * v);
+  out[0] = a.x; out[1] = a.y;
+  if constexpr (TDIM == 3) out[2] = x[3 * v + 2];
+}
+
+// Row of the P1 stiffness tensor that belongs to vertex xr of a simplex, from xr and the
+// other TDIM vertices xo (any order).  With e_k = xo_k - xr and the cofactor vectors c_k
+// (grad lambda_k = c_k / det), grad lambda_r = -(sum c_k) / det and
+//   A[r][k] = |K| grad lambda_r . grad lambda_k = (c_r . c_k) / (TDIM! |det|),
+// the exact integral for any quadrature degree (constant gradients).
+template <int TDIM>
+__device__ __forceinline__ void p1_stiffness_row(const double* xr, const double (*xo)[TDIM], double& diag, double* off)
+{
+  double e[TDIM][TDIM], c[TDIM][TDIM], cr[TDIM];
+#pragma unroll
+  for (int k = 0; k < TDIM; ++k)
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) e[k][d] = xo[k][d] - xr[d];
+  double det;
+  if constexpr (TDIM == 3)
+  {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+    {
+      const double* a = e[(k + 1) % 3];
+      const double* b = e[(k + 2) % 3];
+      c[k][0] = a[1] * b[2] - a[2] * b[1];
+      c[k][1] = a[2] * b[0] - a[0] * b[2];
+      c[k][2] = a[0] * b[1] - a[1] * b[0];
+    }
+    det = e[0][0] * c[0][0] + e[0][1] * c[0][1] + e[0][2] * c[0][2];
+  }
+  else
+  {
+    c[0][0] = e[1][1];  c[0][1] = -e[1][0];
+    c[1][0] = -e[0][1]; c[1][1] = e[0][0];
+    det = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+  }
+  const double scale = 1.0 / ((TDIM == 3 ? 6.0 : 2.0) * fabs(det));
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < TDIM; ++k) t -= c[k][d];
+    cr[d] = t;
+  }
+  double dd = 0.0;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) dd += cr[d] * cr[d];
+  diag = dd * scale;
+#pragma unroll
+  for (int k = 0; k < TDIM; ++k)
+  {
+    double t = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) t += cr[d] * c[k][d];
+    off[k] = t * scale;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -196,19 +284,16 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 // ---------------------------------------------------------------------------
 // stage 2, bilinear forms
 // ---------------------------------------------------------------------------
-// ISO: the space is P1 and its dofmap IS the geometry dofmap, so the columns of
-// row r are exactly the vertices of its incident cells: their coordinates are
-// staged once per row in LDS (~15-30 coalesced 24 B reads) instead of being
-// gathered again for every (row, cell) pair (~100 scattered reads per row).
-template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool ISO>
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED>
 __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row
   constexpr int RPW = kWave / G;
-  __shared__ int32_t s_col[RPW][CAP];
-  __shared__ double s_val[RPW][CAP];
-  __shared__ double s_x[ISO ? RPW : 1][ISO ? CAP : 1][TDIM];
+  // one element of padding per row: the groups of a wavefront probe the same position of
+  // their own rows, which would otherwise sit in the same LDS banks
+  __shared__ int32_t s_col[RPW][CAP + 1];
+  __shared__ double s_val[RPW][CAP + 1];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
   const bool live = ri < A.n_active;
@@ -233,21 +318,20 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
     {
       s_col[grp][k] = mycol[q];
       s_val[grp][k] = 0.0;
-      if constexpr (ISO)
-      {
-#pragma unroll
-        for (int d = 0; d < TDIM; ++d) s_x[grp][k][d] = A.x[3 * (int64_t)mycol[q] + d];
-      }
     }
   }
   __syncthreads();
   const bool cells = live && A.cellmark != nullptr;
   const int64_t cb = cells ? A.d2c_off[r] : 0;
   const int nc = cells ? (int)(A.d2c_off[r + 1] - cb) : 0;
-  const bool facets = live && A.d2f_off != nullptr;
+  const bool facets = live && A.d2f_off != nullptr && (A.mark_mask & 0xF0u) != 0 && !(A.debug & 8);
   const int64_t fb = facets ? A.d2f_off[r] : 0;
   const int nf = facets ? (int)(A.d2f_off[r + 1] - fb) : 0;
   const bool row_bc = live && A.bc0 && A.bc0[r];
+  // every cell item adds to the diagonal: kept in a register per lane and reduced over the
+  // group once, instead of ~24 LDS atomics on one address per row
+  double dsum = 0.0;
+  const bool diag_bc = row_bc || (live && A.bc1 != nullptr && A.bc1[r] != 0);
 
   // add one item (ncols columns) of every group to its row; ORDERED keeps item order
   // CSR slot of column `col` of this row (-1 and the error flag if absent)
@@ -318,7 +402,7 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
       cell[k] = t < ncl ? A.d2c[cb + t] : -1;
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
+    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? (uint8_t)(A.cellmark[cell[k]] & A.mark_mask) : (uint8_t)0;
 #pragma unroll
     for (int k = 0; k < R; ++k)
     {
@@ -338,66 +422,76 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
     for (int k = 0; k < R; ++k)
     {
       if (__ballot(mk[k] != 0) == 0) continue;
-      double acc[ND];
-      int csl[ND];
+#ifndef CFX_ROWS_NO_SCHED_BARRIER
+      // keep the items sequential: hoisting the coordinate loads of all R items above the
+      // first item's arithmetic costs more registers than the 5 waves/SIMD budget has
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+      const int64_t c = cell[k];
+      const uint8_t mark = mk[k];
+      // local column of r itself (cd[k][lr] == r for every marked item)
+      int lr = 0;
 #pragma unroll
-      for (int j = 0; j < ND; ++j) { acc[j] = 0.0; csl[j] = -1; }
-      if (mk[k])
+      for (int j = 0; j < ND; ++j) lr = (cd[k][j] == (int32_t)r) ? j : lr;
       {
-        const int64_t c = cell[k];
-        const uint8_t mark = mk[k];
-        int lr = 0;
+        double acc[ND];
+        int csl[ND];
 #pragma unroll
-        for (int j = 0; j < ND; ++j)
+        for (int j = 0; j < ND; ++j) { acc[j] = 0.0; csl[j] = -1; }
+        if (mk[k])
         {
-          lr = (cd[k][j] == (int32_t)r) ? j : lr;
-          csl[j] = (A.debug & 4) ? j : find_slot(cd[k][j]);
-        }
-        for (int i = 0; i < ((A.debug & 2) ? 0 : A.n_cell); ++i)
-        {
-          const RowIntegral& I = A.cell[i];
-          if (mark & (1u << i))
+#pragma unroll
+          for (int j = 0; j < ND; ++j) csl[j] = (A.debug & 4) ? j : find_slot(cd[k][j]);
+          for (int i = 0; i < ((A.debug & 2) ? 0 : A.n_cell); ++i)
           {
-            if (I.std_inline)
+            const RowIntegral& I = A.cell[i];
+            if (mark & (1u << i))
             {
-              Geo<TDIM> g;
-              if constexpr (ISO)
+              if (I.std_inline)
               {
-#pragma unroll
-                for (int j = 0; j < ND; ++j)
-#pragma unroll
-                  for (int d = 0; d < TDIM; ++d) g.x[j][d] = s_x[grp][csl[j] < 0 ? 0 : csl[j]][d];
+                Geo<TDIM> g;
+                load_cell<TDIM>(A.x, A.conn, c, g);
+                jacobian<TDIM>(g);
+                int npts;
+                const double* wts;
+                const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+                cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
+                                                fabs(g.detJ), nullptr, lr, 0, acc);
               }
               else
-                load_cell<TDIM>(A.x, A.conn, c, g);
-              jacobian<TDIM>(g);
-              int npts;
-              const double* wts;
-              const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
-              cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
-                                              fabs(g.detJ), nullptr, lr, 0, acc);
-            }
-            else
-            {
-              const int64_t e = entity_index(I.std_bits, I.std_rank, c);
-              const double* T = I.std_tensors + (e * ND + lr) * ND;
+              {
+                const int64_t e = entity_index(I.std_bits, I.std_rank, c);
+                const double* T = I.std_tensors + (e * ND + lr) * ND;
 #pragma unroll
-              for (int j = 0; j < ND; ++j) acc[j] += T[j];
+                for (int j = 0; j < ND; ++j) acc[j] += T[j];
+              }
+            }
+            if (mark & (16u << i))
+            {
+              for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+              {
+                const double* T = I.rule_tensors + (e * ND + lr) * ND;
+#pragma unroll
+                for (int j = 0; j < ND; ++j) acc[j] += T[j];
+              }
             }
           }
-          if (mark & (16u << i))
-          {
-            // an interface cell may own several consecutive rules (cut.cpp:1286-1294)
-            for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
-            {
-              const double* T = I.rule_tensors + (e * ND + lr) * ND;
 #pragma unroll
-              for (int j = 0; j < ND; ++j) acc[j] += T[j];
-            }
-          }
+          for (int j = 0; j < ND; ++j)
+            if (j == lr) { dsum += diag_bc ? 0.0 : acc[j]; csl[j] = -1; }
         }
+        add_item(std::integral_constant<int, ND>{}, mk[k] != 0, cd[k], acc, csl);
       }
-      add_item(std::integral_constant<int, ND>{}, mk[k] != 0, cd[k], acc, csl);
+    }
+  }
+  {
+    double d = dsum;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
+    if (live && gl == 0 && len > 0 && nc > 0 && !(A.debug & 1))
+    {
+      const int slot = find_slot((int32_t)r);
+      if (slot >= 0) atomicAdd(&s_val[grp][slot], d);
     }
   }
 
@@ -410,9 +504,8 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
     if (__ballot(has) == 0) break;
     double acc[W];
     int32_t cols[W];
-    int fsl[W];
 #pragma unroll
-    for (int j = 0; j < W; ++j) { acc[j] = 0.0; cols[j] = -1; fsl[j] = -1; }
+    for (int j = 0; j < W; ++j) { acc[j] = 0.0; cols[j] = -1; }
     if (has)
     {
       const int64_t f = A.d2f[fb + t];
@@ -424,21 +517,236 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
         cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
       }
       // r may be a dof of both cells: both macro rows land in global row r
+      int i0 = -1, i1 = -1;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        i0 = cols[j] == (int32_t)r ? j : i0;
+        i1 = cols[ND + j] == (int32_t)r ? ND + j : i1;
+      }
       const double* T = A.facet_tensors + f * (W * W);
+      if (i0 >= 0)
+      {
 #pragma unroll
-      for (int i = 0; i < W; ++i)
-        if (cols[i] == (int32_t)r)
-        {
+        for (int j = 0; j < W; ++j) acc[j] += T[i0 * W + j];
+      }
+      if (i1 >= 0)
+      {
 #pragma unroll
-          for (int j = 0; j < W; ++j) acc[j] += T[i * W + j];
-        }
-#pragma unroll
-      for (int j = 0; j < W; ++j) fsl[j] = find_slot(cols[j]);
+        for (int j = 0; j < W; ++j) acc[j] += T[i1 * W + j];
+      }
     }
-    add_item(std::integral_constant<int, W>{}, has, cols, acc, fsl);
+    if constexpr (DEG == 1)
+    {
+      // P1: the two cells share the facet's TDIM vertices, so the macro row has ND + 1
+      // distinct columns: fold the shared dofs of cell 1 onto cell 0's, 5 slot searches
+      // and LDS adds instead of 8
+      int32_t c5[ND + 1];
+      double a5[ND + 1];
+      int s5[ND + 1];
+      int nfree = 0;
+      int32_t ocol = -1;
+      double oacc = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        bool shared = false;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+          if (has && cols[ND + j] == cols[i]) { acc[i] += acc[ND + j]; shared = true; }
+        if (has && !shared) { ocol = cols[ND + j]; oacc = acc[ND + j]; ++nfree; }
+      }
+      if (has && nfree != 1) *A.error = 4; // not an interior facet of a conforming simplicial mesh
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { c5[j] = cols[j]; a5[j] = acc[j]; s5[j] = -1; }
+      c5[ND] = ocol; a5[ND] = oacc; s5[ND] = -1;
+      if (has)
+      {
+#pragma unroll
+        for (int j = 0; j <= ND; ++j) s5[j] = find_slot(c5[j]);
+      }
+      add_item(std::integral_constant<int, ND + 1>{}, has, c5, a5, s5);
+    }
+    else
+    {
+      int fsl[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) fsl[j] = has ? find_slot(cols[j]) : -1;
+      add_item(std::integral_constant<int, W>{}, has, cols, acc, fsl);
+    }
   }
   __syncthreads();
   // Row epilogue: values[row] += reduced row, loads batched
+  double myval[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    myval[q] = k < len ? A.values[rb + k] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len) A.values[rb + k] = myval[q] + s_val[grp][k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stage 2, bilinear forms, the uncut P1 cells alone.  P1 space on the geometry dofmap:
+// an item is the row's vertex plus the TDIM other vertices of the cell, its row of the
+// stiffness tensor comes from p1_stiffness_row() (6 coordinate loads, no Jacobian
+// inverse, no pass through the connectivity), only the TDIM off-diagonal columns go
+// through LDS and the diagonal is reduced in registers.  Everything that is not an
+// uncut-cell stiffness item (cut-cell rule tensors, facets) is left to
+// assemble_rows_kernel on the rows next to the interface (plan.special_rows).
+// ---------------------------------------------------------------------------
+#ifndef CFX_P1_WAVES
+#define CFX_P1_WAVES 6
+#endif
+template <int TDIM, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(RowArgs A)
+{
+  constexpr int ND = TDIM + 1;
+  constexpr int RPW = kWave / G;
+  __shared__ int32_t s_col[RPW][CAP + 1];
+  __shared__ double s_val[RPW][CAP + 1];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n_active;
+  const int64_t r = live ? A.active_rows[ri] : 0;
+  const int64_t rb = live ? A.indptr[r] : 0;
+  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+  constexpr int KMAX = CAP / G;
+  {
+    int32_t mycol[KMAX];
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      mycol[q] = k < len ? A.indices[rb + k] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len) { s_col[grp][k] = mycol[q]; s_val[grp][k] = 0.0; }
+    }
+  }
+  __syncthreads();
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = (live && len > 0) ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  const bool row_bc = live && A.bc0 && A.bc0[r];
+  const bool diag_bc = row_bc || (live && A.bc1 != nullptr && A.bc1[r] != 0);
+  double xr[TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) xr[d] = 0.0;
+  if (live) load_vertex<TDIM>(A.x, r, xr);
+  double dsum = 0.0;
+
+  auto find_slot = [&](int32_t col) -> int
+  {
+    int lo = 0, hi = len;
+    while (lo < hi)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (s_col[grp][mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (lo < len && s_col[grp][lo] == col) return lo;
+    *A.error = 1;
+    return -1;
+  };
+
+  constexpr int R = 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  for (int base = 0;; base += R * G)
+  {
+    if (__ballot(base + gl < nc) == 0) break;
+    int32_t cell[R];
+    int rep[R];
+    int32_t cd[R][ND];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      const int t = base + k * G + gl;
+      cell[k] = t < nc ? A.d2c[cb + t] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) rep[k] = cell[k] >= 0 ? __popc(A.cellmark[cell[k]] & A.inline_bits) : 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (!rep[k]) continue;
+      if constexpr (ND == 4)
+      {
+        const int4 v = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)cell[k] * 4);
+        cd[k][0] = v.x; cd[k][1] = v.y; cd[k][2] = v.z; cd[k][3] = v.w;
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) cd[k][j] = A.dofmap[(int64_t)cell[k] * ND + j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (__ballot(rep[k] != 0) == 0) continue;
+      const bool has = rep[k] != 0;
+      int lr = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) lr = (has && cd[k][j] == (int32_t)r) ? j : lr;
+      int32_t oc[TDIM];
+      int osl[TDIM];
+      double ov[TDIM];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) { oc[t] = has ? (t < lr ? cd[k][t] : cd[k][t + 1]) : (int32_t)r; osl[t] = -1; ov[t] = 0.0; }
+      if (has)
+      {
+        double xo[TDIM][TDIM], dg, off[TDIM];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) load_vertex<TDIM>(A.x, oc[t], xo[t]);
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) osl[t] = find_slot(oc[t]);
+        p1_stiffness_row<TDIM>(xr, xo, dg, off);
+        const double scale = (double)rep[k]; // the same cell in several inline integrals
+        dsum += diag_bc ? 0.0 : dg * scale;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+          ov[t] = (row_bc || (A.bc1 != nullptr && A.bc1[oc[t]] != 0)) ? 0.0 : off[t] * scale;
+      }
+      if constexpr (ORDERED)
+      {
+        for (int turn = 0; turn < G; ++turn) // one lane of each group at a time: item order
+        {
+          if (gl == turn)
+          {
+#pragma unroll
+            for (int t = 0; t < TDIM; ++t)
+              if (osl[t] >= 0) s_val[grp][osl[t]] += ov[t];
+          }
+          __syncthreads();
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+          if (osl[t] >= 0) atomicAdd(&s_val[grp][osl[t]], ov[t]);
+      }
+    }
+  }
+  {
+    double d = dsum;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
+    if (gl == 0 && nc > 0)
+    {
+      const int slot = find_slot((int32_t)r);
+      if (slot >= 0) atomicAdd(&s_val[grp][slot], d);
+    }
+  }
+  __syncthreads();
   double myval[KMAX];
 #pragma unroll
   for (int q = 0; q < KMAX; ++q)
@@ -501,7 +809,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
         if (mk[k] & (1u << i))
           part += I.std_tensors[entity_index(I.std_bits, I.std_rank, c) * ND + lr[k]];
         if (mk[k] & (16u << i))
-          for (int64_t e = lower_bound_i32(I.parent_map, I.nr, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
             part += I.rule_tensors[e * ND + lr[k]];
       }
     }
@@ -555,6 +863,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
   cfx_space_s* V = a->V;
   RowArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
+  A.iso_geometry = (DEG == 1 && V->dofmap.p == V->mesh->conn.p) ? 1 : 0;
   A.n_active = plan.n_active_rows; A.active_rows = plan.active_rows.p;
   if (plan.any_cells)
   {
@@ -578,6 +887,8 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     // uncut P1 stiffness is one point: cheaper to recompute than to stage
     const char* inl = getenv("CFX_STD_INLINE");
     R.std_inline = (a->rank == 2 && I.kernel == CFX_K_STIFFNESS && DEG == 1 && !(inl && inl[0] == '0')) ? 1 : 0;
+    if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
+    if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
     if (!R.std_inline && I.n_entities > 0)
     {
       st.buffers.emplace_back(I.n_entities * tsize);
@@ -588,6 +899,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     if (I.rules && I.rules->nr > 0)
     {
       R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
+      R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
       st.buffers.emplace_back(I.rules->nr * tsize);
       R.rule_tensors = st.buffers.back().p;
       if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
@@ -625,23 +937,60 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   if (A.n_active > 0)
   {
     const bool det = deterministic();
-    // P1 space whose dofmap aliases the geometry dofmap: vertex coordinates via LDS
-    // (measured: no gain -- the kernel is bound by the dependent index chain; CFX_ISO=1 enables it)
-    const char* iso_env = getenv("CFX_ISO");
-    const bool iso = DEG == 1 && a->V->dofmap.p == a->V->mesh->conn.p && iso_env && iso_env[0] == '1';
     const int mr = P->max_row_len;
-#define CFX_ROWS(GG, CAPP, NAME)                                                                          \
+    cfx_row_plan& plan = row_plan(a);
+#define CFX_ROWS(GG, CAPP, NAME, ARGS)                                                                    \
   do                                                                                                      \
   {                                                                                                       \
-    const dim3 grid = xcd_grid((A.n_active + (kWave / GG) - 1) / (kWave / GG));                           \
-    if (det && iso) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, true>, grid, dim3(kWave), 0, A);   \
-    else if (det) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, false>, grid, dim3(kWave), 0, A);    \
-    else if (iso) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, true>, grid, dim3(kWave), 0, A);    \
-    else launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, A);            \
+    const dim3 grid = xcd_grid(((ARGS).n_active + (kWave / GG) - 1) / (kWave / GG));                      \
+    if (det) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true>, grid, dim3(kWave), 0, ARGS);   \
+    else launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false>, grid, dim3(kWave), 0, ARGS);      \
   } while (0)
-    if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows");
-    else if (mr <= 64) CFX_ROWS(8, 64, "assemble_rows");
-    else CFX_ROWS(64, 512, "assemble_rows_wide");
+    // P1 space on the geometry dofmap whose uncut-cell integrals are all inline stiffness:
+    // lean kernel for the uncut items of every row, generic kernel for the rule / facet
+    // items of the rows next to the interface
+    bool split = false;
+    if constexpr (DEG == 1)
+    {
+      unsigned inline_bits = 0;
+      bool all_inline = A.iso_geometry != 0 && mr <= 64;
+      for (int s = 0; s < A.n_cell; ++s)
+      {
+        if (A.cell[s].std_inline == 2) inline_bits |= 1u << s;
+        else if (A.cell[s].std_bits) all_inline = false; // staged uncut tensors: generic path
+      }
+      if (all_inline && inline_bits && 2 * plan.n_special_rows <= plan.n_active_rows)
+      {
+        split = true;
+        RowArgs F = A;
+        F.inline_bits = inline_bits;
+        const dim3 grid = xcd_grid((F.n_active + 7) / 8);
+        if (mr <= 32)
+        {
+          if (det) launch("assemble_rows_p1", assemble_rows_p1_kernel<TDIM, 8, 32, true>, grid, dim3(kWave), 0, F);
+          else launch("assemble_rows_p1", assemble_rows_p1_kernel<TDIM, 8, 32, false>, grid, dim3(kWave), 0, F);
+        }
+        else
+        {
+          if (det) launch("assemble_rows_p1", assemble_rows_p1_kernel<TDIM, 8, 64, true>, grid, dim3(kWave), 0, F);
+          else launch("assemble_rows_p1", assemble_rows_p1_kernel<TDIM, 8, 64, false>, grid, dim3(kWave), 0, F);
+        }
+        RowArgs S = A;
+        S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
+        if (S.n_active > 0)
+        {
+          if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows_cut", S);
+          else CFX_ROWS(8, 64, "assemble_rows_cut", S);
+        }
+      }
+    }
+    if (!split)
+    {
+      A.mark_mask = 0xFFu;
+      if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows", A);
+      else if (mr <= 64) CFX_ROWS(8, 64, "assemble_rows", A);
+      else CFX_ROWS(64, 512, "assemble_rows_wide", A);
+    }
 #undef CFX_ROWS
   }
   return read_scalar(err.p);
@@ -672,6 +1021,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
                                      : run_matrix<3, 1>(a, P, bc0, bc1, values);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
+  require(err != 4, CFX_ERR_INVALID_ARGUMENT, "assemble_matrix: a facet row does not join two cells across a shared facet");
   return true;
 }
 

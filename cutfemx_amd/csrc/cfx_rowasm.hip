@@ -62,13 +62,35 @@ __global__ void plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict_
   pop[w] = __popcll(v);
 }
 
+// `special` (may be null): rows that receive something other than uncut-cell items
 __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride,
-                                            const int32_t* __restrict__ dofmap, int nd, uint8_t* rowmark)
+                                            const int32_t* __restrict__ dofmap, int nd, uint8_t* rowmark,
+                                            uint8_t* special)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * nd) return;
   const int64_t c = cells[(i / nd) * stride];
-  rowmark[dofmap[c * nd + (int)(i % nd)]] = 1;
+  const int32_t dof = dofmap[c * nd + (int)(i % nd)];
+  rowmark[dof] = 1;
+  if (special) special[dof] = 1;
+}
+
+// hash map parent cell -> first rule index (one entry per run of equal parents)
+__global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ parent, uint32_t mask,
+                                      int32_t* __restrict__ keys, int32_t* __restrict__ first)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nr) return;
+  const int32_t c = parent[e];
+  if (e > 0 && parent[e - 1] == c) return;
+  uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+  while (true)
+  {
+    const int32_t old = atomicCAS(&keys[h], -1, c);
+    if (old == -1 || old == c) break; // (a repeated run can only come from an unsorted list, flagged elsewhere)
+    h = (h + 1) & mask;
+  }
+  first[h] = (int32_t)e;
 }
 
 // flags a list that is not ascending (strict: not strictly ascending)
@@ -382,6 +404,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   P.cellmark.zero();
   P.rowmark.alloc(V->ndofs);
   P.rowmark.zero();
+  DevArray<uint8_t> special(V->ndofs); // rows touched by a runtime-rule cell or a facet
+  special.zero();
   DevArray<int> flag(1);
   flag.zero();
   P.nfacets = 0;
@@ -398,7 +422,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
                I.entities.p, 1, (uint8_t)(1u << slot), P.cellmark.p);
         launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-               I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p);
+               I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p, (uint8_t*)nullptr);
         launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
                I.entities.p, 1, flag.p);
         P.any_cells = true;
@@ -408,9 +432,17 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
                I.rules->parent_map.p, 1, (uint8_t)(16u << slot), P.cellmark.p);
         launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.rules->nr * nd), dim3(kBlock), 0,
-               I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p);
+               I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p, special.p);
         launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
                I.rules->parent_map.p, 0, flag.p);
+        uint32_t size = 64;
+        while (size < 2 * (uint64_t)I.rules->nr) size <<= 1;
+        P.rule_mask[slot] = size - 1;
+        P.rule_keys[slot].alloc(size);
+        P.rule_first[slot].alloc(size);
+        CFX_HIP(hipMemsetAsync(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size, ctx().stream));
+        launch("plan_rule_hash", plan_rule_hash_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+               I.rules->parent_map.p, P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p);
         P.any_cells = true;
       }
     }
@@ -434,9 +466,9 @@ cfx_row_plan& row_plan(cfx_form_s* a)
                              hipMemcpyDeviceToDevice, ctx().stream));
       CFX_HIP(hipMemsetAsync(P.facet_slot.p + o, s, (size_t)I.n_entities, ctx().stream));
       launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-             I.n_entities, I.entities.p, 4, V->dofmap.p, nd, P.rowmark.p);
+             I.n_entities, I.entities.p, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
       launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-             I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p);
+             I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
       o += I.n_entities;
     }
     DevArray<int32_t> fcount(V->ndofs);
@@ -452,6 +484,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
            P.facet_rows.p, V->dofmap.p, nd, P.d2f_offsets.p, fcount.p, P.d2f.p);
   }
   P.n_active_rows = compact_bytes("plan_active_rows", V->ndofs, P.rowmark.p, ByteNonZero{}, P.active_rows);
+  P.n_special_rows = compact_bytes("plan_special_rows", V->ndofs, special.p, ByteNonZero{}, P.special_rows);
   // rank structure of every uncut entity list: entity index of cell c =
   // rank[c/64] + popcount(bits[c/64] below c), two cached loads instead of a
   // binary search over the (10^8-entry) list

@@ -1,0 +1,15 @@
+#!/bin/bash
+# usage: tools/rows_variants.sh "<flags1>" "<flags2>" ...   (run on the GPU box)
+set -e
+BASE="-O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-pass-failed"
+for f in "$@"; do
+  touch cutfemx_amd/csrc/cfx_gather.hip
+  make -C cutfemx_amd/csrc -j8 CXXFLAGS="$BASE $f" > /dev/null 2>&1
+  echo "== variant [$f]"
+  python bench.py --mesh ${MESH:-256} --no-cpu --no-secondary --steps 10 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+k=d['kernels']
+print('ms/step', round(d['ms_per_step'],3), {n: round(k[n]['avg_us'],1) for n in ('assemble_rows','assemble_rows_p1','assemble_rows_cut','plan_special_rows','assemble_vec_rows','pattern_rows') if n in k})
+"
+done

@@ -57,7 +57,7 @@ SYMBOLS = [
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_cut_destroy", "cfx_space_create",
     "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_create_sparsity",
     "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_vector",
-    "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
+    "cfx_apply_lifting", "cfx_set_bc", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
     "cfx_active_destroy",
 ]
 

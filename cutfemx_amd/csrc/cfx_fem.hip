@@ -43,6 +43,12 @@ struct AsmArgs
   double* values; // rank 2: CSR values; rank 1: vector
   double* dump;   // if set: write the local tensor here instead of scattering
   int* error;
+  // lifting mode (lift_bc_impl, assemble_vector_impl.h:383-436): if set, `values` is the vector b and
+  // the row of Ae is contracted with alpha (g - x0) over the Dirichlet columns instead of scattered
+  const int8_t* lift_markers;
+  const double* lift_values;
+  const double* lift_x0;
+  double lift_alpha;
 };
 
 // ---------------------------------------------------------------------------
@@ -64,6 +70,17 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
   const int i = (int)(tid - e * NLOC);
   const int ia = i / BS, ik = i - ia * BS;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
+  if constexpr (RANK == 2)
+  {
+    // LiftingMode: only entities with a Dirichlet column are tabulated
+    if (A.lift_markers)
+    {
+      bool any = false;
+      for (int j = 0; j < ND; ++j)
+        for (int b = 0; b < BS; ++b) any = any || A.lift_markers[BS * A.dofmap[cell * ND + j] + b] != 0;
+      if (!any) return;
+    }
+  }
 
   Geo<TDIM> g;
   load_cell<TDIM>(A.x, A.conn, cell, g);
@@ -115,6 +132,25 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
   }
   else
   {
+    if (A.lift_markers)
+    {
+      double s = 0.0;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+        {
+          const int32_t col = BS * cd[j] + b;
+          if (A.lift_markers[col])
+          {
+            s += acc[j * BS + b] * A.lift_alpha * (A.lift_values[col] - (A.lift_x0 ? A.lift_x0[col] : 0.0));
+            any = true;
+          }
+        }
+      if (any) atomicAdd(A.values + row, -s);
+      return;
+    }
     // zero BC rows / columns: assemble_matrix_impl.h:151-185
     const bool row_bc = A.bc0 && A.bc0[row];
     const int64_t rb = A.indptr[row], re = A.indptr[row + 1];
@@ -155,6 +191,14 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   const int4 row4 = *reinterpret_cast<const int4*>(A.entities + 4 * f);
   const int64_t c0 = row4.x, c1 = row4.z;
   const int lf0 = row4.y;
+  if (A.lift_markers)
+  {
+    bool any = false;
+    for (int j = 0; j < ND; ++j)
+      for (int b = 0; b < BS; ++b)
+        any = any || A.lift_markers[BS * A.dofmap[c0 * ND + j] + b] != 0 || A.lift_markers[BS * A.dofmap[c1 * ND + j] + b] != 0;
+    if (!any) return;
+  }
 
   Geo<TDIM> g0, g1;
   load_cell<TDIM>(A.x, A.conn, c0, g0);
@@ -176,6 +220,29 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   const int64_t crow = (ia < ND) ? c0 : c1;
   const int la = (ia < ND) ? ia : ia - ND;
   const int32_t row = BS * A.dofmap[crow * ND + la] + ik;
+  if (A.lift_markers)
+  {
+    double s = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < 2 * ND; ++j)
+    {
+      const int64_t ccol = (j < ND) ? c0 : c1;
+      const int lj = (j < ND) ? j : j - ND;
+#pragma unroll
+      for (int b = 0; b < BS; ++b)
+      {
+        const int32_t col = BS * A.dofmap[ccol * ND + lj] + b;
+        if (A.lift_markers[col])
+        {
+          s += acc[j * BS + b] * A.lift_alpha * (A.lift_values[col] - (A.lift_x0 ? A.lift_x0[col] : 0.0));
+          any = true;
+        }
+      }
+    }
+    if (any) atomicAdd(A.values + row, -s);
+    return;
+  }
   const bool row_bc = A.bc0 && A.bc0[row];
   const int64_t rb = A.indptr[row], re = A.indptr[row + 1];
 #pragma unroll
@@ -525,6 +592,51 @@ int cfx_assemble_vector(cfx_form_t L, double* b)
     for (const auto& I : L->integrals) launch_integral(L, I, A);
   out.finish();
   if (out.dev == b) { /* device output: leave the stream running */ }
+  CFX_API_END
+}
+
+int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_values, const double* x0, double alpha,
+                      double* b)
+{
+  CFX_API_BEGIN
+  require(a && bc_markers && bc_values && b, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting: null argument");
+  require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting: form is not bilinear");
+  cfx_space_s* V = a->V;
+  const int64_t n = V->ndofs * V->bs;
+  DevArray<int8_t> dm = to_device(bc_markers, n);
+  DevArray<double> dv = to_device(bc_values, n), dx0 = to_device(x0, x0 ? n : 0);
+  OutArray<double> out(b, n, true);
+  DevArray<int> err(1);
+  err.zero();
+  AsmArgs A{};
+  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
+  A.values = out.dev; A.error = err.p;
+  A.lift_markers = dm.p; A.lift_values = dv.p; A.lift_x0 = x0 ? dx0.p : nullptr; A.lift_alpha = alpha;
+  for (const auto& I : a->integrals) launch_integral(a, I, A);
+  out.finish();
+  CFX_API_END
+}
+
+namespace
+{
+__global__ void set_bc_kernel(int64_t n, const int8_t* __restrict__ markers, const double* __restrict__ g,
+                              const double* __restrict__ x0, double alpha, double* __restrict__ b)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && markers[i]) b[i] = alpha * (g[i] - (x0 ? x0[i] : 0.0));
+}
+} // namespace
+
+int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, const double* x0, double alpha, double* b)
+{
+  CFX_API_BEGIN
+  require(n >= 0 && bc_markers && bc_values && b, CFX_ERR_INVALID_ARGUMENT, "cfx_set_bc: null argument");
+  ctx().ensure();
+  DevArray<int8_t> dm = to_device(bc_markers, n);
+  DevArray<double> dv = to_device(bc_values, n), dx0 = to_device(x0, x0 ? n : 0);
+  OutArray<double> out(b, n, true);
+  launch("set_bc", set_bc_kernel, grid_for(n), dim3(kBlock), 0, n, dm.p, dv.p, x0 ? dx0.p : nullptr, alpha, out.dev);
+  out.finish();
   CFX_API_END
 }
 

@@ -213,6 +213,32 @@ def assemble_vector(L: CutForm, b=None):
     return b
 
 
+def _vec_ptr(b):
+    return C.c_void_p(b.data_ptr()) if _lib.is_torch(b) else b.ctypes.data_as(C.c_void_p)
+
+
+def apply_lifting(b, a: CutForm, bc_markers, bc_values, x0=None, alpha: float = 1.0):
+    """b <- b - alpha A (g - x0) over the Dirichlet columns, entity by entity
+    (python/cutfemx/fem.py:604-632 -> lift_bc_impl, assemble_vector_impl.h:383-436).
+    `bc_markers` (int8) / `bc_values` / `x0` hold one entry per dof; one bilinear form,
+    i.e. one block of the reference's list-of-forms signature."""
+    keep: list = []
+    _lib.check(_lib.lib().cfx_apply_lifting(
+        a._h, _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float64, keep),
+        _lib.as_ptr(x0, np.float64, keep), C.c_double(alpha), _vec_ptr(b)))
+    return b
+
+
+def set_bc(b, bc_markers, bc_values, x0=None, alpha: float = 1.0):
+    """b[dofs] = alpha (g - x0) on the marked dofs (dolfinx.fem.set_bc / DirichletBC.set)."""
+    keep: list = []
+    n = b.numel() if _lib.is_torch(b) else b.size
+    _lib.check(_lib.lib().cfx_set_bc(
+        C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float64, keep),
+        _lib.as_ptr(x0, np.float64, keep), C.c_double(alpha), _vec_ptr(b)))
+    return b
+
+
 def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np.ndarray:
     """Local tensor of one entity (for local-entry parity checks)."""
     V = a.function_space

@@ -227,6 +227,19 @@ int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0,
                         const int8_t* bc1, double* values);
 /* assemble_vector(): assembler.h:252-262 -> assemble_vector_impl.h:573-767 */
 int cfx_assemble_vector(cfx_form_t L, double* b);
+
+/* Dirichlet lifting  b <- b - alpha A (g - x0)  restricted to the Dirichlet columns, formed entity by
+ * entity without the assembled matrix: dolfinx_custom_data::fem::apply_lifting / lift_bc_impl
+ * (cpp/dolfinx_custom_data/fem/assemble_vector_impl.h:383-436, python/cutfemx/fem.py:604-632).
+ * bc_markers / bc_values / x0 (nullable) have one entry per dof (ndofs * bs); only entities with a
+ * marked column are tabulated (LiftingMode).  All integrals of the form take part: uncut cells,
+ * runtime-rule cells and interior facets. */
+int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_values, const double* x0,
+                      double alpha, double* b);
+/* b[i] = alpha (g[i] - x0[i]) on the marked dofs: dolfinx::fem::DirichletBC::set as called by
+ * python/demo/demo_elasticity.py:87-93 after the lifting. */
+int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, const double* x0, double alpha,
+               double* b);
 /* local tensor of one entity (parity tests of local entries) */
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
 

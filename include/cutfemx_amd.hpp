@@ -343,6 +343,27 @@ inline void assemble_matrix(std::span<double> values, const Form& a, const Spars
 /// assemble_vector(): assembler.h:252-262
 inline void assemble_vector(std::span<double> b, const Form& L) { check(cfx_assemble_vector(L.handle.h, b.data())); }
 
+/// apply_lifting(): b <- b - alpha A (g - x0) over the Dirichlet columns
+/// (cpp/dolfinx_custom_data/fem/assemble_vector_impl.h:383-436); one form, markers/values per dof
+inline void apply_lifting(std::span<double> b, const Form& a, std::span<const std::int8_t> bc_markers,
+                          std::span<const double> bc_values, std::span<const double> x0 = {}, double alpha = 1.0)
+{
+  if (bc_markers.size() != b.size() || bc_values.size() != b.size() || (!x0.empty() && x0.size() != b.size()))
+    throw std::invalid_argument("apply_lifting: marker / value arrays must have one entry per dof");
+  check(cfx_apply_lifting(a.handle.h, bc_markers.data(), bc_values.data(), x0.empty() ? nullptr : x0.data(), alpha,
+                          b.data()));
+}
+
+/// DirichletBC::set: b[dofs] = alpha (g - x0)
+inline void set_bc(std::span<double> b, std::span<const std::int8_t> bc_markers, std::span<const double> bc_values,
+                   std::span<const double> x0 = {}, double alpha = 1.0)
+{
+  if (bc_markers.size() != b.size() || bc_values.size() != b.size() || (!x0.empty() && x0.size() != b.size()))
+    throw std::invalid_argument("set_bc: marker / value arrays must have one entry per dof");
+  check(cfx_set_bc((std::int64_t)b.size(), bc_markers.data(), bc_values.data(), x0.empty() ? nullptr : x0.data(), alpha,
+                   b.data()));
+}
+
 /// cutfemx::fem::ActiveDomain (deactivate.h:387-400)
 struct ActiveDomain
 {

@@ -1273,6 +1273,42 @@ int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
   return 0;
 }
 
+/* Dirichlet lifting: b -= alpha Ae (g - x0) over the marked columns, only on      */
+/* entities that have one.  ref: assemble_vector_impl.h:383-436 (lifting_fn),     */
+/* assemble_matrix_impl.h LiftingMode                                            */
+int orc_apply_lifting(const orc_mesh* mesh, const orc_space* V,
+                      const orc_integral* integrals, int n_integrals,
+                      const int8_t* markers, const double* g, const double* x0,
+                      double alpha, double* b)
+{
+  double Ae[MAXLOC * MAXLOC];
+  int32_t dofs[MAXLOC];
+  for (int ii = 0; ii < n_integrals; ++ii)
+  {
+    const orc_integral* I = &integrals[ii];
+    for (int part = 0; part < 2; ++part)
+    {
+      const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+      for (int64_t e = 0; e < ne; ++e)
+      {
+        const int n = entity_dofs(V, I, e, part, dofs);
+        int any = 0;
+        for (int j = 0; j < n; ++j) any |= markers[dofs[j]] != 0;
+        if (!any) continue;
+        memset(Ae, 0, sizeof(double) * (size_t)(n * n));
+        orc_tabulate_entity(mesh, V, I, e, part, Ae);
+        for (int j = 0; j < n; ++j)
+          if (markers[dofs[j]])
+          {
+            const double d = alpha * (g[dofs[j]] - (x0 ? x0[dofs[j]] : 0.0));
+            for (int i = 0; i < n; ++i) b[dofs[i]] -= Ae[i * n + j] * d;
+          }
+      }
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------ */
 /* a11 active domain / deactivation                                          */
 /* ref: cpp/cutfemx/fem/deactivate.h:103-162 (cells), :164-183 (indicator),  */

@@ -137,6 +137,11 @@ int orc_assemble_matrix(const orc_mesh* mesh, const orc_space* V,
 int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
                         const orc_integral* integrals, int n_integrals,
                         double* b);
+/* b -= alpha Ae (g - x0) on entities with a Dirichlet column: assemble_vector_impl.h:383-436 */
+int orc_apply_lifting(const orc_mesh* mesh, const orc_space* V,
+                      const orc_integral* integrals, int n_integrals,
+                      const int8_t* markers, const double* g, const double* x0,
+                      double alpha, double* b);
 /* local tensor of one entity (for local-entry parity tests) */
 int orc_tabulate_entity(const orc_mesh* mesh, const orc_space* V,
                         const orc_integral* integral, int64_t entity_or_rule,

@@ -307,6 +307,16 @@ def assemble_vector(mesh, V: Space, integrals):
     return b
 
 
+def apply_lifting(mesh, V: Space, integrals, markers, g, b, x0=None, alpha=1.0):
+    arr = _integral_array(integrals)
+    markers = np.ascontiguousarray(markers, dtype=np.int8)
+    g = np.ascontiguousarray(g, dtype=np.float64)
+    x0 = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+    lib().orc_apply_lifting(C.byref(mesh.c), C.byref(V.c), arr, len(integrals), _p(markers), _p(g), _p(x0),
+                            C.c_double(alpha), _p(b))
+    return b
+
+
 def tabulate_entity(mesh, V: Space, integral: Integral, idx: int, use_rule: bool):
     ic = integral.cstruct()
     nloc = V.dofmap.shape[1] * V.bs * (2 if integral.type == INTERIOR_FACET else 1)

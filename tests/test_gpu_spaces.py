@@ -137,6 +137,55 @@ def test_dirichlet_markers_zero_rows_and_columns(oracle, mode, monkeypatch):
     assert np.all(M[bc == 1, :] == 0) and np.all(M[:, bc == 1] == 0)
 
 
+@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 6, 1, 1), (2, 10, 2, 1), (3, 4, 2, 3)])
+def test_apply_lifting_and_set_bc(oracle, tdim, n, degree, bs):
+    # assemble_vector_impl.h:383-436 (lifting_fn), python/demo/demo_elasticity.py:67-93
+    import cutfemx_amd as cfx
+    s = setup(oracle, tdim, n, degree, bs)
+    O, om, dom, cd, oV = s["O"], s["om"], s["dom"], s["cd"], s["oV"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 2)
+    vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+    q = 2 * (degree - 1)
+    if bs == 1:
+        oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+        oa = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=ovol, qdegree=q),
+              O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.1,), qdegree=q)]
+        ga = [cfx.fem.Integral(cfx.fem.STIFFNESS, cells=inside, rules=vol, qdegree=q),
+              cfx.fem.Integral(cfx.fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=q)]
+    else:
+        oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=inside, rules=ovol, params=(1.0e3, 0.3), qdegree=q)]
+        ga = [cfx.fem.Integral(cfx.fem.ELASTICITY, cells=inside, rules=vol, params=(1.0e3, 0.3), qdegree=q)]
+    ndofs = oV.ndofs * bs
+    rng = np.random.default_rng(5)
+    markers = np.zeros(ndofs, dtype=np.int8)
+    touched = np.unique(oV.dofmap[inside])
+    chosen = touched[::5]
+    for k in range(bs):
+        markers[chosen * bs + k] = 1
+    g = rng.standard_normal(ndofs)
+    x0 = rng.standard_normal(ndofs)
+    b0 = rng.standard_normal(ndofs)
+    a = cfx.fem.form(ga, s["V"])
+    for alpha, x in [(1.0, None), (0.7, x0)]:
+        want = O.apply_lifting(om, oV, oa, markers, g, b0.copy(), x0=x, alpha=alpha)
+        got = cfx.fem.apply_lifting(b0.copy(), a, markers, g, x0=x, alpha=alpha)
+        assert rel_err(got, want) < RTOL
+        # the same thing through the unconstrained matrix: b - alpha A (g - x0) restricted to marked columns
+        A = cfx.fem.assemble_matrix(a).to_scipy()
+        d = np.where(markers == 1, alpha * (g - (0.0 if x is None else x)), 0.0)
+        assert rel_err(got, b0 - A @ d) < 1e-11
+        fixed = cfx.fem.set_bc(got.copy(), markers, g, x0=x, alpha=alpha)
+        assert np.array_equal(fixed[markers == 0], got[markers == 0])
+        assert np.allclose(fixed[markers == 1], d[markers == 1], rtol=0, atol=0)
+    # device vectors
+    import torch
+    bt = torch.tensor(b0, device="cuda")
+    cfx.fem.apply_lifting(bt, a, torch.tensor(markers, device="cuda"), torch.tensor(g, device="cuda"))
+    assert rel_err(bt.cpu().numpy(), O.apply_lifting(om, oV, oa, markers, g, b0.copy())) < RTOL
+
+
 @pytest.mark.parametrize("kernel,order,tol", [("stiffness", 2, 1e-12), ("mass", 2, 1e-12), ("elasticity", 2, 1e-9)])
 def test_runtime_vs_standard_matrix_on_gpu(oracle, kernel, order, tol):
     # test_assembly_poisson.py:18-59, test_assembly_elasticity.py:18-68: whole-cell runtime

@@ -44,6 +44,9 @@ B_UNCUT_CELL = 60.0             # id 4 + geometry dofmap 16 + dofmap 16 + coords
 B_QUAD_PER_POINT = 32.0         # (tdim+1)*8 written per emitted point (3-D)
 B_QUAD_PER_CUT_CELL = 152.0     # dofmap 16 + coords 96 + phi 32 + offsets/parent 8
 B_GHOST_FACET = 600.0           # row ids 16 + 2x(16+16) maps + 64 values x 8 B
+# sparsity (not priced in SURVEY 8d): per marked cell its dofmap row (16 B) and its four
+# incidence entries (16 B), per CSR entry 4 B written, per row 8 B of indptr
+B_PATTERN_PER_CELL, B_PATTERN_PER_NNZ, B_PATTERN_PER_ROW = 32.0, 4.0, 8.0
 
 
 def parse():
@@ -57,6 +60,8 @@ def parse():
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     p.add_argument("--cpu-n", type=int, default=160, help="mesh size of the bounded CPU sample")
     p.add_argument("--no-secondary", action="store_true", help="skip the 128^3 (configs[1]) line")
+    p.add_argument("--cpu-worker", nargs=4, type=int, metavar=("N", "Z0", "Z1", "ORDER"),
+                   help="internal: one process of the all-cores CPU baseline")
     return p.parse_args()
 
 
@@ -153,6 +158,46 @@ def cpu_baseline(n, order):
                 host_cores_available=os.cpu_count())
 
 
+def cpu_slab_worker(n, z0, z1, order):
+    """One of `cores` CPU processes: the oracle hot path on the cell layers z0..z1-1 of the
+    n^3 mesh (the reference's `mpirun -n cores` decomposition, without ghost layers)."""
+    import numpy as np
+    from helpers import level_set_values, oracle_poisson
+    from oracle import pyoracle as O
+    O.build()
+    full = O.mesh_box(3, n)
+    s2 = (n + 1) ** 2
+    om = O.Mesh(3, full.x[s2 * z0: s2 * (z1 + 1)], full.conn[6 * n * n * z0: 6 * n * n * z1] - s2 * z0)
+    phi = level_set_values(om.x, 3)
+    t0 = time.perf_counter()
+    ref = oracle_poisson(O, om, phi, order=order)
+    vals, b = ref["values"], ref["b"]
+    O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, b)
+    dt = time.perf_counter() - t0
+    owned_hi = s2 * (z1 - z0 + (1 if z1 == n else 0))       # the lower rank owns a shared plane
+    active = owned_hi - int(np.count_nonzero(ref["inactive"] < owned_hi))
+    print(json.dumps(dict(seconds=dt, active=active)))
+
+
+def cpu_baseline_all_cores(n, order):
+    """The same CPU port run as one process per host core on z-slabs of the bounded sample:
+    stand-in for the reference under `mpirun -n <cores>`.  Children are separate
+    programs (no GPU use); throughput = active dofs / slowest process."""
+    import subprocess
+    cores = max(1, min(os.cpu_count() or 1, n))
+    bounds = [round(i * n / cores) for i in range(cores + 1)]
+    procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", str(n), str(bounds[i]),
+                               str(bounds[i + 1]), str(order)], stdout=subprocess.PIPE, text=True,
+                              env={**os.environ, "OMP_NUM_THREADS": "1"})
+             for i in range(cores) if bounds[i + 1] > bounds[i]]
+    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    secs = max(o["seconds"] for o in outs)
+    active = sum(o["active"] for o in outs)
+    return dict(value=active / secs, unit="DOF/s", cores=len(procs), kind="port",
+                sample=f"{n}^3 sphere workload split into {len(procs)} z-slabs, one oracle process per host core "
+                       f"(no ghost layers), slowest process {secs:.1f} s", seconds=secs, active_dofs=active)
+
+
 def kernel_profile(_lib, step, psteps):
     """Per-kernel HIP-event times (events on the launch stream) over psteps steps."""
     _lib.check(_lib.lib().cfx_profile_enable(1))
@@ -242,6 +287,9 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     alg_bytes = {
         "classify": B_CLASSIFY_PER_CELL * mesh.num_cells,
         "assemble_rows": B_UNCUT_CELL * info["n_inside"],
+        "assemble_rows_p1": B_UNCUT_CELL * info["n_inside"],
+        "pattern_rows": (B_PATTERN_PER_CELL * (info["n_inside"] + info["n_cut"]) + B_PATTERN_PER_NNZ * info["nnz"]
+                         + B_PATTERN_PER_ROW * info["active_dofs"]),
         "cut_emit": (B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])
                      + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])) / 2,   # two launches per step
         "assemble_facets": B_GHOST_FACET * info["n_ghost"],
@@ -252,7 +300,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
             ach = ab / (kernels[name]["avg_us"] * 1e-6) / 1e9
             roof[name] = dict(avg_us=round(kernels[name]["avg_us"], 2), algorithmic_bytes=ab,
                               achieved_GBs=round(ach, 1), frac=round(ach / HBM_PEAK_GBS, 4))
-    dominant = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    priced = [k for k in kernels if alg_bytes.get(k)]
+    dominant = max(priced, key=lambda k: kernels[k]["total_ms"]) if priced else None
     roofline = None
     if dominant is not None:
         k = kernels[dominant]
@@ -277,6 +326,9 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
 
 def main():
     args = parse()
+    if args.cpu_worker:
+        cpu_slab_worker(*args.cpu_worker)
+        return
     import torch
     import torch.distributed as dist
 
@@ -328,6 +380,7 @@ def main():
             out["config_128"] = {"workload": "configs[1]: 128^3 background mesh, same form", "value": s["value"],
                                  "unit": "DOF/s", "ms_per_step": s["ms_per_step"], "active_dofs": s["active_dofs"]}
         out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
+        out["cpu_baseline_all_cores"] = None if args.no_cpu else cpu_baseline_all_cores(args.cpu_n, args.order)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -288,6 +288,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         "classify": B_CLASSIFY_PER_CELL * mesh.num_cells,
         "assemble_rows": B_UNCUT_CELL * info["n_inside"],
         "assemble_rows_p1": B_UNCUT_CELL * info["n_inside"],
+        "assemble_rows_plain": B_UNCUT_CELL * info["n_inside"],
         "pattern_rows": (B_PATTERN_PER_CELL * (info["n_inside"] + info["n_cut"]) + B_PATTERN_PER_NNZ * info["nnz"]
                          + B_PATTERN_PER_ROW * info["active_dofs"]),
         "cut_emit": (B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])

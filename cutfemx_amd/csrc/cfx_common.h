@@ -270,6 +270,21 @@ struct Adjacency
 
 void build_adjacency(const int32_t* map, int64_t ncells, int width, int64_t nitems, Adjacency& adj);
 
+// Mesh-static row stencil of a P1 space on the geometry dofmap: the sorted neighbour list of
+// every dof (the CSR row it has when all its cells are present) and, for every (dof, incident
+// cell) pair of the dof->cells incidence, the positions of the cell's dofs inside that list.
+// A row whose items are uncut cells only is then a SUBSET of its stencil: the sparsity and
+// assembly kernels describe it by a 64-bit mask and find CSR slots by popcount, with no hash
+// set, no sort and no column search.
+struct Stencil
+{
+  DevArray<int64_t> offsets; // [ndofs+1]
+  DevArray<int32_t> nbr;     // neighbours incl. the dof itself, ascending
+  DevArray<uint32_t> slot4;  // parallel to dof_cells().cells: byte j = position of the cell's j-th dof
+  DevArray<uint8_t> diagpos; // position of the dof in its own list
+  bool built = false, usable = false;
+};
+
 } // namespace cfx
 
 struct cfx_mesh_s
@@ -317,6 +332,7 @@ struct cfx_space_s
   cfx::DevArray<int32_t> dofmap;
   cfx::Adjacency d2c; // dof -> cells
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
+  cfx::Stencil stencil; // built on first use by cfx::space_stencil()
   const cfx::Adjacency& dof_cells()
   {
     // a P1 space whose dofmap aliases the geometry dofmap shares the mesh's vertex->cells table
@@ -348,6 +364,9 @@ struct cfx_row_plan
   int64_t n_active_rows = 0;
   cfx::DevArray<int32_t> special_rows; // active rows next to the interface: touched by a runtime-rule cell or a facet
   int64_t n_special_rows = 0;
+  cfx::DevArray<int32_t> plain_rows;   // the other active rows: uncut-cell items only
+  int64_t n_plain_rows = 0;
+  uint64_t serial = 0;                 // identity of this plan (a pattern remembers the plan it was built from)
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
@@ -382,6 +401,7 @@ struct cfx_form_s
 namespace cfx
 {
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
+const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values);
 bool assemble_vector_rows(cfx_form_s* L, double* b);
@@ -391,6 +411,7 @@ struct cfx_pattern_s
 {
   int64_t nrows = 0, nnz = 0;
   int max_row_len = 0; // upper bound on the scalar-dof row length
+  uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)
   cfx::DevArray<int64_t> indptr;
   cfx::DevArray<int32_t> indices;
 };

@@ -81,6 +81,8 @@ struct RowArgs
   int iso_geometry; // the space's dofmap is the geometry dofmap (P1): dofs are vertex ids
   unsigned mark_mask;   // cell-mark bits this launch handles: 0x0F uncut entities, 0xF0 runtime rules (+ facets)
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
+  const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
+  const uint8_t* diagpos;
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -762,6 +764,191 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
   }
 }
 
+// ---------------------------------------------------------------------------
+// stage 2, bilinear forms, PLAIN rows: active rows whose items are uncut cells only.
+// Their CSR row is the subset of the mesh-static stencil selected by a 64-bit mask
+// (build_pattern laid it out that way), so the CSR slot of a column is
+// popcount(mask below its stencil position) and the position comes with the incidence
+// entry (Stencil::slot4): no column list in LDS, no search, no comparison against r.
+// ---------------------------------------------------------------------------
+#ifndef CFX_PLAIN_WAVES
+#define CFX_PLAIN_WAVES 6
+#endif
+template <int TDIM, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_kernel(RowArgs A)
+{
+  constexpr int ND = TDIM + 1;
+  constexpr int RPW = kWave / G;
+  constexpr int KMAX = CAP / G;
+  constexpr int R = 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  __shared__ double s_val[RPW][CAP + 1];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n_active;
+  const int64_t r = live ? A.active_rows[ri] : 0;
+  const int64_t rb = live ? A.indptr[r] : 0;
+  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len) s_val[grp][k] = 0.0;
+  }
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = (live && len > 0) ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  const unsigned dpos = live ? A.diagpos[r] : 0u;
+  const bool row_bc = live && A.bc0 && A.bc0[r];
+  const bool diag_bc = row_bc || (live && A.bc1 != nullptr && A.bc1[r] != 0);
+  double xr[TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) xr[d] = 0.0;
+  if (live) load_vertex<TDIM>(A.x, r, xr);
+
+  // the first R*G items stay in registers between the mask pass and the add pass
+  int32_t cell[R];
+  uint32_t s4[R];
+  uint8_t mk[R];
+  auto load_chunk = [&](int base)
+  {
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      const int t = base + k * G + gl;
+      cell[k] = t < nc ? A.d2c[cb + t] : -1;
+      s4[k] = t < nc ? A.slot4[cb + t] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
+  };
+  load_chunk(0);
+  unsigned long long mask = 0;
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    if (mk[k])
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) mask |= 1ull << ((s4[k] >> (8 * j)) & 0xffu);
+    }
+  for (int base = R * G;; base += R * G) // vertices with more than R*G cells (unstructured meshes)
+  {
+    if (__ballot(base + gl < nc) == 0) break;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      const int t = base + k * G + gl;
+      if (t < nc && A.cellmark[A.d2c[cb + t]])
+      {
+        const uint32_t w = A.slot4[cb + t];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) mask |= 1ull << ((w >> (8 * j)) & 0xffu);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, G);
+  // the pattern row must be exactly this subset (build_pattern from the same plan)
+  if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
+  __syncthreads();
+
+  double dsum = 0.0;
+  for (int base = 0;; base += R * G)
+  {
+    if (__ballot(base + gl < nc) == 0) break;
+    if (base > 0) load_chunk(base);
+    int rep[R];
+    int32_t cd[R][ND];
+#pragma unroll
+    for (int k = 0; k < R; ++k) rep[k] = (len > 0 && cell[k] >= 0) ? __popc(mk[k] & A.inline_bits) : 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (!rep[k]) continue;
+      if constexpr (ND == 4)
+      {
+        const int4 v = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)cell[k] * 4);
+        cd[k][0] = v.x; cd[k][1] = v.y; cd[k][2] = v.z; cd[k][3] = v.w;
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) cd[k][j] = A.dofmap[(int64_t)cell[k] * ND + j];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (__ballot(rep[k] != 0) == 0) continue;
+      const bool has = rep[k] != 0;
+      int lr = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) lr = (((s4[k] >> (8 * j)) & 0xffu) == dpos) ? j : lr;
+      int32_t oc[TDIM];
+      int osl[TDIM];
+      double ov[TDIM];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) { oc[t] = has ? (t < lr ? cd[k][t] : cd[k][t + 1]) : (int32_t)r; osl[t] = -1; ov[t] = 0.0; }
+      if (has)
+      {
+        double xo[TDIM][TDIM], dg, off[TDIM];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) load_vertex<TDIM>(A.x, oc[t], xo[t]);
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+        {
+          const unsigned pos = (s4[k] >> (8 * (t < lr ? t : t + 1))) & 0xffu;
+          osl[t] = __popcll(mask & ((1ull << pos) - 1ull));
+        }
+        p1_stiffness_row<TDIM>(xr, xo, dg, off);
+        const double scale = (double)rep[k]; // the same cell in several inline integrals
+        dsum += diag_bc ? 0.0 : dg * scale;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+          ov[t] = (row_bc || (A.bc1 != nullptr && A.bc1[oc[t]] != 0)) ? 0.0 : off[t] * scale;
+      }
+      if constexpr (ORDERED)
+      {
+        for (int turn = 0; turn < G; ++turn) // one lane of each group at a time: item order
+        {
+          if (gl == turn)
+          {
+#pragma unroll
+            for (int t = 0; t < TDIM; ++t)
+              if (osl[t] >= 0) s_val[grp][osl[t]] += ov[t];
+          }
+          __syncthreads();
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t)
+          if (osl[t] >= 0) atomicAdd(&s_val[grp][osl[t]], ov[t]);
+      }
+    }
+  }
+  {
+    double d = dsum;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
+    if (gl == 0 && nc > 0 && len > 0) atomicAdd(&s_val[grp][__popcll(mask & ((1ull << dpos) - 1ull))], d);
+  }
+  __syncthreads();
+  double myval[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    myval[q] = k < len ? A.values[rb + k] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len) A.values[rb + k] = myval[q] + s_val[grp][k];
+  }
+}
+
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
 template <int TDIM, int DEG, int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
@@ -775,6 +962,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   const int64_t cb = live ? A.d2c_off[r] : 0;
   const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
   double part = 0.0; // items gl, gl+G, ... in ascending order
+  const unsigned dpos = (live && A.slot4) ? A.diagpos[r] : 0u;
   constexpr int R = G <= 4 ? 6 : 4;
   for (int base = 0;; base += R * G)
   {
@@ -782,11 +970,13 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
     int64_t cell[R];
     uint8_t mk[R];
     int lr[R];
+    uint32_t s4[R];
 #pragma unroll
     for (int k = 0; k < R; ++k)
     {
       const int t = base + k * G + gl;
       cell[k] = t < nc ? (int64_t)A.d2c[cb + t] : -1;
+      s4[k] = (A.slot4 && t < nc) ? A.slot4[cb + t] : 0u; // static stencil: local index without the dofmap row
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
@@ -795,8 +985,16 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
     {
       lr[k] = 0;
       if (!mk[k]) continue;
+      if (A.slot4)
+      {
 #pragma unroll
-      for (int j = 0; j < ND; ++j) lr[k] = (A.dofmap[cell[k] * ND + j] == (int32_t)r) ? j : lr[k];
+        for (int j = 0; j < ND; ++j) lr[k] = (((s4[k] >> (8 * j)) & 0xffu) == dpos) ? j : lr[k];
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) lr[k] = (A.dofmap[cell[k] * ND + j] == (int32_t)r) ? j : lr[k];
+      }
     }
 #pragma unroll
     for (int k = 0; k < R; ++k)
@@ -964,6 +1162,27 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         split = true;
         RowArgs F = A;
         F.inline_bits = inline_bits;
+        // rows laid out as stencil subsets by build_pattern from this very plan: slots by popcount
+        const Stencil& stn = a->V->stencil;
+        if (stn.usable && plan.n_plain_rows > 0 && P->stencil_plan == plan.serial)
+        {
+          RowArgs Q = F;
+          Q.n_active = plan.n_plain_rows; Q.active_rows = plan.plain_rows.p;
+          Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p;
+          const dim3 gq = xcd_grid((Q.n_active + 7) / 8);
+          if (mr <= 32)
+          {
+            if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 32, true>, gq, dim3(kWave), 0, Q);
+            else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 32, false>, gq, dim3(kWave), 0, Q);
+          }
+          else
+          {
+            if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 64, true>, gq, dim3(kWave), 0, Q);
+            else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 64, false>, gq, dim3(kWave), 0, Q);
+          }
+          // the uncut items of the interface rows keep the searching kernel
+          F.n_active = plan.n_special_rows; F.active_rows = plan.special_rows.p;
+        }
         const dim3 grid = xcd_grid((F.n_active + 7) / 8);
         if (mr <= 32)
         {
@@ -1002,6 +1221,11 @@ void run_vector(cfx_form_s* L, double* b)
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG>(L, st);
   A.values = b;
+  if constexpr (DEG == 1)
+  {
+    const Stencil& stn = space_stencil(L->V);
+    if (stn.usable) { A.slot4 = stn.slot4.p; A.diagpos = stn.diagpos.p; }
+  }
   if (A.n_active > 0)
     launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 4>, xcd_grid((A.n_active + 15) / 16), dim3(kWave), 0,
            A);
@@ -1021,6 +1245,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
                                      : run_matrix<3, 1>(a, P, bc0, bc1, values);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
+  require(err != 5, CFX_ERR_RUNTIME, "assemble_matrix: a stencil-subset row does not match its sparsity pattern");
   require(err != 4, CFX_ERR_INVALID_ARGUMENT, "assemble_matrix: a facet row does not join two cells across a shared facet");
   return true;
 }

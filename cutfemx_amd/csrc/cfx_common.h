@@ -283,6 +283,7 @@ struct Stencil
   DevArray<uint32_t> slot4;  // parallel to dof_cells().cells: byte j = position of the cell's j-th dof
   DevArray<uint8_t> diagpos; // position of the dof in its own list
   bool built = false, usable = false;
+  int max_len = 0; // longest neighbour list
 };
 
 } // namespace cfx

@@ -83,6 +83,8 @@ struct RowArgs
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
+  const int64_t* st_off;
+  const int32_t* st_nbr;
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -774,14 +776,19 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
 #ifndef CFX_PLAIN_WAVES
 #define CFX_PLAIN_WAVES 6
 #endif
-template <int TDIM, int G, int CAP, bool ORDERED>
+// STAGE (stencils of at most 32 vertices): the coordinates of the row's stencil vertices are
+// loaded once per row into LDS (~15 gathers) and every item reads its TDIM other vertices from
+// there by stencil position: no dofmap row and no coordinate gathers per item (~170 per row).
+template <int TDIM, int G, int CAP, bool ORDERED, bool STAGE>
 __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_kernel(RowArgs A)
 {
   constexpr int ND = TDIM + 1;
   constexpr int RPW = kWave / G;
   constexpr int KMAX = CAP / G;
   constexpr int R = 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  constexpr int SX = 32; // staged stencil entries per row
   __shared__ double s_val[RPW][CAP + 1];
+  __shared__ double s_x[STAGE ? RPW : 1][STAGE ? SX + 1 : 1][TDIM];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
   const bool live = ri < A.n_active;
@@ -803,7 +810,34 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   double xr[TDIM];
 #pragma unroll
   for (int d = 0; d < TDIM; ++d) xr[d] = 0.0;
-  if (live) load_vertex<TDIM>(A.x, r, xr);
+  if constexpr (STAGE)
+  {
+    const int64_t sb = live ? A.st_off[r] : 0;
+    const int slen = live ? (int)(A.st_off[r + 1] - sb) : 0;
+    int32_t vid[SX / G];
+#pragma unroll
+    for (int q = 0; q < SX / G; ++q)
+    {
+      const int p = gl + q * G;
+      vid[q] = p < slen ? A.st_nbr[sb + p] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < SX / G; ++q)
+    {
+      const int p = gl + q * G;
+      if (vid[q] >= 0)
+      {
+        double xv[TDIM];
+        load_vertex<TDIM>(A.x, vid[q], xv);
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) s_x[grp][p][d] = xv[d];
+      }
+    }
+  }
+  else
+  {
+    if (live) load_vertex<TDIM>(A.x, r, xr);
+  }
 
   // the first R*G items stay in registers between the mask pass and the add pass
   int32_t cell[R];
@@ -850,6 +884,14 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   // the pattern row must be exactly this subset (build_pattern from the same plan)
   if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
   __syncthreads();
+  if constexpr (STAGE)
+  {
+    if (live)
+    {
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) xr[d] = s_x[grp][dpos][d];
+    }
+  }
 
   double dsum = 0.0;
   for (int base = 0;; base += R * G)
@@ -860,19 +902,22 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
     int32_t cd[R][ND];
 #pragma unroll
     for (int k = 0; k < R; ++k) rep[k] = (len > 0 && cell[k] >= 0) ? __popc(mk[k] & A.inline_bits) : 0;
-#pragma unroll
-    for (int k = 0; k < R; ++k)
+    if constexpr (!STAGE)
     {
-      if (!rep[k]) continue;
-      if constexpr (ND == 4)
-      {
-        const int4 v = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)cell[k] * 4);
-        cd[k][0] = v.x; cd[k][1] = v.y; cd[k][2] = v.z; cd[k][3] = v.w;
-      }
-      else
-      {
 #pragma unroll
-        for (int j = 0; j < ND; ++j) cd[k][j] = A.dofmap[(int64_t)cell[k] * ND + j];
+      for (int k = 0; k < R; ++k)
+      {
+        if (!rep[k]) continue;
+        if constexpr (ND == 4)
+        {
+          const int4 v = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)cell[k] * 4);
+          cd[k][0] = v.x; cd[k][1] = v.y; cd[k][2] = v.z; cd[k][3] = v.w;
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j) cd[k][j] = A.dofmap[(int64_t)cell[k] * ND + j];
+        }
       }
     }
 #pragma unroll
@@ -883,22 +928,34 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
       int lr = 0;
 #pragma unroll
       for (int j = 0; j < ND; ++j) lr = (((s4[k] >> (8 * j)) & 0xffu) == dpos) ? j : lr;
+      unsigned opos[TDIM];
       int32_t oc[TDIM];
       int osl[TDIM];
       double ov[TDIM];
 #pragma unroll
-      for (int t = 0; t < TDIM; ++t) { oc[t] = has ? (t < lr ? cd[k][t] : cd[k][t + 1]) : (int32_t)r; osl[t] = -1; ov[t] = 0.0; }
+      for (int t = 0; t < TDIM; ++t)
+      {
+        opos[t] = has ? (s4[k] >> (8 * (t < lr ? t : t + 1))) & 0xffu : dpos;
+        if constexpr (STAGE) oc[t] = (has && A.bc1 != nullptr) ? A.st_nbr[A.st_off[r] + opos[t]] : (int32_t)r;
+        else oc[t] = has ? (t < lr ? cd[k][t] : cd[k][t + 1]) : (int32_t)r;
+        osl[t] = -1; ov[t] = 0.0;
+      }
       if (has)
       {
         double xo[TDIM][TDIM], dg, off[TDIM];
 #pragma unroll
-        for (int t = 0; t < TDIM; ++t) load_vertex<TDIM>(A.x, oc[t], xo[t]);
-#pragma unroll
         for (int t = 0; t < TDIM; ++t)
         {
-          const unsigned pos = (s4[k] >> (8 * (t < lr ? t : t + 1))) & 0xffu;
-          osl[t] = __popcll(mask & ((1ull << pos) - 1ull));
+          if constexpr (STAGE)
+          {
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d) xo[t][d] = s_x[grp][opos[t]][d];
+          }
+          else
+            load_vertex<TDIM>(A.x, oc[t], xo[t]);
         }
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) osl[t] = __popcll(mask & ((1ull << opos[t]) - 1ull));
         p1_stiffness_row<TDIM>(xr, xo, dg, off);
         const double scale = (double)rep[k]; // the same cell in several inline integrals
         dsum += diag_bc ? 0.0 : dg * scale;
@@ -1168,18 +1225,20 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         {
           RowArgs Q = F;
           Q.n_active = plan.n_plain_rows; Q.active_rows = plan.plain_rows.p;
-          Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p;
+          Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p; Q.st_off = stn.offsets.p; Q.st_nbr = stn.nbr.p;
           const dim3 gq = xcd_grid((Q.n_active + 7) / 8);
-          if (mr <= 32)
-          {
-            if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 32, true>, gq, dim3(kWave), 0, Q);
-            else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 32, false>, gq, dim3(kWave), 0, Q);
-          }
-          else
-          {
-            if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 64, true>, gq, dim3(kWave), 0, Q);
-            else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, 64, false>, gq, dim3(kWave), 0, Q);
-          }
+          const char* stage_env = getenv("CFX_PLAIN_STAGE");
+          const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');
+#define CFX_PLAIN(CAPP)                                                                                                \
+  do                                                                                                                   \
+  {                                                                                                                    \
+    if (det && stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, true, true>, gq, dim3(kWave), 0, Q);   \
+    else if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, true, false>, gq, dim3(kWave), 0, Q);     \
+    else if (stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, true>, gq, dim3(kWave), 0, Q);   \
+    else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, false>, gq, dim3(kWave), 0, Q);             \
+  } while (0)
+          if (mr <= 32) CFX_PLAIN(32); else CFX_PLAIN(64);
+#undef CFX_PLAIN
           // the uncut items of the interface rows keep the searching kernel
           F.n_active = plan.n_special_rows; F.active_rows = plan.special_rows.p;
         }

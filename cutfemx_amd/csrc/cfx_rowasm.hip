@@ -677,6 +677,7 @@ const Stencil& space_stencil(cfx_space_s* V)
   // count, scan, then build every set again and write it in place (no ndofs x 64 staging)
   launch("stencil_rows", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
   if (read_scalar(overflow.p)) return S; // a vertex with more than 63 neighbours: keep the hashed paths
+  S.max_len = read_scalar(maxlen.p);
   S.offsets.alloc(V->ndofs + 1);
   exclusive_scan(counts.p, S.offsets.p, V->ndofs);
   S.nbr.alloc(read_scalar(S.offsets.p + V->ndofs));

@@ -10,6 +10,6 @@ for f in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']
-print('ms/step', round(d['ms_per_step'],3), {n: round(k[n]['avg_us'],1) for n in ('assemble_rows','assemble_rows_p1','assemble_rows_cut','plan_special_rows','assemble_vec_rows','pattern_rows') if n in k})
+print('ms/step', round(d['ms_per_step'],3), {n: round(k[n]['avg_us'],1) for n in ('assemble_rows_plain','assemble_rows_p1','assemble_rows_cut','assemble_vec_rows','pattern_rows','pattern_plain') if n in k})
 "
 done

@@ -47,7 +47,7 @@ class PatternView(C.Structure):
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
     "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_copy",
-    "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_profile_enable", "cfx_profile_reset",
+    "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
@@ -170,6 +170,11 @@ def as_ptr(a, dtype, keep: list):
     arr = np.ascontiguousarray(a, dtype=dtype)
     keep.append(arr)
     return arr.ctypes.data_as(C.c_void_p)
+
+
+def release_cache():
+    """Give the engine's cached HBM blocks back to the driver (they are reused between steps otherwise)."""
+    check(lib().cfx_device_cache_release())
 
 
 def download(ptr, n: int, dtype) -> np.ndarray:

@@ -356,6 +356,14 @@ int cfx_device_free(void* ptr)
   CFX_API_END
 }
 
+int cfx_device_cache_release(void)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  dev_cache_release();
+  CFX_API_END
+}
+
 int cfx_device_memset(void* ptr, int byte, size_t bytes)
 {
   CFX_API_BEGIN

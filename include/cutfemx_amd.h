@@ -133,6 +133,7 @@ int cfx_synchronize(void);
 int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
 int cfx_device_alloc(void** ptr, size_t bytes);
 int cfx_device_free(void* ptr);
+int cfx_device_cache_release(void); /* hand the library's cached (free) HBM blocks back to the driver */
 int cfx_device_memset(void* ptr, int byte, size_t bytes); /* la::MatrixCSR::set_value(0) / la::Vector zeroing, on the stream */
 /* per-kernel HIP-event timing of the launches made by this library */
 int cfx_profile_enable(int on);

@@ -34,7 +34,12 @@ def _torch():
 
 
 def _need_hbm(gib):
+    import gc
     torch = _torch()
+    from cutfemx_amd import _lib
+    gc.collect()
+    torch.cuda.empty_cache()
+    _lib.release_cache()       # blocks cached by earlier tests
     free, _ = torch.cuda.mem_get_info()
     if free < gib * 2 ** 30:
         pytest.skip(f"needs {gib} GiB of free HBM, {free / 2 ** 30:.0f} available")
@@ -148,7 +153,7 @@ def oracle_slab(oracle, cfx, n, z0, nz, kind, device, degree=1):
 
 
 # --------------------------------------------------------------------------- config 3
-@pytest.fixture(scope="module")
+@pytest.fixture(scope="class")
 def sphere512():
     torch = _torch()
     import cutfemx_amd as cfx
@@ -169,97 +174,101 @@ def sphere512():
     del A, system, cd
 
 
-def test_cfg3_counts_volume_area(sphere512):
-    s, torch = sphere512, _torch()
-    from cutfemx_amd.dist import as_torch
-    n, dev, sysm = s["n"], s["dev"], s["system"]
-    dom = s["cd"].domain()
-    n_in, n_cut, n_out = int((dom == -1).sum()), int((dom == 0).sum()), int((dom == 1).sum())
-    assert n_in + n_cut + n_out == 6 * n ** 3
-    vr, ir = sysm.volume_rules, sysm.interface_rules
-    assert sysm.inside_cells[1] == n_in
-    # every cut cell hosts volume rules and interface rules (one per sub-facet), parents ascending
-    for rules in (vr, ir):
-        parents = rules.parent_map
-        assert np.all(np.diff(parents) >= 0) and np.unique(parents).size == n_cut
-        assert np.all(dom[parents] == 0)
-    wv = as_torch(vr._view.weights, vr.total_points, "float64", dev)
-    wi = as_torch(ir._view.weights, ir.total_points, "float64", dev)
-    assert float(wv.min()) > 0.0 and float(wi.min()) > 0.0
-    volume = float(wv.sum()) + n_in / (6.0 * n ** 3)
-    area = float(wi.sum())
-    # P1 interpolation of the sphere: O(h^2) geometric error, h = 1/512
-    assert abs(volume - 4.0 / 3.0 * math.pi * RADIUS ** 3) < 1e-4 * volume
-    assert abs(area - 4.0 * math.pi * RADIUS ** 2) < 1e-4 * area
-    s["volume"] = volume
+class TestConfig3:
+    """512^3 P1 sphere system, built once for the three checks below and freed afterwards."""
+
+    def test_cfg3_counts_volume_area(self, sphere512):
+        s, torch = sphere512, _torch()
+        from cutfemx_amd.dist import as_torch
+        n, dev, sysm = s["n"], s["dev"], s["system"]
+        dom = s["cd"].domain()
+        n_in, n_cut, n_out = int((dom == -1).sum()), int((dom == 0).sum()), int((dom == 1).sum())
+        assert n_in + n_cut + n_out == 6 * n ** 3
+        vr, ir = sysm.volume_rules, sysm.interface_rules
+        assert sysm.inside_cells[1] == n_in
+        # every cut cell hosts volume rules and interface rules (one per sub-facet), parents ascending
+        for rules in (vr, ir):
+            parents = rules.parent_map
+            assert np.all(np.diff(parents) >= 0) and np.unique(parents).size == n_cut
+            assert np.all(dom[parents] == 0)
+        wv = as_torch(vr._view.weights, vr.total_points, "float64", dev)
+        wi = as_torch(ir._view.weights, ir.total_points, "float64", dev)
+        assert float(wv.min()) > 0.0 and float(wi.min()) > 0.0
+        volume = float(wv.sum()) + n_in / (6.0 * n ** 3)
+        area = float(wi.sum())
+        # P1 interpolation of the sphere: O(h^2) geometric error, h = 1/512
+        assert abs(volume - 4.0 / 3.0 * math.pi * RADIUS ** 3) < 1e-4 * volume
+        assert abs(area - 4.0 * math.pi * RADIUS ** 2) < 1e-4 * area
+        s["volume"] = volume
 
 
-@pytest.mark.parametrize("k0", [210, 366])
-def test_cfg3_plane_rows_match_oracle_slab(sphere512, oracle, k0):
-    s = sphere512
-    cfx, n, dev = s["cfx"], s["n"], s["dev"]
-    z0, nz = k0 - 3, 6
-    om, phi = oracle_slab(oracle, cfx, n, z0, nz, "sphere", dev)
-    voff = (n + 1) ** 2 * z0
-    assert np.array_equal(phi, s["phi"][voff:voff + phi.size].cpu().numpy())   # identical inputs
-    o = oracle_poisson(oracle, om, phi)
-    # classification of the slab's cells, bit-exact
-    c0, c1 = 6 * n * n * z0, 6 * n * n * (z0 + nz)
-    dom = s["cd"].domain()[c0:c1]
-    assert np.array_equal(dom, o["domain"])
-    # runtime rules of the slab's cut cells
-    from cutfemx_amd import _lib
-    for rules, want in ((s["system"].volume_rules, o["vol"]), (s["system"].interface_rules, o["itf"])):
-        parents = rules.parent_map
-        r0, r1 = np.searchsorted(parents, [c0, c1])
-        assert np.array_equal(parents[r0:r1] - c0, want.parent_map)
-        offs = rules.offsets
-        q0, q1 = int(offs[r0]), int(offs[r1])
-        assert np.array_equal(offs[r0:r1 + 1] - q0, want.offsets)
-        w = _lib.download(rules._view.weights + 8 * q0, q1 - q0, np.float64)
-        p = _lib.download(rules._view.points + 24 * q0, 3 * (q1 - q0), np.float64).reshape(-1, 3)
-        assert rel_err(w, want.weights) < RTOL
-        assert np.abs(p - want.points).max() < 1e-13
-    full, slab = Numbering(n, 0, n, 1), Numbering(n, z0, nz, 1)
-    nnz = compare_plane(s["A"], s["b"].cpu().numpy(), full, o, slab, k0)
-    assert nnz > (n + 1) ** 2     # the plane crosses the sphere: more than the diagonal
-    # inactive dofs of the plane
-    act = cfx.fem.active_domain(s["system"].a)
-    ina = act.inactive_dofs
-    lo = (n + 1) ** 2 * k0
-    mine = ina[(ina >= lo) & (ina < lo + (n + 1) ** 2)]
-    want = o["inactive"]
-    want = want[(want >= lo - voff) & (want < lo - voff + (n + 1) ** 2)] + voff
-    assert np.array_equal(mine, want)
+    @pytest.mark.parametrize("k0", [210, 366])
+    def test_cfg3_plane_rows_match_oracle_slab(self, sphere512, oracle, k0):
+        s = sphere512
+        cfx, n, dev = s["cfx"], s["n"], s["dev"]
+        z0, nz = k0 - 3, 6
+        om, phi = oracle_slab(oracle, cfx, n, z0, nz, "sphere", dev)
+        voff = (n + 1) ** 2 * z0
+        assert np.array_equal(phi, s["phi"][voff:voff + phi.size].cpu().numpy())   # identical inputs
+        o = oracle_poisson(oracle, om, phi)
+        # classification of the slab's cells, bit-exact
+        c0, c1 = 6 * n * n * z0, 6 * n * n * (z0 + nz)
+        dom = s["cd"].domain()[c0:c1]
+        assert np.array_equal(dom, o["domain"])
+        # runtime rules of the slab's cut cells
+        from cutfemx_amd import _lib
+        for rules, want in ((s["system"].volume_rules, o["vol"]), (s["system"].interface_rules, o["itf"])):
+            parents = rules.parent_map
+            r0, r1 = np.searchsorted(parents, [c0, c1])
+            assert np.array_equal(parents[r0:r1] - c0, want.parent_map)
+            offs = rules.offsets
+            q0, q1 = int(offs[r0]), int(offs[r1])
+            assert np.array_equal(offs[r0:r1 + 1] - q0, want.offsets)
+            w = _lib.download(rules._view.weights + 8 * q0, q1 - q0, np.float64)
+            p = _lib.download(rules._view.points + 24 * q0, 3 * (q1 - q0), np.float64).reshape(-1, 3)
+            assert rel_err(w, want.weights) < RTOL
+            assert np.abs(p - want.points).max() < 1e-13
+        full, slab = Numbering(n, 0, n, 1), Numbering(n, z0, nz, 1)
+        nnz = compare_plane(s["A"], s["b"].cpu().numpy(), full, o, slab, k0)
+        assert nnz > (n + 1) ** 2     # the plane crosses the sphere: more than the diagonal
+        # inactive dofs of the plane
+        act = cfx.fem.active_domain(s["system"].a)
+        ina = act.inactive_dofs
+        lo = (n + 1) ** 2 * k0
+        mine = ina[(ina >= lo) & (ina < lo + (n + 1) ** 2)]
+        want = o["inactive"]
+        want = want[(want >= lo - voff) & (want < lo - voff + (n + 1) ** 2)] + voff
+        assert np.array_equal(mine, want)
 
 
-def test_cfg3_size_independent_properties(sphere512):
-    s, torch = sphere512, _torch()
-    cfx, dev, sysm, V = s["cfx"], s["dev"], s["system"], s["V"]
-    fem = cfx.fem
-    # (1) sum(b) == |Omega_h| for f = 1
-    L1 = fem.form([fem.Integral(fem.SOURCE, cells=sysm.inside_cells, rules=sysm.volume_rules,
-                                params=(fem.F_ONE, 1.0), qdegree=1)], V)
-    b1 = torch.zeros(V.ndofs, device=dev, dtype=torch.float64)
-    fem.assemble_vector(L1, b1)
-    vr = sysm.volume_rules
-    from cutfemx_amd.dist import as_torch
-    volume = float(as_torch(vr._view.weights, vr.total_points, "float64", dev).sum()) \
-        + sysm.inside_cells[1] / (6.0 * s["n"] ** 3)
-    assert abs(float(b1.sum()) - volume) < 1e-12 * volume
-    # (2) constants lie in the null space of the stiffness block (cut cells included)
-    aK = fem.form([fem.Integral(fem.STIFFNESS, cells=sysm.inside_cells, rules=sysm.volume_rules, qdegree=0)], V)
-    K = fem.assemble_matrix(aK)
-    one = torch.ones(V.ndofs, device=dev, dtype=torch.float64)
-    _, _, kv = K.torch_views(dev)
-    assert float(spmv(K, one).abs().max()) < 1e-11 * float(kv.abs().max())
-    del K, aK
-    # (3) symmetry of the full operator through two matrix-vector products
-    idx = torch.arange(V.ndofs, device=dev, dtype=torch.float64)
-    x, y = torch.sin(0.37 * idx), torch.cos(0.11 * idx + 0.3)
-    xAy, yAx = float(torch.dot(x, spmv(s["A"], y))), float(torch.dot(y, spmv(s["A"], x)))
-    scale = float(torch.dot(x.abs(), spmv(s["A"], y.abs(), absolute=True)))
-    assert abs(xAy - yAx) < 1e-12 * scale
+    def test_cfg3_size_independent_properties(self, sphere512):
+        s, torch = sphere512, _torch()
+        cfx, dev, sysm, V = s["cfx"], s["dev"], s["system"], s["V"]
+        fem = cfx.fem
+        # (1) sum(b) == |Omega_h| for f = 1
+        L1 = fem.form([fem.Integral(fem.SOURCE, cells=sysm.inside_cells, rules=sysm.volume_rules,
+                                    params=(fem.F_ONE, 1.0), qdegree=1)], V)
+        b1 = torch.zeros(V.ndofs, device=dev, dtype=torch.float64)
+        fem.assemble_vector(L1, b1)
+        vr = sysm.volume_rules
+        from cutfemx_amd.dist import as_torch
+        volume = float(as_torch(vr._view.weights, vr.total_points, "float64", dev).sum()) \
+            + sysm.inside_cells[1] / (6.0 * s["n"] ** 3)
+        assert abs(float(b1.sum()) - volume) < 1e-12 * volume
+        # (2) constants lie in the null space of the stiffness block (cut cells included)
+        aK = fem.form([fem.Integral(fem.STIFFNESS, cells=sysm.inside_cells, rules=sysm.volume_rules, qdegree=0)], V)
+        K = fem.assemble_matrix(aK)
+        one = torch.ones(V.ndofs, device=dev, dtype=torch.float64)
+        _, _, kv = K.torch_views(dev)
+        assert float(spmv(K, one).abs().max()) < 1e-11 * float(kv.abs().max())
+        del K, aK
+        # (3) symmetry of the full operator through two matrix-vector products
+        idx = torch.arange(V.ndofs, device=dev, dtype=torch.float64)
+        x, y = torch.sin(0.37 * idx), torch.cos(0.11 * idx + 0.3)
+        xAy, yAx = float(torch.dot(x, spmv(s["A"], y))), float(torch.dot(y, spmv(s["A"], x)))
+        scale = float(torch.dot(x.abs(), spmv(s["A"], y.abs(), absolute=True)))
+        assert abs(xAy - yAx) < 1e-12 * scale
+
 
 
 # --------------------------------------------------------------------------- config 4
@@ -312,7 +321,7 @@ def test_cfg5_p2_vector_elasticity_rank_share(oracle):
     torch = _torch()
     import cutfemx_amd as cfx
     from cutfemx_amd.dist import as_torch
-    _need_hbm(120)
+    _need_hbm(60)
     n, dev, fem = 256, torch.device("cuda", 0), cfx.fem
     gz0, gnz = 89, 32                      # one of eight ranks' share of the 256^3 mesh
     mesh = cfx.Mesh.create_slab(n, gz0, gnz)

@@ -308,12 +308,23 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         k = kernels[dominant]
         ab = alg_bytes.get(dominant)
         ach = None if ab is None else ab / (k["avg_us"] * 1e-6) / 1e9
+        # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
+        # command, tools/profile_round.sh); only quoted for the mesh they were collected on
+        traffic, tnote = None, "no PMC pass for this mesh in profiles/"
+        tfile = ROOT / "profiles" / "r01_traffic.json"
+        if tfile.exists():
+            t = json.loads(tfile.read_text())
+            e = t["kernels"].get(dominant)
+            if t.get("mesh") == n and e and "fetch_bytes_raw" in e and "write_bytes" in e:
+                traffic = e["fetch_bytes_raw"] + e["write_bytes"]
+                tnote = (f"FETCH_SIZE + WRITE_SIZE per launch from {t['source']} (raw counters; WRITE_SIZE equals the "
+                         "CSR value bytes written, and the gfx950 half-count of FETCH_SIZE applies to 16 B/lane "
+                         "streaming loads, not to this kernel's mix: DESIGN.md 4)")
         roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=None,
+                        frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,
                         note="achieved = SURVEY 8d bytes/unit x units of the launch / HIP-event duration on the "
-                             f"launch stream, {psteps} profiled steps right after the timed region; traffic (PMC) "
-                             "is in profiles/ (rocprofv3 --pmc passes), not re-collected per run")
+                             f"launch stream, {psteps} profiled steps right after the timed region; traffic: " + tnote)
     out.update(phases_ms=phases_ms,
                cut_quadrature_points_per_s=(nq_total / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
                                             if "cut" in phases_ms else None),

@@ -237,8 +237,10 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     else:
         # z-slabs weighted by active cells, one rank per GPU, RCCL point-to-point row reduction
         from cutfemx_amd import dist as cdist
-        part = cdist.SlabPartition.create(n, world, rank)
-        dp = cdist.DistributedPoisson(part, device, order=order)
+        mode = os.environ.get("CFX_DIST_MODE", "owner")   # "reduce": the reference's scatter_reverse flow
+        part = (cdist.SlabPartition.create_owner(n, world, rank) if mode == "owner"
+                else cdist.SlabPartition.create(n, world, rank))
+        dp = cdist.DistributedPoisson(part, device, order=order, mode=mode)
         mesh = dp.mesh
 
         def step(timer=None):
@@ -290,7 +292,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         "assemble_rows_p1": B_UNCUT_CELL * info["n_inside"],
         "assemble_rows_plain": B_UNCUT_CELL * info["n_inside"],
         "pattern_rows": (B_PATTERN_PER_CELL * (info["n_inside"] + info["n_cut"]) + B_PATTERN_PER_NNZ * info["nnz"]
-                         + B_PATTERN_PER_ROW * info["active_dofs"]),
+                         + B_PATTERN_PER_ROW * info.get("active_dofs", info.get("active_dofs_owned", 0))),
         "cut_emit": (B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])
                      + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])) / 2,   # two launches per step
         "assemble_facets": B_GHOST_FACET * info["n_ghost"],
@@ -380,8 +382,10 @@ def main():
                                f"Nitsche + ghost penalty, runtime quadrature order {args.order}; one step = cut + "
                                "rules + sparsity + assemble_matrix + assemble_vector + deactivation",
                    "cells": 6 * n ** 3, "active_dofs": m["active_dofs"],
-                   "parallelism": "1 gpu" if world == 1 else f"z-slabs x{world}, halo 3 layers, RCCL p2p row "
-                                                             "reduction"},
+                   "parallelism": "1 gpu" if world == 1 else (
+                       f"z-slabs x{world} weighted by active cells, owner computes (halo 1+2 layers), RCCL p2p "
+                       "level-set halo" if os.environ.get("CFX_DIST_MODE", "owner") == "owner" else
+                       f"z-slabs x{world} weighted by active cells, halo 3 layers, RCCL p2p row reduction")},
     }
     for k in ("cut_quadrature_points_per_s", "assemble_matrix_dofs_per_s", "counts", "phases_ms", "kernels",
               "roofline", "roofline_by_kernel"):

@@ -126,32 +126,50 @@ struct SelectorPred
 // a1 classification: one thread per cell, coalesced dofmap rows (16 B/lane for
 // tets), gathered level-set values (L2/MALL resident), 1 B/cell out.
 // ---------------------------------------------------------------------------
+#ifndef CFX_CLASSIFY_UNROLL
+#define CFX_CLASSIFY_UNROLL 4
+#endif
 template <int ND>
 __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const int32_t* __restrict__ dofmap,
                                                           const double* __restrict__ phi, int8_t* __restrict__ domain)
 {
-  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (c >= ncells) return;
-  int32_t d[ND];
-  if constexpr (ND == 4)
-  {
-    const int4 v = *reinterpret_cast<const int4*>(dofmap + c * 4);
-    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-  }
-  else
-  {
+  // U cells per thread, a block-wide stride apart: U independent 16 B/lane streaming loads in
+  // flight per lane before the first dependent level-set gather
+  constexpr int U = CFX_CLASSIFY_UNROLL;
+  const int64_t c0 = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
+  int32_t d[U][ND];
 #pragma unroll
-    for (int i = 0; i < ND; ++i) d[i] = dofmap[c * ND + i];
-  }
-  bool all_neg = true, all_pos = true;
-#pragma unroll
-  for (int i = 0; i < ND; ++i)
+  for (int u = 0; u < U; ++u)
   {
-    const double v = phi[d[i]];
-    all_neg = all_neg && (v < 0.0);
-    all_pos = all_pos && (v > 0.0);
+    const int64_t c = c0 + (int64_t)u * kBlock;
+    if (c >= ncells) continue;
+    if constexpr (ND == 4)
+    {
+      typedef int cfx_i4 __attribute__((ext_vector_type(4)));
+      const cfx_i4 v = __builtin_nontemporal_load(reinterpret_cast<const cfx_i4*>(dofmap + c * 4)); // streamed once
+      d[u][0] = v.x; d[u][1] = v.y; d[u][2] = v.z; d[u][3] = v.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) d[u][i] = dofmap[c * ND + i];
+    }
   }
-  domain[c] = all_neg ? (int8_t)CFX_INSIDE : (all_pos ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+  {
+    const int64_t c = c0 + (int64_t)u * kBlock;
+    if (c >= ncells) continue;
+    bool all_neg = true, all_pos = true;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const double v = phi[d[u][i]];
+      all_neg = all_neg && (v < 0.0);
+      all_pos = all_pos && (v > 0.0);
+    }
+    domain[c] = all_neg ? (int8_t)CFX_INSIDE : (all_pos ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -742,10 +760,10 @@ void classify(cfx_cut_t cut)
     const double* phi = cut->ls_values[k].p;
     switch (cut->ls_ndofs_cell)
     {
-    case 3: launch("classify", classify_kernel<3>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 4: launch("classify", classify_kernel<4>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 6: launch("classify", classify_kernel<6>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 10: launch("classify", classify_kernel<10>, grid_for(nc), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 10: launch("classify", classify_kernel<10>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
     default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported level-set element (dofs per cell must be 3, 4, 6 or 10)");
     }
   }

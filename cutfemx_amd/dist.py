@@ -1,5 +1,21 @@
 """Multi-GPU sharding of the hot path: one process per GPU, z-slabs of the
-background mesh, RCCL point-to-point over xGMI for the row reduction.
+background mesh, RCCL point-to-point over xGMI between slab neighbours.
+
+Two modes of `DistributedPoisson`:
+
+* "owner" (default, what bench.py runs): a rank keeps 1 halo layer below and 2
+  above its slab, receives the level-set values of the halo vertex planes from
+  its neighbours (`phi.x.scatter_forward()`, python/demo/demo_poisson.py:157;
+  the only exchange of the step: 2 planes per neighbour) and assembles ALL its
+  local entities.  Every cell and ghost-penalty facet that touches an owned row
+  is local, so the owned rows are complete without a reverse reduction; halo
+  rows are scratch.  One row plan per step, the stencil kernels apply, no
+  packing, ~5 % redundant halo work at 8 ranks of the 512^3 sphere.
+* "reduce": the reference's flow restated literally (below): owned entities
+  only, then `A.scatter_reverse()` / `b.scatter_reverse(add)` of the two
+  boundary planes.  Kept as the cross-check of the owner mode.
+
+Reference semantics of the reduce mode (python/demo/demo_poisson.py:51-55):
 
 Reference semantics reproduced (python/demo/demo_poisson.py:51-55):
 
@@ -60,12 +76,19 @@ class SlabPartition:
     world: int
     rank: int
     bounds: list
-    halo: int = 3
+    halo: int = 3            # layers kept below the slab
+    halo_hi: int | None = None  # layers kept above (None: same as below)
 
     @classmethod
-    def create(cls, n, world, rank, weights=None, halo=3):
+    def create(cls, n, world, rank, weights=None, halo=3, halo_hi=None):
         w = sphere_layer_weights(n) if weights is None else weights
-        return cls(n, world, rank, balanced_boundaries(w, world), halo)
+        return cls(n, world, rank, balanced_boundaries(w, world), halo, halo_hi)
+
+    @classmethod
+    def create_owner(cls, n, world, rank, weights=None):
+        """Layout of the owner-computes mode: owned rows are planes (z0, z1]; their cells lie in
+        layers z0..z1 and the ghost-penalty facets of those cells reach layers z0-1 and z1+1."""
+        return cls.create(n, world, rank, weights, halo=1, halo_hi=2)
 
     # --- hex layers -----------------------------------------------------------
     @property
@@ -75,7 +98,7 @@ class SlabPartition:
     @property
     def lz0(self): return max(self.z0 - self.halo, 0)
     @property
-    def lz1(self): return min(self.z1 + self.halo, self.n)
+    def lz1(self): return min(self.z1 + (self.halo if self.halo_hi is None else self.halo_hi), self.n)
     @property
     def nz_local(self): return self.lz1 - self.lz0
     # --- numbering ------------------------------------------------------------
@@ -109,6 +132,48 @@ class SlabPartition:
         if self.rank < self.world - 1:          # I own plane z1; the facets I own reach plane z1+1 of the upper rank
             out.append((self.rank + 1, self.z1 + 1, self.z1))
         return out
+
+
+def halo_forward(phi, part: SlabPartition, group=None):
+    """Fill the halo vertex planes of the level-set vector from their owners
+    (`phi.x.scatter_forward()`): planes lz0..z0 come from the rank below, planes
+    z1+1..lz1 from the rank above; planes are contiguous slices."""
+    import torch
+    import torch.distributed as dist
+    stage = phi.is_cuda and dist.get_backend(group) == "gloo"
+    ps = part.plane_size
+    ops, recvs = [], []
+
+    def plane_slice(g0, g1):   # global vertex planes [g0, g1] -> local element range
+        return ps * (g0 - part.lz0), ps * (g1 + 1 - part.lz0)
+
+    if part.rank > 0:
+        below = part.bounds[part.rank - 1]
+        assert part.lz0 > below, "slab thinner than the halo of its neighbour"
+        r0, r1 = plane_slice(part.lz0, part.z0)                       # owned by rank-1
+        up_hi = min(part.z0 + 2, part.n)                              # its halo above: planes z0+1..z0+2
+        s0, s1 = plane_slice(part.z0 + 1, up_hi)
+        recvs.append((r0, r1, part.rank - 1))
+        ops.append((s0, s1, part.rank - 1))
+    if part.rank < part.world - 1:
+        r0, r1 = plane_slice(part.z1 + 1, part.lz1)                   # owned by rank+1
+        s0, s1 = plane_slice(part.z1 - 1, part.z1)                    # its halo below: planes z1-1..z1
+        assert part.z1 - 1 > part.z0 or part.rank == 0, "slab thinner than the halo of its neighbour"
+        recvs.append((r0, r1, part.rank + 1))
+        ops.append((s0, s1, part.rank + 1))
+    p2p, bufs = [], []
+    for (s0, s1, peer), (r0, r1, _) in zip(ops, recvs):
+        send = phi[s0:s1].cpu() if stage else phi[s0:s1]
+        recv = torch.empty(r1 - r0, dtype=phi.dtype, device="cpu" if stage else phi.device)
+        p2p.append(dist.P2POp(dist.isend, send, peer, group))
+        p2p.append(dist.P2POp(dist.irecv, recv, peer, group))
+        bufs.append((r0, r1, recv))
+    if p2p:
+        for req in dist.batch_isend_irecv(p2p):
+            req.wait()
+    for r0, r1, recv in bufs:
+        phi[r0:r1] = recv.to(phi.device)
+    return phi
 
 
 def scatter_reverse(values, row_ptr, part: SlabPartition, group=None):
@@ -160,12 +225,15 @@ def as_torch(ptr, n, dtype, device):
 class DistributedPoisson:
     """The cut Poisson hot path on this rank's slab (GPU)."""
 
-    def __init__(self, part: SlabPartition, device, order=4, gamma=40.0, gamma_g=0.1):
+    def __init__(self, part: SlabPartition, device, order=4, gamma=40.0, gamma_g=0.1, mode="owner"):
         import torch
 
         import cutfemx_amd as cfx
         self.torch, self.cfx = torch, cfx
         self.part, self.device, self.order, self.gamma, self.gamma_g = part, device, order, gamma, gamma_g
+        if mode not in ("owner", "reduce"):
+            raise ValueError("mode must be 'owner' or 'reduce'")
+        self.mode = mode
         self.mesh = cfx.Mesh.create_slab(part.n, part.lz0, part.nz_local)
         self.V = cfx.FunctionSpace(self.mesh, 1)
         n = part.n
@@ -173,12 +241,60 @@ class DistributedPoisson:
         az = torch.arange(part.lz0, part.lz1 + 1, device=device, dtype=torch.float64) / n
         cx, cy, cz, R = 0.47, 0.43, 0.41, 0.31
         d2 = (az[:, None, None] - cz) ** 2 + (ax[None, :, None] - cy) ** 2 + (ax[None, None, :] - cx) ** 2
-        self.phi = cfx.Function(self.V, (torch.sqrt(d2) - R).reshape(-1).contiguous())
+        self.phi_values = (torch.sqrt(d2) - R).reshape(-1).contiguous()
+        self.phi = cfx.Function(self.V, self.phi_values)
         nn = self.mesh.num_nodes
         self.values = torch.zeros(nn + 40 * int(0.25 * nn + 100000), device=device, dtype=torch.float64)
         self.b = torch.zeros(nn, device=device, dtype=torch.float64)
 
     def step(self):
+        return self.step_owner() if self.mode == "owner" else self.step_reduce()
+
+    def step_owner(self):
+        """Level-set halo forward, then the serial hot path on the local slab; owned rows are complete."""
+        torch, cfx, part, dev = self.torch, self.cfx, self.part, self.device
+        from . import fem, poisson
+        if part.world > 1:
+            # the halo planes hold whatever the neighbours computed: poison them first so that a broken
+            # exchange cannot go unnoticed behind the analytic initial values
+            ps = part.plane_size
+            if part.rank > 0:
+                self.phi_values[: ps * (part.z0 + 1 - part.lz0)] = float("nan")
+            if part.rank < part.world - 1:
+                self.phi_values[ps * (part.z1 + 1 - part.lz0):] = float("nan")
+            halo_forward(self.phi_values, part)
+        cd = cfx.cut(self.phi)
+        system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
+        self.b.zero_()
+        A = fem.create_matrix(system.a, values=self.values)
+        self.values[:A.nnz].zero_()
+        fem.assemble_matrix(system.a, A=A)
+        fem.assemble_vector(system.L, self.b)
+        dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
+        # counters of the owned share (device reductions, one host read)
+        r_lo, r_hi = part.owned_rows
+        c_lo, c_hi = part.owned_cells
+        inactive = as_torch(dom._id, dom._ni, "int32", dev)
+        inside = as_torch(system.inside_cells[0], system.inside_cells[1], "int32", dev)
+        vr, ir = system.volume_rules, system.interface_rules
+
+        def owned_points(rules):
+            parents = as_torch(rules._view.parent_map, rules.num_rules, "int32", dev)
+            offs = as_torch(rules._view.offsets, rules.num_rules + 1, "int32", dev)
+            k = torch.searchsorted(parents, torch.tensor([c_lo, c_hi], device=dev, dtype=torch.int32))
+            return (offs[k[1]] - offs[k[0]]).to(torch.int64), (k[1] - k[0]).to(torch.int64)
+
+        qv, nv = owned_points(vr)
+        qi, ni = owned_points(ir)
+        ki = torch.searchsorted(inside, torch.tensor([c_lo, c_hi], device=dev, dtype=torch.int32))
+        n_in_own = ((inactive >= r_lo) & (inactive < r_hi)).sum()
+        counts = torch.stack([n_in_own, (ki[1] - ki[0]).to(torch.int64), qv, qi, ni, nv]).tolist()
+        ghost_n = 0 if system.ghost_facets is None else system.ghost_facets.size
+        return dict(active_dofs_owned=(r_hi - r_lo) - counts[0], nnz=A.nnz, n_inside=counts[1],
+                    nq_volume=counts[2], nq_interface=counts[3], n_cut=counts[4], n_vol_rules=counts[5],
+                    n_ghost=ghost_n, A=A, dom=dom)
+
+    def step_reduce(self):
         torch, cfx, part = self.torch, self.cfx, self.part
         from . import fem
         from .cut import RuntimeQuadratureRules

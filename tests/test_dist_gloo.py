@@ -94,6 +94,79 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
+def _owner_worker(rank, world, port, n, q):
+    """Owner-computes mode: level-set halo forward over gloo, every local entity assembled,
+    no reverse reduction; the owned rows must equal the serial ones."""
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    import scipy.sparse as sp
+    import torch
+    import torch.distributed as dist
+
+    from cutfemx_amd.dist import SlabPartition, halo_forward
+    from helpers import level_set_values, oracle_poisson
+    from oracle import pyoracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gm = O.mesh_box(3, n)
+        gphi = level_set_values(gm.x, 3)
+        gref = oracle_poisson(O, gm, gphi)
+        G = sp.csr_matrix((gref["values"], gref["indices"], gref["indptr"]), shape=(gm.nnodes,) * 2)
+        part = SlabPartition.create_owner(n, world, rank, weights=np.ones(n))
+        nv, nc = part.plane_size * (part.nz_local + 1), part.cells_per_layer * part.nz_local
+        lm = O.Mesh(3, gm.x[part.vertex_offset:part.vertex_offset + nv],
+                    gm.conn[part.cell_offset:part.cell_offset + nc] - part.vertex_offset)
+        # level set: owned planes known, halo planes poisoned, then received from the neighbours
+        phi = torch.from_numpy(gphi[part.vertex_offset:part.vertex_offset + nv].copy())
+        r_lo, r_hi = part.owned_rows
+        halo = torch.ones(nv, dtype=torch.bool)
+        halo[r_lo:r_hi] = False
+        phi[halo] = float("nan")
+        halo_forward(phi, part)
+        assert np.array_equal(phi.numpy(), gphi[part.vertex_offset:part.vertex_offset + nv])
+        ref = oracle_poisson(O, lm, phi.numpy())
+        A = sp.csr_matrix((ref["values"], ref["indices"], ref["indptr"]), shape=(lm.nnodes,) * 2)
+        rows = np.arange(r_lo, r_hi)
+        mine = A[rows].tocoo()
+        got = sp.csr_matrix((mine.data, (mine.row, mine.col + part.vertex_offset)), shape=(rows.size, gm.nnodes))
+        want = G[rows + part.vertex_offset]
+        same_pattern = (got != 0).astype(np.int8).nnz == (want != 0).astype(np.int8).nnz and \
+            np.array_equal(np.diff(A.indptr)[rows], np.diff(G.indptr)[rows + part.vertex_offset])
+        err = abs(got - want).max() / abs(want).max()
+        errb = np.abs(ref["b"][rows] - gref["b"][rows + part.vertex_offset]).max() / np.abs(gref["b"]).max()
+        ina = ref["inactive"]
+        own_inactive = ina[(ina >= r_lo) & (ina < r_hi)] + part.vertex_offset
+        gi = gref["inactive"]
+        want_inactive = gi[(gi >= r_lo + part.vertex_offset) & (gi < r_hi + part.vertex_offset)]
+        q.put((rank, float(err), float(errb), bool(np.array_equal(own_inactive, want_inactive)) and bool(same_pattern),
+               rows.size))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 8), (3, 12)])
+def test_owner_mode_matches_serial(oracle, world, n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    total_rows = 0
+    for rank, err, errb, ok, nrows in res:
+        assert err < 1e-12, (rank, err)
+        assert errb < 1e-12, (rank, errb)
+        assert ok
+        total_rows += nrows
+    assert total_rows == (n + 1) ** 3
+
+
 @pytest.mark.parametrize("n", [8])
 def test_two_rank_slab_assembly_matches_serial(oracle, n):
     import torch.multiprocessing as mp

@@ -12,7 +12,7 @@ ROOT = Path(__file__).resolve().parent.parent
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, mode):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFX_DEVICE="0")
@@ -28,8 +28,8 @@ def _worker(rank, world, port, n, q):
         gm = O.mesh_box(3, n)
         gref = oracle_poisson(O, gm, level_set_values(gm.x, 3))
         G = sp.csr_matrix((gref["values"], gref["indices"], gref["indptr"]), shape=(gm.nnodes,) * 2)
-        part = SlabPartition.create(n, world, rank)
-        dp = DistributedPoisson(part, torch.device("cuda", 0))
+        part = SlabPartition.create_owner(n, world, rank) if mode == "owner" else SlabPartition.create(n, world, rank)
+        dp = DistributedPoisson(part, torch.device("cuda", 0), mode=mode)
         info = dp.step()
         info = dp.step()  # twice: buffers are reused between steps
         A = info["A"]
@@ -56,13 +56,14 @@ def _worker(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_match_serial(oracle):
+@pytest.mark.parametrize("mode", ["owner", "reduce"])
+def test_two_ranks_on_one_gpu_match_serial(oracle, mode):
     import torch.multiprocessing as mp
     n = 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    port = 29600 + (os.getpid() % 2000) + (7 if mode == "owner" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=600) for _ in procs]

@@ -188,8 +188,8 @@ __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restric
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = tile_offsets[blockIdx.x] + total;
 }
 
-template <typename Tout>
-__global__ void scan_small_kernel(const Tout* in, int64_t n, Tout* out)
+template <typename Tin, typename Tout>
+__global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out)
 {
   // single thread block, n <= kTile: used for the top of the recursion
   const int64_t base = (int64_t)threadIdx.x * kScanItems;
@@ -198,7 +198,7 @@ __global__ void scan_small_kernel(const Tout* in, int64_t n, Tout* out)
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
   {
-    v[k] = (base + k < n) ? in[base + k] : (Tout)0;
+    v[k] = (base + k < n) ? (Tout)in[base + k] : (Tout)0;
     s += v[k];
   }
   Tout total;
@@ -212,6 +212,89 @@ __global__ void scan_small_kernel(const Tout* in, int64_t n, Tout* out)
   if (threadIdx.x == 0) out[n] = total;
 }
 
+// Single-pass scan (chained tiles with wave-wide look-back): one launch, the input is read
+// once.  A tile takes its number from an atomic ticket when its block starts, so every
+// predecessor it waits for is already resident and makes progress.  Tile state = one 64-bit
+// word (2-bit flag | 62-bit value) exchanged with agent-scope atomics: the L2s of the eight
+// XCDs are not coherent with each other for plain loads.
+constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1ull;
+
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restrict__ in, int64_t n,
+                                                              unsigned long long* __restrict__ state,
+                                                              unsigned int* __restrict__ ticket, Tout* __restrict__ out)
+{
+  __shared__ unsigned int s_tile;
+  __shared__ unsigned long long s_prefix;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const unsigned int tile = s_tile;
+  const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kScanItems;
+  Tout v[kScanItems];
+  Tout s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    v[k] = (base + k < n) ? (Tout)in[base + k] : (Tout)0;
+    s += v[k];
+  }
+  Tout total;
+  const Tout local = block_exclusive_scan<Tout>(s, total);
+  if (threadIdx.x < 64)
+  {
+    const int lane = threadIdx.x;
+    unsigned long long prefix = 0;
+    if (tile == 0)
+    {
+      if (lane == 0)
+        __hip_atomic_store(&state[0], kScanPrefix | ((unsigned long long)total & kScanValueMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else
+    {
+      if (lane == 0)
+        __hip_atomic_store(&state[tile], kScanAggregate | ((unsigned long long)total & kScanValueMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      // look back 64 tiles at a time until a tile with a complete prefix is found
+      int64_t hi = (int64_t)tile - 1;
+      while (true)
+      {
+        const int64_t p = hi - lane;
+        unsigned long long w = kScanPrefix; // tiles before the first: prefix 0
+        if (p >= 0)
+        {
+          do
+          {
+            w = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } while ((w >> 62) == 0ull);
+        }
+        const unsigned long long done = __ballot((w >> 62) == 2ull);
+        const int first = done ? __ffsll((long long)done) - 1 : 64; // nearest tile whose prefix is complete
+        unsigned long long part = (lane <= first) ? (w & kScanValueMask) : 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        prefix += part;
+        if (done) break;
+        hi -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&state[tile], kScanPrefix | ((prefix + (unsigned long long)total) & kScanValueMask),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  Tout off = local + (Tout)s_prefix;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    if (base + k < n) out[base + k] = off;
+    off += v[k];
+  }
+  // the element one past the end receives the grand total
+  if ((int64_t)(tile + 1) * kTile >= n && threadIdx.x == kBlock - 1) out[n] = (Tout)s_prefix + total;
+}
+
 template <typename Tin, typename Tout>
 static void scan_impl(const Tin* in, Tout* out, int64_t n)
 {
@@ -221,10 +304,28 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n)
     return;
   }
   const int64_t ntiles = (n + kTile - 1) / kTile;
+  // chained up to 16 M elements (one launch instead of three to five: what matters for the many
+  // short scans of a step and for the slabs of a multi-GPU run); longer arrays keep the three-kernel
+  // form, whose tiles never wait on each other (measured at 135 M elements: 0.60 vs 0.75 ms)
+  static const int64_t chained_max = getenv("CFX_SCAN_CHAINED_TILES") ? atoll(getenv("CFX_SCAN_CHAINED_TILES")) : 8192;
+  if (ntiles > 1 && ntiles <= chained_max)
+  {
+    // tile states + ticket, zeroed by one memset
+    DevArray<unsigned long long> state(ntiles + 1);
+    state.zero();
+    launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, state.p,
+           reinterpret_cast<unsigned int*>(state.p + ntiles), out);
+    return;
+  }
+  if (ntiles == 1)
+  {
+    launch("scan_top", scan_small_kernel<Tin, Tout>, dim3(1), dim3(kBlock), 0, in, n, out);
+    return;
+  }
   DevArray<Tout> sums(ntiles), offs(ntiles + 1);
   launch("scan_reduce", scan_reduce_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, sums.p);
   if (ntiles <= kTile)
-    launch("scan_top", scan_small_kernel<Tout>, dim3(1), dim3(kBlock), 0, sums.p, ntiles, offs.p);
+    launch("scan_top", scan_small_kernel<Tout, Tout>, dim3(1), dim3(kBlock), 0, sums.p, ntiles, offs.p);
   else
     scan_impl<Tout, Tout>(sums.p, offs.p, ntiles);
   launch("scan_write", scan_write_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, offs.p, out);

@@ -60,14 +60,20 @@ def balanced_boundaries(weights, world: int):
     return bounds
 
 
-def sphere_layer_weights(n: int, active_weight: float = 140.0):
-    """Cost model per hex layer for the sphere workload: 1 per cell (classification
-    stream) + active_weight per cell that is inside or cut (everything else)."""
+def sphere_layer_weights(n: int, active_weight: float = 18.0, cut_weight: float = 830.0):
+    """Cost model per hex layer for the sphere workload, in units of one background cell
+    (~12 ps on MI355X: classification, selector scans, mark arrays; fitted to the per-rank
+    times of tools/rank_balance.py): an active (inside) cell costs ~0.22 ns more of assembly
+    (18), a cut cell ~10 ns of sub-triangulation, runtime quadrature, local tensors and
+    ghost-penalty facets (830).  The surface of a sphere
+    between two parallel planes is 2 pi R dz (Archimedes), so the cut cells are spread evenly
+    over the layers that meet the sphere: ~4.7 cut tets per h^2 of surface."""
     c, R = np.array([0.47, 0.43, 0.41]), 0.31
     z = (np.arange(n) + 0.5) / n
     r2 = np.maximum(R * R - (z - c[2]) ** 2, 0.0)           # radius^2 of the sphere's cross-section
     active = np.pi * r2 * n * n * 6.0                        # tets per layer inside the disc
-    return 6.0 * n * n + active_weight * active
+    cut = np.where(r2 > 0.0, 4.7 * 2.0 * np.pi * R * n, 0.0)
+    return 6.0 * n * n + active_weight * active + cut_weight * cut
 
 
 @dataclass

@@ -184,8 +184,11 @@ def cpu_baseline_all_cores(n, order):
     stand-in for the reference under `mpirun -n <cores>`.  Children are separate
     programs (no GPU use); throughput = active dofs / slowest process."""
     import subprocess
-    cores = max(1, min(os.cpu_count() or 1, n))
-    bounds = [round(i * n / cores) for i in range(cores + 1)]
+
+    from cutfemx_amd.dist import balanced_boundaries, sphere_layer_weights
+    # a one-GPU box shares its host: its CPU share is 16 cores whatever os.cpu_count() says
+    cores = max(1, min(os.cpu_count() or 1, 16, n // 4))
+    bounds = balanced_boundaries(sphere_layer_weights(n), cores)   # the same weighted z-slabs as the GPU ranks
     procs = [subprocess.Popen([sys.executable, str(ROOT / "bench.py"), "--cpu-worker", str(n), str(bounds[i]),
                                str(bounds[i + 1]), str(order)], stdout=subprocess.PIPE, text=True,
                               env={**os.environ, "OMP_NUM_THREADS": "1"})
@@ -194,8 +197,9 @@ def cpu_baseline_all_cores(n, order):
     secs = max(o["seconds"] for o in outs)
     active = sum(o["active"] for o in outs)
     return dict(value=active / secs, unit="DOF/s", cores=len(procs), kind="port",
-                sample=f"{n}^3 sphere workload split into {len(procs)} z-slabs, one oracle process per host core "
-                       f"(no ghost layers), slowest process {secs:.1f} s", seconds=secs, active_dofs=active)
+                sample=f"{n}^3 sphere workload split into {len(procs)} weighted z-slabs, one oracle process per host "
+                       f"core of this box's 16-core share (no ghost layers), slowest process {secs:.1f} s",
+                seconds=secs, active_dofs=active, host_cores_available=os.cpu_count())
 
 
 def kernel_profile(_lib, step, psteps):
@@ -297,6 +301,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
                      + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])) / 2,   # two launches per step
         "assemble_facets": B_GHOST_FACET * info["n_ghost"],
     }
+    if "assemble_rows_plain" in kernels:      # the p1 kernel then only serves the interface rows
+        alg_bytes.pop("assemble_rows_p1")
     roof = {}
     for name, ab in alg_bytes.items():
         if name in kernels and ab:

@@ -4,7 +4,7 @@ standard assembly on whole-cell rules, and the reference's error classes."""
 import numpy as np
 import pytest
 
-from helpers import level_set_values, rel_err
+from helpers import level_set_values, oracle_poisson, rel_err
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -271,6 +271,44 @@ def test_update_reclassifies(oracle):
     r = cfx.runtime_quadrature(cd, "phi<0", 2)
     want = oracle.runtime_quadrature(om, om.conn, f.values, dom, "phi<0", 2)
     assert np.array_equal(r.parent_map, want.parent_map) and rel_err(r.weights, want.weights) < RTOL
+
+
+def test_moving_domain_loop(oracle):
+    # python/demo/demo_moving_poisson.py:53-90: one CutData, the level set moves in place on the
+    # device, update() + rules + forms + sparsity + assembly every step; each step equals the oracle
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    n = 12
+    om = oracle.mesh_box(3, n)
+    mesh = cfx.Mesh.from_arrays(3, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    xt = torch.tensor(om.x, device="cuda")
+    phi = torch.empty(om.nnodes, device="cuda", dtype=torch.float64)
+    f = cfx.Function(V, phi)
+    cd = None
+    seen = []
+    for step in range(4):
+        centre = torch.tensor([0.40 + 0.05 * step, 0.45, 0.5 - 0.03 * step], device="cuda", dtype=torch.float64)
+        phi.copy_(torch.linalg.norm(xt - centre, dim=1) - 0.27)        # in place: the engine aliases this array
+        if cd is None:
+            cd = cfx.cut(f)
+        else:
+            cfx.update(cd)
+        system = poisson.build_forms(V, cd, order=4)
+        A = cfx.fem.assemble_matrix(system.a)
+        b = cfx.fem.assemble_vector(system.L)
+        dom = cfx.fem.deactivate_outside(A, b, cfx.fem.active_domain(system.a))
+        ref = oracle_poisson(oracle, om, phi.cpu().numpy())
+        vals, bb = ref["values"].copy(), ref["b"].copy()
+        oracle.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, bb)
+        assert np.array_equal(cd.domain(), ref["domain"])
+        assert np.array_equal(A.indptr, ref["indptr"]) and np.array_equal(A.indices, ref["indices"])
+        assert rel_err(A.data, vals) < RTOL and rel_err(b, bb) < RTOL
+        assert np.array_equal(dom.inactive_dofs, ref["inactive"])
+        seen.append(int(A.nnz))
+    assert len(set(seen)) > 1   # the pattern really changed between steps
 
 
 def test_deterministic_mode_is_bitwise_reproducible(oracle, monkeypatch):

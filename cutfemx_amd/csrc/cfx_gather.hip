@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   constexpr int RPW = kWave / G;
   constexpr int KMAX = CAP / G;
   constexpr int R = 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
-  constexpr int SX = 32; // staged stencil entries per row
+  constexpr int SX = CAP <= 32 ? CAP : 32; // staged stencil entries per row (a plain row is no longer than its stencil)
   __shared__ double s_val[RPW][CAP + 1];
   __shared__ double s_x[STAGE ? RPW : 1][STAGE ? SX + 1 : 1][TDIM];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
@@ -814,6 +814,7 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   {
     const int64_t sb = live ? A.st_off[r] : 0;
     const int slen = live ? (int)(A.st_off[r + 1] - sb) : 0;
+    static_assert(!STAGE || SX % G == 0, "stencil staging: SX must be a multiple of the group size");
     int32_t vid[SX / G];
 #pragma unroll
     for (int q = 0; q < SX / G; ++q)
@@ -1229,6 +1230,9 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           const dim3 gq = xcd_grid((Q.n_active + 7) / 8);
           const char* stage_env = getenv("CFX_PLAIN_STAGE");
           const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');
+          // plain rows are subsets of their stencil: the LDS footprint follows the longest stencil
+          // (16 covers the 15-vertex stencil of Kuhn meshes: 4.4 KB per block instead of 8.4 KB)
+          const int plain_cap = stn.max_len <= 16 ? 16 : (stn.max_len <= 32 ? 32 : 64);
 #define CFX_PLAIN(CAPP)                                                                                                \
   do                                                                                                                   \
   {                                                                                                                    \
@@ -1237,7 +1241,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     else if (stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, true>, gq, dim3(kWave), 0, Q);   \
     else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, false>, gq, dim3(kWave), 0, Q);             \
   } while (0)
-          if (mr <= 32) CFX_PLAIN(32); else CFX_PLAIN(64);
+          if (plain_cap == 16) CFX_PLAIN(16); else if (plain_cap == 32) CFX_PLAIN(32); else CFX_PLAIN(64);
 #undef CFX_PLAIN
           // the uncut items of the interface rows keep the searching kernel
           F.n_active = plan.n_special_rows; F.active_rows = plan.special_rows.p;

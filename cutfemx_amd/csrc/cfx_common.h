@@ -334,6 +334,7 @@ struct cfx_space_s
   cfx::Adjacency d2c; // dof -> cells
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
+  bool long_rows = false; // a sparsity build of this space overflowed the 63-entry row sets: start with the wide kernel
   const cfx::Adjacency& dof_cells()
   {
     // a P1 space whose dofmap aliases the geometry dofmap shares the mesh's vertex->cells table

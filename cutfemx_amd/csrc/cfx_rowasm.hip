@@ -724,11 +724,17 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   int T = 64;
   if (n_h > 0)
   {
-    tmp.alloc(n_h * 64);
-    S.tmp = tmp.p;
-    launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((n_h + 15) / 16), dim3(kWave), 0, S);
-    if (read_scalar(overflow.p))
+    bool wide = V->long_rows;
+    if (!wide)
     {
+      tmp.alloc(n_h * 64);
+      S.tmp = tmp.p;
+      launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((n_h + 15) / 16), dim3(kWave), 0, S);
+      wide = read_scalar(overflow.p) != 0;
+    }
+    if (wide)
+    {
+      V->long_rows = true; // P2 / vector spaces: skip the narrow attempt next time (150 ms of 450 at config 4)
       // long rows (P2, vector spaces, many facet couplings): one wavefront per row with a
       // 512-slot set.  n_active * 512 staged columns would be ~150 GB for config 4, so the
       // wide path counts first and builds each set again to write it in place.

@@ -201,12 +201,15 @@ inline DevArray<T> to_device(const T* src, int64_t n)
   return a;
 }
 
+int64_t& sync_counter(); // host round trips so far (cfx_runtime.hip), reported by CFX_COUNT_SYNC=1
+
 template <typename T>
 inline T read_scalar(const T* dev)
 {
   T v;
   CFX_HIP(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
   CFX_HIP(hipStreamSynchronize(ctx().stream));
+  ++sync_counter();
   return v;
 }
 

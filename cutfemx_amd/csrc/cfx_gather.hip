@@ -313,8 +313,9 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 // ---------------------------------------------------------------------------
 // stage 2, bilinear forms
 // ---------------------------------------------------------------------------
+// (degree 2: 10 columns per cell item, 20 per facet item: 2 waves/SIMD leave 256 VGPRs)
 template <int TDIM, int DEG, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
+__global__ void __launch_bounds__(kWave, DEG > 1 ? 2 : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row
@@ -416,7 +417,7 @@ __global__ void __launch_bounds__(kWave, CFX_ROWS_WAVES) assemble_rows_kernel(Ro
   // ---- cell items, R per lane per pass.  The index loads of a pass (incidence
   // list, marks, dof rows) are issued together so that their latencies overlap:
   // the kernel is bound by dependent gathers, not by bandwidth or flops.
-  constexpr int R = G <= 4 ? 6 : 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  constexpr int R = DEG > 1 ? 1 : (G <= 4 ? 6 : 3); // P1: 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
   const int ncl = len > 0 ? nc : 0;
   for (int base = 0;; base += R * G)
   {
@@ -1167,7 +1168,10 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     }
     // uncut P1 stiffness is one point: cheaper to recompute than to stage
     const char* inl = getenv("CFX_STD_INLINE");
-    R.std_inline = (a->rank == 2 && I.kernel == CFX_K_STIFFNESS && DEG == 1 && !(inl && inl[0] == '0')) ? 1 : 0;
+    // (degree 2: staging 100 doubles per uncut cell would be 38 GB at config 4 -- the row of the
+    // local tensor is recomputed per (row, cell) item instead, 4-14 quadrature points)
+    const bool inline_ok = DEG == 1 ? I.kernel == CFX_K_STIFFNESS : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS);
+    R.std_inline = (a->rank == 2 && inline_ok && !(inl && inl[0] == '0')) ? 1 : 0;
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
     if (!R.std_inline && I.n_entities > 0)
@@ -1296,6 +1300,10 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       A.mark_mask = 0xFFu;
       if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows", A);
       else if (mr <= 64) CFX_ROWS(8, 64, "assemble_rows", A);
+      else if (DEG > 1 && mr <= 256)
+      {
+        if constexpr (DEG > 1) CFX_ROWS(16, 256, "assemble_rows", A); // P2 rows: 20-70 columns, up to ~200 with facets
+      }
       else CFX_ROWS(64, 512, "assemble_rows_wide", A);
     }
 #undef CFX_ROWS
@@ -1328,9 +1336,12 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
 {
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
-  if (!plan.usable || V->degree != 1 || V->bs != 1 || P->max_row_len > 512) return false;
-  const int err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values)
-                                     : run_matrix<3, 1>(a, P, bc0, bc1, values);
+  if (!plan.usable || V->degree > 2 || V->bs != 1 || P->max_row_len > 512) return false;
+  int err = 0;
+  if (V->degree == 1)
+    err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values) : run_matrix<3, 1>(a, P, bc0, bc1, values);
+  else
+    err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values) : run_matrix<3, 2>(a, P, bc0, bc1, values);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
   require(err != 5, CFX_ERR_RUNTIME, "assemble_matrix: a stencil-subset row does not match its sparsity pattern");
@@ -1344,8 +1355,9 @@ bool assemble_vector_rows(cfx_form_s* L, double* b)
   cfx_space_s* V = L->V;
   for (const auto& I : L->integrals)
     if (I.type == CFX_INTERIOR_FACET) return false;
-  if (!plan.usable || V->degree != 1 || V->bs != 1) return false;
-  if (V->mesh->tdim == 2) run_vector<2, 1>(L, b); else run_vector<3, 1>(L, b);
+  if (!plan.usable || V->degree > 2 || V->bs != 1) return false;
+  if (V->degree == 1) { if (V->mesh->tdim == 2) run_vector<2, 1>(L, b); else run_vector<3, 1>(L, b); }
+  else { if (V->mesh->tdim == 2) run_vector<2, 2>(L, b); else run_vector<3, 2>(L, b); }
   return true;
 }
 

@@ -86,6 +86,18 @@ size_t round_size(size_t bytes)
 }
 } // namespace
 
+int64_t& sync_counter()
+{
+  static int64_t n = 0;
+  static const bool report = []() {
+    const char* e = getenv("CFX_COUNT_SYNC");
+    if (e && e[0] == '1') atexit([]() { fprintf(stderr, "cutfemx_amd: %lld size read-backs\n", (long long)sync_counter()); });
+    return true;
+  }();
+  (void)report;
+  return n;
+}
+
 void* dev_alloc(size_t bytes)
 {
   BlockCache& c = cache();

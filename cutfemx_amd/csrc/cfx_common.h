@@ -417,6 +417,10 @@ struct cfx_pattern_s
   int64_t nrows = 0, nnz = 0;
   int max_row_len = 0; // upper bound on the scalar-dof row length
   uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)
+  // long-row spaces: the plan's active rows split by row length (<= 64 columns / longer)
+  uint64_t split_plan = 0;
+  cfx::DevArray<int32_t> short_rows, long_rows;
+  int64_t n_short_rows = 0, n_long_rows = 0;
   cfx::DevArray<int64_t> indptr;
   cfx::DevArray<int32_t> indices;
 };

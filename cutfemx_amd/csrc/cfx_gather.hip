@@ -314,8 +314,10 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 // stage 2, bilinear forms
 // ---------------------------------------------------------------------------
 // (degree 2: 10 columns per cell item, 20 per facet item: 2 waves/SIMD leave 256 VGPRs)
-template <int TDIM, int DEG, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave, DEG > 1 ? 2 : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
+// CUTS = false compiles the rule-tensor and facet items out: the lean form that serves the uncut
+// items of every row of a degree-2 space (the facet section alone holds 100 registers there).
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true>
+__global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? 2 : CFX_ROWS_WAVES) assemble_
                 for (int j = 0; j < ND; ++j) acc[j] += T[j];
               }
             }
-            if (mark & (16u << i))
+            if (CUTS && (mark & (16u << i)))
             {
               for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
               {
@@ -526,8 +528,8 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? 2 : CFX_ROWS_WAVES) assemble_
   }
 
   // ---- facet items (rows next to the interface only)
-  const int nfl = len > 0 ? nf : 0;
-  for (int base = 0;; base += G)
+  const int nfl = (CUTS && len > 0) ? nf : 0;
+  for (int base = 0; CUTS; base += G)
   {
     const int t = base + gl;
     const bool has = t < nfl;
@@ -1293,6 +1295,34 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows_cut", S);
           else CFX_ROWS(8, 64, "assemble_rows_cut", S);
         }
+      }
+    }
+    if constexpr (DEG > 1)
+    {
+      // degree 2: (a) the uncut items of every row with the lean kernel, short rows (<= 64 columns:
+      // the edge dofs, ~5 cells each) 8 lanes per row, long rows 16; (b) rule + facet items of the
+      // interface rows with the full kernel.  Needs the row partition made with the pattern.
+      if (P->split_plan == plan.serial && mr > 64 && mr <= 256 && plan.n_special_rows * 2 <= plan.n_active_rows)
+      {
+        split = true;
+#define CFX_LEAN(GG, CAPP, ROWS, NROWS)                                                                              \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    RowArgs Q = A;                                                                                                   \
+    Q.mark_mask = 0x0Fu; Q.active_rows = (ROWS); Q.n_active = (NROWS);                                               \
+    const dim3 grid = row_grid((Q.n_active + (kWave / GG) - 1) / (kWave / GG));                                      \
+    if (Q.n_active > 0)                                                                                              \
+    {                                                                                                                \
+      if (det) launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, false>, grid, dim3(kWave), 0, Q);  \
+      else launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, Q);     \
+    }                                                                                                                \
+  } while (0)
+        CFX_LEAN(8, 64, P->short_rows.p, P->n_short_rows);
+        CFX_LEAN(16, 256, P->long_rows.p, P->n_long_rows);
+#undef CFX_LEAN
+        RowArgs S = A;
+        S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
+        if (S.n_active > 0) CFX_ROWS(16, 256, "assemble_rows_cut", S);
       }
     }
     if (!split)

@@ -75,6 +75,27 @@ __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict
   if (special) special[dof] = 1;
 }
 
+// active-row positions whose CSR row is at most / longer than `limit` columns
+struct RowLenTest
+{
+  const int32_t* rows;
+  const int64_t* indptr;
+  int limit;
+  bool longer;
+  __device__ bool operator()(int64_t i) const
+  {
+    const int64_t r = rows[i];
+    return ((indptr[r + 1] - indptr[r]) > limit) == longer;
+  }
+};
+
+// positions in the active-row list -> row ids, in place
+__global__ void map_rows_kernel(int64_t n, const int32_t* __restrict__ rows, int32_t* __restrict__ idx)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) idx[i] = rows[idx[i]];
+}
+
 // hash map parent cell -> first rule index (one entry per run of equal parents)
 __global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ parent, uint32_t mask,
                                       int32_t* __restrict__ keys, int32_t* __restrict__ first)
@@ -238,6 +259,19 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
       constexpr int R = G <= 4 ? 6 : (G <= 8 ? 4 : 2);
       const int64_t cb = P.d2c_off[r];
       const int nc = (int)(P.d2c_off[r + 1] - cb);
+      if (P.nd != 4)
+      {
+        // (cell, local dof) pairs spread over the lanes: a degree-2 row has 5-24 cells of 10 dofs,
+        // one lane per cell would leave most of a 64-lane group idle
+        const int npairs = nc * P.nd;
+        for (int t = gl; t < npairs; t += G)
+        {
+          const int q = t / P.nd;
+          const int64_t cell = P.d2c[cb + q];
+          if (P.all_cells || P.cellmark[cell]) ok = hash_insert<T>(tab, P.dofmap[cell * P.nd + (t - q * P.nd)]) && ok;
+        }
+      }
+      else
       for (int base = 0; base < nc; base += R * G)
       {
         int64_t cell[R];
@@ -276,15 +310,19 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
       }
     }
     if (P.d2f_off)
-      for (int64_t k = P.d2f_off[r] + gl; k < P.d2f_off[r + 1]; k += G)
+    {
+      // (facet, side, local dof) triples spread over the lanes
+      const int64_t fb = P.d2f_off[r];
+      const int per = 2 * P.nd;
+      const int ntr = (int)(P.d2f_off[r + 1] - fb) * per;
+      for (int t = gl; t < ntr; t += G)
       {
-        const int64_t f = P.d2f[k];
-        for (int s = 0; s < 2; ++s)
-        {
-          const int64_t c = P.facet_rows[4 * f + 2 * s];
-          for (int j = 0; j < P.nd; ++j) ok = hash_insert<T>(tab, P.dofmap[c * P.nd + j]) && ok;
-        }
+        const int q = t / per, u = t - q * per;
+        const int64_t f = P.d2f[fb + q];
+        const int64_t c = P.facet_rows[4 * f + 2 * (u / P.nd)];
+        ok = hash_insert<T>(tab, P.dofmap[c * P.nd + u % P.nd]) && ok;
       }
+    }
   }
   __syncthreads();
   if (!ok) *P.overflow = 1;
@@ -777,6 +815,20 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     }
   }
   P->stencil_plan = use_stencil ? plan.serial : 0;
+  // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
+  P->split_plan = 0;
+  if (P->max_row_len > 64 && V->bs == 1 && plan.n_active_rows > 0)
+  {
+    P->n_short_rows = compact("pattern_short_rows", plan.n_active_rows,
+                              RowLenTest{plan.active_rows.p, P->indptr.p, 64, false}, P->short_rows);
+    P->n_long_rows = compact("pattern_long_rows", plan.n_active_rows,
+                             RowLenTest{plan.active_rows.p, P->indptr.p, 64, true}, P->long_rows);
+    launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_short_rows), dim3(kBlock), 0, P->n_short_rows,
+           plan.active_rows.p, P->short_rows.p);
+    launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_long_rows), dim3(kBlock), 0, P->n_long_rows,
+           plan.active_rows.p, P->long_rows.p);
+    P->split_plan = plan.serial;
+  }
 }
 
 } // namespace cfx

@@ -10,6 +10,7 @@ downloaded on first access.
 from __future__ import annotations
 
 import ctypes as C
+import re
 from collections.abc import Sequence
 
 import numpy as np
@@ -118,10 +119,11 @@ class RuntimeQuadratureRules:
 class CutData:
     """Python handle for cut data (python/cutfemx/cut.py:94-146)."""
 
-    def __init__(self, handle, level_sets: Sequence[Function], keep=()):
+    def __init__(self, handle, level_sets: Sequence[Function], keep=(), names=None):
         self._h = handle
         self._level_sets = tuple(level_sets)
         self._keep = list(keep)
+        self._names = frozen_level_set_names([f.name for f in level_sets]) if names is None else tuple(names)
 
     def update(self) -> None:
         update(self)
@@ -144,7 +146,8 @@ class CutData:
 
     @property
     def level_set_names(self) -> tuple[str, ...]:
-        return tuple("phi" if i == 0 else f"phi{i}" for i in range(len(self._level_sets)))
+        """Frozen at cut(): renaming a Function afterwards does not change them (test_cut_api.py:750-763)."""
+        return self._names
 
     @property
     def level_sets(self) -> tuple[Function, ...]:
@@ -167,6 +170,59 @@ class CutData:
                 self._h = None
         except Exception:
             pass
+
+
+_UNSPECIFIED_NAMES = ("", "u", "f")
+_IDENT = re.compile(r"[A-Za-z_][A-Za-z0-9_]*")
+
+
+def frozen_level_set_names(raw_names: Sequence[str]) -> tuple[str, ...]:
+    """Selector names of the level sets, fixed at cut() time (cut.cpp:82-138): a Function's own
+    name when it has one (not "", "u", "f"), else "phi", "phi1", ...; real names must be valid
+    identifiers and unique; defaults step aside for real names that look like them."""
+    real: list[str | None] = []
+    seen: set[str] = set()
+    for raw in raw_names:
+        if raw in _UNSPECIFIED_NAMES:
+            real.append(None)
+            continue
+        if not _IDENT.fullmatch(raw):
+            raise ValueError(f"Level-set function name '{raw}' is not a valid selector identifier. "
+                             "Expected [A-Za-z_][A-Za-z0-9_]*.")
+        if raw in seen:
+            raise ValueError(f"Duplicate level-set function name '{raw}'. Level-set selector names must be unique.")
+        seen.add(raw)
+        real.append(raw)
+    used = set(seen)
+    names = []
+    for i, r in enumerate(real):
+        if r is not None:
+            names.append(r)
+            continue
+        candidate = "phi" if i == 0 else f"phi{i}"
+        counter = 1 if i == 0 else i + 1
+        while candidate in used:
+            candidate = f"phi{counter}"
+            counter += 1
+        used.add(candidate)
+        names.append(candidate)
+    return tuple(names)
+
+
+def _engine_selector(cut_data: "CutData", selector: str) -> bytes:
+    """Rewrite a selector written with the frozen names into the engine's positional names
+    (phi, phi1, ...); keywords pass through, unknown identifiers are user errors."""
+    names = cut_data.level_set_names
+    table = {n: ("phi" if i == 0 else f"phi{i}") for i, n in enumerate(names)}
+
+    def repl(m):
+        word = m.group(0)
+        if word in table:
+            return table[word]
+        if word.lower() in ("and", "or", "not"):
+            return word
+        raise ValueError(f"invalid selector '{selector}': unknown level set '{word}'")
+    return _IDENT.sub(repl, str(selector)).encode()
 
 
 def _normalise_level_sets(level_set) -> list[Function]:
@@ -196,6 +252,7 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
         edge_max_depth: int = 20) -> CutData:
     """Classify all cells against one or more level sets (python/cutfemx/cut.py:186-249)."""
     level_sets = _normalise_level_sets(level_set)
+    names = frozen_level_set_names([f.name for f in level_sets])
     if entities is not None or entity_dim is not None:
         if entities is None:
             raise ValueError("entity_dim is only valid when entities are supplied")
@@ -212,7 +269,7 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
     h = C.c_void_p()
     _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
                                          C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
-    return CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V])
+    return CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
 
 
 def update(cut_data: CutData) -> None:
@@ -226,21 +283,21 @@ def update(cut_data: CutData) -> None:
 def locate_entities(cut_data: CutData, ls_part: str) -> np.ndarray:
     """Background cells matched by a selector, ascending int32 (cut.cpp:877-924)."""
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, ls_part.encode(), C.byref(p), C.byref(n)))
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, _engine_selector(cut_data, ls_part), C.byref(p), C.byref(n)))
     return _lib.download(p.value, n.value, np.int32)
 
 
 def locate_entities_device(cut_data: CutData, ls_part: str):
     """(device pointer, count) of the selector result; owned by `cut_data`."""
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, ls_part.encode(), C.byref(p), C.byref(n)))
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, _engine_selector(cut_data, ls_part), C.byref(p), C.byref(n)))
     return p.value, n.value
 
 
 def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: str = "straight"):
     """Runtime quadrature on the cut entities of a selector (cut.cpp:1311-1335)."""
     h = C.c_void_p()
-    _lib.check(_lib.lib().cfx_runtime_quadrature(cut_data._h, ls_part.encode(), int(order), backend.encode(),
+    _lib.check(_lib.lib().cfx_runtime_quadrature(cut_data._h, _engine_selector(cut_data, ls_part), int(order), backend.encode(),
                                                  C.byref(h)))
     return RuntimeQuadratureRules(h, cut_data.mesh)
 
@@ -285,7 +342,7 @@ def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, in
     if depth != 1:
         raise NotImplementedError("ghost_penalty_facets currently supports depth=1.")
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, selector.encode(), C.byref(p), C.byref(n)))
+    _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, _engine_selector(cut_data, selector), C.byref(p), C.byref(n)))
     # the rows stay in HBM (owned by cut_data until update()/destruction); .rows downloads on demand
     return FacetRows(p.value, n.value, cut_data)
 

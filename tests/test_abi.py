@@ -49,3 +49,17 @@ def test_fails_loudly_without_gpu():
     import cutfemx_amd as cfx
     with pytest.raises(RuntimeError):
         cfx.Mesh.create_box(3, 2)
+
+
+def test_frozen_level_set_names_follow_the_reference():
+    # cpp/cutfemx/cut/cut.cpp:82-138, python/tests/test_cut_api.py:750-773
+    from cutfemx_amd.cut import frozen_level_set_names
+    assert frozen_level_set_names(["f"]) == ("phi",)
+    assert frozen_level_set_names(["", "u", "f"]) == ("phi", "phi1", "phi2")
+    assert frozen_level_set_names(["fluid", "f"]) == ("fluid", "phi1")
+    assert frozen_level_set_names(["f", "phi"]) == ("phi1", "phi")          # the default steps aside
+    assert frozen_level_set_names(["phi1", "f", "f"]) == ("phi1", "phi2", "phi3")
+    with pytest.raises(ValueError, match="Duplicate level-set function name"):
+        frozen_level_set_names(["fluid", "fluid"])
+    with pytest.raises(ValueError, match="not a valid selector identifier"):
+        frozen_level_set_names(["2phase"])

@@ -273,6 +273,36 @@ def test_update_reclassifies(oracle):
     assert np.array_equal(r.parent_map, want.parent_map) and rel_err(r.weights, want.weights) < RTOL
 
 
+def test_named_level_sets_in_selectors(oracle):
+    # python/tests/test_cut_api.py:713-773: real Function names are the selector names, frozen at cut()
+    import cutfemx_amd as cfx
+    om = oracle.mesh_box(2, 12)
+    mesh = cfx.Mesh.from_arrays(2, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    a_vals = level_set_values(om.x, 2)
+    b_vals = om.x[:, 1] - 0.51
+    fluid, second = cfx.Function(V, a_vals, name="fluid"), cfx.Function(V, b_vals)
+    cd = cfx.cut([fluid, second])
+    assert cd.level_set_names == ("fluid", "phi1")
+    ref = cfx.cut([cfx.Function(V, a_vals), cfx.Function(V, b_vals)])
+    assert ref.level_set_names == ("phi", "phi1")
+    for named, plain in [("fluid<0", "phi<0"), ("fluid=0 or phi1=0", "phi=0 or phi1=0"),
+                         ("fluid<0 and phi1>0", "phi<0 and phi1>0")]:
+        assert np.array_equal(cfx.locate_entities(cd, named), cfx.locate_entities(ref, plain))
+    second.name = "renamed_after_cut"
+    cd.update()
+    assert cd.level_set_names == ("fluid", "phi1")
+    assert cfx.locate_entities(cd, "fluid=0 or phi1=0").size > 0
+    with pytest.raises(ValueError):
+        cfx.locate_entities(cd, "phi<0")                       # no level set of that name here
+    with pytest.raises(ValueError, match="Duplicate level-set function name"):
+        cfx.cut([cfx.Function(V, a_vals, name="fluid"), cfx.Function(V, b_vals, name="fluid")])
+    single = cfx.cut(cfx.Function(V, a_vals, name="fluid"))
+    r = cfx.runtime_quadrature(single, "fluid<0", 2)
+    want = cfx.runtime_quadrature(cfx.cut(cfx.Function(V, a_vals)), "phi<0", 2)
+    assert np.array_equal(r.parent_map, want.parent_map) and np.array_equal(r.weights, want.weights)
+
+
 def test_moving_domain_loop(oracle):
     # python/demo/demo_moving_poisson.py:53-90: one CutData, the level set moves in place on the
     # device, update() + rules + forms + sparsity + assembly every step; each step equals the oracle

@@ -264,6 +264,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         info = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        info = dp.counters(info)       # owned-share counts of the last step, outside the timed region
     info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
     if world > 1:
         cdev = device if dist.get_backend() == "nccl" else "cpu"

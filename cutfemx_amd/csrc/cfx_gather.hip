@@ -124,7 +124,7 @@ __device__ __forceinline__ int64_t entity_index(const unsigned long long* __rest
 __device__ __forceinline__ int64_t first_rule(const int32_t* __restrict__ keys, const int32_t* __restrict__ first,
                                               unsigned mask, int32_t c)
 {
-  unsigned h = ((unsigned)c * 2654435761u) & mask;
+  unsigned h = cfx_hash32((uint32_t)c) & mask;
   for (unsigned probe = 0; probe <= mask; ++probe)
   {
     const int32_t k = keys[h];

@@ -104,7 +104,7 @@ __global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ pa
   if (e >= nr) return;
   const int32_t c = parent[e];
   if (e > 0 && parent[e - 1] == c) return;
-  uint32_t h = ((uint32_t)c * 2654435761u) & mask;
+  uint32_t h = cfx_hash32((uint32_t)c) & mask;
   while (true)
   {
     const int32_t old = atomicCAS(&keys[h], -1, c);

@@ -60,12 +60,12 @@ def balanced_boundaries(weights, world: int):
     return bounds
 
 
-def sphere_layer_weights(n: int, active_weight: float = 18.0, cut_weight: float = 830.0):
+def sphere_layer_weights(n: int, active_weight: float = 15.0, cut_weight: float = 400.0):
     """Cost model per hex layer for the sphere workload, in units of one background cell
-    (~12 ps on MI355X: classification, selector scans, mark arrays; fitted to the per-rank
+    (~15 ps on MI355X: classification, selector scans, mark arrays; fitted to the per-rank
     times of tools/rank_balance.py): an active (inside) cell costs ~0.22 ns more of assembly
-    (18), a cut cell ~10 ns of sub-triangulation, runtime quadrature, local tensors and
-    ghost-penalty facets (830).  The surface of a sphere
+    (15), a cut cell ~6 ns of sub-triangulation, runtime quadrature, local tensors and
+    ghost-penalty facets (400).  The surface of a sphere
     between two parallel planes is 2 pi R dz (Archimedes), so the cut cells are spread evenly
     over the layers that meet the sphere: ~4.7 cut tets per h^2 of surface."""
     c, R = np.array([0.47, 0.43, 0.41]), 0.31
@@ -277,7 +277,15 @@ class DistributedPoisson:
         fem.assemble_matrix(system.a, A=A)
         fem.assemble_vector(system.L, self.b)
         dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
-        # counters of the owned share (device reductions, one host read)
+        return dict(A=A, dom=dom, system=system, nnz=A.nnz)
+
+    def counters(self, info):
+        """Counts of the owned share (active dofs, quadrature points, cut cells ...) of a step's
+        result: diagnostics, computed on request so that they stay out of the step itself."""
+        if "active_dofs_owned" in info:
+            return info
+        torch, part, dev = self.torch, self.part, self.device
+        system, dom, A = info["system"], info["dom"], info["A"]
         r_lo, r_hi = part.owned_rows
         c_lo, c_hi = part.owned_cells
         inactive = as_torch(dom._id, dom._ni, "int32", dev)

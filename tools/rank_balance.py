@@ -17,6 +17,7 @@ for r in range(world):
     for _ in range(5):
         info = dp.step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+    info = dp.counters(info)
     out.append((r, part.z0, part.z1, round(1e3 * dt, 3), info['active_dofs_owned'], info['n_cut']))
     del dp, info
     from cutfemx_amd import _lib

@@ -542,11 +542,21 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
     {
       const int64_t f = A.d2f[fb + t];
       const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
+      if constexpr (ND == 4)
       {
-        cols[j] = A.dofmap[(int64_t)row4.x * ND + j];
-        cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
+        const int4 d0 = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)row4.x * 4);
+        const int4 d1 = *reinterpret_cast<const int4*>(A.dofmap + (int64_t)row4.z * 4);
+        cols[0] = d0.x; cols[1] = d0.y; cols[2] = d0.z; cols[3] = d0.w;
+        cols[4] = d1.x; cols[5] = d1.y; cols[6] = d1.z; cols[7] = d1.w;
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          cols[j] = A.dofmap[(int64_t)row4.x * ND + j];
+          cols[ND + j] = A.dofmap[(int64_t)row4.z * ND + j];
+        }
       }
       // r may be a dof of both cells: both macro rows land in global row r
       int i0 = -1, i1 = -1;

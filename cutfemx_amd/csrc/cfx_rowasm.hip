@@ -213,7 +213,11 @@ struct PatArgs
 template <int T>
 __device__ __forceinline__ bool hash_insert(int32_t* tab, int32_t v)
 {
+#ifdef CFX_PATTERN_MURMUR
+  unsigned slot = cfx_hash32((uint32_t)v);
+#else
   unsigned slot = ((unsigned)v * 2654435761u) >> 7;
+#endif
   for (int probe = 0; probe < T; ++probe)
   {
     slot &= (T - 1);
@@ -309,7 +313,24 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         }
       }
     }
-    if (P.d2f_off)
+    if (P.d2f_off && P.nd == 4)
+    {
+      // P1: one facet per lane (11 loads for 8 candidates; the triple form below costs 24)
+      for (int64_t k = P.d2f_off[r] + gl; k < P.d2f_off[r + 1]; k += G)
+      {
+        const int64_t f = P.d2f[k];
+        for (int s = 0; s < 2; ++s)
+        {
+          const int64_t c = P.facet_rows[4 * f + 2 * s];
+          const int4 v = *reinterpret_cast<const int4*>(P.dofmap + c * 4);
+          ok = hash_insert<T>(tab, v.x) && ok;
+          ok = hash_insert<T>(tab, v.y) && ok;
+          ok = hash_insert<T>(tab, v.z) && ok;
+          ok = hash_insert<T>(tab, v.w) && ok;
+        }
+      }
+    }
+    else if (P.d2f_off)
     {
       // (facet, side, local dof) triples spread over the lanes
       const int64_t fb = P.d2f_off[r];

@@ -18,6 +18,7 @@ OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_OUT_OF_RANGE, ERR_HIP = 0, -1, -2, -3
 INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
 CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
+K_EXTENSION_L2 = 8
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
 

@@ -295,6 +295,49 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
                                                 double* acc)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
+  if (kernel == CFX_K_EXTENSION_L2)
+  {
+    // pair (bad = cell0, root = cell1): full-cell rule of the bad cell, the root's basis evaluated
+    // at the pulled-back points (its polynomial extension), macro basis M = [N_bad, -N_root]
+    int nref;
+    const double* wref;
+    const double* pref = ref_rule(TDIM, qdegree, nref, wref);
+    const double scale = params[0] * fabs(g0.detJ);
+    for (int q = 0; q < nref; ++q)
+    {
+      double X0[TDIM], X1[TDIM], xq[TDIM], l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) { X0[t] = pref[q * TDIM + t]; l0 -= X0[t]; }
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = l0 * g0.x[0][d];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v += X0[t] * g0.x[t + 1][d];
+        xq[d] = v;
+      }
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        double v = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) v += g1.K[t][d] * (xq[d] - g1.x[0][d]);
+        X1[t] = v;
+      }
+      double N0[ND], N1[ND], dN[ND][TDIM];
+      tabulate<TDIM, DEG>(X0, N0, dN);
+      tabulate<TDIM, DEG>(X1, N1, dN);
+      const double mi = ia < ND ? N0[ia] : -N1[ia - ND];
+      const double w = wref[q] * scale * mi;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        acc[j * BS + ik] += w * N0[j];
+        acc[(ND + j) * BS + ik] -= w * N1[j];
+      }
+    }
+    return;
+  }
   const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
   // outward unit normal of cell0 on facet lf0: -grad(lambda_lf0)/|.|
   double nrm[TDIM];

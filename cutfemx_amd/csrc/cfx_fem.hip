@@ -209,6 +209,12 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 #pragma unroll
   for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
   facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
+  if (A.kernel == CFX_K_EXTENSION_L2 && A.point_data)
+  {
+    const double factor = A.point_data[f]; // cellwise beta of the pair's bad cell
+#pragma unroll
+    for (int j = 0; j < NLOC; ++j) acc[j] *= factor;
+  }
 
   if (A.dump)
   {
@@ -274,6 +280,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "interior-facet integrals are implemented for bilinear forms");
     A.n = single ? 1 : I.n_entities;
     A.entities = I.entities.p + (single ? 4 * only_index : 0);
+    A.point_data = I.point_data.n > 0 ? I.point_data.p + (single ? only_index : 0) : nullptr; // per-pair factors
     launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
     return;
   }
@@ -485,8 +492,10 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     require(in.qdegree >= 0 && in.qdegree <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT,
             "cfx_form_create: quadrature degree out of range");
     if (in.type == CFX_INTERIOR_FACET)
-      require(in.kernel == CFX_K_GHOST_GRADJUMP && in.rules == nullptr, CFX_ERR_INVALID_ARGUMENT,
-              "cfx_form_create: interior-facet integrals support the ghost-penalty kernel with standard quadrature");
+      require((in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2) && in.rules == nullptr,
+              CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: interior-facet integrals support the ghost-penalty and extension-penalty kernels "
+              "with standard quadrature");
     else
       require(in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS || in.kernel == CFX_K_NITSCHE
                   || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS,
@@ -510,6 +519,8 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
       require(in.rules->mesh == V->mesh, CFX_ERR_INVALID_ARGUMENT, "rules belong to a different mesh");
       if (in.point_data) I.point_data = to_device(in.point_data, in.rules->nq * (int64_t)in.point_stride);
     }
+    else if (in.kernel == CFX_K_EXTENSION_L2 && in.point_data)
+      I.point_data = to_device(in.point_data, in.n_entities); // one factor per pair (cellwise beta)
     for (int k = 0; k < 8; ++k) I.params[k] = in.params[k];
     a->integrals.push_back(std::move(I));
   }

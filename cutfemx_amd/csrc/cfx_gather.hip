@@ -105,6 +105,7 @@ struct RowArgs
   int debug; // ablation switches (CFX_DEBUG_ROWS), 0 in production
   int iso_geometry; // the space's dofmap is the geometry dofmap (P1): dofs are vertex ids
   unsigned mark_mask;   // cell-mark bits this launch handles: 0x0F uncut entities, 0xF0 runtime rules (+ facets)
+  int fold_facets;      // every facet-type entity joins two cells across a shared facet (no extension pairs)
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
@@ -578,8 +579,10 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
         for (int j = 0; j < W; ++j) acc[j] += T[i1 * W + j];
       }
     }
-    if constexpr (DEG == 1)
+    if (DEG == 1 && A.fold_facets)
     {
+     if constexpr (DEG == 1)
+     {
       // P1: the two cells share the facet's TDIM vertices, so the macro row has ND + 1
       // distinct columns: fold the shared dofs of cell 1 onto cell 0's, 5 slot searches
       // and LDS adds instead of 8
@@ -608,6 +611,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
         for (int j = 0; j <= ND; ++j) s5[j] = find_slot(c5[j]);
       }
       add_item(std::integral_constant<int, ND + 1>{}, has, c5, a5, s5);
+     }
     }
     else
     {
@@ -1204,7 +1208,12 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     }
   }
   bool has_facets = false;
-  for (const auto& I : a->integrals) has_facets = has_facets || I.type == CFX_INTERIOR_FACET;
+  A.fold_facets = 1;
+  for (const auto& I : a->integrals)
+  {
+    has_facets = has_facets || I.type == CFX_INTERIOR_FACET;
+    if (I.type == CFX_INTERIOR_FACET && I.kernel != CFX_K_GHOST_GRADJUMP) A.fold_facets = 0; // (bad, root) pairs
+  }
   if (has_facets && plan.nfacets > 0)
   {
     A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;

@@ -24,6 +24,7 @@ from .mesh import FunctionSpace
 
 MASS, STIFFNESS, NITSCHE, GHOST_GRADJUMP, ELASTICITY = (_lib.K_MASS, _lib.K_STIFFNESS, _lib.K_NITSCHE,
                                                         _lib.K_GHOST_GRADJUMP, _lib.K_ELASTICITY)
+EXTENSION_L2 = _lib.K_EXTENSION_L2
 SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
 F_ONE, F_SINPROD, F_POISSON_RHS = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS
 

@@ -57,6 +57,11 @@ extern "C" {
                                    point_data = unit normals (gdim per point)  */
 #define CFX_K_GHOST_GRADJUMP 4  /* gamma_g h_avg [dn u][dn v]; params[0]=gamma_g */
 #define CFX_K_ELASTICITY 5      /* sigma(u):eps(v); params[0]=E, params[1]=nu  */
+/* extension penalty pair block, beta (v|bad - E v|root)(u|bad - E u|root) over the full bad cell
+ * (cpp/cutfemx/extensions/extension_penalty.cpp:191-369): an interior-facet-TYPE integral whose
+ * entity rows are (bad_cell, 0, root_cell, 0) from cfx_extension_pairs; params[0]=beta, qdegree =
+ * quadrature degree on the bad cell; point_data (stride 1, one value per pair) = cellwise beta factor */
+#define CFX_K_EXTENSION_L2 8
 #define CFX_L_SOURCE 101        /* f v; params[0]=field id, params[1]=scale    */
 #define CFX_L_NITSCHE_RHS 102   /* -dn(v) g + gamma/h g v; params[0]=gamma,
                                    params[1]=field id of g, params[2]=scale    */

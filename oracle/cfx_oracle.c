@@ -974,7 +974,38 @@ static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integr
   const int lf0 = row[1];
   double x0[MAXV][3], x1[MAXV][3], J0[3][3], K0[3][3], J1[3][3], K1[3][3];
   cell_coords(m, c0, x0); cell_coords(m, c1, x1);
-  jacobian(tdim, x0, J0, K0); jacobian(tdim, x1, J1, K1);
+  const double det0 = jacobian(tdim, x0, J0, K0); jacobian(tdim, x1, J1, K1);
+  if (I->kernel == ORC_K_EXTENSION_L2)
+  {
+    /* extension penalty pair block (extension_penalty.cpp:191-369, :395-470): full-cell rule of
+       the bad cell c0; the root cell's basis is evaluated at the pulled-back points (outside
+       its reference simplex: the polynomial extension); macro basis [N_bad, -N_root] */
+    int nref; const double *pref, *wref;
+    ref_rule(tdim, I->qdegree, &nref, &pref, &wref);
+    for (int q = 0; q < nref; ++q)
+    {
+      const double* X0 = pref + tdim * q;
+      double l0 = 1.0, xq[3] = {0, 0, 0}, X1[3] = {0, 0, 0};
+      for (int t = 0; t < tdim; ++t) l0 -= X0[t];
+      for (int d = 0; d < gdim; ++d)
+      {
+        xq[d] = l0 * x0[0][d];
+        for (int t = 0; t < tdim; ++t) xq[d] += X0[t] * x0[t + 1][d];
+      }
+      for (int t = 0; t < tdim; ++t)
+        for (int d = 0; d < gdim; ++d) X1[t] += K1[t][d] * (xq[d] - x1[0][d]);
+      double N0[MAXND], dN0[MAXND][3], N1[MAXND], dN1[MAXND][3], M[2 * MAXND];
+      tabulate(tdim, V->degree, X0, N0, dN0);
+      tabulate(tdim, V->degree, X1, N1, dN1);
+      for (int i = 0; i < nd; ++i) { M[i] = N0[i]; M[nd + i] = -N1[i]; }
+      const double w = wref[q] * fabs(det0) * I->params[0];
+      for (int i = 0; i < 2 * nd; ++i)
+        for (int j = 0; j < 2 * nd; ++j)
+          for (int kk = 0; kk < bs; ++kk)
+            Ae[(i * bs + kk) * nloc + j * bs + kk] += w * M[i] * M[j];
+    }
+    return;
+  }
   const double havg = 0.5 * (cell_diameter(tdim, x0) + cell_diameter(tdim, x1));
   /* outward normal of cell0 on facet lf0: -grad(lambda_lf0)/|.| */
   double n[3] = {0, 0, 0};
@@ -1068,6 +1099,12 @@ int orc_tabulate_entity(const orc_mesh* mesh, const orc_space* V,
   if (I->type == ORC_INTERIOR_FACET)
   {
     facet_kernel(mesh, V, I, I->entities + 4 * idx, Ae);
+    if (I->kernel == ORC_K_EXTENSION_L2 && I->point_data)
+    {
+      /* cellwise (DG0) beta: beta_cell_values[bad_cell] gathered per pair by the caller */
+      const int nloc = 2 * V->ndofs_cell * V->bs;
+      for (int i = 0; i < nloc * nloc; ++i) Ae[i] *= I->point_data[idx];
+    }
     return 0;
   }
   if (use_rule)
@@ -1271,6 +1308,73 @@ int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
     }
   }
   return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* 8f-3 cell aggregation.  ref: cell_aggregation.cpp:143-270                  */
+/* ------------------------------------------------------------------------ */
+int64_t orc_cell_aggregation(const orc_mesh* mesh, const int8_t* domain, int relation,
+                             const double* fraction, double threshold, int policy,
+                             int max_iterations, int32_t* root_cell, int32_t* aggregate_id,
+                             int32_t* depth)
+{
+  const int64_t nc = mesh->ncells;
+  const int nv = mesh->tdim + 1;
+  /* facet neighbours of every cell, ascending (cell_neighbors, :73-110) */
+  int32_t* nb = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nc * nv + 1));
+  for (int64_t i = 0; i < nc * nv; ++i) nb[i] = -1;
+  {
+    int64_t nf; facet_key* f = build_facets(mesh, NULL, &nf);
+    for (int64_t i = 0; i + 1 < nf; ++i)
+      if (f[i].v[0] == f[i + 1].v[0] && f[i].v[1] == f[i + 1].v[1] && f[i].v[2] == f[i + 1].v[2])
+      {
+        const int32_t a = f[i].cell, b = f[i + 1].cell;
+        for (int k = 0; k < nv; ++k) if (nb[a * nv + k] < 0) { nb[a * nv + k] = b; break; }
+        for (int k = 0; k < nv; ++k) if (nb[b * nv + k] < 0) { nb[b * nv + k] = a; break; }
+        ++i;
+      }
+    free(f);
+    for (int64_t c = 0; c < nc; ++c)   /* sort ascending, -1 (none) last */
+      for (int a = 0; a < nv; ++a)
+        for (int b = a + 1; b < nv; ++b)
+        {
+          int32_t* p = nb + c * nv;
+          if (p[b] >= 0 && (p[a] < 0 || p[b] < p[a])) { int32_t t = p[a]; p[a] = p[b]; p[b] = t; }
+        }
+  }
+  const int8_t sel = (int8_t)(relation < 0 ? -1 : 1); /* classification code of the strict selector */
+  int32_t next = 0;
+  for (int64_t c = 0; c < nc; ++c)
+  {
+    root_cell[c] = aggregate_id[c] = depth[c] = -1;
+    const int interior = domain[c] == sel;
+    const int well_cut = domain[c] == 0 && policy == 1 && fraction[c] >= threshold;
+    if (interior || well_cut) { root_cell[c] = (int32_t)c; aggregate_id[c] = next++; depth[c] = 0; }
+  }
+  const int64_t limit = max_iterations < 0 ? nc : max_iterations;
+  for (int64_t it = 0; it < limit; ++it)
+  {
+    int64_t mapped = 0;
+    for (int64_t c = 0; c < nc; ++c)
+    {
+      if (domain[c] != 0 || root_cell[c] >= 0) continue;       /* ill-posed = unrooted cut cells */
+      for (int k = 0; k < nv; ++k)
+      {
+        const int32_t o = nb[c * nv + k];
+        if (o < 0) break;
+        if (!(domain[o] == sel || domain[o] == 0)) continue;      /* active cells only */
+        if (root_cell[o] < 0) continue;
+        root_cell[c] = root_cell[o]; aggregate_id[c] = aggregate_id[o]; depth[c] = depth[o] + 1;
+        ++mapped;
+        break;
+      }
+    }
+    if (mapped == 0) break;
+  }
+  int64_t rootless = 0;
+  for (int64_t c = 0; c < nc; ++c) if (domain[c] == 0 && root_cell[c] < 0) ++rootless;
+  free(nb);
+  return rootless;
 }
 
 /* Dirichlet lifting: b -= alpha Ae (g - x0) over the marked columns, only on      */

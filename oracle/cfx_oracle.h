@@ -42,6 +42,8 @@ enum {
   ORC_K_ELASTICITY = 5,     /* sigma(u):eps(v), params[0]=E, params[1]=nu  */
   ORC_K_NITSCHE_ELASTICITY = 6,
   ORC_K_GHOST_GRADJUMP_VEC = 7,
+  ORC_K_EXTENSION_L2 = 8,   /* beta (v|bad - E v|root)(u|bad - E u|root) over the bad cell; pairs (bad,0,root,0) as
+                               interior-facet-type entities; params[0]=beta, point_data (stride 1) = per-pair factor */
   ORC_L_SOURCE = 101,       /* f v, f = analytic id params[0], scale params[1] */
   ORC_L_NITSCHE_RHS = 102   /* -dn(v) g + gamma/h g v, gamma=params[0], g id params[1], scale params[2] */
 };
@@ -134,6 +136,18 @@ int orc_assemble_matrix(const orc_mesh* mesh, const orc_space* V,
                         const int64_t* indptr, const int32_t* indices,
                         double* values);
 /* a8 */
+/* Cell aggregation: ill-posed cut cells inherit a root from a facet neighbour, in sequential
+   sweeps over the ascending ill-posed list (an earlier cell of the same sweep already counts).
+   ref: cpp/cutfemx/extensions/cell_aggregation.cpp:143-270.  `domain` is the classification of
+   the selector's level set, `relation` -1 for "phi<0", +1 for "phi>0", `fraction[c]` the cut
+   volume fraction of the selected part (cut cells).  policy 0 interior_only, 1 interior_or_well_cut.
+   Outputs (size ncells): root_cell, aggregate_id, depth (-1 where unset).  Returns the number of
+   rootless ill-posed cells. */
+int64_t orc_cell_aggregation(const orc_mesh* mesh, const int8_t* domain, int relation,
+                             const double* fraction, double threshold, int policy,
+                             int max_iterations, int32_t* root_cell, int32_t* aggregate_id,
+                             int32_t* depth);
+
 int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
                         const orc_integral* integrals, int n_integrals,
                         double* b);

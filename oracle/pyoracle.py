@@ -19,6 +19,7 @@ _LIB = None
 INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
 CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
+K_EXTENSION_L2 = 8
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
 
@@ -345,3 +346,66 @@ def deactivate(inactive, indptr, indices, values, b=None, diagonal=1.0, rhs_valu
     inactive = np.ascontiguousarray(inactive, dtype=np.int32)
     lib().orc_deactivate(_p(inactive), C.c_int64(inactive.size), 1, _p(indptr), _p(indices),
                          _p(values), _p(b), C.c_double(diagonal), C.c_double(rhs_value))
+
+
+# ---- 8f-3: cell aggregation and extension penalty (cpp/cutfemx/extensions/) ---------------------
+def cell_volumes(mesh: Mesh) -> np.ndarray:
+    x, c = mesh.x, mesh.conn
+    e = x[c[:, 1:]] - x[c[:, :1]]
+    if mesh.tdim == 2:
+        return 0.5 * np.abs(e[:, 0, 0] * e[:, 1, 1] - e[:, 0, 1] * e[:, 1, 0])
+    return np.abs(np.einsum("ij,ij->i", e[:, 0], np.cross(e[:, 1], e[:, 2]))) / 6.0
+
+
+def volume_fractions(mesh: Mesh, ls_dofmap, ls_values, domain, selector: str) -> np.ndarray:
+    """|selected part of a cut cell| / |cell| (cutcells::output::volume_fractions as used by
+    cell_aggregation.cpp:180-186); 0 on cells without a cut part."""
+    rules = runtime_quadrature(mesh, ls_dofmap, ls_values, domain, selector, 1)
+    part = np.zeros(mesh.ncells)
+    np.add.at(part, rules.parent_map, np.add.reduceat(rules.weights, rules.offsets[:-1]) if rules.parent_map.size
+              else np.zeros(0))
+    return part / cell_volumes(mesh)
+
+
+def cell_aggregation(mesh: Mesh, ls_dofmap, ls_values, domain, selector: str, threshold: float,
+                     root_policy: str = "interior_or_well_cut", max_iterations: int = -1,
+                     allow_rootless: bool = False) -> dict:
+    text = "".join(selector.split())
+    if ("<" in text) == (">" in text) or "=" in text or not text.endswith("0"):
+        raise ValueError("CellAggregation v1 expects a strict single level-set selector such as 'phi < 0' or 'phi > 0'.")
+    if not 0.0 <= threshold <= 1.0:
+        raise ValueError("Volume fraction threshold must be in [0, 1].")
+    if root_policy not in ("interior_only", "interior_or_well_cut"):
+        raise ValueError("Unknown root policy. Expected 'interior_only' or 'interior_or_well_cut'.")
+    rel = -1 if "<" in text else 1
+    domain = np.ascontiguousarray(domain, dtype=np.int8)
+    frac = volume_fractions(mesh, ls_dofmap, ls_values, domain, text)
+    frac = np.where(domain == 0, frac, 0.0)
+    root = np.empty(mesh.ncells, dtype=np.int32)
+    agg = np.empty(mesh.ncells, dtype=np.int32)
+    depth = np.empty(mesh.ncells, dtype=np.int32)
+    lib().orc_cell_aggregation.restype = C.c_int64
+    nroot = lib().orc_cell_aggregation(C.byref(mesh.c), _p(domain), rel, _p(frac), C.c_double(threshold),
+                                       1 if root_policy == "interior_or_well_cut" else 0, int(max_iterations),
+                                       _p(root), _p(agg), _p(depth))
+    cut = np.flatnonzero(domain == 0).astype(np.int32)
+    interior = np.flatnonzero(domain == rel).astype(np.int32)
+    well = np.flatnonzero((root == np.arange(mesh.ncells)) & (depth == 0)).astype(np.int32)
+    ill = np.setdiff1d(cut, well).astype(np.int32)
+    rootless = ill[root[ill] < 0]
+    if nroot and not allow_rootless:
+        raise RuntimeError("CellAggregation found active ill-posed cells without an admissible root. Adjust the root "
+                           "policy or threshold, or explicitly allow rootless aggregation for diagnostics.")
+    return dict(active_cells=np.union1d(interior, cut).astype(np.int32), cut_cells=cut, interior_cells=interior,
+                well_posed_cells=well, ill_posed_cells=ill, root_cell=root, aggregate_id=agg,
+                propagation_depth=depth, rootless_cells=rootless, cut_volume_fraction=frac)
+
+
+def extension_pairs(agg: dict) -> np.ndarray:
+    """(bad, 0, root, 0) rows of the ill-posed cells that found a root (extension_penalty.cpp:373-392)."""
+    ill = agg["ill_posed_cells"]
+    ill = ill[agg["root_cell"][ill] >= 0]
+    rows = np.zeros((ill.size, 4), dtype=np.int32)
+    rows[:, 0] = ill
+    rows[:, 2] = agg["root_cell"][ill]
+    return rows

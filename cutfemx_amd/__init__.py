@@ -7,6 +7,7 @@ HIP kernels for gfx950 behind the C ABI of include/cutfemx_amd.h; importing the
 package needs no GPU, calling into it does.
 """
 from . import fem
+from . import extensions
 from .cut import (CutData, FacetRows, RuntimeQuadratureRules, cut, full_cell_rules, ghost_penalty_facets,
                   level_set_value, locate_entities, locate_entities_device, normal, runtime_quadrature,
                   runtime_quadratures, update)
@@ -16,5 +17,5 @@ __all__ = [
     "CutData", "FacetRows", "RuntimeQuadratureRules", "cut", "update", "locate_entities",
     "locate_entities_device", "runtime_quadrature", "runtime_quadratures", "full_cell_rules",
     "ghost_penalty_facets", "normal", "level_set_value", "Mesh", "FunctionSpace", "Function",
-    "box_mesh_arrays", "box_lagrange2_dofmap", "lagrange_dofmap", "fem",
+    "box_mesh_arrays", "box_lagrange2_dofmap", "lagrange_dofmap", "fem", "extensions",
 ]

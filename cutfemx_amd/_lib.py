@@ -40,6 +40,16 @@ class Integral(C.Structure):
                 ("rules", C.c_void_p), ("point_data", C.c_void_p), ("params", C.c_double * 8)]
 
 
+class AggregationView(C.Structure):
+    _fields_ = [("ncells", C.c_int64), ("root_cell", C.c_void_p), ("aggregate_id", C.c_void_p),
+                ("propagation_depth", C.c_void_p), ("cut_volume_fraction", C.c_void_p),
+                ("active_cells", C.c_void_p), ("cut_cells", C.c_void_p), ("interior_cells", C.c_void_p),
+                ("well_posed_cells", C.c_void_p), ("ill_posed_cells", C.c_void_p), ("rootless_cells", C.c_void_p),
+                ("n_active", C.c_int64), ("n_cut", C.c_int64), ("n_interior", C.c_int64),
+                ("n_well_posed", C.c_int64), ("n_ill_posed", C.c_int64), ("n_rootless", C.c_int64),
+                ("pairs", C.c_void_p), ("n_pairs", C.c_int64)]
+
+
 class PatternView(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("nnz", C.c_int64), ("indptr", C.c_void_p),
                 ("indices", C.c_void_p)]
@@ -55,7 +65,8 @@ SYMBOLS = [
     "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
     "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
-    "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_cut_destroy", "cfx_space_create",
+    "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",
+    "cfx_cell_aggregation_destroy", "cfx_cut_destroy", "cfx_space_create",
     "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_create_sparsity",
     "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_vector",
     "cfx_apply_lifting", "cfx_set_bc", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",

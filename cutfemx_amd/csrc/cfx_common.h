@@ -425,6 +425,15 @@ struct cfx_pattern_s
   cfx::DevArray<int32_t> indices;
 };
 
+struct cfx_aggregation_s
+{
+  int64_t ncells = 0;
+  cfx::DevArray<int32_t> root_cell, aggregate_id, depth;
+  cfx::DevArray<double> fraction;
+  cfx::DevArray<int32_t> active, cut, interior, well, ill, rootless, pairs;
+  int64_t n_pairs = 0;
+};
+
 struct cfx_active_s
 {
   cfx_space_t V = nullptr;

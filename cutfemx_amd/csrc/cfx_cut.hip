@@ -745,6 +745,164 @@ __global__ void __launch_bounds__(kBlock) ghost_facets_kernel(int64_t ncut, cons
   if (!WRITE) counts[i] = n;
 }
 
+// ---------------------------------------------------------------------------
+// 8f-3 cell aggregation (cell_aggregation.cpp:143-270) without its sequential sweeps.
+// Sweep k of the reference visits the unrooted cut cells in ascending order; cell c takes the
+// first (ascending) active neighbour that is rooted AT THAT MOMENT: a root, a cell rooted in an
+// earlier sweep, or a lower-numbered cell rooted earlier in this sweep.  Hence the sweep t(c) in
+// which c is rooted is the least fixed point of
+//     t(c) = max(0, min over active neighbours o of t(o) + [o > c]),   t(root) = -1,
+// a shortest-path problem with 0/1 edge weights solved by parallel relaxation; the neighbour
+// chosen in sweep t(c) is the first o with t(o) < t(c) or (t(o) == t(c) and o < c); roots,
+// aggregate ids and depths then follow the parent pointers (pointer jumping).
+// ---------------------------------------------------------------------------
+constexpr int32_t kAggUnset = 0x7fffffff;
+
+template <int TDIM>
+__device__ __forceinline__ int sorted_neighbours(const int32_t* __restrict__ conn, const int64_t* __restrict__ v2c_off,
+                                                 const int32_t* __restrict__ v2c, int64_t c, int32_t* nbs)
+{
+  int n = 0;
+  for (int lf = 0; lf <= TDIM; ++lf)
+  {
+    int32_t nb;
+    int nlf;
+    if (facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf)) nbs[n++] = nb;
+  }
+  for (int a = 1; a < n; ++a) // insertion sort, n <= 4
+  {
+    const int32_t v = nbs[a];
+    int b = a - 1;
+    while (b >= 0 && nbs[b] > v) { nbs[b + 1] = nbs[b]; --b; }
+    nbs[b + 1] = v;
+  }
+  return n;
+}
+
+// selected volume fraction of the cut cells from order-1 volume rules
+template <int TDIM>
+__global__ void agg_fraction_kernel(int64_t nr, const int32_t* __restrict__ offsets, const int32_t* __restrict__ parent,
+                                    const double* __restrict__ weights, const double* __restrict__ x,
+                                    const int32_t* __restrict__ conn, double* fraction)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nr) return;
+  double s = 0.0;
+  for (int32_t q = offsets[e]; q < offsets[e + 1]; ++q) s += weights[q];
+  Geo<TDIM> g;
+  load_cell<TDIM>(x, conn, parent[e], g);
+  jacobian<TDIM>(g);
+  atomicAdd(&fraction[parent[e]], s / (fabs(g.detJ) / (TDIM == 2 ? 2.0 : 6.0)));
+}
+
+// cls bits: 1 interior, 2 cut, 4 well posed (root), 8 ill posed
+__global__ void agg_init_kernel(int64_t nc, const int8_t* __restrict__ domain, int8_t selcode, int policy,
+                                const double* __restrict__ fraction, double threshold, int32_t* t, uint8_t* cls)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  const bool interior = domain[c] == selcode, cutc = domain[c] == CFX_INTERSECTED;
+  const bool well = interior || (cutc && policy == 1 && fraction[c] >= threshold);
+  t[c] = well ? -1 : kAggUnset;
+  cls[c] = (uint8_t)((interior ? 1 : 0) | (cutc ? 2 : 0) | (well ? 4 : 0) | ((cutc && !well) ? 8 : 0));
+}
+
+template <int TDIM>
+__global__ void agg_relax_kernel(int64_t n_ill, const int32_t* __restrict__ ill, const int32_t* __restrict__ conn,
+                                 const int64_t* __restrict__ v2c_off, const int32_t* __restrict__ v2c,
+                                 const uint8_t* __restrict__ cls, int32_t* t, int* changed)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ill) return;
+  const int32_t c = ill[i];
+  int32_t nbs[TDIM + 1];
+  const int n = sorted_neighbours<TDIM>(conn, v2c_off, v2c, c, nbs);
+  int32_t best = kAggUnset;
+  for (int k = 0; k < n; ++k)
+  {
+    const int32_t o = nbs[k];
+    if (!(cls[o] & 3)) continue; // active cells only
+    const int32_t to = *reinterpret_cast<volatile int32_t*>(&t[o]);
+    if (to == kAggUnset) continue;
+    const int32_t cand = to + (o > c ? 1 : 0);
+    best = cand < best ? cand : best;
+  }
+  if (best != kAggUnset && best < 0) best = 0;
+  if (best < t[c]) { t[c] = best; *changed = 1; }
+}
+
+template <int TDIM>
+__global__ void agg_parent_kernel(int64_t n_ill, const int32_t* __restrict__ ill, const int32_t* __restrict__ conn,
+                                  const int64_t* __restrict__ v2c_off, const int32_t* __restrict__ v2c,
+                                  const uint8_t* __restrict__ cls, const int32_t* __restrict__ t, int64_t limit,
+                                  int32_t* parent)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ill) return;
+  const int32_t c = ill[i];
+  int32_t p = -1;
+  const int32_t tc = t[c];
+  if (tc != kAggUnset && (int64_t)tc < limit)
+  {
+    int32_t nbs[TDIM + 1];
+    const int n = sorted_neighbours<TDIM>(conn, v2c_off, v2c, c, nbs);
+    for (int k = 0; k < n && p < 0; ++k)
+    {
+      const int32_t o = nbs[k];
+      if (!(cls[o] & 3) || t[o] == kAggUnset) continue;
+      if (t[o] < tc || (t[o] == tc && o < c)) p = o;
+    }
+  }
+  parent[i] = p;
+}
+
+__global__ void agg_roots_kernel(int64_t n_well, const int32_t* __restrict__ well, int32_t* root, int32_t* agg,
+                                 int32_t* depth)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_well) return;
+  const int32_t c = well[i];
+  root[c] = c; agg[c] = (int32_t)i; depth[c] = 0; // aggregate ids follow the ascending root order (:211-217)
+}
+
+__global__ void agg_resolve_kernel(int64_t n_ill, const int32_t* __restrict__ ill, const int32_t* __restrict__ parent,
+                                   int32_t* root, int32_t* agg, int32_t* depth, int* changed)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_ill) return;
+  const int32_t c = ill[i], p = parent[i];
+  if (p < 0 || root[c] >= 0) return;
+  const int32_t rp = *reinterpret_cast<volatile int32_t*>(&root[p]);
+  if (rp < 0) return;
+  // the parent's three fields were written before its root became visible only within one
+  // thread; read depth/aggregate after the root and re-run until nothing changes
+  depth[c] = depth[p] + 1; agg[c] = agg[p];
+  __threadfence();
+  root[c] = rp;
+  *changed = 1;
+}
+
+__global__ void agg_flag_rootless_kernel(int64_t n_ill, const int32_t* __restrict__ ill, const int32_t* __restrict__ root,
+                                         uint8_t* cls)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_ill && root[ill[i]] < 0) cls[ill[i]] |= 16;
+}
+
+__global__ void agg_pairs_kernel(int64_t n, const int32_t* __restrict__ bad, const int32_t* __restrict__ root,
+                                 int32_t* rows)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) *reinterpret_cast<int4*>(rows + 4 * i) = make_int4(bad[i], 0, root[bad[i]], 0);
+}
+
+struct ClsMask
+{
+  const uint8_t* cls;
+  uint8_t any, none;
+  __device__ bool operator()(int64_t c) const { return (cls[c] & any) != 0 && (cls[c] & none) == 0; }
+};
+
 struct IsCut
 {
   const int8_t* domain;
@@ -1109,6 +1267,130 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   }
   *rows = grows.p;
   *n = total;
+  CFX_API_END
+}
+
+int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double threshold, int root_policy,
+                                int max_iterations, int allow_rootless, cfx_aggregation_t* out)
+{
+  CFX_API_BEGIN
+  require(cut && selector && out, CFX_ERR_INVALID_ARGUMENT, "cfx_cell_aggregation_create: null argument");
+  require(threshold >= 0.0 && threshold <= 1.0, CFX_ERR_INVALID_ARGUMENT, "Volume fraction threshold must be in [0, 1].");
+  require(root_policy == 0 || root_policy == 1, CFX_ERR_INVALID_ARGUMENT,
+          "Unknown root policy. Expected 'interior_only' or 'interior_or_well_cut'.");
+  const Selector sel = parse_selector(selector, cut->nls);
+  require(sel.n == 1 && (sel.mask[0] == 1 || sel.mask[0] == 4), CFX_ERR_INVALID_ARGUMENT,
+          "CellAggregation v1 expects a strict single level-set selector such as 'phi < 0' or 'phi > 0'.");
+  cfx_mesh_t mesh = cut->mesh;
+  const int64_t nc = mesh->ncells;
+  const int tdim = mesh->tdim;
+  const int8_t selcode = sel.mask[0] == 1 ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE;
+  const int8_t* domain = cut->domain.p + (int64_t)sel.ls[0] * nc;
+  auto A = std::make_unique<cfx_aggregation_s>();
+  A->ncells = nc;
+  A->root_cell.alloc(nc); A->aggregate_id.alloc(nc); A->depth.alloc(nc); A->fraction.alloc(nc);
+  A->fraction.zero();
+  CFX_HIP(hipMemsetAsync(A->root_cell.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
+  CFX_HIP(hipMemsetAsync(A->aggregate_id.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
+  CFX_HIP(hipMemsetAsync(A->depth.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
+  {
+    // volume fraction of the selected part: order-1 rules of the cut cells (weights sum to the part's measure)
+    cfx_rules_t rules = nullptr;
+    const int rc = cfx_runtime_quadrature(cut, selector, 1, "straight", &rules);
+    if (rc != CFX_OK) throw Error(rc, cfx_last_error());
+    std::unique_ptr<cfx_rules_s> guard(rules);
+    if (rules->nr > 0)
+    {
+      if (tdim == 2)
+        launch("agg_fraction", agg_fraction_kernel<2>, grid_for(rules->nr), dim3(kBlock), 0, rules->nr, rules->offsets.p,
+               rules->parent_map.p, rules->weights.p, mesh->x.p, mesh->conn.p, A->fraction.p);
+      else
+        launch("agg_fraction", agg_fraction_kernel<3>, grid_for(rules->nr), dim3(kBlock), 0, rules->nr, rules->offsets.p,
+               rules->parent_map.p, rules->weights.p, mesh->x.p, mesh->conn.p, A->fraction.p);
+    }
+    CFX_HIP(hipStreamSynchronize(ctx().stream)); // the rules die here
+  }
+  DevArray<int32_t> t(nc);
+  DevArray<uint8_t> cls(nc);
+  launch("agg_init", agg_init_kernel, grid_for(nc), dim3(kBlock), 0, nc, domain, selcode, root_policy, A->fraction.p,
+         threshold, t.p, cls.p);
+  const int64_t n_interior = compact("agg_lists", nc, ClsMask{cls.p, 1, 0}, A->interior);
+  const int64_t n_cut = compact("agg_lists", nc, ClsMask{cls.p, 2, 0}, A->cut);
+  compact("agg_lists", nc, ClsMask{cls.p, 3, 0}, A->active);
+  const int64_t n_well = compact("agg_lists", nc, ClsMask{cls.p, 4, 0}, A->well);
+  const int64_t n_ill = compact("agg_lists", nc, ClsMask{cls.p, 8, 0}, A->ill);
+  (void)n_interior; (void)n_cut;
+  launch("agg_roots", agg_roots_kernel, grid_for(n_well), dim3(kBlock), 0, n_well, A->well.p, A->root_cell.p,
+         A->aggregate_id.p, A->depth.p);
+  const Adjacency& adj = mesh->vertex_cells();
+  DevArray<int> changed(1);
+  DevArray<int32_t> parent(n_ill);
+  if (n_ill > 0)
+  {
+    for (int64_t it = 0;; ++it)
+    {
+      require(it <= nc, CFX_ERR_RUNTIME, "cell aggregation: relaxation did not converge");
+      changed.zero();
+      if (tdim == 2)
+        launch("agg_relax", agg_relax_kernel<2>, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p, mesh->conn.p,
+               adj.offsets.p, adj.cells.p, cls.p, t.p, changed.p);
+      else
+        launch("agg_relax", agg_relax_kernel<3>, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p, mesh->conn.p,
+               adj.offsets.p, adj.cells.p, cls.p, t.p, changed.p);
+      if (!read_scalar(changed.p)) break;
+    }
+    const int64_t limit = max_iterations < 0 ? nc : max_iterations;
+    if (tdim == 2)
+      launch("agg_parent", agg_parent_kernel<2>, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p, mesh->conn.p,
+             adj.offsets.p, adj.cells.p, cls.p, t.p, limit, parent.p);
+    else
+      launch("agg_parent", agg_parent_kernel<3>, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p, mesh->conn.p,
+             adj.offsets.p, adj.cells.p, cls.p, t.p, limit, parent.p);
+    for (int64_t it = 0;; ++it)
+    {
+      require(it <= nc, CFX_ERR_RUNTIME, "cell aggregation: root propagation did not converge");
+      changed.zero();
+      launch("agg_resolve", agg_resolve_kernel, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p, parent.p,
+             A->root_cell.p, A->aggregate_id.p, A->depth.p, changed.p);
+      if (!read_scalar(changed.p)) break;
+    }
+    launch("agg_flag_rootless", agg_flag_rootless_kernel, grid_for(n_ill), dim3(kBlock), 0, n_ill, A->ill.p,
+           A->root_cell.p, cls.p);
+  }
+  const int64_t n_rootless = compact("agg_lists", nc, ClsMask{cls.p, 16, 0}, A->rootless);
+  require(allow_rootless || n_rootless == 0, CFX_ERR_RUNTIME,
+          "CellAggregation found active ill-posed cells without an admissible root. Adjust the root policy or "
+          "threshold, or explicitly allow rootless aggregation for diagnostics.");
+  DevArray<int32_t> bad;
+  A->n_pairs = compact("agg_lists", nc, ClsMask{cls.p, 8, 16}, bad);
+  A->pairs.alloc(A->n_pairs * 4);
+  launch("agg_pairs", agg_pairs_kernel, grid_for(A->n_pairs), dim3(kBlock), 0, A->n_pairs, bad.p, A->root_cell.p,
+         A->pairs.p);
+  *out = A.release();
+  CFX_API_END
+}
+
+int cfx_cell_aggregation_view_get(cfx_aggregation_t agg, cfx_aggregation_view* v)
+{
+  CFX_API_BEGIN
+  require(agg && v, CFX_ERR_INVALID_ARGUMENT, "cfx_cell_aggregation_view_get: null argument");
+  v->ncells = agg->ncells;
+  v->root_cell = agg->root_cell.p; v->aggregate_id = agg->aggregate_id.p; v->propagation_depth = agg->depth.p;
+  v->cut_volume_fraction = agg->fraction.p;
+  v->active_cells = agg->active.p; v->n_active = agg->active.n;
+  v->cut_cells = agg->cut.p; v->n_cut = agg->cut.n;
+  v->interior_cells = agg->interior.p; v->n_interior = agg->interior.n;
+  v->well_posed_cells = agg->well.p; v->n_well_posed = agg->well.n;
+  v->ill_posed_cells = agg->ill.p; v->n_ill_posed = agg->ill.n;
+  v->rootless_cells = agg->rootless.p; v->n_rootless = agg->rootless.n;
+  v->pairs = agg->pairs.p; v->n_pairs = agg->n_pairs;
+  CFX_API_END
+}
+
+int cfx_cell_aggregation_destroy(cfx_aggregation_t agg)
+{
+  CFX_API_BEGIN
+  delete agg;
   CFX_API_END
 }
 

@@ -77,6 +77,7 @@ typedef struct cfx_space_s* cfx_space_t;
 typedef struct cfx_form_s* cfx_form_t;
 typedef struct cfx_pattern_s* cfx_pattern_t;
 typedef struct cfx_active_s* cfx_active_t;
+typedef struct cfx_aggregation_s* cfx_aggregation_t;
 
 /* Options of cutfemx.cut(); defaults of python/cutfemx/wrappers/cut.cpp:117-140 */
 typedef struct
@@ -210,6 +211,31 @@ int cfx_evaluate_values(cfx_cut_t cut, int level_set, cfx_rules_t rules,
  * rows = (cell0, local_facet0, cell1, local_facet1), cell0 < cell1. */
 int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector,
                              const int32_t** rows, int64_t* n);
+/* ---- cell aggregation (extension stabilisation): cutfemx::extensions::create_cell_aggregation,
+ *      cpp/cutfemx/extensions/cell_aggregation.{h,cpp}, python/cutfemx/extensions.py -------------
+ * selector: strict single level set ("phi<0" / "phi>0").  Roots = interior cells (+ cut cells whose
+ * selected volume fraction >= threshold when root_policy = 1, "interior_or_well_cut"; 0 =
+ * "interior_only"); every other cut cell is ill-posed and inherits the root of a facet neighbour.
+ * The reference's sequential sweeps (ascending cells, a cell rooted earlier in the same sweep
+ * already counts, first rooted neighbour in ascending order wins) are reproduced exactly.
+ * max_iterations < 0: unlimited.  Rootless ill-posed cells raise CFX_ERR_RUNTIME unless
+ * allow_rootless. */
+typedef struct
+{
+  int64_t ncells;
+  const int32_t* root_cell;         /* [ncells], -1 where unset */
+  const int32_t* aggregate_id;      /* [ncells] */
+  const int32_t* propagation_depth; /* [ncells] */
+  const double* cut_volume_fraction; /* [ncells], 0 off the cut cells */
+  const int32_t *active_cells, *cut_cells, *interior_cells, *well_posed_cells, *ill_posed_cells, *rootless_cells;
+  int64_t n_active, n_cut, n_interior, n_well_posed, n_ill_posed, n_rootless;
+  const int32_t* pairs;             /* [n_pairs*4] (bad, 0, root, 0): extension_pairs(), entity rows of CFX_K_EXTENSION_L2 */
+  int64_t n_pairs;
+} cfx_aggregation_view;
+int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double volume_fraction_threshold,
+                                int root_policy, int max_iterations, int allow_rootless, cfx_aggregation_t* out);
+int cfx_cell_aggregation_view_get(cfx_aggregation_t agg, cfx_aggregation_view* view);
+int cfx_cell_aggregation_destroy(cfx_aggregation_t agg);
 int cfx_cut_destroy(cfx_cut_t cut);
 
 /* ---- function space: dolfinx DofMap as read by

@@ -305,3 +305,45 @@ def test_cut_poisson_solution_converges(oracle):
         act = np.setdiff1d(np.arange(m.nnodes), ref["inactive"])
         errs.append(np.abs(u - uex)[act].max())
     assert errs[1] < errs[0] / 3
+
+
+def test_cell_aggregation_and_extension_penalty_invariants(oracle):
+    # python/tests/test_extensions_cell_aggregation.py:30-146 restated on the oracle
+    import scipy.sparse as sp
+    O = oracle
+    m = O.mesh_box(2, 3)
+    phi = m.x[:, 0] - 0.51
+    dom = O.classify(m.conn, phi)
+    agg = O.cell_aggregation(m, m.conn, phi, dom, "phi < 0", 0.2)
+    assert np.array_equal(agg["cut_cells"], O.locate_entities(dom, "phi=0"))
+    assert np.array_equal(agg["interior_cells"], O.locate_entities(dom, "phi<0"))
+    assert np.array_equal(agg["active_cells"], O.locate_entities(dom, "phi<=0"))
+    assert set(agg["well_posed_cells"]) <= set(agg["active_cells"]) and set(agg["ill_posed_cells"]) <= set(agg["cut_cells"])
+    assert agg["rootless_cells"].size == 0
+    # every cut cell ill posed (threshold 1): all propagate to interior roots, depth > 0 (:55-71)
+    agg = O.cell_aggregation(m, m.conn, phi, dom, "phi<0", 1.0)
+    assert agg["ill_posed_cells"].size == agg["cut_cells"].size and agg["rootless_cells"].size == 0
+    for c in agg["ill_posed_cells"]:
+        assert agg["root_cell"][c] in set(agg["interior_cells"]) and agg["propagation_depth"][c] > 0
+    # opposite volume fractions sum to one on the cut cells (:74-98)
+    pos = O.cell_aggregation(m, m.conn, phi, dom, "phi>0", 0.5)
+    neg = O.cell_aggregation(m, m.conn, phi, dom, "phi<0", 0.5)
+    np.testing.assert_allclose((pos["cut_volume_fraction"] + neg["cut_volume_fraction"])[neg["cut_cells"]], 1.0, atol=1e-12)
+    # an active component without admissible root (:101-120)
+    with pytest.raises(RuntimeError, match="without an admissible root"):
+        O.cell_aggregation(m, m.conn, phi, dom, "phi<0", 1.0, max_iterations=0)
+    free = O.cell_aggregation(m, m.conn, phi, dom, "phi<0", 1.0, max_iterations=0, allow_rootless=True)
+    assert free["rootless_cells"].size == free["ill_posed_cells"].size
+    # penalty matrix: symmetric, annihilates constants (and, for P1, linear functions), non-zero (:123-146);
+    # the quadrature carries the full bad-cell measure (:149-175)
+    V = O.Space(m.conn, m.nnodes, 1)
+    pairs = O.extension_pairs(agg)
+    I = [O.Integral(O.INTERIOR_FACET, O.K_EXTENSION_L2, entities=pairs, params=(1.0,), qdegree=2)]
+    ip, ix = O.create_sparsity(m, V, I)
+    A = sp.csr_matrix((O.assemble_matrix(m, V, I, ip, ix), ix, ip)).toarray()
+    assert np.abs(A - A.T).max() < 1e-14 and np.abs(A @ np.ones(m.nnodes)).max() < 1e-14
+    assert np.abs(A @ m.x[:, 1]).max() < 1e-14 and np.linalg.norm(A) > 0
+    vols = O.cell_volumes(m)
+    for k, (bad, _, root, _) in enumerate(pairs):
+        Ae = O.tabulate_entity(m, V, I[0], k, False)
+        np.testing.assert_allclose(Ae[:3, :3].sum(), vols[bad], rtol=1e-13)   # sum_ij int N_i N_j = |K_bad|

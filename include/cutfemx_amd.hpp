@@ -395,4 +395,54 @@ inline ActiveDomain& deactivate_outside(std::span<double> values, const Sparsity
 }
 
 } // namespace fem
+
+namespace extensions
+{
+/// cutfemx::extensions::RootPolicy / CellAggregation (cpp/cutfemx/extensions/cell_aggregation.h:24-47)
+enum class RootPolicy { interior_only = 0, interior_or_well_cut = 1 };
+
+inline RootPolicy root_policy_from_string(std::string_view policy)
+{
+  if (policy == "interior_only") return RootPolicy::interior_only;
+  if (policy == "interior_or_well_cut") return RootPolicy::interior_or_well_cut;
+  throw std::invalid_argument("Unknown root policy. Expected 'interior_only' or 'interior_or_well_cut'.");
+}
+
+struct CellAggregation
+{
+  detail::Handle<cfx_aggregation_t, cfx_cell_aggregation_destroy> handle;
+  std::vector<std::int32_t> active_cells, cut_cells, interior_cells, well_posed_cells, ill_posed_cells, root_cell,
+      aggregate_id, propagation_depth, rootless_cells;
+  std::vector<double> cut_volume_fraction;
+  /// (bad, 0, root, 0) rows: extension_pairs(), the entities of a CFX_K_EXTENSION_L2 integral
+  std::vector<std::int32_t> pairs;
+};
+
+/// create_cell_aggregation(): cell_aggregation.cpp:143-270
+inline CellAggregation create_cell_aggregation(const CutData& cut_data, std::string_view selector,
+                                               double volume_fraction_threshold,
+                                               RootPolicy root_policy = RootPolicy::interior_or_well_cut,
+                                               int max_iterations = -1, bool allow_rootless = false)
+{
+  cfx_aggregation_t h = nullptr;
+  check(cfx_cell_aggregation_create(cut_data.handle.h, std::string(selector).c_str(), volume_fraction_threshold,
+                                    static_cast<int>(root_policy), max_iterations, allow_rootless ? 1 : 0, &h));
+  CellAggregation a;
+  a.handle = detail::Handle<cfx_aggregation_t, cfx_cell_aggregation_destroy>(h);
+  cfx_aggregation_view v;
+  check(cfx_cell_aggregation_view_get(h, &v));
+  a.active_cells = download(v.active_cells, v.n_active);
+  a.cut_cells = download(v.cut_cells, v.n_cut);
+  a.interior_cells = download(v.interior_cells, v.n_interior);
+  a.well_posed_cells = download(v.well_posed_cells, v.n_well_posed);
+  a.ill_posed_cells = download(v.ill_posed_cells, v.n_ill_posed);
+  a.rootless_cells = download(v.rootless_cells, v.n_rootless);
+  a.root_cell = download(v.root_cell, v.ncells);
+  a.aggregate_id = download(v.aggregate_id, v.ncells);
+  a.propagation_depth = download(v.propagation_depth, v.ncells);
+  a.cut_volume_fraction = download(v.cut_volume_fraction, v.ncells);
+  a.pairs = download(v.pairs, 4 * v.n_pairs);
+  return a;
+}
+} // namespace extensions
 } // namespace cutfemx_amd

@@ -20,7 +20,7 @@ CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
 L_SOURCE, L_NITSCHE_RHS = 101, 102
-F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
+F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
 
 class CutOptions(C.Structure):
@@ -37,7 +37,8 @@ class RulesView(C.Structure):
 class Integral(C.Structure):
     _fields_ = [("type", C.c_int32), ("kernel", C.c_int32), ("qdegree", C.c_int32),
                 ("point_stride", C.c_int32), ("entities", C.c_void_p), ("n_entities", C.c_int64),
-                ("rules", C.c_void_p), ("point_data", C.c_void_p), ("params", C.c_double * 8)]
+                ("rules", C.c_void_p), ("point_data", C.c_void_p), ("params", C.c_double * 8),
+                ("coefficient", C.c_void_p)]
 
 
 class AggregationView(C.Structure):

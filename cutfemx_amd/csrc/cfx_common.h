@@ -354,6 +354,7 @@ struct cfx_integral_dev
   int64_t n_entities = 0;
   cfx_rules_t rules = nullptr;
   cfx::DevArray<double> point_data;
+  cfx::DevArray<double> coefficient; // dof values of a CFX_F_COEFFICIENT field
   double params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 

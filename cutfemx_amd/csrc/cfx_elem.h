@@ -152,8 +152,9 @@ __device__ __forceinline__ void cell_local_row(int kernel, const double* __restr
                                                const Geo<TDIM>& g, double h, int npts,
                                                const double* __restrict__ pts, const double* __restrict__ wts,
                                                double wscale, const double* __restrict__ pdata, int ia, int ik,
-                                               double* acc)
+                                               double* acc, const double* cw = nullptr)
 {
+  // cw: the cell's ND coefficient dof values (pack_coefficients) when a field id is CFX_F_COEFFICIENT
   constexpr int ND = Elem<TDIM, DEG>::ND;
   for (int q = 0; q < npts; ++q)
   {
@@ -265,7 +266,16 @@ __device__ __forceinline__ void cell_local_row(int kernel, const double* __restr
       }
       if (kernel == CFX_L_SOURCE)
       {
-        const double f = params[1] * field_eval<TDIM>((int)params[0], xq);
+        double f;
+        if ((int)params[0] == CFX_F_COEFFICIENT)
+        {
+          f = 0.0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j) f += N[j] * cw[j];
+          f *= params[1];
+        }
+        else
+          f = params[1] * field_eval<TDIM>((int)params[0], xq);
         acc[0] += w * f * Ni;
       }
       else if (kernel == CFX_L_NITSCHE_RHS)

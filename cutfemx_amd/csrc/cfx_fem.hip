@@ -49,6 +49,7 @@ struct AsmArgs
   const double* lift_values;
   const double* lift_x0;
   double lift_alpha;
+  const double* coeff; // dof values of a CFX_F_COEFFICIENT field (rank-1 source terms)
 };
 
 // ---------------------------------------------------------------------------
@@ -110,7 +111,18 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
 #pragma unroll
   for (int j = 0; j < (RANK == 2 ? NLOC : 1); ++j) acc[j] = 0.0;
 
-  cell_local_row<TDIM, DEG, BS, RANK>(A.kernel, A.params, A.point_stride, g, h, npts, pts, wts, wscale, pdata, ia, ik, acc);
+  double cw[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) cw[j] = 0.0;
+  if constexpr (RANK == 1)
+  {
+    if (A.coeff) // pack_coefficients (pack_form.h:32-170): the cell's coefficient dofs
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) cw[j] = A.coeff[A.dofmap[cell * ND + j]];
+    }
+  }
+  cell_local_row<TDIM, DEG, BS, RANK>(A.kernel, A.params, A.point_stride, g, h, npts, pts, wts, wscale, pdata, ia, ik, acc, cw);
 
   if (A.dump)
   {
@@ -326,6 +338,7 @@ void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, 
   const int tdim = V->mesh->tdim;
   A.kernel = I.kernel; A.qdegree = I.qdegree; A.point_stride = I.point_stride;
   for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
+  A.coeff = I.coefficient.n > 0 ? I.coefficient.p : nullptr;
   const int key = tdim * 100 + V->degree * 10 + V->bs;
   switch (key)
   {
@@ -510,6 +523,15 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     if (in.kernel == CFX_K_ELASTICITY)
       require(V->bs == V->mesh->gdim, CFX_ERR_INVALID_ARGUMENT, "elasticity needs a vector space (bs == gdim)");
     if (in.kernel == CFX_L_SOURCE) require(V->bs == 1, CFX_ERR_INVALID_ARGUMENT, "source kernel is scalar");
+    {
+      const bool wants = (in.kernel == CFX_L_SOURCE && (int)in.params[0] == CFX_F_COEFFICIENT)
+                         || (in.kernel == CFX_L_NITSCHE_RHS && (int)in.params[1] == CFX_F_COEFFICIENT);
+      require(!(in.kernel == CFX_L_NITSCHE_RHS && wants), CFX_ERR_INVALID_ARGUMENT,
+              "the Nitsche datum takes an analytic field id");
+      require(wants == (in.coefficient != nullptr), CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: `coefficient` goes with the field id CFX_F_COEFFICIENT (and only with it)");
+      if (wants) I.coefficient = to_device(in.coefficient, V->ndofs);
+    }
     I.n_entities = in.n_entities;
     const int64_t width = in.type == CFX_INTERIOR_FACET ? 4 : 1;
     I.entities = to_device(in.entities, in.n_entities * width);

@@ -231,6 +231,8 @@ struct VecArgs
   const double* point_data;
   int point_stride, kernel, qdegree;
   double params[8];
+  const int32_t* dofmap;
+  const double* coeff; // dof values of a CFX_F_COEFFICIENT source, or null
   double* out; // [n][ND]
 };
 
@@ -282,7 +284,16 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
     tabulate<TDIM, DEG>(X, N, dN);
     if (A.kernel == CFX_L_SOURCE)
     {
-      const double f = w * A.params[1] * field_eval<TDIM>((int)A.params[0], xq);
+      double fv;
+      if (A.coeff)
+      {
+        fv = 0.0;
+#pragma unroll
+        for (int j = 0; j < ND; ++j) fv += N[j] * A.coeff[A.dofmap[cell * ND + j]];
+      }
+      else
+        fv = field_eval<TDIM>((int)A.params[0], xq);
+      const double f = w * A.params[1] * fv;
 #pragma unroll
       for (int i = 0; i < ND; ++i) be[i] += f * N[i];
     }
@@ -1137,6 +1148,8 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p;
   A.kernel = I.kernel; A.qdegree = I.qdegree; A.point_stride = I.point_stride;
   for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
+  A.dofmap = V->dofmap.p;
+  A.coeff = I.coefficient.n > 0 ? I.coefficient.p : nullptr;
   A.out = out;
   if (!runtime)
   {

@@ -26,7 +26,7 @@ MASS, STIFFNESS, NITSCHE, GHOST_GRADJUMP, ELASTICITY = (_lib.K_MASS, _lib.K_STIF
                                                         _lib.K_GHOST_GRADJUMP, _lib.K_ELASTICITY)
 EXTENSION_L2 = _lib.K_EXTENSION_L2
 SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
-F_ONE, F_SINPROD, F_POISSON_RHS = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS
+F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS, _lib.F_COEFFICIENT
 
 
 @dataclass
@@ -39,6 +39,7 @@ class Integral:
     point_data: object = None                 # per-point coefficients aligned with `rules`
     params: tuple = ()
     qdegree: int = 2                          # quadrature degree on the standard entities
+    coefficient: object = None                # Function / dof values of the form's space (field id F_COEFFICIENT)
     _keep: list = field(default_factory=list, repr=False)
 
     def _cstruct(self) -> _lib.Integral:
@@ -67,8 +68,12 @@ class Integral:
             stride = 1 if pdata.ndim == 1 else int(pdata.shape[1])
             pd = _lib.as_ptr(pdata, np.float64, keep)
         params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
+        coeff = None
+        if self.coefficient is not None:
+            values = getattr(self.coefficient, "values", self.coefficient)   # a Function or its dof array
+            coeff = _lib.as_ptr(values, np.float64, keep)
         return _lib.Integral(itype, self.kernel, int(self.qdegree), stride, ent_ptr, n_ent,
-                             self.rules._h if self.rules is not None else None, pd, params)
+                             self.rules._h if self.rules is not None else None, pd, params, coeff)
 
 
 class CutForm:

@@ -69,6 +69,8 @@ extern "C" {
 #define CFX_F_ONE 0             /* 1 */
 #define CFX_F_SINPROD 1         /* prod_i sin(pi x_i) */
 #define CFX_F_POISSON_RHS 2     /* gdim pi^2 prod_i sin(pi x_i) */
+#define CFX_F_COEFFICIENT 3     /* a Function of the form's space: sum_j N_j(X_q) w[dof_j], `coefficient` = its dof values
+                                   (the packed coefficient of pack_form.h:32-170 evaluated by the kernel) */
 
 typedef struct cfx_mesh_s* cfx_mesh_t;
 typedef struct cfx_cut_s* cfx_cut_t;
@@ -121,6 +123,8 @@ typedef struct
   cfx_rules_t rules;       /* or NULL                                          */
   const double* point_data;/* per-point coefficients aligned with rules, or NULL */
   double params[8];
+  const double* coefficient; /* dof values (ndofs) of the coefficient Function when a field id is
+                                CFX_F_COEFFICIENT, else NULL; scalar spaces                  */
 } cfx_integral;
 
 typedef struct

@@ -279,6 +279,7 @@ struct Integral
   int point_stride = 0;
   std::vector<double> params{};
   int quadrature_degree = 2;
+  std::span<const double> coefficient{};       // dof values of a CFX_F_COEFFICIENT field
 };
 
 struct Form
@@ -298,6 +299,7 @@ struct Form
       r.n_entities = static_cast<std::int64_t>(in.entities.size()) / (in.type == CFX_INTERIOR_FACET ? 4 : 1);
       r.rules = in.rules ? in.rules->handle.h : nullptr;
       r.point_data = in.point_data.empty() ? nullptr : in.point_data.data();
+      r.coefficient = in.coefficient.empty() ? nullptr : in.coefficient.data();
       for (std::size_t k = 0; k < in.params.size() && k < 8; ++k) r.params[k] = in.params[k];
     }
     cfx_form_t h = nullptr;

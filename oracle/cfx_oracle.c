@@ -940,7 +940,15 @@ static void cell_kernel(const orc_mesh* m, const orc_space* V, const orc_integra
     }
     case ORC_L_SOURCE:
     {
-      const double f = I->params[1] * field_eval((int)I->params[0], gdim, xq);
+      double f;
+      if ((int)I->params[0] == ORC_F_COEFFICIENT)
+      {
+        f = 0.0;
+        for (int j = 0; j < nd; ++j) f += N[j] * I->coefficient[V->dofmap[cell * nd + j]];
+        f *= I->params[1];
+      }
+      else
+        f = I->params[1] * field_eval((int)I->params[0], gdim, xq);
       for (int i = 0; i < nd; ++i) Ae[i] += w * f * N[i];
       break;
     }

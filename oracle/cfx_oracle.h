@@ -52,7 +52,8 @@ enum {
 enum {
   ORC_F_ONE = 0,           /* 1                                    */
   ORC_F_SINPROD = 1,       /* prod_i sin(pi x_i)                   */
-  ORC_F_POISSON_RHS = 2    /* gdim pi^2 prod_i sin(pi x_i)         */
+  ORC_F_POISSON_RHS = 2,   /* gdim pi^2 prod_i sin(pi x_i)         */
+  ORC_F_COEFFICIENT = 3    /* sum_j N_j w[dof_j], w = integral.coefficient (pack_form.h:32-170) */
 };
 
 typedef struct {
@@ -75,6 +76,7 @@ typedef struct {
   const orc_rules* rules;  /* runtime rules for the cut entities, or NULL       */
   const double* point_data;/* per-point coefficients aligned with rules points  */
   double params[8];
+  const double* coefficient; /* dof values of the coefficient Function, or NULL */
 } orc_integral;
 
 typedef struct {

@@ -21,7 +21,7 @@ CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
 L_SOURCE, L_NITSCHE_RHS = 101, 102
-F_ONE, F_SINPROD, F_POISSON_RHS = 0, 1, 2
+F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
 
 class _Rules(C.Structure):
@@ -34,7 +34,7 @@ class _Integral(C.Structure):
     _fields_ = [("type", C.c_int32), ("kernel", C.c_int32), ("qdegree", C.c_int32),
                 ("point_stride", C.c_int32), ("entities", C.c_void_p),
                 ("n_entities", C.c_int64), ("rules", C.c_void_p),
-                ("point_data", C.c_void_p), ("params", C.c_double * 8)]
+                ("point_data", C.c_void_p), ("params", C.c_double * 8), ("coefficient", C.c_void_p)]
 
 
 class _Mesh(C.Structure):
@@ -248,6 +248,7 @@ class Integral:
     point_data: np.ndarray | None = None
     params: tuple = ()
     qdegree: int = 2
+    coefficient: np.ndarray | None = None
     _keep: list = field(default_factory=list)
 
     def cstruct(self):
@@ -267,7 +268,12 @@ class Integral:
             pd = _p(pdarr)
             stride = 1 if pdarr.ndim == 1 else pdarr.shape[1]
         params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
-        return _Integral(self.type, self.kernel, self.qdegree, stride, _p(ent), n_ent, rptr, pd, params)
+        co = None
+        if self.coefficient is not None:
+            carr = np.ascontiguousarray(self.coefficient, dtype=np.float64)
+            self._keep.append(carr)
+            co = _p(carr)
+        return _Integral(self.type, self.kernel, self.qdegree, stride, _p(ent), n_ent, rptr, pd, params, co)
 
 
 def _integral_array(integrals):

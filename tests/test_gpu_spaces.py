@@ -273,6 +273,35 @@ def test_update_reclassifies(oracle):
     assert np.array_equal(r.parent_map, want.parent_map) and rel_err(r.weights, want.weights) < RTOL
 
 
+@pytest.mark.parametrize("mode", ["rows", "atomic"])
+@pytest.mark.parametrize("tdim,n,degree", [(3, 6, 1), (2, 10, 2)])
+def test_source_term_from_a_coefficient_function(oracle, monkeypatch, mode, tdim, n, degree):
+    # a10 (pack_form.h:32-170): f given as a Function of the space instead of an expression
+    import cutfemx_amd as cfx
+    if mode == "atomic":
+        monkeypatch.setenv("CFX_ASSEMBLY", "atomic")
+    s = setup(oracle, tdim, n, degree, 1)
+    O, om, dom, cd, oV = s["O"], s["om"], s["dom"], s["cd"], s["oV"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 4)
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    w = np.random.default_rng(3).standard_normal(oV.ndofs)
+    q = 2 * degree
+    oL = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=ovol, params=(O.F_COEFFICIENT, 1.5), qdegree=q,
+                     coefficient=w)]
+    gL = [cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, rules=vol, params=(cfx.fem.F_COEFFICIENT, 1.5), qdegree=q,
+                           coefficient=cfx.Function(s["V"], w))]
+    b = compare_forms(s, oL, gL, rank=1)
+    # (f, v) with f in the space is the mass matrix applied to its dof values
+    M = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(cfx.fem.MASS, cells=inside, rules=vol, qdegree=q)],
+                                             s["V"])).to_scipy()
+    assert rel_err(b, 1.5 * (M @ w)) < 1e-11
+    with pytest.raises(ValueError):      # the field id and the array go together
+        cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, params=(cfx.fem.F_COEFFICIENT, 1.0))], s["V"])
+    with pytest.raises(ValueError):
+        cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, params=(cfx.fem.F_ONE, 1.0), coefficient=w)], s["V"])
+
+
 def test_named_level_sets_in_selectors(oracle):
     # python/tests/test_cut_api.py:713-773: real Function names are the selector names, frozen at cut()
     import cutfemx_amd as cfx

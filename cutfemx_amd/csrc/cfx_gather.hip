@@ -1060,6 +1060,150 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   }
 }
 
+// ---------------------------------------------------------------------------
+// stage 2, bilinear forms on BLOCK spaces (bs = gdim: elasticity, BASELINE config 5).  A group
+// of G lanes owns one matrix row R = bs * dof + component; the CSR row is bs-blocked (column
+// list = scalar columns expanded by bs), so the group searches scalar columns and adds bs
+// values per column.  Items: marked incident cells of the dof -- the local row (dof, component)
+// of an uncut cell is recomputed inline (a staged 30 x 30 tensor per uncut P2 cell would be
+// 7 KB), the rows of cut cells come from the stage-1 rule tensors.  No facet items: forms with
+// facet integrals on block spaces keep the entity-parallel path.
+// ---------------------------------------------------------------------------
+template <int TDIM, int DEG, int BS, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave, 2) assemble_rows_block_kernel(RowArgs A)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  constexpr int NLOC = ND * BS;
+  constexpr int RPW = kWave / G;
+  __shared__ int32_t s_col[RPW][CAP + 1];
+  __shared__ double s_val[RPW][CAP * BS + 1];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n_active * BS;
+  const int64_t rr = live ? ri / BS : 0;
+  const int kc = live ? (int)(ri - rr * BS) : 0;
+  const int64_t r = live ? A.active_rows[rr] : 0;
+  const int64_t R = r * BS + kc;
+  const int64_t rb = live ? A.indptr[R] : 0;
+  int lene = live ? (int)(A.indptr[R + 1] - rb) : 0;
+  int len = lene / BS;
+  if (len > CAP) { *A.error = 2; len = 0; lene = 0; }
+  for (int k = gl; k < len; k += G) s_col[grp][k] = A.indices[rb + (int64_t)k * BS] / BS;
+  for (int k = gl; k < lene; k += G) s_val[grp][k] = 0.0;
+  __syncthreads();
+  const bool cells = live && A.cellmark != nullptr && len > 0;
+  const int64_t cb = cells ? A.d2c_off[r] : 0;
+  const int nc = cells ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  const bool row_bc = live && A.bc0 && A.bc0[R];
+  auto find_slot = [&](int32_t col) -> int
+  {
+    int lo = 0, hi = len;
+    while (lo < hi)
+    {
+      const int mid = (lo + hi) >> 1;
+      if (s_col[grp][mid] < col) lo = mid + 1; else hi = mid;
+    }
+    if (lo < len && s_col[grp][lo] == col) return lo;
+    *A.error = 1;
+    return -1;
+  };
+  for (int base = 0;; base += G)
+  {
+    if (__ballot(base + gl < nc) == 0) break;
+    const int t = base + gl;
+    const int64_t c = t < nc ? (int64_t)A.d2c[cb + t] : -1;
+    const uint8_t mark = c >= 0 ? (uint8_t)(A.cellmark[c] & A.mark_mask) : (uint8_t)0;
+    double acc[NLOC];
+    int csl[ND];
+    int32_t cd[ND];
+#pragma unroll
+    for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) { csl[j] = -1; cd[j] = 0; }
+    if (mark)
+    {
+      int lr = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        cd[j] = A.dofmap[c * ND + j];
+        lr = (cd[j] == (int32_t)r) ? j : lr;
+      }
+#pragma unroll
+      for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[j]);
+      for (int i = 0; i < A.n_cell; ++i)
+      {
+        const RowIntegral& I = A.cell[i];
+        if (mark & (1u << i))
+        {
+          if (I.std_inline)
+          {
+            Geo<TDIM> g;
+            load_cell<TDIM>(A.x, A.conn, c, g);
+            jacobian<TDIM>(g);
+            int npts;
+            const double* wts;
+            const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+            cell_local_row<TDIM, DEG, BS, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts, fabs(g.detJ),
+                                             nullptr, lr, kc, acc);
+          }
+          else
+          {
+            const int64_t e = entity_index(I.std_bits, I.std_rank, c);
+            const double* T = I.std_tensors + (e * NLOC + lr * BS + kc) * NLOC;
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) acc[j] += T[j];
+          }
+        }
+        if (mark & (16u << i))
+        {
+          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+          {
+            const double* T = I.rule_tensors + (e * NLOC + lr * BS + kc) * NLOC;
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) acc[j] += T[j];
+          }
+        }
+      }
+      // zero BC rows / columns (assemble_matrix_impl.h:151-185)
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+          if (row_bc || (A.bc1 != nullptr && A.bc1[(int64_t)cd[j] * BS + b] != 0)) acc[j * BS + b] = 0.0;
+    }
+    if constexpr (ORDERED)
+    {
+      for (int turn = 0; turn < G; ++turn) // one lane of each group at a time: item order
+      {
+        if (gl == turn)
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            if (csl[j] >= 0)
+            {
+#pragma unroll
+              for (int b = 0; b < BS; ++b) s_val[grp][csl[j] * BS + b] += acc[j * BS + b];
+            }
+        }
+        __syncthreads();
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        if (csl[j] >= 0)
+        {
+#pragma unroll
+          for (int b = 0; b < BS; ++b) atomicAdd(&s_val[grp][csl[j] * BS + b], acc[j * BS + b]);
+        }
+    }
+  }
+  __syncthreads();
+  for (int k = gl; k < lene; k += G) A.values[rb + k] += s_val[grp][k];
+}
+
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
 template <int TDIM, int DEG, int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
@@ -1166,10 +1310,10 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
 }
 
 // stage 1 + RowArgs for a form
-template <int TDIM, int DEG>
+template <int TDIM, int DEG, int BS = 1>
 RowArgs prepare(cfx_form_s* a, Stage1& st)
 {
-  constexpr int ND = Elem<TDIM, DEG>::ND;
+  constexpr int ND = Elem<TDIM, DEG>::ND * BS; // local tensor dimension (scalar dofs x block size)
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
   RowArgs A{};
@@ -1199,7 +1343,9 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     const char* inl = getenv("CFX_STD_INLINE");
     // (degree 2: staging 100 doubles per uncut cell would be 38 GB at config 4 -- the row of the
     // local tensor is recomputed per (row, cell) item instead, 4-14 quadrature points)
-    const bool inline_ok = DEG == 1 ? I.kernel == CFX_K_STIFFNESS : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS);
+    const bool inline_ok = BS > 1 ? (I.kernel == CFX_K_ELASTICITY || I.kernel == CFX_K_MASS || I.kernel == CFX_K_STIFFNESS)
+                                  : (DEG == 1 ? I.kernel == CFX_K_STIFFNESS
+                                              : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS));
     R.std_inline = (a->rank == 2 && inline_ok && !(inl && inl[0] == '0')) ? 1 : 0;
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
@@ -1208,7 +1354,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       st.buffers.emplace_back(I.n_entities * tsize);
       R.std_tensors = st.buffers.back().p;
       if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
-      else vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p);
+      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p);
     }
     if (I.rules && I.rules->nr > 0)
     {
@@ -1217,7 +1363,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       st.buffers.emplace_back(I.rules->nr * tsize);
       R.rule_tensors = st.buffers.back().p;
       if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
-      else vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
+      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
     }
   }
   bool has_facets = false;
@@ -1373,6 +1519,35 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   return read_scalar(err.p);
 }
 
+template <int TDIM, int DEG, int BS>
+int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+{
+  Stage1 st;
+  RowArgs A = prepare<TDIM, DEG, BS>(a, st);
+  A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
+  A.mark_mask = 0xFFu;
+  DevArray<int> err(1);
+  err.zero();
+  A.error = err.p;
+  if (A.n_active > 0)
+  {
+    const bool det = deterministic();
+    const int mr = P->max_row_len; // scalar columns per row
+#define CFX_BLOCK(GG, CAPP)                                                                                          \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    const dim3 grid = row_grid((A.n_active * BS + (kWave / GG) - 1) / (kWave / GG));                                 \
+    if (det) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true>, grid, dim3(kWave), 0, A);   \
+    else launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false>, grid, dim3(kWave), 0, A);     \
+  } while (0)
+    if (mr <= 32) CFX_BLOCK(8, 32);
+    else if (mr <= 128) CFX_BLOCK(16, 128);
+    else CFX_BLOCK(32, 256);
+#undef CFX_BLOCK
+  }
+  return read_scalar(err.p);
+}
+
 template <int TDIM, int DEG>
 void run_vector(cfx_form_s* L, double* b)
 {
@@ -1398,9 +1573,24 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
 {
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
-  if (!plan.usable || V->degree > 2 || V->bs != 1 || P->max_row_len > 512) return false;
+  if (!plan.usable || V->degree > 2 || P->max_row_len > 512) return false;
   int err = 0;
-  if (V->degree == 1)
+  if (V->bs != 1)
+  {
+    // block spaces: bs = gdim, cell integrals only.  Measured on config 5's rank share (3.7 M P2
+    // cells, 30 x 30 tensors): 181 ms against 149 ms of the entity-parallel atomic kernels -- both
+    // are bound by the per-(cell, row) arithmetic of the elasticity row, not by the scatter -- so
+    // the gather form is used where its reproducibility is asked for (CFX_DETERMINISTIC=1) or on
+    // request (CFX_BLOCK_GATHER=1).
+    const char* bg = getenv("CFX_BLOCK_GATHER");
+    if (!(deterministic() || (bg && bg[0] == '1'))) return false;
+    if (V->bs != V->mesh->tdim || plan.nfacets > 0 || P->max_row_len > 256) return false;
+    if (V->mesh->tdim == 2)
+      err = V->degree == 1 ? run_matrix_block<2, 1, 2>(a, P, bc0, bc1, values) : run_matrix_block<2, 2, 2>(a, P, bc0, bc1, values);
+    else
+      err = V->degree == 1 ? run_matrix_block<3, 1, 3>(a, P, bc0, bc1, values) : run_matrix_block<3, 2, 3>(a, P, bc0, bc1, values);
+  }
+  else if (V->degree == 1)
     err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values) : run_matrix<3, 1>(a, P, bc0, bc1, values);
   else
     err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values) : run_matrix<3, 2>(a, P, bc0, bc1, values);

@@ -708,7 +708,6 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
   if (read_scalar(flag.p)) P.usable = false;
-  if (V->bs != 1) P.usable = false;
   P.built = true;
   return P;
 }

@@ -1,0 +1,25 @@
+"""Timing of one rank's share of BASELINE config 5 (256^3, P2 vector elasticity, sphere): slab of 32 layers."""
+import sys, time
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import torch
+import cutfemx_amd as cfx
+from cutfemx_amd import fem
+from test_gpu_fullsize import level_set
+dev = torch.device('cuda', 0)
+n, z0, nz = 256, 89, 32
+mesh = cfx.Mesh.create_slab(n, z0, nz)
+Vphi = cfx.FunctionSpace(mesh, 1)
+cd = cfx.cut(cfx.Function(Vphi, level_set('sphere', n, z0, nz, dev)))
+dm, nd = cfx.box_lagrange2_dofmap(mesh, n, dev)
+V = cfx.FunctionSpace(mesh, 2, dofmap=dm, ndofs=nd, bs=3)
+inside = cfx.locate_entities_device(cd, "phi<0")
+vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+ga = [fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(1.0e3, 0.3), qdegree=2)]
+def T(fn):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize(); return r, round(1e3 * (time.perf_counter() - t0), 2)
+for it in range(3):
+    a = fem.form(ga, V)
+    A, ts = T(lambda: fem.create_matrix(a))
+    _, ta = T(lambda: fem.assemble_matrix(a, A=A))
+    print('cfg5 share: inside', inside[1], 'nnz', A.nnz, 'sparsity ms', ts, 'assemble_matrix ms', ta, flush=True)
+    del A, a

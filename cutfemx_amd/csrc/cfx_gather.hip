@@ -1347,6 +1347,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
                                   : (DEG == 1 ? I.kernel == CFX_K_STIFFNESS
                                               : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS));
     R.std_inline = (a->rank == 2 && inline_ok && !(inl && inl[0] == '0')) ? 1 : 0;
+    if (BS > 1 && !(inl && inl[0] == '1')) R.std_inline = 0; // block spaces stage their uncut tensors (see assemble_matrix_rows)
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
     if (!R.std_inline && I.n_entities > 0)
@@ -1577,13 +1578,19 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
   int err = 0;
   if (V->bs != 1)
   {
-    // block spaces: bs = gdim, cell integrals only.  Measured on config 5's rank share (3.7 M P2
-    // cells, 30 x 30 tensors): 181 ms against 149 ms of the entity-parallel atomic kernels -- both
-    // are bound by the per-(cell, row) arithmetic of the elasticity row, not by the scatter -- so
-    // the gather form is used where its reproducibility is asked for (CFX_DETERMINISTIC=1) or on
-    // request (CFX_BLOCK_GATHER=1).
-    const char* bg = getenv("CFX_BLOCK_GATHER");
-    if (!(deterministic() || (bg && bg[0] == '1'))) return false;
+    // block spaces: bs = gdim, cell integrals only.  The local tensors of the uncut cells are
+    // staged (30 x 30 doubles per P2 elasticity cell): recomputing a row per (cell, row) item costs
+    // 30x the arithmetic (measured on config 5's rank share, 3.7 M cells: 181 ms inline, 149 ms
+    // entity-parallel atomics, 66 ms staged + gathered).  Needs the staging to fit in HBM.
+    {
+      const int nloc = V->ndofs_cell * V->bs;
+      size_t need = 0, free_b = 0, total_b = 0;
+      for (const auto& I : a->integrals)
+        need += (size_t)(I.n_entities + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
+      CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+      const char* bg = getenv("CFX_BLOCK_GATHER");
+      if ((bg && bg[0] == '0') || need > free_b / 2) return false;
+    }
     if (V->bs != V->mesh->tdim || plan.nfacets > 0 || P->max_row_len > 256) return false;
     if (V->mesh->tdim == 2)
       err = V->degree == 1 ? run_matrix_block<2, 1, 2>(a, P, bc0, bc1, values) : run_matrix_block<2, 2, 2>(a, P, bc0, bc1, values);

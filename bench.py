@@ -363,6 +363,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: cutfemx_amd has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 as `python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...`")
     # rehearsal on a one-GPU box: CFX_REHEARSE=1 puts every rank on cuda:0 and uses gloo
     # (RCCL cannot place two ranks on one device); never set on the real multi-GPU run
     rehearse = os.environ.get("CFX_REHEARSE") == "1"

@@ -22,4 +22,15 @@ for it in range(3):
     A, ts = T(lambda: fem.create_matrix(a))
     _, ta = T(lambda: fem.assemble_matrix(a, A=A))
     print('cfg5 share: inside', inside[1], 'nnz', A.nnz, 'sparsity ms', ts, 'assemble_matrix ms', ta, flush=True)
+    if it == 2:
+        import ctypes as C
+        from cutfemx_amd import _lib
+        l = _lib.lib(); _lib.check(l.cfx_profile_enable(1)); _lib.check(l.cfx_profile_reset())
+        fem.assemble_matrix(a, A=A)
+        out = {}
+        for i in range(l.cfx_profile_count()):
+            name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+            _lib.check(l.cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            if cnt.value: out[name.value.decode()] = round(ms.value, 2)
+        print(' kernels', dict(sorted(out.items(), key=lambda kv: -kv[1])[:6]))
     del A, a

@@ -713,36 +713,52 @@ __device__ __forceinline__ bool facet_neighbour(const int32_t* __restrict__ conn
   return false;
 }
 
-template <int TDIM, bool WRITE>
-__global__ void __launch_bounds__(kBlock) ghost_facets_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
-                                                              const int32_t* __restrict__ conn,
-                                                              const int64_t* __restrict__ v2c_off,
-                                                              const int32_t* __restrict__ v2c,
-                                                              const int8_t* __restrict__ domain, SelectorPred sel,
-                                                              int32_t* __restrict__ counts,
-                                                              const int64_t* __restrict__ offs, int32_t* __restrict__ rows)
+// One thread per (cut cell, local facet): the neighbour search (a scan of the vertex->cells list of a
+// facet vertex) runs once, its result is parked in `cand` and packed in cell / facet order afterwards.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
+                                                                   const int32_t* __restrict__ conn,
+                                                                   const int64_t* __restrict__ v2c_off,
+                                                                   const int32_t* __restrict__ v2c,
+                                                                   const int8_t* __restrict__ domain, SelectorPred sel,
+                                                                   int32_t* __restrict__ counts, int32_t* __restrict__ cand)
 {
+  constexpr int NV = TDIM + 1;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= ncut * NV) return;
+  const int64_t i = t / NV;
+  const int lf = (int)(t - i * NV);
+  const int64_t c = cut_cells[i];
+  int4 r = make_int4(-1, -1, -1, -1);
+  int32_t nb;
+  int nlf;
+  if (facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf))
+  {
+    const bool nb_cut = domain[nb] == CFX_INTERSECTED;
+    if ((nb_cut || sel(nb)) && !(nb_cut && nb < c))
+    {
+      r = (c < nb) ? make_int4((int)c, lf, nb, nlf) : make_int4(nb, nlf, (int)c, lf);
+      atomicAdd(&counts[i], 1);
+    }
+  }
+  *reinterpret_cast<int4*>(cand + 4 * t) = r;
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) ghost_facets_pack_kernel(int64_t ncut, const int32_t* __restrict__ cand,
+                                                                   const int64_t* __restrict__ offs,
+                                                                   int32_t* __restrict__ rows)
+{
+  constexpr int NV = TDIM + 1;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncut) return;
-  const int64_t c = cut_cells[i];
-  int n = 0;
-  int64_t o = WRITE ? offs[i] : 0;
-  for (int lf = 0; lf <= TDIM; ++lf)
+  int64_t o = offs[i];
+#pragma unroll
+  for (int lf = 0; lf < NV; ++lf)
   {
-    int32_t nb; int nlf;
-    if (!facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf)) continue;
-    const bool nb_cut = domain[nb] == CFX_INTERSECTED;
-    if (!(nb_cut || sel(nb))) continue;
-    if (nb_cut && nb < c) continue;
-    if (WRITE)
-    {
-      int4 r = (c < nb) ? make_int4((int)c, lf, nb, nlf) : make_int4(nb, nlf, (int)c, lf);
-      *reinterpret_cast<int4*>(rows + 4 * o) = r;
-      ++o;
-    }
-    ++n;
+    const int4 r = *reinterpret_cast<const int4*>(cand + 4 * (i * NV + lf));
+    if (r.x >= 0) { *reinterpret_cast<int4*>(rows + 4 * o) = r; ++o; }
   }
-  if (!WRITE) counts[i] = n;
 }
 
 // ---------------------------------------------------------------------------
@@ -1236,19 +1252,19 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   const DevArray<int32_t>& cutc = locate(cut, "phi=0");
   const int64_t ncut = cutc.n;
   const Adjacency& adj = mesh->vertex_cells();
-  DevArray<int32_t> counts(ncut);
+  DevArray<int32_t> counts(ncut), cand(ncut * (int64_t)(mesh->tdim + 1) * 4);
   DevArray<int64_t> offs(ncut + 1);
   int64_t total = 0;
   if (ncut > 0)
   {
+    counts.zero();
+    const int64_t nthreads = ncut * (mesh->tdim + 1);
     if (mesh->tdim == 2)
-      launch("ghost_facets_count", ghost_facets_kernel<2, false>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, (const int64_t*)nullptr,
-             (int32_t*)nullptr);
+      launch("ghost_facets_find", ghost_facets_find_kernel<2>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, cand.p);
     else
-      launch("ghost_facets_count", ghost_facets_kernel<3, false>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, (const int64_t*)nullptr,
-             (int32_t*)nullptr);
+      launch("ghost_facets_find", ghost_facets_find_kernel<3>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, cand.p);
     exclusive_scan(counts.p, offs.p, ncut);
     total = read_scalar(offs.p + ncut);
   }
@@ -1257,12 +1273,10 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   if (total > 0)
   {
     if (mesh->tdim == 2)
-      launch("ghost_facets_write", ghost_facets_kernel<2, true>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, (int32_t*)nullptr, offs.p,
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cand.p, offs.p,
              grows.p);
     else
-      launch("ghost_facets_write", ghost_facets_kernel<3, true>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, (int32_t*)nullptr, offs.p,
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cand.p, offs.p,
              grows.p);
   }
   *rows = grows.p;

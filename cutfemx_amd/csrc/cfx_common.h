@@ -370,6 +370,9 @@ struct cfx_row_plan
   int64_t n_active_rows = 0;
   cfx::DevArray<int32_t> special_rows; // active rows next to the interface: touched by a runtime-rule cell or a facet
   int64_t n_special_rows = 0;
+  cfx::DevArray<uint8_t> special_mark; // [ndofs] 1 on the special rows
+  cfx::DevArray<int32_t> special_pos;  // [ndofs] position of a special row in special_rows (undefined elsewhere);
+                                       // the dof->facets incidence (d2f_offsets) is indexed by that position
   cfx::DevArray<int32_t> plain_rows;   // the other active rows: uncut-cell items only
   int64_t n_plain_rows = 0;
   uint64_t serial = 0;                 // identity of this plan (a pattern remembers the plan it was built from)

@@ -90,7 +90,9 @@ struct RowArgs
   const int64_t* d2c_off;
   const int32_t* d2c;
   const uint8_t* cellmark;
-  const int64_t* d2f_off;
+  const int64_t* d2f_off;      // indexed by special_pos[r] where special_mark[r]
+  const uint8_t* special_mark;
+  const int32_t* special_pos;
   const int32_t* d2f;
   const int32_t* facet_rows;
   const double* facet_tensors; // [nfacets][(2ND)^2]
@@ -369,8 +371,9 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
   const int64_t cb = cells ? A.d2c_off[r] : 0;
   const int nc = cells ? (int)(A.d2c_off[r + 1] - cb) : 0;
   const bool facets = live && A.d2f_off != nullptr && (A.mark_mask & 0xF0u) != 0 && !(A.debug & 8);
-  const int64_t fb = facets ? A.d2f_off[r] : 0;
-  const int nf = facets ? (int)(A.d2f_off[r + 1] - fb) : 0;
+  const int64_t fpos = (facets && A.special_mark[r]) ? (int64_t)A.special_pos[r] : -1; // incidence is per special row
+  const int64_t fb = fpos >= 0 ? A.d2f_off[fpos] : 0;
+  const int nf = fpos >= 0 ? (int)(A.d2f_off[fpos + 1] - fb) : 0;
   const bool row_bc = live && A.bc0 && A.bc0[r];
   // every cell item adds to the diagonal: kept in a register per lane and reduced over the
   // group once, instead of ~24 LDS atomics on one address per row
@@ -1377,6 +1380,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
   if (has_facets && plan.nfacets > 0)
   {
     A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
+    A.special_mark = plan.special_mark.p; A.special_pos = plan.special_pos.p;
     st.buffers.emplace_back(plan.nfacets * (int64_t)(4 * ND * ND));
     A.facet_tensors = st.buffers.back().p;
     int64_t o = 0;

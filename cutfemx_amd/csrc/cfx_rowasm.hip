@@ -121,8 +121,16 @@ __global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ 
   if (i + 1 < n && (a[i] > a[i + 1] || (strict && a[i] == a[i + 1]))) *flag = 1;
 }
 
+// (counts / offsets / cursors are indexed by the dof's position in the special-row list: the
+// incidence only exists next to the interface, a scan over all dofs would cost more than the rest)
+__global__ void plan_scatter_pos_kernel(int64_t n, const int32_t* __restrict__ rows, int32_t* __restrict__ pos)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) pos[rows[i]] = (int32_t)i;
+}
+
 __global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                       int nd, int32_t* counts)
+                                       int nd, const int32_t* __restrict__ pos, int32_t* counts)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nf * 2 * nd) return;
@@ -137,11 +145,12 @@ __global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ r
     for (int j = 0; j < nd; ++j)
       if (dofmap[c0 * nd + j] == dof) return;
   }
-  atomicAdd(&counts[dof], 1);
+  atomicAdd(&counts[pos[dof]], 1);
 }
 
 __global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                      int nd, const int64_t* __restrict__ offs, int32_t* cursor, int32_t* facets)
+                                      int nd, const int32_t* __restrict__ pos, const int64_t* __restrict__ offs,
+                                      int32_t* cursor, int32_t* facets)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nf * 2 * nd) return;
@@ -155,17 +164,16 @@ __global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ ro
     for (int j = 0; j < nd; ++j)
       if (dofmap[c0 * nd + j] == dof) return;
   }
-  facets[offs[dof] + atomicAdd(&cursor[dof], 1)] = (int32_t)f;
+  const int32_t q = pos[dof];
+  facets[offs[q] + atomicAdd(&cursor[q], 1)] = (int32_t)f;
 }
 
 // sort each listed dof's facet list so the gather order is reproducible
-__global__ void seg_sort_kernel(int64_t nrows, const int32_t* __restrict__ rows, const int64_t* __restrict__ offsets,
-                                int32_t* vals)
+__global__ void seg_sort_kernel(int64_t nseg, const int64_t* __restrict__ offsets, int32_t* vals)
 {
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i0 >= nrows) return;
-  const int64_t it = rows[i0];
-  const int64_t b = offsets[it], e = offsets[it + 1];
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nseg) return;
+  const int64_t b = offsets[r], e = offsets[r + 1];
   for (int64_t i = b + 1; i < e; ++i)
   {
     const int32_t v = vals[i];
@@ -204,6 +212,8 @@ struct PatArgs
   const int64_t* indptr; // wide path, second pass: write rows directly
   int32_t* indices;
   int all_cells;    // stencil build: every incident cell counts (cellmark is null), active_rows null = all rows
+  const uint8_t* special_mark; // dof->facets incidence: d2f_off is indexed by special_pos[r] where special_mark[r]
+  const int32_t* special_pos;
   int32_t* len;     // [n_active]
   int32_t* counts;  // [ndofs*bs] expanded row lengths
   int* overflow;
@@ -313,10 +323,11 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         }
       }
     }
-    if (P.d2f_off && P.nd == 4)
+    const int64_t fpos = (P.d2f_off && P.special_mark[r]) ? (int64_t)P.special_pos[r] : -1;
+    if (fpos >= 0 && P.nd == 4)
     {
       // P1: one facet per lane (11 loads for 8 candidates; the triple form below costs 24)
-      for (int64_t k = P.d2f_off[r] + gl; k < P.d2f_off[r + 1]; k += G)
+      for (int64_t k = P.d2f_off[fpos] + gl; k < P.d2f_off[fpos + 1]; k += G)
       {
         const int64_t f = P.d2f[k];
         for (int s = 0; s < 2; ++s)
@@ -330,12 +341,12 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         }
       }
     }
-    else if (P.d2f_off)
+    else if (fpos >= 0)
     {
       // (facet, side, local dof) triples spread over the lanes
-      const int64_t fb = P.d2f_off[r];
+      const int64_t fb = P.d2f_off[fpos];
       const int per = 2 * P.nd;
-      const int ntr = (int)(P.d2f_off[r + 1] - fb) * per;
+      const int ntr = (int)(P.d2f_off[fpos + 1] - fb) * per;
       for (int t = gl; t < ntr; t += G)
       {
         const int q = t / per, u = t - q * per;
@@ -663,17 +674,6 @@ cfx_row_plan& row_plan(cfx_form_s* a)
              I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
       o += I.n_entities;
     }
-    DevArray<int32_t> fcount(V->ndofs);
-    fcount.zero();
-    launch("facet_dof_count", facet_dof_count_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
-           P.facet_rows.p, V->dofmap.p, nd, fcount.p);
-    P.d2f_offsets.alloc(V->ndofs + 1);
-    exclusive_scan(fcount.p, P.d2f_offsets.p, V->ndofs);
-    const int64_t total = read_scalar(P.d2f_offsets.p + V->ndofs);
-    P.d2f.alloc(total);
-    fcount.zero();
-    launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
-           P.facet_rows.p, V->dofmap.p, nd, P.d2f_offsets.p, fcount.p, P.d2f.p);
   }
   P.n_active_rows = compact_bytes("plan_active_rows", V->ndofs, P.rowmark.p, ByteNonZero{}, P.active_rows);
   {
@@ -683,6 +683,25 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     P.n_special_rows = compact_bytes("plan_special_rows", V->ndofs, cls.p, ByteIs{2}, P.special_rows);
     if (space_stencil(V).usable)
       P.n_plain_rows = compact_bytes("plan_plain_rows", V->ndofs, cls.p, ByteIs{1}, P.plain_rows);
+  }
+  P.special_mark = std::move(special);
+  if (P.nfacets > 0)
+  {
+    // dof -> facets incidence of the rows that have facets (all of them special)
+    P.special_pos.alloc(V->ndofs);
+    launch("plan_scatter_pos", plan_scatter_pos_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
+           P.special_rows.p, P.special_pos.p);
+    DevArray<int32_t> fcount(P.n_special_rows);
+    fcount.zero();
+    launch("facet_dof_count", facet_dof_count_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
+           P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
+    P.d2f_offsets.alloc(P.n_special_rows + 1);
+    exclusive_scan(fcount.p, P.d2f_offsets.p, P.n_special_rows);
+    const int64_t total = read_scalar(P.d2f_offsets.p + P.n_special_rows);
+    P.d2f.alloc(total);
+    fcount.zero();
+    launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
+           P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
   }
   // rank structure of every uncut entity list: entity index of cell c =
   // rank[c/64] + popcount(bits[c/64] below c), two cached loads instead of a
@@ -703,8 +722,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   if (P.nfacets > 0 && det && det[0] == '1')
   {
     // reproducible gather order (the lists were filled through an atomic cursor)
-    launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_active_rows), dim3(kBlock), 0, P.n_active_rows,
-           P.active_rows.p, P.d2f_offsets.p, P.d2f.p);
+    launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
+           P.d2f_offsets.p, P.d2f.p);
   }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
   if (read_scalar(flag.p)) P.usable = false;
@@ -770,6 +789,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   if (plan.nfacets > 0)
   {
     S.d2f_off = plan.d2f_offsets.p; S.d2f = plan.d2f.p; S.facet_rows = plan.facet_rows.p;
+    S.special_mark = plan.special_mark.p; S.special_pos = plan.special_pos.p;
   }
   P->nrows = V->ndofs * V->bs;
   DevArray<int32_t> counts(P->nrows), len(n_h), tmp;

@@ -52,3 +52,21 @@ def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     scale = max(np.max(np.abs(b)) if b.size else 0.0, 1e-300)
     return float(np.max(np.abs(a - b)) / scale) if a.size else 0.0
+
+
+def scrambled_mesh(O, tdim: int, n: int, seed: int = 11):
+    """The n^tdim Kuhn box mesh made unstructured: interior vertices moved by up to 0.2 h,
+    vertices and cells renumbered at random, local vertex order of every cell shuffled (both
+    orientations occur).  Nothing of the generator's numbering survives."""
+    rng = np.random.default_rng(seed)
+    om = O.mesh_box(tdim, n)
+    x = om.x.copy()
+    interior = np.all((x[:, :tdim] > 1e-12) & (x[:, :tdim] < 1.0 - 1e-12), axis=1)
+    x[interior, :tdim] += (0.2 / n) * rng.uniform(-1.0, 1.0, size=(int(interior.sum()), tdim))
+    p = rng.permutation(om.nnodes)                 # new id of old vertex v: p[v]
+    xn = np.empty_like(x)
+    xn[p] = x
+    conn = p[om.conn]
+    conn = conn[rng.permutation(om.ncells)]
+    conn = rng.permuted(conn, axis=1)
+    return O.Mesh(tdim, xn, conn.astype(np.int32))

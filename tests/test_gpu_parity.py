@@ -4,13 +4,14 @@ within 1e-12 relative (north_star tolerance)."""
 import numpy as np
 import pytest
 
-from helpers import level_set_values, oracle_poisson, rel_err
+from helpers import level_set_values, oracle_poisson, rel_err, scrambled_mesh
 
 pytestmark = pytest.mark.gpu
 
 RTOL = 1e-12
 
-CASES = [(2, 16, "sphere"), (2, 64, "sphere"), (3, 8, "sphere"), (3, 20, "sphere"), (3, 12, "gyroid")]
+CASES = [(2, 16, "sphere"), (2, 64, "sphere"), (3, 8, "sphere"), (3, 20, "sphere"), (3, 12, "gyroid"),
+         (2, 24, "sphere-scrambled"), (3, 10, "sphere-scrambled"), (3, 10, "gyroid-scrambled")]
 
 
 @pytest.fixture(scope="module", params=CASES, ids=lambda c: f"{c[0]}d-n{c[1]}-{c[2]}")
@@ -18,7 +19,9 @@ def case(request, oracle):
     import cutfemx_amd as cfx
     tdim, n, kind = request.param
     O = oracle
-    om = O.mesh_box(tdim, n)
+    scrambled = kind.endswith("-scrambled")
+    kind = kind.replace("-scrambled", "")
+    om = scrambled_mesh(O, tdim, n) if scrambled else O.mesh_box(tdim, n)   # unstructured numbering + geometry
     phi = level_set_values(om.x, tdim, kind)
     ref = oracle_poisson(O, om, phi)
     mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
@@ -27,11 +30,13 @@ def case(request, oracle):
     cd = cfx.cut(f)
     from cutfemx_amd import poisson
     sysm = poisson.build_forms(V, cd)
-    return dict(O=O, om=om, phi=phi, ref=ref, mesh=mesh, V=V, cd=cd, sys=sysm, tdim=tdim)
+    return dict(O=O, om=om, phi=phi, ref=ref, mesh=mesh, V=V, cd=cd, sys=sysm, tdim=tdim, scrambled=scrambled)
 
 
 def test_box_mesh_generator(case):
     import cutfemx_amd as cfx
+    if case["scrambled"]:
+        pytest.skip("not the generator's mesh")
     tdim = case["tdim"]
     n = round((case["om"].nnodes) ** (1.0 / tdim)) - 1
     m = cfx.Mesh.create_box(tdim, n)

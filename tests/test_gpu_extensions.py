@@ -3,7 +3,7 @@
 import numpy as np
 import pytest
 
-from helpers import level_set_values, rel_err
+from helpers import level_set_values, rel_err, scrambled_mesh
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -12,8 +12,8 @@ RTOL = 1e-12
 def _setup(oracle, tdim, n, degree=1, kind="sphere"):
     import cutfemx_amd as cfx
     O = oracle
-    om = O.mesh_box(tdim, n)
-    phi = level_set_values(om.x, tdim, kind)
+    om = scrambled_mesh(O, tdim, n) if kind.endswith("-scrambled") else O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim, kind.replace("-scrambled", ""))
     dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, degree)
     mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
     V = cfx.FunctionSpace(mesh, degree, dofmap=None if degree == 1 else dofmap, ndofs=ndofs)
@@ -76,7 +76,8 @@ def _compare_aggregation(a, o):
     assert rel_err(a.cut_volume_fraction, o["cut_volume_fraction"]) < RTOL
 
 
-@pytest.mark.parametrize("tdim,n,kind", [(2, 16, "sphere"), (3, 8, "sphere"), (3, 10, "gyroid"), (2, 24, "gyroid")])
+@pytest.mark.parametrize("tdim,n,kind", [(2, 16, "sphere"), (3, 8, "sphere"), (3, 10, "gyroid"), (2, 24, "gyroid"),
+                                         (3, 8, "sphere-scrambled"), (2, 20, "gyroid-scrambled")])
 @pytest.mark.parametrize("threshold,policy", [(0.3, "interior_or_well_cut"), (1.0, "interior_or_well_cut"),
                                               (0.0, "interior_only")])
 def test_cell_aggregation_matches_sequential_oracle(oracle, tdim, n, kind, threshold, policy):

@@ -63,7 +63,7 @@ SYMBOLS = [
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
-    "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
+    "cfx_cut_restrict", "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
     "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",

@@ -324,6 +324,7 @@ struct cfx_cut_s
   cfx::DevArray<int32_t> ls_dofmap;
   std::vector<cfx::DevArray<double>> ls_values;
   cfx::DevArray<int8_t> domain; // [nls*ncells]
+  cfx::DevArray<uint8_t> host_mask; // cut(level_set, cells, tdim): 1 on the candidate cells; empty = all cells
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
 };

@@ -919,6 +919,22 @@ struct ClsMask
   __device__ bool operator()(int64_t c) const { return (cls[c] & any) != 0 && (cls[c] & none) == 0; }
 };
 
+// cells outside a candidate subset: a classification code no selector matches
+__global__ void restrict_domain_kernel(int64_t n, const uint8_t* __restrict__ keep, int8_t* __restrict__ domain)
+{
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < n && !keep[c]) domain[c] = (int8_t)CFX_NOT_CANDIDATE;
+}
+
+__global__ void mark_subset_kernel(int64_t n, const int32_t* __restrict__ cells, int64_t ncells, uint8_t* keep, int* bad)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cells[i];
+  if (c < 0 || c >= ncells) { *bad = 1; return; }
+  keep[c] = 1;
+}
+
 struct IsCut
 {
   const int8_t* domain;
@@ -941,6 +957,10 @@ void classify(cfx_cut_t cut)
     default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported level-set element (dofs per cell must be 3, 4, 6 or 10)");
     }
   }
+  if (cut->host_mask.n > 0)
+    for (int k = 0; k < cut->nls; ++k)
+      launch("restrict_domain", restrict_domain_kernel, grid_for(nc), dim3(kBlock), 0, nc, cut->host_mask.p,
+             cut->domain.p + (int64_t)k * nc);
   cut->located.clear();
   cut->ghost_rows.clear();
 }
@@ -1003,6 +1023,22 @@ int cfx_cut_create(cfx_mesh_t mesh, int nls, const int32_t* ls_dofmap, int ls_nd
   cut->domain.alloc((int64_t)nls * mesh->ncells);
   classify(cut.get());
   *out = cut.release();
+  CFX_API_END
+}
+
+int cfx_cut_restrict(cfx_cut_t cut, const int32_t* cells, int64_t n)
+{
+  CFX_API_BEGIN
+  require(cut && (cells || n == 0) && n >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_restrict: null argument");
+  const int64_t nc = cut->mesh->ncells;
+  DevArray<int32_t> dcells = to_device(cells, n);
+  cut->host_mask.alloc(nc);
+  cut->host_mask.zero();
+  DevArray<int> bad(1);
+  bad.zero();
+  launch("mark_subset", mark_subset_kernel, grid_for(n), dim3(kBlock), 0, n, dcells.p, nc, cut->host_mask.p, bad.p);
+  require(!read_scalar(bad.p), CFX_ERR_OUT_OF_RANGE, "cfx_cut_restrict: cell index out of range");
+  classify(cut);
   CFX_API_END
 }
 

@@ -155,7 +155,11 @@ class CutData:
 
     @property
     def entity_dim(self):
-        return None
+        return getattr(self, "_entity_dim", None)
+
+    @property
+    def entities(self):
+        return getattr(self, "_entities", None)
 
     def domain(self, level_set: int = 0) -> np.ndarray:
         """int8 classification per cell: -1 inside, 0 intersected, +1 outside."""
@@ -253,9 +257,11 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
     """Classify all cells against one or more level sets (python/cutfemx/cut.py:186-249)."""
     level_sets = _normalise_level_sets(level_set)
     names = frozen_level_set_names([f.name for f in level_sets])
-    if entities is not None or entity_dim is not None:
-        if entities is None:
-            raise ValueError("entity_dim is only valid when entities are supplied")
+    if entities is None and entity_dim is not None:
+        raise ValueError("entity_dim is only valid when entities are supplied")
+    if entities is not None and entity_dim is None:
+        raise ValueError("entity_dim must be supplied when entities are supplied")
+    if entities is not None and entity_dim != level_sets[0].function_space.mesh.tdim:
         raise NotImplementedError("facet-hosted cuts are outside the accelerated path (SURVEY 8f-4)")
     V = level_sets[0].function_space
     for f in level_sets[1:]:
@@ -269,7 +275,12 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
     h = C.c_void_p()
     _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
                                          C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
-    return CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
+    cd = CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
+    if entities is not None:   # cell subset as host (python/tests/test_cut_api.py:160-168)
+        cells = np.ascontiguousarray(np.asarray(entities, dtype=np.int32))
+        _lib.check(_lib.lib().cfx_cut_restrict(h, cells.ctypes.data_as(C.c_void_p), C.c_int64(cells.size)))
+        cd._entities, cd._entity_dim = cells, int(entity_dim)
+    return cd
 
 
 def update(cut_data: CutData) -> None:

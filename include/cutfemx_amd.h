@@ -180,6 +180,12 @@ int cfx_cut_create(cfx_mesh_t mesh, int n_level_sets, const int32_t* ls_dofmap,
                    int ls_ndofs_cell, int64_t ls_ndofs, const double* const* ls_values,
                    const cfx_cut_options* opt, cfx_cut_t* out);
 /* update(): cut.cpp:845-868 -- re-classify from new values (same pointers if NULL) */
+/* cut(level_set, entities, entity_dim = tdim) (cut.cpp:788-830, python/cutfemx/cut.py:186-249): keep only
+ * the listed background cells as candidates; every other cell gets the classification code
+ * CFX_NOT_CANDIDATE, which no selector matches, so located lists, rules, ghost facets and aggregations
+ * see the subset only.  Survives cfx_cut_update. */
+#define CFX_NOT_CANDIDATE 2
+int cfx_cut_restrict(cfx_cut_t cut, const int32_t* cells, int64_t n);
 int cfx_cut_update(cfx_cut_t cut, const double* const* ls_values);
 int cfx_cut_info(cfx_cut_t cut, int* tdim, int* gdim, int64_t* num_local_cells,
                  int* n_level_sets);

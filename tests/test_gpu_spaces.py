@@ -332,6 +332,44 @@ def test_named_level_sets_in_selectors(oracle):
     assert np.array_equal(r.parent_map, want.parent_map) and np.array_equal(r.weights, want.weights)
 
 
+def test_cut_with_cell_subset_as_host(oracle):
+    # python/tests/test_cut_api.py:160-168, :211-222, python/tests/test_locate_entities.py:40-71
+    import cutfemx_amd as cfx
+    om = oracle.mesh_box(2, 8)
+    mesh = cfx.Mesh.from_arrays(2, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    phi = om.x[:, 0] - 0.51
+    f = cfx.Function(V, phi)
+    full = cfx.cut(f)
+    part = np.arange(0, om.ncells, 3, dtype=np.int32)
+    sub = cfx.cut(f, part, mesh.tdim)
+    assert sub.entity_dim == 2 and np.array_equal(sub.entities, part)
+    for sel in ("phi=0", "phi<0", "phi>0", "phi<=0"):
+        assert np.array_equal(cfx.locate_entities(sub, sel), np.intersect1d(cfx.locate_entities(full, sel), part))
+    dom = oracle.classify(om.conn, phi)
+    want = np.where(np.isin(np.arange(om.ncells), part), dom, 2)
+    assert np.array_equal(sub.domain(), want)
+    # rules only on the candidate cut cells, identical to the full cut's rules there
+    r_sub, r_full = cfx.runtime_quadrature(sub, "phi<0", 2), cfx.runtime_quadrature(full, "phi<0", 2)
+    keep = np.isin(r_full.parent_map, part)
+    assert np.array_equal(r_sub.parent_map, r_full.parent_map[keep])
+    assert np.array_equal(r_sub.weights, np.concatenate(
+        [r_full.weights[r_full.offsets[k]:r_full.offsets[k + 1]] for k in np.flatnonzero(keep)]))
+    # the subset survives update()
+    f.values = om.x[:, 0] - 0.37
+    sub.update()
+    full.update()
+    assert np.array_equal(cfx.locate_entities(sub, "phi=0"), np.intersect1d(cfx.locate_entities(full, "phi=0"), part))
+    with pytest.raises(ValueError, match="entity_dim must be supplied"):
+        cfx.cut(f, entities=part)
+    with pytest.raises(ValueError, match="entity_dim is only valid"):
+        cfx.cut(f, entity_dim=0)
+    with pytest.raises(NotImplementedError):
+        cfx.cut(f, part, 1)                       # facet hosts: SURVEY 8f-4
+    with pytest.raises(IndexError):
+        cfx.cut(f, np.array([om.ncells], dtype=np.int32), 2)
+
+
 def test_moving_domain_loop(oracle):
     # python/demo/demo_moving_poisson.py:53-90: one CutData, the level set moves in place on the
     # device, update() + rules + forms + sparsity + assembly every step; each step equals the oracle

@@ -157,6 +157,18 @@ inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, in
   return cd;
 }
 
+/// cut(level_set, entities, entity_dim): cut.cpp:788-830 with entity_dim == tdim -- only the listed
+/// background cells are candidates (facet hosts are not part of the accelerated path)
+inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, int ls_ndofs_cell,
+                   std::int64_t ls_ndofs, std::span<const double* const> level_set_values,
+                   std::span<const std::int32_t> entities, int entity_dim, const CutOptions& options = CutOptions{})
+{
+  CutData cd = cut(mesh, ls_dofmap, ls_ndofs_cell, ls_ndofs, level_set_values, options);
+  if (entity_dim != cd.tdim) throw std::invalid_argument("cut: only cell subsets (entity_dim == tdim) can host cuts here");
+  check(cfx_cut_restrict(cd.handle.h, entities.data(), static_cast<std::int64_t>(entities.size())));
+  return cd;
+}
+
 /// update(): cut.cpp:845-868 -- re-classify from the current values (same pointers when empty)
 inline void update(CutData& cut_data, std::span<const double* const> level_set_values = {})
 {

@@ -935,6 +935,38 @@ __global__ void mark_subset_kernel(int64_t n, const int32_t* __restrict__ cells,
   keep[c] = 1;
 }
 
+// interior facets inside a cell set: thread per (listed cell, facet), emitted from the lower cell
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) interior_facets_find_kernel(int64_t n, const int32_t* __restrict__ cells,
+                                                                      const int32_t* __restrict__ conn,
+                                                                      const int64_t* __restrict__ v2c_off,
+                                                                      const int32_t* __restrict__ v2c,
+                                                                      const uint8_t* __restrict__ inset,
+                                                                      int32_t* __restrict__ counts, int32_t* __restrict__ cand)
+{
+  constexpr int NV = TDIM + 1;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * NV) return;
+  const int64_t i = t / NV;
+  const int lf = (int)(t - i * NV);
+  const int64_t c = cells[i];
+  int4 r = make_int4(-1, -1, -1, -1);
+  int32_t nb;
+  int nlf;
+  if (facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf) && inset[nb] && c < nb)
+  {
+    r = make_int4((int)c, lf, nb, nlf);
+    atomicAdd(&counts[i], 1);
+  }
+  *reinterpret_cast<int4*>(cand + 4 * t) = r;
+}
+
+struct ByteSet
+{
+  const uint8_t* b;
+  __device__ bool operator()(int64_t i) const { return b[i] != 0; }
+};
+
 struct IsCut
 {
   const int8_t* domain;
@@ -1317,6 +1349,51 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   }
   *rows = grows.p;
   *n = total;
+  CFX_API_END
+}
+
+int cfx_interior_facets_for_cells(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int32_t** rows, int64_t* n_rows)
+{
+  CFX_API_BEGIN
+  require(mesh && (cells || n == 0) && rows && n_rows && n >= 0, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_interior_facets_for_cells: null argument");
+  const int64_t nc = mesh->ncells;
+  DevArray<int32_t> dcells = to_device(cells, n);
+  DevArray<uint8_t> inset(nc);
+  inset.zero();
+  DevArray<int> bad(1);
+  bad.zero();
+  launch("mark_subset", mark_subset_kernel, grid_for(n), dim3(kBlock), 0, n, dcells.p, nc, inset.p, bad.p);
+  require(!read_scalar(bad.p), CFX_ERR_OUT_OF_RANGE, "cfx_interior_facets_for_cells: cell index out of range");
+  DevArray<int32_t> sorted; // ascending, duplicates removed
+  const int64_t m = compact("interior_facets", nc, ByteSet{inset.p}, sorted);
+  const int nv = mesh->tdim + 1;
+  DevArray<int32_t> counts(m), cand(m * nv * 4);
+  DevArray<int64_t> offs(m + 1);
+  int64_t total = 0;
+  const Adjacency& adj = mesh->vertex_cells();
+  if (m > 0)
+  {
+    counts.zero();
+    if (mesh->tdim == 2)
+      launch("interior_facets_find", interior_facets_find_kernel<2>, grid_for(m * nv), dim3(kBlock), 0, m, sorted.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, inset.p, counts.p, cand.p);
+    else
+      launch("interior_facets_find", interior_facets_find_kernel<3>, grid_for(m * nv), dim3(kBlock), 0, m, sorted.p,
+             mesh->conn.p, adj.offsets.p, adj.cells.p, inset.p, counts.p, cand.p);
+    exclusive_scan(counts.p, offs.p, m);
+    total = read_scalar(offs.p + m);
+  }
+  int32_t* out = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * 4 * (size_t)(total > 0 ? total : 1)));
+  if (total > 0)
+  {
+    if (mesh->tdim == 2)
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<2>, grid_for(m), dim3(kBlock), 0, m, cand.p, offs.p, out);
+    else
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<3>, grid_for(m), dim3(kBlock), 0, m, cand.p, offs.p, out);
+  }
+  *rows = out;
+  *n_rows = total;
   CFX_API_END
 }
 

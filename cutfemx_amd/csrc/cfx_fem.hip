@@ -673,6 +673,37 @@ int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, con
   CFX_API_END
 }
 
+namespace
+{
+struct RowAllZero
+{
+  const int64_t* indptr;
+  const double* values;
+  double tol;
+  __device__ bool operator()(int64_t r) const
+  {
+    for (int64_t k = indptr[r]; k < indptr[r + 1]; ++k)
+      if (fabs(values[k]) > tol) return false;
+    return true;
+  }
+};
+} // namespace
+
+int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** rows, int64_t* n_rows)
+{
+  CFX_API_BEGIN
+  require(P && values && rows && n_rows, CFX_ERR_INVALID_ARGUMENT, "cfx_zero_rows: null argument");
+  DevArray<double> dv = to_device(values, P->nnz);
+  DevArray<int32_t> list;
+  const int64_t n = compact("zero_rows", P->nrows, RowAllZero{P->indptr.p, dv.p, tol}, list);
+  int32_t* out = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
+  if (n > 0)
+    CFX_HIP(hipMemcpyAsync(out, list.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx().stream));
+  *rows = out;
+  *n_rows = n;
+  CFX_API_END
+}
+
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae)
 {
   CFX_API_BEGIN

@@ -348,6 +348,31 @@ class FacetRows:
         return self.size
 
 
+class _OwnedRows:
+    """Device rows returned by the engine through cfx_device_alloc."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().cfx_device_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def interior_facets_for_cells(mesh: Mesh, cells, *, include_ghosts: bool = False) -> FacetRows:
+    """Interior facets whose two cells both lie in `cells` (python/cutfemx/cut.py:320-337,
+    cut.cpp:926-994), as integration rows (c0, lf0, c1, lf1), c0 < c1, ascending."""
+    cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int32))
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_interior_facets_for_cells(mesh._h, cells.ctypes.data_as(C.c_void_p), C.c_int64(cells.size),
+                                                        C.byref(p), C.byref(n)))
+    return FacetRows(p.value, n.value, owner=_OwnedRows(p.value))
+
+
 def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, include_ghosts: bool = False):
     """Interior facets of the cut-cell stabilisation band (python/cutfemx/cut.py:340-380)."""
     if depth != 1:

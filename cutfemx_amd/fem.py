@@ -245,6 +245,26 @@ def set_bc(b, bc_markers, bc_values, x0=None, alpha: float = 1.0):
     return b
 
 
+def assemble_scalar(M: CutForm) -> float:
+    """Functional int f over the form's cells and runtime rules (python/cutfemx/fem.py:522-528).
+    `M` is a linear form of SOURCE integrals: the Lagrange basis is a partition of unity, so the
+    functional is the sum of the assembled vector (python/tests/test_cut_api.py:796-811 checks the
+    reference the same way)."""
+    if M.rank != 1 or any(i.kernel != SOURCE for i in M.integrals):
+        raise ValueError("assemble_scalar takes a linear form made of SOURCE integrals (f dx)")
+    b = assemble_vector(M)
+    return float(b.sum())
+
+
+def zero_rows(A: MatrixCSR, *, tol: float = 0.0) -> np.ndarray:
+    """Rows whose assembled entries are all <= tol in magnitude (python/cutfemx/fem.py:777-782)."""
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_zero_rows(A._p, C.c_void_p(A.values_ptr), C.c_double(tol), C.byref(p), C.byref(n)))
+    out = _lib.download(p.value, n.value, np.int32)
+    _lib.check(_lib.lib().cfx_device_free(p))
+    return out
+
+
 def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np.ndarray:
     """Local tensor of one entity (for local-entry parity checks)."""
     V = a.function_space

@@ -221,6 +221,11 @@ int cfx_evaluate_values(cfx_cut_t cut, int level_set, cfx_rules_t rules,
  * rows = (cell0, local_facet0, cell1, local_facet1), cell0 < cell1. */
 int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector,
                              const int32_t** rows, int64_t* n);
+/* interior_facets_for_cells(mesh, cells) (cut.cpp:926-994 + wrappers/cut.cpp:54-115): the interior facets
+ * whose two cells both belong to `cells`, as (c0, lf0, c1, lf1) rows with c0 < c1, ascending.  *rows is a
+ * device array the caller releases with cfx_device_free. */
+int cfx_interior_facets_for_cells(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int32_t** rows, int64_t* n_rows);
+
 /* ---- cell aggregation (extension stabilisation): cutfemx::extensions::create_cell_aggregation,
  *      cpp/cutfemx/extensions/cell_aggregation.{h,cpp}, python/cutfemx/extensions.py -------------
  * selector: strict single level set ("phi<0" / "phi>0").  Roots = interior cells (+ cut cells whose
@@ -283,6 +288,9 @@ int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_v
 int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, const double* x0, double alpha,
                double* b);
 /* local tensor of one entity (parity tests of local entries) */
+/* zero_rows(A, tol) (python/cutfemx/fem.py:777-782): rows whose assembled entries are all <= tol in
+ * magnitude, ascending; *rows is released with cfx_device_free. */
+int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** rows, int64_t* n_rows);
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
 
 /* ---- deactivation: cpp/cutfemx/fem/deactivate.h:387-418 ------------------- */

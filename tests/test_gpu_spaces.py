@@ -332,6 +332,38 @@ def test_named_level_sets_in_selectors(oracle):
     assert np.array_equal(r.parent_map, want.parent_map) and np.array_equal(r.weights, want.weights)
 
 
+def test_interior_facets_scalar_functional_and_zero_rows(oracle):
+    import cutfemx_amd as cfx
+    # interior_facets_for_cells stays inside the cell set (python/tests/test_cut_api.py:1176-1196)
+    for tdim, n in ((2, 6), (3, 4)):
+        om = oracle.mesh_box(tdim, n)
+        mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+        sel = np.arange(0, om.ncells, 2, dtype=np.int32)
+        for cells in (sel, sel[::-1].copy(), np.arange(om.ncells, dtype=np.int32)):
+            rows = cfx.interior_facets_for_cells(mesh, cells).rows
+            assert np.array_equal(rows, oracle.interior_facets_for_cells(om, np.sort(cells)))
+            assert np.all(np.isin(rows[:, 0], cells)) and np.all(np.isin(rows[:, 2], cells))
+    # functionals: area and perimeter of the circle (test_cut_api.py:796-811, :1268-1300)
+    om = oracle.mesh_box(2, 21)
+    mesh = cfx.Mesh.from_arrays(2, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(V, level_set_values(om.x, 2)))
+    inside = cfx.locate_entities(cd, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    itf = cfx.runtime_quadrature(cd, "phi=0", 4)
+    one = (cfx.fem.F_ONE, 1.0)
+    area = cfx.fem.assemble_scalar(cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, rules=vol, params=one,
+                                                                   qdegree=1)], V))
+    perimeter = cfx.fem.assemble_scalar(cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, rules=itf, params=one)], V))
+    assert abs(area - np.pi * 0.31 ** 2) < 1e-2 and abs(perimeter - 2 * np.pi * 0.31) < 1e-2
+    assert abs(area - (vol.weights.sum() + inside.size * 0.5 / 21 ** 2)) < 1e-13
+    # zero_rows: exactly the rows that no entity touches (fem.py:777-782)
+    A = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(cfx.fem.STIFFNESS, cells=inside, rules=vol, qdegree=0)], V))
+    dom = cfx.fem.active_domain(cfx.fem.form([cfx.fem.Integral(cfx.fem.STIFFNESS, cells=inside, rules=vol, qdegree=0)], V))
+    assert np.array_equal(cfx.fem.zero_rows(A), dom.inactive_dofs)
+    assert cfx.fem.zero_rows(A, tol=1e300).size == A.nrows
+
+
 def test_cut_with_cell_subset_as_host(oracle):
     # python/tests/test_cut_api.py:160-168, :211-222, python/tests/test_locate_entities.py:40-71
     import cutfemx_amd as cfx

@@ -661,6 +661,9 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
 // uncut-cell stiffness item (cut-cell rule tensors, facets) is left to
 // assemble_rows_kernel on the rows next to the interface (plan.special_rows).
 // ---------------------------------------------------------------------------
+#ifndef CFX_BLOCK_WAVES
+#define CFX_BLOCK_WAVES 4
+#endif
 #ifndef CFX_P1_WAVES
 #define CFX_P1_WAVES 6
 #endif
@@ -1072,8 +1075,10 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
 // 7 KB), the rows of cut cells come from the stage-1 rule tensors.  No facet items: forms with
 // facet integrals on block spaces keep the entity-parallel path.
 // ---------------------------------------------------------------------------
-template <int TDIM, int DEG, int BS, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave, 2) assemble_rows_block_kernel(RowArgs A)
+// INLINE = false (default): uncut tensors are staged, the elasticity arithmetic is not compiled in
+// and the kernel fits 4 waves/SIMD.
+template <int TDIM, int DEG, int BS, int G, int CAP, bool ORDERED, bool INLINE>
+__global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_rows_block_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int NLOC = ND * BS;
@@ -1139,16 +1144,19 @@ __global__ void __launch_bounds__(kWave, 2) assemble_rows_block_kernel(RowArgs A
         const RowIntegral& I = A.cell[i];
         if (mark & (1u << i))
         {
-          if (I.std_inline)
+          if (INLINE && I.std_inline)
           {
-            Geo<TDIM> g;
-            load_cell<TDIM>(A.x, A.conn, c, g);
-            jacobian<TDIM>(g);
-            int npts;
-            const double* wts;
-            const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
-            cell_local_row<TDIM, DEG, BS, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts, fabs(g.detJ),
-                                             nullptr, lr, kc, acc);
+            if constexpr (INLINE)
+            {
+              Geo<TDIM> g;
+              load_cell<TDIM>(A.x, A.conn, c, g);
+              jacobian<TDIM>(g);
+              int npts;
+              const double* wts;
+              const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+              cell_local_row<TDIM, DEG, BS, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts, fabs(g.detJ),
+                                               nullptr, lr, kc, acc);
+            }
           }
           else
           {
@@ -1538,12 +1546,16 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   {
     const bool det = deterministic();
     const int mr = P->max_row_len; // scalar columns per row
+    bool inl = false;
+    for (int s = 0; s < A.n_cell; ++s) inl = inl || A.cell[s].std_inline != 0;
 #define CFX_BLOCK(GG, CAPP)                                                                                          \
   do                                                                                                                 \
   {                                                                                                                  \
     const dim3 grid = row_grid((A.n_active * BS + (kWave / GG) - 1) / (kWave / GG));                                 \
-    if (det) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true>, grid, dim3(kWave), 0, A);   \
-    else launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false>, grid, dim3(kWave), 0, A);     \
+    if (det && inl) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true, true>, grid, dim3(kWave), 0, A);    \
+    else if (det) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true, false>, grid, dim3(kWave), 0, A);  \
+    else if (inl) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, true>, grid, dim3(kWave), 0, A);  \
+    else launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, false>, grid, dim3(kWave), 0, A);          \
   } while (0)
     if (mr <= 32) CFX_BLOCK(8, 32);
     else if (mr <= 128) CFX_BLOCK(16, 128);

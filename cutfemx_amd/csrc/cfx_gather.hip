@@ -64,6 +64,13 @@ inline dim3 row_grid(int64_t nblocks)
 #define CFX_ROWS_WAVES 5 // waves per SIMD the gather kernel is compiled for (measured: 4 -> 2.27, 5 -> 2.09, 6 -> 2.58 ms at 256^3)
 #endif
 
+// whether assemble_rows_kernel carries the generic inline local-row code for a degree
+#ifndef CFX_ROWS_INLINE_DEG2
+#define CFX_ROWS_INLINE_DEG2 0 // degree 2 stages its uncut tensors: the inline code costs 60 VGPRs (config 4: 215 -> 151 ms)
+#endif
+template <int DEG>
+constexpr bool kRowsInline = DEG == 1 || CFX_ROWS_INLINE_DEG2 != 0;
+
 struct RowIntegral
 {
   int kernel, qdegree, point_stride;
@@ -494,16 +501,19 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
             const RowIntegral& I = A.cell[i];
             if (mark & (1u << i))
             {
-              if (I.std_inline)
+              if (kRowsInline<DEG> && I.std_inline)
               {
-                Geo<TDIM> g;
-                load_cell<TDIM>(A.x, A.conn, c, g);
-                jacobian<TDIM>(g);
-                int npts;
-                const double* wts;
-                const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
-                cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
-                                                fabs(g.detJ), nullptr, lr, 0, acc);
+                if constexpr (kRowsInline<DEG>)
+                {
+                  Geo<TDIM> g;
+                  load_cell<TDIM>(A.x, A.conn, c, g);
+                  jacobian<TDIM>(g);
+                  int npts;
+                  const double* wts;
+                  const double* pts = ref_rule(TDIM, I.qdegree, npts, wts);
+                  cell_local_row<TDIM, DEG, 1, 2>(I.kernel, I.params, I.point_stride, g, 0.0, npts, pts, wts,
+                                                  fabs(g.detJ), nullptr, lr, 0, acc);
+                }
               }
               else
               {
@@ -1357,7 +1367,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     const bool inline_ok = BS > 1 ? (I.kernel == CFX_K_ELASTICITY || I.kernel == CFX_K_MASS || I.kernel == CFX_K_STIFFNESS)
                                   : (DEG == 1 ? I.kernel == CFX_K_STIFFNESS
                                               : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS));
-    R.std_inline = (a->rank == 2 && inline_ok && !(inl && inl[0] == '0')) ? 1 : 0;
+    R.std_inline = (a->rank == 2 && inline_ok && kRowsInline<DEG> && !(inl && inl[0] == '0')) ? 1 : 0;
     if (BS > 1 && !(inl && inl[0] == '1')) R.std_inline = 0; // block spaces stage their uncut tensors (see assemble_matrix_rows)
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
@@ -1615,6 +1625,16 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
   }
   else if (V->degree == 1)
     err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values) : run_matrix<3, 1>(a, P, bc0, bc1, values);
+  else if (!kRowsInline<2> && [&]() {
+             // degree 2 stages 100 doubles per uncut cell (38 GB at config 4): must fit next to the matrix
+             size_t need = 0, free_b = 0, total_b = 0;
+             const int nloc = V->ndofs_cell;
+             for (const auto& I : a->integrals)
+               if (I.type == CFX_CELL) need += (size_t)(I.n_entities + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
+             CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+             return need > free_b / 2;
+           }())
+    return false;
   else
     err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values) : run_matrix<3, 2>(a, P, bc0, bc1, values);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");

@@ -337,7 +337,9 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 // (degree 2: 10 columns per cell item, 20 per facet item: 2 waves/SIMD leave 256 VGPRs)
 // CUTS = false compiles the rule-tensor and facet items out: the lean form that serves the uncut
 // items of every row of a degree-2 space (the facet section alone holds 100 registers there).
-template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true>
+// STD = false compiles the uncut-cell items out: the form that serves only the rule / facet items
+// of the interface rows (mark_mask 0xF0) next to a lean kernel for everything else.
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true, bool STD = true>
 __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
@@ -499,7 +501,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
           for (int i = 0; i < ((A.debug & 2) ? 0 : A.n_cell); ++i)
           {
             const RowIntegral& I = A.cell[i];
-            if (mark & (1u << i))
+            if (STD && (mark & (1u << i)))
             {
               if (kRowsInline<DEG> && I.std_inline)
               {
@@ -1493,8 +1495,16 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
         if (S.n_active > 0)
         {
-          if (mr <= 32) CFX_ROWS(8, 32, "assemble_rows_cut", S);
-          else CFX_ROWS(8, 64, "assemble_rows_cut", S);
+#define CFX_ROWS_CUT(GG, CAPP)                                                                                       \
+  do                                                                                                                 \
+  {                                                                                                                  \
+    const dim3 grid = row_grid((S.n_active + (kWave / GG) - 1) / (kWave / GG));                                      \
+    if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, true, false>, grid, dim3(kWave), 0, S);   \
+    else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, true, false>, grid, dim3(kWave), 0, S);      \
+  } while (0)
+          if (mr <= 32) CFX_ROWS_CUT(8, 32);
+          else CFX_ROWS_CUT(8, 64);
+#undef CFX_ROWS_CUT
         }
       }
     }
@@ -1523,7 +1533,12 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
 #undef CFX_LEAN
         RowArgs S = A;
         S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
-        if (S.n_active > 0) CFX_ROWS(16, 256, "assemble_rows_cut", S);
+        if (S.n_active > 0)
+        {
+          const dim3 grid = row_grid((S.n_active + 3) / 4);
+          if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, false>, grid, dim3(kWave), 0, S);
+          else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, false, true, false>, grid, dim3(kWave), 0, S);
+        }
       }
     }
     if (!split)

@@ -281,6 +281,108 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   }
 }
 
+// ---------------------------------------------------------------------------
+// stage-1 tensors of the cut cells of a P1 scalar space: one thread per runtime rule forms the whole
+// (tdim+1)^2 tensor.  P1 gradients are constant on the cell, so the stiffness part is
+// (sum of the rule's weights) * G_i . G_j and only Nitsche / mass terms walk the points -- the generic
+// kernel spends one thread per (rule, row) and re-tabulates at every point.
+// ---------------------------------------------------------------------------
+constexpr int kCutLanes = 8; // lanes per rule: the points are dealt round-robin (coalesced, balanced), partial tensors folded by shuffles
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) cut_tensors_p1_kernel(AsmArgs A)
+{
+  constexpr int ND = TDIM + 1;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = tid / kCutLanes;
+  const int sub = (int)(tid - e * kCutLanes);
+  if (e >= A.n) return;
+  const int64_t cell = A.parent_map[e];
+  Geo<TDIM> g;
+  load_cell<TDIM>(A.x, A.conn, cell, g);
+  jacobian<TDIM>(g);
+  // physical gradients of the barycentric basis: G_j = K^T dN_j, dN_0 = -1, dN_t = e_t
+  double G[ND][TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double s = 0.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) { G[t + 1][d] = g.K[t][d]; s += g.K[t][d]; }
+    G[0][d] = -s;
+  }
+  double T[ND][ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+#pragma unroll
+    for (int j = 0; j < ND; ++j) T[i][j] = 0.0;
+  const int32_t q0 = A.offsets[e], q1 = A.offsets[e + 1];
+  if (A.kernel == CFX_K_STIFFNESS)
+  {
+    double wsum = 0.0;
+    for (int32_t q = q0 + sub; q < q1; q += kCutLanes) wsum += A.weights[q];
+#pragma unroll
+    for (int o = kCutLanes / 2; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o, kCutLanes);
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) s += G[i][d] * G[j][d];
+        T[i][j] = wsum * s;
+      }
+  }
+  else
+  {
+    const double gam = A.kernel == CFX_K_NITSCHE ? A.params[0] / cell_diameter<TDIM>(g) : 0.0;
+    for (int32_t q = q0 + sub; q < q1; q += kCutLanes)
+    {
+      const double w = A.weights[q];
+      double N[ND], l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) { N[t + 1] = A.points[(int64_t)q * TDIM + t]; l0 -= N[t + 1]; }
+      N[0] = l0;
+      if (A.kernel == CFX_K_MASS)
+      {
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) T[i][j] += w * N[i] * N[j];
+      }
+      else // Nitsche: -dn(u) v - dn(v) u + gamma/h u v with the per-point normal
+      {
+        const double* nrm = A.point_data + (int64_t)q * A.point_stride;
+        double dn[ND];
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) s += G[j][d] * nrm[d];
+          dn[j] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+          for (int j = 0; j < ND; ++j) T[i][j] += w * (-dn[j] * N[i] - dn[i] * N[j] + gam * N[j] * N[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int o = kCutLanes / 2; o > 0; o >>= 1) T[i][j] += __shfl_xor(T[i][j], o, kCutLanes);
+  }
+  if (sub != 0) return;
+  double* out = A.dump + e * (ND * ND);
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+#pragma unroll
+    for (int j = 0; j < ND; ++j) out[i * ND + j] = T[i][j];
+}
+
 template <int TDIM, int DEG, int BS>
 void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule,
                        int parts)
@@ -321,7 +423,14 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
     if (A.n > 0)
     {
-      if (a->rank == 2)
+      const char* spec = getenv("CFX_CUT_TENSORS_P1");
+      if (a->rank == 2 && DEG == 1 && BS == 1 && A.dump && !single && !(spec && spec[0] == '0')
+          && (A.kernel == CFX_K_STIFFNESS || A.kernel == CFX_K_MASS || A.kernel == CFX_K_NITSCHE))
+      {
+        if constexpr (DEG == 1 && BS == 1)
+          launch("cut_tensors_p1", cut_tensors_p1_kernel<TDIM>, grid_for(A.n * kCutLanes), dim3(kBlock), 0, A);
+      }
+      else if (a->rank == 2)
         launch("assemble_cells_cut", assemble_cells_kernel<TDIM, DEG, BS, 2, true>, grid_for(A.n * ND * BS),
                dim3(kBlock), 0, A);
       else

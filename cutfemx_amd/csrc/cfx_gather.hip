@@ -245,11 +245,16 @@ struct VecArgs
   double* out; // [n][ND]
 };
 
-template <int TDIM, int DEG, bool RUNTIME>
+// LANES > 1 (runtime rules): a group of lanes shares one rule, the points of the rule are dealt
+// round-robin to the lanes (coalesced point / weight / normal reads, balanced 6-42 point rules) and
+// the ND partial sums are folded with shuffles.
+template <int TDIM, int DEG, bool RUNTIME, int LANES = 1>
 __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = tid / LANES;
+  const int sub = (int)(tid - e * LANES);
   if (e >= A.n) return;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
   Geo<TDIM> g;
@@ -275,7 +280,7 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
   double be[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) be[i] = 0.0;
-  for (int q = 0; q < npts; ++q)
+  for (int q = sub; q < npts; q += LANES)
   {
     double X[TDIM], xq[TDIM], l0 = 1.0;
 #pragma unroll
@@ -326,6 +331,14 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
         be[i] += w * (-dni * gv + gam * gv * N[i]);
       }
     }
+  }
+  if constexpr (LANES > 1)
+  {
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+      for (int o = LANES / 2; o > 0; o >>= 1) be[i] += __shfl_xor(be[i], o, LANES);
+    if (sub != 0) return;
   }
 #pragma unroll
   for (int i = 0; i < ND; ++i) A.out[e * ND + i] = be[i];
@@ -1328,7 +1341,7 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
     const cfx_rules_s* R = I.rules;
     A.n = R->nr; A.offsets = R->offsets.p; A.parent_map = R->parent_map.p; A.points = R->points.p;
     A.weights = R->weights.p; A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true>, grid_for(A.n), dim3(kBlock), 0, A);
+    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, 8>, grid_for(A.n * 8), dim3(kBlock), 0, A);
   }
 }
 

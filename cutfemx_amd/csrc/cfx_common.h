@@ -377,6 +377,11 @@ struct cfx_row_plan
   cfx::DevArray<int32_t> plain_rows;   // the other active rows: uncut-cell items only
   int64_t n_plain_rows = 0;
   uint64_t serial = 0;                 // identity of this plan (a pattern remembers the plan it was built from)
+  // per plain row (built on first use by cfx::plain_row_masks): its stencil mask, and the mark byte that ALL
+  // its incident cells carry (0 if they differ or one is unmarked) -- such rows need no mark gathers
+  cfx::DevArray<unsigned long long> plain_masks;
+  cfx::DevArray<uint8_t> plain_uniform;
+  bool plain_masks_built = false;
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
@@ -412,6 +417,7 @@ namespace cfx
 {
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
+void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values);
 bool assemble_vector_rows(cfx_form_s* L, double* b);

@@ -120,6 +120,8 @@ struct RowArgs
   const uint8_t* diagpos;
   const int64_t* st_off;
   const int32_t* st_nbr;
+  const unsigned long long* plain_masks; // plan.plain_masks / plain_uniform, indexed like active_rows
+  const uint8_t* plain_uniform;
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -924,7 +926,9 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
     if (live) load_vertex<TDIM>(A.x, r, xr);
   }
 
-  // the first R*G items stay in registers between the mask pass and the add pass
+  // mask and (where all incident cells carry one mark) the mark itself come from the plan
+  const unsigned long long mask = live ? A.plain_masks[ri] : 0ull;
+  const uint8_t umark = live ? A.plain_uniform[ri] : (uint8_t)0;
   int32_t cell[R];
   uint32_t s4[R];
   uint8_t mk[R];
@@ -938,34 +942,9 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
       s4[k] = t < nc ? A.slot4[cb + t] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
+    for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? (umark ? umark : A.cellmark[cell[k]]) : (uint8_t)0;
   };
-  load_chunk(0);
-  unsigned long long mask = 0;
-#pragma unroll
-  for (int k = 0; k < R; ++k)
-    if (mk[k])
-    {
-#pragma unroll
-      for (int j = 0; j < ND; ++j) mask |= 1ull << ((s4[k] >> (8 * j)) & 0xffu);
-    }
-  for (int base = R * G;; base += R * G) // vertices with more than R*G cells (unstructured meshes)
-  {
-    if (__ballot(base + gl < nc) == 0) break;
-#pragma unroll
-    for (int k = 0; k < R; ++k)
-    {
-      const int t = base + k * G + gl;
-      if (t < nc && A.cellmark[A.d2c[cb + t]])
-      {
-        const uint32_t w = A.slot4[cb + t];
-#pragma unroll
-        for (int j = 0; j < ND; ++j) mask |= 1ull << ((w >> (8 * j)) & 0xffu);
-      }
-    }
-  }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) mask |= __shfl_xor(mask, o, G);
+  load_chunk(0); // in flight together with the stencil staging above
   // the pattern row must be exactly this subset (build_pattern from the same plan)
   if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
   __syncthreads();
@@ -1474,6 +1453,8 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           RowArgs Q = F;
           Q.n_active = plan.n_plain_rows; Q.active_rows = plan.plain_rows.p;
           Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p; Q.st_off = stn.offsets.p; Q.st_nbr = stn.nbr.p;
+          plain_row_masks(a);
+          Q.plain_masks = plan.plain_masks.p; Q.plain_uniform = plan.plain_uniform.p;
           const dim3 gq = row_grid((Q.n_active + 7) / 8);
           const char* stage_env = getenv("CFX_PLAIN_STAGE");
           const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');

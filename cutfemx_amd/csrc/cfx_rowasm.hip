@@ -476,16 +476,23 @@ struct ByteIs
   __device__ bool operator()(uint8_t x) const { return x == v; }
 };
 
-// stencil mask of a plain row: OR over its marked incident cells of the positions of their dofs.
-// G lanes per row; every lane of the group returns the full mask.
-template <int G>
-__device__ __forceinline__ unsigned long long plain_row_mask(const int64_t* __restrict__ d2c_off,
-                                                             const int32_t* __restrict__ d2c,
-                                                             const uint32_t* __restrict__ slot4,
-                                                             const uint8_t* __restrict__ cellmark, int nd, int64_t r,
-                                                             bool live, int gl)
+// stencil mask of a plain row: OR over its marked incident cells of the positions of their dofs, and
+// the mark byte shared by all its incident cells (0: not uniform).  G lanes per row.
+__global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+                                                            const int64_t* __restrict__ d2c_off,
+                                                            const int32_t* __restrict__ d2c,
+                                                            const uint32_t* __restrict__ slot4,
+                                                            const uint8_t* __restrict__ cellmark, int nd,
+                                                            unsigned long long* __restrict__ masks,
+                                                            uint8_t* __restrict__ uniform)
 {
+  constexpr int G = 8;
+  const int lane = threadIdx.x, gl = lane % G;
+  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
+  const bool live = i < n_plain;
+  const int64_t r = live ? rows[i] : 0;
   unsigned long long m = 0;
+  unsigned all_or = 0, all_and = 0xffu; // over the incident cells: equal iff every cell has the same mark
   if (live)
   {
     const int64_t cb = d2c_off[r];
@@ -507,37 +514,37 @@ __device__ __forceinline__ unsigned long long plain_row_mask(const int64_t* __re
       for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? cellmark[cell[k]] : (uint8_t)0;
 #pragma unroll
       for (int k = 0; k < R; ++k)
+      {
+        if (cell[k] >= 0) { all_or |= mk[k]; all_and &= mk[k]; }
         if (mk[k])
           for (int j = 0; j < nd; ++j) m |= 1ull << ((s4[k] >> (8 * j)) & 0xffu);
+      }
     }
   }
 #pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) m |= __shfl_xor(m, o, G);
-  return m;
-}
-
-// sparsity of the plain rows, pass 1: mask and length
-__global__ void __launch_bounds__(kWave) pattern_plain_count_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
-                                                                    const int64_t* __restrict__ d2c_off,
-                                                                    const int32_t* __restrict__ d2c,
-                                                                    const uint32_t* __restrict__ slot4,
-                                                                    const uint8_t* __restrict__ cellmark, int nd,
-                                                                    unsigned long long* __restrict__ masks,
-                                                                    int32_t* __restrict__ counts, int* maxlen)
-{
-  constexpr int G = 8;
-  const int lane = threadIdx.x, gl = lane % G;
-  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
-  const bool live = i < n_plain;
-  const int64_t r = live ? rows[i] : 0;
-  const unsigned long long m = plain_row_mask<G>(d2c_off, d2c, slot4, cellmark, nd, r, live, gl);
+  for (int o = G / 2; o > 0; o >>= 1)
+  {
+    m |= __shfl_xor(m, o, G);
+    all_or |= __shfl_xor(all_or, o, G);
+    all_and &= __shfl_xor(all_and, o, G);
+  }
   if (live && gl == 0)
   {
-    const int cnt = __popcll(m);
     masks[i] = m;
-    counts[r] = cnt;
-    if (cnt > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, cnt);
+    uniform[i] = (all_or == all_and) ? (uint8_t)all_or : (uint8_t)0;
   }
+}
+
+// sparsity of the plain rows, pass 1: row length = popcount of the mask
+__global__ void pattern_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+                                         const unsigned long long* __restrict__ masks, int32_t* __restrict__ counts,
+                                         int* maxlen)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_plain) return;
+  const int cnt = __popcll(masks[i]);
+  counts[rows[i]] = cnt;
+  if (cnt > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, cnt);
 }
 
 // pass 2: the set bits of the mask select the row's columns from the (sorted) stencil
@@ -768,6 +775,22 @@ const Stencil& space_stencil(cfx_space_s* V)
   return S;
 }
 
+void plain_row_masks(cfx_form_s* a)
+{
+  cfx_row_plan& plan = row_plan(a);
+  if (plan.plain_masks_built) return;
+  plan.plain_masks_built = true;
+  cfx_space_s* V = a->V;
+  const Stencil& st = space_stencil(V);
+  if (!st.usable || plan.n_plain_rows == 0 || !plan.any_cells) return;
+  const Adjacency& adj = V->dof_cells();
+  plan.plain_masks.alloc(plan.n_plain_rows);
+  plan.plain_uniform.alloc(plan.n_plain_rows);
+  launch("plan_plain_masks", plain_masks_kernel, dim3((unsigned)((plan.n_plain_rows + 7) / 8)), dim3(kWave), 0,
+         plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
+         plan.plain_masks.p, plan.plain_uniform.p);
+}
+
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
 {
   cfx_space_s* V = a->V;
@@ -793,7 +816,6 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   P->nrows = V->ndofs * V->bs;
   DevArray<int32_t> counts(P->nrows), len(n_h), tmp;
-  DevArray<unsigned long long> masks;
   DevArray<int> overflow(1), maxlen(1);
   overflow.zero();
   maxlen.zero();
@@ -827,11 +849,9 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   if (use_stencil)
   {
-    const Adjacency& adj = V->dof_cells();
-    masks.alloc(plan.n_plain_rows);
-    launch("pattern_plain", pattern_plain_count_kernel, dim3((unsigned)((plan.n_plain_rows + 7) / 8)), dim3(kWave), 0,
-           plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p,
-           V->ndofs_cell, masks.p, counts.p, maxlen.p);
+    plain_row_masks(a);
+    launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows), dim3(kBlock), 0, plan.n_plain_rows,
+           plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
   }
   P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
   P->indptr.alloc(P->nrows + 1);
@@ -842,7 +862,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
          P->indptr.p, P->indices.p);
   if (use_stencil)
     launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows * 8), dim3(kBlock), 0,
-           plan.n_plain_rows, plan.plain_rows.p, masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
+           plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
   if (n_h > 0)
   {
     if (T == 64)

@@ -862,6 +862,12 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
 #ifndef CFX_PLAIN_WAVES
 #define CFX_PLAIN_WAVES 6
 #endif
+#ifndef CFX_PLAIN_G
+#define CFX_PLAIN_G 4 // lanes per plain row (measured at 512^3: G=8,R=3 3.55 ms; G=4,R=6 3.14 ms; G=16 5.1 ms)
+#endif
+#ifndef CFX_PLAIN_R
+#define CFX_PLAIN_R 6 // items per lane per pass
+#endif
 // STAGE (stencils of at most 32 vertices): the coordinates of the row's stencil vertices are
 // loaded once per row into LDS (~15 gathers) and every item reads its TDIM other vertices from
 // there by stencil position: no dofmap row and no coordinate gathers per item (~170 per row).
@@ -871,7 +877,7 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   constexpr int ND = TDIM + 1;
   constexpr int RPW = kWave / G;
   constexpr int KMAX = CAP / G;
-  constexpr int R = 3; // 3 x 8 lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
+  constexpr int R = CFX_PLAIN_R; // R x G lanes cover the 24 tets around a Kuhn-mesh vertex in one pass
   constexpr int SX = CAP <= 32 ? CAP : 32; // staged stencil entries per row (a plain row is no longer than its stencil)
   __shared__ double s_val[RPW][CAP + 1];
   __shared__ double s_x[STAGE ? RPW : 1][STAGE ? SX + 1 : 1][TDIM];
@@ -1455,7 +1461,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p; Q.st_off = stn.offsets.p; Q.st_nbr = stn.nbr.p;
           plain_row_masks(a);
           Q.plain_masks = plan.plain_masks.p; Q.plain_uniform = plan.plain_uniform.p;
-          const dim3 gq = row_grid((Q.n_active + 7) / 8);
+          const dim3 gq = row_grid((Q.n_active + (kWave / CFX_PLAIN_G) - 1) / (kWave / CFX_PLAIN_G));
           const char* stage_env = getenv("CFX_PLAIN_STAGE");
           const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');
           // plain rows are subsets of their stencil: the LDS footprint follows the longest stencil
@@ -1464,10 +1470,10 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
 #define CFX_PLAIN(CAPP)                                                                                                \
   do                                                                                                                   \
   {                                                                                                                    \
-    if (det && stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, true, true>, gq, dim3(kWave), 0, Q);   \
-    else if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, true, false>, gq, dim3(kWave), 0, Q);     \
-    else if (stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, true>, gq, dim3(kWave), 0, Q);   \
-    else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, 8, CAPP, false, false>, gq, dim3(kWave), 0, Q);             \
+    if (det && stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, true, true>, gq, dim3(kWave), 0, Q);   \
+    else if (det) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, true, false>, gq, dim3(kWave), 0, Q);     \
+    else if (stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, false, true>, gq, dim3(kWave), 0, Q);   \
+    else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, false, false>, gq, dim3(kWave), 0, Q);             \
   } while (0)
           if (plain_cap == 16) CFX_PLAIN(16); else if (plain_cap == 32) CFX_PLAIN(32); else CFX_PLAIN(64);
 #undef CFX_PLAIN

@@ -476,6 +476,9 @@ struct ByteIs
   __device__ bool operator()(uint8_t x) const { return x == v; }
 };
 
+#ifndef CFX_MASKS_G
+#define CFX_MASKS_G 4
+#endif
 // stencil mask of a plain row: OR over its marked incident cells of the positions of their dofs, and
 // the mark byte shared by all its incident cells (0: not uniform).  G lanes per row.
 __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
@@ -486,7 +489,7 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
                                                             unsigned long long* __restrict__ masks,
                                                             uint8_t* __restrict__ uniform)
 {
-  constexpr int G = 8;
+  constexpr int G = CFX_MASKS_G;
   const int lane = threadIdx.x, gl = lane % G;
   const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
   const bool live = i < n_plain;
@@ -497,7 +500,7 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
   {
     const int64_t cb = d2c_off[r];
     const int nc = (int)(d2c_off[r + 1] - cb);
-    constexpr int R = 3;
+    constexpr int R = 24 / G;
     for (int base = 0; base < nc; base += R * G)
     {
       int32_t cell[R];
@@ -786,7 +789,8 @@ void plain_row_masks(cfx_form_s* a)
   const Adjacency& adj = V->dof_cells();
   plan.plain_masks.alloc(plan.n_plain_rows);
   plan.plain_uniform.alloc(plan.n_plain_rows);
-  launch("plan_plain_masks", plain_masks_kernel, dim3((unsigned)((plan.n_plain_rows + 7) / 8)), dim3(kWave), 0,
+  launch("plan_plain_masks", plain_masks_kernel,
+         dim3((unsigned)((plan.n_plain_rows + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
          plan.plain_masks.p, plan.plain_uniform.p);
 }

@@ -862,6 +862,9 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
 #ifndef CFX_PLAIN_WAVES
 #define CFX_PLAIN_WAVES 6
 #endif
+#ifndef CFX_VEC_G
+#define CFX_VEC_G 8 // lanes per row of the vector gather (512^3: G=4 3.05 ms, G=8 2.89 ms, G=2 4.67 ms)
+#endif
 #ifndef CFX_PLAIN_G
 #define CFX_PLAIN_G 4 // lanes per plain row (measured at 512^3: G=8,R=3 3.55 ms; G=4,R=6 3.14 ms; G=16 5.1 ms)
 #endif
@@ -1602,7 +1605,8 @@ void run_vector(cfx_form_s* L, double* b)
     if (stn.usable) { A.slot4 = stn.slot4.p; A.diagpos = stn.diagpos.p; }
   }
   if (A.n_active > 0)
-    launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, 4>, row_grid((A.n_active + 15) / 16), dim3(kWave), 0,
+    launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,
+           row_grid((A.n_active + (kWave / CFX_VEC_G) - 1) / (kWave / CFX_VEC_G)), dim3(kWave), 0,
            A);
 }
 

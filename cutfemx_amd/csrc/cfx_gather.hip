@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
   Geo<TDIM> g;
   load_cell<TDIM>(A.x, A.conn, cell, g);
   jacobian<TDIM>(g);
-  const double h = cell_diameter<TDIM>(g);
+  const bool nitsche = A.kernel == CFX_L_NITSCHE_RHS;
+  const double h = nitsche ? cell_diameter<TDIM>(g) : 1.0; // only the Nitsche datum needs h (and K)
   int npts;
   const double *pts, *wts, *pdata = nullptr;
   double wscale = 1.0;

@@ -325,6 +325,8 @@ struct cfx_cut_s
   std::vector<cfx::DevArray<double>> ls_values;
   cfx::DevArray<int8_t> domain; // [nls*ncells]
   cfx::DevArray<uint8_t> host_mask; // cut(level_set, cells, tdim): 1 on the candidate cells; empty = all cells
+  // inside / cut cells per compaction tile of level set 0, counted by the classification itself (empty: not available)
+  cfx::DevArray<int32_t> tiles_inside, tiles_cut;
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
 };

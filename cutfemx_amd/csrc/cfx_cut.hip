@@ -142,13 +142,15 @@ __global__ void __launch_bounds__(kBlock) sign_codes_kernel(int64_t n, const dou
 #endif
 template <int ND>
 __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const int32_t* __restrict__ dofmap,
-                                                          const uint8_t* __restrict__ code, int8_t* __restrict__ domain)
+                                                          const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
+                                                          int32_t* tiles_inside, int32_t* tiles_cut)
 {
   // U cells per thread, a block-wide stride apart: U independent 16 B/lane streaming loads in
   // flight per lane before the first dependent level-set gather
   constexpr int U = CFX_CLASSIFY_UNROLL;
   const int64_t c0 = (int64_t)blockIdx.x * (kBlock * U) + threadIdx.x;
   int32_t d[U][ND];
+  int n_in = 0, n_cut = 0;
 #pragma unroll
   for (int u = 0; u < U; ++u)
   {
@@ -175,6 +177,22 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const 
 #pragma unroll
     for (int i = 0; i < ND; ++i) all &= code[d[u][i]];
     domain[c] = all == 1u ? (int8_t)CFX_INSIDE : (all == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+    n_in += all == 1u ? 1 : 0;
+    n_cut += (all != 1u && all != 2u) ? 1 : 0;
+  }
+  // the two selector scans every solve starts with ("phi<0", "phi=0") get their tile counts here
+  if (tiles_inside)
+  {
+    static_assert(kByteTile % (kBlock * U) == 0, "classification blocks must nest in compaction tiles");
+    int tot_in, tot_cut;
+    (void)block_exclusive_scan<int>(n_in, tot_in);
+    (void)block_exclusive_scan<int>(n_cut, tot_cut);
+    if (threadIdx.x == 0)
+    {
+      const int64_t tile = ((int64_t)blockIdx.x * (kBlock * U)) / kByteTile;
+      if (tot_in) atomicAdd(&tiles_inside[tile], tot_in);
+      if (tot_cut) atomicAdd(&tiles_cut[tile], tot_cut);
+    }
   }
 }
 
@@ -989,12 +1007,21 @@ void classify(cfx_cut_t cut)
     launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
            codes.p);
     const uint8_t* phi = codes.p;
+    int32_t *t_in = nullptr, *t_cut = nullptr;
+    if (k == 0 && cut->host_mask.n == 0)
+    {
+      const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
+      cut->tiles_inside.alloc(ntiles); cut->tiles_cut.alloc(ntiles);
+      cut->tiles_inside.zero(); cut->tiles_cut.zero();
+      t_in = cut->tiles_inside.p; t_cut = cut->tiles_cut.p;
+    }
+    else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
     switch (cut->ls_ndofs_cell)
     {
-    case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
-    case 10: launch("classify", classify_kernel<10>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom); break;
+    case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
+    case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
+    case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
+    case 10: launch("classify", classify_kernel<10>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
     default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported level-set element (dofs per cell must be 3, 4, 6 or 10)");
     }
   }
@@ -1014,7 +1041,13 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
   DevArray<int32_t> out;
   const uint8_t* bytes = reinterpret_cast<const uint8_t*>(cut->domain.p) + (int64_t)pred.sel.ls[0] * cut->mesh->ncells;
   if (pred.sel.n == 1 && (reinterpret_cast<uintptr_t>(bytes) & 15) == 0)
-    compact_bytes("locate_entities", cut->mesh->ncells, bytes, DomainMask{pred.sel.mask[0]}, out); // 1 B/cell stream
+  {
+    // "phi<0" / "phi=0" of the first level set: the classification already counted the tiles
+    const int32_t* known = nullptr;
+    if (pred.sel.ls[0] == 0 && cut->tiles_inside.n > 0)
+      known = pred.sel.mask[0] == 1 ? cut->tiles_inside.p : (pred.sel.mask[0] == 2 ? cut->tiles_cut.p : nullptr);
+    compact_bytes("locate_entities", cut->mesh->ncells, bytes, DomainMask{pred.sel.mask[0]}, out, known); // 1 B/cell stream
+  }
   else
     compact("locate_entities", cut->mesh->ncells, pred, out);
   auto res = cut->located.emplace(selector, std::move(out));

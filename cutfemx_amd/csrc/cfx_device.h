@@ -188,16 +188,22 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
 }
 
 // `bytes` must be 16-byte aligned
+// `tile_counts` (optional): matches per tile of kByteTile bytes already known to the caller
 template <typename ByteTest>
-inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, ByteTest test, DevArray<int32_t>& out)
+inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, ByteTest test, DevArray<int32_t>& out,
+                             const int32_t* tile_counts = nullptr)
 {
   const int64_t ntiles = (n + kByteTile - 1) / kByteTile;
   if (ntiles == 0) { out.alloc(0); return 0; }
-  DevArray<int32_t> counts(ntiles);
+  DevArray<int32_t> counts;
   DevArray<int64_t> offsets(ntiles + 1);
-  launch(name, compact_bytes_count_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
-         counts.p);
-  exclusive_scan(counts.p, offsets.p, ntiles);
+  if (!tile_counts)
+  {
+    counts.alloc(ntiles);
+    launch(name, compact_bytes_count_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
+           counts.p);
+  }
+  exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles);
   const int64_t total = read_scalar(offsets.p + ntiles);
   out.alloc(total);
   launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,

@@ -305,10 +305,10 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     }
     if "assemble_rows_plain" in kernels:      # the p1 kernel then only serves the interface rows
         alg_bytes.pop("assemble_rows_p1")
-    if "pattern_plain" in kernels:            # the hashed kernel then only serves the interface rows
+    if "plan_plain_masks" in kernels:         # the hashed kernel then only serves the interface rows
         alg_bytes.pop("pattern_rows")
-        alg_bytes["pattern_plain"] = (B_PATTERN_PER_CELL * info["n_inside"] + B_PATTERN_PER_ROW
-                                      * info.get("active_dofs", info.get("active_dofs_owned", 0)))
+        alg_bytes["plan_plain_masks"] = (B_PATTERN_PER_CELL * info["n_inside"] + B_PATTERN_PER_ROW
+                                         * info.get("active_dofs", info.get("active_dofs_owned", 0)))
     roof = {}
     for name, ab in alg_bytes.items():
         if name in kernels and ab:

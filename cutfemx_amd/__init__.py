@@ -8,8 +8,8 @@ package needs no GPU, calling into it does.
 """
 from . import fem
 from . import extensions
-from .cut import (CutData, FacetRows, RuntimeQuadratureRules, cut, full_cell_rules, ghost_penalty_facets,
-                  interior_facets_for_cells,
+from .cut import (CutData, FacetRows, RuntimeQuadratureRules, cut, exterior_facets, full_cell_rules, full_facet_rules,
+                  ghost_penalty_facets, interior_facets_for_cells,
                   level_set_value, locate_entities, locate_entities_device, normal, runtime_quadrature,
                   runtime_quadratures, update)
 from .mesh import Function, FunctionSpace, Mesh, box_lagrange2_dofmap, box_mesh_arrays, lagrange_dofmap
@@ -17,6 +17,6 @@ from .mesh import Function, FunctionSpace, Mesh, box_lagrange2_dofmap, box_mesh_
 __all__ = [
     "CutData", "FacetRows", "RuntimeQuadratureRules", "cut", "update", "locate_entities",
     "locate_entities_device", "runtime_quadrature", "runtime_quadratures", "full_cell_rules",
-    "ghost_penalty_facets", "interior_facets_for_cells", "normal", "level_set_value", "Mesh", "FunctionSpace", "Function",
+    "ghost_penalty_facets", "interior_facets_for_cells", "exterior_facets", "full_facet_rules", "normal", "level_set_value", "Mesh", "FunctionSpace", "Function",
     "box_mesh_arrays", "box_lagrange2_dofmap", "lagrange_dofmap", "fem", "extensions",
 ]

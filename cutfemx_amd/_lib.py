@@ -19,6 +19,7 @@ INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
 CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
+K_JUMP = 9
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
@@ -31,7 +32,8 @@ class CutOptions(C.Structure):
 class RulesView(C.Structure):
     _fields_ = [("tdim", C.c_int32), ("gdim", C.c_int32), ("nq", C.c_int64), ("nr", C.c_int64),
                 ("points", C.c_void_p), ("weights", C.c_void_p), ("offsets", C.c_void_p),
-                ("parent_map", C.c_void_p)]
+                ("parent_map", C.c_void_p), ("host_width", C.c_int32), ("reserved", C.c_int32),
+                ("host_rows", C.c_void_p), ("host_verts", C.c_void_p)]
 
 
 class Integral(C.Structure):
@@ -63,7 +65,8 @@ SYMBOLS = [
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
-    "cfx_cut_restrict", "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
+    "cfx_cut_restrict", "cfx_cut_create_facets", "cfx_exterior_facets", "cfx_full_facet_rules",
+    "cfx_facet_rules_to_cells", "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
     "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_interior_facets_for_cells", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",

@@ -312,6 +312,11 @@ struct cfx_rules_s
   int64_t nq = 0, nr = 0;
   cfx::DevArray<double> points, weights;
   cfx::DevArray<int32_t> offsets, parent_map;
+  // rules hosted by facets (cut(level_set, facets, tdim-1)): tdim == mesh tdim - 1, points are coordinates of
+  // the host facet's reference simplex spanned by host_verts, parent_map = the caller's facet ids
+  int host_width = 0;                 // 0: hosted by cells; 2: (cell, lf) rows; 4: (c0, lf0, c1, lf1) rows
+  cfx::DevArray<int32_t> host_rows;   // [nr*host_width]
+  cfx::DevArray<int32_t> host_verts;  // [nr*(tdim+1)] mesh vertices of the host facet, in host order
 };
 
 struct cfx_cut_s
@@ -329,6 +334,16 @@ struct cfx_cut_s
   cfx::DevArray<int32_t> tiles_inside, tiles_cut;
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
+  // facet hosts (cut(level_set, facets, tdim-1), cut.cpp:540-591): the hosts are n_hosts facets of the mesh;
+  // ls_dofmap then holds the level-set dofs of each host ([n_hosts*tdim]) and domain has n_hosts entries per level set
+  int host_width = 0;                 // 0: the hosts are the mesh cells
+  int64_t n_hosts = 0;
+  cfx::DevArray<int32_t> host_ids;    // parent_entities
+  cfx::DevArray<int32_t> host_rows;   // [n_hosts*host_width]
+  cfx::DevArray<int32_t> host_verts;  // [n_hosts*tdim]
+  std::map<std::string, cfx::DevArray<int32_t>> located_ids; // located host indices mapped to parent entity ids
+  int64_t nhosts() const { return host_width ? n_hosts : mesh->ncells; }
+  int host_dim() const { return host_width ? mesh->tdim - 1 : mesh->tdim; }
 };
 
 struct cfx_space_s
@@ -356,6 +371,7 @@ struct cfx_integral_dev
   cfx::DevArray<int32_t> entities;
   int64_t n_entities = 0;
   cfx_rules_t rules = nullptr;
+  int64_t n_std = 0; // interior-facet integrals with facet-hosted rules: entities [n_std, n_entities) are the rules' rows
   cfx::DevArray<double> point_data;
   cfx::DevArray<double> coefficient; // dof values of a CFX_F_COEFFICIENT field
   double params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -387,6 +403,7 @@ struct cfx_row_plan
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
+  bool fold_ok = true;                // P1: every facet row shares all dofs but one per cell (continuous space)
   cfx::DevArray<int32_t> facet_rows;  // [nfacets*4]
   cfx::DevArray<uint8_t> facet_slot;  // facet integral slot of each row
   cfx::DevArray<int64_t> d2f_offsets; // dof -> facets incidence

@@ -11,6 +11,10 @@
 #include <cctype>
 #include <cstdlib>
 
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
 #include "cfx_device.h"
 
 #define CFX_QUAD_TABLE_QUALIFIER static __device__ const
@@ -985,6 +989,377 @@ __global__ void __launch_bounds__(kBlock) interior_facets_find_kernel(int64_t n,
   *reinterpret_cast<int4*>(cand + 4 * t) = r;
 }
 
+// ---------------------------------------------------------------------------
+// 8f-4 facet hosts: cut(level_set, facets, tdim - 1) (cut.cpp:540-591, 788-830).  The hosts are facets of
+// the mesh given as integration rows (cell, local facet[, cell1, local facet1]); host vertex j is either the
+// j-th vertex of cell0 that is not opposite the facet (ascending local index) or the caller's
+// entities_to_geometry row.  The sub-triangulation of a host is the (tdim-1)-dimensional marching case of its
+// P1 level-set values; points live on the host's reference simplex, weights carry the physical measure.
+// ---------------------------------------------------------------------------
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_hosts_kernel(int64_t n, const int32_t* __restrict__ rows, int width,
+                                                             const int32_t* __restrict__ geom,
+                                                             const int32_t* __restrict__ conn, int64_t ncells,
+                                                             const int32_t* __restrict__ ls_dofmap,
+                                                             int32_t* __restrict__ verts, int32_t* __restrict__ ls, int* bad)
+{
+  constexpr int NV = TDIM + 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = rows[i * width];
+  const int lf = rows[i * width + 1];
+  if (c < 0 || c >= ncells || lf < 0 || lf > TDIM) { *bad = 1; return; }
+  int32_t cv[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) cv[k] = conn[c * NV + k];
+  for (int j = 0; j < TDIM; ++j)
+  {
+    int loc = -1;
+    if (geom)
+    {
+      const int32_t g = geom[i * TDIM + j];
+      for (int k = 0; k < NV; ++k) loc = (k != lf && cv[k] == g) ? k : loc;
+    }
+    else
+      loc = j < lf ? j : j + 1;
+    if (loc < 0) { *bad = 2; return; }
+    int32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v = (k == loc) ? cv[k] : v;
+    verts[i * TDIM + j] = v;
+    ls[i * TDIM + j] = ls_dofmap[c * NV + loc];
+  }
+  if (width == 4)
+  {
+    const int64_t c1 = rows[i * 4 + 2];
+    const int lf1 = rows[i * 4 + 3];
+    if (c1 < 0 || c1 >= ncells || lf1 < 0 || lf1 > TDIM) { *bad = 1; return; }
+    // the same facet seen from cell1: every facet vertex of cell0 is a vertex of cell1 other than lf1
+    for (int k = 0; k < NV; ++k)
+    {
+      if (k == lf) continue;
+      bool found = false;
+      for (int m = 0; m < NV; ++m) found = found || (m != lf1 && conn[c1 * NV + m] == cv[k]);
+      if (!found) { *bad = 3; return; }
+    }
+  }
+}
+
+// sub-simplices of a host of dimension HD with sign mask `mask` in `part`
+template <int HD>
+__device__ __forceinline__ int host_subcount(int mask, int part)
+{
+  if constexpr (HD == 1)
+  {
+    const int nn = __popc(mask & 3);
+    return part == PART_IN ? (nn >= 1 ? 1 : 0) : (nn <= 1 ? 1 : 0);
+  }
+  else
+  {
+    const CutCase& cs = c_cases[0][mask & 7];
+    return part == PART_IN ? cs.n_in : cs.n_out;
+  }
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_count_kernel(int64_t ncut, const int32_t* __restrict__ cut_hosts,
+                                                             const int32_t* __restrict__ ls, const double* __restrict__ phi_v,
+                                                             int part, int nref, int32_t* __restrict__ n_rules,
+                                                             int32_t* __restrict__ n_points)
+{
+  constexpr int HD = TDIM - 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncut) return;
+  const int64_t h = cut_hosts[i];
+  double phi[HD + 1];
+#pragma unroll
+  for (int v = 0; v <= HD; ++v) phi[v] = phi_v[ls[h * TDIM + v]];
+  const int ns = host_subcount<HD>(sign_mask<HD>(phi), part);
+  n_rules[i] = ns > 0 ? 1 : 0;
+  n_points[i] = ns * nref;
+}
+
+// physical measure factor of a host: |x1 - x0| (segment) or |(x1 - x0) x (x2 - x0)| (triangle)
+template <int TDIM>
+__device__ __forceinline__ double host_measure(const double (*xv)[TDIM])
+{
+  if constexpr (TDIM == 2)
+  {
+    const double dx = xv[1][0] - xv[0][0], dy = xv[1][1] - xv[0][1];
+    return sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = xv[1][d] - xv[0][d]; b[d] = xv[2][d] - xv[0][d]; }
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    return sqrt(cx * cx + cy * cy + cz * cz);
+  }
+}
+
+// one thread per cut host (there are O(N^(tdim-2)) .. O(N^(tdim-1)) of them): one rule per host
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_emit_kernel(
+    int64_t ncut, const int32_t* __restrict__ cut_hosts, const double* __restrict__ x, const int32_t* __restrict__ verts,
+    const int32_t* __restrict__ ls, const double* __restrict__ phi_v, const int32_t* __restrict__ host_ids, int part,
+    int degree, const int32_t* __restrict__ rule_off, const int32_t* __restrict__ point_off, double* __restrict__ points,
+    double* __restrict__ weights, int32_t* __restrict__ offsets, int32_t* __restrict__ parent_map,
+    int32_t* __restrict__ rule_host)
+{
+  constexpr int HD = TDIM - 1, NV = HD + 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncut) return;
+  const int64_t h = cut_hosts[i];
+  double phi[NV], xv[NV][TDIM];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+  {
+    phi[v] = phi_v[ls[h * TDIM + v]];
+    const int64_t g = verts[h * TDIM + v];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) xv[v][d] = x[3 * g + d];
+  }
+  const int mask = sign_mask<HD>(phi);
+  const int ns = host_subcount<HD>(mask, part);
+  if (ns == 0) return;
+  const double measure = host_measure<TDIM>(xv);
+  int nref;
+  const double* wref;
+  const double* pref = ref_points<TDIM>(HD, degree, nref, wref);
+  const int32_t pbase = point_off[i], rbase = rule_off[i];
+  for (int k = 0; k < ns; ++k)
+  {
+    double V[NV][HD];
+    double dsub;
+    if constexpr (HD == 1)
+    {
+      // cut point from the negative vertex a towards the other vertex b
+      double A = 0.0, B = 1.0;
+      if (mask == 1 || mask == 2)
+      {
+        const int a = mask == 1 ? 0 : 1;
+        const double pa = a == 0 ? phi[0] : phi[1], pb = a == 0 ? phi[1] : phi[0];
+        const double t = pa / (pa - pb);
+        const double xa = a == 0 ? 0.0 : 1.0, xb = a == 0 ? 1.0 : 0.0;
+        const double q = xa + t * (xb - xa);
+        if (part == PART_IN) { A = xa; B = q; } else { A = q; B = xb; }
+      }
+      V[0][0] = A; V[1][0] = B;
+      dsub = B - A;
+    }
+    else
+    {
+      const CutCase& cs = c_cases[0][mask & 7];
+      const int8_t* sx = part == PART_IN ? cs.in[k] : cs.out[k];
+#pragma unroll
+      for (int j = 0; j < NV; ++j) local_point<2>(cs, sx[j], phi, V[j]);
+      dsub = (V[1][0] - V[0][0]) * (V[2][1] - V[0][1]) - (V[1][1] - V[0][1]) * (V[2][0] - V[0][0]);
+    }
+    const double scale = fabs(dsub) * measure;
+    for (int q = 0; q < nref; ++q)
+    {
+      const double* xi = pref + HD * q;
+      double l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < HD; ++t) l0 -= xi[t];
+      const int64_t o = pbase + k * nref + q;
+#pragma unroll
+      for (int d = 0; d < HD; ++d)
+      {
+        double v = l0 * V[0][d];
+#pragma unroll
+        for (int t = 0; t < HD; ++t) v += xi[t] * V[t + 1][d];
+        points[o * HD + d] = v;
+      }
+      weights[o] = wref[q] * scale;
+    }
+  }
+  parent_map[rbase] = host_ids[h];
+  rule_host[rbase] = (int32_t)h;
+  offsets[rbase + 1] = pbase + ns * nref;
+}
+
+// whole-host rules (the standard facets of a mixed measure): reference points, weights * host measure
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_full_rules_kernel(int64_t n, const int32_t* __restrict__ hosts,
+                                                                  const double* __restrict__ x,
+                                                                  const int32_t* __restrict__ verts,
+                                                                  const int32_t* __restrict__ host_ids, int degree,
+                                                                  double* __restrict__ points, double* __restrict__ weights,
+                                                                  int32_t* __restrict__ offsets, int32_t* __restrict__ parent_map,
+                                                                  int32_t* __restrict__ rule_host)
+{
+  constexpr int HD = TDIM - 1, NV = HD + 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t h = hosts ? hosts[i] : i;
+  double xv[NV][TDIM];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+  {
+    const int64_t g = verts[h * TDIM + v];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) xv[v][d] = x[3 * g + d];
+  }
+  const double measure = host_measure<TDIM>(xv);
+  int nref;
+  const double* wref;
+  const double* pref = ref_points<TDIM>(HD, degree, nref, wref);
+  for (int q = 0; q < nref; ++q)
+  {
+#pragma unroll
+    for (int d = 0; d < HD; ++d) points[(i * nref + q) * HD + d] = pref[q * HD + d];
+    weights[i * nref + q] = wref[q] * measure;
+  }
+  parent_map[i] = host_ids[h];
+  rule_host[i] = (int32_t)h;
+  offsets[i + 1] = (int32_t)((i + 1) * nref);
+  if (i == 0) offsets[0] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) gather_rows_kernel(int64_t n, const int32_t* __restrict__ idx, int width,
+                                                             const int32_t* __restrict__ src, int32_t* __restrict__ dst)
+{
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * width) return;
+  const int64_t i = t / width;
+  const int k = (int)(t - i * width);
+  dst[t] = src[(int64_t)idx[i] * width + k];
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_physical_points_kernel(int64_t nq, int64_t nr,
+                                                                       const int32_t* __restrict__ offsets,
+                                                                       const int32_t* __restrict__ verts,
+                                                                       const double* __restrict__ points,
+                                                                       const double* __restrict__ x, double* __restrict__ out)
+{
+  constexpr int HD = TDIM - 1;
+  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nq) return;
+  const int64_t r = rule_of_point(offsets, nr, q);
+  double lam[HD + 1];
+  lam[0] = 1.0;
+#pragma unroll
+  for (int t = 0; t < HD; ++t) { lam[t + 1] = points[q * HD + t]; lam[0] -= lam[t + 1]; }
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int j = 0; j <= HD; ++j) v += lam[j] * x[3 * (int64_t)verts[r * TDIM + j] + d];
+    out[q * TDIM + d] = v;
+  }
+}
+
+// facet-hosted rule r seen from cell `side` of its row: parent = that cell, points = the cell's reference
+// coordinates of the same physical points (barycentric weights moved to the cell's local vertices) --
+// what facet_runtime_quadrature_payload / interior_facet_runtime_quadrature_payload hand to the kernels
+// (python/cutfemx/_runintgen_adapter.py:605-680).  Rule i of the output is rule perm[i] of the input.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_to_cell_kernel(int64_t nq, int64_t nr, const int32_t* __restrict__ new_off,
+                                                               const int32_t* __restrict__ perm,
+                                                               const int32_t* __restrict__ offsets,
+                                                               const int32_t* __restrict__ rows, int width, int side,
+                                                               const int32_t* __restrict__ verts,
+                                                               const double* __restrict__ points,
+                                                               const double* __restrict__ weights,
+                                                               const int32_t* __restrict__ conn,
+                                                               double* __restrict__ out_points, double* __restrict__ out_weights,
+                                                               int32_t* __restrict__ out_parent)
+{
+  constexpr int HD = TDIM - 1, NV = TDIM + 1;
+  const int64_t p = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= nq) return;
+  const int64_t i = rule_of_point(new_off, nr, p);
+  const int64_t r = perm[i];
+  const int64_t q = offsets[r] + (p - new_off[i]);
+  const int64_t c = rows[r * width + 2 * side];
+  double lam[HD + 1];
+  lam[0] = 1.0;
+#pragma unroll
+  for (int t = 0; t < HD; ++t) { lam[t + 1] = points[q * HD + t]; lam[0] -= lam[t + 1]; }
+  double X[TDIM];
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) X[t] = 0.0;
+#pragma unroll
+  for (int j = 0; j <= HD; ++j)
+  {
+    const int32_t g = verts[r * TDIM + j];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) X[t] += (conn[c * NV + t + 1] == g) ? lam[j] : 0.0;
+  }
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) out_points[p * TDIM + t] = X[t];
+  out_weights[p] = weights[q];
+  if (p == new_off[i]) out_parent[i] = (int32_t)c;
+}
+
+__global__ void __launch_bounds__(kBlock) rule_cell_keys_kernel(int64_t nr, const int32_t* __restrict__ rows, int width,
+                                                                int side, int32_t* __restrict__ keys, int* unsorted)
+{
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nr) return;
+  const int32_t k = rows[r * width + 2 * side];
+  keys[r] = k;
+  if (r > 0 && rows[(r - 1) * width + 2 * side] > k) *unsorted = 1;
+}
+
+__global__ void __launch_bounds__(kBlock) permuted_counts_kernel(int64_t nr, const int32_t* __restrict__ perm,
+                                                                 const int32_t* __restrict__ offsets, int32_t* __restrict__ counts)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nr) return;
+  const int64_t r = perm ? perm[i] : i;
+  counts[i] = offsets[r + 1] - offsets[r];
+}
+
+__global__ void __launch_bounds__(kBlock) iota_kernel(int64_t n, int32_t* __restrict__ a)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) a[i] = (int32_t)i;
+}
+
+// exterior facets: per cell the bit mask of its local facets without a neighbour
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) exterior_mask_kernel(int64_t ncells, const int32_t* __restrict__ conn,
+                                                               const int64_t* __restrict__ v2c_off,
+                                                               const int32_t* __restrict__ v2c, uint8_t* __restrict__ mask)
+{
+  constexpr int NV = TDIM + 1;
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= ncells) return;
+  unsigned m = 0;
+  for (int lf = 0; lf < NV; ++lf)
+  {
+    int32_t nb;
+    int nlf;
+    if (!facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf)) m |= 1u << lf;
+  }
+  mask[c] = (uint8_t)m;
+}
+
+__global__ void __launch_bounds__(kBlock) exterior_count_kernel(int64_t n, const int32_t* __restrict__ cells,
+                                                                const uint8_t* __restrict__ mask, int32_t* __restrict__ counts)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n) counts[i] = __popc((unsigned)mask[cells[i]]);
+}
+
+__global__ void __launch_bounds__(kBlock) exterior_pack_kernel(int64_t n, const int32_t* __restrict__ cells,
+                                                               const uint8_t* __restrict__ mask,
+                                                               const int64_t* __restrict__ offs, int32_t* __restrict__ rows)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int32_t c = cells[i];
+  unsigned m = mask[c];
+  int64_t o = offs[i];
+  for (int lf = 0; lf < 4; ++lf)
+    if ((m >> lf) & 1u) { rows[2 * o] = c; rows[2 * o + 1] = lf; ++o; }
+}
+
 struct ByteSet
 {
   const uint8_t* b;
@@ -999,7 +1374,7 @@ struct IsCut
 
 void classify(cfx_cut_t cut)
 {
-  const int64_t nc = cut->mesh->ncells;
+  const int64_t nc = cut->nhosts();
   for (int k = 0; k < cut->nls; ++k)
   {
     int8_t* dom = cut->domain.p + (int64_t)k * nc;
@@ -1018,6 +1393,7 @@ void classify(cfx_cut_t cut)
     else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
     switch (cut->ls_ndofs_cell)
     {
+    case 2: launch("classify", classify_kernel<2>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
     case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
     case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
     case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
@@ -1030,6 +1406,7 @@ void classify(cfx_cut_t cut)
       launch("restrict_domain", restrict_domain_kernel, grid_for(nc), dim3(kBlock), 0, nc, cut->host_mask.p,
              cut->domain.p + (int64_t)k * nc);
   cut->located.clear();
+  cut->located_ids.clear();
   cut->ghost_rows.clear();
 }
 
@@ -1037,22 +1414,25 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
 {
   auto it = cut->located.find(selector);
   if (it != cut->located.end()) return it->second;
-  SelectorPred pred{cut->domain.p, cut->mesh->ncells, parse_selector(selector.c_str(), cut->nls)};
+  const int64_t nh = cut->nhosts();
+  SelectorPred pred{cut->domain.p, nh, parse_selector(selector.c_str(), cut->nls)};
   DevArray<int32_t> out;
-  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(cut->domain.p) + (int64_t)pred.sel.ls[0] * cut->mesh->ncells;
+  const uint8_t* bytes = reinterpret_cast<const uint8_t*>(cut->domain.p) + (int64_t)pred.sel.ls[0] * nh;
   if (pred.sel.n == 1 && (reinterpret_cast<uintptr_t>(bytes) & 15) == 0)
   {
     // "phi<0" / "phi=0" of the first level set: the classification already counted the tiles
     const int32_t* known = nullptr;
     if (pred.sel.ls[0] == 0 && cut->tiles_inside.n > 0)
       known = pred.sel.mask[0] == 1 ? cut->tiles_inside.p : (pred.sel.mask[0] == 2 ? cut->tiles_cut.p : nullptr);
-    compact_bytes("locate_entities", cut->mesh->ncells, bytes, DomainMask{pred.sel.mask[0]}, out, known); // 1 B/cell stream
+    compact_bytes("locate_entities", nh, bytes, DomainMask{pred.sel.mask[0]}, out, known); // 1 B/cell stream
   }
   else
-    compact("locate_entities", cut->mesh->ncells, pred, out);
+    compact("locate_entities", nh, pred, out);
   auto res = cut->located.emplace(selector, std::move(out));
   return res.first->second;
 }
+
+void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bool whole_hosts, cfx_rules_t* out);
 
 } // namespace
 
@@ -1104,6 +1484,7 @@ int cfx_cut_restrict(cfx_cut_t cut, const int32_t* cells, int64_t n)
 {
   CFX_API_BEGIN
   require(cut && (cells || n == 0) && n >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_restrict: null argument");
+  require(cut->host_width == 0, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_restrict: the cut is hosted by facets (pass the subset to cfx_cut_create_facets)");
   const int64_t nc = cut->mesh->ncells;
   DevArray<int32_t> dcells = to_device(cells, n);
   cut->host_mask.alloc(nc);
@@ -1131,9 +1512,9 @@ int cfx_cut_info(cfx_cut_t cut, int* tdim, int* gdim, int64_t* ncells, int* nls)
 {
   CFX_API_BEGIN
   require(cut != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_info: null handle");
-  if (tdim) *tdim = cut->mesh->tdim;
+  if (tdim) *tdim = cut->host_dim();
   if (gdim) *gdim = cut->mesh->gdim;
-  if (ncells) *ncells = cut->mesh->ncells;
+  if (ncells) *ncells = cut->nhosts();
   if (nls) *nls = cut->nls;
   CFX_API_END
 }
@@ -1143,7 +1524,7 @@ int cfx_cut_domain(cfx_cut_t cut, int ls, const int8_t** domain)
   CFX_API_BEGIN
   require(cut && domain, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_domain: null argument");
   require(ls >= 0 && ls < cut->nls, CFX_ERR_OUT_OF_RANGE, "level-set index out of range");
-  *domain = cut->domain.p + (int64_t)ls * cut->mesh->ncells;
+  *domain = cut->domain.p + (int64_t)ls * cut->nhosts();
   CFX_API_END
 }
 
@@ -1152,6 +1533,21 @@ int cfx_locate_entities(cfx_cut_t cut, const char* selector, const int32_t** ent
   CFX_API_BEGIN
   require(cut && selector && entities && n, CFX_ERR_INVALID_ARGUMENT, "cfx_locate_entities: null argument");
   const DevArray<int32_t>& a = locate(cut, selector);
+  if (cut->host_width != 0)
+  {
+    // host_parent_index (cut.cpp:352-359): facet hosts answer with the caller's facet ids
+    auto it = cut->located_ids.find(selector);
+    if (it == cut->located_ids.end())
+    {
+      DevArray<int32_t> ids(a.n);
+      if (a.n > 0)
+        launch("locate_entities", gather_rows_kernel, grid_for(a.n), dim3(kBlock), 0, a.n, a.p, 1, cut->host_ids.p, ids.p);
+      it = cut->located_ids.emplace(selector, std::move(ids)).first;
+    }
+    *entities = it->second.p;
+    *n = it->second.n;
+    return CFX_OK;
+  }
   *entities = a.p;
   *n = a.n;
   CFX_API_END
@@ -1166,6 +1562,11 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
                                               + "' (only 'straight' is implemented)");
   require(order >= 0, CFX_ERR_INVALID_ARGUMENT, "quadrature order must be non-negative");
   require(order <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT, "quadrature order exceeds the built-in tables");
+  if (cut->host_width != 0)
+  {
+    facet_runtime_quadrature(cut, selector, order, false, out);
+    return CFX_OK;
+  }
   require(cut->nls == 1, CFX_ERR_INVALID_ARGUMENT,
           "runtime quadrature for several level sets is not implemented");
   cfx_mesh_t mesh = cut->mesh;
@@ -1273,6 +1674,9 @@ int cfx_rules_view_get(cfx_rules_t r, cfx_rules_view* v)
   require(r && v, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_view_get: null argument");
   v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq; v->nr = r->nr;
   v->points = r->points.p; v->weights = r->weights.p; v->offsets = r->offsets.p; v->parent_map = r->parent_map.p;
+  v->host_width = r->host_width; v->reserved = 0;
+  v->host_rows = r->host_width ? r->host_rows.p : nullptr;
+  v->host_verts = r->host_width ? r->host_verts.p : nullptr;
   CFX_API_END
 }
 
@@ -1281,7 +1685,17 @@ int cfx_rules_physical_points(cfx_rules_t r, double* out)
   CFX_API_BEGIN
   require(r && out, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_physical_points: null argument");
   OutArray<double> o(out, r->nq * r->gdim, false);
-  if (r->nq > 0)
+  if (r->nq > 0 && r->host_width != 0)
+  {
+    // physical_points_for_host_mesh (cut.cpp:1344-1345)
+    if (r->mesh->tdim == 2)
+      launch("physical_points", facet_physical_points_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+             r->offsets.p, r->host_verts.p, r->points.p, r->mesh->x.p, o.dev);
+    else
+      launch("physical_points", facet_physical_points_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+             r->offsets.p, r->host_verts.p, r->points.p, r->mesh->x.p, o.dev);
+  }
+  else if (r->nq > 0)
   {
     if (r->tdim == 2)
       launch("physical_points", physical_points_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
@@ -1348,6 +1762,7 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
 {
   CFX_API_BEGIN
   require(cut && selector && rows && n, CFX_ERR_INVALID_ARGUMENT, "cfx_ghost_penalty_facets: null argument");
+  require(cut->host_width == 0, CFX_ERR_INVALID_ARGUMENT, "ghost_penalty_facets needs a cut hosted by the mesh cells");
   cfx_mesh_t mesh = cut->mesh;
   {
     auto it = cut->ghost_rows.find(selector);
@@ -1444,6 +1859,7 @@ int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double thre
 {
   CFX_API_BEGIN
   require(cut && selector && out, CFX_ERR_INVALID_ARGUMENT, "cfx_cell_aggregation_create: null argument");
+  require(cut->host_width == 0, CFX_ERR_INVALID_ARGUMENT, "Cell aggregation requires cell-hosted cut data."); // cell_aggregation.cpp:114
   require(threshold >= 0.0 && threshold <= 1.0, CFX_ERR_INVALID_ARGUMENT, "Volume fraction threshold must be in [0, 1].");
   require(root_policy == 0 || root_policy == 1, CFX_ERR_INVALID_ARGUMENT,
           "Unknown root policy. Expected 'interior_only' or 'interior_or_well_cut'.");
@@ -1567,6 +1983,277 @@ int cfx_cut_destroy(cfx_cut_t cut)
 {
   CFX_API_BEGIN
   delete cut;
+  CFX_API_END
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// 8f-4 facet hosts
+// ---------------------------------------------------------------------------
+namespace
+{
+void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bool whole_hosts, cfx_rules_t* out)
+{
+  cfx_mesh_t mesh = cut->mesh;
+  const int tdim = mesh->tdim, hd = tdim - 1;
+  require(cut->nls == 1, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature for several level sets is not implemented");
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = hd; r->gdim = mesh->gdim; r->host_width = cut->host_width;
+  DevArray<int32_t> rule_host;
+  const double* phi = cut->ls_values[0].p;
+  if (whole_hosts)
+  {
+    const DevArray<int32_t>* hosts = selector ? &locate(cut, selector) : nullptr;
+    const int64_t n = hosts ? hosts->n : cut->n_hosts;
+    const int nref = quad_npoints(hd, order);
+    require(n * nref < 2147483647LL, CFX_ERR_RUNTIME, "too many points for int32 offsets");
+    r->nr = n; r->nq = n * nref;
+    r->points.alloc(r->nq * hd); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
+    rule_host.alloc(n);
+    CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+    if (n > 0)
+    {
+      if (tdim == 2)
+        launch("facet_full_rules", facet_full_rules_kernel<2>, grid_for(n), dim3(kBlock), 0, n, hosts ? hosts->p : nullptr,
+               mesh->x.p, cut->host_verts.p, cut->host_ids.p, order, r->points.p, r->weights.p, r->offsets.p,
+               r->parent_map.p, rule_host.p);
+      else
+        launch("facet_full_rules", facet_full_rules_kernel<3>, grid_for(n), dim3(kBlock), 0, n, hosts ? hosts->p : nullptr,
+               mesh->x.p, cut->host_verts.p, cut->host_ids.p, order, r->points.p, r->weights.p, r->offsets.p,
+               r->parent_map.p, rule_host.p);
+    }
+  }
+  else
+  {
+    const Selector sel = parse_selector(selector, cut->nls);
+    require(sel.n == 1, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature expects a single-clause selector");
+    const int m = sel.mask[0];
+    require(m != 2, CFX_ERR_INVALID_ARGUMENT,
+            "runtime quadrature on facet hosts integrates the phi<0 / phi>0 part of the facets (the codimension-2 "
+            "set phi=0 is not implemented)");
+    const int part = (m & 1) ? PART_IN : PART_OUT;
+    const int nref = quad_npoints(hd, order);
+    const DevArray<int32_t>& cuth = locate(cut, "phi=0");
+    const int64_t ncut = cuth.n;
+    DevArray<int32_t> n_rules(ncut), n_points(ncut), rule_off(ncut + 1), point_off(ncut + 1);
+    if (ncut > 0)
+    {
+      if (tdim == 2)
+        launch("facet_count", facet_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cuth.p, cut->ls_dofmap.p, phi,
+               part, nref, n_rules.p, n_points.p);
+      else
+        launch("facet_count", facet_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cuth.p, cut->ls_dofmap.p, phi,
+               part, nref, n_rules.p, n_points.p);
+    }
+    DevArray<int64_t> point_off64(ncut + 1);
+    exclusive_scan(n_points.p, point_off64.p, ncut);
+    const int64_t nq = read_scalar(point_off64.p + ncut);
+    require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
+    exclusive_scan(n_points.p, point_off.p, ncut);
+    exclusive_scan(n_rules.p, rule_off.p, ncut);
+    const int64_t nr = read_scalar(rule_off.p + ncut);
+    r->nq = nq; r->nr = nr;
+    r->points.alloc(nq * hd); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);
+    rule_host.alloc(nr);
+    CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+    if (ncut > 0)
+    {
+      if (tdim == 2)
+        launch("facet_emit", facet_emit_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cuth.p, mesh->x.p,
+               cut->host_verts.p, cut->ls_dofmap.p, phi, cut->host_ids.p, part, order, rule_off.p, point_off.p,
+               r->points.p, r->weights.p, r->offsets.p, r->parent_map.p, rule_host.p);
+      else
+        launch("facet_emit", facet_emit_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cuth.p, mesh->x.p,
+               cut->host_verts.p, cut->ls_dofmap.p, phi, cut->host_ids.p, part, order, rule_off.p, point_off.p,
+               r->points.p, r->weights.p, r->offsets.p, r->parent_map.p, rule_host.p);
+    }
+  }
+  // the rules carry their hosts' rows and vertices: they outlive the cut object
+  r->host_rows.alloc(r->nr * cut->host_width);
+  r->host_verts.alloc(r->nr * tdim);
+  if (r->nr > 0)
+  {
+    launch("facet_gather_rows", gather_rows_kernel, grid_for(r->nr * cut->host_width), dim3(kBlock), 0, r->nr, rule_host.p,
+           cut->host_width, cut->host_rows.p, r->host_rows.p);
+    launch("facet_gather_rows", gather_rows_kernel, grid_for(r->nr * tdim), dim3(kBlock), 0, r->nr, rule_host.p, tdim,
+           cut->host_verts.p, r->host_verts.p);
+  }
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  *out = r.release();
+}
+} // namespace
+
+extern "C" {
+
+int cfx_exterior_facets(cfx_mesh_t mesh, int32_t** rows, int64_t* n_rows)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  require(mesh && rows && n_rows, CFX_ERR_INVALID_ARGUMENT, "cfx_exterior_facets: null argument");
+  const int64_t nc = mesh->ncells;
+  const Adjacency& adj = mesh->vertex_cells();
+  DevArray<uint8_t> mask(nc);
+  if (mesh->tdim == 2)
+    launch("exterior_facets", exterior_mask_kernel<2>, grid_for(nc), dim3(kBlock), 0, nc, mesh->conn.p, adj.offsets.p,
+           adj.cells.p, mask.p);
+  else
+    launch("exterior_facets", exterior_mask_kernel<3>, grid_for(nc), dim3(kBlock), 0, nc, mesh->conn.p, adj.offsets.p,
+           adj.cells.p, mask.p);
+  DevArray<int32_t> cells;
+  const int64_t m = compact("exterior_facets", nc, ByteSet{mask.p}, cells);
+  DevArray<int32_t> counts(m);
+  DevArray<int64_t> offs(m + 1);
+  int64_t total = 0;
+  if (m > 0)
+  {
+    launch("exterior_facets", exterior_count_kernel, grid_for(m), dim3(kBlock), 0, m, cells.p, mask.p, counts.p);
+    exclusive_scan(counts.p, offs.p, m);
+    total = read_scalar(offs.p + m);
+  }
+  int32_t* out = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * 2 * (size_t)(total > 0 ? total : 1)));
+  if (total > 0)
+    launch("exterior_facets", exterior_pack_kernel, grid_for(m), dim3(kBlock), 0, m, cells.p, mask.p, offs.p, out);
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  *rows = out;
+  *n_rows = total;
+  CFX_API_END
+}
+
+int cfx_cut_create_facets(cfx_mesh_t mesh, int64_t n, const int32_t* facet_ids, const int32_t* rows, int row_width,
+                          const int32_t* entity_geometry, int nls, const int32_t* ls_dofmap, int ls_ndofs_cell,
+                          int64_t ls_ndofs, const double* const* ls_values, const cfx_cut_options* opt, cfx_cut_t* out)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  require(mesh && out, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: null mesh/output");
+  require(n >= 0 && (rows || n == 0), CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: null facet rows");
+  require(row_width == 2 || row_width == 4, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_cut_create_facets: rows are (cell, local facet) or (cell0, local facet0, cell1, local facet1)");
+  require(nls >= 1 && ls_values, CFX_ERR_INVALID_ARGUMENT, "cutfemx.cut requires at least one level-set function");
+  require(nls <= 8, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: at most 8 level sets");
+  require(ls_dofmap && ls_ndofs > 0, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: empty level-set dofmap");
+  const int tdim = mesh->tdim;
+  require(ls_ndofs_cell == tdim + 1, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_cut_create_facets: facet hosts take a P1 level set (its dofs on a facet are its vertex dofs)");
+  ensure_cases();
+  auto cut = std::make_unique<cfx_cut_s>();
+  cut->mesh = mesh;
+  cut->nls = nls;
+  cut->ls_ndofs_cell = tdim; // dofs per host
+  cut->ls_ndofs = ls_ndofs;
+  if (opt) cut->options = *opt; else cfx_cut_options_default(&cut->options);
+  require(cut->options.cut_approximation_order == 1, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_cut_create_facets: only straight (order-1) cut approximation is implemented");
+  cut->host_width = row_width;
+  cut->n_hosts = n;
+  cut->host_rows.alloc(n * row_width);
+  cut->host_ids.alloc(n);
+  cut->host_verts.alloc(n * tdim);
+  cut->ls_dofmap.alloc(n * tdim);
+  {
+    DevArray<int32_t> drows = to_device(rows, n * row_width);
+    DevArray<int32_t> dgeom = to_device(entity_geometry, entity_geometry ? n * tdim : 0);
+    DevArray<int32_t> dls = to_device(ls_dofmap, mesh->ncells * (int64_t)ls_ndofs_cell);
+    DevArray<int> bad(1);
+    bad.zero();
+    if (n > 0)
+    {
+      CFX_HIP(hipMemcpyAsync(cut->host_rows.p, drows.p, sizeof(int32_t) * (size_t)(n * row_width), hipMemcpyDeviceToDevice,
+                             ctx().stream));
+      if (facet_ids)
+      {
+        DevArray<int32_t> dids = to_device(facet_ids, n);
+        CFX_HIP(hipMemcpyAsync(cut->host_ids.p, dids.p, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToDevice, ctx().stream));
+        CFX_HIP(hipStreamSynchronize(ctx().stream));
+      }
+      else
+        launch("iota", iota_kernel, grid_for(n), dim3(kBlock), 0, n, cut->host_ids.p);
+      const int32_t* geom = entity_geometry ? dgeom.p : nullptr;
+      if (tdim == 2)
+        launch("facet_hosts", facet_hosts_kernel<2>, grid_for(n), dim3(kBlock), 0, n, drows.p, row_width, geom, mesh->conn.p,
+               mesh->ncells, dls.p, cut->host_verts.p, cut->ls_dofmap.p, bad.p);
+      else
+        launch("facet_hosts", facet_hosts_kernel<3>, grid_for(n), dim3(kBlock), 0, n, drows.p, row_width, geom, mesh->conn.p,
+               mesh->ncells, dls.p, cut->host_verts.p, cut->ls_dofmap.p, bad.p);
+    }
+    const int b = read_scalar(bad.p);
+    require(b != 1, CFX_ERR_OUT_OF_RANGE, "cfx_cut_create_facets: cell index or local facet out of range");
+    require(b != 2, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: entity_geometry names a vertex that is not on the facet");
+    require(b != 3, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: the two (cell, local facet) pairs of a row are different facets");
+  }
+  for (int k = 0; k < nls; ++k)
+  {
+    require(ls_values[k] != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_create_facets: null level-set values");
+    cut->ls_values.push_back(to_device(ls_values[k], ls_ndofs));
+  }
+  cut->domain.alloc((int64_t)nls * n);
+  classify(cut.get());
+  *out = cut.release();
+  CFX_API_END
+}
+
+int cfx_full_facet_rules(cfx_cut_t cut, const char* selector, int order, cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(cut && out, CFX_ERR_INVALID_ARGUMENT, "cfx_full_facet_rules: null argument");
+  require(cut->host_width != 0, CFX_ERR_INVALID_ARGUMENT, "cfx_full_facet_rules: the cut is hosted by cells");
+  require(order >= 0 && order <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT, "quadrature order out of range");
+  facet_runtime_quadrature(cut, selector, order, true, out);
+  CFX_API_END
+}
+
+int cfx_facet_rules_to_cells(cfx_rules_t R, int side, cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(R && out, CFX_ERR_INVALID_ARGUMENT, "cfx_facet_rules_to_cells: null argument");
+  require(R->host_width != 0, CFX_ERR_INVALID_ARGUMENT, "cfx_facet_rules_to_cells: the rules are hosted by cells");
+  require(side == 0 || (side == 1 && R->host_width == 4), CFX_ERR_INVALID_ARGUMENT,
+          "cfx_facet_rules_to_cells: side is 0, or 1 for interior-facet rows");
+  cfx_mesh_t mesh = R->mesh;
+  const int tdim = mesh->tdim;
+  const int64_t nr = R->nr, nq = R->nq;
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = nr; r->nq = nq;
+  r->points.alloc(nq * tdim); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);
+  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  if (nr > 0)
+  {
+    // cell-hosted rules are consumed in ascending parent order (runs of one parent are contiguous)
+    DevArray<int32_t> keys(nr), perm(nr), counts(nr);
+    DevArray<int> unsorted(1);
+    unsorted.zero();
+    launch("facet_to_cells", rule_cell_keys_kernel, grid_for(nr), dim3(kBlock), 0, nr, R->host_rows.p, R->host_width, side,
+           keys.p, unsorted.p);
+    launch("iota", iota_kernel, grid_for(nr), dim3(kBlock), 0, nr, perm.p);
+    if (read_scalar(unsorted.p))
+    {
+      DevArray<int32_t> keys_out(nr), perm_out(nr);
+      size_t tmp_bytes = 0;
+      CFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, keys_out.p, perm.p, perm_out.p, (size_t)nr, 0, 32,
+                                        ctx().stream));
+      DevArray<uint8_t> tmp((int64_t)tmp_bytes);
+      CFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.p, keys_out.p, perm.p, perm_out.p, (size_t)nr, 0, 32,
+                                        ctx().stream));
+      CFX_HIP(hipStreamSynchronize(ctx().stream));
+      perm = std::move(perm_out);
+    }
+    launch("facet_to_cells", permuted_counts_kernel, grid_for(nr), dim3(kBlock), 0, nr, perm.p, R->offsets.p, counts.p);
+    exclusive_scan(counts.p, r->offsets.p, nr);
+    if (nq > 0)
+    {
+      if (tdim == 2)
+        launch("facet_to_cells", facet_to_cell_kernel<2>, grid_for(nq), dim3(kBlock), 0, nq, nr, r->offsets.p, perm.p,
+               R->offsets.p, R->host_rows.p, R->host_width, side, R->host_verts.p, R->points.p, R->weights.p, mesh->conn.p,
+               r->points.p, r->weights.p, r->parent_map.p);
+      else
+        launch("facet_to_cells", facet_to_cell_kernel<3>, grid_for(nq), dim3(kBlock), 0, nq, nr, r->offsets.p, perm.p,
+               R->offsets.p, R->host_rows.p, R->host_width, side, R->host_verts.p, R->points.p, R->weights.p, mesh->conn.p,
+               r->points.p, r->weights.p, r->parent_map.p);
+    }
+    CFX_HIP(hipStreamSynchronize(ctx().stream));
+  }
+  *out = r.release();
   CFX_API_END
 }
 

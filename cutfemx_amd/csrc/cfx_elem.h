@@ -299,8 +299,12 @@ __device__ __forceinline__ void cell_local_row(int kernel, const double* __restr
 template <int TDIM, int DEG, int BS>
 __device__ __forceinline__ void facet_local_row(int kernel, const double* __restrict__ params, int qdegree,
                                                 const Geo<TDIM>& g0, const Geo<TDIM>& g1, int lf0, int ia, int ik,
-                                                double* acc)
+                                                double* acc, int npts = 0, const double* __restrict__ pts = nullptr,
+                                                const double* __restrict__ wts = nullptr,
+                                                const double (*xhost)[TDIM] = nullptr)
 {
+  // pts != nullptr: a facet-hosted runtime rule (8f-4) -- npts points on the reference simplex spanned by the
+  // host vertices xhost, physical-measure weights; else the reference facet rule of degree qdegree
   constexpr int ND = Elem<TDIM, DEG>::ND;
   if (kernel == CFX_K_EXTENSION_L2)
   {
@@ -403,6 +407,14 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
   int nref;
   const double* wref;
   const double* pref = ref_rule(TDIM - 1, qdegree, nref, wref);
+  if (pts)
+  {
+    nref = npts; pref = pts; wref = wts; scale = 1.0;
+#pragma unroll
+    for (int j = 0; j < TDIM; ++j)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) xf[j][d] = xhost[j][d];
+  }
   for (int q = 0; q < nref; ++q)
   {
     double l0 = 1.0, xq[TDIM];
@@ -458,6 +470,22 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
       for (int j = 0; j < 2 * ND; ++j)
 #pragma unroll
         for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * ji * jn[j] : 0.0;
+    }
+    else if (kernel == CFX_K_JUMP)
+    {
+      // gamma / h_avg [u][v]: the value jump of the macro basis is [N0, -N1]
+      const double wj = wref[q] * scale * params[0] / havg;
+      double vi = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { vi = (j == ia) ? N0[j] : vi; vi = (ND + j == ia) ? -N1[j] : vi; }
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+        {
+          acc[j * BS + b] += (b == ik) ? wj * vi * N0[j] : 0.0;
+          acc[(ND + j) * BS + b] -= (b == ik) ? wj * vi * N1[j] : 0.0;
+        }
     }
   }
 }

@@ -50,6 +50,10 @@ struct AsmArgs
   const double* lift_x0;
   double lift_alpha;
   const double* coeff; // dof values of a CFX_F_COEFFICIENT field (rank-1 source terms)
+  // interior-facet integrals with facet-hosted rules (8f-4): entity f of the integral with f >= n_std integrates
+  // over rule f - n_std (offsets / points / weights above, host vertices below); f0 = first entity of this launch
+  int64_t n_std, f0;
+  const int32_t* host_verts;
 };
 
 // ---------------------------------------------------------------------------
@@ -220,7 +224,23 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   double acc[NLOC];
 #pragma unroll
   for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
-  facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
+  if (A.host_verts && f + A.f0 >= A.n_std)
+  {
+    const int64_t r = f + A.f0 - A.n_std;
+    const int32_t q0 = A.offsets[r], q1 = A.offsets[r + 1];
+    double xhost[TDIM][TDIM];
+#pragma unroll
+    for (int j = 0; j < TDIM; ++j)
+    {
+      const int64_t v = A.host_verts[r * TDIM + j];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) xhost[j][d] = A.x[3 * v + d];
+    }
+    facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc, q1 - q0,
+                                   A.points + (int64_t)q0 * (TDIM - 1), A.weights + q0, xhost);
+  }
+  else
+    facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
   if (A.kernel == CFX_K_EXTENSION_L2 && A.point_data)
   {
     const double factor = A.point_data[f]; // cellwise beta of the pair's bad cell
@@ -395,6 +415,13 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     A.n = single ? 1 : I.n_entities;
     A.entities = I.entities.p + (single ? 4 * only_index : 0);
     A.point_data = I.point_data.n > 0 ? I.point_data.p + (single ? only_index : 0) : nullptr; // per-pair factors
+    A.f0 = single ? only_index : 0;
+    A.n_std = I.n_std;
+    if (I.rules)
+    {
+      A.offsets = I.rules->offsets.p; A.points = I.rules->points.p; A.weights = I.rules->weights.p;
+      A.host_verts = I.rules->host_verts.p;
+    }
     launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
     return;
   }
@@ -614,10 +641,20 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     require(in.qdegree >= 0 && in.qdegree <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT,
             "cfx_form_create: quadrature degree out of range");
     if (in.type == CFX_INTERIOR_FACET)
-      require((in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2) && in.rules == nullptr,
+    {
+      require(in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2 || in.kernel == CFX_K_JUMP,
               CFX_ERR_INVALID_ARGUMENT,
-              "cfx_form_create: interior-facet integrals support the ghost-penalty and extension-penalty kernels "
-              "with standard quadrature");
+              "cfx_form_create: interior-facet integrals support the ghost-penalty, value-jump and extension-penalty kernels");
+      if (in.rules)
+        require(in.kernel != CFX_K_EXTENSION_L2 && in.rules->host_width == 4 && in.point_data == nullptr,
+                CFX_ERR_INVALID_ARGUMENT,
+                "cfx_form_create: runtime rules of an interior-facet integral are facet-hosted rules over interior rows "
+                "(cfx_cut_create_facets with row_width 4)");
+    }
+    else if (in.rules && in.rules->host_width != 0)
+      throw Error(CFX_ERR_INVALID_ARGUMENT,
+                  "cfx_form_create: a cell integral takes cell-hosted rules (pass facet-hosted rules through "
+                  "cfx_facet_rules_to_cells)");
     else
       require(in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS || in.kernel == CFX_K_NITSCHE
                   || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS,
@@ -645,7 +682,24 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     const int64_t width = in.type == CFX_INTERIOR_FACET ? 4 : 1;
     I.entities = to_device(in.entities, in.n_entities * width);
     I.rules = in.rules;
-    if (in.rules)
+    I.n_std = in.n_entities;
+    if (in.rules && in.type == CFX_INTERIOR_FACET)
+    {
+      // one entity list for the pattern / row plan / staging: [standard rows, the rules' rows]
+      require(in.rules->mesh == V->mesh, CFX_ERR_INVALID_ARGUMENT, "rules belong to a different mesh");
+      const int64_t nr = in.rules->nr;
+      DevArray<int32_t> all((in.n_entities + nr) * 4);
+      if (in.n_entities > 0)
+        CFX_HIP(hipMemcpyAsync(all.p, I.entities.p, sizeof(int32_t) * 4 * (size_t)in.n_entities, hipMemcpyDeviceToDevice,
+                               ctx().stream));
+      if (nr > 0)
+        CFX_HIP(hipMemcpyAsync(all.p + 4 * in.n_entities, in.rules->host_rows.p, sizeof(int32_t) * 4 * (size_t)nr,
+                               hipMemcpyDeviceToDevice, ctx().stream));
+      CFX_HIP(hipStreamSynchronize(ctx().stream));
+      I.entities = std::move(all);
+      I.n_entities = in.n_entities + nr;
+    }
+    else if (in.rules)
     {
       require(in.rules->mesh == V->mesh, CFX_ERR_INVALID_ARGUMENT, "rules belong to a different mesh");
       if (in.point_data) I.point_data = to_device(in.point_data, in.rules->nq * (int64_t)in.point_stride);

@@ -1393,11 +1393,11 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     }
   }
   bool has_facets = false;
-  A.fold_facets = 1;
+  A.fold_facets = plan.fold_ok ? 1 : 0;
   for (const auto& I : a->integrals)
   {
     has_facets = has_facets || I.type == CFX_INTERIOR_FACET;
-    if (I.type == CFX_INTERIOR_FACET && I.kernel != CFX_K_GHOST_GRADJUMP) A.fold_facets = 0; // (bad, root) pairs
+    if (I.type == CFX_INTERIOR_FACET && I.kernel == CFX_K_EXTENSION_L2) A.fold_facets = 0; // (bad, root) pairs
   }
   if (has_facets && plan.nfacets > 0)
   {

@@ -118,7 +118,25 @@ __global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ pa
 __global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ a, int strict, int* flag)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i + 1 < n && (a[i] > a[i + 1] || (strict && a[i] == a[i + 1]))) *flag = 1;
+  if (i + 1 < n && (a[i] > a[i + 1] || (strict && a[i] == a[i + 1]))) atomicOr(flag, 1);
+}
+
+// P1 facet folding (assemble_rows_kernel) needs every facet row to join two cells that share all dofs but one
+// each -- a continuous P1 space on a conforming mesh.  Flags bit 1 otherwise (DG spaces, extension pairs).
+__global__ void plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
+                                       int nd, int* flag)
+{
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= nf) return;
+  const int64_t c0 = rows[4 * f], c1 = rows[4 * f + 2];
+  int nfree = 0;
+  for (int j = 0; j < nd; ++j)
+  {
+    bool shared = false;
+    for (int i = 0; i < nd; ++i) shared = shared || dofmap[c1 * nd + j] == dofmap[c0 * nd + i];
+    nfree += shared ? 0 : 1;
+  }
+  if (nfree != 1) atomicOr(flag, 2);
 }
 
 // (counts / offsets / cursors are indexed by the dof's position in the special-row list: the
@@ -735,8 +753,13 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
+  if (P.nfacets > 0 && nd == V->mesh->tdim + 1)
+    launch("plan_check_fold", plan_check_fold_kernel, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+           V->dofmap.p, nd, flag.p);
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
-  if (read_scalar(flag.p)) P.usable = false;
+  const int flags = read_scalar(flag.p);
+  if (flags & 1) P.usable = false;
+  P.fold_ok = !(flags & 2);
   P.built = true;
   return P;
 }

@@ -34,6 +34,7 @@ class RuntimeQuadratureRules:
         self.tdim, self.gdim = v.tdim, v.gdim
         self.total_points = int(v.nq)
         self.num_rules = int(v.nr)
+        self.host_width = int(v.host_width)   # 0: hosted by cells; 2 / 4: by exterior / interior facets
         self._cache: dict = {}
 
     @classmethod
@@ -85,6 +86,23 @@ class RuntimeQuadratureRules:
         _ = self.physical_points
         return self
 
+    @property
+    def host_rows(self):
+        """Facet-hosted rules: the integration row (cell, local facet[, cell1, local facet1]) of each rule's facet."""
+        if not self.host_width:
+            raise ValueError("rules hosted by cells have no facet rows")
+        return self._get("host_rows", self._view.host_rows, self.num_rules * self.host_width, np.int32,
+                         (-1, self.host_width))
+
+    def to_cells(self, side: int = 0) -> "RuntimeQuadratureRules":
+        """Facet-hosted rules seen from cell `side` of their facets: cell-hosted rules (points in that cell's
+        reference coordinates, parents ascending) for dx-type integrals -- the mapping of
+        facet_runtime_quadrature_payload / interior_facet_runtime_quadrature_payload
+        (python/cutfemx/_runintgen_adapter.py:605-680)."""
+        h = C.c_void_p()
+        _lib.check(_lib.lib().cfx_facet_rules_to_cells(self._h, int(side), C.byref(h)))
+        return RuntimeQuadratureRules(h, self.mesh)
+
     def slice_by_parent(self, cell_lo: int, cell_hi: int, device):
         """Zero-copy sub-rule-set of the rules whose parent cell lies in
         [cell_lo, cell_hi) (parents are ascending): `offsets` / `parent_map` are
@@ -132,9 +150,15 @@ class CutData:
     def mesh(self) -> Mesh:
         return self._level_sets[0].function_space.mesh
 
+    def _info(self):
+        t, g, n, k = C.c_int(), C.c_int(), C.c_int64(), C.c_int()
+        _lib.check(_lib.lib().cfx_cut_info(self._h, C.byref(t), C.byref(g), C.byref(n), C.byref(k)))
+        return t.value, g.value, n.value, k.value
+
     @property
     def tdim(self) -> int:
-        return self.mesh.tdim
+        """Dimension of the hosts (cut.cpp:571): the mesh cells, or tdim - 1 for facet hosts."""
+        return self._info()[0]
 
     @property
     def gdim(self) -> int:
@@ -142,7 +166,8 @@ class CutData:
 
     @property
     def num_local_cells(self) -> int:
-        return self.mesh.num_cells
+        """Number of hosts (cut.cpp:572)."""
+        return self._info()[2]
 
     @property
     def level_set_names(self) -> tuple[str, ...]:
@@ -253,17 +278,24 @@ def _value_ptrs(level_sets, keep):
 
 def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "auto",
         cut_approximation_order: int = 1, max_refinement_iterations: int = 8,
-        edge_max_depth: int = 20) -> CutData:
-    """Classify all cells against one or more level sets (python/cutfemx/cut.py:186-249)."""
+        edge_max_depth: int = 20, facet_ids=None, entity_geometry=None) -> CutData:
+    """Classify all cells -- or the given host entities -- against one or more level sets
+    (python/cutfemx/cut.py:186-249).  entity_dim = tdim: `entities` is a cell subset; entity_dim = tdim - 1:
+    `entities` are facets as integration rows ((n, 2) exterior / (n, 4) interior array or FacetRows; the engine
+    has no global facet numbering), numbered by position or by `facet_ids`; `entity_geometry` (n, tdim)
+    optionally fixes the host vertex order (dolfinx entities_to_geometry)."""
     level_sets = _normalise_level_sets(level_set)
     names = frozen_level_set_names([f.name for f in level_sets])
     if entities is None and entity_dim is not None:
         raise ValueError("entity_dim is only valid when entities are supplied")
     if entities is not None and entity_dim is None:
         raise ValueError("entity_dim must be supplied when entities are supplied")
-    if entities is not None and entity_dim != level_sets[0].function_space.mesh.tdim:
-        raise NotImplementedError("facet-hosted cuts are outside the accelerated path (SURVEY 8f-4)")
     V = level_sets[0].function_space
+    tdim = V.mesh.tdim
+    if entities is not None and (entity_dim <= 0 or entity_dim > tdim):
+        raise ValueError("cutfemx::cut entity_dim must select positive-dimensional mesh entities")  # cut.cpp:546-550
+    if entities is not None and entity_dim < tdim - 1:
+        raise NotImplementedError("hosts of codimension > 1 are not implemented")
     for f in level_sets[1:]:
         if f.function_space is not V:
             raise ValueError("all level sets must share one function space")
@@ -273,6 +305,33 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
     keep: list = []
     vals = _value_ptrs(level_sets, keep)
     h = C.c_void_p()
+    if entities is not None and entity_dim == tdim - 1:
+        # facets as hosts (cut.cpp:540-591, python/tests/test_cut_api.py:171-187, 349-367): the facets are their
+        # integration rows; facet id = position in `entities` unless facet_ids says otherwise
+        if isinstance(entities, FacetRows):
+            rows_ptr, n, width = C.c_void_p(entities.ptr), entities.size, entities.width
+            keep.append(entities)
+        else:
+            rows = np.ascontiguousarray(np.asarray(entities, dtype=np.int32))
+            if rows.ndim != 2 or rows.shape[1] not in (2, 4):
+                raise ValueError("facet hosts are integration rows: (n, 2) exterior or (n, 4) interior")
+            rows_ptr, n, width = rows.ctypes.data_as(C.c_void_p), rows.shape[0], rows.shape[1]
+            keep.append(rows)
+        ids = None if facet_ids is None else np.ascontiguousarray(np.asarray(facet_ids, dtype=np.int32))
+        geom = None if entity_geometry is None else np.ascontiguousarray(np.asarray(entity_geometry, dtype=np.int32))
+        if ids is not None and ids.size != n:
+            raise ValueError("facet_ids must name every facet")
+        if geom is not None and geom.size != n * tdim:
+            raise ValueError("entity_geometry must hold tdim vertices per facet")
+        _lib.check(_lib.lib().cfx_cut_create_facets(
+            V.mesh._h, C.c_int64(n), None if ids is None else ids.ctypes.data_as(C.c_void_p), rows_ptr, int(width),
+            None if geom is None else geom.ctypes.data_as(C.c_void_p), len(level_sets), V._dofmap_ptr, V.ndofs_cell,
+            C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
+        cd = CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
+        cd._entities = entities if ids is None else ids
+        cd._entity_dim = int(entity_dim)
+        cd._host_rows = entities
+        return cd
     _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
                                          C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
     cd = CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
@@ -334,14 +393,14 @@ class FacetRows:
     (python/cutfemx/wrappers/cut.cpp:54-115).  The engine has no global facet
     numbering, so the rows ARE the facet identity."""
 
-    def __init__(self, ptr, n, owner):
-        self.ptr, self.size, self._owner = ptr, int(n), owner
+    def __init__(self, ptr, n, owner, width: int = 4):
+        self.ptr, self.size, self._owner, self.width = ptr, int(n), owner, int(width)
         self._rows = None
 
     @property
     def rows(self) -> np.ndarray:
         if self._rows is None:
-            self._rows = _lib.download(self.ptr, 4 * self.size, np.int32).reshape(-1, 4)
+            self._rows = _lib.download(self.ptr, self.width * self.size, np.int32).reshape(-1, self.width)
         return self._rows
 
     def __len__(self):
@@ -371,6 +430,23 @@ def interior_facets_for_cells(mesh: Mesh, cells, *, include_ghosts: bool = False
     _lib.check(_lib.lib().cfx_interior_facets_for_cells(mesh._h, cells.ctypes.data_as(C.c_void_p), C.c_int64(cells.size),
                                                         C.byref(p), C.byref(n)))
     return FacetRows(p.value, n.value, owner=_OwnedRows(p.value))
+
+
+def exterior_facets(mesh: Mesh) -> FacetRows:
+    """Boundary facets as (cell, local facet) integration rows, ascending: dolfinx
+    exterior_facet_indices + facet_integration_rows (python/cutfemx/wrappers/cut.cpp:54-115)."""
+    p, n = C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_exterior_facets(mesh._h, C.byref(p), C.byref(n)))
+    return FacetRows(p.value, n.value, owner=_OwnedRows(p.value), width=2)
+
+
+def full_facet_rules(cut_data: CutData, ls_part: str | None, order: int) -> RuntimeQuadratureRules:
+    """Whole-facet rules over the hosts of a facet-hosted cut matching `ls_part` (None: all hosts): the
+    standard facets of a mixed [facets, rules] measure (python/tests/test_cut_api.py:527-560)."""
+    h = C.c_void_p()
+    sel = None if ls_part is None else _engine_selector(cut_data, ls_part)
+    _lib.check(_lib.lib().cfx_full_facet_rules(cut_data._h, sel, int(order), C.byref(h)))
+    return RuntimeQuadratureRules(h, cut_data.mesh)
 
 
 def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, include_ghosts: bool = False):

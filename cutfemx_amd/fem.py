@@ -10,6 +10,8 @@ domain data the reference puts in `ufl.Measure(subdomain_data=...)`:
     dx(subdomain_data=[inside_cells, rules]) -> Integral(..., cells=inside_cells, rules=rules)
     dx(subdomain_data=interface_rules)       -> Integral(..., rules=interface_rules, point_data=normals)
     dS(subdomain_data=ghost_facets)          -> Integral(..., facets=ghost_facets)
+    dS(subdomain_data=[facets, facet_rules]) -> Integral(..., facets=facets, rules=facet_rules)   (rules hosted by interior facets)
+    ds(subdomain_data=[facets, facet_rules]) -> Integral(..., rules=full_facet_rules(...).to_cells()), Integral(..., rules=facet_rules.to_cells())
 """
 from __future__ import annotations
 
@@ -25,6 +27,7 @@ from .mesh import FunctionSpace
 MASS, STIFFNESS, NITSCHE, GHOST_GRADJUMP, ELASTICITY = (_lib.K_MASS, _lib.K_STIFFNESS, _lib.K_NITSCHE,
                                                         _lib.K_GHOST_GRADJUMP, _lib.K_ELASTICITY)
 EXTENSION_L2 = _lib.K_EXTENSION_L2
+JUMP = _lib.K_JUMP
 SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS, _lib.F_COEFFICIENT
 
@@ -46,6 +49,9 @@ class Integral:
         keep = self._keep = []
         itype = _lib.CELL
         ent_ptr, n_ent = None, 0
+        if self.facets is None and self.rules is not None and self.rules.host_width == 4 and self.kernel in (
+                _lib.K_GHOST_GRADJUMP, _lib.K_JUMP):
+            itype = _lib.INTERIOR_FACET       # dS over runtime rules only
         if self.facets is not None:
             itype = _lib.INTERIOR_FACET
             if isinstance(self.facets, FacetRows):
@@ -269,7 +275,8 @@ def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np
     """Local tensor of one entity (for local-entry parity checks)."""
     V = a.function_space
     I = a.integrals[integral]
-    nloc = V.ndofs_cell * V.bs * (2 if I.facets is not None else 1)
+    facet_type = I.facets is not None or (I.rules is not None and I.rules.host_width == 4)
+    nloc = V.ndofs_cell * V.bs * (2 if facet_type else 1)
     Ae = np.zeros((nloc, nloc) if a.rank == 2 else (nloc,))
     _lib.check(_lib.lib().cfx_tabulate_entity(a._h, integral, C.c_int64(index), int(use_rule),
                                               Ae.ctypes.data_as(C.c_void_p)))

@@ -62,6 +62,8 @@ extern "C" {
  * entity rows are (bad_cell, 0, root_cell, 0) from cfx_extension_pairs; params[0]=beta, qdegree =
  * quadrature degree on the bad cell; point_data (stride 1, one value per pair) = cellwise beta factor */
 #define CFX_K_EXTENSION_L2 8
+#define CFX_K_JUMP 9             /* interior facets: gamma / h_avg [u][v] (DG / skeleton value-jump penalty);
+                                   params[0]=gamma */
 #define CFX_L_SOURCE 101        /* f v; params[0]=field id, params[1]=scale    */
 #define CFX_L_NITSCHE_RHS 102   /* -dn(v) g + gamma/h g v; params[0]=gamma,
                                    params[1]=field id of g, params[2]=scale    */
@@ -101,7 +103,12 @@ typedef struct
   const double* points;      /* [nq*tdim] parent-reference coordinates (HBM)   */
   const double* weights;     /* [nq] physical-measure weights (HBM)            */
   const int32_t* offsets;    /* [nr+1] (HBM)                                   */
-  const int32_t* parent_map; /* [nr] parent background cell (HBM)              */
+  const int32_t* parent_map; /* [nr] parent background cell (HBM); facet-hosted rules: the caller's facet id */
+  /* facet-hosted rules (cfx_cut_create_facets): tdim above is the facet dimension */
+  int32_t host_width;        /* 0: hosted by cells; 2 | 4: width of host_rows                   */
+  int32_t reserved;
+  const int32_t* host_rows;  /* [nr*host_width] integration row of each rule's facet (HBM), or NULL */
+  const int32_t* host_verts; /* [nr*(tdim+1)] mesh vertices spanning each rule's reference simplex, or NULL */
 } cfx_rules_view;
 
 /* One integral of a form: the (kernel_ptr, entities, active_coeffs, custom_data)
@@ -114,13 +121,16 @@ typedef struct
  * (forms of one space that reference the same arrays share derived tables). */
 typedef struct
 {
-  int32_t type;            /* CFX_CELL | CFX_INTERIOR_FACET                    */
+  int32_t type;            /* CFX_CELL | CFX_INTERIOR_FACET (exterior-facet terms are CFX_CELL integrals over
+                              cfx_facet_rules_to_cells rules)                                          */
   int32_t kernel;          /* CFX_K_* (rank 2) or CFX_L_* (rank 1)             */
   int32_t qdegree;         /* standard quadrature degree for uncut entities    */
   int32_t point_stride;    /* doubles per point in point_data                  */
   const int32_t* entities; /* cells: ids; interior facets: (c0,lf0,c1,lf1)     */
   int64_t n_entities;
-  cfx_rules_t rules;       /* or NULL                                          */
+  cfx_rules_t rules;       /* or NULL.  CFX_CELL: cell-hosted rules; CFX_INTERIOR_FACET: facet-hosted rules
+                              over interior rows (cfx_cut_create_facets, row_width 4) -- the cut facets of
+                              a dS measure, `entities` being its standard facets                      */
   const double* point_data;/* per-point coefficients aligned with rules, or NULL */
   double params[8];
   const double* coefficient; /* dof values (ndofs) of the coefficient Function when a field id is
@@ -225,6 +235,39 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector,
  * whose two cells both belong to `cells`, as (c0, lf0, c1, lf1) rows with c0 < c1, ascending.  *rows is a
  * device array the caller releases with cfx_device_free. */
 int cfx_interior_facets_for_cells(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int32_t** rows, int64_t* n_rows);
+
+/* ---- facet hosts: cutfemx::cut(mesh, level_sets, entities, entity_dim = tdim - 1)
+ *      (cpp/cutfemx/cut/cut.cpp:540-591 build_entity_mesh_view, :788-830, :1022-1063 build_entity_level_sets;
+ *      tests python/tests/test_cut_api.py:171-187, 349-367, 424-496) -----------------------------------------
+ * The hosts are n facets of the mesh.  A facet is handed over the way DOLFINx integrates over it: as its
+ * integration row (cell, local facet) for exterior facets (row_width 2) or (cell0, local facet0, cell1,
+ * local facet1) for interior facets (row_width 4) -- facet_integration_rows(), python/cutfemx/wrappers/cut.cpp:54-115.
+ * facet_ids[n] (NULL: 0..n-1) are the caller's facet numbers: locate_entities and rules.parent_map answer with
+ * them (host_parent_index, cut.cpp:352-359).  entity_geometry [n*tdim] (NULL: the vertices of cell0 other than
+ * the one opposite the facet, ascending local index) is the host vertex order of entities_to_geometry()
+ * (cut.cpp:567-569): the reference simplex of host i is spanned by its vertices in that order.
+ * ls_dofmap is the CELL dofmap of the P1 level sets, as for cfx_cut_create.
+ * On the returned handle: cfx_cut_info reports tdim - 1 and n; cfx_cut_domain / cfx_locate_entities /
+ * cfx_cut_update work per host; cfx_runtime_quadrature(cut, "phi<0" | "phi>0", order) gives one rule per cut
+ * host with points on the host's reference simplex (view.tdim = tdim - 1), physical-measure weights and
+ * parent_map = facet ids; cfx_rules_physical_points works on such rules.  Everything that needs cell hosts
+ * (cfx_cut_restrict, normals, ghost facets, aggregation) returns CFX_ERR_INVALID_ARGUMENT. */
+int cfx_cut_create_facets(cfx_mesh_t mesh, int64_t n, const int32_t* facet_ids, const int32_t* rows, int row_width,
+                          const int32_t* entity_geometry, int n_level_sets, const int32_t* ls_dofmap, int ls_ndofs_cell,
+                          int64_t ls_ndofs, const double* const* ls_values, const cfx_cut_options* opt, cfx_cut_t* out);
+/* exterior_facet_indices() + facet_integration_rows(): the (cell, local facet) rows of the boundary facets,
+ * ascending; *rows is a device array released with cfx_device_free. */
+int cfx_exterior_facets(cfx_mesh_t mesh, int32_t** rows, int64_t* n_rows);
+/* rules over whole hosts -- the standard facets of a mixed [facets, rules] measure (test_cut_api.py:527-560)
+ * taken through the same path: the hosts matching `selector` (NULL: all), reference points of `order`,
+ * weights * facet measure. */
+int cfx_full_facet_rules(cfx_cut_t facet_cut, const char* selector, int order, cfx_rules_t* out);
+/* facet_runtime_quadrature_payload / interior_facet_runtime_quadrature_payload
+ * (python/cutfemx/_runintgen_adapter.py:605-680): the same points seen from cell `side` (0, or 1 for interior
+ * rows) of each rule's facet -- cell-hosted rules (view.tdim = tdim, parent_map = that cell, ascending) that
+ * any CFX_CELL integral takes, which is how exterior-facet terms (ds: mass, source, Nitsche with the facet
+ * normal as point_data) are assembled. */
+int cfx_facet_rules_to_cells(cfx_rules_t facet_rules, int side, cfx_rules_t* out);
 
 /* ---- cell aggregation (extension stabilisation): cutfemx::extensions::create_cell_aggregation,
  *      cpp/cutfemx/extensions/cell_aggregation.{h,cpp}, python/cutfemx/extensions.py -------------

@@ -385,6 +385,17 @@ static void subtriangulate(int tdim, const double* phi, subtri* s)
     if (phi[v] < 0.0) neg[nn++] = v; else pos[np++] = v;
   }
   s->npts = nv;
+  if (tdim == 1)
+  {
+    /* segment host of a facet-hosted cut in 2-D (8f-4): a = negative end, b = the other end */
+    if (nn == 0) { s->n_out = 1; s->out[0][0] = 0; s->out[0][1] = 1; return; }
+    if (nn == 2) { s->n_in = 1; s->in[0][0] = 0; s->in[0][1] = 1; return; }
+    const int a = neg[0], b = pos[0];
+    const int q = cut_point(s, 1, a, b, phi);
+    s->n_in = 1; s->in[0][0] = a; s->in[0][1] = q;
+    s->n_out = 1; s->out[0][0] = q; s->out[0][1] = b;
+    return;
+  }
   if (tdim == 2)
   {
     if (nn == 0) { s->n_out = 1; set_simplex(s->out[0], 3, 0, 1, 2, 0); return; }
@@ -458,6 +469,7 @@ static void subtriangulate(int tdim, const double* phi, subtri* s)
 /* ------------------------------------------------------------------------ */
 static double det_sub(int tdim, double V[4][3])
 {
+  if (tdim == 1) return V[1][0] - V[0][0];
   if (tdim == 2)
     return (V[1][0] - V[0][0]) * (V[2][1] - V[0][1]) - (V[1][1] - V[0][1]) * (V[2][0] - V[0][0]);
   double a[3], b[3], c[3];
@@ -587,6 +599,116 @@ int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
         nq += nref;
       }
       out->parent_map[nr] = (int32_t)c;
+      out->offsets[nr + 1] = (int32_t)nq;
+      ++nr;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* 8f-4 facet hosts: cut(level_set, facets, tdim-1) (cut.cpp:540-591, 788-830, */
+/* 1022-1063).  Host i is the facet spanned by the mesh vertices verts[i*tdim..] */
+/* with level-set dofs ls[i*tdim..]; its rule lives on the (tdim-1)-simplex of   */
+/* those vertices, weights carry the physical measure, parent_map = ids[i]       */
+/* (host_parent_index, cut.cpp:352-359).  whole != 0: whole-host rules over the  */
+/* hosts whose domain code is in `mask` (the standard facets of a mixed          */
+/* measure); else one rule per INTERSECTED host over its phi<0 / phi>0 part.     */
+/* rule_host[r] = host index of rule r (caller frees).                           */
+/* ------------------------------------------------------------------------ */
+static double host_measure(int tdim, double xv[3][3])
+{
+  if (tdim == 2)
+  {
+    const double dx = xv[1][0] - xv[0][0], dy = xv[1][1] - xv[0][1];
+    return sqrt(dx * dx + dy * dy);
+  }
+  double a[3], b[3];
+  for (int d = 0; d < 3; ++d) { a[d] = xv[1][d] - xv[0][d]; b[d] = xv[2][d] - xv[0][d]; }
+  const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+  return sqrt(cx * cx + cy * cy + cz * cz);
+}
+
+int orc_facet_runtime_quadrature(const orc_mesh* mesh, int64_t n, const int32_t* verts, const int32_t* ls,
+                                 const int32_t* ids, const double* ls_values, const int8_t* domain,
+                                 const char* selector, int order, int whole, orc_rules* out, int32_t** rule_host)
+{
+  sel_clause cl[4];
+  int mask = 7;
+  if (selector)
+  {
+    if (parse_selector(selector, 1, cl, 4) != 1) return -1;
+    mask = cl[0].mask;
+  }
+  const int want_in = mask & 1;
+  if (!whole && (mask == 2 || ((mask & 1) && (mask & 4)))) return -1;
+  const int tdim = mesh->tdim, hd = tdim - 1, nv = hd + 1;
+  int nref; const double *pref, *wref;
+  ref_rule(hd, order, &nref, &pref, &wref);
+  int64_t nr = 0, nq = 0;
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    if (pass == 1)
+    {
+      memset(out, 0, sizeof(*out));
+      out->tdim = hd; out->nq = nq; out->nr = nr;
+      out->points = (double*)malloc(sizeof(double) * (size_t)(nq * hd + 1));
+      out->weights = (double*)malloc(sizeof(double) * (size_t)(nq + 1));
+      out->offsets = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+      out->parent_map = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+      *rule_host = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+      out->offsets[0] = 0;
+      nr = 0; nq = 0;
+    }
+    for (int64_t h = 0; h < n; ++h)
+    {
+      subtri s;
+      int ns;
+      if (whole)
+      {
+        if (!((mask >> (domain[h] + 1)) & 1)) continue;
+        double none[3] = {-1.0, -1.0, -1.0};
+        subtriangulate(hd, none, &s); /* the whole host as one "inside" simplex */
+        ns = 1;
+      }
+      else
+      {
+        if (domain[h] != ORC_INTERSECTED) continue;
+        double phi[3];
+        for (int i = 0; i < nv; ++i) phi[i] = ls_values[ls[h * tdim + i]];
+        subtriangulate(hd, phi, &s);
+        ns = want_in ? s.n_in : s.n_out;
+        if (ns == 0) continue;
+      }
+      if (pass == 0) { nr += 1; nq += (int64_t)ns * nref; continue; }
+      double xv[3][3];
+      for (int i = 0; i < nv; ++i)
+        for (int d = 0; d < 3; ++d) xv[i][d] = mesh->x[3 * (int64_t)verts[h * tdim + i] + d];
+      const double measure = host_measure(tdim, xv);
+      for (int k = 0; k < ns; ++k)
+      {
+        const int* sx = (whole || want_in) ? s.in[k] : s.out[k];
+        double V[4][3];
+        for (int i = 0; i < nv; ++i)
+          for (int d = 0; d < hd; ++d) V[i][d] = s.P[sx[i]][d];
+        const double scale = fabs(det_sub(hd, V)) * measure;
+        for (int q = 0; q < nref; ++q)
+        {
+          const double* xi = pref + hd * q;
+          double l0 = 1.0;
+          for (int t = 0; t < hd; ++t) l0 -= xi[t];
+          for (int d = 0; d < hd; ++d)
+          {
+            double v = l0 * V[0][d];
+            for (int t = 0; t < hd; ++t) v += xi[t] * V[t + 1][d];
+            out->points[(nq + q) * hd + d] = v;
+          }
+          out->weights[nq + q] = wref[q] * scale;
+        }
+        nq += nref;
+      }
+      out->parent_map[nr] = ids ? ids[h] : (int32_t)h;
+      (*rule_host)[nr] = (int32_t)h;
       out->offsets[nr + 1] = (int32_t)nq;
       ++nr;
     }
@@ -974,7 +1096,7 @@ static void cell_kernel(const orc_mesh* m, const orc_space* V, const orc_integra
 /* Ae is (2 nd)^2 with block layout [[00,01],[10,11]]                        */
 /* ref: assemble_matrix_impl.h:537-542; python/demo/demo_poisson.py:189-198 */
 static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integral* I,
-                         const int32_t* row, double* Ae)
+                         const int32_t* row, int64_t idx, double* Ae)
 {
   const int tdim = m->tdim, gdim = m->gdim, nv = tdim + 1;
   const int nd = V->ndofs_cell, bs = V->bs, nloc = 2 * nd * bs;
@@ -1049,6 +1171,18 @@ static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integr
   }
   int nref; const double *pref, *wref;
   ref_rule(tdim - 1, I->qdegree, &nref, &pref, &wref);
+  if (I->host_verts && idx >= I->n_std)
+  {
+    /* facet-hosted runtime rule (8f-4): points on the simplex of the host vertices, physical weights */
+    const orc_rules* R = I->rules;
+    const int64_t r = idx - I->n_std;
+    nref = R->offsets[r + 1] - R->offsets[r];
+    pref = R->points + (int64_t)R->offsets[r] * (tdim - 1);
+    wref = R->weights + R->offsets[r];
+    scale = 1.0;
+    for (int j = 0; j < tdim; ++j)
+      for (int d = 0; d < 3; ++d) xf[j][d] = m->x[3 * (int64_t)I->host_verts[r * tdim + j] + d];
+  }
   for (int q = 0; q < nref; ++q)
   {
     const double* xi = pref + (tdim - 1) * q;
@@ -1092,6 +1226,17 @@ static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integr
           for (int kk = 0; kk < bs; ++kk)
             Ae[(i * bs + kk) * nloc + j * bs + kk] += w * jn[i] * jn[j];
     }
+    else if (I->kernel == ORC_K_JUMP)
+    {
+      /* gamma / h_avg [u][v] */
+      double jv[2 * MAXND];
+      for (int i = 0; i < nd; ++i) { jv[i] = N0[i]; jv[nd + i] = -N1[i]; }
+      const double wj = wref[q] * scale * I->params[0] / havg;
+      for (int i = 0; i < 2 * nd; ++i)
+        for (int j = 0; j < 2 * nd; ++j)
+          for (int kk = 0; kk < bs; ++kk)
+            Ae[(i * bs + kk) * nloc + j * bs + kk] += wj * jv[i] * jv[j];
+    }
   }
 }
 
@@ -1106,7 +1251,7 @@ int orc_tabulate_entity(const orc_mesh* mesh, const orc_space* V,
 {
   if (I->type == ORC_INTERIOR_FACET)
   {
-    facet_kernel(mesh, V, I, I->entities + 4 * idx, Ae);
+    facet_kernel(mesh, V, I, I->entities + 4 * idx, idx, Ae);
     if (I->kernel == ORC_K_EXTENSION_L2 && I->point_data)
     {
       /* cellwise (DG0) beta: beta_cell_values[bad_cell] gathered per pair by the caller */
@@ -1198,7 +1343,7 @@ int orc_create_sparsity(const orc_mesh* mesh, const orc_space* V,
       const orc_integral* I = &integrals[ii];
       for (int part = 0; part < 2; ++part)
       {
-        const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+        const int64_t ne = part == 0 ? I->n_entities : ((I->rules && I->type == ORC_CELL) ? I->rules->nr : 0);
         for (int64_t e = 0; e < ne; ++e)
         {
           const int n = entity_dofs(V, I, e, part, dofs);
@@ -1275,7 +1420,7 @@ int orc_assemble_matrix(const orc_mesh* mesh, const orc_space* V,
     const orc_integral* I = &integrals[ii];
     for (int part = 0; part < 2; ++part)
     {
-      const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+      const int64_t ne = part == 0 ? I->n_entities : ((I->rules && I->type == ORC_CELL) ? I->rules->nr : 0);
       for (int64_t e = 0; e < ne; ++e)
       {
         const int n = entity_dofs(V, I, e, part, dofs);
@@ -1305,7 +1450,7 @@ int orc_assemble_vector(const orc_mesh* mesh, const orc_space* V,
     const orc_integral* I = &integrals[ii];
     for (int part = 0; part < 2; ++part)
     {
-      const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+      const int64_t ne = part == 0 ? I->n_entities : ((I->rules && I->type == ORC_CELL) ? I->rules->nr : 0);
       for (int64_t e = 0; e < ne; ++e)
       {
         const int n = entity_dofs(V, I, e, part, dofs);
@@ -1400,7 +1545,7 @@ int orc_apply_lifting(const orc_mesh* mesh, const orc_space* V,
     const orc_integral* I = &integrals[ii];
     for (int part = 0; part < 2; ++part)
     {
-      const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+      const int64_t ne = part == 0 ? I->n_entities : ((I->rules && I->type == ORC_CELL) ? I->rules->nr : 0);
       for (int64_t e = 0; e < ne; ++e)
       {
         const int n = entity_dofs(V, I, e, part, dofs);
@@ -1440,7 +1585,7 @@ int64_t orc_active_cells(const orc_integral* integrals, int n_integrals,
       }
     else
       for (int64_t e = 0; e < I->n_entities; ++e) flag[I->entities[e]] = 1;
-    if (I->rules)
+    if (I->rules && I->type == ORC_CELL)
       for (int64_t r = 0; r < I->rules->nr; ++r) flag[I->rules->parent_map[r]] = 1;
   }
   int64_t n = 0;

@@ -44,6 +44,7 @@ enum {
   ORC_K_GHOST_GRADJUMP_VEC = 7,
   ORC_K_EXTENSION_L2 = 8,   /* beta (v|bad - E v|root)(u|bad - E u|root) over the bad cell; pairs (bad,0,root,0) as
                                interior-facet-type entities; params[0]=beta, point_data (stride 1) = per-pair factor */
+  ORC_K_JUMP = 9,           /* interior facets: gamma / h_avg [u][v]  (params[0]=gamma)         */
   ORC_L_SOURCE = 101,       /* f v, f = analytic id params[0], scale params[1] */
   ORC_L_NITSCHE_RHS = 102   /* -dn(v) g + gamma/h g v, gamma=params[0], g id params[1], scale params[2] */
 };
@@ -77,6 +78,10 @@ typedef struct {
   const double* point_data;/* per-point coefficients aligned with rules points  */
   double params[8];
   const double* coefficient; /* dof values of the coefficient Function, or NULL */
+  /* interior-facet integrals with facet-hosted rules (8f-4): entities [n_std, n_entities) are the rows of the
+     rules' facets, host_verts [nr*tdim] the mesh vertices spanning each rule's reference simplex; else NULL */
+  int64_t n_std;
+  const int32_t* host_verts;
 } orc_integral;
 
 typedef struct {
@@ -112,6 +117,9 @@ int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
                            const char* selector, int order, orc_rules* out);
 /* rule for a whole reference simplex of each listed cell (test helper that
    mirrors python/tests/quadrature_utils.py:12-70) */
+int orc_facet_runtime_quadrature(const orc_mesh* mesh, int64_t n, const int32_t* verts, const int32_t* ls,
+                                 const int32_t* ids, const double* ls_values, const int8_t* domain,
+                                 const char* selector, int order, int whole, orc_rules* out, int32_t** rule_host);
 int orc_full_cell_rules(const orc_mesh* mesh, const int32_t* cells, int64_t n,
                         int order, orc_rules* out);
 /* a12 */

@@ -20,6 +20,7 @@ INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
 CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
+K_JUMP = 9
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
@@ -34,7 +35,8 @@ class _Integral(C.Structure):
     _fields_ = [("type", C.c_int32), ("kernel", C.c_int32), ("qdegree", C.c_int32),
                 ("point_stride", C.c_int32), ("entities", C.c_void_p),
                 ("n_entities", C.c_int64), ("rules", C.c_void_p),
-                ("point_data", C.c_void_p), ("params", C.c_double * 8), ("coefficient", C.c_void_p)]
+                ("point_data", C.c_void_p), ("params", C.c_double * 8), ("coefficient", C.c_void_p),
+                ("n_std", C.c_int64), ("host_verts", C.c_void_p)]
 
 
 class _Mesh(C.Structure):
@@ -114,6 +116,8 @@ class Rules:
     offsets: np.ndarray
     parent_map: np.ndarray
     kind: str = "per_entity"
+    host_rows: np.ndarray | None = None    # facet-hosted rules (8f-4): integration row of each rule's facet
+    host_verts: np.ndarray | None = None   # ... and the mesh vertices spanning its reference simplex
 
     def cstruct(self):
         self.points = np.ascontiguousarray(self.points, dtype=np.float64)
@@ -255,7 +259,15 @@ class Integral:
         ent = np.zeros(0, dtype=np.int32) if self.entities is None else \
             np.ascontiguousarray(self.entities, dtype=np.int32)
         n_ent = ent.size // 4 if self.type == INTERIOR_FACET else ent.size
-        self._keep = [ent]
+        n_std, hv = n_ent, None
+        if self.type == INTERIOR_FACET and self.rules is not None:
+            # facet-hosted rules (8f-4): one entity list [standard rows, the rules' rows]
+            ent = np.ascontiguousarray(np.concatenate([ent.reshape(-1, 4), self.rules.host_rows.reshape(-1, 4)]),
+                                       dtype=np.int32)
+            n_ent = ent.shape[0]
+            hvarr = np.ascontiguousarray(self.rules.host_verts, dtype=np.int32)
+            hv = _p(hvarr)
+        self._keep = [ent] + ([hvarr] if hv is not None else [])
         rptr = None
         if self.rules is not None:
             rc = self.rules.cstruct()
@@ -273,7 +285,7 @@ class Integral:
             carr = np.ascontiguousarray(self.coefficient, dtype=np.float64)
             self._keep.append(carr)
             co = _p(carr)
-        return _Integral(self.type, self.kernel, self.qdegree, stride, _p(ent), n_ent, rptr, pd, params, co)
+        return _Integral(self.type, self.kernel, self.qdegree, stride, _p(ent), n_ent, rptr, pd, params, co, n_std, hv)
 
 
 def _integral_array(integrals):
@@ -415,3 +427,129 @@ def extension_pairs(agg: dict) -> np.ndarray:
     rows[:, 0] = ill
     rows[:, 2] = agg["root_cell"][ill]
     return rows
+
+
+# ---------------------------------------------------------------------------
+# 8f-4 facet hosts: cut(level_set, facets, tdim - 1)  (cpp/cutfemx/cut/cut.cpp:540-591, 788-830, 1022-1063;
+# python/tests/test_cut_api.py:171-187, 349-367, 424-496).  Facets are their integration rows.
+# ---------------------------------------------------------------------------
+def exterior_facets(mesh: Mesh) -> np.ndarray:
+    """(cell, local facet) rows of the facets that belong to one cell only, ascending
+    (dolfinx exterior_facet_indices + facet_integration_rows, python/cutfemx/wrappers/cut.cpp:54-115)."""
+    nv = mesh.tdim + 1
+    conn = mesh.conn.reshape(-1, nv)
+    keys, owner = [], []
+    for lf in range(nv):
+        keys.append(np.sort(np.delete(conn, lf, axis=1), axis=1))
+        owner.append(np.stack([np.arange(conn.shape[0]), np.full(conn.shape[0], lf)], axis=1))
+    keys, owner = np.concatenate(keys), np.concatenate(owner)
+    _, inv, counts = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
+    rows = owner[counts[inv.ravel()] == 1]
+    return rows[np.lexsort((rows[:, 1], rows[:, 0]))].astype(np.int32)
+
+
+@dataclass
+class FacetHosts:
+    rows: np.ndarray          # (n, 2) or (n, 4)
+    ids: np.ndarray           # (n,) the caller's facet numbers (parent_entities)
+    verts: np.ndarray         # (n, tdim) host vertex order
+    ls: np.ndarray            # (n, tdim) level-set dofs of the host vertices
+
+
+def facet_hosts(mesh: Mesh, rows, ls_dofmap, facet_ids=None, entity_geometry=None) -> FacetHosts:
+    """build_entity_mesh_view / build_entity_level_sets for facets: host vertex j is the j-th vertex of cell0
+    that is not opposite the facet (ascending local index), or the entity_geometry row."""
+    tdim, nv = mesh.tdim, mesh.tdim + 1
+    rows = np.asarray(rows, dtype=np.int32)
+    conn = mesh.conn.reshape(-1, nv)
+    lsd = np.asarray(ls_dofmap).reshape(-1, nv)
+    n = rows.shape[0]
+    verts = np.empty((n, tdim), dtype=np.int32)
+    ls = np.empty((n, tdim), dtype=np.int32)
+    for i in range(n):
+        c, lf = int(rows[i, 0]), int(rows[i, 1])
+        if not (0 <= c < conn.shape[0] and 0 <= lf <= tdim):
+            raise IndexError("cell index or local facet out of range")
+        if entity_geometry is None:
+            loc = [k for k in range(nv) if k != lf]
+        else:
+            loc = []
+            for g in np.asarray(entity_geometry).reshape(n, tdim)[i]:
+                k = [k for k in range(nv) if k != lf and conn[c, k] == g]
+                if not k:
+                    raise ValueError("entity_geometry names a vertex that is not on the facet")
+                loc.append(k[0])
+        verts[i], ls[i] = conn[c, loc], lsd[c, loc]
+        if rows.shape[1] == 4:
+            c1, lf1 = int(rows[i, 2]), int(rows[i, 3])
+            if not (0 <= c1 < conn.shape[0] and 0 <= lf1 <= tdim):
+                raise IndexError("cell index or local facet out of range")
+            if set(np.delete(conn[c1], lf1)) != set(verts[i]):
+                raise ValueError("the two (cell, local facet) pairs of a row are different facets")
+    ids = np.arange(n, dtype=np.int32) if facet_ids is None else np.asarray(facet_ids, dtype=np.int32)
+    return FacetHosts(rows, ids, verts, ls)
+
+
+def facet_classify(hosts: FacetHosts, ls_values):
+    return classify(hosts.ls, ls_values)
+
+
+def facet_locate_entities(hosts: FacetHosts, domain, selector: str):
+    """locate_entities on facet hosts answers with the parent facet ids (cut.cpp:352-359, 921)."""
+    return hosts.ids[locate_entities(domain, selector)]
+
+
+def facet_runtime_quadrature(mesh: Mesh, hosts: FacetHosts, ls_values, domain, selector, order: int,
+                             whole: bool = False) -> Rules:
+    out = _Rules()
+    rh = C.POINTER(C.c_int32)()
+    verts = np.ascontiguousarray(hosts.verts, dtype=np.int32)
+    ls = np.ascontiguousarray(hosts.ls, dtype=np.int32)
+    ids = np.ascontiguousarray(hosts.ids, dtype=np.int32)
+    vals = np.ascontiguousarray(ls_values, dtype=np.float64)
+    dom = np.ascontiguousarray(domain, dtype=np.int8)
+    rc = lib().orc_facet_runtime_quadrature(C.byref(mesh.c), C.c_int64(verts.shape[0]), _p(verts), _p(ls), _p(ids), _p(vals),
+                                            _p(dom), None if selector is None else selector.encode(), int(order),
+                                            int(bool(whole)), C.byref(out), C.byref(rh))
+    if rc != 0:
+        raise ValueError("facet hosts integrate the phi<0 / phi>0 part (single clause)")
+    nr = out.nr
+    host = np.ctypeslib.as_array(rh, shape=(max(nr, 1),))[:nr].copy()
+    lib().orc_free(rh)
+    r = _rules_from_c(out)
+    r.host_rows = hosts.rows[host]
+    r.host_verts = hosts.verts[host]
+    return r
+
+
+def facet_physical_points(mesh: Mesh, rules: Rules) -> np.ndarray:
+    """physical_points_for_host_mesh (cut.cpp:1344-1345): (nq, gdim)."""
+    hd = rules.tdim
+    rule = np.repeat(np.arange(rules.parent_map.size), np.diff(rules.offsets))
+    lam = np.concatenate([1.0 - rules.points.sum(axis=1, keepdims=True), rules.points], axis=1)   # (nq, hd+1)
+    xv = mesh.x.reshape(-1, 3)[rules.host_verts[rule]]                                          # (nq, hd+1, 3)
+    return np.einsum("qj,qjd->qd", lam, xv)[:, :mesh.tdim]
+
+
+def facet_rules_to_cells(mesh: Mesh, rules: Rules, side: int = 0) -> Rules:
+    """The same points in the reference coordinates of cell `side` of each rule's facet, rules stably ordered by
+    that cell (facet_runtime_quadrature_payload, python/cutfemx/_runintgen_adapter.py:605-680)."""
+    tdim, nv = mesh.tdim, mesh.tdim + 1
+    conn = mesh.conn.reshape(-1, nv)
+    cells = rules.host_rows[:, 2 * side].astype(np.int64)
+    perm = np.argsort(cells, kind="stable")
+    counts = np.diff(rules.offsets)
+    pts, wts, offs = [], [], [0]
+    for r in perm:
+        q0, q1 = rules.offsets[r], rules.offsets[r + 1]
+        P = rules.points[q0:q1]
+        lam = np.concatenate([1.0 - P.sum(axis=1, keepdims=True), P], axis=1)
+        X = np.zeros((q1 - q0, tdim))
+        for j in range(tdim):
+            k = int(np.nonzero(conn[cells[r]] == rules.host_verts[r, j])[0][0])
+            if k > 0:
+                X[:, k - 1] += lam[:, j]
+        pts.append(X); wts.append(rules.weights[q0:q1]); offs.append(offs[-1] + counts[r])
+    return Rules(tdim, np.concatenate(pts) if pts else np.zeros((0, tdim)),
+                 np.concatenate(wts) if wts else np.zeros(0), np.asarray(offs, dtype=np.int32),
+                 cells[perm].astype(np.int32))

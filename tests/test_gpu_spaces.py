@@ -396,8 +396,8 @@ def test_cut_with_cell_subset_as_host(oracle):
         cfx.cut(f, entities=part)
     with pytest.raises(ValueError, match="entity_dim is only valid"):
         cfx.cut(f, entity_dim=0)
-    with pytest.raises(NotImplementedError):
-        cfx.cut(f, part, 1)                       # facet hosts: SURVEY 8f-4
+    with pytest.raises(ValueError, match="integration rows"):
+        cfx.cut(f, part, 1)                       # facet hosts are (cell, local facet) rows: tests/test_gpu_facets.py
     with pytest.raises(IndexError):
         cfx.cut(f, np.array([om.ncells], dtype=np.int32), 2)
 

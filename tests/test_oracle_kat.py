@@ -347,3 +347,163 @@ def test_cell_aggregation_and_extension_penalty_invariants(oracle):
     for k, (bad, _, root, _) in enumerate(pairs):
         Ae = O.tabulate_entity(m, V, I[0], k, False)
         np.testing.assert_allclose(Ae[:3, :3].sum(), vols[bad], rtol=1e-13)   # sum_ij int N_i N_j = |K_bad|
+
+
+# ---------------------------------------------------------------------------
+# 8f-4 facet hosts: cut(level_set, facets, tdim - 1)
+# ---------------------------------------------------------------------------
+def _interior_rows(O, m):
+    return O.interior_facets_for_cells(m, np.arange(m.ncells, dtype=np.int32))
+
+
+def _clipped_measure(xv, a=0.51):
+    """measure of {x < a} within a segment (2, gdim) or triangle (3, gdim), by clipping."""
+    poly = [p for p in xv]
+    out = []
+    for i in range(len(poly)):
+        p, q = poly[i], poly[(i + 1) % len(poly)]
+        if len(poly) == 2 and i == 1:
+            break
+        pin, qin = p[0] < a, q[0] < a
+        if pin:
+            out.append(p)
+        if pin != qin:
+            t = (a - p[0]) / (q[0] - p[0])
+            out.append(p + t * (q - p))
+        if len(poly) == 2 and qin:
+            out.append(q)
+    if len(xv) == 2:
+        return 0.0 if len(out) < 2 else float(np.linalg.norm(out[-1] - out[0]))
+    area = 0.0
+    for i in range(1, len(out) - 1):
+        area += 0.5 * np.linalg.norm(np.cross(out[i] - out[0], out[i + 1] - out[0]))
+    return float(area)
+
+
+def test_facet_hosts_partition_and_rule_contracts(oracle):
+    # test_cut_api.py:171-187 (all facets as hosts: the three parts partition them) and :424-496
+    # (rules on exterior / interior facets: tdim 1, parent_map within the cut facets, same
+    # weights whether all facets or only the cut ones are the hosts)
+    O = oracle
+    m = tri_mesh(O, 3, 3)
+    phi = m.x[:, 0] - 0.51
+    for rows in (O.exterior_facets(m), _interior_rows(O, m)):
+        ids = 100 + np.arange(rows.shape[0], dtype=np.int32)
+        H = O.facet_hosts(m, rows, m.conn, facet_ids=ids)
+        dom = O.facet_classify(H, phi)
+        neg, cut, pos = (O.facet_locate_entities(H, dom, s) for s in ("phi<0", "phi=0", "phi>0"))
+        assert cut.size > 0
+        assert np.array_equal(np.sort(np.concatenate([neg, cut, pos])), ids)
+        R = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2)
+        assert R.tdim == 1 and R.points.shape == (R.weights.size, 1)
+        assert R.offsets[0] == 0 and R.offsets[-1] == R.weights.size and R.parent_map.size == R.offsets.size - 1
+        assert set(R.parent_map.tolist()) <= set(cut.tolist())
+        sub = np.isin(ids, cut)
+        H2 = O.facet_hosts(m, rows[sub], m.conn, facet_ids=ids[sub])
+        R2 = O.facet_runtime_quadrature(m, H2, phi, O.facet_classify(H2, phi), "phi<0", 2)
+        assert np.isclose(R.weights.sum(), R2.weights.sum(), rtol=1e-14)
+        pp = O.facet_physical_points(m, R)
+        assert pp.shape == (R.weights.size, 2) and np.all(pp[:, 0] < 0.51 + 1e-14)
+
+
+def test_facet_hosts_measures_line_3x3(oracle):
+    # the functionals of test_cut_api.py:499-605: int 1 ds / dS over the phi<0 part, mixed = standard + runtime.
+    # Closed forms on the 3x3 right-diagonal mesh with phi = x - 0.51.
+    O = oracle
+    m = tri_mesh(O, 3, 3)
+    phi = m.x[:, 0] - 0.51
+    ext = O.exterior_facets(m)
+    assert ext.shape == (12, 2)
+    H = O.facet_hosts(m, ext, m.conn)
+    dom = O.facet_classify(H, phi)
+    run = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2)
+    std = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2, whole=True)
+    assert np.isclose(run.weights.sum(), 2 * (0.51 - 1 / 3), rtol=1e-14)
+    assert np.isclose(std.weights.sum(), 1 + 2 / 3, rtol=1e-14)
+    rows = _interior_rows(O, m)
+    H = O.facet_hosts(m, rows, m.conn)
+    dom = O.facet_classify(H, phi)
+    run = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2)
+    std = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2, whole=True)
+    assert np.isclose(run.weights.sum() + std.weights.sum(), 1 + 2 * 0.51 + 3 * 0.51 * np.sqrt(2.0), rtol=1e-14)
+    out = O.facet_runtime_quadrature(m, H, phi, dom, "phi>0", 2)
+    allw = O.facet_runtime_quadrature(m, H, phi, dom, None, 2, whole=True)
+    cuth = O.facet_runtime_quadrature(m, H, phi, dom, "phi=0", 2, whole=True)
+    assert np.isclose(run.weights.sum() + out.weights.sum(), cuth.weights.sum(), rtol=1e-14)
+    assert np.isclose(allw.weights.sum(), 2 + 2 + 9 * np.sqrt(2.0) / 3, rtol=1e-14)
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 5), (3, 3)])
+def test_facet_hosts_against_clipping(oracle, tdim, n):
+    # every cut host: the rule's weight sum is the clipped measure; degree-2 exactness on x^2 moments;
+    # the cell views (both sides) reproduce the facet's physical points; host vertex order does not matter
+    O = oracle
+    m = O.mesh_box(tdim, n)
+    phi = m.x[:, 0] - 0.51 + 0.07 * m.x[:, 1]
+    x = m.x.reshape(-1, 3)
+    for rows in (O.exterior_facets(m), _interior_rows(O, m)):
+        H = O.facet_hosts(m, rows, m.conn)
+        dom = O.facet_classify(H, phi)
+        R = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 3)
+        assert R.parent_map.size == np.count_nonzero(dom == 0) - np.count_nonzero(
+            (dom == 0) & np.all(phi[H.ls] >= 0, axis=1))
+        # clip against the oblique line/plane through an affine change of coordinates: y0 = phi + 0.51
+        y = x.copy()
+        y[:, 0] = phi + 0.51
+        for r in range(R.parent_map.size):
+            w = R.weights[R.offsets[r]:R.offsets[r + 1]].sum()
+            xv = y[R.host_verts[r]][:, :tdim]
+            full = np.linalg.norm(x[R.host_verts[r]][1] - x[R.host_verts[r]][0]) if tdim == 2 else \
+                0.5 * np.linalg.norm(np.cross(x[R.host_verts[r]][1] - x[R.host_verts[r]][0],
+                                              x[R.host_verts[r]][2] - x[R.host_verts[r]][0]))
+            fully = np.linalg.norm(xv[1] - xv[0]) if tdim == 2 else 0.5 * np.linalg.norm(np.cross(
+                np.append(xv[1] - xv[0], 0)[:3], np.append(xv[2] - xv[0], 0)[:3]))
+            assert np.isclose(w / full, _clipped_measure(xv) / fully, rtol=1e-11, atol=1e-14)
+        pp = O.facet_physical_points(m, R)
+        for side in range(rows.shape[1] // 2):
+            Rc = O.facet_rules_to_cells(m, R, side)
+            assert np.all(np.diff(Rc.parent_map) >= 0)
+            assert np.isclose(Rc.weights.sum(), R.weights.sum(), rtol=1e-14)
+            pc = O.physical_points(m, Rc)
+            # same multiset of physical points (the rules were re-ordered by cell)
+            key = lambda a: a[np.lexsort(np.round(a, 12).T[::-1])]
+            assert np.allclose(key(pc), key(pp), atol=1e-13)
+            assert np.all(Rc.points >= -1e-14) and np.all(Rc.points.sum(axis=1) <= 1 + 1e-14)
+        # reversed host vertex order: same measure, same moments
+        Hr = O.facet_hosts(m, rows, m.conn, entity_geometry=H.verts[:, ::-1])
+        Rr = O.facet_runtime_quadrature(m, Hr, phi, O.facet_classify(Hr, phi), "phi<0", 3)
+        assert np.array_equal(Rr.parent_map, R.parent_map)
+        ppr = O.facet_physical_points(m, Rr)
+        for mom in (lambda p: np.ones(len(p)), lambda p: p[:, 0] ** 2, lambda p: p[:, 0] * p[:, 1] ** 2):
+            assert np.isclose((Rr.weights * mom(ppr)).sum(), (R.weights * mom(pp)).sum(), rtol=1e-12)
+
+
+def test_facet_hosted_rules_in_interior_facet_integrals(oracle):
+    # mixed dS measure [standard facets, runtime rules]: with every interior facet inside (phi < 0 everywhere
+    # but for a sliver) the runtime part vanishes; with whole-host rules as the "runtime" part the matrix
+    # equals the standard assembly of the same facets (test_assembly_stokes.py:99-140 compares dS that way)
+    O = oracle
+    m = O.mesh_box(2, 4)
+    phi = m.x[:, 0] - 0.51
+    rows = _interior_rows(O, m)
+    H = O.facet_hosts(m, rows, m.conn)
+    dom = O.facet_classify(H, phi)
+    V = O.Space(m.conn, m.nnodes, 1)
+    whole = O.facet_runtime_quadrature(m, H, phi, dom, None, 2, whole=True)
+    for kernel in (O.K_GHOST_GRADJUMP, O.K_JUMP):
+        a_std = [O.Integral(O.INTERIOR_FACET, kernel, entities=rows, params=(0.7,), qdegree=2)]
+        a_run = [O.Integral(O.INTERIOR_FACET, kernel, rules=whole, params=(0.7,), qdegree=2)]
+        ip, ix = O.create_sparsity(m, V, a_std)
+        ip2, ix2 = O.create_sparsity(m, V, a_run)
+        assert np.array_equal(ip, ip2) and np.array_equal(ix, ix2)
+        A = O.assemble_matrix(m, V, a_std, ip, ix)
+        B = O.assemble_matrix(m, V, a_run, ip, ix)
+        assert np.allclose(A, B, rtol=1e-12, atol=1e-14)
+    # jump penalty on the cut part only: u = x is continuous -> [u] = 0 -> A u = 0; and the matrix is symmetric
+    cutr = O.facet_runtime_quadrature(m, H, phi, dom, "phi<0", 2)
+    std_rows = rows[np.isin(H.ids, O.facet_locate_entities(H, dom, "phi<0"))]
+    a = [O.Integral(O.INTERIOR_FACET, O.K_JUMP, entities=std_rows, rules=cutr, params=(3.0,), qdegree=2)]
+    ip, ix = O.create_sparsity(m, V, a)
+    A = sp.csr_matrix((O.assemble_matrix(m, V, a, ip, ix), ix, ip), shape=(m.nnodes, m.nnodes))
+    assert abs(A - A.T).max() < 1e-13
+    assert np.abs(A @ m.x[:, 0]).max() < 1e-12

@@ -158,14 +158,63 @@ inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, in
 }
 
 /// cut(level_set, entities, entity_dim): cut.cpp:788-830 with entity_dim == tdim -- only the listed
-/// background cells are candidates (facet hosts are not part of the accelerated path)
+/// background cells are candidates (facets as hosts: the FacetRows overload below)
 inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, int ls_ndofs_cell,
                    std::int64_t ls_ndofs, std::span<const double* const> level_set_values,
                    std::span<const std::int32_t> entities, int entity_dim, const CutOptions& options = CutOptions{})
 {
   CutData cd = cut(mesh, ls_dofmap, ls_ndofs_cell, ls_ndofs, level_set_values, options);
-  if (entity_dim != cd.tdim) throw std::invalid_argument("cut: only cell subsets (entity_dim == tdim) can host cuts here");
+  if (entity_dim != cd.tdim) throw std::invalid_argument("cut: a cell subset has entity_dim == tdim (facets are passed as FacetRows)");
   check(cfx_cut_restrict(cd.handle.h, entities.data(), static_cast<std::int64_t>(entities.size())));
+  return cd;
+}
+
+/// Facets as integration rows: (cell, local facet) for exterior facets (width 2) or
+/// (cell0, local facet0, cell1, local facet1) for interior facets (width 4) --
+/// facet_integration_rows(), python/cutfemx/wrappers/cut.cpp:54-115.
+struct FacetRows
+{
+  std::vector<std::int32_t> rows;
+  int width = 4;
+  std::size_t size() const { return rows.size() / static_cast<std::size_t>(width); }
+};
+
+/// exterior_facet_indices() + facet_integration_rows(): the boundary facets, ascending
+inline FacetRows exterior_facets(const Mesh& mesh)
+{
+  std::int32_t* p = nullptr;
+  std::int64_t n = 0;
+  check(cfx_exterior_facets(mesh.handle.h, &p, &n));
+  FacetRows out{download(p, 2 * n), 2};
+  check(cfx_device_free(p));
+  return out;
+}
+
+/// cut(level_set, facets, tdim - 1): cut.cpp:540-591, 788-830 -- the facets host the cut.
+/// facet_ids (empty: positions) are the numbers locate_entities / parent_map answer with;
+/// entity_geometry (empty: cell0's vertices other than the opposite one, ascending) is the
+/// host vertex order of entities_to_geometry() (cut.cpp:567-569).
+inline CutData cut(const Mesh& mesh, std::span<const std::int32_t> ls_dofmap, int ls_ndofs_cell,
+                   std::int64_t ls_ndofs, std::span<const double* const> level_set_values, const FacetRows& facets,
+                   std::span<const std::int32_t> facet_ids = {}, std::span<const std::int32_t> entity_geometry = {},
+                   const CutOptions& options = CutOptions{})
+{
+  if (level_set_values.empty())
+    throw std::invalid_argument("cutfemx.cut requires at least one level-set function");
+  cfx_cut_options opt{options.cut_approximation_order, options.max_refinement_iterations, options.edge_max_depth, 0};
+  cfx_cut_t h = nullptr;
+  check(cfx_cut_create_facets(mesh.handle.h, static_cast<std::int64_t>(facets.size()),
+                              facet_ids.empty() ? nullptr : facet_ids.data(), facets.rows.data(), facets.width,
+                              entity_geometry.empty() ? nullptr : entity_geometry.data(),
+                              static_cast<int>(level_set_values.size()), ls_dofmap.data(), ls_ndofs_cell, ls_ndofs,
+                              level_set_values.data(), &opt, &h));
+  CutData cd;
+  cd.handle = detail::Handle<cfx_cut_t, cfx_cut_destroy>(h);
+  std::int64_t nc = 0;
+  int nls = 0;
+  check(cfx_cut_info(h, &cd.tdim, &cd.gdim, &nc, &nls)); // tdim = mesh tdim - 1, nc = number of hosts
+  cd.num_local_cells = static_cast<std::int32_t>(nc);
+  for (int k = 0; k < nls; ++k) cd.level_set_names.push_back(k == 0 ? "phi" : "phi" + std::to_string(k));
   return cd;
 }
 
@@ -215,6 +264,31 @@ inline RuntimeQuadrature runtime_quadrature(const CutData& cut_data, std::string
   cfx_rules_t h = nullptr;
   check(cfx_runtime_quadrature(cut_data.handle.h, std::string(ls_part).c_str(), order, std::string(backend).c_str(),
                                &h));
+  RuntimeQuadrature r;
+  r.handle = detail::Handle<cfx_rules_t, cfx_rules_destroy>(h);
+  check(cfx_rules_view_get(h, &r.view));
+  return r;
+}
+
+/// whole-facet rules over the hosts of a facet-hosted cut matching ls_part (empty: all): the standard facets
+/// of a mixed [facets, rules] measure (python/tests/test_cut_api.py:527-560)
+inline RuntimeQuadrature full_facet_rules(const CutData& facet_cut, std::string_view ls_part, int order)
+{
+  cfx_rules_t h = nullptr;
+  const std::string sel(ls_part);
+  check(cfx_full_facet_rules(facet_cut.handle.h, sel.empty() ? nullptr : sel.c_str(), order, &h));
+  RuntimeQuadrature r;
+  r.handle = detail::Handle<cfx_rules_t, cfx_rules_destroy>(h);
+  check(cfx_rules_view_get(h, &r.view));
+  return r;
+}
+
+/// facet_runtime_quadrature_payload / interior_facet_runtime_quadrature_payload
+/// (python/cutfemx/_runintgen_adapter.py:605-680): facet-hosted rules seen from cell `side` of their facets
+inline RuntimeQuadrature facet_rules_to_cells(const RuntimeQuadrature& facet_rules, int side = 0)
+{
+  cfx_rules_t h = nullptr;
+  check(cfx_facet_rules_to_cells(facet_rules.handle.h, side, &h));
   RuntimeQuadrature r;
   r.handle = detail::Handle<cfx_rules_t, cfx_rules_destroy>(h);
   check(cfx_rules_view_get(h, &r.view));

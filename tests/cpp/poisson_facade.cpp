@@ -85,6 +85,27 @@ int main(int argc, char** argv)
     dump(f, A);
     dump(f, b);
     dump(f, dom.inactive_dofs);
+
+    // facets as hosts (cut.cpp:788-830): the boundary facets against the plane x = 0.51
+    std::vector<double> plane(static_cast<std::size_t>(mesh.num_nodes));
+    for (std::int64_t v = 0; v < mesh.num_nodes; ++v) plane[v] = x[3 * v] - 0.51;
+    const double* pvalues[1] = {plane.data()};
+    const cfx::FacetRows ext = cfx::exterior_facets(mesh);
+    cfx::CutData fcd = cfx::cut(mesh, conn, tdim + 1, mesh.num_nodes, pvalues, ext);
+    if (fcd.tdim != tdim - 1 || fcd.num_local_cells != (std::int32_t)ext.size())
+      throw std::runtime_error("facet-hosted CutData reports the wrong host dimension / count");
+    const std::vector<std::int32_t> cut_facets = cfx::locate_entities(fcd, "phi=0");
+    cfx::RuntimeQuadrature frules = cfx::runtime_quadrature(fcd, "phi<0", 2);
+    cfx::RuntimeQuadrature fcell = cfx::facet_rules_to_cells(frules, 0);
+    cfx::RuntimeQuadrature fstd = cfx::full_facet_rules(fcd, "phi<0", 2);
+    dump(f, ext.rows);
+    dump(f, cut_facets);
+    dump(f, frules.parent_map());
+    dump(f, frules.weights());
+    dump(f, frules.physical_points());
+    dump(f, fcell.parent_map());
+    dump(f, fcell.points());
+    dump(f, fstd.weights());
     std::printf("facade ok: %lld cells, %zu inside, %zu cut rules, nnz %lld\n", (long long)mesh.num_cells,
                 inside.size(), vol.num_rules(), (long long)sp.num_nonzeros());
     return 0;

@@ -23,7 +23,8 @@ def _build(tmp_path):
 def _read(path):
     out, buf, o = [], path.read_bytes(), 0
     dtypes = [np.int8, np.int32, np.int32, np.int32, np.float64, np.float64, np.int32, np.int64, np.int32,
-              np.float64, np.float64, np.int32]
+              np.float64, np.float64, np.int32,
+              np.int32, np.int32, np.int32, np.float64, np.float64, np.int32, np.float64, np.float64]
     for dt in dtypes:
         n = int(np.frombuffer(buf, dtype=np.int64, count=1, offset=o)[0]); o += 8
         out.append(np.frombuffer(buf, dtype=dt, count=n, offset=o).copy()); o += n * np.dtype(dt).itemsize
@@ -41,7 +42,8 @@ def test_facade_matches_oracle(oracle, tmp_path, tdim, n):
     exe = _build(tmp_path)
     out = tmp_path / "facade.bin"
     subprocess.run([str(exe), str(tdim), str(n), str(out)], check=True)
-    dom, inside, voff, vpar, vw, iw, ghost, ip, ix, A, b, inactive = _read(out)
+    (dom, inside, voff, vpar, vw, iw, ghost, ip, ix, A, b, inactive,
+     ext, cut_facets, fpar, fw, fphys, cpar, cpts, sw) = _read(out)
     O = oracle
     om = O.mesh_box(tdim, n)
     ref = oracle_poisson(O, om, level_set_values(om.x, tdim))
@@ -54,3 +56,19 @@ def test_facade_matches_oracle(oracle, tmp_path, tdim, n):
     assert np.array_equal(ip, ref["indptr"]) and np.array_equal(ix, ref["indices"])
     assert rel_err(A, vals) < 1e-12 and rel_err(b, bb) < 1e-12
     assert np.array_equal(inactive, ref["inactive"])
+    # facets as hosts: boundary facets against the plane x = 0.51
+    plane = om.x[:, 0] - 0.51
+    orows = O.exterior_facets(om)
+    assert np.array_equal(ext.reshape(-1, 2), orows)
+    H = O.facet_hosts(om, orows, om.conn)
+    fdom = O.facet_classify(H, plane)
+    assert np.array_equal(cut_facets, O.facet_locate_entities(H, fdom, "phi=0"))
+    oR = O.facet_runtime_quadrature(om, H, plane, fdom, "phi<0", 2)
+    assert np.array_equal(fpar, oR.parent_map) and rel_err(fw, oR.weights) < 1e-12
+    assert np.max(np.abs(fphys.reshape(-1, tdim) - O.facet_physical_points(om, oR))) < 1e-13
+    oC = O.facet_rules_to_cells(om, oR, 0)
+    assert np.array_equal(cpar, oC.parent_map) and np.max(np.abs(cpts.reshape(-1, tdim) - oC.points)) < 1e-13
+    oS = O.facet_runtime_quadrature(om, H, plane, fdom, "phi<0", 2, whole=True)
+    assert rel_err(sw, oS.weights) < 1e-12
+    # wet part of the boundary of the unit box: the face x = 0 plus 0.51 of the 2 (tdim - 1) faces along x
+    assert abs(fw.sum() + sw.sum() - (1 + 2 * (tdim - 1) * 0.51)) < 1e-12

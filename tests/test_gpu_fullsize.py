@@ -202,6 +202,62 @@ class TestConfig3:
         s["volume"] = volume
 
 
+    def test_cfg3_facet_hosts(self, sphere512, oracle):
+        """8f-4 at full size: the 3.1 M boundary facets against a plane (closed-form wet area), and the 4.3 M
+        ghost-penalty facets as hosts of the sphere (complement property + oracle parity on a slab)."""
+        import time
+        s, torch = sphere512, _torch()
+        cfx, n, dev, mesh, V = s["cfx"], s["n"], s["dev"], s["mesh"], s["V"]
+        from cutfemx_amd import _lib
+        from cutfemx_amd.dist import as_torch
+        t0 = time.perf_counter()
+        ext = cfx.exterior_facets(mesh)
+        t1 = time.perf_counter()
+        assert ext.size == 12 * n * n
+        x = torch.arange(n + 1, device=dev, dtype=torch.float64) / n
+        plane = (x[None, None, :] - 0.51).expand(n + 1, n + 1, n + 1).reshape(-1).contiguous()
+        fcd = cfx.cut(cfx.Function(V, plane), ext, 2)
+        run = cfx.runtime_quadrature(fcd, "phi<0", 2)
+        std = cfx.full_facet_rules(fcd, "phi<0", 2)
+        cells = run.to_cells()
+        _lib.check(_lib.lib().cfx_synchronize())
+        t2 = time.perf_counter()
+        print(f"exterior_facets {1e3 * (t1 - t0):.1f} ms; facet cut + rules + cell view {1e3 * (t2 - t1):.1f} ms")
+        assert run.num_rules == 4 * 2 * n                # the 4 faces along x, 2 triangles per boundary square
+        wet = float(as_torch(run._view.weights, run.total_points, "float64", dev).sum()) + \
+            float(as_torch(std._view.weights, std.total_points, "float64", dev).sum())
+        assert abs(wet - (1.0 + 4 * 0.51)) < 1e-11
+        assert np.all(np.diff(cells.parent_map) >= 0) and cells.tdim == 3
+        # ghost-penalty facets of the sphere as hosts
+        ghost = s["system"].ghost_facets
+        gcd = cfx.cut(cfx.Function(V, s["phi"]), ghost, 2)
+        gin, gout = cfx.runtime_quadrature(gcd, "phi<0", 3), cfx.runtime_quadrature(gcd, "phi>0", 3)
+        gall = cfx.full_facet_rules(gcd, "phi=0", 3)
+        tot = lambda r: float(as_torch(r._view.weights, r.total_points, "float64", dev).sum())
+        assert abs(tot(gin) + tot(gout) - tot(gall)) < 1e-12 * tot(gall)
+        ids_cut = cfx.locate_entities(gcd, "phi=0")
+        assert set(gin.parent_map.tolist()) <= set(ids_cut.tolist())
+        # oracle parity on the facets whose two cells lie in a 6-layer slab through the sphere
+        z0, nz = 300, 6
+        om, phi = oracle_slab(oracle, cfx, n, z0, nz, "sphere", dev)
+        c0, c1 = 6 * n * n * z0, 6 * n * n * (z0 + nz)
+        rows = ghost.rows
+        inslab = (rows[:, 0] >= c0) & (rows[:, 0] < c1) & (rows[:, 2] >= c0) & (rows[:, 2] < c1)
+        assert inslab.sum() > 1000
+        local = rows[inslab].copy()
+        local[:, 0] -= c0; local[:, 2] -= c0
+        ids = np.flatnonzero(inslab).astype(np.int32)
+        H = oracle.facet_hosts(om, local, om.conn, facet_ids=ids)
+        odom = oracle.facet_classify(H, phi)
+        assert np.array_equal(gcd.domain()[inslab], odom)
+        oR = oracle.facet_runtime_quadrature(om, H, phi, odom, "phi<0", 3)
+        sel = np.isin(gin.parent_map, ids)
+        assert np.array_equal(gin.parent_map[sel], oR.parent_map)
+        offs = gin.offsets
+        w, pts = gin.weights, gin.points
+        take = np.concatenate([np.arange(offs[r], offs[r + 1]) for r in np.flatnonzero(sel)])
+        assert rel_err(w[take], oR.weights) < RTOL and np.abs(pts[take] - oR.points).max() < 1e-13
+
     @pytest.mark.parametrize("k0", [210, 366])
     def test_cfg3_plane_rows_match_oracle_slab(self, sphere512, oracle, k0):
         s = sphere512

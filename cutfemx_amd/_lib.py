@@ -20,6 +20,7 @@ CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
 K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
 K_JUMP = 9
+K_SIP = 10
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 

@@ -471,6 +471,28 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
 #pragma unroll
         for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * ji * jn[j] : 0.0;
     }
+    else if (kernel == CFX_K_SIP)
+    {
+      // symmetric interior penalty (python/demo/demo_dg_poisson.py:262-265):
+      // -{dn u}[v] - {dn v}[u] + sigma / h_avg [u][v], {dn w} = (grad w+ + grad w-) . n+ / 2, [w] = w+ - w-
+      const double wq = wref[q] * scale;
+      const double pen = params[0] / havg;
+      double vi = 0.0, ai = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        vi = (j == ia) ? N0[j] : vi; vi = (ND + j == ia) ? -N1[j] : vi;
+        ai = (j == ia) ? 0.5 * jn[j] : ai; ai = (ND + j == ia) ? -0.5 * jn[ND + j] : ai;
+      }
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+#pragma unroll
+        for (int b = 0; b < BS; ++b)
+        {
+          acc[j * BS + b] += (b == ik) ? wq * (-0.5 * jn[j] * vi - ai * N0[j] + pen * vi * N0[j]) : 0.0;
+          acc[(ND + j) * BS + b] += (b == ik) ? wq * (0.5 * jn[ND + j] * vi + ai * N1[j] - pen * vi * N1[j]) : 0.0;
+        }
+    }
     else if (kernel == CFX_K_JUMP)
     {
       // gamma / h_avg [u][v]: the value jump of the macro basis is [N0, -N1]

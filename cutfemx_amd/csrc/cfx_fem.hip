@@ -642,9 +642,11 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
             "cfx_form_create: quadrature degree out of range");
     if (in.type == CFX_INTERIOR_FACET)
     {
-      require(in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2 || in.kernel == CFX_K_JUMP,
+      require(in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2 || in.kernel == CFX_K_JUMP
+                  || in.kernel == CFX_K_SIP,
               CFX_ERR_INVALID_ARGUMENT,
-              "cfx_form_create: interior-facet integrals support the ghost-penalty, value-jump and extension-penalty kernels");
+              "cfx_form_create: interior-facet integrals support the ghost-penalty, value-jump, interior-penalty and "
+              "extension-penalty kernels");
       if (in.rules)
         require(in.kernel != CFX_K_EXTENSION_L2 && in.rules->host_width == 4 && in.point_data == nullptr,
                 CFX_ERR_INVALID_ARGUMENT,

@@ -28,6 +28,7 @@ MASS, STIFFNESS, NITSCHE, GHOST_GRADJUMP, ELASTICITY = (_lib.K_MASS, _lib.K_STIF
                                                         _lib.K_GHOST_GRADJUMP, _lib.K_ELASTICITY)
 EXTENSION_L2 = _lib.K_EXTENSION_L2
 JUMP = _lib.K_JUMP
+SIP = _lib.K_SIP
 SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS, _lib.F_COEFFICIENT
 
@@ -50,7 +51,7 @@ class Integral:
         itype = _lib.CELL
         ent_ptr, n_ent = None, 0
         if self.facets is None and self.rules is not None and self.rules.host_width == 4 and self.kernel in (
-                _lib.K_GHOST_GRADJUMP, _lib.K_JUMP):
+                _lib.K_GHOST_GRADJUMP, _lib.K_JUMP, _lib.K_SIP):
             itype = _lib.INTERIOR_FACET       # dS over runtime rules only
         if self.facets is not None:
             itype = _lib.INTERIOR_FACET

@@ -64,6 +64,9 @@ extern "C" {
 #define CFX_K_EXTENSION_L2 8
 #define CFX_K_JUMP 9             /* interior facets: gamma / h_avg [u][v] (DG / skeleton value-jump penalty);
                                    params[0]=gamma */
+#define CFX_K_SIP 10             /* interior facets: symmetric interior penalty of DG Poisson,
+                                   -{dn u}[v] - {dn v}[u] + sigma / h_avg [u][v] (python/demo/demo_dg_poisson.py:262-265);
+                                   params[0]=sigma */
 #define CFX_L_SOURCE 101        /* f v; params[0]=field id, params[1]=scale    */
 #define CFX_L_NITSCHE_RHS 102   /* -dn(v) g + gamma/h g v; params[0]=gamma,
                                    params[1]=field id of g, params[2]=scale    */

@@ -1226,6 +1226,30 @@ static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integr
           for (int kk = 0; kk < bs; ++kk)
             Ae[(i * bs + kk) * nloc + j * bs + kk] += w * jn[i] * jn[j];
     }
+    else if (I->kernel == ORC_K_SIP)
+    {
+      /* symmetric interior penalty, python/demo/demo_dg_poisson.py:262-265:
+         -<avg(grad u), jump(v, n)> - <avg(grad v), jump(u, n)> + sigma / h_avg <jump(u, n), jump(v, n)>
+         with jump(w, n) = w+ n+ + w- n- = (w+ - w-) n+ and avg(grad w) = (grad w+ + grad w-) / 2 */
+      double jv[2 * MAXND], an[2 * MAXND];
+      for (int i = 0; i < nd; ++i)
+      {
+        double a = 0.0, b = 0.0;
+        for (int d = 0; d < gdim; ++d)
+          for (int t = 0; t < tdim; ++t)
+          {
+            a += K0[t][d] * dN0[i][t] * n[d];
+            b += K1[t][d] * dN1[i][t] * n[d];
+          }
+        jv[i] = N0[i]; jv[nd + i] = -N1[i];
+        an[i] = 0.5 * a; an[nd + i] = 0.5 * b;
+      }
+      const double wq = wref[q] * scale, pen = I->params[0] / havg;
+      for (int i = 0; i < 2 * nd; ++i)
+        for (int j = 0; j < 2 * nd; ++j)
+          for (int kk = 0; kk < bs; ++kk)
+            Ae[(i * bs + kk) * nloc + j * bs + kk] += wq * (-an[j] * jv[i] - an[i] * jv[j] + pen * jv[i] * jv[j]);
+    }
     else if (I->kernel == ORC_K_JUMP)
     {
       /* gamma / h_avg [u][v] */

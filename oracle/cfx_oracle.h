@@ -45,6 +45,7 @@ enum {
   ORC_K_EXTENSION_L2 = 8,   /* beta (v|bad - E v|root)(u|bad - E u|root) over the bad cell; pairs (bad,0,root,0) as
                                interior-facet-type entities; params[0]=beta, point_data (stride 1) = per-pair factor */
   ORC_K_JUMP = 9,           /* interior facets: gamma / h_avg [u][v]  (params[0]=gamma)         */
+  ORC_K_SIP = 10,           /* interior facets: -{dn u}[v] - {dn v}[u] + sigma/h_avg [u][v]  (params[0]=sigma) */
   ORC_L_SOURCE = 101,       /* f v, f = analytic id params[0], scale params[1] */
   ORC_L_NITSCHE_RHS = 102   /* -dn(v) g + gamma/h g v, gamma=params[0], g id params[1], scale params[2] */
 };

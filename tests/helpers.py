@@ -70,3 +70,37 @@ def scrambled_mesh(O, tdim: int, n: int, seed: int = 11):
     conn = conn[rng.permutation(om.ncells)]
     conn = rng.permuted(conn, axis=1)
     return O.Mesh(tdim, xn, conn.astype(np.int32))
+
+
+def oracle_dg_poisson(O, mesh, phi, degree=1, order=4, sigma=10.0, sigma_gamma=20.0, gamma_g=0.1):
+    """Oracle restatement of python/demo/demo_dg_poisson.py:205-277 on `mesh`: cut DG Poisson problem on
+    {phi < 0}: volume terms on [inside cells, cut-cell rules], symmetric interior penalty on the skeleton of the
+    active mesh restricted to the domain ([facets inside, rules of the cut facets]), Nitsche on the interface,
+    ghost penalty on the cut band."""
+    nd = {1: mesh.tdim + 1, 2: (mesh.tdim + 1) * (mesh.tdim + 2) // 2}[degree]
+    ndofs = mesh.ncells * nd
+    dofmap = np.arange(ndofs, dtype=np.int32).reshape(mesh.ncells, nd)
+    V = O.Space(dofmap, ndofs, degree)
+    dom = O.classify(mesh.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    active = O.locate_entities(dom, "phi<=0")
+    vol = O.runtime_quadrature(mesh, mesh.conn, phi, dom, "phi<0", order)
+    itf = O.runtime_quadrature(mesh, mesh.conn, phi, dom, "phi=0", order)
+    normals = O.evaluate_normals(mesh, mesh.conn, phi, itf)
+    skeleton = O.interior_facets_for_cells(mesh, active)
+    H = O.facet_hosts(mesh, skeleton, mesh.conn)
+    fdom = O.facet_classify(H, phi)
+    omega_facets = skeleton[O.facet_locate_entities(H, fdom, "phi<0")]
+    facet_rules = O.facet_runtime_quadrature(mesh, H, phi, fdom, "phi<0", order)
+    ghost = O.ghost_penalty_facets(mesh, dom, "phi<0")
+    s2 = degree * degree
+    a = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=vol, qdegree=2 * (degree - 1)),
+         O.Integral(O.INTERIOR_FACET, O.K_SIP, entities=omega_facets, rules=facet_rules, params=(sigma * s2,),
+                    qdegree=2 * degree),
+         O.Integral(O.CELL, O.K_NITSCHE, rules=itf, point_data=normals, params=(sigma_gamma * s2,)),
+         O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=ghost, params=(gamma_g,), qdegree=2 * (degree - 1))]
+    L = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=vol, params=(O.F_POISSON_RHS, 1.0), qdegree=4),
+         O.Integral(O.CELL, O.L_NITSCHE_RHS, rules=itf, point_data=normals, params=(sigma_gamma * s2, O.F_SINPROD, 1.0))]
+    return dict(V=V, dofmap=dofmap, ndofs=ndofs, domain=dom, inside=inside, active=active, vol=vol, itf=itf,
+                normals=normals, skeleton=skeleton, hosts=H, fdom=fdom, omega_facets=omega_facets,
+                facet_rules=facet_rules, ghost=ghost, a=a, L=L)

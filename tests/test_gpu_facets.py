@@ -232,3 +232,64 @@ def test_interior_facet_integrals_over_facet_rules(oracle, tdim, n, degree, scr,
     A2 = cfx.fem.assemble_matrix(cfx.fem.form(ga2, V))
     assert np.array_equal(A2.indptr, ip) and np.array_equal(A2.indices, ix)
     assert rel_err(A2.data, O.assemble_matrix(om, oV, oa2, ip, ix)) < RTOL
+
+
+@pytest.mark.parametrize("tdim,n,degree", [(2, 12, 1), (3, 5, 1), (2, 8, 2), (3, 4, 2)])
+def test_dg_poisson_system_parity(oracle, tdim, n, degree):
+    """The whole cut DG Poisson system (demo_dg_poisson.py) against the oracle: facet lists, rules, sparsity,
+    matrix, vector, deactivation."""
+    import cutfemx_amd as cfx
+    from helpers import oracle_dg_poisson
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    o = oracle_dg_poisson(O, om, phi, degree=degree)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    f = cfx.Function(cfx.FunctionSpace(mesh, 1), phi)
+    from cutfemx_amd import poisson
+    g = poisson.build_dg_forms(f, degree)
+    a, L = g.a, g.L
+    assert np.array_equal(g.skeleton.rows, o["skeleton"]) and np.array_equal(g.omega_facets, o["omega_facets"])
+    assert np.array_equal(g.facet_rules.host_rows, o["facet_rules"].host_rows)
+    assert rel_err(g.facet_rules.weights, o["facet_rules"].weights) < RTOL
+    ip, ix = O.create_sparsity(om, o["V"], o["a"])
+    want = O.assemble_matrix(om, o["V"], o["a"], ip, ix)
+    bw = O.assemble_vector(om, o["V"], o["L"])
+    A = cfx.fem.assemble_matrix(a)
+    b = cfx.fem.assemble_vector(L)
+    assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
+    assert rel_err(A.data, want) < RTOL and rel_err(b, bw) < RTOL
+    act = cfx.fem.active_domain(a)
+    ina = O.inactive_dofs(o["V"], O.active_cells(o["a"], om.ncells))
+    assert np.array_equal(act.inactive_dofs, ina)
+
+
+def test_dg_poisson_solution_converges():
+    """The engine's own DG system solved (scipy on the host): second-order L2 convergence to
+    sin(pi x) sin(pi y) on the disk, as python/demo/demo_dg_poisson.py reports."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    errs = []
+    for n in (8, 16, 32):
+        x, conn = cfx.box_mesh_arrays(2, n)
+        mesh = cfx.Mesh.from_arrays(2, x, conn)
+        phi = level_set_values(x, 2)
+        f = cfx.Function(cfx.FunctionSpace(mesh, 1), phi)
+        ndofs = conn.shape[0] * 3
+        g = poisson.build_dg_forms(f, 1)
+        V, a = g.function_space, g.a
+        A = cfx.fem.assemble_matrix(a)
+        b = cfx.fem.assemble_vector(g.L)
+        cfx.fem.deactivate_outside(A, b, cfx.fem.active_domain(a))
+        As = sp.csr_matrix((A.data, A.indices, A.indptr), shape=(ndofs, ndofs))
+        u = spla.spsolve(As.tocsc(), np.asarray(b))
+        xd = x[conn.ravel()][:, :2]
+        e = u - np.sin(np.pi * xd[:, 0]) * np.sin(np.pi * xd[:, 1])
+        M = cfx.fem.assemble_matrix(cfx.fem.form([cfx.fem.Integral(
+            cfx.fem.MASS, cells=cfx.locate_entities(g.cell_cut, "phi<0"), rules=g.volume_rules, qdegree=2)], V))
+        Ms = sp.csr_matrix((M.data, M.indices, M.indptr), shape=(ndofs, ndofs))
+        errs.append(float(np.sqrt(e @ (Ms @ e))))
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert errs[-1] < 2e-3 and np.all(rates > 1.7), (errs, rates)

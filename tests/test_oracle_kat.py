@@ -507,3 +507,38 @@ def test_facet_hosted_rules_in_interior_facet_integrals(oracle):
     A = sp.csr_matrix((O.assemble_matrix(m, V, a, ip, ix), ix, ip), shape=(m.nnodes, m.nnodes))
     assert abs(A - A.T).max() < 1e-13
     assert np.abs(A @ m.x[:, 0]).max() < 1e-12
+
+
+def test_dg_poisson_with_cut_skeleton_converges(oracle):
+    # python/demo/demo_dg_poisson.py: DG1 cut Poisson on a disk; the symmetric interior penalty runs over
+    # [facets inside, runtime rules of the cut skeleton facets].  A consistent discretisation converges at
+    # second order in L2 -- this pins the restated SIP term and the facet-hosted rules it integrates over.
+    import scipy.sparse.linalg as spla
+    from helpers import oracle_dg_poisson
+    O = oracle
+    errs = []
+    for n in (8, 16, 32):
+        m = O.mesh_box(2, n)
+        phi = level_set_values(m.x, 2)
+        s = oracle_dg_poisson(O, m, phi)
+        V = s["V"]
+        ip, ix = O.create_sparsity(m, V, s["a"])
+        vals = O.assemble_matrix(m, V, s["a"], ip, ix)
+        b = O.assemble_vector(m, V, s["L"])
+        act = O.active_cells(s["a"], m.ncells)
+        assert np.array_equal(act, s["active"])
+        ina = O.inactive_dofs(V, act)
+        O.deactivate(ina, ip, ix, vals, b)
+        A = sp.csr_matrix((vals, ix, ip), shape=(s["ndofs"], s["ndofs"]))
+        assert abs(A - A.T).max() < 1e-11
+        u = spla.spsolve(A.tocsc(), b)
+        # L2 error over the domain with the runtime rules: int (u_h - u)^2 on [inside, rules]
+        xd = m.x[m.conn.ravel()][:, :2]
+        ue = np.sin(np.pi * xd[:, 0]) * np.sin(np.pi * xd[:, 1])
+        e = u - ue
+        mass = [O.Integral(O.CELL, O.K_MASS, entities=s["inside"], rules=s["vol"], qdegree=2)]
+        mp, mx = O.create_sparsity(m, V, mass)
+        M = sp.csr_matrix((O.assemble_matrix(m, V, mass, mp, mx), mx, mp), shape=A.shape)
+        errs.append(float(np.sqrt(e @ (M @ e))))
+    rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
+    assert errs[-1] < 2e-3 and np.all(rates > 1.7), (errs, rates)

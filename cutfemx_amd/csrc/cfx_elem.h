@@ -296,7 +296,9 @@ __device__ __forceinline__ void cell_local_row(int kernel, const double* __restr
 // points are pushed to physical space from cell0's facet lf0 and pulled back
 // to both reference cells.  acc[j*BS + b], j in [0, 2 ND).
 // ---------------------------------------------------------------------------
-template <int TDIM, int DEG, int BS>
+// KC: kernel class compiled in -- 0: ghost-penalty gradient jump + extension penalty; 1: the DG skeleton terms
+// (value jump, symmetric interior penalty), which keep both cells' basis VALUES live (+55 VGPRs for P1 tets)
+template <int TDIM, int DEG, int BS, int KC = 0>
 __device__ __forceinline__ void facet_local_row(int kernel, const double* __restrict__ params, int qdegree,
                                                 const Geo<TDIM>& g0, const Geo<TDIM>& g1, int lf0, int ia, int ik,
                                                 double* acc, int npts = 0, const double* __restrict__ pts = nullptr,
@@ -306,7 +308,7 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
   // pts != nullptr: a facet-hosted runtime rule (8f-4) -- npts points on the reference simplex spanned by the
   // host vertices xhost, physical-measure weights; else the reference facet rule of degree qdegree
   constexpr int ND = Elem<TDIM, DEG>::ND;
-  if (kernel == CFX_K_EXTENSION_L2)
+  if (KC == 0 && kernel == CFX_K_EXTENSION_L2)
   {
     // pair (bad = cell0, root = cell1): full-cell rule of the bad cell, the root's basis evaluated
     // at the pulled-back points (its polynomial extension), macro basis M = [N_bad, -N_root]
@@ -464,14 +466,14 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
     double ji = 0.0;
 #pragma unroll
     for (int j = 0; j < 2 * ND; ++j) ji = (j == ia) ? jn[j] : ji;
-    if (kernel == CFX_K_GHOST_GRADJUMP)
+    if (KC == 0 && kernel == CFX_K_GHOST_GRADJUMP)
     {
 #pragma unroll
       for (int j = 0; j < 2 * ND; ++j)
 #pragma unroll
         for (int b = 0; b < BS; ++b) acc[j * BS + b] += (b == ik) ? w * ji * jn[j] : 0.0;
     }
-    else if (kernel == CFX_K_SIP)
+    else if (KC == 1 && kernel == CFX_K_SIP)
     {
       // symmetric interior penalty (python/demo/demo_dg_poisson.py:262-265):
       // -{dn u}[v] - {dn v}[u] + sigma / h_avg [u][v], {dn w} = (grad w+ + grad w-) . n+ / 2, [w] = w+ - w-
@@ -493,7 +495,7 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
           acc[(ND + j) * BS + b] += (b == ik) ? wq * (0.5 * jn[ND + j] * vi + ai * N1[j] - pen * vi * N1[j]) : 0.0;
         }
     }
-    else if (kernel == CFX_K_JUMP)
+    else if (KC == 1 && kernel == CFX_K_JUMP)
     {
       // gamma / h_avg [u][v]: the value jump of the macro basis is [N0, -N1]
       const double wj = wref[q] * scale * params[0] / havg;

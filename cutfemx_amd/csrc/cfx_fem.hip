@@ -52,7 +52,7 @@ struct AsmArgs
   const double* coeff; // dof values of a CFX_F_COEFFICIENT field (rank-1 source terms)
   // interior-facet integrals with facet-hosted rules (8f-4): entity f of the integral with f >= n_std integrates
   // over rule f - n_std (offsets / points / weights above, host vertices below); f0 = first entity of this launch
-  int64_t n_std, f0;
+  int64_t n_std, f0, dump0; // dump0: entity written to slot 0 of `dump`
   const int32_t* host_verts;
 };
 
@@ -194,16 +194,19 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
 // points are pushed to physical space from cell0's facet and pulled back to
 // both reference cells.
 // ---------------------------------------------------------------------------
-template <int TDIM, int DEG, int BS>
+// RT: the launch covers facet-hosted runtime rules (8f-4): entity f0 + f of the integral integrates over rule
+// f0 + f - n_std; the standard launch is compiled without that code
+template <int TDIM, int DEG, int BS, bool RT, int KC>
 __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int NLOC = 2 * ND * BS;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t f = tid / NLOC;
-  if (f >= A.n) return;
-  const int I = (int)(tid - f * NLOC);
+  const int64_t fl = tid / NLOC;
+  if (fl >= A.n) return;
+  const int I = (int)(tid - fl * NLOC);
   const int ia = I / BS, ik = I - ia * BS; // macro basis index, component
+  const int64_t f = fl + A.f0;            // entity of the integral; A.entities / point_data / dump are indexed by it
   const int4 row4 = *reinterpret_cast<const int4*>(A.entities + 4 * f);
   const int64_t c0 = row4.x, c1 = row4.z;
   const int lf0 = row4.y;
@@ -224,9 +227,9 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   double acc[NLOC];
 #pragma unroll
   for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
-  if (A.host_verts && f + A.f0 >= A.n_std)
+  if constexpr (RT)
   {
-    const int64_t r = f + A.f0 - A.n_std;
+    const int64_t r = f - A.n_std;
     const int32_t q0 = A.offsets[r], q1 = A.offsets[r + 1];
     double xhost[TDIM][TDIM];
 #pragma unroll
@@ -236,11 +239,11 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 #pragma unroll
       for (int d = 0; d < TDIM; ++d) xhost[j][d] = A.x[3 * v + d];
     }
-    facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc, q1 - q0,
+    facet_local_row<TDIM, DEG, BS, KC>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc, q1 - q0,
                                    A.points + (int64_t)q0 * (TDIM - 1), A.weights + q0, xhost);
   }
   else
-    facet_local_row<TDIM, DEG, BS>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
+    facet_local_row<TDIM, DEG, BS, KC>(A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, ik, acc);
   if (A.kernel == CFX_K_EXTENSION_L2 && A.point_data)
   {
     const double factor = A.point_data[f]; // cellwise beta of the pair's bad cell
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   if (A.dump)
   {
 #pragma unroll
-    for (int j = 0; j < NLOC; ++j) A.dump[(f * NLOC + I) * NLOC + j] = acc[j];
+    for (int j = 0; j < NLOC; ++j) A.dump[((f - A.dump0) * NLOC + I) * NLOC + j] = acc[j];
     return;
   }
 
@@ -412,17 +415,37 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
   if (I.type == CFX_INTERIOR_FACET)
   {
     require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "interior-facet integrals are implemented for bilinear forms");
-    A.n = single ? 1 : I.n_entities;
-    A.entities = I.entities.p + (single ? 4 * only_index : 0);
-    A.point_data = I.point_data.n > 0 ? I.point_data.p + (single ? only_index : 0) : nullptr; // per-pair factors
-    A.f0 = single ? only_index : 0;
+    A.entities = I.entities.p;
+    A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr; // per-pair factors
     A.n_std = I.n_std;
+    A.dump0 = single ? only_index : 0;
     if (I.rules)
     {
       A.offsets = I.rules->offsets.p; A.points = I.rules->points.p; A.weights = I.rules->weights.p;
       A.host_verts = I.rules->host_verts.p;
     }
-    launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
+    // standard entities [0, n_std), then the rules' entities [n_std, n_entities)
+    const int64_t lo = single ? only_index : 0, hi = single ? only_index + 1 : I.n_entities;
+    const int64_t mid = std::min(std::max(I.n_std, lo), hi);
+    const bool dg = A.kernel == CFX_K_JUMP || A.kernel == CFX_K_SIP;
+    if (mid > lo)
+    {
+      A.f0 = lo; A.n = mid - lo;
+      if (dg)
+        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 1>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
+      else
+        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 0>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
+    }
+    if (hi > mid)
+    {
+      A.f0 = mid; A.n = hi - mid;
+      if (dg)
+        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 1>, grid_for(A.n * 2 * ND * BS), dim3(kBlock),
+               0, A);
+      else
+        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 0>, grid_for(A.n * 2 * ND * BS), dim3(kBlock),
+               0, A);
+    }
     return;
   }
   if ((parts & 1) && (!single || !use_rule))

@@ -385,9 +385,10 @@ __device__ __forceinline__ const double* ref_points(int dim, int degree, int& n,
 }
 
 #ifndef CFX_EMIT_LANES
-#define CFX_EMIT_LANES 8
+#define CFX_EMIT_LANES 4
 #endif
 constexpr int kEmitLanes = CFX_EMIT_LANES; // lanes per cut cell (64 = one wavefront per cell)
+static_assert(kEmitLanes >= 4 && 64 % kEmitLanes == 0, "lanes 0..tdim of a group stage the cell's vertices");
 
 // ---------------------------------------------------------------------------
 // a2+a3 emit: a lane group per cut cell.  Lanes 0..tdim stage the cell's
@@ -407,9 +408,10 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     int32_t* __restrict__ parent_map)
 {
   constexpr int NV = TDIM + 1;
-  // kEmitLanes lanes share one cut cell (8 cells per wavefront): a cell emits
+  // kEmitLanes lanes share one cut cell (16 cells per wavefront): a cell emits
   // 6-42 points; measured at 256^3: 64 lanes 705 us, 32 -> 445, 16 -> 293, 8 -> 247: more cells in
-  // flight wins for this latency-bound kernel
+  // flight wins for this latency-bound kernel; with the local points staged in LDS, at 512^3:
+  // 16 lanes 928 us, 8 -> 763, 4 -> 648
   __shared__ double s_phi[kBlock / kEmitLanes][NV];
   __shared__ double s_x[kBlock / kEmitLanes][NV][TDIM];
   const int wave = threadIdx.x / kEmitLanes, lane = threadIdx.x % kEmitLanes; // group, lane in group
@@ -424,7 +426,6 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     for (int d = 0; d < TDIM; ++d) s_x[wave][lane][d] = x[3 * v + d];
   }
   __syncthreads();
-  if (!live) return;
 
   double phi[NV];
   Geo<TDIM> g;
@@ -437,7 +438,19 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   }
   const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
   const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
-  if (ns == 0) return;
+  // the cell's local points (vertices + edge cut points, at most 2 NV) once per cell: one lane each, so the
+  // division of a cut point is done once instead of once per (quadrature point, sub-simplex vertex)
+  __shared__ double s_P[kBlock / kEmitLanes][2 * NV][TDIM];
+  if (live)
+    for (int p = lane; p < cs.npts; p += kEmitLanes)
+    {
+      double X[TDIM];
+      local_point<TDIM>(cs, p, phi, X);
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) s_P[wave][p][d] = X[d];
+    }
+  __syncthreads();
+  if (!live || ns == 0) return;
   int nref;
   const double* wref;
   const double* pref = ref_points<TDIM>(part == PART_IF ? TDIM - 1 : TDIM, degree, nref, wref);
@@ -464,7 +477,12 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     if (part == PART_IF)
     {
 #pragma unroll
-      for (int j = 0; j < TDIM; ++j) local_point<TDIM>(cs, cs.iface[k][j], phi, V[j]);
+      for (int j = 0; j < TDIM; ++j)
+      {
+        const int p = cs.iface[k][j];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) V[j][d] = s_P[wave][p][d];
+      }
       // physical sub-facet vertices -> surface measure
       double xp[TDIM][TDIM];
 #pragma unroll
@@ -509,7 +527,12 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     {
       const int8_t* sx = part == PART_IN ? cs.in[k] : cs.out[k];
 #pragma unroll
-      for (int j = 0; j < NV; ++j) local_point<TDIM>(cs, sx[j], phi, V[j]);
+      for (int j = 0; j < NV; ++j)
+      {
+        const int p = sx[j];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) V[j][d] = s_P[wave][p][d];
+      }
       double dsub;
       if constexpr (TDIM == 2)
         dsub = (V[1][0] - V[0][0]) * (V[2][1] - V[0][1]) - (V[1][1] - V[0][1]) * (V[2][0] - V[0][0]);

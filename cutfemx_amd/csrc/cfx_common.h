@@ -285,6 +285,7 @@ struct Stencil
   DevArray<int32_t> nbr;     // neighbours incl. the dof itself, ascending
   DevArray<uint32_t> slot4;  // parallel to dof_cells().cells: byte j = position of the cell's j-th dof
   DevArray<uint8_t> diagpos; // position of the dof in its own list
+  DevArray<uint8_t> cpos;    // [ncells*nd]: position of the cell in the dof->cells list of its j-th dof
   bool built = false, usable = false;
   int max_len = 0; // longest neighbour list
 };
@@ -400,6 +401,13 @@ struct cfx_row_plan
   cfx::DevArray<unsigned long long> plain_masks;
   cfx::DevArray<uint8_t> plain_uniform;
   bool plain_masks_built = false;
+  // linear forms, P1: the element vectors of the uncut cells are staged in the order the plain rows read them
+  // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
+  // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
+  cfx::DevArray<int32_t> vec_t2off;
+  int64_t vec_t2_total = 0;
+  int vec_fast = -1;
+  uint8_t vec_mark = 0;
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
@@ -437,6 +445,7 @@ namespace cfx
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
+bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values);
 bool assemble_vector_rows(cfx_form_s* L, double* b);

@@ -77,7 +77,8 @@ struct RowIntegral
   int std_inline;            // uncut entities: read std_tensors (0), generic inline row (1), P1 stiffness row from vertex coordinates (2)
   const unsigned long long* std_bits; // bitset of the uncut entities
   const int32_t* std_rank;            // entities before each 64-cell word
-  const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [n_entities][ND] (rank 1)
+  const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [ND][n_entities] (rank 1)
+  int64_t n_std;             // n_entities
   const int32_t* parent_map; // sorted rule parents
   int64_t nr;
   const double* rule_tensors; // [nr][ND*ND] or [nr][ND]
@@ -247,7 +248,12 @@ struct VecArgs
   double params[8];
   const int32_t* dofmap;
   const double* coeff; // dof values of a CFX_F_COEFFICIENT source, or null
-  double* out; // [n][ND]
+  double* out; // runtime rules: [n][ND]; uncut entities: [ND][n]
+  // P1 row-ordered staging (cfx_row_plan::vec_t2off): entry i of the cell goes to t2[t2off[dof_i] + cpos[cell][i]]
+  // when dof_i is a plain row; the per-cell record is only written for cells with a dof off the plain rows
+  const int32_t* t2off;
+  const uint8_t* cpos;
+  double* t2;
 };
 
 // LANES > 1 (runtime rules): a group of lanes shares one rule, the points of the rule are dealt
@@ -346,8 +352,37 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
       for (int o = LANES / 2; o > 0; o >>= 1) be[i] += __shfl_xor(be[i], o, LANES);
     if (sub != 0) return;
   }
+  // uncut entities: one array per local index ([ND][n]).  The rows gather (cell, local index) pairs; cells
+  // numbered together around a vertex often hold it at the same local index (6 + 6 + 6 x 2 of the 24 tets
+  // around a vertex of a Kuhn box mesh), so their entries share 32 B sectors -- the [n][ND] records never do
+  if constexpr (RUNTIME)
+  {
 #pragma unroll
-  for (int i = 0; i < ND; ++i) A.out[e * ND + i] = be[i];
+    for (int i = 0; i < ND; ++i) A.out[e * ND + i] = be[i];
+  }
+  else
+  {
+    bool record = true;
+    if constexpr (DEG == 1)
+    {
+      if (A.t2)
+      {
+        record = false;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+        {
+          const int32_t o = A.t2off[A.dofmap[cell * ND + i]];
+          if (o >= 0) A.t2[(int64_t)o + A.cpos[cell * ND + i]] = be[i];
+          else record = true;
+        }
+      }
+    }
+    if (record)
+    {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + e] = be[i];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1288,7 +1323,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
       {
         const RowIntegral& I = A.cell[i];
         if (mk[k] & (1u << i))
-          part += I.std_tensors[entity_index(I.std_bits, I.std_rank, c) * ND + lr[k]];
+          part += I.std_tensors[(int64_t)lr[k] * I.n_std + entity_index(I.std_bits, I.std_rank, c)];
         if (mk[k] & (16u << i))
           for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
             part += I.rule_tensors[e * ND + lr[k]];
@@ -1310,13 +1345,19 @@ bool deterministic()
 struct Stage1
 {
   std::vector<DevArray<double>> buffers;
+  DevArray<double> t2;      // linear forms, P1: row-ordered staging of the uncut cells (run_vector), else empty
+  double* vec_t2 = nullptr;
 };
 
 template <int TDIM, int DEG>
-void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out)
+void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out, double* t2 = nullptr)
 {
   cfx_space_s* V = L->V;
   VecArgs A{};
+  if (t2 && !runtime)
+  {
+    A.t2 = t2; A.t2off = row_plan(L).vec_t2off.p; A.cpos = space_stencil(V).cpos.p;
+  }
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p;
   A.kernel = I.kernel; A.qdegree = I.qdegree; A.point_stride = I.point_stride;
   for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
@@ -1382,8 +1423,9 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     {
       st.buffers.emplace_back(I.n_entities * tsize);
       R.std_tensors = st.buffers.back().p;
+      R.n_std = I.n_entities;
       if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
-      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p);
+      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p, st.vec_t2);
     }
     if (I.rules && I.rules->nr > 0)
     {
@@ -1597,16 +1639,59 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   return read_scalar(err.p);
 }
 
+// stage 2 of a linear form on the plain rows of a P1 space: the row's entries are contiguous in the
+// row-ordered staging (cfx_row_plan::vec_t2off) -- no incidence list, no marks, no local-index search
+template <int G>
+__global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+                                                                   const int64_t* __restrict__ d2c_off,
+                                                                   const int32_t* __restrict__ t2off,
+                                                                   const double* __restrict__ t2, double* __restrict__ b)
+{
+  const int lane = threadIdx.x, gl = lane % G;
+  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
+  const bool live = i < n_plain;
+  const int64_t r = live ? rows[i] : 0;
+  const int nc = live ? (int)(d2c_off[r + 1] - d2c_off[r]) : 0;
+  const int64_t o = live ? t2off[r] : 0;
+  double part = 0.0; // entries gl, gl + G, ... in ascending order, then a fixed tree: bitwise reproducible
+  for (int k = gl; k < nc; k += G) part += t2[o + k];
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1) part += __shfl_xor(part, d, G);
+  if (live && gl == 0) b[r] += part;
+}
+
 template <int TDIM, int DEG>
 void run_vector(cfx_form_s* L, double* b)
 {
   Stage1 st;
+  cfx_row_plan& plan = row_plan(L);
+  if constexpr (DEG == 1)
+  {
+    // one integral with uncut entities (the volume term): its element vectors go to the plain rows directly
+    int slot = -1, count = 0;
+    for (int s = 0; s < plan.n_cell_slots; ++s)
+      if (L->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+    const char* ro = getenv("CFX_VEC_ROWORDER");
+    if (count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0') && plain_vec_offsets(L, (uint8_t)(1u << slot)))
+    {
+      st.t2.alloc(plan.vec_t2_total);
+      st.vec_t2 = st.t2.p;
+    }
+  }
   RowArgs A = prepare<TDIM, DEG>(L, st);
   A.values = b;
   if constexpr (DEG == 1)
   {
     const Stencil& stn = space_stencil(L->V);
     if (stn.usable) { A.slot4 = stn.slot4.p; A.diagpos = stn.diagpos.p; }
+  }
+  if (st.vec_t2)
+  {
+    constexpr int G = 4;
+    launch("assemble_vec_plain", assemble_vec_plain_kernel<G>,
+           dim3((unsigned)((plan.n_plain_rows + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
+           plan.plain_rows.p, A.d2c_off, plan.vec_t2off.p, st.vec_t2, b);
+    A.n_active = plan.n_special_rows; A.active_rows = plan.special_rows.p; // the rows next to the interface
   }
   if (A.n_active > 0)
     launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,

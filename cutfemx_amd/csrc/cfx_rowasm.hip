@@ -454,7 +454,8 @@ __global__ void pattern_write_kernel(int64_t n_active, const int32_t* __restrict
 __global__ void stencil_slots_kernel(int64_t ndofs, const int64_t* __restrict__ d2c_off,
                                      const int32_t* __restrict__ d2c, const int32_t* __restrict__ dofmap, int nd,
                                      const int64_t* __restrict__ off, const int32_t* __restrict__ nbr,
-                                     uint32_t* __restrict__ slot4, uint8_t* __restrict__ diagpos)
+                                     uint32_t* __restrict__ slot4, uint8_t* __restrict__ diagpos,
+                                     uint8_t* __restrict__ cpos)
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= ndofs) return;
@@ -475,7 +476,12 @@ __global__ void stencil_slots_kernel(int64_t ndofs, const int64_t* __restrict__ 
   {
     const int64_t c = d2c[t];
     uint32_t w = 0;
-    for (int j = 0; j < nd; ++j) w |= pos_of(dofmap[c * nd + j]) << (8 * j);
+    for (int j = 0; j < nd; ++j)
+    {
+      const int32_t v = dofmap[c * nd + j];
+      w |= pos_of(v) << (8 * j);
+      if (v == (int32_t)r) cpos[c * nd + j] = (uint8_t)(t - d2c_off[r]);
+    }
     slot4[t] = w;
   }
 }
@@ -795,8 +801,9 @@ const Stencil& space_stencil(cfx_space_s* V)
   launch("stencil_rows_write", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
   S.slot4.alloc(adj.cells.n);
   S.diagpos.alloc(V->ndofs);
+  S.cpos.alloc(V->mesh->ncells * (int64_t)V->ndofs_cell);
   launch("stencil_slots", stencil_slots_kernel, grid_for(V->ndofs), dim3(kBlock), 0, V->ndofs, adj.offsets.p,
-         adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slot4.p, S.diagpos.p);
+         adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slot4.p, S.diagpos.p, S.cpos.p);
   S.usable = true;
   return S;
 }
@@ -816,6 +823,59 @@ void plain_row_masks(cfx_form_s* a)
          dim3((unsigned)((plan.n_plain_rows + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
          plan.plain_masks.p, plan.plain_uniform.p);
+}
+
+// lengths of the plain rows' dof->cells lists; flags rows whose incident cells do not all carry `mark`
+__global__ void vec_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
+                                     const uint8_t* __restrict__ uniform, uint8_t mark, int32_t* __restrict__ len, int* bad)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_plain) return;
+  const int64_t r = rows[i];
+  len[i] = (int32_t)(d2c_off[r + 1] - d2c_off[r]);
+  if (uniform[i] != mark) atomicOr(bad, 1);
+}
+
+__global__ void vec_plain_scatter_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ off,
+                                         int32_t* __restrict__ t2off)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_plain) t2off[rows[i]] = (int32_t)off[i];
+}
+
+// Layout of the row-ordered staging of a linear form's uncut-cell element vectors (see cfx_row_plan::vec_t2off).
+// Usable when every plain row's incident cells are uncut entities of the one integral whose mark bit is `mark`
+// (always so for the volume terms of a single-level-set problem: a vertex without a cut cell around it has
+// only inside cells around it).  False: the caller keeps the per-cell staging for all rows.
+bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
+{
+  cfx_row_plan& plan = row_plan(L);
+  if (plan.vec_fast >= 0 && plan.vec_mark == mark) return plan.vec_fast == 1;
+  plan.vec_mark = mark;
+  plan.vec_fast = 0;
+  cfx_space_s* V = L->V;
+  const Stencil& st = space_stencil(V);
+  if (!st.usable || plan.n_plain_rows == 0 || !plan.any_cells) return false;
+  plain_row_masks(L);
+  if (plan.plain_uniform.n != plan.n_plain_rows) return false;
+  const Adjacency& adj = V->dof_cells();
+  const int64_t n = plan.n_plain_rows;
+  DevArray<int32_t> len(n);
+  DevArray<int64_t> off(n + 1);
+  DevArray<int> bad(1);
+  bad.zero();
+  launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, adj.offsets.p,
+         plan.plain_uniform.p, mark, len.p, bad.p);
+  exclusive_scan(len.p, off.p, n);
+  const int64_t total = read_scalar(off.p + n);
+  if (read_scalar(bad.p) || total >= 2147483647LL) return false;
+  plan.vec_t2off.alloc(V->ndofs);
+  CFX_HIP(hipMemsetAsync(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs, ctx().stream));
+  launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, off.p,
+         plan.vec_t2off.p);
+  plan.vec_t2_total = total;
+  plan.vec_fast = 1;
+  return true;
 }
 
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P)

@@ -113,7 +113,10 @@ __device__ __forceinline__ double cfx_sinpi(double x)
   p = fma(p, r2, -0x1.4abbce625be52p+2);
   p = fma(p, r2, 0x1.921fb54442d18p+1);
   const double s = p * r;
-  return (((long long)k) & 1LL) ? -s : s;
+  // (-1)^k through the sign bit; k = rint(x) converts exactly for |x| < 2^31 (beyond that the conversion
+  // saturates: coordinates of that size have no fractional digits left that a mesh could use)
+  const int odd = ((int)k) & 1;
+  return __hiloint2double(__double2hiint(s) ^ (odd << 31), __double2loint(s));
 }
 
 template <int GDIM>

@@ -265,7 +265,9 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
   constexpr int ND = Elem<TDIM, DEG>::ND;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e = tid / LANES;
-  const int sub = (int)(tid - e * LANES);
+  // LANES == 1: the point index is the same in every lane, so the rule's points / weights (and the P1 basis
+  // values) are scalar loads and scalar operands
+  const int sub = LANES == 1 ? 0 : (int)(tid - e * LANES);
   if (e >= A.n) return;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
   Geo<TDIM> g;

@@ -1075,12 +1075,13 @@ __device__ __forceinline__ int host_subcount(int mask, int part)
   if constexpr (HD == 1)
   {
     const int nn = __popc(mask & 3);
+    if (part == PART_IF) return nn == 1 ? 1 : 0; // the cut point
     return part == PART_IN ? (nn >= 1 ? 1 : 0) : (nn <= 1 ? 1 : 0);
   }
   else
   {
     const CutCase& cs = c_cases[0][mask & 7];
-    return part == PART_IN ? cs.n_in : cs.n_out;
+    return part == PART_IF ? cs.n_if : (part == PART_IN ? cs.n_in : cs.n_out);
   }
 }
 
@@ -1147,10 +1148,55 @@ __global__ void __launch_bounds__(kBlock) facet_emit_kernel(
   const int ns = host_subcount<HD>(mask, part);
   if (ns == 0) return;
   const double measure = host_measure<TDIM>(xv);
+  const int32_t pbase = point_off[i], rbase = rule_off[i];
+  if (part == PART_IF)
+  {
+    // the set phi = 0 on the host (codimension 2 in the mesh): a point of a segment host (weight 1), a
+    // straight segment across a triangle host (1-D rule, weights carry its physical length)
+    if constexpr (HD == 1)
+    {
+      const int a = mask == 1 ? 0 : 1;
+      const double pa = a == 0 ? phi[0] : phi[1], pb = a == 0 ? phi[1] : phi[0];
+      const double t = pa / (pa - pb);
+      const double xa = a == 0 ? 0.0 : 1.0, xb = a == 0 ? 1.0 : 0.0;
+      points[pbase] = xa + t * (xb - xa);
+      weights[pbase] = 1.0;
+      offsets[rbase + 1] = pbase + 1;
+    }
+    else
+    {
+      const CutCase& cs = c_cases[0][mask & 7];
+      double V[2][HD], xp[2][TDIM];
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+      {
+        local_point<2>(cs, cs.iface[0][j], phi, V[j]);
+        const double l0 = 1.0 - V[j][0] - V[j][1];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) xp[j][d] = l0 * xv[0][d] + V[j][0] * xv[1][d] + V[j][1] * xv[2][d];
+      }
+      double len = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) len += (xp[1][d] - xp[0][d]) * (xp[1][d] - xp[0][d]);
+      len = sqrt(len);
+      int n1;
+      const double* w1;
+      const double* p1 = ref_points<TDIM>(1, degree, n1, w1);
+      for (int q = 0; q < n1; ++q)
+      {
+#pragma unroll
+        for (int d = 0; d < HD; ++d) points[(int64_t)(pbase + q) * HD + d] = V[0][d] + p1[q] * (V[1][d] - V[0][d]);
+        weights[pbase + q] = w1[q] * len;
+      }
+      offsets[rbase + 1] = pbase + n1;
+    }
+    parent_map[rbase] = host_ids[h];
+    rule_host[rbase] = (int32_t)h;
+    return;
+  }
   int nref;
   const double* wref;
   const double* pref = ref_points<TDIM>(HD, degree, nref, wref);
-  const int32_t pbase = point_off[i], rbase = rule_off[i];
   for (int k = 0; k < ns; ++k)
   {
     double V[NV][HD];
@@ -2052,11 +2098,9 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
     const Selector sel = parse_selector(selector, cut->nls);
     require(sel.n == 1, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature expects a single-clause selector");
     const int m = sel.mask[0];
-    require(m != 2, CFX_ERR_INVALID_ARGUMENT,
-            "runtime quadrature on facet hosts integrates the phi<0 / phi>0 part of the facets (the codimension-2 "
-            "set phi=0 is not implemented)");
-    const int part = (m & 1) ? PART_IN : PART_OUT;
-    const int nref = quad_npoints(hd, order);
+    const int part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
+    // phi = 0 on a facet: a point (segment hosts) or a straight segment (triangle hosts)
+    const int nref = part == PART_IF ? (hd == 1 ? 1 : quad_npoints(1, order)) : quad_npoints(hd, order);
     const DevArray<int32_t>& cuth = locate(cut, "phi=0");
     const int64_t ncut = cuth.n;
     DevArray<int32_t> n_rules(ncut), n_points(ncut), rule_off(ncut + 1), point_off(ncut + 1);

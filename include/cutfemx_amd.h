@@ -253,7 +253,9 @@ int cfx_interior_facets_for_cells(cfx_mesh_t mesh, const int32_t* cells, int64_t
  * On the returned handle: cfx_cut_info reports tdim - 1 and n; cfx_cut_domain / cfx_locate_entities /
  * cfx_cut_update work per host; cfx_runtime_quadrature(cut, "phi<0" | "phi>0", order) gives one rule per cut
  * host with points on the host's reference simplex (view.tdim = tdim - 1), physical-measure weights and
- * parent_map = facet ids; cfx_rules_physical_points works on such rules.  Everything that needs cell hosts
+ * parent_map = facet ids; "phi=0" gives the cut of the facet itself (docs/user-guide/element-classification.md
+ * :138-142: "a curve on those boundary facets"): the cut point of a segment host (weight 1) or a rule along the
+ * straight cut segment of a triangle host (weights carry its length); cfx_rules_physical_points works on such rules.  Everything that needs cell hosts
  * (cfx_cut_restrict, normals, ghost facets, aggregation) returns CFX_ERR_INVALID_ARGUMENT. */
 int cfx_cut_create_facets(cfx_mesh_t mesh, int64_t n, const int32_t* facet_ids, const int32_t* rows, int row_width,
                           const int32_t* entity_geometry, int n_level_sets, const int32_t* ls_dofmap, int ls_ndofs_cell,

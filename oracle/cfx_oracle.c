@@ -394,6 +394,7 @@ static void subtriangulate(int tdim, const double* phi, subtri* s)
     const int q = cut_point(s, 1, a, b, phi);
     s->n_in = 1; s->in[0][0] = a; s->in[0][1] = q;
     s->n_out = 1; s->out[0][0] = q; s->out[0][1] = b;
+    s->n_if = 1; s->iface[0][0] = q;
     return;
   }
   if (tdim == 2)
@@ -641,10 +642,13 @@ int orc_facet_runtime_quadrature(const orc_mesh* mesh, int64_t n, const int32_t*
     mask = cl[0].mask;
   }
   const int want_in = mask & 1;
-  if (!whole && (mask == 2 || ((mask & 1) && (mask & 4)))) return -1;
+  const int want_if = !whole && mask == 2; /* phi = 0 on the host: a point (segment) / a straight segment (triangle) */
+  if (!whole && !want_if && ((mask & 1) && (mask & 4))) return -1;
   const int tdim = mesh->tdim, hd = tdim - 1, nv = hd + 1;
   int nref; const double *pref, *wref;
-  ref_rule(hd, order, &nref, &pref, &wref);
+  static const double one = 1.0, zero = 0.0;
+  if (want_if && hd == 1) { nref = 1; pref = &zero; wref = &one; }
+  else ref_rule(want_if ? 1 : hd, order, &nref, &pref, &wref);
   int64_t nr = 0, nq = 0;
   for (int pass = 0; pass < 2; ++pass)
   {
@@ -677,13 +681,46 @@ int orc_facet_runtime_quadrature(const orc_mesh* mesh, int64_t n, const int32_t*
         double phi[3];
         for (int i = 0; i < nv; ++i) phi[i] = ls_values[ls[h * tdim + i]];
         subtriangulate(hd, phi, &s);
-        ns = want_in ? s.n_in : s.n_out;
+        ns = want_if ? s.n_if : (want_in ? s.n_in : s.n_out);
         if (ns == 0) continue;
       }
       if (pass == 0) { nr += 1; nq += (int64_t)ns * nref; continue; }
       double xv[3][3];
       for (int i = 0; i < nv; ++i)
         for (int d = 0; d < 3; ++d) xv[i][d] = mesh->x[3 * (int64_t)verts[h * tdim + i] + d];
+      if (want_if)
+      {
+        if (hd == 1)
+        {
+          out->points[nq] = s.P[s.iface[0][0]][0];
+          out->weights[nq] = 1.0;
+        }
+        else
+        {
+          double xp[2][3];
+          for (int j = 0; j < 2; ++j)
+          {
+            const double* V = s.P[s.iface[0][j]];
+            const double l0 = 1.0 - V[0] - V[1];
+            for (int d = 0; d < 3; ++d) xp[j][d] = l0 * xv[0][d] + V[0] * xv[1][d] + V[1] * xv[2][d];
+          }
+          double len = 0.0;
+          for (int d = 0; d < tdim; ++d) len += (xp[1][d] - xp[0][d]) * (xp[1][d] - xp[0][d]);
+          len = sqrt(len);
+          const double *V0 = s.P[s.iface[0][0]], *V1 = s.P[s.iface[0][1]];
+          for (int q = 0; q < nref; ++q)
+          {
+            for (int d = 0; d < hd; ++d) out->points[(nq + q) * hd + d] = V0[d] + pref[q] * (V1[d] - V0[d]);
+            out->weights[nq + q] = wref[q] * len;
+          }
+        }
+        nq += nref;
+        out->parent_map[nr] = ids ? ids[h] : (int32_t)h;
+        (*rule_host)[nr] = (int32_t)h;
+        out->offsets[nr + 1] = (int32_t)nq;
+        ++nr;
+        continue;
+      }
       const double measure = host_measure(tdim, xv);
       for (int k = 0; k < ns; ++k)
       {

@@ -50,7 +50,7 @@ def test_facet_hosts_cut_parity(oracle, tdim, n, kind, scr, which):
     assert np.array_equal(cd.domain(), dom)
     for sel in ("phi<0", "phi=0", "phi>0", "phi<=0"):
         assert np.array_equal(cfx.locate_entities(cd, sel), O.facet_locate_entities(H, dom, sel))
-    for sel, order in (("phi<0", 2), ("phi>0", 4), ("phi<0", 0)):
+    for sel, order in (("phi<0", 2), ("phi>0", 4), ("phi<0", 0), ("phi=0", 3)):
         R = cfx.runtime_quadrature(cd, sel, order)
         oR = O.facet_runtime_quadrature(om, H, phi, dom, sel, order)
         _rules_equal(R, oR, tdim - 1)
@@ -65,7 +65,7 @@ def test_facet_hosts_cut_parity(oracle, tdim, n, kind, scr, which):
         oW = O.facet_runtime_quadrature(om, H, phi, dom, sel, 3, whole=True)
         _rules_equal(W, oW, tdim - 1)
     with pytest.raises(ValueError):
-        cfx.runtime_quadrature(cd, "phi=0", 2)       # codimension-2 set: not implemented
+        cfx.runtime_quadrature(cd, "psi<0", 2)       # unknown level-set name
     with pytest.raises(ValueError):
         cfx.ghost_penalty_facets(cd, "phi<0")        # needs cell hosts
     # the level set moves: update() re-classifies the hosts (cut.cpp:845-868)

@@ -542,3 +542,27 @@ def test_dg_poisson_with_cut_skeleton_converges(oracle):
         errs.append(float(np.sqrt(e @ (M @ e))))
     rates = np.log2(np.array(errs[:-1]) / np.array(errs[1:]))
     assert errs[-1] < 2e-3 and np.all(rates > 1.7), (errs, rates)
+
+
+@pytest.mark.parametrize("tdim", [2, 3])
+def test_facet_hosts_interface_of_the_facets(oracle, tdim):
+    # "phi=0" on facet hosts (docs/user-guide/element-classification.md:138-142): the points where the boundary
+    # of the unit square crosses x = 0.51 (weight 1 each), the perimeter of the unit cube's cross-section
+    O = oracle
+    m = O.mesh_box(tdim, 3 if tdim == 2 else 4)
+    phi = m.x[:, 0] - 0.51
+    H = O.facet_hosts(m, O.exterior_facets(m), m.conn)
+    dom = O.facet_classify(H, phi)
+    R = O.facet_runtime_quadrature(m, H, phi, dom, "phi=0", 3)
+    pp = O.facet_physical_points(m, R)
+    assert R.tdim == tdim - 1 and np.all(np.abs(pp[:, 0] - 0.51) < 1e-15)
+    assert R.parent_map.size == np.count_nonzero(dom == 0)
+    if tdim == 2:
+        assert R.weights.tolist() == [1.0, 1.0] and sorted(pp[:, 1].tolist()) == [0.0, 1.0]
+    else:
+        assert np.isclose(R.weights.sum(), 4.0, rtol=1e-14)
+        # exact for cubics along each segment: int y^3 + z^3 over the perimeter of the unit square = 4/4 + 2 = 3
+        assert np.isclose((R.weights * (pp[:, 1] ** 3 + pp[:, 2] ** 3)).sum(), 3.0, rtol=1e-13)
+    for side in range(1):
+        Rc = O.facet_rules_to_cells(m, R, side)
+        assert np.allclose(np.sort(O.physical_points(m, Rc)[:, 0]), 0.51, atol=1e-14)

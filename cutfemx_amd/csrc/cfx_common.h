@@ -405,6 +405,8 @@ struct cfx_row_plan
   // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
   // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
   cfx::DevArray<int32_t> vec_t2off;
+  cfx::DevArray<int32_t> vec_slow_rows; // active rows without a segment: they gather the per-cell records
+  int64_t n_vec_slow_rows = 0;
   int64_t vec_t2_total = 0;
   int vec_fast = -1;
   uint8_t vec_mark = 0;

@@ -1654,12 +1654,13 @@ __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_pla
   const bool live = i < n_plain;
   const int64_t r = live ? rows[i] : 0;
   const int nc = live ? (int)(d2c_off[r + 1] - d2c_off[r]) : 0;
-  const int64_t o = live ? t2off[r] : 0;
+  const int64_t o = live ? t2off[r] : -1; // -1: the row has no segment (it is in the plan's vec_slow_rows)
   double part = 0.0; // entries gl, gl + G, ... in ascending order, then a fixed tree: bitwise reproducible
-  for (int k = gl; k < nc; k += G) part += t2[o + k];
+  if (o >= 0)
+    for (int k = gl; k < nc; k += G) part += t2[o + k];
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) part += __shfl_xor(part, d, G);
-  if (live && gl == 0) b[r] += part;
+  if (live && gl == 0 && o >= 0) b[r] += part;
 }
 
 template <int TDIM, int DEG>
@@ -1693,7 +1694,7 @@ void run_vector(cfx_form_s* L, double* b)
     launch("assemble_vec_plain", assemble_vec_plain_kernel<G>,
            dim3((unsigned)((plan.n_plain_rows + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
            plan.plain_rows.p, A.d2c_off, plan.vec_t2off.p, st.vec_t2, b);
-    A.n_active = plan.n_special_rows; A.active_rows = plan.special_rows.p; // the rows next to the interface
+    A.n_active = plan.n_vec_slow_rows; A.active_rows = plan.vec_slow_rows.p; // the rows next to the interface, mostly
   }
   if (A.n_active > 0)
     launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,

@@ -825,28 +825,42 @@ void plain_row_masks(cfx_form_s* a)
          plan.plain_masks.p, plan.plain_uniform.p);
 }
 
-// lengths of the plain rows' dof->cells lists; flags rows whose incident cells do not all carry `mark`
+// lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:
+// rows at the edge of a restricted entity list, e.g. a rank's owned cells, keep the per-cell records)
 __global__ void vec_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
-                                     const uint8_t* __restrict__ uniform, uint8_t mark, int32_t* __restrict__ len, int* bad)
+                                     const uint8_t* __restrict__ uniform, uint8_t mark, int32_t* __restrict__ len)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_plain) return;
   const int64_t r = rows[i];
-  len[i] = (int32_t)(d2c_off[r + 1] - d2c_off[r]);
-  if (uniform[i] != mark) atomicOr(bad, 1);
+  len[i] = uniform[i] == mark ? (int32_t)(d2c_off[r + 1] - d2c_off[r]) : 0;
 }
 
 __global__ void vec_plain_scatter_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ off,
                                          int32_t* __restrict__ t2off)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_plain) t2off[rows[i]] = (int32_t)off[i];
+  if (i < n_plain && off[i + 1] > off[i]) t2off[rows[i]] = (int32_t)off[i];
+}
+
+struct LenIsZero
+{
+  const int32_t* len;
+  __device__ bool operator()(int64_t i) const { return len[i] == 0; }
+};
+
+__global__ void gather_i32_kernel(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
+                                  int32_t* __restrict__ dst)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[idx[i]];
 }
 
 // Layout of the row-ordered staging of a linear form's uncut-cell element vectors (see cfx_row_plan::vec_t2off).
-// Usable when every plain row's incident cells are uncut entities of the one integral whose mark bit is `mark`
-// (always so for the volume terms of a single-level-set problem: a vertex without a cut cell around it has
-// only inside cells around it).  False: the caller keeps the per-cell staging for all rows.
+// A plain row takes part when all its incident cells are uncut entities of the one integral whose mark bit is
+// `mark` (always so for the volume terms of a single-level-set problem: a vertex without a cut cell around it
+// has only inside cells around it; not so at the edge of a restricted entity list).  False: no such row, the
+// caller keeps the per-cell staging for all rows.
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
 {
   cfx_row_plan& plan = row_plan(L);
@@ -862,17 +876,27 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   const int64_t n = plan.n_plain_rows;
   DevArray<int32_t> len(n);
   DevArray<int64_t> off(n + 1);
-  DevArray<int> bad(1);
-  bad.zero();
   launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, adj.offsets.p,
-         plan.plain_uniform.p, mark, len.p, bad.p);
+         plan.plain_uniform.p, mark, len.p);
   exclusive_scan(len.p, off.p, n);
   const int64_t total = read_scalar(off.p + n);
-  if (read_scalar(bad.p) || total >= 2147483647LL) return false;
+  if (total == 0 || total >= 2147483647LL) return false;
   plan.vec_t2off.alloc(V->ndofs);
   CFX_HIP(hipMemsetAsync(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs, ctx().stream));
   launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, off.p,
          plan.vec_t2off.p);
+  // everything else (the rows next to the interface, plain rows that are not uniform) reads the per-cell records
+  // = the special rows, then the plain rows without a segment (the order of this list is free)
+  DevArray<int32_t> odd;
+  const int64_t n_odd = compact("vec_plain_offsets", n, LenIsZero{len.p}, odd);
+  plan.n_vec_slow_rows = plan.n_special_rows + n_odd;
+  plan.vec_slow_rows.alloc(plan.n_vec_slow_rows);
+  if (plan.n_special_rows > 0)
+    CFX_HIP(hipMemcpyAsync(plan.vec_slow_rows.p, plan.special_rows.p, sizeof(int32_t) * (size_t)plan.n_special_rows,
+                           hipMemcpyDeviceToDevice, ctx().stream));
+  if (n_odd > 0)
+    launch("vec_plain_offsets", gather_i32_kernel, grid_for(n_odd), dim3(kBlock), 0, n_odd, odd.p, plan.plain_rows.p,
+           plan.vec_slow_rows.p + plan.n_special_rows);
   plan.vec_t2_total = total;
   plan.vec_fast = 1;
   return true;

@@ -316,12 +316,15 @@ __device__ __forceinline__ int sign_mask(const double* phi)
   return m;
 }
 
+constexpr int kPackShift = 34; // (points, rules) of a cut cell packed into one int64 (see cfx_runtime_quadrature)
+constexpr int64_t kPackMask = (1ll << kPackShift) - 1;
+
 // per cut cell: number of rules and points it will emit for `part`
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_count_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
                                                            const int32_t* __restrict__ ls_dofmap,
                                                            const double* __restrict__ phi_v, int part, int nref,
-                                                           int32_t* __restrict__ n_rules, int32_t* __restrict__ n_points)
+                                                           int64_t* __restrict__ packed)
 {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncut) return;
@@ -331,8 +334,8 @@ __global__ void __launch_bounds__(kBlock) cut_count_kernel(int64_t ncut, const i
   for (int v = 0; v <= TDIM; ++v) phi[v] = phi_v[ls_dofmap[c * (TDIM + 1) + v]];
   const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
   const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
-  n_rules[i] = part == PART_IF ? ns : (ns > 0 ? 1 : 0);
-  n_points[i] = ns * nref;
+  // points in the low kPackShift bits, rules above: one scan gives both offsets
+  packed[i] = (int64_t)(ns * nref) | ((int64_t)(part == PART_IF ? ns : (ns > 0 ? 1 : 0)) << kPackShift);
 }
 
 // parent-reference coordinates of local point p of the cut case
@@ -403,7 +406,7 @@ template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     int64_t ncut, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
     const int32_t* __restrict__ conn, const int32_t* __restrict__ ls_dofmap, const double* __restrict__ phi_v,
-    int part, int degree, const int32_t* __restrict__ rule_off, const int32_t* __restrict__ point_off,
+    int part, int degree, const int64_t* __restrict__ packed_off,
     double* __restrict__ points, double* __restrict__ weights, int32_t* __restrict__ offsets,
     int32_t* __restrict__ parent_map)
 {
@@ -455,7 +458,8 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   const double* wref;
   const double* pref = ref_points<TDIM>(part == PART_IF ? TDIM - 1 : TDIM, degree, nref, wref);
   const int npts = ns * nref;
-  const int32_t pbase = point_off[i], rbase = rule_off[i];
+  const int64_t po = packed_off[i];
+  const int32_t pbase = (int32_t)(po & kPackMask), rbase = (int32_t)(po >> kPackShift);
 
   // J[d][t] = x_{t+1}[d] - x_0[d]
   double J[TDIM][TDIM];
@@ -1652,25 +1656,25 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
   const int64_t ncut = cutc.n;
   auto r = std::make_unique<cfx_rules_s>();
   r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim;
-  DevArray<int32_t> n_rules(ncut), n_points(ncut), rule_off(ncut + 1), point_off(ncut + 1);
+  DevArray<int64_t> packed(ncut), packed_off(ncut + 1);
   const double* phi = cut->ls_values[0].p;
   if (ncut > 0)
   {
     if (tdim == 2)
       launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
-             part, nref, n_rules.p, n_points.p);
+             part, nref, packed.p);
     else
       launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
-             part, nref, n_rules.p, n_points.p);
+             part, nref, packed.p);
   }
-  // int32 offsets are part of the RuntimeQuadrature contract; guard the total in 64 bit
-  DevArray<int64_t> point_off64(ncut + 1);
-  exclusive_scan(n_points.p, point_off64.p, ncut);
-  const int64_t nq = read_scalar(point_off64.p + ncut);
+  // one scan, one read-back for both totals: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so
+  // below 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
+  // int32 offsets are part of the RuntimeQuadrature contract: the point total is checked against 2^31 below
+  require(ncut < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
+  exclusive_scan(packed.p, packed_off.p, ncut);
+  const int64_t totals = read_scalar(packed_off.p + ncut);
+  const int64_t nq = totals & kPackMask, nr = totals >> kPackShift;
   require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
-  exclusive_scan(n_points.p, point_off.p, ncut);
-  exclusive_scan(n_rules.p, rule_off.p, ncut);
-  const int64_t nr = read_scalar(rule_off.p + ncut);
   r->nq = nq; r->nr = nr;
   r->points.alloc(nq * tdim);
   r->weights.alloc(nq);
@@ -1682,11 +1686,11 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
     const dim3 grid((unsigned)((ncut + kBlock / kEmitLanes - 1) / (kBlock / kEmitLanes)));
     if (tdim == 2)
       launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
-             cut->ls_dofmap.p, phi, part, order, rule_off.p, point_off.p, r->points.p, r->weights.p, r->offsets.p,
+             cut->ls_dofmap.p, phi, part, order, packed_off.p, r->points.p, r->weights.p, r->offsets.p,
              r->parent_map.p);
     else
       launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
-             cut->ls_dofmap.p, phi, part, order, rule_off.p, point_off.p, r->points.p, r->weights.p, r->offsets.p,
+             cut->ls_dofmap.p, phi, part, order, packed_off.p, r->points.p, r->weights.p, r->offsets.p,
              r->parent_map.p);
   }
   *out = r.release();

@@ -310,7 +310,10 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 // (sum of the rule's weights) * G_i . G_j and only Nitsche / mass terms walk the points -- the generic
 // kernel spends one thread per (rule, row) and re-tabulates at every point.
 // ---------------------------------------------------------------------------
-constexpr int kCutLanes = 8; // lanes per rule: the points are dealt round-robin (coalesced, balanced), partial tensors folded by shuffles
+#ifndef CFX_CUT_LANES
+#define CFX_CUT_LANES 4 // 512^3: 16 -> 830 us per launch, 8 -> 500, 4 -> 385, 2 -> 380
+#endif
+constexpr int kCutLanes = CFX_CUT_LANES; // lanes per rule: the points are dealt round-robin (coalesced, balanced), partial tensors folded by shuffles
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_tensors_p1_kernel(AsmArgs A)
 {

@@ -60,6 +60,9 @@ inline dim3 row_grid(int64_t nblocks)
   return xcd_grid(nblocks);
 #endif
 }
+#ifndef CFX_VEC_CUT_LANES
+#define CFX_VEC_CUT_LANES 4 // lanes per runtime rule in stage 1 of the linear forms (512^3: 16 -> 887 us, 8 -> 580, 4 -> 469, 2 -> 541)
+#endif
 #ifndef CFX_ROWS_WAVES
 #define CFX_ROWS_WAVES 5 // waves per SIMD the gather kernel is compiled for (measured: 4 -> 2.27, 5 -> 2.09, 6 -> 2.58 ms at 256^3)
 #endif
@@ -1376,7 +1379,7 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
     const cfx_rules_s* R = I.rules;
     A.n = R->nr; A.offsets = R->offsets.p; A.parent_map = R->parent_map.p; A.points = R->points.p;
     A.weights = R->weights.p; A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, 8>, grid_for(A.n * 8), dim3(kBlock), 0, A);
+    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES>, grid_for(A.n * CFX_VEC_CUT_LANES), dim3(kBlock), 0, A);
   }
 }
 
@@ -1643,6 +1646,9 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 
 // stage 2 of a linear form on the plain rows of a P1 space: the row's entries are contiguous in the
 // row-ordered staging (cfx_row_plan::vec_t2off) -- no incidence list, no marks, no local-index search
+#ifndef CFX_VEC_PLAIN_G
+#define CFX_VEC_PLAIN_G 4
+#endif
 template <int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
                                                                    const int64_t* __restrict__ d2c_off,
@@ -1690,7 +1696,7 @@ void run_vector(cfx_form_s* L, double* b)
   }
   if (st.vec_t2)
   {
-    constexpr int G = 4;
+    constexpr int G = CFX_VEC_PLAIN_G;
     launch("assemble_vec_plain", assemble_vec_plain_kernel<G>,
            dim3((unsigned)((plan.n_plain_rows + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
            plan.plain_rows.p, A.d2c_off, plan.vec_t2off.p, st.vec_t2, b);

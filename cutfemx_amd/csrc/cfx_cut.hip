@@ -627,17 +627,19 @@ __device__ __forceinline__ int64_t rule_of_point(const int32_t* __restrict__ off
 // point.  normal = sign * K^T grad_ref(phi) / max(|.|, 1e-14)
 // (cpp/cutfemx/level_set/normal.h:150-186)
 // ---------------------------------------------------------------------------
+// one thread per rule: the normal of a P1 level set over P1 geometry is constant on the parent cell,
+// so it is formed once per rule and written to the rule's points (no search of the rule, one cell load)
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) normals_kernel(int64_t nq, int64_t nr, const int32_t* __restrict__ offsets,
-                                                         const int32_t* __restrict__ parent_map,
-                                                         const double* __restrict__ x, const int32_t* __restrict__ conn,
-                                                         const int32_t* __restrict__ ls_dofmap,
-                                                         const double* __restrict__ phi_v, double sign,
-                                                         double* __restrict__ out)
+__global__ void __launch_bounds__(kBlock) normals_rule_kernel(int64_t nr, const int32_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ parent_map,
+                                                              const double* __restrict__ x, const int32_t* __restrict__ conn,
+                                                              const int32_t* __restrict__ ls_dofmap,
+                                                              const double* __restrict__ phi_v, double sign,
+                                                              double* __restrict__ out)
 {
-  const int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= nq) return;
-  const int64_t c = parent_map[rule_of_point(offsets, nr, q)];
+  const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= nr) return;
+  const int64_t c = parent_map[r];
   Geo<TDIM> g;
   load_cell<TDIM>(x, conn, c, g);
   jacobian<TDIM>(g);
@@ -660,7 +662,12 @@ __global__ void __launch_bounds__(kBlock) normals_kernel(int64_t nq, int64_t nr,
   norm = sqrt(norm);
   if (norm < 1.0e-14) norm = 1.0e-14;
 #pragma unroll
-  for (int d = 0; d < TDIM; ++d) out[q * TDIM + d] = sign * gp[d] / norm;
+  for (int d = 0; d < TDIM; ++d) gp[d] = sign * gp[d] / norm;
+  for (int64_t q = offsets[r]; q < offsets[r + 1]; ++q)
+  {
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) out[q * TDIM + d] = gp[d];
+  }
 }
 
 template <int TDIM>
@@ -1800,10 +1807,10 @@ int cfx_evaluate_normals(cfx_cut_t cut, int ls, cfx_rules_t r, double sign, doub
   if (r->nq > 0)
   {
     if (r->tdim == 2)
-      launch("evaluate_normals", normals_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+      launch("evaluate_normals", normals_rule_kernel<2>, grid_for(r->nr), dim3(kBlock), 0, r->nr, r->offsets.p,
              r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
     else
-      launch("evaluate_normals", normals_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+      launch("evaluate_normals", normals_rule_kernel<3>, grid_for(r->nr), dim3(kBlock), 0, r->nr, r->offsets.p,
              r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
   }
   o.finish();

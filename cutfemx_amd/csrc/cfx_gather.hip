@@ -60,6 +60,9 @@ inline dim3 row_grid(int64_t nblocks)
   return xcd_grid(nblocks);
 #endif
 }
+#ifndef CFX_CUT_G
+#define CFX_CUT_G 8 // lanes per interface row in assemble_rows_kernel (P1)
+#endif
 #ifndef CFX_VEC_CUT_LANES
 #define CFX_VEC_CUT_LANES 4 // lanes per runtime rule in stage 1 of the linear forms (512^3: 16 -> 887 us, 8 -> 580, 4 -> 469, 2 -> 541)
 #endif
@@ -1556,8 +1559,8 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, true, false>, grid, dim3(kWave), 0, S);   \
     else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, true, false>, grid, dim3(kWave), 0, S);      \
   } while (0)
-          if (mr <= 32) CFX_ROWS_CUT(8, 32);
-          else CFX_ROWS_CUT(8, 64);
+          if (mr <= 32) CFX_ROWS_CUT(CFX_CUT_G, 32);
+          else CFX_ROWS_CUT(CFX_CUT_G, 64);
 #undef CFX_ROWS_CUT
         }
       }

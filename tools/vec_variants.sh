@@ -9,6 +9,6 @@ for f in "$@"; do
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 k=d['kernels']
-print('ms/step', round(d['ms_per_step'],3), {n: round(k[n]['avg_us'],1) for n in ('vec_tensors_std','vec_tensors_cut','cut_tensors_p1','assemble_vec_plain') if n in k})
+print('ms/step', round(d['ms_per_step'],3), {n: round(k[n]['avg_us'],1) for n in ('assemble_rows_cut','assemble_rows_plain','assemble_vec_rows','vec_tensors_cut') if n in k})
 " | tee -a gpurun_out/vec_variants.log
 done

@@ -1490,6 +1490,32 @@ void classify(cfx_cut_t cut)
   cut->ghost_rows.clear();
 }
 
+// "phi<0" and "phi=0" of the first level set in one pass over the classification bytes: every solve asks for
+// both (the uncut entities, and the cut cells behind runtime_quadrature), and the classification has counted both
+__global__ void __launch_bounds__(kBlock) locate_inside_cut_kernel(int64_t n, const uint8_t* __restrict__ bytes,
+                                                                   const int64_t* __restrict__ off_in,
+                                                                   const int64_t* __restrict__ off_cut,
+                                                                   int32_t* __restrict__ out_in, int32_t* __restrict__ out_cut)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  unsigned f_in = 0, f_cut = 0;
+  if (base < n)
+  {
+    f_in = byte_flags(bytes, base, n, DomainMask{1});
+    f_cut = byte_flags(bytes, base, n, DomainMask{2});
+  }
+  int total;
+  const int o_in = block_exclusive_scan<int>(__popc(f_in), total);
+  const int o_cut = block_exclusive_scan<int>(__popc(f_cut), total);
+  int64_t a = off_in[blockIdx.x] + o_in, b = off_cut[blockIdx.x] + o_cut;
+#pragma unroll
+  for (int k = 0; k < kByteItems; ++k)
+  {
+    if (f_in & (1u << k)) out_in[a++] = (int32_t)(base + k);
+    if (f_cut & (1u << k)) out_cut[b++] = (int32_t)(base + k);
+  }
+}
+
 const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
 {
   auto it = cut->located.find(selector);
@@ -1501,6 +1527,22 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
   if (pred.sel.n == 1 && (reinterpret_cast<uintptr_t>(bytes) & 15) == 0)
   {
     // "phi<0" / "phi=0" of the first level set: the classification already counted the tiles
+    if (pred.sel.ls[0] == 0 && cut->tiles_inside.n > 0 && (pred.sel.mask[0] == 1 || pred.sel.mask[0] == 2)
+        && cut->located.find("phi<0") == cut->located.end() && cut->located.find("phi=0") == cut->located.end()
+        && (selector == "phi<0" || selector == "phi=0"))
+    {
+      const int64_t ntiles = cut->tiles_inside.n;
+      DevArray<int64_t> off_in(ntiles + 1), off_cut(ntiles + 1);
+      exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
+      exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles);
+      const int64_t n_in = read_scalar(off_in.p + ntiles), n_cut = read_scalar(off_cut.p + ntiles);
+      DevArray<int32_t> l_in(n_in), l_cut(n_cut);
+      launch("locate_entities", locate_inside_cut_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nh, bytes, off_in.p,
+             off_cut.p, l_in.p, l_cut.p);
+      cut->located.emplace("phi<0", std::move(l_in));
+      cut->located.emplace("phi=0", std::move(l_cut));
+      return cut->located.find(selector)->second;
+    }
     const int32_t* known = nullptr;
     if (pred.sel.ls[0] == 0 && cut->tiles_inside.n > 0)
       known = pred.sel.mask[0] == 1 ? cut->tiles_inside.p : (pred.sel.mask[0] == 2 ? cut->tiles_cut.p : nullptr);

@@ -304,6 +304,11 @@ struct cfx_mesh_s
     if (!v2c.built) cfx::build_adjacency(conn.p, ncells, tdim + 1, nnodes, v2c);
     return v2c;
   }
+  // cell -> cell across local facet lf ([ncells*(tdim+1)], -1 on the boundary): the mesh's facet connectivity
+  // (dolfinx topology.create_connectivity(tdim-1, tdim)), built on first use by cfx::build_cell_neighbours
+  cfx::DevArray<int32_t> c2c;
+  bool c2c_built = false;
+  const cfx::DevArray<int32_t>& cell_neighbours();
 };
 
 struct cfx_rules_s

@@ -777,11 +777,50 @@ __device__ __forceinline__ bool facet_neighbour(const int32_t* __restrict__ conn
 
 // One thread per (cut cell, local facet): the neighbour search (a scan of the vertex->cells list of a
 // facet vertex) runs once, its result is parked in `cand` and packed in cell / facet order afterwards.
+// neighbour of cell c across local facet lf from the mesh's cell->cell table; nb_lf = the vertex of the
+// neighbour that is not on the facet
+template <int TDIM>
+__device__ __forceinline__ bool facet_neighbour_tab(const int32_t* __restrict__ conn, const int32_t* __restrict__ c2c,
+                                                    int64_t c, int lf, int32_t& nb, int& nb_lf)
+{
+  constexpr int NV = TDIM + 1;
+  nb = c2c[c * NV + lf];
+  if (nb < 0) return false;
+  int32_t cv[NV], ov[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { cv[i] = conn[c * NV + i]; ov[i] = conn[(int64_t)nb * NV + i]; }
+  nb_lf = 0;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+  {
+    bool onf = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) onf = onf || (i != lf && cv[i] == ov[j]);
+    if (!onf) nb_lf = j;
+  }
+  return true;
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) cell_neighbours_kernel(int64_t ncells, const int32_t* __restrict__ conn,
+                                                                 const int64_t* __restrict__ v2c_off,
+                                                                 const int32_t* __restrict__ v2c, int32_t* __restrict__ c2c)
+{
+  constexpr int NV = TDIM + 1;
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c >= ncells) return;
+  for (int lf = 0; lf < NV; ++lf)
+  {
+    int32_t nb;
+    int nlf;
+    c2c[c * NV + lf] = facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf) ? nb : -1;
+  }
+}
+
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
                                                                    const int32_t* __restrict__ conn,
-                                                                   const int64_t* __restrict__ v2c_off,
-                                                                   const int32_t* __restrict__ v2c,
+                                                                   const int32_t* __restrict__ c2c,
                                                                    const int8_t* __restrict__ domain, SelectorPred sel,
                                                                    int32_t* __restrict__ counts, int32_t* __restrict__ cand)
 {
@@ -794,7 +833,7 @@ __global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(int64_t ncut,
   int4 r = make_int4(-1, -1, -1, -1);
   int32_t nb;
   int nlf;
-  if (facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf))
+  if (facet_neighbour_tab<TDIM>(conn, c2c, c, lf, nb, nlf))
   {
     const bool nb_cut = domain[nb] == CFX_INTERSECTED;
     if ((nb_cut || sel(nb)) && !(nb_cut && nb < c))
@@ -1898,7 +1937,7 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   SelectorPred pred{cut->domain.p, mesh->ncells, parse_selector(selector, cut->nls)};
   const DevArray<int32_t>& cutc = locate(cut, "phi=0");
   const int64_t ncut = cutc.n;
-  const Adjacency& adj = mesh->vertex_cells();
+  const DevArray<int32_t>& c2c = mesh->cell_neighbours();
   DevArray<int32_t> counts(ncut), cand(ncut * (int64_t)(mesh->tdim + 1) * 4);
   DevArray<int64_t> offs(ncut + 1);
   int64_t total = 0;
@@ -1908,10 +1947,10 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
     const int64_t nthreads = ncut * (mesh->tdim + 1);
     if (mesh->tdim == 2)
       launch("ghost_facets_find", ghost_facets_find_kernel<2>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, cand.p);
+             mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);
     else
       launch("ghost_facets_find", ghost_facets_find_kernel<3>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
-             mesh->conn.p, adj.offsets.p, adj.cells.p, cut->domain.p, pred, counts.p, cand.p);
+             mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);
     exclusive_scan(counts.p, offs.p, ncut);
     total = read_scalar(offs.p + ncut);
   }
@@ -2109,6 +2148,24 @@ int cfx_cut_destroy(cfx_cut_t cut)
 }
 
 } // extern "C"
+
+const cfx::DevArray<int32_t>& cfx_mesh_s::cell_neighbours()
+{
+  if (c2c_built) return c2c;
+  const Adjacency& adj = vertex_cells();
+  c2c.alloc(ncells * (int64_t)(tdim + 1));
+  if (ncells > 0)
+  {
+    if (tdim == 2)
+      launch("cell_neighbours", cell_neighbours_kernel<2>, grid_for(ncells), dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
+             adj.cells.p, c2c.p);
+    else
+      launch("cell_neighbours", cell_neighbours_kernel<3>, grid_for(ncells), dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
+             adj.cells.p, c2c.p);
+  }
+  c2c_built = true;
+  return c2c;
+}
 
 // ---------------------------------------------------------------------------
 // 8f-4 facet hosts

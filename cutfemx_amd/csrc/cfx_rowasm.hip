@@ -62,6 +62,33 @@ __global__ void plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict_
   pop[w] = __popcll(v);
 }
 
+// uncut entities of a cell integral, nd <= 4 dofs per cell, in one pass over the list: cell mark, row marks
+// (dofmap row as one 16 B load when nd == 4) and the ascending check
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(int64_t n, const int32_t* __restrict__ cells,
+                                                                    const int32_t* __restrict__ dofmap, uint8_t bit,
+                                                                    uint8_t* mark, uint8_t* rowmark, int* flag)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t c = cells[i];
+  if (i + 1 < n && cells[i + 1] <= c) atomicOr(flag, 1); // strictly ascending (plan_check_sorted_kernel, strict)
+  mark[c] = mark[c] | bit;
+  int32_t d[ND];
+  if constexpr (ND == 4)
+  {
+    const int4 v = *reinterpret_cast<const int4*>(dofmap + c * 4);
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) d[j] = dofmap[c * ND + j];
+  }
+#pragma unroll
+  for (int j = 0; j < ND; ++j) rowmark[d[j]] = 1;
+}
+
 // `special` (may be null): rows that receive something other than uncut-cell items
 __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride,
                                             const int32_t* __restrict__ dofmap, int nd, uint8_t* rowmark,
@@ -656,12 +683,21 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       P.cell_slot_integral[slot] = (int)ii;
       if (I.n_entities > 0)
       {
-        launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
-               I.entities.p, 1, (uint8_t)(1u << slot), P.cellmark.p);
-        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-               I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p, (uint8_t*)nullptr);
-        launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
-               I.entities.p, 1, flag.p);
+        if (nd == 4)
+          launch("plan_mark_entities", plan_mark_entities_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+                 I.entities.p, V->dofmap.p, (uint8_t)(1u << slot), P.cellmark.p, P.rowmark.p, flag.p);
+        else if (nd == 3)
+          launch("plan_mark_entities", plan_mark_entities_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+                 I.entities.p, V->dofmap.p, (uint8_t)(1u << slot), P.cellmark.p, P.rowmark.p, flag.p);
+        else
+        {
+          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+                 I.entities.p, 1, (uint8_t)(1u << slot), P.cellmark.p);
+          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+                 I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p, (uint8_t*)nullptr);
+          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+                 I.entities.p, 1, flag.p);
+        }
         P.any_cells = true;
       }
       if (I.rules && I.rules->nr > 0)

@@ -89,6 +89,59 @@ __global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(int64_t n, c
   for (int j = 0; j < ND; ++j) rowmark[d[j]] = 1;
 }
 
+// runtime rules of a cell integral, nd <= 4: one pass over the parent list -- ascending check, and at the first
+// rule of every parent its cell mark, row marks (special rows) and hash-map entry parent -> first rule
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_rules_kernel(int64_t nr, const int32_t* __restrict__ parent,
+                                                            const int32_t* __restrict__ dofmap, uint8_t bit, uint8_t* mark,
+                                                            uint8_t* rowmark, uint8_t* special, uint32_t hmask,
+                                                            int32_t* __restrict__ keys, int32_t* __restrict__ first, int* flag)
+{
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nr) return;
+  const int32_t c = parent[e];
+  if (e > 0)
+  {
+    const int32_t prev = parent[e - 1];
+    if (prev > c) atomicOr(flag, 1);
+    if (prev == c) return;
+  }
+  mark[c] = mark[c] | bit;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    const int32_t dof = dofmap[(int64_t)c * ND + j];
+    rowmark[dof] = 1;
+    special[dof] = 1;
+  }
+  uint32_t h = cfx_hash32((uint32_t)c) & hmask;
+  while (true)
+  {
+    const int32_t old = atomicCAS(&keys[h], -1, c);
+    if (old == -1 || old == c) break;
+    h = (h + 1) & hmask;
+  }
+  first[h] = (int32_t)e;
+}
+
+// interior-facet entities, nd <= 4: row marks (special rows) of both cells of every row
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(int64_t nf, const int32_t* __restrict__ rows,
+                                                                 const int32_t* __restrict__ dofmap, uint8_t* rowmark,
+                                                                 uint8_t* special)
+{
+  const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (f >= nf) return;
+  const int4 r = *reinterpret_cast<const int4*>(rows + 4 * f);
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    const int32_t d0 = dofmap[(int64_t)r.x * ND + j], d1 = dofmap[(int64_t)r.z * ND + j];
+    rowmark[d0] = 1; special[d0] = 1;
+    rowmark[d1] = 1; special[d1] = 1;
+  }
+}
+
 // `special` (may be null): rows that receive something other than uncut-cell items
 __global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride,
                                             const int32_t* __restrict__ dofmap, int nd, uint8_t* rowmark,
@@ -702,20 +755,31 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       }
       if (I.rules && I.rules->nr > 0)
       {
-        launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
-               I.rules->parent_map.p, 1, (uint8_t)(16u << slot), P.cellmark.p);
-        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.rules->nr * nd), dim3(kBlock), 0,
-               I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p, special.p);
-        launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
-               I.rules->parent_map.p, 0, flag.p);
         uint32_t size = 64;
         while (size < 2 * (uint64_t)I.rules->nr) size <<= 1;
         P.rule_mask[slot] = size - 1;
         P.rule_keys[slot].alloc(size);
         P.rule_first[slot].alloc(size);
         CFX_HIP(hipMemsetAsync(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size, ctx().stream));
-        launch("plan_rule_hash", plan_rule_hash_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
-               I.rules->parent_map.p, P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p);
+        if (nd == 4)
+          launch("plan_rules", plan_rules_kernel<4>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+                 I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
+                 P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
+        else if (nd == 3)
+          launch("plan_rules", plan_rules_kernel<3>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+                 I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
+                 P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
+        else
+        {
+          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+                 I.rules->parent_map.p, 1, (uint8_t)(16u << slot), P.cellmark.p);
+          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.rules->nr * nd), dim3(kBlock), 0,
+                 I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p, special.p);
+          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+                 I.rules->parent_map.p, 0, flag.p);
+          launch("plan_rule_hash", plan_rule_hash_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+                 I.rules->parent_map.p, P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p);
+        }
         P.any_cells = true;
       }
     }
@@ -738,10 +802,19 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)I.n_entities,
                              hipMemcpyDeviceToDevice, ctx().stream));
       CFX_HIP(hipMemsetAsync(P.facet_slot.p + o, s, (size_t)I.n_entities, ctx().stream));
-      launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-             I.n_entities, I.entities.p, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
-      launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
-             I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
+      if (nd == 4)
+        launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+               I.entities.p, V->dofmap.p, P.rowmark.p, special.p);
+      else if (nd == 3)
+        launch("plan_facet_rows", plan_facet_rows_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+               I.entities.p, V->dofmap.p, P.rowmark.p, special.p);
+      else
+      {
+        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+               I.n_entities, I.entities.p, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
+        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+               I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
+      }
       o += I.n_entities;
     }
   }

@@ -562,7 +562,9 @@ __global__ void deactivate_kernel(int64_t n, const int32_t* __restrict__ rows, c
   const int32_t r = rows[i];
   if (values)
   {
-    const int64_t pos = csr_find(indices, indptr[r], indptr[r + 1], r);
+    const int64_t rb = indptr[r], re = indptr[r + 1];
+    // a deactivated row is normally its diagonal alone (assembler.h:538-560): position known without the search
+    const int64_t pos = (re - rb == 1 && indices[rb] == r) ? rb : csr_find(indices, rb, re, r);
     if (pos < 0) *error = 1; else values[pos] = diagonal; // set, not add (set_diagonal via mat_set_values)
   }
   if (b) b[r] = rhs_value;

@@ -566,6 +566,55 @@ __global__ void stencil_slots_kernel(int64_t ndofs, const int64_t* __restrict__ 
   }
 }
 
+// The three row lists of a plan -- active (rowmark), special (rowmark & special) and plain (rowmark & !special),
+// all ascending -- from one count pass and one write pass over the two byte arrays.  Tile counts of the special
+// and plain rows are packed into one int64 for a single scan; active = special + plain.
+__global__ void __launch_bounds__(kBlock) plan_row_lists_count_kernel(int64_t n, const uint8_t* __restrict__ rowmark,
+                                                                      const uint8_t* __restrict__ special,
+                                                                      int64_t* __restrict__ tile_counts)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  unsigned fa = 0, fs = 0;
+  if (base < n)
+  {
+    fa = byte_flags(rowmark, base, n, ByteNonZero{});
+    fs = byte_flags(special, base, n, ByteNonZero{}) & fa;
+  }
+  int tot_s, tot_p;
+  (void)block_exclusive_scan<int>(__popc(fs), tot_s);
+  (void)block_exclusive_scan<int>(__popc(fa & ~fs), tot_p);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = (int64_t)tot_s | ((int64_t)tot_p << 32);
+}
+
+__global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n, const uint8_t* __restrict__ rowmark,
+                                                                      const uint8_t* __restrict__ special,
+                                                                      const int64_t* __restrict__ tile_offsets,
+                                                                      int32_t* __restrict__ active,
+                                                                      int32_t* __restrict__ special_rows,
+                                                                      int32_t* __restrict__ plain_rows)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  unsigned fa = 0, fs = 0;
+  if (base < n)
+  {
+    fa = byte_flags(rowmark, base, n, ByteNonZero{});
+    fs = byte_flags(special, base, n, ByteNonZero{}) & fa;
+  }
+  const unsigned fp = fa & ~fs;
+  int tot;
+  const int os = block_exclusive_scan<int>(__popc(fs), tot);
+  const int op = block_exclusive_scan<int>(__popc(fp), tot);
+  const int64_t t = tile_offsets[blockIdx.x];
+  int64_t s = (t & 0xffffffffll) + os, p = (t >> 32) + op;
+#pragma unroll
+  for (int k = 0; k < kByteItems; ++k)
+  {
+    const int32_t row = (int32_t)(base + k);
+    if (fs & (1u << k)) { active[s + p] = row; special_rows[s++] = row; }
+    else if (fp & (1u << k)) { active[s + p] = row; if (plain_rows) plain_rows[p] = row; ++p; }
+  }
+}
+
 // 0 inactive, 1 plain (uncut-cell items only), 2 special
 __global__ void plan_row_class_kernel(int64_t n, const uint8_t* __restrict__ rowmark, const uint8_t* __restrict__ special,
                                       uint8_t* __restrict__ cls)
@@ -818,14 +867,23 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       o += I.n_entities;
     }
   }
-  P.n_active_rows = compact_bytes("plan_active_rows", V->ndofs, P.rowmark.p, ByteNonZero{}, P.active_rows);
   {
-    DevArray<uint8_t> cls(V->ndofs);
-    launch("plan_row_class", plan_row_class_kernel, grid_for(V->ndofs), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
-           special.p, cls.p);
-    P.n_special_rows = compact_bytes("plan_special_rows", V->ndofs, cls.p, ByteIs{2}, P.special_rows);
-    if (space_stencil(V).usable)
-      P.n_plain_rows = compact_bytes("plan_plain_rows", V->ndofs, cls.p, ByteIs{1}, P.plain_rows);
+    const int64_t ntiles = (V->ndofs + kByteTile - 1) / kByteTile;
+    DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
+    launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
+           special.p, tcounts.p);
+    exclusive_scan(tcounts.p, toffs.p, ntiles);
+    const int64_t totals = read_scalar(toffs.p + ntiles);
+    const int64_t n_special = totals & 0xffffffffll, n_plain = totals >> 32;
+    const bool want_plain = space_stencil(V).usable;
+    P.n_active_rows = n_special + n_plain;
+    P.n_special_rows = n_special;
+    P.n_plain_rows = want_plain ? n_plain : 0;
+    P.active_rows.alloc(P.n_active_rows);
+    P.special_rows.alloc(n_special);
+    if (want_plain) P.plain_rows.alloc(n_plain);
+    launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
+           special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr);
   }
   P.special_mark = std::move(special);
   if (P.nfacets > 0)

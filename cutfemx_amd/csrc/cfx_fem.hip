@@ -570,6 +570,14 @@ __global__ void deactivate_kernel(int64_t n, const int32_t* __restrict__ rows, c
   if (b) b[r] = rhs_value;
 }
 
+__global__ void facet_cells_covered_kernel(int64_t nf, const int32_t* __restrict__ rows, const uint8_t* __restrict__ cellmark,
+                                           int* uncovered)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * nf) return;
+  if (cellmark[rows[4 * (i >> 1) + 2 * (i & 1)]] == 0) atomicOr(uncovered, 1);
+}
+
 void collect_cell_marks(const cfx_form_s* a, bool include_facets, DevArray<uint8_t>& mark, bool& any)
 {
   const int64_t nc = a->V->mesh->ncells;
@@ -933,7 +941,18 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   // entity) -- collect_active_cells / build_active_indicator of deactivate.h:103-183.
   cfx_row_plan& plan = row_plan(a);
   const int64_t nc = V->mesh->ncells;
-  if (plan.nfacets == 0)
+  bool facets_covered = plan.nfacets == 0;
+  if (!facets_covered)
+  {
+    // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty
+    // band lies in the cut and inside cells): then the cell marks alone are the indicator
+    DevArray<int> uncovered(1);
+    uncovered.zero();
+    launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets * 2), dim3(kBlock), 0, plan.nfacets,
+           plan.facet_rows.p, plan.cellmark.p, uncovered.p);
+    facets_covered = read_scalar(uncovered.p) == 0;
+  }
+  if (facets_covered)
     d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells);
   else
   {

@@ -128,18 +128,30 @@ __global__ void __launch_bounds__(kBlock) plan_rules_kernel(int64_t nr, const in
 template <int ND>
 __global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(int64_t nf, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, uint8_t* rowmark,
-                                                                 uint8_t* special)
+                                                                 uint8_t* special, int* flag)
 {
   const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (f >= nf) return;
   const int4 r = *reinterpret_cast<const int4*>(rows + 4 * f);
+  int32_t d0[ND], d1[ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j)
   {
-    const int32_t d0 = dofmap[(int64_t)r.x * ND + j], d1 = dofmap[(int64_t)r.z * ND + j];
-    rowmark[d0] = 1; special[d0] = 1;
-    rowmark[d1] = 1; special[d1] = 1;
+    d0[j] = dofmap[(int64_t)r.x * ND + j]; d1[j] = dofmap[(int64_t)r.z * ND + j];
+    rowmark[d0[j]] = 1; special[d0[j]] = 1;
+    rowmark[d1[j]] = 1; special[d1[j]] = 1;
   }
+  // P1 facet folding needs all dofs but one per cell shared (plan_check_fold_kernel): flag bit 1 otherwise
+  int nfree = 0;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    bool shared = false;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) shared = shared || d1[j] == d0[i];
+    nfree += shared ? 0 : 1;
+  }
+  if (nfree != 1) atomicOr(flag, 2);
 }
 
 // `special` (may be null): rows that receive something other than uncut-cell items
@@ -853,10 +865,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       CFX_HIP(hipMemsetAsync(P.facet_slot.p + o, s, (size_t)I.n_entities, ctx().stream));
       if (nd == 4)
         launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
-               I.entities.p, V->dofmap.p, P.rowmark.p, special.p);
+               I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
       else if (nd == 3)
         launch("plan_facet_rows", plan_facet_rows_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
-               I.entities.p, V->dofmap.p, P.rowmark.p, special.p);
+               I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
       else
       {
         launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
@@ -926,7 +938,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
-  if (P.nfacets > 0 && nd == V->mesh->tdim + 1)
+  if (P.nfacets > 0 && nd == V->mesh->tdim + 1 && nd > 4) // (nd <= 4: checked by plan_facet_rows_kernel)
     launch("plan_check_fold", plan_check_fold_kernel, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
            V->dofmap.p, nd, flag.p);
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up

@@ -229,9 +229,14 @@ def test_interior_facet_integrals_over_facet_rules(oracle, tdim, n, degree, scr,
     oa2 = [O.Integral(O.INTERIOR_FACET, ok, rules=orun, params=(0.3,), qdegree=2 * degree)]
     ga2 = [cfx.fem.Integral(gk, rules=run, params=(0.3,), qdegree=2 * degree)]
     ip, ix = O.create_sparsity(om, oV, oa2)
-    A2 = cfx.fem.assemble_matrix(cfx.fem.form(ga2, V))
+    a2 = cfx.fem.form(ga2, V)
+    A2 = cfx.fem.assemble_matrix(a2)
     assert np.array_equal(A2.indptr, ip) and np.array_equal(A2.indices, ix)
     assert rel_err(A2.data, O.assemble_matrix(om, oV, oa2, ip, ix)) < RTOL
+    # a form without cell integrals: its active cells are the facets' cells alone
+    act2 = cfx.fem.active_domain(a2)
+    want2 = O.active_cells(oa2, om.ncells)
+    assert np.array_equal(act2.active_cells, want2) and np.array_equal(act2.inactive_dofs, O.inactive_dofs(oV, want2))
 
 
 @pytest.mark.parametrize("tdim,n,degree", [(2, 12, 1), (3, 5, 1), (2, 8, 2), (3, 4, 2)])

@@ -1543,16 +1543,22 @@ __global__ void __launch_bounds__(kBlock) locate_inside_cut_kernel(int64_t n, co
     f_in = byte_flags(bytes, base, n, DomainMask{1});
     f_cut = byte_flags(bytes, base, n, DomainMask{2});
   }
-  int total;
-  const int o_in = block_exclusive_scan<int>(__popc(f_in), total);
+  // the inside cells (the dense list) are packed in LDS and stored as one coalesced run per tile; the few cut
+  // cells go out directly
+  __shared__ int32_t s_in[kByteTile];
+  int total_in, total;
+  int o_in = block_exclusive_scan<int>(__popc(f_in), total_in);
   const int o_cut = block_exclusive_scan<int>(__popc(f_cut), total);
-  int64_t a = off_in[blockIdx.x] + o_in, b = off_cut[blockIdx.x] + o_cut;
+  int64_t b = off_cut[blockIdx.x] + o_cut;
 #pragma unroll
   for (int k = 0; k < kByteItems; ++k)
   {
-    if (f_in & (1u << k)) out_in[a++] = (int32_t)(base + k);
+    if (f_in & (1u << k)) s_in[o_in++] = (int32_t)(base + k);
     if (f_cut & (1u << k)) out_cut[b++] = (int32_t)(base + k);
   }
+  __syncthreads();
+  const int64_t a = off_in[blockIdx.x];
+  for (int i = threadIdx.x; i < total_in; i += kBlock) out_in[a + i] = s_in[i];
 }
 
 const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)

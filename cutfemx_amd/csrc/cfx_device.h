@@ -177,14 +177,19 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
                                                                      const int64_t* __restrict__ tile_offsets,
                                                                      int32_t* __restrict__ out)
 {
+  // the tile's hits are packed in LDS first: the global stores are then one contiguous, coalesced run per tile
+  // (direct stores leave every lane with its own short run: 64 partial sectors per store instruction)
+  __shared__ int32_t s_out[kByteTile];
   const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
   const unsigned f = base < n ? byte_flags(bytes, base, n, test) : 0u;
   int total;
-  const int off = block_exclusive_scan<int>(__popc(f), total);
-  int64_t o = tile_offsets[blockIdx.x] + off;
+  int off = block_exclusive_scan<int>(__popc(f), total);
 #pragma unroll
   for (int k = 0; k < kByteItems; ++k)
-    if (f & (1u << k)) out[o++] = (int32_t)(base + k);
+    if (f & (1u << k)) s_out[off++] = (int32_t)(base + k);
+  __syncthreads();
+  const int64_t o = tile_offsets[blockIdx.x];
+  for (int i = threadIdx.x; i < total; i += kBlock) out[o + i] = s_out[i];
 }
 
 // `bytes` must be 16-byte aligned

@@ -570,6 +570,14 @@ __global__ void deactivate_kernel(int64_t n, const int32_t* __restrict__ rows, c
   if (b) b[r] = rhs_value;
 }
 
+__global__ void inactive_tile_counts_kernel(int64_t ntiles, int64_t n, const int64_t* __restrict__ active, int32_t* __restrict__ zeros)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= ntiles) return;
+  const int64_t len = min((int64_t)kByteTile, n - t * kByteTile);
+  zeros[t] = (int32_t)(len - (active[t] & 0xffffffffll) - (active[t] >> 32));
+}
+
 __global__ void facet_cells_covered_kernel(int64_t nf, const int32_t* __restrict__ rows, const uint8_t* __restrict__ cellmark,
                                            int* uncovered)
 {
@@ -969,7 +977,19 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   require(d->n_active > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
   const int64_t nrows = V->ndofs * V->bs;
   if (V->bs == 1)
-    d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs);
+  {
+    // the plan counted the active rows per tile: the inactive ones are the rest of the tile
+    const int64_t ntiles = (nrows + kByteTile - 1) / kByteTile;
+    DevArray<int32_t> zeros;
+    if (plan.row_tile_counts.n == ntiles)
+    {
+      zeros.alloc(ntiles);
+      launch("inactive_dofs", inactive_tile_counts_kernel, grid_for(ntiles), dim3(kBlock), 0, ntiles, nrows,
+             plan.row_tile_counts.p, zeros.p);
+    }
+    d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
+                                  zeros.n > 0 ? zeros.p : nullptr);
+  }
   else
   {
     DevArray<uint8_t> ind(nrows);

@@ -896,6 +896,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     if (want_plain) P.plain_rows.alloc(n_plain);
     launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr);
+    P.row_tile_counts = std::move(tcounts); // the inactive dofs of a tile are the rest (cfx_active_domain)
   }
   P.special_mark = std::move(special);
   if (P.nfacets > 0)

@@ -165,11 +165,14 @@ bool is_device_pointer(const void* p)
 template <typename Tin, typename Tout>
 __global__ void __launch_bounds__(kBlock) scan_reduce_kernel(const Tin* __restrict__ in, int64_t n, Tout* tile_sums)
 {
-  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  const int64_t tile = (int64_t)blockIdx.x * kTile; // the order of a sum is free: coalesced, block-strided loads
   Tout s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
-    if (base + k < n) s += (Tout)in[base + k];
+  {
+    const int64_t i = tile + k * kBlock + threadIdx.x;
+    if (i < n) s += (Tout)in[i];
+  }
   Tout total;
   (void)block_exclusive_scan<Tout>(s, total);
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
@@ -179,13 +182,23 @@ template <typename Tin, typename Tout>
 __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restrict__ in, int64_t n,
                                                             const Tout* __restrict__ tile_offsets, Tout* out)
 {
-  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  // a thread scans kScanItems consecutive items; the tile goes through LDS both ways so that the global loads
+  // and stores are coalesced (lane i touches element i of a 256-element row, not its own 64 B run)
+  __shared__ Tout s_v[kTile];
+  const int64_t tile = (int64_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    s_v[i] = (tile + i < n) ? (Tout)in[tile + i] : (Tout)0;
+  }
+  __syncthreads();
   Tout v[kScanItems];
   Tout s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
   {
-    v[k] = (base + k < n) ? (Tout)in[base + k] : (Tout)0;
+    v[k] = s_v[threadIdx.x * kScanItems + k];
     s += v[k];
   }
   Tout total;
@@ -193,8 +206,15 @@ __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restric
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
   {
-    if (base + k < n) out[base + k] = off;
+    s_v[threadIdx.x * kScanItems + k] = off;
     off += v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    if (tile + i < n) out[tile + i] = s_v[i];
   }
   // the element one past the end receives the grand total
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = tile_offsets[blockIdx.x] + total;

@@ -261,13 +261,22 @@ __global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restr
   if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
   __syncthreads();
   const unsigned int tile = s_tile;
-  const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kScanItems;
+  // the tile goes through LDS both ways: coalesced global loads and stores (see scan_write_kernel)
+  __shared__ Tout s_v[kTile];
+  const int64_t tbase = (int64_t)tile * kTile;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    s_v[i] = (tbase + i < n) ? (Tout)in[tbase + i] : (Tout)0;
+  }
+  __syncthreads();
   Tout v[kScanItems];
   Tout s = 0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
   {
-    v[k] = (base + k < n) ? (Tout)in[base + k] : (Tout)0;
+    v[k] = s_v[threadIdx.x * kScanItems + k];
     s += v[k];
   }
   Tout total;
@@ -320,8 +329,15 @@ __global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restr
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
   {
-    if (base + k < n) out[base + k] = off;
+    s_v[threadIdx.x * kScanItems + k] = off;
     off += v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    if (tbase + i < n) out[tbase + i] = s_v[i];
   }
   // the element one past the end receives the grand total
   if ((int64_t)(tile + 1) * kTile >= n && threadIdx.x == kBlock - 1) out[n] = (Tout)s_prefix + total;

@@ -253,8 +253,23 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 
   if (A.dump)
   {
+    if constexpr (NLOC <= 16)
+    {
+      // a thread holds one row (NLOC doubles) of the facet tensor; the block's rows are contiguous in `dump`:
+      // through LDS the stores are coalesced (lane i writes double i of a 256-double line, not its own 64 B run)
+      __shared__ double s_row[kBlock * NLOC];
 #pragma unroll
-    for (int j = 0; j < NLOC; ++j) A.dump[((f - A.dump0) * NLOC + I) * NLOC + j] = acc[j];
+      for (int j = 0; j < NLOC; ++j) s_row[threadIdx.x * NLOC + j] = acc[j];
+      __syncthreads(); // (threads past the end of the launch have left: the barrier counts the live waves)
+      const int64_t first = ((int64_t)blockIdx.x * kBlock + (A.f0 - A.dump0) * NLOC) * NLOC;
+      const int nthreads = (int)min((int64_t)kBlock, A.n * NLOC - (int64_t)blockIdx.x * kBlock); // threads 0..nthreads-1 are here
+      for (int i = threadIdx.x; i < nthreads * NLOC; i += nthreads) A.dump[first + i] = s_row[i];
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NLOC; ++j) A.dump[((f - A.dump0) * NLOC + I) * NLOC + j] = acc[j];
+    }
     return;
   }
 

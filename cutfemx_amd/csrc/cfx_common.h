@@ -418,6 +418,7 @@ struct cfx_row_plan
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
+  cfx::DevArray<int32_t> cell_tile_counts; // marked cells per compaction tile of the cells (empty: not counted)
   cfx::DevArray<int64_t> row_tile_counts; // per compaction tile of the dofs: special rows | plain rows << 32
   bool fold_ok = true;                // P1: every facet row shares all dofs but one per cell (continuous space)
   cfx::DevArray<int32_t> facet_rows;  // [nfacets*4]

@@ -976,7 +976,8 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
     facets_covered = read_scalar(uncovered.p) == 0;
   }
   if (facets_covered)
-    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells);
+    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
+                                plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr);
   else
   {
     // facet integrals contribute both of their cells (deactivate.h:138-146)

@@ -35,14 +35,19 @@ __global__ void plan_mark_cells_kernel(int64_t n, const int32_t* __restrict__ ce
 }
 
 // bit `bit` of 64 consecutive cell marks -> one word; its popcount for the rank scan
-__global__ void plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict__ mark, uint8_t bit,
-                                      unsigned long long* __restrict__ words, int32_t* __restrict__ pop)
+// `marked_tiles` (optional): marked cells (any bit) per compaction tile of kByteTile cells = the 64 words of one
+// wavefront -- the count pass of the active-cell list (cfx_active_domain) for free
+__global__ void __launch_bounds__(kBlock) plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict__ mark, uint8_t bit,
+                                                                unsigned long long* __restrict__ words,
+                                                                int32_t* __restrict__ pop, int32_t* __restrict__ marked_tiles)
 {
-  const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w * 64 >= ncells) return;
+  static_assert(kByteTile == 64 * 64, "one wavefront of 64-cell words per compaction tile");
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const bool live = w * 64 < ncells;
   unsigned long long v = 0;
+  int marked = 0;
   const int64_t base = w * 64;
-  if (base + 64 <= ncells)
+  if (live && base + 64 <= ncells)
   {
     const uint4* p = reinterpret_cast<const uint4*>(mark + base);
 #pragma unroll
@@ -52,14 +57,30 @@ __global__ void plan_pack_bits_kernel(int64_t ncells, const uint8_t* __restrict_
       const unsigned x[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        if ((x[k >> 2] >> (8 * (k & 3))) & bit) v |= 1ull << (16 * q + k);
+      {
+        const unsigned byte = (x[k >> 2] >> (8 * (k & 3))) & 0xffu;
+        if (byte & bit) v |= 1ull << (16 * q + k);
+        marked += byte ? 1 : 0;
+      }
     }
   }
-  else
+  else if (live)
     for (int k = 0; base + k < ncells; ++k)
+    {
       if (mark[base + k] & bit) v |= 1ull << k;
-  words[w] = v;
-  pop[w] = __popcll(v);
+      marked += mark[base + k] ? 1 : 0;
+    }
+  if (live)
+  {
+    words[w] = v;
+    pop[w] = __popcll(v);
+  }
+  if (marked_tiles)
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) marked += __shfl_xor(marked, o, 64);
+    if ((threadIdx.x & 63) == 0 && live) marked_tiles[w >> 6] = marked;
+  }
 }
 
 // uncut entities of a cell integral, nd <= 4 dofs per cell, in one pass over the list: cell mark, row marks
@@ -931,8 +952,14 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     P.std_bits[slot].alloc(nwords);
     P.std_rank[slot].alloc(nwords + 1);
     DevArray<int32_t> pop(nwords);
+    int32_t* tiles = nullptr;
+    if (P.cell_tile_counts.n == 0)
+    {
+      P.cell_tile_counts.alloc((nc + kByteTile - 1) / kByteTile);
+      tiles = P.cell_tile_counts.p;
+    }
     launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, P.cellmark.p,
-           (uint8_t)(1u << slot), reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p);
+           (uint8_t)(1u << slot), reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p, tiles);
     exclusive_scan(pop.p, P.std_rank[slot].p, nwords);
   }
   const char* det = getenv("CFX_DETERMINISTIC");

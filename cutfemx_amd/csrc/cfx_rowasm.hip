@@ -672,6 +672,7 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
                                                             const int32_t* __restrict__ d2c,
                                                             const uint32_t* __restrict__ slot4,
                                                             const uint8_t* __restrict__ cellmark, int nd,
+                                                            const int64_t* __restrict__ st_off,
                                                             unsigned long long* __restrict__ masks,
                                                             uint8_t* __restrict__ uniform)
 {
@@ -682,6 +683,8 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
   const int64_t r = live ? rows[i] : 0;
   unsigned long long m = 0;
   unsigned all_or = 0, all_and = 0xffu; // over the incident cells: equal iff every cell has the same mark
+  bool need_slots = false; // this lane met an unmarked cell
+  int full_cells = 0;      // marked cells this lane did not expand into stencil positions
   if (live)
   {
     const int64_t cb = d2c_off[r];
@@ -690,32 +693,70 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
     for (int base = 0; base < nc; base += R * G)
     {
       int32_t cell[R];
-      uint32_t s4[R];
       uint8_t mk[R];
 #pragma unroll
       for (int k = 0; k < R; ++k)
       {
         const int t = base + k * G + gl;
         cell[k] = t < nc ? d2c[cb + t] : -1;
-        s4[k] = t < nc ? slot4[cb + t] : 0u;
       }
 #pragma unroll
       for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? cellmark[cell[k]] : (uint8_t)0;
+      bool all_marked = true;
 #pragma unroll
       for (int k = 0; k < R; ++k)
       {
-        if (cell[k] >= 0) { all_or |= mk[k]; all_and &= mk[k]; }
-        if (mk[k])
-          for (int j = 0; j < nd; ++j) m |= 1ull << ((s4[k] >> (8 * j)) & 0xffu);
+        if (cell[k] >= 0) { all_or |= mk[k]; all_and &= mk[k]; all_marked = all_marked && mk[k] != 0; }
+      }
+      // the stencil positions are only needed around an unmarked cell: a row whose incident cells are all
+      // marked has every stencil neighbour (the stencil is the union of its incident cells' dofs)
+      if (!all_marked)
+      {
+        need_slots = true;
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+          if (mk[k])
+          {
+            const uint32_t s4 = slot4[cb + base + k * G + gl];
+            for (int j = 0; j < nd; ++j) m |= 1ull << ((s4 >> (8 * j)) & 0xffu);
+          }
+      }
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < R; ++k) full_cells += cell[k] >= 0 ? 1 : 0;
       }
     }
   }
+  int any_unmarked = need_slots ? 1 : 0;
 #pragma unroll
   for (int o = G / 2; o > 0; o >>= 1)
   {
     m |= __shfl_xor(m, o, G);
     all_or |= __shfl_xor(all_or, o, G);
     all_and &= __shfl_xor(all_and, o, G);
+    any_unmarked |= __shfl_xor(any_unmarked, o, G);
+    full_cells += __shfl_xor(full_cells, o, G);
+  }
+  if (live && (any_unmarked == 0 || full_cells == 0) == false)
+  {
+    // mixed row: some lanes skipped the positions of their (all marked) chunk -- expand those cells now
+    const int64_t cb = d2c_off[r];
+    const int nc = (int)(d2c_off[r + 1] - cb);
+    m = 0;
+    for (int t = gl; t < nc; t += G)
+      if (cellmark[d2c[cb + t]])
+      {
+        const uint32_t s4 = slot4[cb + t];
+        for (int j = 0; j < nd; ++j) m |= 1ull << ((s4 >> (8 * j)) & 0xffu);
+      }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) m |= __shfl_xor(m, o, G);
+  }
+  else if (live && any_unmarked == 0)
+  {
+    const int len = (int)(st_off[r + 1] - st_off[r]);
+    m = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
   }
   if (live && gl == 0)
   {
@@ -1032,7 +1073,7 @@ void plain_row_masks(cfx_form_s* a)
   launch("plan_plain_masks", plain_masks_kernel,
          dim3((unsigned)((plan.n_plain_rows + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
-         plan.plain_masks.p, plan.plain_uniform.p);
+         st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p);
 }
 
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:

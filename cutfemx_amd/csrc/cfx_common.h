@@ -308,6 +308,9 @@ struct cfx_mesh_s
   // (dolfinx topology.create_connectivity(tdim-1, tdim)), built on first use by cfx::build_cell_neighbours
   cfx::DevArray<int32_t> c2c;
   bool c2c_built = false;
+  // generated box / slab mesh (cfx_mesh_create_box / _slab): box_n cubes per edge, Kuhn split, vertex id
+  // ix + (n+1)(iy + (n+1) iz): the connectivity is a function of the cell id ("implicit-structured")
+  int box_n = 0;
   const cfx::DevArray<int32_t>& cell_neighbours();
 };
 

@@ -200,6 +200,55 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const 
   }
 }
 
+// Implicit-structured variant of a1 for the generated box / slab meshes with the level set on the geometry dofmap
+// (CFX_IMPLICIT_BOX=1): the connectivity of a Kuhn-split cube is a function of the cube index, so one thread
+// classifies the cells of a cube from its 2^tdim corner codes and the 12.9 GB connectivity stream of
+// classify_kernel (16 of its 18.3 algorithmic bytes per cell) is not read at all.  Same domain array.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) classify_box_kernel(int64_t ncubes, int n, const uint8_t* __restrict__ code,
+                                                              int8_t* __restrict__ domain, int32_t* tiles_inside,
+                                                              int32_t* tiles_cut)
+{
+  constexpr int NC = TDIM == 3 ? 6 : 2; // cells per cube
+  constexpr int NV = TDIM + 1;
+  // corners of the Kuhn simplices, local corner i = bx + 2 by + 4 bz (the generator's tables, cfx_mesh.hip)
+  constexpr int tet[6][4] = {{0, 1, 3, 7}, {0, 1, 5, 7}, {0, 2, 3, 7}, {0, 2, 6, 7}, {0, 4, 5, 7}, {0, 4, 6, 7}};
+  constexpr int tri[2][3] = {{0, 1, 3}, {0, 3, 2}};
+  __shared__ int8_t s_dom[kBlock * NC];
+  __shared__ int s_cnt[4]; // inside / cut cells of the block in the two compaction tiles it can overlap
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t h = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t tile0 = ((int64_t)blockIdx.x * kBlock * NC) / kByteTile;
+  if (h < ncubes)
+  {
+    const int64_t n1 = n + 1;
+    const int64_t ix = h % n, iy = (h / n) % n, iz = TDIM == 3 ? h / ((int64_t)n * n) : 0;
+    const int64_t v0 = ix + n1 * (iy + n1 * iz);
+    unsigned c[1 << TDIM];
+#pragma unroll
+    for (int i = 0; i < (1 << TDIM); ++i)
+      c[i] = code[v0 + (i & 1) + n1 * (((i >> 1) & 1) + n1 * ((i >> 2) & 1))];
+#pragma unroll
+    for (int k = 0; k < NC; ++k)
+    {
+      unsigned all = 3u;
+#pragma unroll
+      for (int j = 0; j < NV; ++j) all &= c[TDIM == 3 ? tet[k][j] : tri[k][j]];
+      s_dom[threadIdx.x * NC + k] = all == 1u ? (int8_t)CFX_INSIDE : (all == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+      if (tiles_inside && all != 2u)
+        atomicAdd(&s_cnt[2 * (int)((h * NC + k) / kByteTile - tile0) + (all == 1u ? 0 : 1)], 1);
+    }
+  }
+  __syncthreads();
+  if (tiles_inside && threadIdx.x < 4 && s_cnt[threadIdx.x])
+    atomicAdd((threadIdx.x & 1 ? tiles_cut : tiles_inside) + tile0 + (threadIdx.x >> 1), s_cnt[threadIdx.x]);
+  // the block's cells are contiguous: coalesced byte stores out of LDS
+  const int64_t first = (int64_t)blockIdx.x * kBlock * NC;
+  const int64_t count = min((int64_t)kBlock, ncubes - (int64_t)blockIdx.x * kBlock) * NC;
+  for (int i = threadIdx.x; i < count; i += kBlock) domain[first + i] = s_dom[i];
+}
+
 // ---------------------------------------------------------------------------
 // a2 sub-triangulation tables.  A vertex is "negative" iff phi < 0 (zeros side
 // with the positive part).  Local point ids: 0..tdim parent vertices, then the
@@ -1501,6 +1550,32 @@ void classify(cfx_cut_t cut)
     launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
            codes.p);
     const uint8_t* phi = codes.p;
+    {
+      // implicit-structured variant (opt-in): generated box mesh, P1 level set on the geometry dofmap
+      const char* ib = getenv("CFX_IMPLICIT_BOX");
+      cfx_mesh_t mesh = cut->mesh;
+      if (ib && ib[0] == '1' && cut->host_width == 0 && mesh->box_n > 0 && cut->ls_dofmap.p == mesh->conn.p
+          && cut->ls_ndofs_cell == mesh->tdim + 1)
+      {
+        const int64_t ncubes = nc / (mesh->tdim == 3 ? 6 : 2);
+        int32_t *b_in = nullptr, *b_cut = nullptr;
+        if (k == 0 && cut->host_mask.n == 0)
+        {
+          const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
+          cut->tiles_inside.alloc(ntiles); cut->tiles_cut.alloc(ntiles);
+          cut->tiles_inside.zero(); cut->tiles_cut.zero();
+          b_in = cut->tiles_inside.p; b_cut = cut->tiles_cut.p;
+        }
+        else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
+        if (mesh->tdim == 3)
+          launch("classify_box", classify_box_kernel<3>, grid_for(ncubes), dim3(kBlock), 0, ncubes, mesh->box_n, phi, dom,
+                 b_in, b_cut);
+        else
+          launch("classify_box", classify_box_kernel<2>, grid_for(ncubes), dim3(kBlock), 0, ncubes, mesh->box_n, phi, dom,
+                 b_in, b_cut);
+        continue;
+      }
+    }
     int32_t *t_in = nullptr, *t_cut = nullptr;
     if (k == 0 && cut->host_mask.n == 0)
     {

@@ -114,6 +114,7 @@ int cfx_mesh_create_box(int tdim, int n, cfx_mesh_t* out)
   m->tdim = tdim; m->gdim = tdim; m->nnodes = nnodes; m->ncells = ncells;
   m->x.alloc(nnodes * 3);
   m->conn.alloc(ncells * (tdim + 1));
+  m->box_n = n;
   launch("box_nodes", box_nodes_kernel, grid_for(nnodes), dim3(kBlock), 0, tdim, n, 0, nnodes, m->x.p);
   launch("box_cells", box_cells_kernel, grid_for(ncells), dim3(kBlock), 0, tdim, n, ncells, m->conn.p);
   *out = m.release();
@@ -135,6 +136,7 @@ int cfx_mesh_create_slab(int n, int z0, int nz, cfx_mesh_t* out)
   m->x.alloc(nnodes * 3);
   m->conn.alloc(ncells * 4);
   // the same generators as the full box: local ids = global ids minus the slab offset
+  m->box_n = n;
   launch("box_nodes", box_nodes_kernel, grid_for(nnodes), dim3(kBlock), 0, 3, n, z0, nnodes, m->x.p);
   launch("box_cells", box_cells_kernel, grid_for(ncells), dim3(kBlock), 0, 3, n, ncells, m->conn.p);
   *out = m.release();

@@ -154,3 +154,26 @@ def test_active_domain_and_deactivation(case):
     M = A.to_scipy()
     inact = ref["inactive"]
     assert np.allclose(M.diagonal()[inact], 1.0) and np.all(b[inact] == 0.0)
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 37), (3, 13)])
+def test_implicit_structured_classification(oracle, tdim, n, monkeypatch):
+    """CFX_IMPLICIT_BOX=1: on a generated box mesh the classification computes the Kuhn connectivity from the
+    cube index instead of streaming it ("implicit-structured"): same domain array, bit for bit."""
+    import cutfemx_amd as cfx
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    mesh = cfx.Mesh.create_box(tdim, n)
+    assert np.array_equal(mesh.conn, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    for kind in ("sphere", "gyroid"):
+        phi = level_set_values(om.x, tdim, kind)
+        phi[::7] = 0.0                                   # exact zeros: those cells are intersected
+        want = O.classify(om.conn, phi)
+        monkeypatch.setenv("CFX_IMPLICIT_BOX", "1")
+        cd = cfx.cut(cfx.Function(V, phi))
+        assert np.array_equal(cd.domain(), want)
+        for sel in ("phi<0", "phi=0", "phi>0"):
+            assert np.array_equal(cfx.locate_entities(cd, sel), O.locate_entities(want, sel))
+        monkeypatch.delenv("CFX_IMPLICIT_BOX")
+        assert np.array_equal(cfx.cut(cfx.Function(V, phi)).domain(), want)

@@ -419,7 +419,7 @@ def main():
                 im = measure(n, max(3, args.steps // 2), 2, args.order, 1, 0, device)
                 k = (im.get("kernels") or {}).get("classify_box")
                 cells = 6 * n ** 3
-                alg = (1.0 + 8.0 * (n + 1) ** 3 / cells / 8.0 + 1.0) * cells   # 1 B code gather share + 1 B out per cell
+                alg = float(cells + (n + 1) ** 3)   # 1 B domain code out per cell + the 1 B sign code of every vertex once
                 out["implicit_structured"] = {
                     "what": "same step, classification from the generated mesh's cube index (no connectivity stream)",
                     "value": im["value"], "unit": "DOF/s", "ms_per_step": im["ms_per_step"],

@@ -91,11 +91,13 @@ def hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer=None)
     run = (lambda name, fn: fn()) if timer is None else timer.run
     cd = run("cut", lambda: cfx.cut(phi_fn))
     system = run("rules+facets+forms", lambda: poisson.build_forms(V, cd, order=order))
-    b_buf.zero_()
+    from cutfemx_amd import _lib
+    import ctypes as C
+    _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(b_buf.data_ptr()), 0, C.c_size_t(8 * b_buf.numel())))   # b = 0
     A = run("sparsity", lambda: cfx.fem.create_matrix(system.a, values=values_buf))
     if A.nnz > values_buf.numel():
         raise RuntimeError("values buffer too small")
-    values_buf[: A.nnz].zero_()
+    A.set_value(0.0)                                                                                              # A = 0
     run("assemble_matrix", lambda: cfx.fem.assemble_matrix(system.a, A=A))
     run("assemble_vector", lambda: cfx.fem.assemble_vector(system.L, b_buf))
     dom = run("deactivate", lambda: cfx.fem.deactivate_outside(A, b_buf, cfx.fem.active_domain(system.a)))

@@ -76,6 +76,14 @@ def sphere_layer_weights(n: int, active_weight: float = 15.0, cut_weight: float 
     return 6.0 * n * n + active_weight * active + cut_weight * cut
 
 
+def _zero(t):
+    """t[:] = 0 on the engine's stream with its streaming fill (cfx_device_memset)."""
+    import ctypes as C
+
+    from . import _lib
+    _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(t.data_ptr()), 0, C.c_size_t(t.element_size() * t.numel())))
+
+
 @dataclass
 class SlabPartition:
     n: int
@@ -271,9 +279,9 @@ class DistributedPoisson:
             halo_forward(self.phi_values, part)
         cd = cfx.cut(self.phi)
         system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
-        self.b.zero_()
+        _zero(self.b)
         A = fem.create_matrix(system.a, values=self.values)
-        self.values[:A.nnz].zero_()
+        A.set_value(0.0)
         fem.assemble_matrix(system.a, A=A)
         fem.assemble_vector(system.L, self.b)
         dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
@@ -339,8 +347,8 @@ class DistributedPoisson:
                           fem.Integral(fem.NITSCHE_RHS, rules=itf_o, point_data=normals,
                                        params=(self.gamma, fem.F_SINPROD, 1.0))], self.V)
         A = fem.create_matrix(a_all, values=self.values)
-        self.values[:A.nnz].zero_()
-        self.b.zero_()
+        A.set_value(0.0)
+        _zero(self.b)
         fem.assemble_matrix(a_own, A=A)
         fem.assemble_vector(L_own, self.b)
         # --- A.scatter_reverse(); b.scatter_reverse(add)

@@ -141,6 +141,10 @@ void dev_cache_release(); // hipFree every cached block
 // ---------------------------------------------------------------------------
 // device arrays: owning (cached blocks) or aliasing a caller pointer
 // ---------------------------------------------------------------------------
+// memset on the library stream in ONE launch (hipMemsetAsync splits unaligned sizes into up to three fill kernels,
+// ~100 tiny launches per step); cfx_runtime.hip
+void dev_fill(void* p, int byte, size_t bytes);
+
 template <typename T>
 struct DevArray
 {
@@ -178,7 +182,7 @@ struct DevArray
     if (p && owned) dev_free(p);
     p = nullptr; n = 0; owned = false;
   }
-  void zero() { if (n > 0) CFX_HIP(hipMemsetAsync(p, 0, sizeof(T) * (size_t)n, ctx().stream)); }
+  void zero() { if (n > 0) dev_fill(p, 0, sizeof(T) * (size_t)n); }
   T* get() const { return p; }
 };
 

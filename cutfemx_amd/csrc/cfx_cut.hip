@@ -1849,7 +1849,7 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
   r->weights.alloc(nq);
   r->offsets.alloc(nr + 1);
   r->parent_map.alloc(nr);
-  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  dev_fill(r->offsets.p, 0, sizeof(int32_t));
   if (ncut > 0)
   {
     const dim3 grid((unsigned)((ncut + kBlock / kEmitLanes - 1) / (kBlock / kEmitLanes)));
@@ -1878,7 +1878,7 @@ int cfx_full_cell_rules(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int or
   auto r = std::make_unique<cfx_rules_s>();
   r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = n; r->nq = n * nref;
   r->points.alloc(r->nq * tdim); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
-  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  dev_fill(r->offsets.p, 0, sizeof(int32_t));
   if (n > 0)
   {
     if (tdim == 2)
@@ -2117,9 +2117,9 @@ int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double thre
   A->ncells = nc;
   A->root_cell.alloc(nc); A->aggregate_id.alloc(nc); A->depth.alloc(nc); A->fraction.alloc(nc);
   A->fraction.zero();
-  CFX_HIP(hipMemsetAsync(A->root_cell.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
-  CFX_HIP(hipMemsetAsync(A->aggregate_id.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
-  CFX_HIP(hipMemsetAsync(A->depth.p, 0xff, sizeof(int32_t) * (size_t)nc, ctx().stream));
+  dev_fill(A->root_cell.p, 0xff, sizeof(int32_t) * (size_t)nc);
+  dev_fill(A->aggregate_id.p, 0xff, sizeof(int32_t) * (size_t)nc);
+  dev_fill(A->depth.p, 0xff, sizeof(int32_t) * (size_t)nc);
   {
     // volume fraction of the selected part: order-1 rules of the cut cells (weights sum to the part's measure)
     cfx_rules_t rules = nullptr;
@@ -2271,7 +2271,7 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
     r->nr = n; r->nq = n * nref;
     r->points.alloc(r->nq * hd); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
     rule_host.alloc(n);
-    CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+    dev_fill(r->offsets.p, 0, sizeof(int32_t));
     if (n > 0)
     {
       if (tdim == 2)
@@ -2314,7 +2314,7 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
     r->nq = nq; r->nr = nr;
     r->points.alloc(nq * hd); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);
     rule_host.alloc(nr);
-    CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+    dev_fill(r->offsets.p, 0, sizeof(int32_t));
     if (ncut > 0)
     {
       if (tdim == 2)
@@ -2474,7 +2474,7 @@ int cfx_facet_rules_to_cells(cfx_rules_t R, int side, cfx_rules_t* out)
   auto r = std::make_unique<cfx_rules_s>();
   r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = nr; r->nq = nq;
   r->points.alloc(nq * tdim); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);
-  CFX_HIP(hipMemsetAsync(r->offsets.p, 0, sizeof(int32_t), ctx().stream));
+  dev_fill(r->offsets.p, 0, sizeof(int32_t));
   if (nr > 0)
   {
     // cell-hosted rules are consumed in ascending parent order (runs of one parent are contiguous)

@@ -886,7 +886,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         P.rule_mask[slot] = size - 1;
         P.rule_keys[slot].alloc(size);
         P.rule_first[slot].alloc(size);
-        CFX_HIP(hipMemsetAsync(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size, ctx().stream));
+        dev_fill(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size);
         if (nd == 4)
           launch("plan_rules", plan_rules_kernel<4>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
@@ -927,7 +927,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       if (I.n_entities == 0) continue;
       CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)I.n_entities,
                              hipMemcpyDeviceToDevice, ctx().stream));
-      CFX_HIP(hipMemsetAsync(P.facet_slot.p + o, s, (size_t)I.n_entities, ctx().stream));
+      dev_fill(P.facet_slot.p + o, s, (size_t)I.n_entities);
       if (nd == 4)
         launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
                I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
@@ -1133,7 +1133,7 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   const int64_t total = read_scalar(off.p + n);
   if (total == 0 || total >= 2147483647LL) return false;
   plan.vec_t2off.alloc(V->ndofs);
-  CFX_HIP(hipMemsetAsync(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs, ctx().stream));
+  dev_fill(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs);
   launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, off.p,
          plan.vec_t2off.p);
   // everything else (the rows next to the interface, plain rows that are not uniform) reads the per-cell records

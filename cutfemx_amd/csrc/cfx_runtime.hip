@@ -348,7 +348,7 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n)
 {
   if (n == 0)
   {
-    CFX_HIP(hipMemsetAsync(out, 0, sizeof(Tout), ctx().stream));
+    cfx::dev_fill(out, 0, sizeof(Tout));
     return;
   }
   const int64_t ntiles = (n + kTile - 1) / kTile;
@@ -441,6 +441,42 @@ using namespace cfx;
 // ---------------------------------------------------------------------------
 // C ABI: runtime
 // ---------------------------------------------------------------------------
+namespace
+{
+// streaming fill, 16 B per lane per store, 4 stores per thread (zeroing the 3 GB of CSR values and the 1 GB
+// right-hand side is part of every step); the bytes past the last 16 B chunk go out bytewise from block 0
+__global__ void __launch_bounds__(kBlock) fill16_kernel(unsigned char* __restrict__ p, size_t bytes, unsigned word)
+{
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const uint4 v = make_uint4(word, word, word, word);
+  const int64_t base = (int64_t)blockIdx.x * (kBlock * 4) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const int64_t i = base + (int64_t)k * kBlock;
+    if (i < n16) reinterpret_cast<uint4*>(p)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[(size_t)n16 * 16 + threadIdx.x] = (unsigned char)word;
+}
+} // namespace
+
+namespace cfx
+{
+void dev_fill(void* p, int byte, size_t bytes)
+{
+  if (bytes == 0) return;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) != 0)
+  {
+    CFX_HIP(hipMemsetAsync(p, byte, bytes, ctx().stream));
+    return;
+  }
+  const unsigned b = (unsigned)byte & 0xffu, word = b | (b << 8) | (b << 16) | (b << 24);
+  const int64_t n16 = (int64_t)(bytes / 16);
+  launch("fill", fill16_kernel, grid_for(std::max<int64_t>(n16, 1), kBlock * 4), dim3(kBlock), 0,
+         static_cast<unsigned char*>(p), bytes, word);
+}
+} // namespace cfx
+
 extern "C" {
 
 const char* cfx_last_error(void) { return g_last_error.c_str(); }
@@ -513,35 +549,12 @@ int cfx_device_cache_release(void)
   CFX_API_END
 }
 
-// streaming fill, 16 B per lane per store, 4 stores per thread (zeroing the 3 GB of CSR values and the 1 GB
-// right-hand side is part of every step)
-__global__ void __launch_bounds__(kBlock) fill16_kernel(uint4* __restrict__ p, int64_t n16, unsigned word)
-{
-  const uint4 v = make_uint4(word, word, word, word);
-  const int64_t base = (int64_t)blockIdx.x * (kBlock * 4) + threadIdx.x;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-  {
-    const int64_t i = base + (int64_t)k * kBlock;
-    if (i < n16) p[i] = v;
-  }
-}
-
 int cfx_device_memset(void* ptr, int byte, size_t bytes)
 {
   CFX_API_BEGIN
   ctx().ensure();
   if (bytes && !ptr) throw Error(CFX_ERR_INVALID_ARGUMENT, "cfx_device_memset: null pointer");
-  if (bytes >= (1u << 20) && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0)
-  {
-    const unsigned b = (unsigned)byte & 0xffu, word = b | (b << 8) | (b << 16) | (b << 24);
-    const int64_t n16 = (int64_t)(bytes / 16);
-    launch("fill", fill16_kernel, grid_for(n16, kBlock * 4), dim3(kBlock), 0, static_cast<uint4*>(ptr), n16, word);
-    const size_t tail = bytes - (size_t)n16 * 16;
-    if (tail) CFX_HIP(hipMemsetAsync(static_cast<char*>(ptr) + (size_t)n16 * 16, byte, tail, ctx().stream));
-  }
-  else if (bytes)
-    CFX_HIP(hipMemsetAsync(ptr, byte, bytes, ctx().stream));
+  if (bytes) cfx::dev_fill(ptr, byte, bytes);
   CFX_API_END
 }
 

@@ -177,3 +177,27 @@ def test_implicit_structured_classification(oracle, tdim, n, monkeypatch):
             assert np.array_equal(cfx.locate_entities(cd, sel), O.locate_entities(want, sel))
         monkeypatch.delenv("CFX_IMPLICIT_BOX")
         assert np.array_equal(cfx.cut(cfx.Function(V, phi)).domain(), want)
+
+
+def test_device_memset_any_size_and_alignment():
+    """cfx_device_memset is the library's own fill kernel (16 B stores + a bytewise tail; unaligned pointers go
+    to hipMemsetAsync): every size / offset combination must touch exactly its range."""
+    import ctypes as C
+
+    import cutfemx_amd as cfx  # noqa: F401
+    from cutfemx_amd import _lib
+    n = 1 << 16
+    buf = _lib.DeviceBuffer(n, np.uint8)
+    host = np.full(n, 0xAB, dtype=np.uint8)
+    l = _lib.lib()
+    rng = np.random.default_rng(5)
+    cases = [(0, 0), (0, 1), (0, 15), (0, 16), (0, 17), (16, 4095), (32, 4096), (1, 100), (7, 33), (48, n - 48)]
+    cases += [(int(rng.integers(0, 1000)), int(rng.integers(0, 30000))) for _ in range(20)]
+    for off, size in cases:
+        _lib.check(l.cfx_copy(C.c_void_p(buf.ptr), host.ctypes.data_as(C.c_void_p), C.c_size_t(n)))
+        byte = int(rng.integers(0, 256))
+        _lib.check(l.cfx_device_memset(C.c_void_p(buf.ptr + off), byte, C.c_size_t(size)))
+        got = _lib.download(buf.ptr, n, np.uint8)
+        want = host.copy()
+        want[off:off + size] = byte
+        assert np.array_equal(got, want), (off, size)

@@ -145,6 +145,16 @@ void dev_cache_release(); // hipFree every cached block
 // ~100 tiny launches per step); cfx_runtime.hip
 void dev_fill(void* p, int byte, size_t bytes);
 
+// a zero-initialised device int from a pool that is cleared with one fill per 4096 flags (error / overflow flags:
+// a step took a dozen 4-byte memsets for them)
+int* zero_flag(); // cfx_runtime.hip
+struct ZeroFlag
+{
+  int* p;
+  ZeroFlag() : p(zero_flag()) {}
+  void zero() { dev_fill(p, 0, sizeof(int)); } // a flag that is reused in a loop
+};
+
 template <typename T>
 struct DevArray
 {

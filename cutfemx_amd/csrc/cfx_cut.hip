@@ -1731,8 +1731,7 @@ int cfx_cut_restrict(cfx_cut_t cut, const int32_t* cells, int64_t n)
   DevArray<int32_t> dcells = to_device(cells, n);
   cut->host_mask.alloc(nc);
   cut->host_mask.zero();
-  DevArray<int> bad(1);
-  bad.zero();
+  ZeroFlag bad;
   launch("mark_subset", mark_subset_kernel, grid_for(n), dim3(kBlock), 0, n, dcells.p, nc, cut->host_mask.p, bad.p);
   require(!read_scalar(bad.p), CFX_ERR_OUT_OF_RANGE, "cfx_cut_restrict: cell index out of range");
   classify(cut);
@@ -2060,8 +2059,7 @@ int cfx_interior_facets_for_cells(cfx_mesh_t mesh, const int32_t* cells, int64_t
   DevArray<int32_t> dcells = to_device(cells, n);
   DevArray<uint8_t> inset(nc);
   inset.zero();
-  DevArray<int> bad(1);
-  bad.zero();
+  ZeroFlag bad;
   launch("mark_subset", mark_subset_kernel, grid_for(n), dim3(kBlock), 0, n, dcells.p, nc, inset.p, bad.p);
   require(!read_scalar(bad.p), CFX_ERR_OUT_OF_RANGE, "cfx_interior_facets_for_cells: cell index out of range");
   DevArray<int32_t> sorted; // ascending, duplicates removed
@@ -2150,7 +2148,7 @@ int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double thre
   launch("agg_roots", agg_roots_kernel, grid_for(n_well), dim3(kBlock), 0, n_well, A->well.p, A->root_cell.p,
          A->aggregate_id.p, A->depth.p);
   const Adjacency& adj = mesh->vertex_cells();
-  DevArray<int> changed(1);
+  ZeroFlag changed;
   DevArray<int32_t> parent(n_ill);
   if (n_ill > 0)
   {
@@ -2413,8 +2411,7 @@ int cfx_cut_create_facets(cfx_mesh_t mesh, int64_t n, const int32_t* facet_ids, 
     DevArray<int32_t> drows = to_device(rows, n * row_width);
     DevArray<int32_t> dgeom = to_device(entity_geometry, entity_geometry ? n * tdim : 0);
     DevArray<int32_t> dls = to_device(ls_dofmap, mesh->ncells * (int64_t)ls_ndofs_cell);
-    DevArray<int> bad(1);
-    bad.zero();
+    ZeroFlag bad;
     if (n > 0)
     {
       CFX_HIP(hipMemcpyAsync(cut->host_rows.p, drows.p, sizeof(int32_t) * (size_t)(n * row_width), hipMemcpyDeviceToDevice,
@@ -2479,8 +2476,7 @@ int cfx_facet_rules_to_cells(cfx_rules_t R, int side, cfx_rules_t* out)
   {
     // cell-hosted rules are consumed in ascending parent order (runs of one parent are contiguous)
     DevArray<int32_t> keys(nr), perm(nr), counts(nr);
-    DevArray<int> unsorted(1);
-    unsorted.zero();
+    ZeroFlag unsorted;
     launch("facet_to_cells", rule_cell_keys_kernel, grid_for(nr), dim3(kBlock), 0, nr, R->host_rows.p, R->host_width, side,
            keys.p, unsorted.p);
     launch("iota", iota_kernel, grid_for(nr), dim3(kBlock), 0, nr, perm.p);

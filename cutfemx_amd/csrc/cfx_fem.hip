@@ -644,8 +644,7 @@ namespace cfx
 void dump_integral(cfx_form_s* a, int integral, int parts, double* out)
 {
   cfx_space_s* V = a->V;
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.dump = out; A.error = err.p;
@@ -818,8 +817,7 @@ int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const 
   require(P->nrows == V->ndofs * V->bs, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: pattern/space size mismatch");
   DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->nrows : 0);
   OutArray<double> out(values, P->nnz, true);
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.bc0 = bc0 ? dbc0.p : nullptr; A.bc1 = bc1 ? dbc1.p : nullptr;
@@ -840,8 +838,7 @@ int cfx_assemble_vector(cfx_form_t L, double* b)
   require(L->rank == 1, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_vector: form is not linear");
   cfx_space_s* V = L->V;
   OutArray<double> out(b, V->ndofs * V->bs, true);
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.values = out.dev; A.error = err.p;
@@ -863,8 +860,7 @@ int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_v
   DevArray<int8_t> dm = to_device(bc_markers, n);
   DevArray<double> dv = to_device(bc_values, n), dx0 = to_device(x0, x0 ? n : 0);
   OutArray<double> out(b, n, true);
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.values = out.dev; A.error = err.p;
@@ -940,8 +936,7 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
   const int nloc = V->ndofs_cell * V->bs * (I.type == CFX_INTERIOR_FACET ? 2 : 1);
   const int64_t n = a->rank == 2 ? (int64_t)nloc * nloc : nloc;
   OutArray<double> out(Ae, n, false);
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.dump = out.dev; A.error = err.p;
@@ -969,8 +964,7 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   {
     // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty
     // band lies in the cut and inside cells): then the cell marks alone are the indicator
-    DevArray<int> uncovered(1);
-    uncovered.zero();
+    ZeroFlag uncovered;
     launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets * 2), dim3(kBlock), 0, plan.nfacets,
            plan.facet_rows.p, plan.cellmark.p, uncovered.p);
     facets_covered = read_scalar(uncovered.p) == 0;
@@ -1040,8 +1034,7 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t P, double* values, doub
   std::unique_ptr<OutArray<double>> ov, ob;
   if (values) ov = std::make_unique<OutArray<double>>(values, P->nnz, true);
   if (b) ob = std::make_unique<OutArray<double>>(b, nrows, true);
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   if (d->n_inactive > 0)
     launch("deactivate", deactivate_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
            d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,

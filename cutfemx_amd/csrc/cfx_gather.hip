@@ -1475,8 +1475,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG>(a, st);
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   A.error = err.p;
   if (const char* dbg = getenv("CFX_DEBUG_ROWS")) A.debug = atoi(dbg);
   if (A.n_active > 0)
@@ -1621,8 +1620,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   RowArgs A = prepare<TDIM, DEG, BS>(a, st);
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
   A.mark_mask = 0xFFu;
-  DevArray<int> err(1);
-  err.zero();
+  ZeroFlag err;
   A.error = err.p;
   if (A.n_active > 0)
   {

@@ -849,8 +849,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   P.rowmark.zero();
   DevArray<uint8_t> special(V->ndofs); // rows touched by a runtime-rule cell or a facet
   special.zero();
-  DevArray<int> flag(1);
-  flag.zero();
+  ZeroFlag flag;
   P.nfacets = 0;
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
@@ -1037,9 +1036,7 @@ const Stencil& space_stencil(cfx_space_s* V)
   A.nd = V->ndofs_cell; A.bs = 1; A.dofmap = V->dofmap.p;
   A.d2c_off = adj.offsets.p; A.d2c = adj.cells.p;
   DevArray<int32_t> counts(V->ndofs), len(V->ndofs);
-  DevArray<int> overflow(1), maxlen(1);
-  overflow.zero();
-  maxlen.zero();
+  ZeroFlag overflow, maxlen;
   A.len = len.p; A.counts = counts.p; A.overflow = overflow.p; A.maxlen = maxlen.p;
   // count, scan, then build every set again and write it in place (no ndofs x 64 staging)
   launch("stencil_rows", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
@@ -1178,9 +1175,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   P->nrows = V->ndofs * V->bs;
   DevArray<int32_t> counts(P->nrows), len(n_h), tmp;
-  DevArray<int> overflow(1), maxlen(1);
-  overflow.zero();
-  maxlen.zero();
+  ZeroFlag overflow, maxlen;
   launch("pattern_init", fill_i32_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, (int32_t)V->bs, counts.p);
   S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
   int T = 64;

@@ -462,6 +462,21 @@ __global__ void __launch_bounds__(kBlock) fill16_kernel(unsigned char* __restric
 
 namespace cfx
 {
+int* zero_flag()
+{
+  constexpr int kFlags = 4096;
+  static int* pool = nullptr;
+  static int next = kFlags;
+  if (!pool) pool = static_cast<int*>(dev_alloc(sizeof(int) * kFlags));
+  if (next == kFlags)
+  {
+    // stream order: every earlier user of the pool is ahead of this fill, every later one behind it
+    dev_fill(pool, 0, sizeof(int) * kFlags);
+    next = 0;
+  }
+  return pool + next++;
+}
+
 void dev_fill(void* p, int byte, size_t bytes)
 {
   if (bytes == 0) return;

@@ -358,11 +358,32 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n)
   static const int64_t chained_max = getenv("CFX_SCAN_CHAINED_TILES") ? atoll(getenv("CFX_SCAN_CHAINED_TILES")) : 8192;
   if (ntiles > 1 && ntiles <= chained_max)
   {
-    // tile states + ticket, zeroed by one memset
-    DevArray<unsigned long long> state(ntiles + 1);
-    state.zero();
-    launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, state.p,
-           reinterpret_cast<unsigned int*>(state.p + ntiles), out);
+    // tile states + ticket: a zeroed slice of a pool that is cleared with one fill when it wraps (a step runs
+    // a dozen short scans: one memset each otherwise)
+    constexpr int64_t kPoolWords = 1 << 20;
+    static unsigned long long* pool = nullptr;
+    static int64_t next = kPoolWords;
+    unsigned long long* state;
+    DevArray<unsigned long long> own;
+    if (ntiles + 1 > kPoolWords / 4)
+    {
+      own.alloc(ntiles + 1);
+      own.zero();
+      state = own.p;
+    }
+    else
+    {
+      if (!pool) pool = static_cast<unsigned long long*>(dev_alloc(sizeof(unsigned long long) * kPoolWords));
+      if (next + ntiles + 1 > kPoolWords)
+      {
+        cfx::dev_fill(pool, 0, sizeof(unsigned long long) * kPoolWords); // stream order keeps earlier users ahead of it
+        next = 0;
+      }
+      state = pool + next;
+      next += ntiles + 1;
+    }
+    launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, state,
+           reinterpret_cast<unsigned int*>(state + ntiles), out);
     return;
   }
   if (ntiles == 1)

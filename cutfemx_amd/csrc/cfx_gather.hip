@@ -300,17 +300,23 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
   double be[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) be[i] = 0.0;
+  // edges from vertex 0: x(X) = x_0 + sum_t X_t (x_{t+1} - x_0), TDIM fused multiply-adds per coordinate
+  double ed[TDIM][TDIM];
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t)
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) ed[t][d] = g.x[t + 1][d] - g.x[0][d];
   for (int q = sub; q < npts; q += LANES)
   {
-    double X[TDIM], xq[TDIM], l0 = 1.0;
+    double X[TDIM], xq[TDIM];
 #pragma unroll
-    for (int t = 0; t < TDIM; ++t) { X[t] = pts[(int64_t)q * TDIM + t]; l0 -= X[t]; }
+    for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
 #pragma unroll
     for (int d = 0; d < TDIM; ++d)
     {
-      double v = l0 * g.x[0][d];
+      double v = g.x[0][d];
 #pragma unroll
-      for (int t = 0; t < TDIM; ++t) v += X[t] * g.x[t + 1][d];
+      for (int t = 0; t < TDIM; ++t) v = fma(X[t], ed[t][d], v);
       xq[d] = v;
     }
     const double w = wts[q] * wscale;

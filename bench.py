@@ -58,7 +58,7 @@ def parse():
                    help="background mesh n^3 cubes (x6 tets); use --mesh under torchrun (--n is ambiguous there)")
     p.add_argument("--order", type=int, default=4, help="runtime quadrature order (demo_poisson.py:139)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    p.add_argument("--cpu-n", type=int, default=160, help="mesh size of the bounded CPU sample")
+    p.add_argument("--cpu-n", type=int, default=192, help="mesh size of the bounded CPU sample")
     p.add_argument("--no-secondary", action="store_true", help="skip the 128^3 (configs[1]) line")
     p.add_argument("--cpu-worker", nargs=4, type=int, metavar=("N", "Z0", "Z1", "ORDER"),
                    help="internal: one process of the all-cores CPU baseline")

@@ -485,17 +485,20 @@ namespace cfx
 {
 int* zero_flag()
 {
+  // two alternating pools: only the pool being switched TO is refilled, so a flag a caller still holds
+  // (written by kernels, not yet read back) survives until 4096 further flags have been handed out
   constexpr int kFlags = 4096;
-  static int* pool = nullptr;
-  static int next = kFlags;
-  if (!pool) pool = static_cast<int*>(dev_alloc(sizeof(int) * kFlags));
+  static int* pool[2] = {nullptr, nullptr};
+  static int cur = 1, next = kFlags;
   if (next == kFlags)
   {
-    // stream order: every earlier user of the pool is ahead of this fill, every later one behind it
-    dev_fill(pool, 0, sizeof(int) * kFlags);
+    cur ^= 1;
+    if (!pool[cur]) pool[cur] = static_cast<int*>(dev_alloc(sizeof(int) * kFlags));
+    // stream order: every earlier user of this pool is ahead of the fill, every later one behind it
+    dev_fill(pool[cur], 0, sizeof(int) * kFlags);
     next = 0;
   }
-  return pool + next++;
+  return pool[cur] + next++;
 }
 
 void dev_fill(void* p, int byte, size_t bytes)
@@ -521,11 +524,11 @@ int cfx_init(int device)
 {
   CFX_API_BEGIN
   Context& c = ctx();
+  // one process drives one GPU (one rank per device): the block cache, the flag / scan-state pools and every
+  // live handle hold pointers of the first device, so a later call must name the same device
   if (c.initialised && c.device != device)
-  {
-    c.flush_profile();
-    c.initialised = false;
-  }
+    throw Error(CFX_ERR_INVALID_ARGUMENT, "cfx_init: the library is already bound to device " + std::to_string(c.device)
+                                              + "; use one process per GPU");
   c.device = device;
   c.ensure();
   CFX_API_END
@@ -536,6 +539,8 @@ int cfx_set_stream(void* s)
   CFX_API_BEGIN
   ctx().ensure();
   ctx().flush_profile();
+  // cached blocks and pool slices handed out earlier may still be in use by work queued on the old stream
+  if (ctx().stream != (hipStream_t)s) CFX_HIP(hipStreamSynchronize(ctx().stream));
   ctx().stream = (hipStream_t)s;
   CFX_API_END
 }

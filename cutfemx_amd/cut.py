@@ -357,11 +357,24 @@ def locate_entities(cut_data: CutData, ls_part: str) -> np.ndarray:
     return _lib.download(p.value, n.value, np.int32)
 
 
+class DeviceEntities(tuple):
+    """(device pointer, count) of a located entity list.  The array belongs to the `CutData` it came from:
+    the tuple keeps that object alive (`owner`), and the list is valid until the next `update()` /
+    `locate_entities` with the same selector on it -- forms must be rebuilt after an update, as
+    python/demo/demo_moving_poisson.py:53-67 does."""
+    owner = None
+
+    def __new__(cls, ptr, n, owner):
+        self = super().__new__(cls, (ptr, n))
+        self.owner = owner
+        return self
+
+
 def locate_entities_device(cut_data: CutData, ls_part: str):
-    """(device pointer, count) of the selector result; owned by `cut_data`."""
+    """(device pointer, count) of the selector result; owned by `cut_data` (kept alive by the result)."""
     p, n = C.c_void_p(), C.c_int64()
     _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, _engine_selector(cut_data, ls_part), C.byref(p), C.byref(n)))
-    return p.value, n.value
+    return DeviceEntities(p.value, n.value, cut_data)
 
 
 def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: str = "straight"):

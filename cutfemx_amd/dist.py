@@ -258,8 +258,21 @@ class DistributedPoisson:
         self.phi_values = (torch.sqrt(d2) - R).reshape(-1).contiguous()
         self.phi = cfx.Function(self.V, self.phi_values)
         nn = self.mesh.num_nodes
+        # first guess of the CSR value buffer; _matrix() grows it to the real nnz when a step needs more
         self.values = torch.zeros(nn + 40 * int(0.25 * nn + 100000), device=device, dtype=torch.float64)
         self.b = torch.zeros(nn, device=device, dtype=torch.float64)
+
+    def _matrix(self, a):
+        """create_matrix(a) over the persistent value buffer, reallocated when the pattern outgrows it."""
+        from . import fem
+        try:
+            return fem.create_matrix(a, values=self.values)
+        except ValueError:
+            A = fem.create_matrix(a)            # library-owned values: only to learn nnz
+            nnz = A.nnz
+            del A
+            self.values = self.torch.zeros(nnz + nnz // 8, device=self.device, dtype=self.torch.float64)
+            return fem.create_matrix(a, values=self.values)
 
     def step(self):
         return self.step_owner() if self.mode == "owner" else self.step_reduce()
@@ -280,7 +293,7 @@ class DistributedPoisson:
         cd = cfx.cut(self.phi)
         system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
         _zero(self.b)
-        A = fem.create_matrix(system.a, values=self.values)
+        A = self._matrix(system.a)
         A.set_value(0.0)
         fem.assemble_matrix(system.a, A=A)
         fem.assemble_vector(system.L, self.b)
@@ -346,7 +359,7 @@ class DistributedPoisson:
                                        params=(fem.F_POISSON_RHS, 1.0), qdegree=4),
                           fem.Integral(fem.NITSCHE_RHS, rules=itf_o, point_data=normals,
                                        params=(self.gamma, fem.F_SINPROD, 1.0))], self.V)
-        A = fem.create_matrix(a_all, values=self.values)
+        A = self._matrix(a_all)
         A.set_value(0.0)
         _zero(self.b)
         fem.assemble_matrix(a_own, A=A)

@@ -66,6 +66,7 @@ class Integral:
         elif self.cells is not None:
             if isinstance(self.cells, tuple):  # (device pointer, count)
                 ent_ptr, n_ent = C.c_void_p(self.cells[0]), int(self.cells[1])
+                keep.append(self.cells)       # a DeviceEntities tuple pins the CutData that owns the list
             else:
                 ent_ptr = _lib.as_ptr(self.cells, np.int32, keep)
                 n_ent = int(keep[-1].numel() if _lib.is_torch(keep[-1]) else keep[-1].size)
@@ -129,9 +130,23 @@ class MatrixCSR:
             _lib.check(_lib.lib().cfx_device_alloc(C.byref(p), C.c_size_t(8 * max(self.nnz, 1))))
             self.values_ptr = p.value
             self.set_value(0.0)
-        else:  # torch tensor on the device
+        else:  # caller-owned HBM buffer: set_value / cfx_assemble_matrix write 8*nnz bytes through the raw pointer
+            if isinstance(values, _lib.DeviceBuffer):
+                ok_type, count, ptr = values.dtype == np.dtype(np.float64), values.size, values.ptr
+            elif _lib.is_torch(values):
+                import torch
+                ok_type = values.dtype == torch.float64 and values.is_cuda and values.is_contiguous()
+                count, ptr = int(values.numel()), values.data_ptr()
+            else:
+                raise TypeError("values must be a device torch tensor or a DeviceBuffer")
+            if not ok_type:
+                raise TypeError("values must be a contiguous float64 buffer in HBM")
+            if count < self.nnz:
+                _lib.lib().cfx_pattern_destroy(self._p)
+                self._p = None
+                raise ValueError(f"values holds {count} entries but the sparsity pattern needs nnz = {self.nnz}")
             self._values_keep = values
-            self.values_ptr = values.data_ptr()
+            self.values_ptr = ptr
 
     def set_value(self, v: float):
         if float(v) == 0.0:

@@ -149,9 +149,10 @@ typedef struct
 } cfx_pattern_view;
 
 /* ---- runtime ------------------------------------------------------------- */
-int cfx_init(int device);              /* select the HIP device; fails loudly without one */
+int cfx_init(int device);              /* select the HIP device; fails loudly without one.  One process drives one
+                                          GPU: a later call naming another device is CFX_ERR_INVALID_ARGUMENT */
 const char* cfx_last_error(void);
-int cfx_set_stream(void* hip_stream);  /* all later launches go to this stream */
+int cfx_set_stream(void* hip_stream);  /* all later launches go to this stream (the old one is synchronised first) */
 int cfx_synchronize(void);
 int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
 int cfx_device_alloc(void** ptr, size_t bytes);

@@ -201,5 +201,6 @@ def test_partition_arithmetic():
         assert p.lz0 <= p.z0 < p.z1 <= p.lz1
         for peer, s, rcv in p.exchanges():
             q = SlabPartition.create(64, 8, peer)
-            assert (p.rank, rcv, s) in [(pp, ss, rr) for pp, rr, ss in [(e[0], e[1], e[2]) for e in q.exchanges()]] or True
+            # the peer lists the mirrored exchange: it sends the plane I receive and receives the one I send
+            assert (p.rank, rcv, s) in q.exchanges(), (r, peer, s, rcv, q.exchanges())
     assert planes == list(range(65))

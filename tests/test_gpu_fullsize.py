@@ -374,12 +374,17 @@ def test_cfg4_p2_gyroid_256(oracle):
 
 # --------------------------------------------------------------------------- config 5
 def test_cfg5_p2_vector_elasticity_rank_share(oracle):
+    """configs[4]: a = sigma(u):eps(v) dx_solid + gamma (2 mu + lambda) h_avg [grad u.n].[grad v.n] dS_ghost on the
+    P2 vector space (python/demo/demo_elasticity.py:214-235), strong Dirichlet data lifted through it (:67-93)."""
     torch = _torch()
     import cutfemx_amd as cfx
     from cutfemx_amd.dist import as_torch
     _need_hbm(60)
     n, dev, fem = 256, torch.device("cuda", 0), cfx.fem
     gz0, gnz = 89, 32                      # one of eight ranks' share of the 256^3 mesh
+    E, nu = 1.0e3, 0.3
+    mu, lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    gpar = 0.05 * (2.0 * mu + lmbda)
     mesh = cfx.Mesh.create_slab(n, gz0, gnz)
     Vphi = cfx.FunctionSpace(mesh, 1)
     cd = cfx.cut(cfx.Function(Vphi, level_set("sphere", n, gz0, gnz, dev)))
@@ -387,36 +392,65 @@ def test_cfg5_p2_vector_elasticity_rank_share(oracle):
     V = cfx.FunctionSpace(mesh, 2, dofmap=dm, ndofs=nd, bs=3)
     inside = cfx.locate_entities_device(cd, "phi<0")
     vol = cfx.runtime_quadrature(cd, "phi<0", 2)
-    ga = [fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(1.0e3, 0.3), qdegree=2),
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    assert ghost.size > 10000
+    ga = [fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(E, nu), qdegree=2),
+          fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(gpar,), qdegree=2),
           fem.Integral(fem.MASS, cells=inside, rules=vol, qdegree=4)]
     a = fem.form(ga, V)
     A = fem.assemble_matrix(a)
-    # slab parity: plane k0 needs the two cell layers around it (no facet terms here)
+    # strong Dirichlet data on a scattered set of dofs (all three components), lifted through a
+    num_g = Numbering(n, gz0, gnz, 2)
+    ids = torch.arange(nd, device=dev, dtype=torch.int64)
+    marked = ((ids * 2654435761) % 11 == 0)
+    markers = marked.to(torch.int8).repeat_interleave(3).contiguous()
+    gval = torch.sin(0.013 * torch.arange(3 * nd, device=dev, dtype=torch.float64)) + 0.25
+    b = torch.zeros(3 * nd, device=dev, dtype=torch.float64)
+    fem.apply_lifting(b, a, markers, gval, alpha=0.8)
+    # slab parity: the rows of plane k0 need the cells around it and the partners of their ghost facets
     k0 = 105
-    z0, nz = k0 - 2, 4
+    z0, nz = k0 - 3, 6
     om, phis = oracle_slab(oracle, cfx, n, z0, nz, "sphere", dev)
     O = oracle
     dom = O.classify(om.conn, phis)
+    c0, c1 = 6 * n * n * (z0 - gz0), 6 * n * n * (z0 + nz - gz0)
+    assert np.array_equal(cd.domain()[c0:c1], dom)
     odm, ond = p2_dofmap_host(om.conn, n, om.nnodes)
     oV = O.Space(odm, ond, 2, 3)
     oin = O.locate_entities(dom, "phi<0")
     ovol = O.runtime_quadrature(om, om.conn, phis, dom, "phi<0", 2)
-    oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=oin, rules=ovol, params=(1.0e3, 0.3), qdegree=2),
+    oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+    rows = ghost.rows
+    inslab = (rows[:, 0] >= c0) & (rows[:, 0] < c1) & (rows[:, 2] >= c0) & (rows[:, 2] < c1)
+    # a facet is in the band by the classification of its two cells alone: the slab's facets are the share's
+    got_rows = rows[inslab].copy()
+    got_rows[:, 0] -= c0
+    got_rows[:, 2] -= c0
+    assert np.array_equal(got_rows, oghost)
+    oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=oin, rules=ovol, params=(E, nu), qdegree=2),
+          O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(gpar,), qdegree=2),
           O.Integral(O.CELL, O.K_MASS, entities=oin, rules=ovol, qdegree=4)]
     ip, ix = O.create_sparsity(om, oV, oa)
-    o = dict(indptr=ip, indices=ix, values=O.assemble_matrix(om, oV, oa, ip, ix))
-    nnz = compare_plane(A, None, Numbering(n, gz0, gnz, 2), o, Numbering(n, z0, nz, 2), k0, bs=3)
+    num_o = Numbering(n, z0, nz, 2)
+    ids_o = np.arange(ond, dtype=np.int64)
+    ids_g = num_o.to(num_g, ids_o)
+    m_o = np.repeat(((ids_g * 2654435761) % 11 == 0).astype(np.int8), 3)
+    g_o = np.sin(0.013 * (ids_g[:, None] * 3 + np.arange(3)).ravel().astype(np.float64)) + 0.25
+    ob = O.apply_lifting(om, oV, oa, m_o, g_o, np.zeros(3 * ond), alpha=0.8)
+    o = dict(indptr=ip, indices=ix, values=O.assemble_matrix(om, oV, oa, ip, ix), b=ob)
+    nnz = compare_plane(A, b.cpu().numpy(), num_g, o, num_o, k0, bs=3)
     assert nnz > 3 * 8 * (n + 1) ** 2
-    # rigid translations in the null space of the elasticity block; mass sums to 3 |Omega_h|
-    del A
-    K = fem.assemble_matrix(fem.form(ga[:1], V))
+    # rigid translations in the null space of the elasticity block and of the ghost-penalty block;
+    # mass sums to 3 |Omega_h|
+    del A, a
+    K = fem.assemble_matrix(fem.form(ga[:2], V))
     kmax = float(K.torch_views(dev)[2].abs().max())
     for comp in range(3):
         t = torch.zeros(3 * nd, device=dev, dtype=torch.float64)
         t[comp::3] = 1.0
         assert float(spmv(K, t).abs().max()) < 1e-10 * kmax
     del K
-    M = fem.assemble_matrix(fem.form(ga[1:], V))
+    M = fem.assemble_matrix(fem.form(ga[2:], V))
     volume = float(as_torch(vol._view.weights, vol.total_points, "float64", dev).sum()) \
         + inside[1] / (6.0 * n ** 3)
     assert abs(float(M.torch_views(dev)[2].sum()) - 3.0 * volume) < 1e-12 * volume

@@ -109,6 +109,88 @@ def test_vector_elasticity(oracle, tdim, n, degree):
     assert np.array_equal(dom_a.inactive_dofs, O.inactive_dofs(s["oV"], active))
 
 
+def elasticity_problem(s, degree, order=2, E=1.0e3, nu=0.3, gamma_ghost=0.05):
+    """a of python/demo/demo_elasticity.py:214-235 on the cut domain: sigma(u):eps(v) over [solid cells, rules]
+    plus gamma (2 mu + lambda) h_avg [grad u . n].[grad v . n] over the ghost-penalty facets, for the oracle and
+    for the engine."""
+    import cutfemx_amd as cfx
+    O, om, dom, cd = s["O"], s["om"], s["dom"], s["cd"]
+    mu, lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    gpar = gamma_ghost * (2.0 * mu + lmbda)
+    q = 2 * (degree - 1)
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", order)
+    oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", order)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    assert np.array_equal(ghost.rows, oghost) and len(oghost) > 0
+    oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=inside, rules=ovol, params=(E, nu), qdegree=q),
+          O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(gpar,), qdegree=q)]
+    ga = [cfx.fem.Integral(cfx.fem.ELASTICITY, cells=inside, rules=vol, params=(E, nu), qdegree=q),
+          cfx.fem.Integral(cfx.fem.GHOST_GRADJUMP, facets=ghost, params=(gpar,), qdegree=q)]
+    return inside, oa, ga
+
+
+@pytest.mark.parametrize("mode", ["rows", "atomic", "deterministic"])
+@pytest.mark.parametrize("tdim,n,degree", [(2, 10, 1), (3, 6, 1), (2, 8, 2), (3, 4, 2)])
+def test_vector_elasticity_with_ghost_penalty_and_lifting(oracle, tdim, n, degree, mode, monkeypatch):
+    """BASELINE configs[4] as a parity case: the ghost penalty on a VECTOR space (bs = gdim, P1 and P2) next to
+    the elasticity term, strong Dirichlet data lifted through both (demo_elasticity.py:224-235, :67-93;
+    assemble_matrix_impl.h:409-607 interior-facet loop with bs > 1, assemble_vector_impl.h:383-436)."""
+    import cutfemx_amd as cfx
+    if mode == "atomic":
+        monkeypatch.setenv("CFX_ASSEMBLY", "atomic")
+    if mode == "deterministic":
+        monkeypatch.setenv("CFX_DETERMINISTIC", "1")
+    s = setup(oracle, tdim, n, degree, tdim)
+    O, om, oV = s["O"], s["om"], s["oV"]
+    inside, oa, ga = elasticity_problem(s, degree)
+    A = compare_forms(s, oa, ga)                    # sparsity bit-exact (facet coupling of all components), values 1e-12
+    M = A.to_scipy()
+    assert abs(M - M.T).max() < 1e-10 * abs(M).max()
+    # the ghost-penalty block alone: componentwise, annihilates affine displacement fields (normal-gradient jumps vanish)
+    G = cfx.fem.assemble_matrix(cfx.fem.form(ga[1:], s["V"])).to_scipy()
+    xdof = np.zeros((oV.ndofs, 3))
+    xdof[:om.nnodes] = om.x
+    if degree == 2:                                 # edge dofs sit at the edge midpoints (Basix edge order)
+        edges = [(1, 2), (0, 2), (0, 1)] if tdim == 2 else [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+        for k, (p, q) in enumerate(edges):
+            xdof[oV.dofmap[:, tdim + 1 + k]] = 0.5 * (om.x[om.conn[:, p]] + om.x[om.conn[:, q]])
+    for comp in range(tdim):
+        u = np.zeros(oV.ndofs * tdim)
+        u[comp::tdim] = 1.0 + 2.0 * xdof[:, 0] - 0.5 * xdof[:, 1]
+        assert np.abs(G @ u).max() < 1e-9 * abs(G).max()
+    # local tensor of one facet: 2 cells x nd dofs x bs components, block layout [[00, 01], [10, 11]]
+    a = cfx.fem.form(ga, s["V"])
+    idx = len(oa[1].entities) // 2
+    got = cfx.fem.tabulate_entity(a, 1, idx, False)
+    want = O.tabulate_entity(om, oV, oa[1], idx, False)
+    assert got.shape == want.shape and rel_err(got, want) < RTOL
+    # strong Dirichlet data on every component of some dofs touched by the facets and the cells
+    ndofs = oV.ndofs * tdim
+    rng = np.random.default_rng(9)
+    markers = np.zeros(ndofs, dtype=np.int8)
+    touched = np.unique(oV.dofmap[inside])
+    for k in range(tdim):
+        markers[touched[::4] * tdim + k] = 1
+    g, x0, b0 = rng.standard_normal(ndofs), rng.standard_normal(ndofs), rng.standard_normal(ndofs)
+    for alpha, x in [(1.0, None), (0.6, x0)]:
+        want = O.apply_lifting(om, oV, oa, markers, g, b0.copy(), x0=x, alpha=alpha)
+        got = cfx.fem.apply_lifting(b0.copy(), a, markers, g, x0=x, alpha=alpha)
+        assert rel_err(got, want) < RTOL
+        d = np.where(markers == 1, alpha * (g - (0.0 if x is None else x)), 0.0)
+        assert rel_err(got, b0 - M @ d) < 1e-11
+    ip, ix = O.create_sparsity(om, oV, oa)
+    want = O.assemble_matrix(om, oV, oa, ip, ix, markers, markers)
+    Abc = cfx.fem.assemble_matrix(a, bcs=markers)
+    assert rel_err(Abc.data, want) < RTOL
+    # active domain / deactivation of the vector system
+    dom_a = cfx.fem.active_domain(a)
+    active = O.active_cells(oa, om.ncells)
+    assert np.array_equal(dom_a.active_cells, active)
+    assert np.array_equal(dom_a.inactive_dofs, O.inactive_dofs(oV, active))
+
+
 @pytest.mark.parametrize("mode", ["rows", "atomic"])
 def test_dirichlet_markers_zero_rows_and_columns(oracle, mode, monkeypatch):
     # assemble_matrix_impl.h:151-185

@@ -1,10 +1,11 @@
 #!/bin/bash
 # usage: tools/pmc2.sh <tag> <mesh> <kernel-regex> "<counters pass 1>" "<counters pass 2>" ...
 # one rocprofv3 --pmc pass per counter group (counters only, kernel trace for names), bench.py as workload
-set -e
+set -eu
 TAG=$1; N=$2; RE=$3; shift 3
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
 cd /tmp
 i=0
 for grp in "$@"; do

@@ -1,9 +1,10 @@
 #!/bin/bash
 # usage: tools/profile_round.sh <tag> <mesh>: rocprofv3 kernel stats + three PMC passes of bench.py (run on the GPU box)
-set -e
+set -eu
 TAG=$1; N=$2
 export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+mkdir -p $R/gpurun_out
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG} -- python3 $R/bench.py --mesh $N --steps 10 --warmup 2 --no-cpu --no-secondary > $R/gpurun_out/prof_${TAG}_bench.json 2> $R/gpurun_out/prof_${TAG}.err
 echo stats done

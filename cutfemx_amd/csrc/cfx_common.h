@@ -302,7 +302,17 @@ struct Stencil
   DevArray<uint8_t> cpos;    // [ncells*nd]: position of the cell in the dof->cells list of its j-th dof
   bool built = false, usable = false;
   int max_len = 0; // longest neighbour list
+  // Row tiles: kRowTile consecutive dofs.  Mesh-static per tile: the sorted union of its rows' neighbour lists
+  // (tile_verts) and, parallel to nbr, the position of every neighbour in that union (st_loc).  The gather
+  // kernels stage a tile's coordinates, slot4 range and st_loc range in LDS with coalesced loads -- one
+  // request per 128 B line instead of one per (row, lane) gather.  tiles_usable: every tile fits the LDS budget.
+  DevArray<int64_t> tile_voff;  // [ntiles+1]
+  DevArray<int32_t> tile_verts;
+  DevArray<uint16_t> st_loc;
+  bool tiles_built = false, tiles_usable = false;
+  int max_tile_verts = 0, max_tile_items = 0, max_tile_st = 0; // items: dof->cells entries, st: neighbour entries
 };
+constexpr int kRowTile = 16;
 
 } // namespace cfx
 
@@ -423,6 +433,9 @@ struct cfx_row_plan
   cfx::DevArray<unsigned long long> plain_masks;
   cfx::DevArray<uint8_t> plain_uniform;
   bool plain_masks_built = false;
+  // positions in plain_rows where a new row tile (dof id / kRowTile) starts: the work list of the tile kernels
+  cfx::DevArray<int32_t> plain_tile_first, plain_tile_id; // ... and the tile's number
+  int64_t n_plain_tiles = 0;
   // linear forms, P1: the element vectors of the uncut cells are staged in the order the plain rows read them
   // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
   // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
@@ -471,9 +484,11 @@ namespace cfx
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
+const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
-bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values);
+bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values,
+                          bool fresh = false);
 bool assemble_vector_rows(cfx_form_s* L, double* b);
 } // namespace cfx
 

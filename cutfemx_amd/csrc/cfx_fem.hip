@@ -808,26 +808,42 @@ int cfx_pattern_destroy(cfx_pattern_t p)
   CFX_API_END
 }
 
-int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const int8_t* bc1, double* values)
+// assemble_matrix, optionally preceded by la::MatrixCSR::set_value(0) in the same call (`zero_first`): the
+// zeroing is then the library's to schedule, and rows with a single writer are stored instead of accumulated
+static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const int8_t* bc1, double* values,
+                                 bool zero_first)
 {
-  CFX_API_BEGIN
   require(a && P && values, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: null argument");
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: form is not bilinear");
   cfx_space_s* V = a->V;
   require(P->nrows == V->ndofs * V->bs, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: pattern/space size mismatch");
   DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->nrows : 0);
-  OutArray<double> out(values, P->nnz, true);
+  OutArray<double> out(values, P->nnz, !zero_first);
   ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.bc0 = bc0 ? dbc0.p : nullptr; A.bc1 = bc1 ? dbc1.p : nullptr;
   A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = out.dev; A.dump = nullptr; A.error = err.p;
+  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
   // row-gather path (deterministic, no global atomics) when the form allows it;
   // otherwise the entity-parallel kernels with FP64 atomics
-  if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev)) { out.finish(); return CFX_OK; }
+  if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev, zero_first)) { out.finish(); return; }
   for (const auto& I : a->integrals) launch_integral(a, I, A);
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   out.finish();
+}
+
+int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const int8_t* bc1, double* values)
+{
+  CFX_API_BEGIN
+  assemble_matrix_impl(a, P, bc0, bc1, values, false);
+  CFX_API_END
+}
+
+int cfx_assemble_matrix_zeroed(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const int8_t* bc1, double* values)
+{
+  CFX_API_BEGIN
+  assemble_matrix_impl(a, P, bc0, bc1, values, true);
   CFX_API_END
 }
 

@@ -129,6 +129,7 @@ struct RowArgs
   const int32_t* st_nbr;
   const unsigned long long* plain_masks; // plan.plain_masks / plain_uniform, indexed like active_rows
   const uint8_t* plain_uniform;
+  int fresh; // values holds zeros on entry (cfx_assemble_matrix_zeroed): single-writer rows are stored, not accumulated
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -213,25 +214,27 @@ __device__ __forceinline__ void p1_stiffness_row(const double* xr, const double 
   const double den = (TDIM == 3 ? 6.0 : 2.0) * fabs(det);
   double scale = __builtin_amdgcn_rcp(den);
   scale = fma(scale, fma(-den, scale, 1.0), scale);
+  // cr = -grad lambda_r det: its sign only enters the off-diagonal products, where it goes into the scale
 #pragma unroll
   for (int d = 0; d < TDIM; ++d)
   {
-    double t = 0.0;
+    double t = c[0][d];
 #pragma unroll
-    for (int k = 0; k < TDIM; ++k) t -= c[k][d];
+    for (int k = 1; k < TDIM; ++k) t += c[k][d];
     cr[d] = t;
   }
-  double dd = 0.0;
+  double dd = cr[0] * cr[0];
 #pragma unroll
-  for (int d = 0; d < TDIM; ++d) dd += cr[d] * cr[d];
+  for (int d = 1; d < TDIM; ++d) dd = fma(cr[d], cr[d], dd);
   diag = dd * scale;
+  const double nscale = -scale;
 #pragma unroll
   for (int k = 0; k < TDIM; ++k)
   {
-    double t = 0.0;
+    double t = cr[0] * c[k][0];
 #pragma unroll
-    for (int d = 0; d < TDIM; ++d) t += cr[d] * c[k][d];
-    off[k] = t * scale;
+    for (int d = 1; d < TDIM; ++d) t = fma(cr[d], c[k][d], t);
+    off[k] = t * nscale;
   }
 }
 
@@ -1000,7 +1003,8 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
     for (int k = 0; k < R; ++k)
     {
       const int t = base + k * G + gl;
-      cell[k] = t < nc ? A.d2c[cb + t] : -1;
+      // the cell id is only the key of its mark byte: not read for rows whose incident cells share one mark
+      cell[k] = t < nc ? (umark ? 0 : A.d2c[cb + t]) : -1;
       s4[k] = t < nc ? A.slot4[cb + t] : 0u;
     }
 #pragma unroll
@@ -1009,6 +1013,8 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   load_chunk(0); // in flight together with the stencil staging above
   // the pattern row must be exactly this subset (build_pattern from the same plan)
   if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
+  // a row that holds its whole stencil (mask = the low `len` bits): CSR slot = stencil position
+  const bool full = (mask & (mask + 1ull)) == 0ull;
   __syncthreads();
   if constexpr (STAGE)
   {
@@ -1081,7 +1087,7 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
             load_vertex<TDIM>(A.x, oc[t], xo[t]);
         }
 #pragma unroll
-        for (int t = 0; t < TDIM; ++t) osl[t] = __popcll(mask & ((1ull << opos[t]) - 1ull));
+        for (int t = 0; t < TDIM; ++t) osl[t] = full ? (int)opos[t] : __popcll(mask & ((1ull << opos[t]) - 1ull));
         p1_stiffness_row<TDIM>(xr, xo, dg, off);
         const double scale = (double)rep[k]; // the same cell in several inline integrals
         dsum += diag_bc ? 0.0 : dg * scale;
@@ -1117,6 +1123,17 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
     if (gl == 0 && nc > 0 && len > 0) atomicAdd(&s_val[grp][__popcll(mask & ((1ull << dpos) - 1ull))], d);
   }
   __syncthreads();
+  if (A.fresh)
+  {
+    // `values` was zeroed by this very call (cfx_assemble_matrix_zeroed) and a plain row has one writer: store
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len) A.values[rb + k] = s_val[grp][k];
+    }
+    return;
+  }
   double myval[KMAX];
 #pragma unroll
   for (int q = 0; q < KMAX; ++q)
@@ -1129,6 +1146,306 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   {
     const int k = gl + q * G;
     if (k < len) A.values[rb + k] = myval[q] + s_val[grp][k];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// stage 2, bilinear forms, plain rows by ROW TILE (Stencil::tile_verts / st_loc): one wavefront per tile of
+// kRowTile consecutive dofs, 4 lanes per row.  The rows of a tile sit next to each other in every mesh-static
+// array, so the tile's coordinates (sorted union of the rows' stencils), its slot4 range and its st_loc range
+// are staged in LDS with coalesced loads: a few requests per 128 B line for the whole tile where the row-wise
+// kernel above issues ~100 partial-line gathers per row (it is bound by the request rate of the vector L1, not
+// by HBM bytes).  Items then run out of LDS: positions -> tile-local vertex -> coordinates, accumulators at the
+// row's stencil segment.  With `fresh` the rows are stored, not read back.
+// ---------------------------------------------------------------------------
+#ifndef CFX_TILE_WAVES
+#define CFX_TILE_WAVES 4
+#endif
+#ifndef CFX_TILE_ABLATE
+#define CFX_TILE_ABLATE 0 // timing-only builds (wrong results): 1 no LDS atomics, 2 no coordinate reads, 4 no stiffness arithmetic, 8 no items
+#endif
+struct TileArgs
+{
+  const double* x;
+  int64_t n_tiles;
+  const int32_t* tile_first; // position of the tile's first plain row in `rows`
+  const int32_t* tile_id;
+  int64_t n_plain;
+  const int32_t* rows;
+  const unsigned long long* masks;
+  const uint8_t* uniform;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint32_t* slot4;
+  const uint8_t* cellmark;
+  const int64_t* st_off;
+  const int32_t* st_nbr;
+  const uint16_t* st_loc;
+  const uint8_t* diagpos;
+  const int64_t* tile_voff;
+  const int32_t* tile_verts;
+  const int64_t* indptr;
+  double* values;
+  const int8_t* bc0;
+  const int8_t* bc1;
+  unsigned inline_bits;
+  int fresh;
+  int* error;
+  int64_t ndofs;
+};
+
+// LDS capacity classes of a tile (vertices of the union, neighbour entries, dof->cells entries).  The arrays are
+// separate __shared__ objects so that the compiler knows the accumulator atomics cannot alias the staged tables
+// and is free to run the LDS reads of the next items ahead of them.
+template <int CLS> struct TileCap;
+template <> struct TileCap<0> { static constexpr int V = 192, S = 256, I = 384; };   // Kuhn box meshes: 162 / 240 / 384
+template <> struct TileCap<1> { static constexpr int V = 512, S = 512, I = 1024; };
+inline int tile_class(const Stencil& st)
+{
+  for (int c = 0; c < 2; ++c)
+  {
+    const int V = c == 0 ? TileCap<0>::V : TileCap<1>::V, S = c == 0 ? TileCap<0>::S : TileCap<1>::S,
+              I = c == 0 ? TileCap<0>::I : TileCap<1>::I;
+    if (st.max_tile_verts <= V && st.max_tile_st <= S && st.max_tile_items <= I) return c;
+  }
+  return -1;
+}
+
+// the 3 positions of a cell's other dofs from slot4 (byte j = position of the cell's j-th dof) and the row's own
+// position replicated in every byte: the byte equal to it is dropped (positions of one cell are distinct)
+__device__ __forceinline__ uint32_t other_positions(uint32_t s4, uint32_t dpos4)
+{
+  const uint32_t x = s4 ^ dpos4;
+  const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;     // lowest set bit marks the zero byte
+  const uint32_t sh = (uint32_t)(__ffs((int)z) - 1) & ~7u;     // 8 * index of that byte
+  const uint32_t m = (1u << sh) - 1u;
+  return (s4 & m) | ((s4 >> 8) & ~m);
+}
+
+template <int TDIM, bool ORDERED, int CLS>
+__global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_kernel(TileArgs A)
+{
+  constexpr int G = 4, R = 6;
+  constexpr int CAPV = TileCap<CLS>::V, CAPS = TileCap<CLS>::S, CAPI = TileCap<CLS>::I;
+  constexpr int VR = CAPV / kWave, SR = CAPS / kWave, IR = CAPI / kWave;
+  static_assert(kWave / G == kRowTile, "one lane group per row of the tile");
+  __shared__ double s_x[CAPV * TDIM];
+  __shared__ double s_val[CAPS]; // row g accumulates at its stencil segment
+  __shared__ uint32_t s_s4[CAPI];
+  __shared__ uint16_t s_loc[CAPS];
+  const int lane = threadIdx.x, g = lane / G, gl = lane % G;
+  const int64_t w = CFX_ROW_BLOCK;
+  if (w >= A.n_tiles) return;
+  const int64_t i0 = A.tile_first[w];
+  const int64_t t = A.tile_id[w];
+  const int64_t r0 = t * kRowTile;
+  // ---- every load that does not depend on another one is issued here, ahead of the first wait
+  int32_t rl = -1;
+  if (lane < kRowTile && i0 + lane < A.n_plain) rl = A.rows[i0 + lane];
+  const int64_t rr = r0 + (lane < kRowTile ? lane : kRowTile);
+  const int64_t so = A.st_off[rr < A.ndofs ? rr : A.ndofs], co = A.d2c_off[rr < A.ndofs ? rr : A.ndofs];
+  const int64_t vb = A.tile_voff[t];
+  const int nv = (int)(A.tile_voff[t + 1] - vb);
+  int32_t vid[VR];
+#pragma unroll
+  for (int q = 0; q < VR; ++q) vid[q] = lane + q * kWave < nv ? A.tile_verts[vb + lane + q * kWave] : -1;
+  const int64_t r = r0 + g;
+  const int64_t rq = r < A.ndofs ? r : A.ndofs - 1;
+  const int64_t rb = A.indptr[rq], re = A.indptr[rq + 1];
+  const unsigned dpos = A.diagpos[rq];
+  // which rows of the tile are plain: their ids are the next entries of the (ascending) plain list
+  unsigned pm = (rl >= 0 && rl / kRowTile == t) ? 1u << (rl % kRowTile) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pm |= __shfl_xor(pm, o, 64);
+  const bool live = (pm >> g) & 1u;
+  const int64_t pi = i0 + __popc(pm & ((1u << g) - 1u));
+  const unsigned long long mask = live ? A.masks[pi] : 0ull;
+  const uint8_t umark = live ? A.uniform[pi] : (uint8_t)0;
+  const int64_t sb0 = __shfl(so, 0, 64), cb0 = __shfl(co, 0, 64);
+  const int nst = (int)(__shfl(so, kRowTile, 64) - sb0), nit = (int)(__shfl(co, kRowTile, 64) - cb0);
+  const int st_rel = (int)(__shfl(so, g, 64) - sb0);
+  const int c_rel = (int)(__shfl(co, g, 64) - cb0);
+  int nc = (int)(__shfl(co, g + 1, 64) - __shfl(co, g, 64));
+  if (nst > CAPS || nit > CAPI || nv > CAPV) { *A.error = 2; return; }
+  uint32_t s4r[IR];
+#pragma unroll
+  for (int q = 0; q < IR; ++q) s4r[q] = lane + q * kWave < nit ? A.slot4[cb0 + lane + q * kWave] : 0u;
+  uint16_t locr[SR];
+#pragma unroll
+  for (int q = 0; q < SR; ++q) locr[q] = lane + q * kWave < nst ? A.st_loc[sb0 + lane + q * kWave] : (uint16_t)0;
+  double xv[VR][TDIM];
+#pragma unroll
+  for (int q = 0; q < VR; ++q)
+  {
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) xv[q][d] = 0.0;
+    if (vid[q] >= 0) load_vertex<TDIM>(A.x, vid[q], xv[q]);
+  }
+  const bool row_bc = live && A.bc0 && A.bc0[r];
+  const bool diag_bc = row_bc || (live && A.bc1 != nullptr && A.bc1[r] != 0);
+  // ---- LDS image of the tile
+#pragma unroll
+  for (int q = 0; q < IR; ++q) s_s4[lane + q * kWave] = s4r[q];
+#pragma unroll
+  for (int q = 0; q < SR; ++q)
+  {
+    s_loc[lane + q * kWave] = locr[q];
+    s_val[lane + q * kWave] = 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < VR; ++q)
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) s_x[(lane + q * kWave) * TDIM + d] = xv[q][d];
+  int len = live ? (int)(re - rb) : 0;
+  if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
+  if (!live || len == 0) nc = 0;
+  // a row that holds its whole stencil (mask = the low `len` bits): CSR slot = stencil position
+  const bool full = (mask & (mask + 1ull)) == 0ull;
+  const bool any_bc = A.bc0 != nullptr || A.bc1 != nullptr; // (kernel-uniform)
+  // wave-uniform: every row of the tile has one mark for all its cells and holds its whole stencil
+  const bool fast = __ballot(nc > 0 && (umark == 0 || !full)) == 0ull && !any_bc;
+  const uint32_t dpos4 = dpos * 0x01010101u;
+  const bool nrep1 = __ballot(nc > 0 && __popc(umark & A.inline_bits) != 1) == 0ull; // wave-uniform: one integral per cell
+  __syncthreads();
+  double xr[TDIM];
+  {
+    const int vr = nc > 0 ? s_loc[st_rel + dpos] : 0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) xr[d] = s_x[vr * TDIM + d];
+  }
+  double dsum = 0.0;
+  // lane gl owns the items [gl * per, gl * per + per): lanes that run together work on cells a quarter of the
+  // row's list apart, which rarely share a vertex -- fewer LDS atomics that serialise on one address
+#if (CFX_TILE_ABLATE & 8)
+  const int per = 0; // ablation: staging and write-out only
+#else
+  const int per = (nc + G - 1) / G;
+#endif
+  for (int base = 0;; base += R)
+  {
+    if (__ballot(base < per) == 0) break;
+    uint32_t o3[R];
+    int rep[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      const int tt = gl * per + base + k;
+      const bool in = base + k < per && tt < nc;
+      o3[k] = other_positions(in ? s_s4[c_rel + tt] : (dpos4 ^ 0x00010203u), dpos4);
+      rep[k] = in ? 1 : 0;
+    }
+    if (!fast)
+    {
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+      {
+        const int tt = gl * per + base + k;
+        // the cell id is only the key of its mark byte: not read for rows whose incident cells share one mark
+        const uint8_t mk = rep[k] ? (umark ? umark : A.cellmark[A.d2c[cb0 + c_rel + tt]]) : (uint8_t)0;
+        rep[k] = __popc(mk & A.inline_bits);
+      }
+    }
+    else
+    {
+      const int nrep = __popc(umark & A.inline_bits); // the same cell in several inline integrals
+#pragma unroll
+      for (int k = 0; k < R; ++k) rep[k] *= nrep;
+    }
+    int vo[R][TDIM];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int q = 0; q < TDIM; ++q) vo[k][q] = s_loc[st_rel + ((o3[k] >> (8 * q)) & 0xffu)];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+    {
+      if (!ORDERED && __ballot(rep[k] != 0) == 0) continue;
+      double xo[TDIM][TDIM], dg, off[TDIM];
+#pragma unroll
+      for (int q = 0; q < TDIM; ++q)
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+#if (CFX_TILE_ABLATE & 2)
+          xo[q][d] = xr[d] + 0.001 * (double)(vo[k][q] + d + q * q); // ablation: no coordinate reads
+#else
+          xo[q][d] = s_x[vo[k][q] * TDIM + d];
+#endif
+#if (CFX_TILE_ABLATE & 4)
+      dg = xo[0][0] + xr[0]; // ablation: no stiffness arithmetic
+#pragma unroll
+      for (int q = 0; q < TDIM; ++q) off[q] = xo[q][1] + xo[q][TDIM - 1];
+#else
+      p1_stiffness_row<TDIM>(xr, xo, dg, off);
+#endif
+      int osl[TDIM];
+      double ov[TDIM];
+#pragma unroll
+      for (int q = 0; q < TDIM; ++q)
+      {
+        osl[q] = (int)((o3[k] >> (8 * q)) & 0xffu);
+        ov[q] = off[q];
+      }
+      if (fast && nrep1)
+        dsum += rep[k] ? dg : 0.0; // (lanes without an item computed on a dummy cell)
+      else
+      {
+        const double scale = (double)rep[k]; // the same cell in several inline integrals; 0: no item
+        dsum += diag_bc ? 0.0 : dg * scale;
+#pragma unroll
+        for (int q = 0; q < TDIM; ++q) ov[q] *= scale;
+      }
+      if (!fast)
+      {
+#pragma unroll
+        for (int q = 0; q < TDIM; ++q)
+        {
+          if (!full) osl[q] = __popcll(mask & ((1ull << osl[q]) - 1ull));
+          if (any_bc && rep[k]
+              && (row_bc || (A.bc1 != nullptr && A.bc1[A.st_nbr[sb0 + st_rel + ((o3[k] >> (8 * q)) & 0xffu)]] != 0)))
+            ov[q] = 0.0;
+        }
+      }
+      if constexpr (ORDERED)
+      {
+        for (int turn = 0; turn < G; ++turn) // one lane of each group at a time: item order
+        {
+          if (gl == turn && rep[k])
+          {
+#pragma unroll
+            for (int q = 0; q < TDIM; ++q) s_val[st_rel + osl[q]] += ov[q];
+          }
+          __syncthreads();
+        }
+      }
+      else
+      {
+#if (CFX_TILE_ABLATE & 1)
+#pragma unroll
+        for (int q = 0; q < TDIM; ++q) dsum += rep[k] ? ov[q] * (double)osl[q] : 0.0; // ablation: no LDS atomics
+#else
+        if (rep[k])
+        {
+#pragma unroll
+          for (int q = 0; q < TDIM; ++q) atomicAdd(&s_val[st_rel + osl[q]], ov[q]);
+        }
+#endif
+      }
+    }
+  }
+  {
+    double d = dsum;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
+    if (gl == 0 && nc > 0) atomicAdd(&s_val[st_rel + (full ? (int)dpos : __popcll(mask & ((1ull << dpos) - 1ull)))], d);
+  }
+  __syncthreads();
+  if (A.fresh)
+  {
+    for (int k = gl; k < len; k += G) A.values[rb + k] = s_val[st_rel + k];
+  }
+  else
+  {
+    for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[st_rel + k];
   }
 }
 
@@ -1476,10 +1793,11 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
 }
 
 template <int TDIM, int DEG>
-int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG>(a, st);
+  A.fresh = fresh ? 1 : 0;
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
   ZeroFlag err;
   A.error = err.p;
@@ -1523,6 +1841,32 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           Q.slot4 = stn.slot4.p; Q.diagpos = stn.diagpos.p; Q.st_off = stn.offsets.p; Q.st_nbr = stn.nbr.p;
           plain_row_masks(a);
           Q.plain_masks = plan.plain_masks.p; Q.plain_uniform = plan.plain_uniform.p;
+          // row tiles (coalesced staging of the mesh-static tables), when every tile fits an LDS capacity class
+          const Stencil& stt = space_stencil_tiles(a->V);
+          const int tcls = stt.tiles_usable ? tile_class(stt) : -1;
+          const bool use_tiles = tcls >= 0 && plan.n_plain_tiles > 0;
+          if (use_tiles)
+          {
+            TileArgs T{};
+            T.x = Q.x; T.n_tiles = plan.n_plain_tiles; T.tile_first = plan.plain_tile_first.p; T.tile_id = plan.plain_tile_id.p;
+            T.n_plain = plan.n_plain_rows; T.rows = plan.plain_rows.p; T.masks = plan.plain_masks.p; T.uniform = plan.plain_uniform.p;
+            T.d2c_off = Q.d2c_off; T.d2c = Q.d2c; T.slot4 = stn.slot4.p; T.cellmark = Q.cellmark;
+            T.st_off = stn.offsets.p; T.st_nbr = stn.nbr.p; T.st_loc = stt.st_loc.p; T.diagpos = stn.diagpos.p;
+            T.tile_voff = stt.tile_voff.p; T.tile_verts = stt.tile_verts.p;
+            T.indptr = Q.indptr; T.values = Q.values; T.bc0 = Q.bc0; T.bc1 = Q.bc1;
+            T.inline_bits = inline_bits; T.fresh = Q.fresh; T.error = Q.error; T.ndofs = a->V->ndofs;
+            const dim3 gt = row_grid(plan.n_plain_tiles);
+            if (tcls == 0)
+            {
+              if (det) launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, true, 0>, gt, dim3(kWave), 0, T);
+              else launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, false, 0>, gt, dim3(kWave), 0, T);
+            }
+            else
+            {
+              if (det) launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, true, 1>, gt, dim3(kWave), 0, T);
+              else launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, false, 1>, gt, dim3(kWave), 0, T);
+            }
+          }
           const dim3 gq = row_grid((Q.n_active + (kWave / CFX_PLAIN_G) - 1) / (kWave / CFX_PLAIN_G));
           const char* stage_env = getenv("CFX_PLAIN_STAGE");
           const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');
@@ -1537,7 +1881,8 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     else if (stage) launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, false, true>, gq, dim3(kWave), 0, Q);   \
     else launch("assemble_rows_plain", assemble_rows_plain_kernel<TDIM, CFX_PLAIN_G, CAPP, false, false>, gq, dim3(kWave), 0, Q);             \
   } while (0)
-          if (plain_cap == 16) CFX_PLAIN(16); else if (plain_cap == 32) CFX_PLAIN(32); else CFX_PLAIN(64);
+          if (use_tiles) {}
+          else if (plain_cap == 16) CFX_PLAIN(16); else if (plain_cap == 32) CFX_PLAIN(32); else CFX_PLAIN(64);
 #undef CFX_PLAIN
           // the uncut items of the interface rows keep the searching kernel
           F.n_active = plan.n_special_rows; F.active_rows = plan.special_rows.p;
@@ -1720,7 +2065,7 @@ void run_vector(cfx_form_s* L, double* b)
 namespace cfx
 {
 
-bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
@@ -1748,7 +2093,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
       err = V->degree == 1 ? run_matrix_block<3, 1, 3>(a, P, bc0, bc1, values) : run_matrix_block<3, 2, 3>(a, P, bc0, bc1, values);
   }
   else if (V->degree == 1)
-    err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values) : run_matrix<3, 1>(a, P, bc0, bc1, values);
+    err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values, fresh) : run_matrix<3, 1>(a, P, bc0, bc1, values, fresh);
   else if (!kRowsInline<2> && [&]() {
              // degree 2 stages 100 doubles per uncut cell (38 GB at config 4): must fit next to the matrix
              size_t need = 0, free_b = 0, total_b = 0;
@@ -1760,7 +2105,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
            }())
     return false;
   else
-    err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values) : run_matrix<3, 2>(a, P, bc0, bc1, values);
+    err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values, fresh) : run_matrix<3, 2>(a, P, bc0, bc1, values, fresh);
   require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
   require(err != 5, CFX_ERR_RUNTIME, "assemble_matrix: a stencil-subset row does not match its sparsity pattern");

@@ -799,6 +799,112 @@ __global__ void __launch_bounds__(kBlock) pattern_plain_write_kernel(int64_t n_p
     if ((m >> p) & 1ull) indices[ob + __popcll(m & ((1ull << p) - 1ull))] = nbr[b + p];
 }
 
+// ---------------------------------------------------------------------------
+// Row tiles of the stencil (Stencil::tile_verts / st_loc): one wavefront per tile of kRowTile dofs.
+// The rows' neighbour lists are ascending, so the rank of an entry in the merged list is the sum of its
+// lower bounds in the kRowTile lists; copies of one vertex share a rank, different vertices never do:
+// writing every entry to slot[rank] and packing the used slots gives the sorted union without a sort.
+// ---------------------------------------------------------------------------
+constexpr int kTileMaxSt = kRowTile * 64; // a stencil holds at most 64 neighbours
+
+template <bool WRITE>
+__global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int64_t ntiles,
+                                                              const int64_t* __restrict__ st_off,
+                                                              const int32_t* __restrict__ nbr,
+                                                              const int64_t* __restrict__ d2c_off,
+                                                              int32_t* __restrict__ counts,
+                                                              const int64_t* __restrict__ tile_voff,
+                                                              int32_t* __restrict__ tile_verts,
+                                                              uint16_t* __restrict__ st_loc, int* maxima)
+{
+  __shared__ int32_t s_v[kTileMaxSt];
+  __shared__ int32_t s_m[kTileMaxSt];
+  __shared__ uint16_t s_rank[kTileMaxSt];
+  __shared__ int s_off[kRowTile + 1];
+  const int lane = threadIdx.x;
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x)
+  {
+    const int64_t r0 = t * kRowTile;
+    const int64_t b0 = st_off[r0];
+    if (lane <= kRowTile) s_off[lane] = (int)(st_off[r0 + lane < ndofs ? r0 + lane : ndofs] - b0);
+    __syncthreads();
+    const int n = s_off[kRowTile];
+    if (n > kTileMaxSt)
+    {
+      if (lane == 0) atomicMax(&maxima[1], n);
+      __syncthreads();
+      continue;
+    }
+    for (int e = lane; e < n; e += kWave) { s_v[e] = nbr[b0 + e]; s_m[e] = -1; }
+    __syncthreads();
+    for (int e = lane; e < n; e += kWave)
+    {
+      const int32_t v = s_v[e];
+      int rank = 0;
+#pragma unroll 4
+      for (int j = 0; j < kRowTile; ++j)
+      {
+        int lo = s_off[j], hi = s_off[j + 1];
+        const int b = lo;
+        while (lo < hi)
+        {
+          const int mid = (lo + hi) >> 1;
+          if (s_v[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        rank += lo - b;
+      }
+      s_rank[e] = (uint16_t)rank;
+      s_m[rank] = v; // copies of v write the same value to the same slot
+    }
+    __syncthreads();
+    // pack the used slots in order: slot -> position in the union
+    int total = 0;
+    const int64_t vb = WRITE ? tile_voff[t] : 0;
+    for (int c = 0; c < n; c += kWave)
+    {
+      const int e = c + lane;
+      const int32_t v = e < n ? s_m[e] : -1;
+      const unsigned long long used = __ballot(v >= 0);
+      const int pos = total + __popcll(used & ((1ull << lane) - 1ull));
+      if (v >= 0)
+      {
+        if constexpr (WRITE) tile_verts[vb + pos] = v;
+        s_m[e] = pos;
+      }
+      total += __popcll(used);
+    }
+    __syncthreads();
+    if constexpr (WRITE)
+    {
+      for (int e = lane; e < n; e += kWave) st_loc[b0 + e] = (uint16_t)s_m[s_rank[e]];
+    }
+    else if (lane == 0)
+    {
+      counts[t] = total;
+      const int64_t rl = r0 + kRowTile < ndofs ? r0 + kRowTile : ndofs;
+      const int items = (int)(d2c_off[rl] - d2c_off[r0]);
+      if (total > *reinterpret_cast<volatile int*>(&maxima[0])) atomicMax(&maxima[0], total);
+      if (n > *reinterpret_cast<volatile int*>(&maxima[1])) atomicMax(&maxima[1], n);
+      if (items > *reinterpret_cast<volatile int*>(&maxima[2])) atomicMax(&maxima[2], items);
+    }
+    __syncthreads(); // the LDS arrays are reused by the next tile
+  }
+}
+
+// plain-list positions at which a new row tile starts
+struct TileStart
+{
+  const int32_t* rows;
+  __device__ bool operator()(int64_t i) const { return i == 0 || (rows[i] / kRowTile) != (rows[i - 1] / kRowTile); }
+};
+
+__global__ void tile_ids_kernel(int64_t n, const int32_t* __restrict__ first, const int32_t* __restrict__ rows,
+                                int32_t* __restrict__ ids)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) ids[i] = rows[first[i]] / kRowTile;
+}
+
 } // namespace
 
 namespace cfx
@@ -1056,6 +1162,34 @@ const Stencil& space_stencil(cfx_space_s* V)
   return S;
 }
 
+const Stencil& space_stencil_tiles(cfx_space_s* V)
+{
+  Stencil& S = const_cast<Stencil&>(space_stencil(V));
+  if (S.tiles_built || !S.usable) return S;
+  S.tiles_built = true;
+  const char* env = getenv("CFX_TILES");
+  if (env && env[0] == '0') return S;
+  const Adjacency& adj = V->dof_cells();
+  const int64_t ntiles = (V->ndofs + kRowTile - 1) / kRowTile;
+  DevArray<int32_t> counts(ntiles);
+  DevArray<int> maxima(3);
+  maxima.zero();
+  const dim3 grid = wave_grid(ntiles);
+  launch("stencil_tiles", stencil_tiles_kernel<false>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
+         adj.offsets.p, counts.p, (const int64_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, maxima.p);
+  const std::vector<int> mx = download(maxima.p, 3);
+  S.max_tile_verts = mx[0]; S.max_tile_st = mx[1]; S.max_tile_items = mx[2];
+  if (S.max_tile_st > kTileMaxSt) return S;
+  S.tile_voff.alloc(ntiles + 1);
+  exclusive_scan(counts.p, S.tile_voff.p, ntiles);
+  S.tile_verts.alloc(read_scalar(S.tile_voff.p + ntiles));
+  S.st_loc.alloc(S.nbr.n);
+  launch("stencil_tiles_write", stencil_tiles_kernel<true>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
+         adj.offsets.p, (int32_t*)nullptr, S.tile_voff.p, S.tile_verts.p, S.st_loc.p, maxima.p);
+  S.tiles_usable = true;
+  return S;
+}
+
 void plain_row_masks(cfx_form_s* a)
 {
   cfx_row_plan& plan = row_plan(a);
@@ -1071,6 +1205,16 @@ void plain_row_masks(cfx_form_s* a)
          dim3((unsigned)((plan.n_plain_rows + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
          st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p);
+  if (space_stencil_tiles(V).tiles_usable)
+  {
+    // work list of the tile kernels: one entry per row tile that holds a plain row
+    DevArray<int32_t> first;
+    plan.n_plain_tiles = compact("plan_plain_tiles", plan.n_plain_rows, TileStart{plan.plain_rows.p}, first);
+    plan.plain_tile_first = std::move(first);
+    plan.plain_tile_id.alloc(plan.n_plain_tiles);
+    launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles), dim3(kBlock), 0, plan.n_plain_tiles,
+           plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
+  }
 }
 
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:

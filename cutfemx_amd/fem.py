@@ -125,10 +125,11 @@ class MatrixCSR:
         self._view = v
         self.nrows, self.nnz = int(v.nrows), int(v.nnz)
         self._owns_values = values is None
+        self._zero_pending = False
         if values is None:
             p = C.c_void_p()
             _lib.check(_lib.lib().cfx_device_alloc(C.byref(p), C.c_size_t(8 * max(self.nnz, 1))))
-            self.values_ptr = p.value
+            self._vptr = p.value
             self.set_value(0.0)
         else:  # caller-owned HBM buffer: set_value / cfx_assemble_matrix write 8*nnz bytes through the raw pointer
             if isinstance(values, _lib.DeviceBuffer):
@@ -146,14 +147,29 @@ class MatrixCSR:
                 self._p = None
                 raise ValueError(f"values holds {count} entries but the sparsity pattern needs nnz = {self.nnz}")
             self._values_keep = values
-            self.values_ptr = ptr
+            self._vptr = ptr
+
+    @property
+    def values_ptr(self):
+        """HBM address of the value array; a pending set_value(0) is carried out first."""
+        if self._zero_pending:
+            self._zero_pending = False
+            _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(self._vptr), 0, C.c_size_t(8 * self.nnz)))
+        return self._vptr
+
+    @values_ptr.setter
+    def values_ptr(self, p):
+        self._vptr = p
 
     def set_value(self, v: float):
+        """la::MatrixCSR::set_value.  Zeroing is deferred to the next use of the values: assemble_matrix then
+        clears and assembles in one library call (cfx_assemble_matrix_zeroed)."""
         if float(v) == 0.0:
-            _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(self.values_ptr), 0, C.c_size_t(8 * self.nnz)))
+            self._zero_pending = True
             return
+        self._zero_pending = False
         z = np.full(self.nnz, float(v))
-        _lib.check(_lib.lib().cfx_copy(C.c_void_p(self.values_ptr), z.ctypes.data_as(C.c_void_p),
+        _lib.check(_lib.lib().cfx_copy(C.c_void_p(self._vptr), z.ctypes.data_as(C.c_void_p),
                                        C.c_size_t(z.nbytes)))
 
     def row_block(self, lo: int, hi: int):
@@ -196,9 +212,9 @@ class MatrixCSR:
     def __del__(self):
         try:
             l = _lib.load()
-            if getattr(self, "_owns_values", False) and self.values_ptr:
-                l.cfx_device_free(C.c_void_p(self.values_ptr))
-                self.values_ptr = None
+            if getattr(self, "_owns_values", False) and getattr(self, "_vptr", None):
+                l.cfx_device_free(C.c_void_p(self._vptr))
+                self._vptr = None
             if self._p:
                 l.cfx_pattern_destroy(self._p)
                 self._p = None
@@ -224,7 +240,11 @@ def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixC
     if bcs is not None:
         b0, b1 = bcs if isinstance(bcs, tuple) else (bcs, bcs)
         bc0, bc1 = _lib.as_ptr(b0, np.int8, keep), _lib.as_ptr(b1, np.int8, keep)
-    _lib.check(_lib.lib().cfx_assemble_matrix(a._h, A._p, bc0, bc1, C.c_void_p(A.values_ptr)))
+    if A._zero_pending:     # A.set_value(0) + assemble_matrix(A, a, bcs) as one call
+        A._zero_pending = False
+        _lib.check(_lib.lib().cfx_assemble_matrix_zeroed(a._h, A._p, bc0, bc1, C.c_void_p(A._vptr)))
+    else:
+        _lib.check(_lib.lib().cfx_assemble_matrix(a._h, A._p, bc0, bc1, C.c_void_p(A._vptr)))
     return A
 
 

@@ -321,6 +321,12 @@ int cfx_pattern_destroy(cfx_pattern_t p);
  * Accumulates into values[nnz] (HBM); bc0/bc1 int8 markers or NULL. */
 int cfx_assemble_matrix(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0,
                         const int8_t* bc1, double* values);
+/* A.set_value(0) + assemble_matrix(A, a, bcs) in one call -- how python/cutfemx/fem.py:886-942 and
+ * python/demo/demo_poisson.py:40-60 use a matrix: created (zeros) or cleared, then assembled once.  Same
+ * result as cfx_device_memset(values, 0, 8 nnz) followed by cfx_assemble_matrix; the library schedules the
+ * zeroing itself and stores the rows that have one writer instead of reading them back. */
+int cfx_assemble_matrix_zeroed(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0,
+                               const int8_t* bc1, double* values);
 /* assemble_vector(): assembler.h:252-262 -> assemble_vector_impl.h:573-767 */
 int cfx_assemble_vector(cfx_form_t L, double* b);
 

@@ -428,6 +428,15 @@ inline void assemble_matrix(std::span<double> values, const Form& a, const Spars
                             bc1.empty() ? nullptr : bc1.data(), values.data()));
 }
 
+/// A.set_value(0) followed by assemble_matrix(A.mat_add_values(), a, bcs) as one call (how a matrix is assembled
+/// once per step, python/demo/demo_poisson.py:40-60): `values` is overwritten
+inline void assemble_matrix_zeroed(std::span<double> values, const Form& a, const SparsityPattern& pattern,
+                                   std::span<const std::int8_t> bc0 = {}, std::span<const std::int8_t> bc1 = {})
+{
+  check(cfx_assemble_matrix_zeroed(a.handle.h, pattern.handle.h, bc0.empty() ? nullptr : bc0.data(),
+                                   bc1.empty() ? nullptr : bc1.data(), values.data()));
+}
+
 /// assemble_vector(): assembler.h:252-262
 inline void assemble_vector(std::span<double> b, const Form& L) { check(cfx_assemble_vector(L.handle.h, b.data())); }
 

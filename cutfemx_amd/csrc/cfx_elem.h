@@ -97,12 +97,11 @@ __device__ __forceinline__ const double* ref_rule(int dim, int degree, int& n, c
 // sin(pi x): x = k + r, |r| <= 1/2, sign from the parity of k.  Tighter than libm's sin(pi*x),
 // whose argument already carries the rounding of pi, at ~1/4 of the instructions of ocml's sinpi:
 // the source-term kernels are FP64-VALU bound on exactly this.
-__device__ __forceinline__ double cfx_sinpi(double x)
+// sin(pi r) on |r| <= 1/2: r times a degree-8 polynomial in r^2 (Chebyshev interpolant computed with 60 digits:
+// approximation error 3e-19; 2.5e-16 measured in double over [-3, 3])
+__device__ __forceinline__ double cfx_sinpi_reduced(double r)
 {
-  // sin(pi r) / r as a degree-8 polynomial in r^2 on |r| <= 1/2: Chebyshev interpolant computed with
-  // 60 digits (approximation error 3e-19; 2.5e-16 measured in double over [-3, 3])
-  const double k = rint(x);
-  const double r = x - k, r2 = r * r;
+  const double r2 = r * r;
   double p = 0x1.9d462020fcc78p-21;
   p = fma(p, r2, -0x1.6f7acdb8f6580p-16);
   p = fma(p, r2, 0x1.e8f3675ee37ddp-12);
@@ -112,11 +111,29 @@ __device__ __forceinline__ double cfx_sinpi(double x)
   p = fma(p, r2, 0x1.466bc6775aa7dp+1);
   p = fma(p, r2, -0x1.4abbce625be52p+2);
   p = fma(p, r2, 0x1.921fb54442d18p+1);
-  const double s = p * r;
+  return p * r;
+}
+
+__device__ __forceinline__ double cfx_sinpi(double x)
+{
+  const double k = rint(x);
+  const double s = cfx_sinpi_reduced(x - k);
   // (-1)^k through the sign bit; k = rint(x) converts exactly for |x| < 2^31 (beyond that the conversion
   // saturates: coordinates of that size have no fractional digits left that a mesh could use)
   const int odd = ((int)k) & 1;
   return __hiloint2double(__double2hiint(s) ^ (odd << 31), __double2loint(s));
+}
+
+// sin(pi x) and cos(pi x) from one reduction; cos(pi r) = 1 - 2 sin^2(pi r / 2) (absolute error ~2e-16)
+__device__ __forceinline__ void cfx_sincospi(double x, double& s, double& c)
+{
+  const double k = rint(x);
+  const double r = x - k;
+  const double s0 = cfx_sinpi_reduced(r), sh = cfx_sinpi_reduced(0.5 * r);
+  const double c0 = fma(-2.0 * sh, sh, 1.0);
+  const int flip = (((int)k) & 1) << 31;
+  s = __hiloint2double(__double2hiint(s0) ^ flip, __double2loint(s0));
+  c = __hiloint2double(__double2hiint(c0) ^ flip, __double2loint(c0));
 }
 
 template <int GDIM>

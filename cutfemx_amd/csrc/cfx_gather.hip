@@ -265,6 +265,36 @@ struct VecArgs
   double* t2;
 };
 
+// element vector of uncut entity e: one array per local index ([ND][n]).  The rows gather (cell, local index)
+// pairs; cells numbered together around a vertex often hold it at the same local index (6 + 6 + 6 x 2 of the 24
+// tets around a vertex of a Kuhn box mesh), so their entries share 32 B sectors -- the [n][ND] records never do.
+// P1 with a row-ordered staging (A.t2): entry i goes to the segment of row dof_i; the per-cell record is only
+// written for cells with a dof off the plain rows.
+template <int ND, bool P1>
+__device__ __forceinline__ void store_std_vector(const VecArgs& A, int64_t e, int64_t cell, const double* be)
+{
+  bool record = true;
+  if constexpr (P1)
+  {
+    if (A.t2)
+    {
+      record = false;
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        const int32_t o = A.t2off[A.dofmap[cell * ND + i]];
+        if (o >= 0) A.t2[(int64_t)o + A.cpos[cell * ND + i]] = be[i];
+        else record = true;
+      }
+    }
+  }
+  if (record)
+  {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + e] = be[i];
+  }
+}
+
 // LANES > 1 (runtime rules): a group of lanes shares one rule, the points of the rule are dealt
 // round-robin to the lanes (coalesced point / weight / normal reads, balanced 6-42 point rules) and
 // the ND partial sums are folded with shuffles.
@@ -369,36 +399,217 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
       for (int o = LANES / 2; o > 0; o >>= 1) be[i] += __shfl_xor(be[i], o, LANES);
     if (sub != 0) return;
   }
-  // uncut entities: one array per local index ([ND][n]).  The rows gather (cell, local index) pairs; cells
-  // numbered together around a vertex often hold it at the same local index (6 + 6 + 6 x 2 of the 24 tets
-  // around a vertex of a Kuhn box mesh), so their entries share 32 B sectors -- the [n][ND] records never do
   if constexpr (RUNTIME)
   {
 #pragma unroll
     for (int i = 0; i < ND; ++i) A.out[e * ND + i] = be[i];
   }
   else
+    store_std_vector<ND, DEG == 1>(A, e, cell, be);
+}
+
+// The source term f v with f = c prod_d sin(pi x_d) (CFX_F_SINPROD / CFX_F_POISSON_RHS) on the UNCUT cells of a P1
+// space: the kernel the generic one above spends its time in (14 points x 3 sinpi per tet, FP64-VALU bound).
+// sin(pi (a + delta)) = S cos(pi delta) + C sin(pi delta) with a = the coordinate of vertex 0 (one sincospi per
+// axis and cell) and delta the offset of the point inside the cell: for |pi delta| <= 0.03 the two series up to
+// u^7 are exact to 2e-17, so a point costs 7 fused multiply-adds per axis instead of a range reduction and a
+// degree-17 polynomial.  Larger cells (coarse test meshes) take the exact evaluation.
+// Memory side: entity id -> connectivity row -> 4 vertex / 4 segment-offset gathers are three dependent levels, ~8 us
+// per wave under load against ~1 us of arithmetic, so a thread walks its cells with a software pipeline three
+// deep (cell j is computed while the gathers of j+1, the connectivity row of j+2 and the id of j+3 are in flight).
+#ifndef CFX_SOURCE_BLOCKS_PER_CU
+#define CFX_SOURCE_BLOCKS_PER_CU 16
+#endif
+template <int TDIM>
+struct SourceCell
+{
+  int64_t e;
+  int32_t cell;
+  int32_t v[TDIM + 1];
+  double x[TDIM + 1][TDIM];
+  int32_t t2o[TDIM + 1];
+  uint32_t cp;
+};
+
+template <int TDIM>
+__device__ __forceinline__ void source_load_conn(const VecArgs& A, SourceCell<TDIM>& c)
+{
+  if constexpr (TDIM == 3)
   {
-    bool record = true;
-    if constexpr (DEG == 1)
+    const int4 r = *reinterpret_cast<const int4*>(A.conn + (int64_t)c.cell * 4);
+    c.v[0] = r.x; c.v[1] = r.y; c.v[2] = r.z; c.v[3] = r.w;
+    if (A.t2) c.cp = *reinterpret_cast<const uint32_t*>(A.cpos + (int64_t)c.cell * 4);
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i) c.v[i] = A.conn[(int64_t)c.cell * (TDIM + 1) + i];
+    c.cp = 0;
+    if (A.t2)
     {
-      if (A.t2)
+#pragma unroll
+      for (int i = 0; i <= TDIM; ++i) c.cp |= (uint32_t)A.cpos[(int64_t)c.cell * (TDIM + 1) + i] << (8 * i);
+    }
+  }
+}
+
+template <int TDIM>
+__device__ __forceinline__ void source_load_vertices(const VecArgs& A, SourceCell<TDIM>& c)
+{
+#pragma unroll
+  for (int i = 0; i <= TDIM; ++i)
+  {
+    load_vertex<TDIM>(A.x, c.v[i], c.x[i]);
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 2)
+    c.t2o[i] = c.v[i]; // ablation: no segment-offset gathers
+#else
+    c.t2o[i] = A.t2 ? A.t2off[c.v[i]] : -1;
+#endif
+  }
+}
+
+template <int TDIM>
+__device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCell<TDIM>& c, bool valid, int npts,
+                                               const double* __restrict__ pts, const double* __restrict__ wts, double fscale)
+{
+  constexpr int ND = TDIM + 1;
+  double ed[TDIM][TDIM]; // (x_{t+1} - x_0)_d
+  double hmax = 0.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t)
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      ed[t][d] = c.x[t + 1][d] - c.x[0][d];
+      hmax = fmax(hmax, fabs(ed[t][d]));
+    }
+  double det;
+  if constexpr (TDIM == 2) det = ed[0][0] * ed[1][1] - ed[0][1] * ed[1][0];
+  else
+    det = ed[0][0] * (ed[1][1] * ed[2][2] - ed[1][2] * ed[2][1]) - ed[0][1] * (ed[1][0] * ed[2][2] - ed[1][2] * ed[2][0])
+          + ed[0][2] * (ed[1][0] * ed[2][1] - ed[1][1] * ed[2][0]);
+  const double cscale = fscale * fabs(det);
+  double be[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) be[i] = 0.0;
+  const double umax = kPi * hmax;
+  if (umax <= 0.03)
+  {
+    // sin(pi a + u) = S + C u - S u^2/2 - C u^3/6 + S u^4/24 + C u^5/120 - S u^6/720 - C u^7/5040: the first
+    // neglected term is below 1.1e-16 after u^5 for |u| <= 0.0065 (h <= 1/484) and after u^7 for |u| <= 0.03
+    double S[TDIM], C[TDIM];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      cfx_sincospi(c.x[0][d], S[d], C[d]);
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) ed[t][d] *= kPi;
+    }
+    auto series = [&](auto deg_tag)
+    {
+      constexpr int DEGS = decltype(deg_tag)::value;
+      double co[TDIM][DEGS + 1];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
       {
-        record = false;
+        const double inv[8] = {1.0, 1.0, -1.0 / 2.0, -1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, -1.0 / 720.0, -1.0 / 5040.0};
 #pragma unroll
-        for (int i = 0; i < ND; ++i)
-        {
-          const int32_t o = A.t2off[A.dofmap[cell * ND + i]];
-          if (o >= 0) A.t2[(int64_t)o + A.cpos[cell * ND + i]] = be[i];
-          else record = true;
-        }
+        for (int k = 0; k <= DEGS; ++k) co[d][k] = ((k & 1) ? C[d] : S[d]) * inv[k];
       }
-    }
-    if (record)
-    {
+      for (int q = 0; q < npts; ++q) // (the point index is wave-uniform: points, weights and basis values are scalars)
+      {
+        double X[TDIM], l0 = 1.0;
 #pragma unroll
-      for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + e] = be[i];
+        for (int t = 0; t < TDIM; ++t) { X[t] = pts[q * TDIM + t]; l0 -= X[t]; }
+        double f = wts[q] * cscale;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double u = X[0] * ed[0][d];
+#pragma unroll
+          for (int t = 1; t < TDIM; ++t) u = fma(X[t], ed[t][d], u);
+          double p = co[d][DEGS];
+#pragma unroll
+          for (int k = DEGS - 1; k >= 0; --k) p = fma(p, u, co[d][k]);
+          f *= p;
+        }
+        be[0] = fma(f, l0, be[0]);
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) be[t + 1] = fma(f, X[t], be[t + 1]);
+      }
+    };
+    if (umax <= 0.0065) series(std::integral_constant<int, 5>{});
+    else series(std::integral_constant<int, 7>{});
+  }
+  else
+  {
+    for (int q = 0; q < npts; ++q)
+    {
+      double X[TDIM], l0 = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) { X[t] = pts[q * TDIM + t]; l0 -= X[t]; }
+      double f = wts[q] * cscale;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = c.x[0][d];
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v = fma(X[t], ed[t][d], v);
+        f *= cfx_sinpi(v);
+      }
+      be[0] = fma(f, l0, be[0]);
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) be[t + 1] = fma(f, X[t], be[t + 1]);
     }
+  }
+  if (!valid) return;
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 1)
+  if (be[0] != 1.2345e300) return; // ablation: no stores
+#endif
+  // entry i to the segment of row dof_i (store_std_vector, with the gathers already in registers)
+  bool record = A.t2 == nullptr;
+#pragma unroll
+  for (int i = 0; i < ND; ++i)
+  {
+    if (c.t2o[i] >= 0) A.t2[(int64_t)c.t2o[i] + ((c.cp >> (8 * i)) & 0xffu)] = be[i];
+    else record = true;
+  }
+  if (record)
+  {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + c.e] = be[i];
+  }
+}
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) vec_source_sin_p1_kernel(VecArgs A)
+{
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t last = A.n - 1;
+  int npts;
+  const double* wts;
+  const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
+  const double fscale = A.params[1] * ((int)A.params[0] == CFX_F_POISSON_RHS ? (double)TDIM * kPi * kPi : 1.0);
+  auto ent = [&](int64_t e) { return A.entities[e < last ? e : last]; }; // (clamped: the tail of the pipeline loads the last cell again)
+  SourceCell<TDIM> a, b;
+  int32_t cell_c, cell_d;
+  a.e = e0; b.e = e0 + stride;
+  a.cell = ent(a.e); b.cell = ent(b.e); cell_c = ent(e0 + 2 * stride);
+  source_load_conn<TDIM>(A, a);
+  source_load_conn<TDIM>(A, b);
+  source_load_vertices<TDIM>(A, a);
+  for (int64_t e = e0; e < A.n; e += stride)
+  {
+    cell_d = ent(e + 3 * stride);
+    SourceCell<TDIM> c;
+    c.e = e + 2 * stride; c.cell = cell_c;
+    source_load_conn<TDIM>(A, c);
+    source_load_vertices<TDIM>(A, b);
+    source_compute<TDIM>(A, a, true, npts, pts, wts, fscale);
+    a = b;
+    b = c;
+    cell_c = cell_d;
   }
 }
 
@@ -1698,7 +1909,20 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
   if (!runtime)
   {
     A.n = I.n_entities; A.entities = I.entities.p;
-    launch("vec_tensors_std", vec_tensors_kernel<TDIM, DEG, false>, grid_for(A.n), dim3(kBlock), 0, A);
+    const int field = (int)I.params[0];
+    const char* fs = getenv("CFX_SOURCE_SERIES");
+    if (DEG == 1 && I.kernel == CFX_L_SOURCE && !A.coeff && (field == CFX_F_SINPROD || field == CFX_F_POISSON_RHS)
+        && V->dofmap.p == V->mesh->conn.p && !(fs && fs[0] == '0'))
+    {
+      if constexpr (DEG == 1)
+      {
+        // a resident grid: every thread walks ~n / (256 CUs x blocks x 256) cells through its software pipeline
+        const int64_t blocks = std::min<int64_t>((A.n + kBlock - 1) / kBlock, 256 * CFX_SOURCE_BLOCKS_PER_CU);
+        launch("vec_tensors_std", vec_source_sin_p1_kernel<TDIM>, dim3((unsigned)blocks), dim3(kBlock), 0, A);
+      }
+    }
+    else
+      launch("vec_tensors_std", vec_tensors_kernel<TDIM, DEG, false>, grid_for(A.n), dim3(kBlock), 0, A);
   }
   else
   {

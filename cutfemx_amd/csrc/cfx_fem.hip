@@ -424,6 +424,216 @@ __global__ void __launch_bounds__(kBlock) cut_tensors_p1_kernel(AsmArgs A)
     for (int j = 0; j < ND; ++j) out[i * ND + j] = T[i][j];
 }
 
+// ---------------------------------------------------------------------------
+// Batched B^T D B on the FP64 matrix cores: the element tensors of sigma(u):eps(v) on vector spaces (bs = 3,
+// BASELINE config 5), one wavefront per cell, written entity-major for the row gather.
+// With c = 3 i + a numbering the (dof, component) pairs and g_c(q) = d N_i / d x_a at point q,
+//   H[c][c'] = sum_q w_q g_c(q) g_c'(q)                       (a NLOC x nq times nq x NLOC product: MFMA),
+//   Ae[(i,a),(j,b)] = lambda H[3i+a][3j+b] + mu H[3i+b][3j+a] + mu delta_ab sum_d H[3i+d][3j+d]
+// -- the strain-displacement matrices B_q (6 x NLOC) and D never appear: B^T D B is this combination of the
+// gradient Gram matrix H, whose K dimension is the quadrature point (4 per v_mfma_f64_16x16x4_f64).
+// Lane l of the MFMA holds A[i = l & 15][k = l >> 4] = g_{16 tr + i}(q_k) and B[k][j = l & 15] = w_k g_{16 tc + j}(q_k):
+// the same two gradient values serve as A and B operands of the 2 x 2 (P2) tiles.  H goes through LDS once
+// (the lambda / mu combination reads entries held by other lanes) and the 900 doubles leave as full lines.
+// ---------------------------------------------------------------------------
+typedef double cfx_f64x4 __attribute__((ext_vector_type(4)));
+
+template <int DEG, bool RUNTIME>
+__global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
+{
+  constexpr int TDIM = 3, BS = 3;
+  constexpr int ND = Elem<TDIM, DEG>::ND, NLOC = ND * BS;
+  constexpr int NT = (NLOC + 15) / 16;  // 16 x 16 tiles per side
+  constexpr int NB = ND * ND;           // 3 x 3 blocks (dof i, dof j) of the tensor
+  // (one wavefront per workgroup: the barriers below order the wave's own LDS traffic and cost nothing)
+  __shared__ __align__(16) double s_H[NLOC * NLOC]; // H, then Ae in place: the image that is streamed out
+  __shared__ double s_L[4][3];        // physical gradients of the barycentric coordinates
+  const int lane = threadIdx.x;
+  const int64_t nwaves = gridDim.x;
+  const double E = A.params[0], nu = A.params[1];
+  const double mu = E / (2.0 * (1.0 + nu));
+  const double lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu));
+  // this lane's NT columns of G: dof i, component d, and the two barycentric coordinates of the basis function
+  // (vertex function lam_a (2 lam_a - 1): a == b; edge function 4 lam_a lam_b)
+  int ca[NT], cb[NT], cd[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+  {
+    const int c = 16 * tt + (lane & 15);
+    cok[tt] = c < NLOC;
+    const int i = cok[tt] ? c / 3 : 0;
+    cd[tt] = cok[tt] ? c - 3 * i : 0;
+    if (DEG == 1 || i < 4) { ca[tt] = i; cb[tt] = i; }
+    else
+    {
+      const int e = i - 4; // Basix edge order (2,3),(1,3),(1,2),(0,3),(0,2),(0,1)
+      ca[tt] = e == 0 ? 2 : (e <= 2 ? 1 : 0);
+      cb[tt] = (e == 0 || e == 1 || e == 3) ? 3 : ((e == 2 || e == 4) ? 2 : 1);
+    }
+  }
+  const int k = lane >> 4; // the quadrature point of a group of 4 this lane feeds
+  // cell id -> connectivity row -> vertex coordinates are three dependent loads: a software pipeline three deep
+  // keeps them ahead of the arithmetic (cell e is computed while the coordinates of e + nwaves, the connectivity
+  // row of e + 2 nwaves and the id of e + 3 nwaves are in flight); indices past the end load the last entity again
+  const int64_t last = A.n - 1;
+  auto cell_of = [&](int64_t i) { i = i < last ? i : last; return RUNTIME ? A.parent_map[i] : A.entities[i]; };
+  auto conn_of = [&](int32_t c, int32_t* v)
+  {
+    const int4 r = *reinterpret_cast<const int4*>(A.conn + (int64_t)c * 4);
+    v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+  };
+  int32_t cell_c = cell_of(blockIdx.x + 2 * nwaves);
+  int32_t vb[4], va[4];
+  conn_of(cell_of(blockIdx.x), va);
+  conn_of(cell_of(blockIdx.x + nwaves), vb);
+  double xa[4][3], xb[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xa[i][d] = A.x[3 * (int64_t)va[i] + d];
+  for (int64_t e = blockIdx.x; e < A.n; e += nwaves)
+  {
+    const int32_t cell_d = cell_of(e + 3 * nwaves);
+    int32_t vc[4];
+    conn_of(cell_c, vc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xb[i][d] = A.x[3 * (int64_t)vb[i] + d];
+    Geo<TDIM> g;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) g.x[i][d] = xa[i][d];
+    jacobian<TDIM>(g);
+    if (lane < 12)
+    {
+      const int m = lane / 3, d = lane - 3 * m;
+      // grad lam_m = row m-1 of K for m >= 1, minus their sum for m = 0
+      // (static indices only: a runtime-indexed register array would live in scratch memory)
+      double v = 0.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        double ktd = g.K[t][0];
+#pragma unroll
+        for (int dd = 1; dd < TDIM; ++dd) ktd = (d == dd) ? g.K[t][dd] : ktd;
+        v += (m == 0) ? -ktd : ((m - 1 == t) ? ktd : 0.0);
+      }
+      s_L[m][d] = v;
+    }
+    __syncthreads();
+    double La[NT], Lb[NT];
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) { La[tt] = s_L[ca[tt]][cd[tt]]; Lb[tt] = s_L[cb[tt]][cd[tt]]; }
+    int npts;
+    const double* pts;
+    const double* wts;
+    double wscale = 1.0;
+    if constexpr (RUNTIME)
+    {
+      const int32_t q0 = A.offsets[e];
+      npts = A.offsets[e + 1] - q0;
+      pts = A.points + (int64_t)q0 * TDIM;
+      wts = A.weights + q0;
+    }
+    else
+    {
+      pts = ref_rule(TDIM, A.qdegree, npts, wts);
+      wscale = fabs(g.detJ);
+    }
+    cfx_f64x4 acc[NT][NT];
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < NT; ++tc) acc[tr][tc] = cfx_f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int q0 = 0; q0 < npts; q0 += 4)
+    {
+      const int q = q0 + k;
+      const bool in = q < npts;
+      double lam[4];
+      lam[0] = 1.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        lam[t + 1] = in ? pts[(int64_t)q * TDIM + t] : 0.0;
+        lam[0] -= lam[t + 1];
+      }
+      const double w = in ? wts[q] * wscale : 0.0;
+      double gv[NT];
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+      {
+        double la = lam[0], lb = lam[0];
+#pragma unroll
+        for (int m = 1; m < 4; ++m) { la = (ca[tt] == m) ? lam[m] : la; lb = (cb[tt] == m) ? lam[m] : lb; }
+        double v;
+        if (DEG == 1) v = La[tt];
+        else v = (ca[tt] == cb[tt]) ? (4.0 * la - 1.0) * La[tt] : 4.0 * (lb * La[tt] + la * Lb[tt]);
+        gv[tt] = cok[tt] ? v : 0.0;
+      }
+#pragma unroll
+      for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+        for (int tc = 0; tc < NT; ++tc)
+          acc[tr][tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(gv[tr], w * gv[tc], acc[tr][tc], 0, 0, 0);
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: register r of lane l is H[(l >> 4) + 4 r][l & 15] of the tile
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+      for (int tc = 0; tc < NT; ++tc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+        {
+          const int row = 16 * tr + k + 4 * r, col = 16 * tc + (lane & 15);
+          if (row < NLOC && col < NLOC) s_H[row * NLOC + col] = acc[tr][tc][r];
+        }
+    __syncthreads();
+    // a lane owns the 3 x 3 blocks (i, j) = lane, lane + 64: Ae_blk = lambda H_blk + mu H_blk^T + mu tr(H_blk) I, in place
+#pragma unroll
+    for (int pass = 0; pass < (NB + 63) / 64; ++pass)
+    {
+      const int blk = lane + 64 * pass;
+      if (blk < NB)
+      {
+        const int i = blk / ND, j = blk - i * ND;
+        double* hb = s_H + (3 * i) * NLOC + 3 * j;
+        double h[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) h[a][b] = hb[a * NLOC + b];
+        const double tr = mu * (h[0][0] + h[1][1] + h[2][2]);
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) hb[a * NLOC + b] = lmbda * h[a][b] + mu * h[b][a] + (a == b ? tr : 0.0);
+      }
+    }
+    __syncthreads();
+    double* out = A.dump + e * (int64_t)(NLOC * NLOC);
+    // 16 B per lane: 1 KiB per store instruction (a tensor starts on a 16 B boundary: NLOC^2 is even)
+    typedef double cfx_d2 __attribute__((ext_vector_type(2)));
+#if defined(CFX_MFMA_ABLATE) && (CFX_MFMA_ABLATE & 1)
+    if (s_H[lane] == 1.2345e300) // ablation: no stores
+#endif
+    for (int o = lane; o < NLOC * NLOC / 2; o += 64)
+      reinterpret_cast<cfx_d2*>(out)[o] = reinterpret_cast<const cfx_d2*>(s_H)[o];
+    __syncthreads(); // s_H / s_L are reused by the next cell
+    // rotate the pipeline registers here, behind the arithmetic: the moves wait for this iteration's loads
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+    {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xa[i][d] = xb[i][d];
+      vb[i] = vc[i];
+    }
+    cell_c = cell_d;
+  }
+}
+
 template <int TDIM, int DEG, int BS>
 void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule,
                        int parts)
@@ -466,13 +676,24 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     }
     return;
   }
+  // staged element tensors of the elasticity term on 3-D vector spaces: the MFMA kernel (CFX_MFMA=0: generic rows)
+  const char* mf = getenv("CFX_MFMA");
+  const bool mfma_tensors = TDIM == 3 && BS == 3 && a->rank == 2 && A.dump != nullptr && !single && !A.lift_markers
+                            && A.kernel == CFX_K_ELASTICITY && !(mf && mf[0] == '0');
+  // a resident grid of wavefronts, each walking its share of the cells
+  auto mfma_grid = [](int64_t n) { return dim3((unsigned)std::min<int64_t>(n, 256 * 32)); };
   if ((parts & 1) && (!single || !use_rule))
   {
     A.n = single ? 1 : I.n_entities;
     A.entities = I.entities.p + (single ? only_index : 0);
     if (A.n > 0)
     {
-      if (a->rank == 2)
+      if (mfma_tensors)
+      {
+        if constexpr (TDIM == 3 && BS == 3)
+          launch("elasticity_tensors_mfma", elasticity_tensors_mfma_kernel<DEG, false>, mfma_grid(A.n), dim3(64), 0, A);
+      }
+      else if (a->rank == 2)
         launch("assemble_cells_std", assemble_cells_kernel<TDIM, DEG, BS, 2, false>, grid_for(A.n * ND * BS),
                dim3(kBlock), 0, A);
       else
@@ -497,6 +718,11 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
       {
         if constexpr (DEG == 1 && BS == 1)
           launch("cut_tensors_p1", cut_tensors_p1_kernel<TDIM>, grid_for(A.n * kCutLanes), dim3(kBlock), 0, A);
+      }
+      else if (mfma_tensors)
+      {
+        if constexpr (TDIM == 3 && BS == 3)
+          launch("elasticity_tensors_mfma_cut", elasticity_tensors_mfma_kernel<DEG, true>, mfma_grid(A.n), dim3(64), 0, A);
       }
       else if (a->rank == 2)
         launch("assemble_cells_cut", assemble_cells_kernel<TDIM, DEG, BS, 2, true>, grid_for(A.n * ND * BS),

@@ -47,6 +47,17 @@ B_GHOST_FACET = 600.0           # row ids 16 + 2x(16+16) maps + 64 values x 8 B
 # sparsity (not priced in SURVEY 8d): per marked cell its dofmap row (16 B) and its four
 # incidence entries (16 B), per CSR entry 4 B written, per row 8 B of indptr
 B_PATTERN_PER_CELL, B_PATTERN_PER_NNZ, B_PATTERN_PER_ROW = 32.0, 4.0, 8.0
+B_SELECTOR_PER_CELL, B_SELECTOR_PER_HIT = 2.0, 4.0   # 1 B/cell x 2 passes + 4 B per located entity
+B_NORMAL_PER_POINT = 24.0       # gdim doubles per interface point (a12)
+B_VECTOR_PER_ROW_CELL = 16.0    # element-vector entry written once + read once per (row, cell) pair
+B_DEACTIVATE_PER_ROW = 16.0     # diagonal write + rhs write per inactive row (a11)
+FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = FP32 vector (157.3 TF, MI355X_MICROARCH.md) / 2; FP64 MFMA: the same rate
+# flops of the source-term stage 1 per uncut cell: per point 3 x (5 offset + 2 x 5 series) + 3 products
+# + 8 basis updates = 56, 14 points, + ~250 per cell (edges, determinant, 3 sincospi, 18 coefficients)
+FLOP_SOURCE_PER_CELL = 14 * 56 + 250
+# reference-equivalent quadrature size: Basix 0.11's default simplex scheme (Xiao-Gimbutas) has 11 points at degree 4
+# on a tetrahedron where this engine's positive symmetric rule has 14; 6 = 6 on triangles
+NQ_REF_PER_ENGINE_VOLUME, NQ_REF_PER_ENGINE_INTERFACE = 11.0 / 14.0, 1.0
 
 
 def parse():
@@ -58,8 +69,8 @@ def parse():
                    help="background mesh n^3 cubes (x6 tets); use --mesh under torchrun (--n is ambiguous there)")
     p.add_argument("--order", type=int, default=4, help="runtime quadrature order (demo_poisson.py:139)")
     p.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    p.add_argument("--cpu-n", type=int, default=192, help="mesh size of the bounded CPU sample")
-    p.add_argument("--no-secondary", action="store_true", help="skip the 128^3 (configs[1]) line")
+    p.add_argument("--cpu-n", type=int, default=256, help="mesh size of the bounded CPU sample (BASELINE.md 3: 256^3)")
+    p.add_argument("--no-secondary", action="store_true", help="skip the configs[1], [3], [4] and implicit-structured lines")
     p.add_argument("--cpu-worker", nargs=4, type=int, metavar=("N", "Z0", "Z1", "ORDER"),
                    help="internal: one process of the all-cores CPU baseline")
     return p.parse_args()
@@ -114,7 +125,7 @@ def cpu_baseline(n, order):
     cannot be built here.  The reference is serial per rank."""
     from helpers import level_set_values
     from oracle import pyoracle as O
-    O.build()
+    O.use_native_build()       # gcc -O3 -march=native on this host (BASELINE.md 3); results as the portable build
     om = O.mesh_box(3, n)
     phi = level_set_values(om.x, 3)
     t = {}
@@ -151,8 +162,10 @@ def cpu_baseline(n, order):
     active = om.nnodes - ina.size
     return dict(value=active / total, unit="DOF/s", cores=1, kind="port",
                 sample=f"full hot path on the {n}^3 sphere workload ({6 * n ** 3} tets; oracle/cfx_oracle.c, "
-                       f"gcc -O2, 1 thread), {total:.1f} s",
-                seconds=total, active_dofs=int(active),
+                       f"gcc -O3 -march=native -ffp-contract=off, 1 thread), {total:.1f} s; the 512^3 case does not fit the "
+                       "time budget of this leg: linear extrapolation in cells in `seconds_at_512_extrapolated`",
+                seconds=total, seconds_at_512_extrapolated=total * (512.0 / n) ** 3, extrapolated=(n != 512),
+                active_dofs=int(active),
                 assemble_matrix_dofs_per_s=active / t["assemble_matrix"],
                 cut_qp_per_s=(vol.weights.size + itf.weights.size)
                 / (t["cut"] + t["rules_volume"] + t["rules_interface"]),
@@ -166,10 +179,18 @@ def cpu_slab_worker(n, z0, z1, order):
     import numpy as np
     from helpers import level_set_values, oracle_poisson
     from oracle import pyoracle as O
-    O.build()
-    full = O.mesh_box(3, n)
+    O.use_native_build()
     s2 = (n + 1) ** 2
-    om = O.Mesh(3, full.x[s2 * z0: s2 * (z1 + 1)], full.conn[6 * n * n * z0: 6 * n * n * z1] - s2 * z0)
+    # layers z0..z1-1 of the n^3 Kuhn box (cutfemx_amd.mesh.box_mesh_arrays restricted to the slab)
+    KUHN_TET = np.array([[0, 1, 3, 7], [0, 1, 5, 7], [0, 2, 3, 7], [0, 2, 6, 7], [0, 4, 5, 7], [0, 4, 6, 7]])
+    ax = np.arange(n + 1, dtype=np.float64) / n
+    zz, yy, xx = np.meshgrid(np.arange(z0, z1 + 1, dtype=np.float64) / n, ax, ax, indexing="ij")
+    x = np.stack([xx.ravel(), yy.ravel(), zz.ravel()], axis=1)
+    iz, iy, ix = np.meshgrid(np.arange(z1 - z0), np.arange(n), np.arange(n), indexing="ij")
+    ix, iy, iz = ix.ravel(), iy.ravel(), iz.ravel()
+    corner = np.stack([(ix + (i & 1)) + (n + 1) * ((iy + ((i >> 1) & 1)) + (n + 1) * (iz + ((i >> 2) & 1)))
+                       for i in range(8)], axis=1)
+    om = O.Mesh(3, x, np.ascontiguousarray(corner[:, KUHN_TET].reshape(-1, 4), dtype=np.int32))
     phi = level_set_values(om.x, 3)
     t0 = time.perf_counter()
     ref = oracle_poisson(O, om, phi, order=order)
@@ -199,8 +220,9 @@ def cpu_baseline_all_cores(n, order):
     secs = max(o["seconds"] for o in outs)
     active = sum(o["active"] for o in outs)
     return dict(value=active / secs, unit="DOF/s", cores=len(procs), kind="port",
-                sample=f"{n}^3 sphere workload split into {len(procs)} weighted z-slabs, one oracle process per host "
-                       f"core of this box's 16-core share (no ghost layers), slowest process {secs:.1f} s",
+                sample=f"{n}^3 sphere workload split into {len(procs)} weighted z-slabs, one oracle process (gcc -O3 "
+                       f"-march=native) per host core of this box's 16-core share (the box reports {os.cpu_count()} "
+                       f"cores, a one-GPU job is allotted 16; no ghost layers), slowest process {secs:.1f} s",
                 seconds=secs, active_dofs=active, host_cores_available=os.cpu_count())
 
 
@@ -258,7 +280,14 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(warmup):
+    # the first step also builds the mesh-static tables (dof -> cells incidence, row stencil, row tiles,
+    # cell -> cell): timed on its own and reported as `setup_ms`, never part of `value`
+    barrier()
+    ts = time.perf_counter()
+    info = step()
+    barrier()
+    first_step_ms = 1e3 * (time.perf_counter() - ts)
+    for _ in range(max(warmup - 1, 0)):
         info = step()
     barrier()
     t0 = time.perf_counter()
@@ -283,6 +312,12 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         nq_total = float(info["nq_volume"] + info["nq_interface"])
     out = dict(value=active_total / (elapsed / steps), ms_per_step=1e3 * elapsed / steps,
                active_dofs=int(active_total), counts={k: int(v) for k, v in info.items()})
+    static_bytes = (V if world == 1 else dp.V).static_table_bytes()
+    out["setup"] = dict(setup_ms=first_step_ms - out["ms_per_step"], first_step_ms=first_step_ms,
+                        steps_to_amortise=(first_step_ms - out["ms_per_step"]) / out["ms_per_step"],
+                        static_table_bytes=static_bytes, static_table_bytes_total=sum(static_bytes.values()),
+                        note="mesh-static tables built by the first step and reused by every later one (moving-domain "
+                             "loop: the level set changes, the mesh does not); not part of `value`")
     if not profile:
         return out
 
@@ -305,7 +340,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
                      + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])) / 2,   # two launches per step
         "assemble_facets": B_GHOST_FACET * info["n_ghost"],
     }
-    if "assemble_rows_plain" in kernels:      # the p1 kernel then only serves the interface rows
+    alg_bytes["assemble_tiles_plain"] = alg_bytes["assemble_rows_plain"]   # the same rows by row tile
+    if "assemble_rows_plain" in kernels or "assemble_tiles_plain" in kernels:   # the p1 kernel then only serves the interface rows
         alg_bytes.pop("assemble_rows_p1")
     if "plan_plain_masks" in kernels:         # the hashed kernel then only serves the interface rows
         alg_bytes.pop("pattern_rows")
@@ -341,7 +377,54 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
                         avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,
                         note="achieved = SURVEY 8d bytes/unit x units of the launch / HIP-event duration on the "
                              f"launch stream, {psteps} profiled steps right after the timed region; traffic: " + tnote)
-    out.update(phases_ms=phases_ms,
+    # the kernel that takes longest, whatever bounds it (the headline `roofline` is the longest HBM-priced one)
+    longest = max(kernels, key=lambda k: kernels[k]["total_ms"]) if kernels else None
+    roofline_longest = None
+    if longest == "vec_tensors_std":
+        fl = FLOP_SOURCE_PER_CELL * info["n_inside"]
+        ach = fl / (kernels[longest]["avg_us"] * 1e-6) / 1e12
+        roofline_longest = dict(kernel=longest, bound="fp64-valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
+                                frac=ach / FP64_VALU_PEAK_TFLOPS, avg_launch_us=kernels[longest]["avg_us"],
+                                algorithmic_flops_per_launch=fl,
+                                note="source term f v on the uncut cells: 14 points x (3 offsets + 3 short sine series) per "
+                                     "tet; 4 scattered 8 B stores per cell on top (DESIGN.md 3)")
+    elif longest is not None and longest in roof:
+        roofline_longest = dict(kernel=longest, bound="hbm", achieved=roof[longest]["achieved_GBs"], peak=HBM_PEAK_GBS,
+                                unit="GB/s", frac=roof[longest]["frac"], avg_launch_us=kernels[longest]["avg_us"])
+    # whole step against the HBM roofline: SURVEY 8d's algorithmic bytes of every stage of one step / step time
+    active = info.get("active_dofs", info.get("active_dofs_owned", 0))
+    nrows = (n + 1) ** 3 if world == 1 else mesh.num_nodes
+    step_bytes = dict(
+        classify=B_CLASSIFY_PER_CELL * mesh.num_cells,
+        selector_scans=B_SELECTOR_PER_CELL * mesh.num_cells + B_SELECTOR_PER_HIT * (info["n_inside"] + info["n_cut"]),
+        quadrature=(B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])
+                    + B_QUAD_PER_CUT_CELL * (info["n_vol_rules"] + info["n_cut"])),
+        normals=B_NORMAL_PER_POINT * info["nq_interface"],
+        ghost_facets=B_GHOST_FACET * info["n_ghost"],
+        sparsity=(B_PATTERN_PER_CELL * (info["n_inside"] + info["n_cut"]) + B_PATTERN_PER_NNZ * info["nnz"]
+                  + B_PATTERN_PER_ROW * nrows),
+        matrix_uncut_cells=B_UNCUT_CELL * info["n_inside"],
+        matrix_cut_cells=(B_UNCUT_CELL * (info["n_vol_rules"] + info["n_cut"])
+                          + B_QUAD_PER_POINT * (info["nq_volume"] + info["nq_interface"])
+                          + B_NORMAL_PER_POINT * info["nq_interface"]),
+        matrix_zero=8.0 * info["nnz"],
+        vector=B_VECTOR_PER_ROW_CELL * 4 * info["n_inside"] + 8.0 * nrows,
+        deactivate=B_DEACTIVATE_PER_ROW * (nrows - active))
+    total_bytes = float(sum(step_bytes.values()))
+    whole_step = dict(algorithmic_bytes=total_bytes, achieved=total_bytes / (out["ms_per_step"] * 1e-3) / 1e9,
+                      peak=HBM_PEAK_GBS, unit="GB/s", frac=total_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      bytes_by_stage={k: float(v) for k, v in step_bytes.items()},
+                      note="SURVEY 8d bytes per unit x units of this step (explicit connectivity), summed over the "
+                           "stages, / measured step time")
+    nq_ref = NQ_REF_PER_ENGINE_VOLUME * info["nq_volume"] + NQ_REF_PER_ENGINE_INTERFACE * info["nq_interface"]
+    out.update(phases_ms=phases_ms, roofline_longest_kernel=roofline_longest, whole_step_roofline=whole_step,
+               cut_quadrature_points_reference_equivalent=dict(
+                   points=nq_ref,
+                   points_per_s=(nq_ref * (nq_total / max(info["nq_volume"] + info["nq_interface"], 1))
+                                 / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
+                                 if "cut" in phases_ms else None),
+                   note="the engine's degree-4 tetrahedron rule has 14 points, Basix's (the reference's) 11: the same cut "
+                        "cells would carry 11/14 of the volume points there; interface triangles 6 = 6"),
                cut_quadrature_points_per_s=(nq_total / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
                                             if "cut" in phases_ms else None),
                assemble_matrix_dofs_per_s=(active_total / (1e-3 * phases_ms["assemble_matrix"])
@@ -350,6 +433,113 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
                         for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["total_ms"])},
                roofline=roofline, roofline_by_kernel=roof)
     return out
+
+
+def _timed_steps(torch, step, steps=3, warmup=1):
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info = step()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / steps, info
+
+
+def _kernel_times(step):
+    import cutfemx_amd
+    from cutfemx_amd import _lib
+    k = kernel_profile(_lib, step, 1)
+    return {n: round(v["total_ms"], 2) for n, v in sorted(k.items(), key=lambda kv: -kv[1]["total_ms"])[:10]}
+
+
+def secondary_p2_gyroid(torch, device, n=256):
+    """BASELINE configs[3]: 3-D Poisson, gyroid level set (k = 4) on the 256^3 mesh, P2 solution space over the P1
+    level set, Nitsche + ghost penalty, order 4.  Step = rules + forms + sparsity + assemble_matrix +
+    assemble_vector + deactivation with the cut (classification) included."""
+    import math
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem, poisson
+    mesh = cfx.Mesh.create_box(3, n)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
+    Z, Y, X = ax[:, None, None], ax[None, :, None], ax[None, None, :]
+    k = 2.0 * math.pi * 4.0
+    g = torch.sin(k * X) * torch.cos(k * Y) + torch.sin(k * Y) * torch.cos(k * Z) + torch.sin(k * Z) * torch.cos(k * X)
+    phi = cfx.Function(Vphi, (g + 0.0137).reshape(-1).contiguous())
+    dm, nd = cfx.box_lagrange2_dofmap(mesh, n, device)
+    V = cfx.FunctionSpace(mesh, 2, dofmap=dm, ndofs=nd)
+    b = torch.zeros(nd, device=device, dtype=torch.float64)
+    phases = {}
+
+    def step():
+        t = time.perf_counter
+        torch.cuda.synchronize(); t0 = t()
+        cd = cfx.cut(phi)
+        sysm = poisson.build_forms(V, cd, order=4)
+        torch.cuda.synchronize(); t1 = t()
+        A = fem.create_matrix(sysm.a)
+        torch.cuda.synchronize(); t2 = t()
+        fem.assemble_matrix(sysm.a, A=A)
+        torch.cuda.synchronize(); t3 = t()
+        b.zero_()
+        fem.assemble_vector(sysm.L, b)
+        dom = fem.deactivate_outside(A, b, fem.active_domain(sysm.a))
+        torch.cuda.synchronize(); t4 = t()
+        phases.update(cut_rules_forms=1e3 * (t1 - t0), sparsity=1e3 * (t2 - t1), assemble_matrix=1e3 * (t3 - t2),
+                      assemble_vector_deactivate=1e3 * (t4 - t3))
+        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=sysm.inside_cells[1],
+                    n_cut=sysm.interface_rules.num_rules)
+    ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+    return dict(workload=f"configs[3]: 3D Poisson, gyroid level set on the {n}^3 mesh ({6 * n ** 3} tets), P2 space "
+                         f"({nd} dofs) over the P1 level set, Nitsche + ghost penalty, order 4; one step = cut + rules + "
+                         "sparsity + assemble_matrix + assemble_vector + deactivation",
+                value=info["active_dofs"] / (1e-3 * ms), unit="DOF/s", ms_per_step=ms, counts=info,
+                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=_kernel_times(step))
+
+
+def secondary_elasticity_share(torch, device, n=256, z0=89, nz=32):
+    """BASELINE configs[4] is an 8-GPU configuration: this is ONE rank's share of it (a 256 x 256 x 32 slab of the
+    256^3 mesh through the sphere), P2 vector space, sigma(u):eps(v) over [solid cells, rules] + ghost penalty
+    (python/demo/demo_elasticity.py:214-235).  Step = cut + rules + sparsity + assemble_matrix."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    mesh = cfx.Mesh.create_slab(n, z0, nz)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
+    az = torch.arange(z0, z0 + nz + 1, device=device, dtype=torch.float64) / n
+    d2 = (az[:, None, None] - 0.41) ** 2 + (ax[None, :, None] - 0.43) ** 2 + (ax[None, None, :] - 0.47) ** 2
+    phi = cfx.Function(Vphi, (torch.sqrt(d2) - 0.31).reshape(-1).contiguous())
+    dm, nd = cfx.box_lagrange2_dofmap(mesh, n, device)
+    V = cfx.FunctionSpace(mesh, 2, dofmap=dm, ndofs=nd, bs=3)
+    E, nu = 1.0e3, 0.3
+    mu, lmbda = E / (2.0 * (1.0 + nu)), E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    phases = {}
+
+    def step():
+        t = time.perf_counter
+        torch.cuda.synchronize(); t0 = t()
+        cd = cfx.cut(phi)
+        inside = cfx.locate_entities_device(cd, "phi<0")
+        vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+        a = fem.form([fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(E, nu), qdegree=2),
+                      fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.05 * (2.0 * mu + lmbda),), qdegree=2)], V)
+        torch.cuda.synchronize(); t1 = t()
+        A = fem.create_matrix(a)
+        torch.cuda.synchronize(); t2 = t()
+        fem.assemble_matrix(a, A=A)
+        torch.cuda.synchronize(); t3 = t()
+        phases.update(cut_rules_forms=1e3 * (t1 - t0), sparsity=1e3 * (t2 - t1), assemble_matrix=1e3 * (t3 - t2))
+        dom = fem.active_domain(a)
+        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=inside[1], n_ghost=ghost.size)
+    ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+    return dict(workload=f"configs[4], one of eight ranks' share: layers {z0}..{z0 + nz - 1} of the {n}^3 mesh, sphere level "
+                         f"set, P2 vector space (3 x {nd} dofs), elasticity + ghost penalty; one step = cut + rules + sparsity "
+                         "+ assemble_matrix",
+                value=info["active_dofs"] / (1e-3 * ms), unit="DOF/s", ms_per_step=ms, counts=info,
+                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=_kernel_times(step))
 
 
 def main():
@@ -404,14 +594,25 @@ def main():
                        "level-set halo" if os.environ.get("CFX_DIST_MODE", "owner") == "owner" else
                        f"z-slabs x{world} weighted by active cells, halo 3 layers, RCCL p2p row reduction")},
     }
-    for k in ("cut_quadrature_points_per_s", "assemble_matrix_dofs_per_s", "counts", "phases_ms", "kernels",
-              "roofline", "roofline_by_kernel"):
+    for k in ("cut_quadrature_points_per_s", "cut_quadrature_points_reference_equivalent", "assemble_matrix_dofs_per_s",
+              "counts", "phases_ms", "setup", "kernels", "roofline", "roofline_by_kernel", "roofline_longest_kernel",
+              "whole_step_roofline"):
         out[k] = m.get(k)
     if rank == 0 and world == 1:
         if not args.no_secondary and n != 128:
             s = measure(128, 20, 3, args.order, 1, 0, device, profile=False)
             out["config_128"] = {"workload": "configs[1]: 128^3 background mesh, same form", "value": s["value"],
                                  "unit": "DOF/s", "ms_per_step": s["ms_per_step"], "active_dofs": s["active_dofs"]}
+        if not args.no_secondary:
+            import gc
+            from cutfemx_amd import _lib as _cl
+            gc.collect(); torch.cuda.empty_cache(); _cl.release_cache()
+            for name, fn in (("config_p2_gyroid_256", secondary_p2_gyroid), ("config_elasticity_share", secondary_elasticity_share)):
+                try:
+                    out[name] = fn(torch, device)
+                except Exception as e:      # (e.g. not enough free HBM): reported, never silently dropped
+                    out[name] = {"error": f"{type(e).__name__}: {e}"}
+                gc.collect(); torch.cuda.empty_cache(); _cl.release_cache()
         if not args.no_secondary:
             # "implicit-structured" variant (report both): on the generated box mesh the
             # classification derives the Kuhn connectivity from the cube index instead of streaming 12.9 GB of it.

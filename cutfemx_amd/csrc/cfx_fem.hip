@@ -898,6 +898,20 @@ int cfx_space_create(cfx_mesh_t mesh, int degree, int bs, int64_t ndofs, const i
   CFX_API_END
 }
 
+int cfx_space_static_bytes(cfx_space_t V, int64_t bytes[4])
+{
+  CFX_API_BEGIN
+  require(V && bytes, CFX_ERR_INVALID_ARGUMENT, "cfx_space_static_bytes: null argument");
+  const bool shared = V->dofmap.p == V->mesh->conn.p && V->ndofs == V->mesh->nnodes;
+  const cfx::Adjacency& adj = shared ? V->mesh->v2c : V->d2c;
+  bytes[0] = adj.built ? 8 * adj.offsets.n + 4 * adj.cells.n : 0;
+  const cfx::Stencil& S = V->stencil;
+  bytes[1] = 8 * S.offsets.n + 4 * S.nbr.n + 4 * S.slot4.n + S.diagpos.n + S.cpos.n;
+  bytes[2] = 8 * S.tile_voff.n + 4 * S.tile_verts.n + 2 * S.st_loc.n;
+  bytes[3] = V->mesh->c2c_built ? 4 * V->mesh->c2c.n : 0;
+  CFX_API_END
+}
+
 int cfx_space_destroy(cfx_space_t V)
 {
   CFX_API_BEGIN

@@ -187,6 +187,12 @@ class FunctionSpace:
                                                C.byref(self._h)))
         self._dofmap_ptr = ptr
 
+    def static_table_bytes(self) -> dict:
+        """HBM held by the mesh-static tables built by the first assembly on this space (cfx_space_static_bytes)."""
+        b = (C.c_int64 * 4)()
+        _lib.check(_lib.lib().cfx_space_static_bytes(self._h, b))
+        return dict(dof_cells=int(b[0]), row_stencil=int(b[1]), row_tiles=int(b[2]), cell_neighbours=int(b[3]))
+
     @property
     def dofmap(self) -> np.ndarray:
         if hasattr(self, "_host_dofmap"):

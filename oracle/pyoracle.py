@@ -59,10 +59,39 @@ def build(force: bool = False) -> Path:
     return so
 
 
+_NATIVE = False
+
+
+def use_native_build():
+    """bench.py's cpu_baseline leg: the same C restatement built `-O3 -march=native` ON THE MACHINE THAT RUNS IT
+    (BASELINE.md 3), into oracle/_build/ (never shipped: a -march=native object of another host may not run).
+    -ffp-contract=off and -fno-fast-math stay, so results are those of the portable build.  Must be called
+    before the first use of the library in the process."""
+    global _NATIVE
+    if _LIB is not None and not _NATIVE:
+        raise RuntimeError("the portable oracle library is already loaded")
+    _NATIVE = True
+
+
+def _build_native() -> Path:
+    out = _HERE / "_build"
+    out.mkdir(exist_ok=True)
+    so = out / "liboracle_native.so"
+    src = _HERE / "cfx_oracle.c"
+    if so.exists() and so.stat().st_mtime >= src.stat().st_mtime:
+        return so                      # (built by the parent process of bench.py's all-cores leg)
+    import os
+    tmp = out / f"liboracle_native.{os.getpid()}.tmp"
+    subprocess.run(["gcc", "-O3", "-march=native", "-std=c11", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-shared",
+                    "-o", str(tmp), str(src), "-lm"], check=True)
+    os.replace(tmp, so)                # atomic: concurrent builders never see a partial file
+    return so
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(str(build()))
+        _LIB = C.CDLL(str(_build_native() if _NATIVE else build()))
         _LIB.orc_locate_entities.restype = C.c_int64
         _LIB.orc_ghost_penalty_facets.restype = C.c_int64
         _LIB.orc_interior_facets_for_cells.restype = C.c_int64

@@ -54,6 +54,21 @@ class AggregationView(C.Structure):
                 ("pairs", C.c_void_p), ("n_pairs", C.c_int64)]
 
 
+class DistExchange(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_int32), ("send_offset", C.c_int64), ("send_count", C.c_int64),
+                ("send_index", C.c_void_p), ("recv_offset", C.c_int64), ("recv_count", C.c_int64),
+                ("recv_index", C.c_void_p)]
+
+
+class DistRowExchange(C.Structure):
+    _fields_ = [("peer", C.c_int32), ("reserved", C.c_int32), ("send_row_lo", C.c_int64), ("send_row_hi", C.c_int64),
+                ("recv_row_lo", C.c_int64), ("recv_row_hi", C.c_int64)]
+
+
+HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_void_p),
+                               C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
 class PatternView(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("nnz", C.c_int64), ("indptr", C.c_void_p),
                 ("indices", C.c_void_p)]
@@ -76,6 +91,9 @@ SYMBOLS = [
     "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_matrix_zeroed", "cfx_assemble_vector",
     "cfx_apply_lifting", "cfx_set_bc", "cfx_zero_rows", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
     "cfx_active_destroy",
+    "cfx_dist_unique_id", "cfx_dist_comm_create", "cfx_dist_comm_create_host", "cfx_dist_comm_info", "cfx_dist_comm_destroy",
+    "cfx_dist_scatter_forward", "cfx_dist_scatter_reverse_add", "cfx_dist_scatter_reverse_matrix", "cfx_dist_indicator_or",
+    "cfx_dist_indicator_forward",
 ]
 
 _lib = None

@@ -84,6 +84,122 @@ def _zero(t):
     _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(t.data_ptr()), 0, C.c_size_t(t.element_size() * t.numel())))
 
 
+class DistComm:
+    """cfx_comm_t of this rank: RCCL over xGMI when torch.distributed runs on the nccl backend (the 128-byte
+    ncclUniqueId made by rank 0 travels through torch.distributed, which is only the launcher's side channel
+    here), else the library's host-staged mode with a callback that moves the bytes through torch.distributed
+    (gloo): what a one-GPU box can run with several ranks.  Data-path exchanges then go through
+    cfx_dist_scatter_forward / cfx_dist_scatter_reverse_add / cfx_dist_scatter_reverse_matrix."""
+
+    def __init__(self, group=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        from . import _lib
+        self._lib, self.group = _lib, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self._h = C.c_void_p()
+        l = _lib.lib()
+        self.rccl = dist.get_backend(group) == "nccl"
+        if self.rccl:
+            buf = (C.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(l.cfx_dist_unique_id(buf))
+            obj = [bytes(buf)]
+            dist.broadcast_object_list(obj, src=0, group=group)
+            uid = (C.c_char * 128).from_buffer_copy(obj[0])
+            _lib.check(l.cfx_dist_comm_create(self.world, self.rank, uid, C.byref(self._h)))
+        else:
+            def exchange(_user, n, peers, send, send_bytes, recv, recv_bytes):
+                try:
+                    ops, keep = [], []
+                    for i in range(n):
+                        if send_bytes[i] > 0:
+                            src = (C.c_uint8 * send_bytes[i]).from_address(send[i])
+                            t = torch.frombuffer(src, dtype=torch.uint8).clone()
+                            keep.append(t)
+                            ops.append(dist.P2POp(dist.isend, t, int(peers[i]), group))
+                        if recv_bytes[i] > 0:
+                            t = torch.empty(recv_bytes[i], dtype=torch.uint8)
+                            keep.append((t, recv[i], recv_bytes[i]))
+                            ops.append(dist.P2POp(dist.irecv, t, int(peers[i]), group))
+                    if ops:
+                        for req in dist.batch_isend_irecv(ops):
+                            req.wait()
+                    for k in keep:
+                        if isinstance(k, tuple):
+                            C.memmove(k[1], k[0].data_ptr(), k[2])
+                    return 0
+                except Exception:        # (an exception must not cross the C frame)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            self._cb = _lib.HOST_EXCHANGE_FN(exchange)      # kept alive with the communicator
+            _lib.check(l.cfx_dist_comm_create_host(self.world, self.rank, self._cb, None, C.byref(self._h)))
+
+    def _exchanges(self, triples):
+        """[(peer, (send_lo, send_hi), (recv_lo, recv_hi)), ...] -> cfx_dist_exchange array (contiguous ranges)"""
+        arr = (self._lib.DistExchange * max(len(triples), 1))()
+        self._keep = []
+        for i, (peer, snd, rcv) in enumerate(triples):
+            arr[i].peer = peer
+            for side, part in (("send", snd), ("recv", rcv)):
+                if isinstance(part, tuple):                      # contiguous range [lo, hi)
+                    setattr(arr[i], side + "_offset", part[0])
+                    setattr(arr[i], side + "_count", part[1] - part[0])
+                else:                                            # int32 index list in HBM (an index map's shared / ghost list)
+                    assert part.is_cuda and part.dtype == self._torch_int32() and part.is_contiguous()
+                    self._keep.append(part)
+                    setattr(arr[i], side + "_index", part.data_ptr())
+                    setattr(arr[i], side + "_count", part.numel())
+        return arr
+
+    @staticmethod
+    def _torch_int32():
+        import torch
+        return torch.int32
+
+    def scatter_forward(self, x, triples):
+        import ctypes as C
+        self._lib.check(self._lib.lib().cfx_dist_scatter_forward(self._h, C.c_void_p(x.data_ptr()), len(triples),
+                                                                 self._exchanges(triples)))
+
+    def scatter_reverse_add(self, x, triples):
+        import ctypes as C
+        self._lib.check(self._lib.lib().cfx_dist_scatter_reverse_add(self._h, C.c_void_p(x.data_ptr()), len(triples),
+                                                                     self._exchanges(triples)))
+
+    def scatter_reverse_matrix(self, A, triples):
+        """rows (send_lo, send_hi) of this rank's matrix are added to rows (recv_lo, recv_hi) of the peer's"""
+        import ctypes as C
+        arr = (self._lib.DistRowExchange * max(len(triples), 1))()
+        for i, (peer, (s0, s1), (r0, r1)) in enumerate(triples):
+            arr[i].peer, arr[i].send_row_lo, arr[i].send_row_hi, arr[i].recv_row_lo, arr[i].recv_row_hi = peer, s0, s1, r0, r1
+        self._lib.check(self._lib.lib().cfx_dist_scatter_reverse_matrix(self._h, A._p, C.c_void_p(A.values_ptr),
+                                                                        len(triples), arr))
+
+    def indicator_or(self, ind, triples, forward_triples=None):
+        import ctypes as C
+        l = self._lib.lib()
+        self._lib.check(l.cfx_dist_indicator_or(self._h, C.c_void_p(ind.data_ptr()), len(triples), self._exchanges(triples)))
+        if forward_triples is not None:
+            self._lib.check(l.cfx_dist_indicator_forward(self._h, C.c_void_p(ind.data_ptr()), len(forward_triples),
+                                                         self._exchanges(forward_triples)))
+
+    def close(self):
+        if self._h:
+            self._lib.load().cfx_dist_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass
 class SlabPartition:
     n: int
@@ -148,13 +264,28 @@ class SlabPartition:
         return out
 
 
-def halo_forward(phi, part: SlabPartition, group=None):
+def halo_forward(phi, part: SlabPartition, group=None, comm: DistComm | None = None):
     """Fill the halo vertex planes of the level-set vector from their owners
     (`phi.x.scatter_forward()`): planes lz0..z0 come from the rank below, planes
-    z1+1..lz1 from the rank above; planes are contiguous slices."""
+    z1+1..lz1 from the rank above; planes are contiguous slices.
+    An array in HBM goes through the C ABI (cfx_dist_scatter_forward on `comm`); a host tensor -- the CPU tests,
+    where the oracle stands in for the engine -- through torch.distributed directly."""
     import torch
     import torch.distributed as dist
-    stage = phi.is_cuda and dist.get_backend(group) == "gloo"
+    if phi.is_cuda:
+        if comm is None:
+            raise ValueError("halo_forward of a device array needs the rank's DistComm")
+        ps, tri = part.plane_size, []
+        sl = lambda g0, g1: (ps * (g0 - part.lz0), ps * (g1 + 1 - part.lz0))   # global planes [g0, g1] -> local range
+        if part.rank > 0:
+            assert part.lz0 > part.bounds[part.rank - 1], "slab thinner than the halo of its neighbour"
+            tri.append((part.rank - 1, sl(part.z0 + 1, min(part.z0 + 2, part.n)), sl(part.lz0, part.z0)))
+        if part.rank < part.world - 1:
+            assert part.z1 - 1 > part.z0 or part.rank == 0, "slab thinner than the halo of its neighbour"
+            tri.append((part.rank + 1, sl(part.z1 - 1, part.z1), sl(part.z1 + 1, part.lz1)))
+        comm.scatter_forward(phi, tri)
+        return phi
+    stage = False
     ps = part.plane_size
     ops, recvs = [], []
 
@@ -199,8 +330,9 @@ def scatter_reverse(values, row_ptr, part: SlabPartition, group=None):
     """
     import torch
     import torch.distributed as dist
-    # gloo (CPU rehearsal of the GPU path) moves device slices through the host
-    stage = values.is_cuda and dist.get_backend(group) == "gloo"
+    if values.is_cuda:
+        raise ValueError("device arrays are reduced through DistComm.scatter_reverse_add / scatter_reverse_matrix")
+    stage = False
     ops, recvs = [], []
     for peer, send_plane, recv_plane in part.exchanges():
         s_lo, s_hi = part.plane_rows(send_plane)
@@ -248,6 +380,7 @@ class DistributedPoisson:
         if mode not in ("owner", "reduce"):
             raise ValueError("mode must be 'owner' or 'reduce'")
         self.mode = mode
+        self.comm = DistComm() if part.world > 1 else None
         self.mesh = cfx.Mesh.create_slab(part.n, part.lz0, part.nz_local)
         self.V = cfx.FunctionSpace(self.mesh, 1)
         n = part.n
@@ -289,7 +422,7 @@ class DistributedPoisson:
                 self.phi_values[: ps * (part.z0 + 1 - part.lz0)] = float("nan")
             if part.rank < part.world - 1:
                 self.phi_values[ps * (part.z1 + 1 - part.lz0):] = float("nan")
-            halo_forward(self.phi_values, part)
+            halo_forward(self.phi_values, part, comm=self.comm)
         cd = cfx.cut(self.phi)
         system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
         _zero(self.b)
@@ -366,12 +499,9 @@ class DistributedPoisson:
         fem.assemble_vector(L_own, self.b)
         # --- A.scatter_reverse(); b.scatter_reverse(add)
         if part.world > 1:
-            indptr = as_torch(A._view.indptr, A.nrows + 1, "int64", dev)
-            planes = sorted({p for _, s, r in part.exchanges() for p in (s, r)})
-            bounds = sorted({b for p in planes for b in part.plane_rows(p)})
-            lut = dict(zip(bounds, indptr[torch.tensor(bounds, device=dev)].tolist()))
-            scatter_reverse(self.values, lambda row: lut[row], part)
-            scatter_reverse(self.b, None, part)
+            tri = [(peer, part.plane_rows(sp), part.plane_rows(rp)) for peer, sp, rp in part.exchanges()]
+            self.comm.scatter_reverse_matrix(A, tri)      # cfx_dist_scatter_reverse_matrix
+            self.comm.scatter_reverse_add(self.b, tri)    # cfx_dist_scatter_reverse_add
         dom = fem.deactivate_outside(A, self.b, fem.active_domain(a_all))
         r_lo, r_hi = part.owned_rows
         inactive = as_torch(dom._id, dom._ni, "int32", dev)

@@ -16,7 +16,9 @@
  *   - the caller keeps ownership of inputs; a handle that was given a DEVICE
  *     pointer aliases it (zero copy) and the caller must keep it alive;
  *   - calls on one device are issued on one HIP stream (cfx_set_stream) and
- *     are not thread-safe.
+ *     are not thread-safe;
+ *   - one process drives one GPU; several GPUs = several processes joined by a
+ *     cfx_comm_t (cfx_dist_*, at the end of this header).
  * Scalar/geometry type: float64/float64 (north_star); other instantiations of
  * python/cutfemx/wrappers/fem.cpp:490-500 are not provided.
  */
@@ -360,6 +362,61 @@ int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_act
 int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t pattern, double* values,
                            double* b /* or NULL */, double diagonal, double rhs_value);
 int cfx_active_destroy(cfx_active_t d);
+
+/* ---- multi-GPU exchange steps (one rank per GPU; RCCL send/recv over xGMI between the ranks that share dofs) ----
+ * The reference's collectives on this path (DOLFINx index maps, MPI neighbourhood exchanges):
+ *   phi.x.scatter_forward()                      python/demo/demo_poisson.py:157       -> cfx_dist_scatter_forward
+ *   A.scatter_reverse(); b.scatter_reverse(add)  python/demo/demo_poisson.py:51-54     -> cfx_dist_scatter_reverse_matrix / _add
+ *   indicator.scatter_rev(plus) + scatter_fwd    cpp/cutfemx/fem/deactivate.h:180-181  -> cfx_dist_indicator_or + _forward
+ * A communicator is either RCCL (cfx_dist_unique_id on one rank, the 128 bytes handed to all ranks by the launcher's
+ * own channel -- MPI_Bcast, torch.distributed, a file -- then cfx_dist_comm_create on every rank after cfx_init on its
+ * GPU; librccl.so.1 is loaded on first use) or host-staged (cfx_dist_comm_create_host: the library moves the slices
+ * through pinned host memory and the caller's callback -- MPI_Sendrecv, gloo -- moves the bytes). */
+typedef struct cfx_comm_s* cfx_comm_t;
+#define CFX_DIST_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+/* n messages out and n in: to / from peers[i], send[i] / recv[i] are host buffers of send_bytes[i] / recv_bytes[i] bytes
+ * (either may be 0); returns 0 on success.  All n exchanges may be posted together (they do not depend on each other). */
+typedef int (*cfx_host_exchange_fn)(void* user, int n, const int32_t* peers, const void* const* send,
+                                    const int64_t* send_bytes, void* const* recv, const int64_t* recv_bytes);
+int cfx_dist_unique_id(char id[CFX_DIST_ID_BYTES]);
+int cfx_dist_comm_create(int world, int rank, const char id[CFX_DIST_ID_BYTES], cfx_comm_t* out);
+int cfx_dist_comm_create_host(int world, int rank, cfx_host_exchange_fn fn, void* user, cfx_comm_t* out);
+int cfx_dist_comm_info(cfx_comm_t comm, int* world, int* rank, int* is_rccl);
+int cfx_dist_comm_destroy(cfx_comm_t comm);
+/* What this rank sends to and receives from one peer in one exchange step, in elements of the array: a contiguous
+ * range (offset, count) -- a vertex plane of a slab partition, sent in place -- or, when the index pointer is set, the
+ * `count` entries listed by a DEVICE int32 index list (the shared / ghost index lists of an index map; packed and
+ * unpacked by a kernel; duplicate-free).  The peer's send count must equal this rank's receive count. */
+typedef struct
+{
+  int32_t peer;
+  int32_t reserved;
+  int64_t send_offset, send_count;
+  const int32_t* send_index; /* or NULL */
+  int64_t recv_offset, recv_count;
+  const int32_t* recv_index; /* or NULL */
+} cfx_dist_exchange;
+/* x[recv] = the peer's x[send]: la::Vector::scatter_forward (owners send, ghosts receive) */
+int cfx_dist_scatter_forward(cfx_comm_t comm, double* x, int n, const cfx_dist_exchange* ex);
+/* x[recv] += the peer's x[send]: la::Vector::scatter_reverse(add) (ghost contributions go to the owners); also serves
+ * CSR value arrays when the caller has the value offsets at hand */
+int cfx_dist_scatter_reverse_add(cfx_comm_t comm, double* x, int n, const cfx_dist_exchange* ex);
+/* la::MatrixCSR::scatter_reverse for row blocks: rows [send_row_lo, send_row_hi) of this rank's pattern are added to
+ * rows [recv_row_lo, recv_row_hi) of the peer's -- the same global rows under the two local numberings, built from the
+ * same entities on both ranks so that they hold the same columns in the same order (DOLFINx keeps the sparsity of
+ * ghost rows on both sides); the slices of the value array are exchanged without packing and their lengths compared. */
+typedef struct
+{
+  int32_t peer;
+  int32_t reserved;
+  int64_t send_row_lo, send_row_hi;
+  int64_t recv_row_lo, recv_row_hi;
+} cfx_dist_row_exchange;
+int cfx_dist_scatter_reverse_matrix(cfx_comm_t comm, cfx_pattern_t pattern, double* values, int n,
+                                    const cfx_dist_row_exchange* ex);
+/* 0/1 indicators (int8): indicator[recv] |= the peer's indicator[send], then the owners' values back to the ghosts */
+int cfx_dist_indicator_or(cfx_comm_t comm, int8_t* indicator, int n, const cfx_dist_exchange* ex);
+int cfx_dist_indicator_forward(cfx_comm_t comm, int8_t* indicator, int n, const cfx_dist_exchange* ex);
 
 #ifdef __cplusplus
 }

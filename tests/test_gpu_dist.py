@@ -80,3 +80,90 @@ def test_two_ranks_on_one_gpu_match_serial(oracle, mode):
         assert inactive_ok
         total_active += active
     assert total_active == gm.nnodes - gref["inactive"].size
+
+
+def _prim_worker(rank, world, port, q):
+    """cfx_dist_* primitives between two ranks on one card (host-staged transport): contiguous ranges and index
+    lists, copy / add / or, and the matrix row exchange with its size check."""
+    sys.path.insert(0, str(ROOT))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFX_DEVICE="0")
+    import torch
+    import torch.distributed as dist
+
+    from cutfemx_amd.dist import DistComm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda", 0)
+        comm = DistComm()
+        assert not comm.rccl and comm.world == 2
+        peer = 1 - rank
+        ok = True
+        # scatter_forward, contiguous: my tail [90, 100) <- the peer's head [0, 10)
+        x = torch.arange(100, device=dev, dtype=torch.float64) + 1000.0 * rank
+        comm.scatter_forward(x, [(peer, (0, 10), (90, 100))])
+        ok &= bool(torch.equal(x[90:], torch.arange(10, device=dev, dtype=torch.float64) + 1000.0 * peer))
+        ok &= bool(torch.equal(x[:90], torch.arange(90, device=dev, dtype=torch.float64) + 1000.0 * rank))
+        # scatter_reverse_add through index lists (an index map's ghost -> owner lists)
+        y = torch.ones(50, device=dev, dtype=torch.float64) * (rank + 1)
+        send_idx = torch.tensor([49, 3, 17, 20], device=dev, dtype=torch.int32)
+        recv_idx = torch.tensor([0, 5, 6, 30], device=dev, dtype=torch.int32)
+        comm.scatter_reverse_add(y, [(peer, send_idx, recv_idx)])
+        want = torch.ones(50, device=dev, dtype=torch.float64) * (rank + 1)
+        want[recv_idx.long()] += float(peer + 1)
+        ok &= bool(torch.equal(y, want))
+        # indicator: reverse OR into the owner's entries, then forward back to the ghosts
+        ind = torch.zeros(20, device=dev, dtype=torch.int8)
+        ind[2 + rank] = 1                      # rank 0 marks entry 2, rank 1 marks entry 3
+        comm.indicator_or(ind, [(peer, (0, 10), (0, 10))], forward_triples=[(peer, (0, 10), (10, 20))])
+        ok &= bool(ind[2] == 1 and ind[3] == 1 and int(ind[:10].sum()) == 2)
+        ok &= bool(torch.equal(ind[10:], ind[:10]))    # both ranks hold the same OR-ed values
+        # unequal counts are refused by the library (CFX_ERR_INVALID_ARGUMENT for a bad peer)
+        try:
+            comm.scatter_forward(x, [(rank, (0, 1), (1, 2))])
+            ok = False
+        except ValueError:
+            pass
+        comm.close()
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dist_primitives_two_ranks_host_staged():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_prim_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
+
+
+def test_rccl_communicator_single_rank():
+    """The RCCL branch as far as one GPU allows: librccl.so.1 resolves at run time, ncclGetUniqueId /
+    ncclCommInitRank / ncclCommDestroy work through the C ABI (world size 1: no peer to exchange with)."""
+    import ctypes as C
+
+    from cutfemx_amd import _lib
+    l = _lib.lib()
+    uid = (C.c_char * 128)()
+    _lib.check(l.cfx_dist_unique_id(uid))
+    assert any(bytes(uid))
+    h = C.c_void_p()
+    _lib.check(l.cfx_dist_comm_create(1, 0, uid, C.byref(h)))
+    w, r, k = C.c_int(), C.c_int(), C.c_int()
+    _lib.check(l.cfx_dist_comm_info(h, C.byref(w), C.byref(r), C.byref(k)))
+    assert (w.value, r.value, k.value) == (1, 0, 1)
+    # an exchange that names this rank itself as the peer is refused
+    import torch
+    x = torch.zeros(4, device="cuda", dtype=torch.float64)
+    ex = (_lib.DistExchange * 1)()
+    ex[0].peer, ex[0].send_count, ex[0].recv_count = 0, 1, 1
+    assert l.cfx_dist_scatter_forward(h, C.c_void_p(x.data_ptr()), 1, ex) == _lib.ERR_INVALID_ARGUMENT
+    _lib.check(l.cfx_dist_scatter_forward(h, C.c_void_p(x.data_ptr()), 0, None))
+    _lib.check(l.cfx_dist_comm_destroy(h))

@@ -436,6 +436,272 @@ __device__ __forceinline__ const double* ref_points(int dim, int degree, int& n,
   return cfx_quad_points_3d + 3 * cfx_quad_offset_3d[degree];
 }
 
+// ---------------------------------------------------------------------------
+// a3 with several level sets: runtime_quadrature(cut([phi, phi1, ...]), "phi<0 and phi1>0", k)
+// (cpp/cutfemx/cut/cut.h:122-181, docs/user-guide/element-classification.md:145-160).  One conjunction of
+// clauses; each P1 level set is planar inside a cell, so the cell's part of the region is the parent simplex
+// clipped by one half-space per clause, in the order the clauses are written: every simplex of the current list
+// is sub-triangulated with the single-level-set case tables (phi_k interpolated at its vertices) and its negative
+// ("<") or positive (">") part kept.  With an "=0" clause the list starts from that level set's
+// interface sub-facets and the other clauses clip them.  One thread per rule cell, the simplex lists in
+// private memory: a few thousand cells along the curves / surfaces where two level sets meet, not a hot path.
+// ---------------------------------------------------------------------------
+constexpr int kMultiMaxClauses = 4; // clauses of a conjunction (at most 3 of them clip)
+constexpr int kMultiMaxSimp = 27;   // 3 clips of 3 sub-simplices each
+
+struct MultiArgs
+{
+  int64_t n;                  // rule cells
+  const int32_t* cells;
+  const double* x;
+  const int32_t* conn;
+  const int32_t* ls_dofmap;
+  const double* phi[kMultiMaxClauses]; // dof values of the clause's level set
+  int ncl, eq;                // eq: index of the "=0" clause or -1
+  int mask[kMultiMaxClauses];
+  int order;
+  int64_t* packed;            // count pass: (points | rules << kPackShift) per cell
+  const int64_t* packed_off;  // emit pass
+  double* points;
+  double* weights;
+  int32_t* offsets;
+  int32_t* parent_map;
+};
+
+struct MultiRuleCell
+{
+  const int8_t* domain;
+  int64_t ncells;
+  int ncl;
+  int ls[kMultiMaxClauses], mask[kMultiMaxClauses];
+  __device__ bool operator()(int64_t c) const
+  {
+    bool ok = true, any_cut = false;
+    for (int k = 0; k < ncl; ++k)
+    {
+      const int d = domain[(int64_t)ls[k] * ncells + c];
+      if (d == CFX_INTERSECTED) any_cut = true;
+      else if (d == CFX_NOT_CANDIDATE || mask[k] == 2 || !((mask[k] >> (d + 1)) & 1)) ok = false;
+    }
+    return ok && any_cut;
+  }
+};
+
+template <int TDIM>
+struct MSimp
+{
+  double V[TDIM + 1][TDIM]; // vertices in parent reference coordinates (DIM + 1 of them used)
+};
+
+// the psi < 0 part (keep_out false) or the psi > 0 part (keep_out: the "out" simplices of the same case, so that a
+// ">" clause triangulates exactly like the single-level-set "phi>0" rules) of simplex `in` (dimension DIM),
+// appended to out[m...]; returns the new m
+template <int TDIM, int DIM>
+__device__ int multi_clip_one(const MSimp<TDIM>& in, const double* psi, bool keep_out, MSimp<TDIM>* out, int m)
+{
+  if constexpr (DIM == 1)
+  {
+    const bool n0 = psi[0] < 0.0, n1 = psi[1] < 0.0;
+    if (n0 == n1)
+    {
+      if (n0 != keep_out) { out[m] = in; return m + 1; } // wholly on the kept side
+      return m;
+    }
+    // a = the negative end, b = the other; cut point q; negative part (a, q), positive part (q, b)
+    const int a = n0 ? 0 : 1, b = 1 - a;
+    const double t = psi[a] / (psi[a] - psi[b]);
+    const double La = (a == 1) ? 1.0 : 0.0, Lb = (b == 1) ? 1.0 : 0.0; // local coordinate of the two ends
+    const double Lq = La + t * (Lb - La);
+    const double L0 = keep_out ? Lq : La, L1 = keep_out ? Lb : Lq;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      out[m].V[0][d] = in.V[0][d] + L0 * (in.V[1][d] - in.V[0][d]);
+      out[m].V[1][d] = in.V[0][d] + L1 * (in.V[1][d] - in.V[0][d]);
+    }
+    return m + 1;
+  }
+  else
+  {
+    int sm = 0;
+#pragma unroll
+    for (int v = 0; v <= DIM; ++v) sm |= (psi[v] < 0.0) ? (1 << v) : 0;
+    if (sm == (keep_out ? 0 : (1 << (DIM + 1)) - 1)) { out[m] = in; return m + 1; } // wholly on the kept side: unchanged
+    const CutCase& cs = c_cases[DIM - 2][sm];
+    const int ns = keep_out ? cs.n_out : cs.n_in;
+    for (int k = 0; k < ns; ++k)
+    {
+      for (int v = 0; v <= DIM; ++v)
+      {
+        double L[DIM];
+        local_point<DIM>(cs, keep_out ? cs.out[k][v] : cs.in[k][v], psi, L); // the sub-simplex vertex in the coordinates of `in`
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double xx = in.V[0][d];
+#pragma unroll
+          for (int t = 0; t < DIM; ++t) xx += L[t] * (in.V[t + 1][d] - in.V[0][d]);
+          out[m].V[v][d] = xx;
+        }
+      }
+      ++m;
+    }
+    return m;
+  }
+}
+
+template <int TDIM>
+__device__ __forceinline__ double multi_phi_at(const double* phi, const double* X)
+{
+  double l0 = 1.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) l0 -= X[t];
+  double v = l0 * phi[0];
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) v += X[t] * phi[t + 1];
+  return v;
+}
+
+// DIM = TDIM: volume rules; DIM = TDIM - 1: rules on the interface of clause A.eq
+template <int TDIM, int DIM, bool EMIT>
+__global__ void __launch_bounds__(kBlock) multi_rules_kernel(MultiArgs A)
+{
+  constexpr int NV = TDIM + 1;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.n) return;
+  const int64_t c = A.cells[i];
+  double phi[kMultiMaxClauses][NV];
+  for (int k = 0; k < A.ncl; ++k)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) phi[k][v] = A.phi[k][A.ls_dofmap[c * NV + v]];
+  // base list: the parent simplex, or the interface sub-facets of the "=0" level set
+  MSimp<TDIM> base[2];
+  int nbase = 1;
+  if constexpr (DIM == TDIM)
+  {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) base[0].V[v][d] = (v == d + 1) ? 1.0 : 0.0;
+  }
+  else
+  {
+    const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi[A.eq])];
+    nbase = cs.n_if;
+    for (int f = 0; f < nbase; ++f)
+      for (int v = 0; v < TDIM; ++v) local_point<TDIM>(cs, cs.iface[f][v], phi[A.eq], base[f].V[v]);
+  }
+  int nref;
+  const double* wref;
+  const double* pref = ref_points<TDIM>(DIM, A.order, nref, wref);
+  Geo<TDIM> g;
+  int64_t pq = 0, pr = 0;
+  if constexpr (EMIT)
+  {
+    load_cell<TDIM>(A.x, A.conn, c, g);
+    jacobian<TDIM>(g);
+    const int64_t po = A.packed_off[i];
+    pq = po & kPackMask; pr = po >> kPackShift;
+  }
+  int total_pts = 0, total_rules = 0;
+  const int ngroups = DIM == TDIM ? 1 : nbase;
+  MSimp<TDIM> la[kMultiMaxSimp], lb[kMultiMaxSimp];
+  for (int gi = 0; gi < ngroups; ++gi)
+  {
+    MSimp<TDIM>* cur = la;
+    MSimp<TDIM>* nxt = lb;
+    int n = 1;
+    cur[0] = base[gi];
+    for (int k = 0; k < A.ncl && n > 0; ++k)
+    {
+      if (k == A.eq) continue;
+      const bool keep_out = !(A.mask[k] & 1);
+      int m = 0;
+      for (int q = 0; q < n; ++q)
+      {
+        double psi[DIM + 1];
+#pragma unroll
+        for (int v = 0; v <= DIM; ++v) psi[v] = multi_phi_at<TDIM>(phi[k], cur[q].V[v]);
+        m = multi_clip_one<TDIM, DIM>(cur[q], psi, keep_out, nxt, m);
+      }
+      n = m;
+      MSimp<TDIM>* t = cur; cur = nxt; nxt = t;
+    }
+    if (n == 0) continue;
+    total_rules += 1;
+    total_pts += n * nref;
+    if constexpr (EMIT)
+    {
+      for (int q = 0; q < n; ++q)
+      {
+        double scale;
+        if constexpr (DIM == TDIM)
+        {
+          double e[TDIM][TDIM];
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t)
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d) e[t][d] = cur[q].V[t + 1][d] - cur[q].V[0][d];
+          double det;
+          if constexpr (TDIM == 2) det = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+          else
+            det = e[0][0] * (e[1][1] * e[2][2] - e[1][2] * e[2][1]) - e[0][1] * (e[1][0] * e[2][2] - e[1][2] * e[2][0])
+                  + e[0][2] * (e[1][0] * e[2][1] - e[1][1] * e[2][0]);
+          scale = fabs(det) * fabs(g.detJ);
+        }
+        else
+        {
+          // physical vertices of the piece: x_0 + J X, J[d][t] = x_{t+1,d} - x_{0,d}
+          double xp[TDIM][TDIM];
+#pragma unroll
+          for (int v = 0; v < TDIM; ++v)
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d)
+            {
+              double xx = g.x[0][d];
+#pragma unroll
+              for (int t = 0; t < TDIM; ++t) xx += (g.x[t + 1][d] - g.x[0][d]) * cur[q].V[v][t];
+              xp[v][d] = xx;
+            }
+          if constexpr (TDIM == 2)
+          {
+            const double dx = xp[1][0] - xp[0][0], dy = xp[1][1] - xp[0][1];
+            scale = sqrt(dx * dx + dy * dy);
+          }
+          else
+          {
+            double a[3], b[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { a[d] = xp[1][d] - xp[0][d]; b[d] = xp[2][d] - xp[0][d]; }
+            const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+            scale = sqrt(cx * cx + cy * cy + cz * cz);
+          }
+        }
+        for (int r = 0; r < nref; ++r)
+        {
+          double l0 = 1.0;
+#pragma unroll
+          for (int t = 0; t < DIM; ++t) l0 -= pref[r * DIM + t];
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+          {
+            double v = l0 * cur[q].V[0][d];
+#pragma unroll
+            for (int t = 0; t < DIM; ++t) v += pref[r * DIM + t] * cur[q].V[t + 1][d];
+            A.points[(pq + r) * TDIM + d] = v;
+          }
+          A.weights[pq + r] = wref[r] * scale;
+        }
+        pq += nref;
+      }
+      A.parent_map[pr] = (int32_t)c;
+      A.offsets[pr + 1] = (int32_t)pq;
+      ++pr;
+    }
+  }
+  if constexpr (!EMIT) A.packed[i] = (int64_t)total_pts | ((int64_t)total_rules << kPackShift);
+}
+
 #ifndef CFX_EMIT_LANES
 #define CFX_EMIT_LANES 4
 #endif
@@ -1794,6 +2060,77 @@ int cfx_locate_entities(cfx_cut_t cut, const char* selector, const int32_t** ent
   CFX_API_END
 }
 
+} // extern "C"
+
+namespace
+{
+void multi_runtime_quadrature(cfx_cut_t cut, const Selector& sel, int order, cfx_rules_t* out)
+{
+  cfx_mesh_t mesh = cut->mesh;
+  const int tdim = mesh->tdim;
+  require(sel.term[sel.n - 1] == 0, CFX_ERR_INVALID_ARGUMENT,
+          "runtime quadrature over several level sets takes one conjunction (clauses joined by 'and')");
+  require(sel.n <= kMultiMaxClauses, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature: too many clauses in the selector");
+  MultiArgs A{};
+  MultiRuleCell pred{cut->domain.p, mesh->ncells, sel.n, {}, {}};
+  A.eq = -1;
+  int nclip = 0;
+  for (int k = 0; k < sel.n; ++k)
+  {
+    require(sel.mask[k] != 7 && sel.mask[k] != 5, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature: unsupported relation");
+    if (sel.mask[k] == 2)
+    {
+      require(A.eq < 0, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature: at most one '=0' clause (a codimension-1 interface)");
+      A.eq = k;
+    }
+    else ++nclip;
+    A.mask[k] = sel.mask[k]; A.phi[k] = cut->ls_values[sel.ls[k]].p;
+    pred.ls[k] = sel.ls[k]; pred.mask[k] = sel.mask[k];
+  }
+  require(nclip <= 3, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature: at most three clipping clauses per conjunction");
+  A.ncl = sel.n; A.order = order;
+  DevArray<int32_t> cells;
+  A.n = compact("multi_rule_cells", mesh->ncells, pred, cells);
+  A.cells = cells.p; A.x = mesh->x.p; A.conn = mesh->conn.p; A.ls_dofmap = cut->ls_dofmap.p;
+  auto r = std::make_unique<cfx_rules_s>();
+  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim;
+  DevArray<int64_t> packed(A.n), packed_off(A.n + 1);
+  A.packed = packed.p;
+  const bool iface = A.eq >= 0;
+  auto run = [&](bool emit)
+  {
+    if (A.n == 0) return;
+    const dim3 grid = grid_for(A.n);
+#define CFX_MULTI(T, D)                                                                                   \
+  do                                                                                                      \
+  {                                                                                                       \
+    if (emit) launch("multi_rules_emit", multi_rules_kernel<T, D, true>, grid, dim3(kBlock), 0, A);       \
+    else launch("multi_rules_count", multi_rules_kernel<T, D, false>, grid, dim3(kBlock), 0, A);          \
+  } while (0)
+    if (tdim == 2) { if (iface) CFX_MULTI(2, 1); else CFX_MULTI(2, 2); }
+    else { if (iface) CFX_MULTI(3, 2); else CFX_MULTI(3, 3); }
+#undef CFX_MULTI
+  };
+  ensure_cases();
+  run(false);
+  require(A.n < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
+  exclusive_scan(packed.p, packed_off.p, A.n);
+  const int64_t totals = read_scalar(packed_off.p + A.n);
+  const int64_t nq = totals & kPackMask, nr = totals >> kPackShift;
+  require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
+  r->nq = nq; r->nr = nr;
+  r->points.alloc(nq * tdim); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);
+  dev_fill(r->offsets.p, 0, sizeof(int32_t));
+  A.packed_off = packed_off.p; A.points = r->points.p; A.weights = r->weights.p; A.offsets = r->offsets.p;
+  A.parent_map = r->parent_map.p;
+  run(true);
+  CFX_HIP(hipStreamSynchronize(ctx().stream)); // (`cells` and the count arrays die with this frame)
+  *out = r.release();
+}
+} // namespace
+
+extern "C" {
+
 int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const char* backend, cfx_rules_t* out)
 {
   CFX_API_BEGIN
@@ -1808,14 +2145,16 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
     facet_runtime_quadrature(cut, selector, order, false, out);
     return CFX_OK;
   }
-  require(cut->nls == 1, CFX_ERR_INVALID_ARGUMENT,
-          "runtime quadrature for several level sets is not implemented");
   cfx_mesh_t mesh = cut->mesh;
   const int tdim = mesh->tdim;
   require(cut->ls_ndofs_cell == tdim + 1, CFX_ERR_INVALID_ARGUMENT,
           "runtime quadrature requires a P1 level set (straight cuts)");
   const Selector sel = parse_selector(selector, cut->nls);
-  require(sel.n == 1, CFX_ERR_INVALID_ARGUMENT, "runtime quadrature expects a single-clause selector");
+  if (cut->nls > 1 || sel.n > 1)
+  {
+    multi_runtime_quadrature(cut, sel, order, out);
+    return CFX_OK;
+  }
   const int m = sel.mask[0];
   const int part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
   const int nref = quad_npoints(part == PART_IF ? tdim - 1 : tdim, order);

@@ -608,6 +608,185 @@ int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
 }
 
 /* ------------------------------------------------------------------------ */
+/* a3 with several level sets: runtime_quadrature(cut([phi, phi1, ...]), "phi<0 and phi1>0", k)             */
+/* (cpp/cutfemx/cut/cut.h:122-181, docs/user-guide/element-classification.md:145-160).  One conjunction of  */
+/* clauses; each P1 level set is planar inside a cell, so the region of the cell is the parent simplex      */
+/* clipped by one half-space per clause, one after the other, in the order the clauses are written: every   */
+/* simplex of the current list is sub-triangulated with the single-level-set tables above (phi_k            */
+/* interpolated at its vertices) and its negative ("<") or positive (">") part kept.  With an "=0" clause   */
+/* the list starts from that level set's interface sub-facets and the other clauses clip them (triangles    */
+/* in 3-D, segments in 2-D).  Rule cells: no clause entirely on the wrong side, at least one level set      */
+/* intersected; one rule per cell (volume) / per interface sub-facet ("=0"), none where the clipped part is */
+/* empty.  Inclusive relations behave like the strict ones, as for one level set                            */
+/* (python/tests/test_cut_api.py::test_cut_api_runtime_quadrature_accepts_inclusive_selector).              */
+/* CutCells' own multi-level-set sub-triangulation is third party and absent: parity unpinned, like a2.     */
+/* ------------------------------------------------------------------------ */
+static double host_measure_fwd(int tdim, double xv[3][3]); /* = host_measure below */
+#define ORC_MAX_CLIP 3   /* clipping clauses per conjunction */
+#define ORC_MAX_SIMP 27  /* 3^ORC_MAX_CLIP sub-simplices */
+typedef struct { double V[4][3]; } simp;
+
+static double phi_at(int tdim, const double* phi, const double* X)
+{
+  double v = phi[0], l0 = 1.0;
+  for (int t = 0; t < tdim; ++t) l0 -= X[t];
+  v = l0 * phi[0];
+  for (int t = 0; t < tdim; ++t) v += X[t] * phi[t + 1];
+  return v;
+}
+
+/* the phi < 0 part (keep_out = 0) or the phi > 0 part (keep_out = 1: the "out" simplices of the same tables, so
+   that a ">" clause triangulates exactly like the single-level-set "phi>0" rules) of every simplex of the list
+   (dimension dim, vertices in parent reference coordinates) */
+static int clip_list(int dim, int tdim, const simp* in, int n, const double* phi, int keep_out, simp* out)
+{
+  int m = 0;
+  for (int i = 0; i < n; ++i)
+  {
+    double psi[4];
+    int nneg = 0;
+    for (int v = 0; v <= dim; ++v) { psi[v] = phi_at(tdim, phi, in[i].V[v]); nneg += psi[v] < 0.0; }
+    if (nneg == (keep_out ? 0 : dim + 1)) { out[m++] = in[i]; continue; } /* wholly on the kept side: unchanged */
+    subtri s;
+    subtriangulate(dim, psi, &s);
+    const int ns = keep_out ? s.n_out : s.n_in;
+    for (int k = 0; k < ns; ++k)
+    {
+      const int* sx = keep_out ? s.out[k] : s.in[k];
+      for (int v = 0; v <= dim; ++v)
+      {
+        const double* L = s.P[sx[v]]; /* the sub-simplex vertex in the coordinates of in[i] */
+        for (int d = 0; d < tdim; ++d)
+        {
+          double x = in[i].V[0][d];
+          for (int t = 0; t < dim; ++t) x += L[t] * (in[i].V[t + 1][d] - in[i].V[0][d]);
+          out[m].V[v][d] = x;
+        }
+      }
+      ++m;
+    }
+  }
+  return m;
+}
+
+int orc_runtime_quadrature_multi(const orc_mesh* mesh, int nls, const int32_t* ls_dofmap,
+                                 const double* const* ls_values, const int8_t* domain,
+                                 const char* selector, int order, orc_rules* out)
+{
+  sel_clause cl[8];
+  const int ncl = parse_selector(selector, nls, cl, 8);
+  if (ncl < 1 || cl[ncl - 1].term != 0) return -1; /* one conjunction */
+  int eq = -1, nclip = 0;
+  for (int k = 0; k < ncl; ++k)
+  {
+    if (cl[k].mask == 2) { if (eq >= 0) return -1; eq = k; }
+    else if (cl[k].mask == 7 || cl[k].mask == 5) return -1;
+    else ++nclip;
+  }
+  if (nclip > ORC_MAX_CLIP) return -1;
+  const int tdim = mesh->tdim, nv = tdim + 1, dim = eq >= 0 ? tdim - 1 : tdim;
+  const int64_t nc = mesh->ncells;
+  int nref; const double *pref, *wref;
+  ref_rule(dim, order, &nref, &pref, &wref);
+  int64_t nr = 0, nq = 0;
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    if (pass == 1)
+    {
+      memset(out, 0, sizeof(*out));
+      out->tdim = tdim; out->nq = nq; out->nr = nr;
+      out->points = (double*)malloc(sizeof(double) * (size_t)(nq * tdim + 1));
+      out->weights = (double*)malloc(sizeof(double) * (size_t)(nq + 1));
+      out->offsets = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+      out->parent_map = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nr + 1));
+      out->offsets[0] = 0;
+      nr = 0; nq = 0;
+    }
+    for (int64_t c = 0; c < nc; ++c)
+    {
+      int ok = 1, any_cut = 0;
+      for (int k = 0; k < ncl; ++k)
+      {
+        const int d = domain[(int64_t)cl[k].ls * nc + c];
+        if (d == ORC_INTERSECTED) any_cut = 1;
+        else if (cl[k].mask == 2 || !((cl[k].mask >> (d + 1)) & 1)) ok = 0;
+      }
+      if (!ok || !any_cut) continue;
+      double phi[8][4];
+      for (int k = 0; k < ncl; ++k)
+        for (int i = 0; i < nv; ++i) phi[k][i] = ls_values[cl[k].ls][ls_dofmap[c * nv + i]];
+      /* base list: the parent simplex, or the interface sub-facets of the "=0" level set */
+      simp base[2], a[ORC_MAX_SIMP], b[ORC_MAX_SIMP];
+      int nbase = 1;
+      if (eq < 0)
+        for (int v = 0; v < nv; ++v) ref_vertex(tdim, v, base[0].V[v]);
+      else
+      {
+        subtri s;
+        subtriangulate(tdim, phi[eq], &s);
+        nbase = s.n_if;
+        for (int f = 0; f < nbase; ++f)
+          for (int v = 0; v < tdim; ++v)
+            for (int d = 0; d < tdim; ++d) base[f].V[v][d] = s.P[s.iface[f][v]][d];
+      }
+      double xc[MAXV][3], J[3][3], K[3][3];
+      cell_coords(mesh, c, xc);
+      const double detJ = fabs(jacobian(tdim, xc, J, K));
+      /* volume rules: one rule for the whole cell; interface rules: one per base sub-facet */
+      const int ngroups = eq < 0 ? 1 : nbase;
+      for (int gidx = 0; gidx < ngroups; ++gidx)
+      {
+        int n = 1;
+        a[0] = base[eq < 0 ? 0 : gidx];
+        simp *cur = a, *nxt = b;
+        for (int k = 0; k < ncl && n > 0; ++k)
+        {
+          if (k == eq) continue;
+          n = clip_list(dim, tdim, cur, n, phi[k], (cl[k].mask & 1) ? 0 : 1, nxt);
+          simp* t = cur; cur = nxt; nxt = t;
+        }
+        if (n == 0) continue;
+        if (pass == 0) { nr += 1; nq += (int64_t)n * nref; continue; }
+        for (int i = 0; i < n; ++i)
+        {
+          double scale;
+          if (dim == tdim) scale = fabs(det_sub(tdim, cur[i].V)) * detJ;
+          else
+          {
+            double xp[3][3];
+            for (int v = 0; v < tdim; ++v)
+              for (int d = 0; d < tdim; ++d)
+              {
+                xp[v][d] = xc[0][d];
+                for (int t = 0; t < tdim; ++t) xp[v][d] += J[d][t] * cur[i].V[v][t];
+              }
+            scale = host_measure_fwd(tdim, xp);
+          }
+          for (int q = 0; q < nref; ++q)
+          {
+            const double* xi = pref + dim * q;
+            double l0 = 1.0;
+            for (int t = 0; t < dim; ++t) l0 -= xi[t];
+            for (int d = 0; d < tdim; ++d)
+            {
+              double v = l0 * cur[i].V[0][d];
+              for (int t = 0; t < dim; ++t) v += xi[t] * cur[i].V[t + 1][d];
+              out->points[(nq + q) * tdim + d] = v;
+            }
+            out->weights[nq + q] = wref[q] * scale;
+          }
+          nq += nref;
+        }
+        out->parent_map[nr] = (int32_t)c;
+        out->offsets[nr + 1] = (int32_t)nq;
+        ++nr;
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 /* 8f-4 facet hosts: cut(level_set, facets, tdim-1) (cut.cpp:540-591, 788-830, */
 /* 1022-1063).  Host i is the facet spanned by the mesh vertices verts[i*tdim..] */
 /* with level-set dofs ls[i*tdim..]; its rule lives on the (tdim-1)-simplex of   */
@@ -617,6 +796,8 @@ int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
 /* measure); else one rule per INTERSECTED host over its phi<0 / phi>0 part.     */
 /* rule_host[r] = host index of rule r (caller frees).                           */
 /* ------------------------------------------------------------------------ */
+static double host_measure(int tdim, double xv[3][3]);
+static double host_measure_fwd(int tdim, double xv[3][3]) { return host_measure(tdim, xv); }
 static double host_measure(int tdim, double xv[3][3])
 {
   if (tdim == 2)

@@ -116,6 +116,12 @@ int64_t orc_locate_entities(int64_t ncells, int nls, const int8_t* domain,
 int orc_runtime_quadrature(const orc_mesh* mesh, const int32_t* ls_dofmap,
                            const double* ls_values, const int8_t* domain,
                            const char* selector, int order, orc_rules* out);
+/* several level sets: one conjunction of clauses, e.g. "phi<0 and phi1>0" or "phi=0 and phi1<0"
+   (cut.h:122-181, element-classification.md:145-160); ls_values[k] = dof values of level set k,
+   domain = [nls][ncells] classification codes */
+int orc_runtime_quadrature_multi(const orc_mesh* mesh, int nls, const int32_t* ls_dofmap,
+                                 const double* const* ls_values, const int8_t* domain,
+                                 const char* selector, int order, orc_rules* out);
 /* rule for a whole reference simplex of each listed cell (test helper that
    mirrors python/tests/quadrature_utils.py:12-70) */
 int orc_facet_runtime_quadrature(const orc_mesh* mesh, int64_t n, const int32_t* verts, const int32_t* ls,

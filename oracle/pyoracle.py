@@ -214,6 +214,25 @@ def runtime_quadrature(mesh: Mesh, ls_dofmap, ls_values, domain, selector: str, 
     return _rules_from_c(r)
 
 
+def classify_multi(ls_dofmap, ls_values_list):
+    """[nls, ncells] classification codes of several level sets on one dofmap."""
+    return np.stack([classify(ls_dofmap, v) for v in ls_values_list])
+
+
+def runtime_quadrature_multi(mesh: Mesh, ls_dofmap, ls_values_list, domains, selector: str, order: int):
+    """Rules of one conjunction over several level sets ("phi<0 and phi1>0", "phi=0 and phi1<0")."""
+    ls_dofmap = np.ascontiguousarray(ls_dofmap, dtype=np.int32)
+    vals = [np.ascontiguousarray(v, dtype=np.float64) for v in ls_values_list]
+    ptrs = (C.c_void_p * len(vals))(*[v.ctypes.data for v in vals])
+    domains = np.ascontiguousarray(domains, dtype=np.int8)
+    r = _Rules()
+    rc = lib().orc_runtime_quadrature_multi(C.byref(mesh.c), len(vals), _p(ls_dofmap), ptrs, _p(domains),
+                                            selector.encode(), int(order), C.byref(r))
+    if rc != 0:
+        raise ValueError(f"unsupported selector for runtime quadrature: {selector!r}")
+    return _rules_from_c(r)
+
+
 def full_cell_rules(mesh: Mesh, cells, order: int):
     cells = np.ascontiguousarray(cells, dtype=np.int32)
     r = _Rules()

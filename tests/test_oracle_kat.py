@@ -566,3 +566,71 @@ def test_facet_hosts_interface_of_the_facets(oracle, tdim):
     for side in range(1):
         Rc = O.facet_rules_to_cells(m, R, side)
         assert np.allclose(np.sort(O.physical_points(m, Rc)[:, 0]), 0.51, atol=1e-14)
+
+
+# ---- several level sets: runtime_quadrature(cut([phi, phi1, ...]), "phi<0 and phi1>0", k)
+# (cpp/cutfemx/cut/cut.h:122-181, docs/user-guide/element-classification.md:145-160).  The reference holds no
+# fixture for these rules (its multi-level-set tests stop at locate_entities, test_cut_api.py:713-763), so the
+# oracle is pinned by geometry: planes are P1 functions, so boxes cut out by planes are integrated exactly.
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_multi_level_set_rules_integrate_plane_boxes_exactly(oracle, tdim, n):
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    cuts = [0.51, 0.37, 0.63][:tdim]
+    ls = [om.x[:, d] - cuts[d] for d in range(tdim)]
+    dom = O.classify_multi(om.conn, ls)
+    cellvol = 1.0 / n ** tdim / (2 if tdim == 2 else 6)
+    names = ["phi", "phi1", "phi2"][:tdim]
+    for signs in [(1,) * tdim, (1, -1, 1)[:tdim], (-1, -1, -1)[:tdim]]:
+        sel = " and ".join(f"{nm}{'<' if s > 0 else '>'}0" for nm, s in zip(names, signs))
+        r = O.runtime_quadrature_multi(om, om.conn, ls, dom, sel, 2)
+        full = O.locate_entities(dom, sel)
+        exact = np.prod([c if s > 0 else 1.0 - c for c, s in zip(cuts, signs)])
+        assert abs(r.weights.sum() + full.size * cellvol - exact) < 1e-13
+        assert np.all(r.weights > 0) and r.offsets[-1] == r.weights.size
+        assert np.all(np.diff(r.parent_map) > 0)                      # one rule per cell, ascending
+        assert not set(r.parent_map.tolist()) & set(full.tolist())    # rule cells are not standard cells
+        # every point satisfies every clause and lies in the reference simplex
+        assert r.points.min() > -1e-14 and r.points.sum(axis=1).max() < 1 + 1e-14
+        xq = O.physical_points(om, r)
+        for d, s in enumerate(signs):
+            assert np.all(s * (xq[:, d] - cuts[d]) < 1e-13)
+    # the part of the first plane inside the other half spaces: a segment / rectangle of known measure
+    sel_i = "phi=0 and " + " and ".join(f"{nm}<0" for nm in names[1:])
+    ri = O.runtime_quadrature_multi(om, om.conn, ls, dom, sel_i, 2)
+    assert abs(ri.weights.sum() - np.prod(cuts[1:])) < 1e-13
+    xq = O.physical_points(om, ri)
+    assert np.abs(xq[:, 0] - cuts[0]).max() < 1e-14
+    # complement property: the two sides of the second level set partition the first one's negative part
+    a = O.runtime_quadrature_multi(om, om.conn, ls[:2], dom[:2], "phi<0 and phi1<0", 2)
+    b = O.runtime_quadrature_multi(om, om.conn, ls[:2], dom[:2], "phi<0 and phi1>0", 2)
+    va = a.weights.sum() + O.locate_entities(dom[:2], "phi<0 and phi1<0").size * cellvol
+    vb = b.weights.sum() + O.locate_entities(dom[:2], "phi<0 and phi1>0").size * cellvol
+    assert abs(va + vb - cuts[0]) < 1e-13
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 12), (3, 6)])
+def test_multi_level_set_rules_reduce_to_the_single_level_set_rules(oracle, tdim, n):
+    """A second level set that is negative everywhere changes nothing: same rules, bit for bit; and a clause on
+    the second level set alone ("phi1<0") equals the single-level-set rules of that function."""
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    far = -1.0 - om.x[:, 0]
+    dom = O.classify_multi(om.conn, [phi, far])
+    for sel_m, sel_s in [("phi<0 and phi1<0", "phi<0"), ("phi>0 and phi1<0", "phi>0"), ("phi=0 and phi1<0", "phi=0")]:
+        m = O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, sel_m, 3)
+        s1 = O.runtime_quadrature(om, om.conn, phi, dom[0], sel_s, 3)
+        assert np.array_equal(m.offsets, s1.offsets) and np.array_equal(m.parent_map, s1.parent_map)
+        assert np.array_equal(m.points, s1.points) and np.array_equal(m.weights, s1.weights)
+    dom2 = O.classify_multi(om.conn, [far, phi])
+    m = O.runtime_quadrature_multi(om, om.conn, [far, phi], dom2, "phi1<0", 2)
+    s1 = O.runtime_quadrature(om, om.conn, phi, dom2[1], "phi<0", 2)
+    assert np.array_equal(m.parent_map, s1.parent_map) and np.array_equal(m.weights, s1.weights)
+    # a region the second level set excludes entirely has no rules
+    e = O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, "phi<0 and phi1>0", 2)
+    assert e.parent_map.size == 0 and e.weights.size == 0
+    with pytest.raises(ValueError):
+        O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, "phi<0 or phi1<0", 2)     # not one conjunction
+    with pytest.raises(ValueError):
+        O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, "phi=0 and phi1=0", 2)    # codimension 2

@@ -171,16 +171,25 @@ __device__ __forceinline__ void cell_local_row(int kernel, const double* __restr
                                                double wscale, const double* __restrict__ pdata, int ia, int ik,
                                                double* acc, const double* cw = nullptr)
 {
-  // cw: the cell's ND coefficient dof values (pack_coefficients) when a field id is CFX_F_COEFFICIENT
+  // cw: the cell's ND packed coefficient dof values (pack_coefficients, pack_form.h:32-170).  RANK 1: the source
+  // field f = sum_j N_j cw[j] when the field id is CFX_F_COEFFICIENT (vector spaces: component ik of a vector-valued
+  // Function); RANK 2: a scalar coefficient kappa = sum_j N_j cw[j] that multiplies the integrand
   constexpr int ND = Elem<TDIM, DEG>::ND;
   for (int q = 0; q < npts; ++q)
   {
     double X[TDIM];
 #pragma unroll
     for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
-    const double w = wts[q] * wscale;
+    double w = wts[q] * wscale;
     double N[ND], dN[ND][TDIM], G[ND][TDIM];
     tabulate<TDIM, DEG>(X, N, dN);
+    if (RANK == 2 && cw != nullptr)
+    {
+      double kappa = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) kappa += N[j] * cw[j];
+      w *= kappa;
+    }
 #pragma unroll
     for (int j = 0; j < ND; ++j)
 #pragma unroll

@@ -118,15 +118,15 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
   double cw[ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j) cw[j] = 0.0;
-  if constexpr (RANK == 1)
+  if (A.coeff) // pack_coefficients (pack_form.h:32-170): the cell's coefficient dofs
   {
-    if (A.coeff) // pack_coefficients (pack_form.h:32-170): the cell's coefficient dofs
-    {
+    // rank 1 on a vector space: component ik of the vector-valued source; rank 2: a scalar coefficient
+    const int cbs = RANK == 1 ? BS : 1, comp = RANK == 1 ? ik : 0;
 #pragma unroll
-      for (int j = 0; j < ND; ++j) cw[j] = A.coeff[A.dofmap[cell * ND + j]];
-    }
+    for (int j = 0; j < ND; ++j) cw[j] = A.coeff[(int64_t)A.dofmap[cell * ND + j] * cbs + comp];
   }
-  cell_local_row<TDIM, DEG, BS, RANK>(A.kernel, A.params, A.point_stride, g, h, npts, pts, wts, wscale, pdata, ia, ik, acc, cw);
+  cell_local_row<TDIM, DEG, BS, RANK>(A.kernel, A.params, A.point_stride, g, h, npts, pts, wts, wscale, pdata, ia, ik, acc,
+                                      A.coeff ? cw : nullptr);
 
   if (A.dump)
   {
@@ -679,7 +679,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
   // staged element tensors of the elasticity term on 3-D vector spaces: the MFMA kernel (CFX_MFMA=0: generic rows)
   const char* mf = getenv("CFX_MFMA");
   const bool mfma_tensors = TDIM == 3 && BS == 3 && a->rank == 2 && A.dump != nullptr && !single && !A.lift_markers
-                            && A.kernel == CFX_K_ELASTICITY && !(mf && mf[0] == '0');
+                            && A.kernel == CFX_K_ELASTICITY && !A.coeff && !(mf && mf[0] == '0');
   // a resident grid of wavefronts, each walking its share of the cells
   auto mfma_grid = [](int64_t n) { return dim3((unsigned)std::min<int64_t>(n, 256 * 32)); };
   if ((parts & 1) && (!single || !use_rule))
@@ -713,7 +713,7 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     if (A.n > 0)
     {
       const char* spec = getenv("CFX_CUT_TENSORS_P1");
-      if (a->rank == 2 && DEG == 1 && BS == 1 && A.dump && !single && !(spec && spec[0] == '0')
+      if (a->rank == 2 && DEG == 1 && BS == 1 && A.dump && !single && !A.coeff && !(spec && spec[0] == '0')
           && (A.kernel == CFX_K_STIFFNESS || A.kernel == CFX_K_MASS || A.kernel == CFX_K_NITSCHE))
       {
         if constexpr (DEG == 1 && BS == 1)
@@ -968,7 +968,19 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     }
     if (in.kernel == CFX_K_ELASTICITY)
       require(V->bs == V->mesh->gdim, CFX_ERR_INVALID_ARGUMENT, "elasticity needs a vector space (bs == gdim)");
-    if (in.kernel == CFX_L_SOURCE) require(V->bs == 1, CFX_ERR_INVALID_ARGUMENT, "source kernel is scalar");
+    if (in.kernel == CFX_L_SOURCE)
+      require(V->bs == 1 || (int)in.params[0] == CFX_F_COEFFICIENT, CFX_ERR_INVALID_ARGUMENT,
+              "the source term of a vector space takes a vector-valued Function (field id CFX_F_COEFFICIENT)");
+    if (bilinear)
+    {
+      // a scalar coefficient of the form's element multiplies the integrand (kappa grad u . grad v, rho u v, the
+      // density-weighted elasticity of python/demo/demo_compliance_optimization.py)
+      require(in.coefficient == nullptr || in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS
+                  || in.kernel == CFX_K_ELASTICITY,
+              CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: a coefficient is accepted by the mass, stiffness and elasticity terms");
+      if (in.coefficient) I.coefficient = to_device(in.coefficient, V->ndofs);
+    }
+    else
     {
       const bool wants = (in.kernel == CFX_L_SOURCE && (int)in.params[0] == CFX_F_COEFFICIENT)
                          || (in.kernel == CFX_L_NITSCHE_RHS && (int)in.params[1] == CFX_F_COEFFICIENT);
@@ -976,7 +988,7 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
               "the Nitsche datum takes an analytic field id");
       require(wants == (in.coefficient != nullptr), CFX_ERR_INVALID_ARGUMENT,
               "cfx_form_create: `coefficient` goes with the field id CFX_F_COEFFICIENT (and only with it)");
-      if (wants) I.coefficient = to_device(in.coefficient, V->ndofs);
+      if (wants) I.coefficient = to_device(in.coefficient, V->ndofs * V->bs); // vector spaces: bs values per dof
     }
     I.n_entities = in.n_entities;
     const int64_t width = in.type == CFX_INTERIOR_FACET ? 4 : 1;

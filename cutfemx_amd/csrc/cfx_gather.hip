@@ -1970,7 +1970,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     const bool inline_ok = BS > 1 ? (I.kernel == CFX_K_ELASTICITY || I.kernel == CFX_K_MASS || I.kernel == CFX_K_STIFFNESS)
                                   : (DEG == 1 ? I.kernel == CFX_K_STIFFNESS
                                               : (I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS));
-    R.std_inline = (a->rank == 2 && inline_ok && kRowsInline<DEG> && !(inl && inl[0] == '0')) ? 1 : 0;
+    R.std_inline = (a->rank == 2 && inline_ok && kRowsInline<DEG> && I.coefficient.n == 0 && !(inl && inl[0] == '0')) ? 1 : 0;
     if (BS > 1 && !(inl && inl[0] == '1')) R.std_inline = 0; // block spaces stage their uncut tensors (see assemble_matrix_rows)
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form

@@ -138,8 +138,11 @@ typedef struct
                               a dS measure, `entities` being its standard facets                      */
   const double* point_data;/* per-point coefficients aligned with rules, or NULL */
   double params[8];
-  const double* coefficient; /* dof values (ndofs) of the coefficient Function when a field id is
-                                CFX_F_COEFFICIENT, else NULL; scalar spaces                  */
+  const double* coefficient; /* packed coefficient of pack_form.h:32-170, given as the dof values of a Function:
+                                rank 1, field id CFX_F_COEFFICIENT: the source f (ndofs values; on a vector
+                                space ndofs * bs values of a vector-valued f); rank 2 (mass, stiffness,
+                                elasticity): a scalar coefficient kappa of the form's element (ndofs values)
+                                that multiplies the integrand; else NULL.  Constants travel in `params`  */
 } cfx_integral;
 
 typedef struct

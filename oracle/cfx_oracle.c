@@ -1225,13 +1225,21 @@ static void cell_kernel(const orc_mesh* m, const orc_space* V, const orc_integra
         for (int t = 0; t < tdim; ++t) xq[d] += X[t] * xc[t + 1][d];
       }
     }
+    /* a scalar coefficient of the form's element multiplies a bilinear integrand (pack_form.h:32-170) */
+    double kw = w;
+    if (I->kernel < 100 && I->coefficient)
+    {
+      double kappa = 0.0;
+      for (int j = 0; j < nd; ++j) kappa += N[j] * I->coefficient[V->dofmap[cell * nd + j]];
+      kw = w * kappa;
+    }
     switch (I->kernel)
     {
     case ORC_K_MASS:
       for (int i = 0; i < nd; ++i)
         for (int j = 0; j < nd; ++j)
           for (int k = 0; k < bs; ++k)
-            Ae[(i * bs + k) * nloc + j * bs + k] += w * N[i] * N[j];
+            Ae[(i * bs + k) * nloc + j * bs + k] += kw * N[i] * N[j];
       break;
     case ORC_K_STIFFNESS:
       for (int i = 0; i < nd; ++i)
@@ -1239,7 +1247,7 @@ static void cell_kernel(const orc_mesh* m, const orc_space* V, const orc_integra
         {
           double s = 0.0;
           for (int d = 0; d < gdim; ++d) s += G[i][d] * G[j][d];
-          for (int k = 0; k < bs; ++k) Ae[(i * bs + k) * nloc + j * bs + k] += w * s;
+          for (int k = 0; k < bs; ++k) Ae[(i * bs + k) * nloc + j * bs + k] += kw * s;
         }
       break;
     case ORC_K_NITSCHE:
@@ -1274,12 +1282,23 @@ static void cell_kernel(const orc_mesh* m, const orc_space* V, const orc_integra
               for (int d = 0; d < gdim; ++d) gg += G[i][d] * G[j][d];
               double val = mu * ((a == b ? gg : 0.0) + G[i][b] * G[j][a])
                            + lmbda * G[i][a] * G[j][b];
-              Ae[(i * bs + a) * nloc + j * bs + b] += w * val;
+              Ae[(i * bs + a) * nloc + j * bs + b] += kw * val;
             }
       break;
     }
     case ORC_L_SOURCE:
     {
+      if (bs > 1) /* vector space: a vector-valued Function f, be[(i,a)] = int f_a N_i */
+      {
+        for (int a = 0; a < bs; ++a)
+        {
+          double f = 0.0;
+          for (int j = 0; j < nd; ++j) f += N[j] * I->coefficient[(int64_t)V->dofmap[cell * nd + j] * bs + a];
+          f *= I->params[1];
+          for (int i = 0; i < nd; ++i) Ae[i * bs + a] += w * f * N[i];
+        }
+        break;
+      }
       double f;
       if ((int)I->params[0] == ORC_F_COEFFICIENT)
       {

@@ -545,3 +545,64 @@ def test_deterministic_mode_is_bitwise_reproducible(oracle, monkeypatch):
         runs.append((A.data.copy(), b.copy()))
     for vals, b in runs[1:]:
         assert np.array_equal(vals, runs[0][0]) and np.array_equal(b, runs[0][1])
+
+
+@pytest.mark.parametrize("mode", ["rows", "atomic"])
+@pytest.mark.parametrize("tdim,n,degree,bs", [(2, 10, 1, 1), (3, 6, 1, 1), (2, 8, 2, 1), (3, 4, 2, 1), (3, 5, 1, 3), (2, 6, 2, 2)])
+def test_coefficients_in_bilinear_forms(oracle, tdim, n, degree, bs, mode, monkeypatch):
+    """a10, pack_form.h:69-158: a scalar coefficient Function inside bilinear forms -- kappa grad u . grad v,
+    rho u v, and the density-weighted elasticity of python/demo/demo_compliance_optimization.py -- over
+    [inside cells, cut-cell rules]; constants travel in `params`."""
+    import cutfemx_amd as cfx
+    if mode == "atomic":
+        monkeypatch.setenv("CFX_ASSEMBLY", "atomic")
+    s = setup(oracle, tdim, n, degree, bs)
+    O, om, dom, cd, oV = s["O"], s["om"], s["dom"], s["cd"], s["oV"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 4)
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    rng = np.random.default_rng(3)
+    kappa = 1.0 + rng.uniform(0.0, 2.0, oV.ndofs)            # dof values of a scalar Function of the form's element
+    q = 2 * degree
+    terms = [(O.K_STIFFNESS, cfx.fem.STIFFNESS, ()), (O.K_MASS, cfx.fem.MASS, ())]
+    if bs > 1:
+        terms.append((O.K_ELASTICITY, cfx.fem.ELASTICITY, (1.0e3, 0.3)))
+    for ok, gk, params in terms:
+        oa = [O.Integral(O.CELL, ok, entities=inside, rules=ovol, params=params, qdegree=q, coefficient=kappa)]
+        ga = [cfx.fem.Integral(gk, cells=inside, rules=vol, params=params, qdegree=q, coefficient=kappa)]
+        A = compare_forms(s, oa, ga)
+        # a constant coefficient is a constant factor
+        c = np.full(oV.ndofs, 2.5)
+        Ac = cfx.fem.assemble_matrix(cfx.fem.form(
+            [cfx.fem.Integral(gk, cells=inside, rules=vol, params=params, qdegree=q, coefficient=c)], s["V"]))
+        A1 = cfx.fem.assemble_matrix(cfx.fem.form(
+            [cfx.fem.Integral(gk, cells=inside, rules=vol, params=params, qdegree=q)], s["V"]))
+        assert rel_err(Ac.data, 2.5 * A1.data) < 1e-12
+        assert rel_err(A.data, A1.data) > 1e-3               # the varying coefficient does change the matrix
+    with pytest.raises(ValueError):                          # only these three terms take a coefficient
+        cfx.fem.form([cfx.fem.Integral(cfx.fem.GHOST_GRADJUMP, facets=np.zeros((0, 4), np.int32), params=(0.1,),
+                                       coefficient=kappa)], s["V"])
+
+
+@pytest.mark.parametrize("tdim,n,degree", [(2, 10, 1), (3, 5, 1), (2, 6, 2), (3, 4, 2)])
+def test_vector_valued_source_coefficient(oracle, tdim, n, degree):
+    """a10: L = f . v with f a vector-valued Function of the (vector) space: be[(i, a)] = int f_a N_i."""
+    import cutfemx_amd as cfx
+    s = setup(oracle, tdim, n, degree, tdim)
+    O, om, dom, cd, oV = s["O"], s["om"], s["dom"], s["cd"], s["oV"]
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 4)
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    rng = np.random.default_rng(4)
+    f = rng.standard_normal(oV.ndofs * tdim)
+    q = 2 * degree
+    oL = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=ovol, params=(O.F_COEFFICIENT, 1.5), qdegree=q, coefficient=f)]
+    gL = [cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, rules=vol, params=(cfx.fem.F_COEFFICIENT, 1.5), qdegree=q,
+                           coefficient=f)]
+    b = compare_forms(s, oL, gL, rank=1)
+    # the same through the vector mass matrix: b = 1.5 M f
+    M = cfx.fem.assemble_matrix(cfx.fem.form(
+        [cfx.fem.Integral(cfx.fem.MASS, cells=inside, rules=vol, qdegree=q)], s["V"])).to_scipy()
+    assert rel_err(b, 1.5 * (M @ f)) < 1e-11
+    with pytest.raises(ValueError):                          # an analytic scalar field cannot source a vector space
+        cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, params=(cfx.fem.F_ONE, 1.0))], s["V"])

@@ -634,3 +634,41 @@ def test_multi_level_set_rules_reduce_to_the_single_level_set_rules(oracle, tdim
         O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, "phi<0 or phi1<0", 2)     # not one conjunction
     with pytest.raises(ValueError):
         O.runtime_quadrature_multi(om, om.conn, [phi, far], dom, "phi=0 and phi1=0", 2)    # codimension 2
+
+
+@pytest.mark.parametrize("tdim,n,degree,bs", [(2, 8, 1, 1), (3, 4, 2, 1), (3, 4, 1, 3)])
+def test_oracle_coefficients_in_forms(oracle, tdim, n, degree, bs):
+    """a10 (pack_form.h:69-158) restated: a scalar coefficient multiplies a bilinear integrand, a vector-valued
+    Function sources a vector space.  Pinned by linearity: constant coefficient = constant factor, kappa = 1 + x
+    splits into the plain matrix plus the x-weighted one, and b = M f."""
+    import cutfemx_amd as cfx
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    dom = O.classify(om.conn, phi)
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, degree)
+    V = O.Space(dofmap, ndofs, degree, bs)
+    inside = O.locate_entities(dom, "phi<0")
+    vol = O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", 4)
+    rng = np.random.default_rng(1)
+    k1, k2 = 1.0 + rng.uniform(0, 1, ndofs), 0.5 + rng.uniform(0, 1, ndofs)
+
+    def mat(kernel, coeff, params=()):
+        a = [O.Integral(O.CELL, kernel, entities=inside, rules=vol, params=params, qdegree=2 * degree, coefficient=coeff)]
+        ip, ix = O.create_sparsity(om, V, a)
+        return O.assemble_matrix(om, V, a, ip, ix)
+    kernels = [(O.K_MASS, ()), (O.K_STIFFNESS, ())] + ([(O.K_ELASTICITY, (1.0e3, 0.3))] if bs > 1 else [])
+    for kern, params in kernels:
+        A0 = mat(kern, None, params)
+        assert np.abs(mat(kern, np.full(ndofs, 3.0), params) - 3.0 * A0).max() < 1e-12 * np.abs(A0).max()
+        assert np.abs(mat(kern, k1 + k2, params) - mat(kern, k1, params) - mat(kern, k2, params)).max() \
+            < 1e-12 * np.abs(A0).max()
+    if bs > 1:
+        f = rng.standard_normal(ndofs * bs)
+        L = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=vol, params=(O.F_COEFFICIENT, 1.0), qdegree=2 * degree,
+                        coefficient=f)]
+        b = O.assemble_vector(om, V, L)
+        a = [O.Integral(O.CELL, O.K_MASS, entities=inside, rules=vol, qdegree=2 * degree)]
+        ip, ix = O.create_sparsity(om, V, a)
+        M = sp.csr_matrix((O.assemble_matrix(om, V, a, ip, ix), ix, ip), shape=(ndofs * bs,) * 2)
+        assert np.abs(b - M @ f).max() < 1e-12 * np.abs(b).max()

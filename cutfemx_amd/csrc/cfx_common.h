@@ -454,6 +454,7 @@ struct cfx_row_plan
   cfx::DevArray<int32_t> facet_rows;  // [nfacets*4]
   cfx::DevArray<uint8_t> facet_slot;  // facet integral slot of each row
   cfx::DevArray<int64_t> d2f_offsets; // dof -> facets incidence
+  bool d2f_sorted = false; // built by the sort path: every list already in ascending facet order
   cfx::DevArray<int32_t> d2f;
   int n_cell_slots = 0, n_facet_slots = 0;
   // per cell slot: bitset of its uncut entities + exclusive popcount ranks (entity index lookup)

@@ -76,7 +76,7 @@ class PatternView(C.Structure):
 
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
-    "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_copy",
+    "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
     "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
@@ -87,7 +87,7 @@ SYMBOLS = [
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_interior_facets_for_cells", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",
     "cfx_cell_aggregation_destroy", "cfx_cut_destroy", "cfx_space_create",
-    "cfx_space_static_bytes", "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_create_sparsity",
+    "cfx_space_static_bytes", "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_form_prepare", "cfx_create_sparsity",
     "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_matrix_zeroed", "cfx_assemble_vector",
     "cfx_apply_lifting", "cfx_set_bc", "cfx_zero_rows", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
     "cfx_active_destroy",

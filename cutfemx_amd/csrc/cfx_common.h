@@ -73,7 +73,11 @@ struct Context
 {
   int device = -1;
   bool initialised = false;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream launches go to: main_stream, or side_stream inside cfx_overlap_side()
+  hipStream_t main_stream = nullptr; // what cfx_set_stream chose (default: the null stream)
+  hipStream_t side_stream = nullptr; // second lane of an overlap section (created on first use, non-blocking)
+  bool overlap = false;              // inside cfx_overlap_begin / cfx_overlap_end: block frees are deferred
+  std::vector<void*> deferred_free;
   bool profile = false;
   std::vector<ProfileEntry> entries;
   std::map<std::string, int> entry_index;
@@ -488,6 +492,7 @@ void plain_row_masks(cfx_form_s* a);                                    // cfx_r
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
+void prepare_form_tables(cfx_form_s* a);                                // cfx_gather.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values,
                           bool fresh = false);
 bool assemble_vector_rows(cfx_form_s* L, double* b);

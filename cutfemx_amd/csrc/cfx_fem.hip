@@ -1025,6 +1025,14 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
   CFX_API_END
 }
 
+int cfx_form_prepare(cfx_form_t a)
+{
+  CFX_API_BEGIN
+  require(a != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_form_prepare: null argument");
+  if (!force_atomic()) prepare_form_tables(a);
+  CFX_API_END
+}
+
 int cfx_form_destroy(cfx_form_t a)
 {
   CFX_API_BEGIN

@@ -2337,6 +2337,25 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
   return true;
 }
 
+// cfx_form_prepare: everything the gather assembly derives from the form's entity lists, built now
+void prepare_form_tables(cfx_form_s* a)
+{
+  cfx_row_plan& plan = row_plan(a);
+  cfx_space_s* V = a->V;
+  if (!plan.usable || V->degree != 1 || V->bs != 1) return;
+  const Stencil& stn = space_stencil(V);
+  if (!stn.usable) return;
+  (void)space_stencil_tiles(V);
+  plain_row_masks(a);
+  if (a->rank == 1)
+  {
+    int slot = -1, count = 0;
+    for (int s = 0; s < plan.n_cell_slots; ++s)
+      if (a->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+    if (count == 1) (void)plain_vec_offsets(a, (uint8_t)(1u << slot));
+  }
+}
+
 bool assemble_vector_rows(cfx_form_s* L, double* b)
 {
   cfx_row_plan& plan = row_plan(L);

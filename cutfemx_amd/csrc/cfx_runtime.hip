@@ -50,7 +50,8 @@ int Context::entry(const char* name)
 void Context::flush_profile()
 {
   if (pending.empty()) return;
-  CFX_HIP(hipStreamSynchronize(stream));
+  CFX_HIP(hipStreamSynchronize(main_stream));
+  if (side_stream) CFX_HIP(hipStreamSynchronize(side_stream));
   for (auto& p : pending)
   {
     float ms = 0.f;
@@ -128,6 +129,9 @@ void* dev_alloc(size_t bytes)
 void dev_free(void* p)
 {
   if (!p) return;
+  // two streams in flight: a block handed back now could reach a launch on the other stream while queued work of
+  // this one still uses it -- it stays out of the cache until the section is joined
+  if (ctx().overlap) { ctx().deferred_free.push_back(p); return; }
   BlockCache& c = cache();
   auto it = c.live.find(p);
   if (it == c.live.end()) return; // not ours
@@ -140,7 +144,8 @@ void dev_cache_release()
 {
   BlockCache& c = cache();
   if (c.free_blocks.empty()) return;
-  (void)hipStreamSynchronize(ctx().stream); // a cached block may still be in use by queued work
+  (void)hipStreamSynchronize(ctx().main_stream); // a cached block may still be in use by queued work
+  if (ctx().side_stream) (void)hipStreamSynchronize(ctx().side_stream);
   for (auto& kv : c.free_blocks) (void)hipFree(kv.second);
   c.free_blocks.clear();
   c.cached = 0;
@@ -361,8 +366,12 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n)
     // tile states + ticket: a zeroed slice of a pool that is cleared with one fill when it wraps (a step runs
     // a dozen short scans: one memset each otherwise)
     constexpr int64_t kPoolWords = 1 << 20;
-    static unsigned long long* pool = nullptr;
-    static int64_t next = kPoolWords;
+    // (one pool per stream: the refill at wrap-around is ordered against earlier users by the stream it runs on)
+    struct ScanPool { unsigned long long* pool = nullptr; int64_t next = kPoolWords; };
+    static std::map<hipStream_t, ScanPool> pools;
+    ScanPool& sp = pools[ctx().stream];
+    unsigned long long*& pool = sp.pool;
+    int64_t& next = sp.next;
     unsigned long long* state;
     DevArray<unsigned long long> own;
     if (ntiles + 1 > kPoolWords / 4)
@@ -488,8 +497,12 @@ int* zero_flag()
   // two alternating pools: only the pool being switched TO is refilled, so a flag a caller still holds
   // (written by kernels, not yet read back) survives until 4096 further flags have been handed out
   constexpr int kFlags = 4096;
-  static int* pool[2] = {nullptr, nullptr};
-  static int cur = 1, next = kFlags;
+  struct FlagPool { int* pool[2] = {nullptr, nullptr}; int cur = 1, next = kFlags; };
+  static std::map<hipStream_t, FlagPool> pools; // one per stream, as for the scan states
+  FlagPool& fp = pools[ctx().stream];
+  int* (&pool)[2] = fp.pool;
+  int& cur = fp.cur;
+  int& next = fp.next;
   if (next == kFlags)
   {
     cur ^= 1;
@@ -540,8 +553,9 @@ int cfx_set_stream(void* s)
   ctx().ensure();
   ctx().flush_profile();
   // cached blocks and pool slices handed out earlier may still be in use by work queued on the old stream
+  require(!ctx().overlap, CFX_ERR_RUNTIME, "cfx_set_stream inside an overlap section");
   if (ctx().stream != (hipStream_t)s) CFX_HIP(hipStreamSynchronize(ctx().stream));
-  ctx().stream = (hipStream_t)s;
+  ctx().stream = ctx().main_stream = (hipStream_t)s;
   CFX_API_END
 }
 
@@ -549,7 +563,48 @@ int cfx_synchronize(void)
 {
   CFX_API_BEGIN
   ctx().ensure();
-  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  CFX_HIP(hipStreamSynchronize(ctx().main_stream));
+  if (ctx().side_stream) CFX_HIP(hipStreamSynchronize(ctx().side_stream));
+  CFX_API_END
+}
+
+int cfx_overlap_begin(void)
+{
+  CFX_API_BEGIN
+  Context& c = ctx();
+  c.ensure();
+  require(!c.overlap, CFX_ERR_RUNTIME, "cfx_overlap_begin: already inside an overlap section");
+  if (!c.side_stream) CFX_HIP(hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking));
+  hipEvent_t e = c.get_event();
+  CFX_HIP(hipEventRecord(e, c.main_stream));          // the side lane starts behind everything queued so far
+  CFX_HIP(hipStreamWaitEvent(c.side_stream, e, 0));
+  c.event_pool.push_back(e);
+  c.overlap = true;
+  CFX_API_END
+}
+
+int cfx_overlap_side(int side)
+{
+  CFX_API_BEGIN
+  Context& c = ctx();
+  require(c.overlap, CFX_ERR_RUNTIME, "cfx_overlap_side: not inside an overlap section");
+  c.stream = side ? c.side_stream : c.main_stream;
+  CFX_API_END
+}
+
+int cfx_overlap_end(void)
+{
+  CFX_API_BEGIN
+  Context& c = ctx();
+  require(c.overlap, CFX_ERR_RUNTIME, "cfx_overlap_end: not inside an overlap section");
+  hipEvent_t e = c.get_event();
+  CFX_HIP(hipEventRecord(e, c.side_stream));          // join: the main lane continues behind the side lane's work
+  CFX_HIP(hipStreamWaitEvent(c.main_stream, e, 0));
+  c.event_pool.push_back(e);
+  c.stream = c.main_stream;
+  c.overlap = false;
+  for (void* p : c.deferred_free) dev_free(p);        // stream order on the main lane now covers both lanes' users
+  c.deferred_free.clear();
   CFX_API_END
 }
 

@@ -94,6 +94,11 @@ class CutForm:
         self._h = C.c_void_p()
         _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(self._h)))
 
+    def prepare(self):
+        """Build the form's derived tables now (cfx_form_prepare) instead of inside the first assembly call."""
+        _lib.check(_lib.lib().cfx_form_prepare(self._h))
+        return self
+
     def __del__(self):
         try:
             if self._h:
@@ -101,6 +106,33 @@ class CutForm:
                 self._h = None
         except Exception:
             pass
+
+
+class overlap:
+    """Two independent pieces of a step on two HIP streams (cfx_overlap_begin / _side / _end):
+
+        L.prepare(); a.prepare()                 # shared tables are built before the lanes part
+        with fem.overlap() as lanes:
+            lanes.side(lambda: fem.assemble_vector(L, b))          # queued on the second stream
+            A = fem.create_matrix(a); fem.assemble_matrix(a, A=A)  # meanwhile on the main stream
+        # joined here
+
+    The reference assembles a and L one after the other (python/demo/demo_poisson.py:40-60); they share inputs only."""
+
+    def __enter__(self):
+        _lib.check(_lib.lib().cfx_overlap_begin())
+        return self
+
+    def side(self, fn):
+        _lib.check(_lib.lib().cfx_overlap_side(1))
+        try:
+            return fn()
+        finally:
+            _lib.check(_lib.lib().cfx_overlap_side(0))
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.lib().cfx_overlap_end())
+        return False
 
 
 def form(integrals, V: FunctionSpace, rank: int | None = None) -> CutForm:

@@ -159,6 +159,18 @@ int cfx_init(int device);              /* select the HIP device; fails loudly wi
 const char* cfx_last_error(void);
 int cfx_set_stream(void* hip_stream);  /* all later launches go to this stream (the old one is synchronised first) */
 int cfx_synchronize(void);
+/* Two independent pieces of a step side by side (an extension: the reference is serial).  cfx_overlap_begin() opens
+ * a section with a second HIP stream that starts behind everything queued so far; cfx_overlap_side(1) / (0) chooses the
+ * lane the following calls are queued on; cfx_overlap_end() joins the lanes.  The caller guarantees that the two
+ * lanes neither write the same arrays nor build the same derived tables: a form's row plan is built by the first
+ * call that needs it, so call cfx_form_prepare() on forms that share entity lists before the section.  Host-side
+ * size read-backs inside a call wait for that call's lane only: queue the lane with the fewest of them first.
+ * Typical use: assemble_vector(L) next to create_sparsity(a) + assemble_matrix(a) (python/demo/demo_poisson.py:40-60
+ * assembles them one after the other; they share inputs only).  Pays on small meshes, where single kernels leave
+ * CUs idle; at 512^3 every kernel fills the chip and the two lanes only contend (measured: DESIGN.md 3). */
+int cfx_overlap_begin(void);
+int cfx_overlap_side(int side);
+int cfx_overlap_end(void);
 int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
 int cfx_device_alloc(void** ptr, size_t bytes);
 int cfx_device_free(void* ptr);
@@ -323,6 +335,9 @@ int cfx_space_destroy(cfx_space_t V);
 int cfx_form_create(cfx_space_t V, int rank, int n_integrals,
                     const cfx_integral* integrals, cfx_form_t* out);
 int cfx_form_destroy(cfx_form_t a);
+/* build the form's derived tables now (row plan: cell / row marks, row classes, rule maps, facet incidence, stencil
+ * masks, the row-ordered staging layout of a linear form) instead of inside the first assembly call that needs them */
+int cfx_form_prepare(cfx_form_t a);
 /* create_sparsity_pattern(): assembler.h:567-592 (+ :442-529, :538-560) */
 int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out);
 int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* view);

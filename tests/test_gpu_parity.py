@@ -201,3 +201,26 @@ def test_device_memset_any_size_and_alignment():
         want = host.copy()
         want[off:off + size] = byte
         assert np.array_equal(got, want), (off, size)
+
+
+def test_overlapped_assembly_matches(case):
+    """L next to a on two HIP streams (cfx_overlap_*): same matrix, same vector."""
+    import torch
+
+    import cutfemx_amd as cfx
+    fem, sysm, ref = cfx.fem, case["sys"], case["ref"]
+    b = torch.zeros(case["V"].ndofs, device="cuda", dtype=torch.float64)
+    for _ in range(2):          # twice: the second pass runs with every table cached
+        b.zero_()
+        sysm.L.prepare()
+        with fem.overlap() as lanes:
+            lanes.side(lambda: fem.assemble_vector(sysm.L, b))
+            A = fem.create_matrix(sysm.a)
+            fem.assemble_matrix(sysm.a, A=A)
+        assert np.array_equal(A.indptr, ref["indptr"]) and np.array_equal(A.indices, ref["indices"])
+        assert rel_err(A.data, ref["values"]) < RTOL
+        assert rel_err(b.cpu().numpy(), ref["b"]) < RTOL
+    with pytest.raises(RuntimeError):
+        with fem.overlap():
+            with fem.overlap():
+                pass

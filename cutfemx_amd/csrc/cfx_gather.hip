@@ -1805,6 +1805,92 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
         }
     }
   }
+  // ---- facet items (rows next to the interface): ghost penalty / extension terms on block spaces.  The macro
+  // row (local dof i of cell 0 or 1, component kc) of the staged (2 NLOC)^2 facet tensor, one cell's half of the
+  // columns at a time (NLOC accumulators live, not 2 NLOC)
+  const bool facets = live && len > 0 && A.d2f_off != nullptr && (A.mark_mask & 0xF0u) != 0;
+  const int64_t fpos = (facets && A.special_mark[r]) ? (int64_t)A.special_pos[r] : -1; // incidence is per special row
+  const int64_t fb = fpos >= 0 ? A.d2f_off[fpos] : 0;
+  const int nf = fpos >= 0 ? (int)(A.d2f_off[fpos + 1] - fb) : 0;
+  for (int base = 0;; base += G)
+  {
+    if (__ballot(base + gl < nf) == 0) break;
+    const int t = base + gl;
+    const bool has = t < nf;
+    const int64_t f = has ? (int64_t)A.d2f[fb + t] : 0;
+    int64_t fc[2] = {0, 0};
+    int32_t cols[2][ND];
+    int irow[2] = {-1, -1};
+    if (has)
+    {
+      fc[0] = A.facet_rows[4 * f]; fc[1] = A.facet_rows[4 * f + 2];
+#pragma unroll
+      for (int side = 0; side < 2; ++side)
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+        {
+          cols[side][j] = A.dofmap[fc[side] * ND + j];
+          irow[side] = cols[side][j] == (int32_t)r ? side * ND + j : irow[side]; // r may be a dof of both cells
+        }
+    }
+    constexpr int W = 2 * NLOC;
+    const double* T = A.facet_tensors + f * (int64_t)(W * W);
+#pragma unroll
+    for (int side = 0; side < 2; ++side)
+    {
+      double acc[NLOC];
+      int csl[ND];
+#pragma unroll
+      for (int j = 0; j < NLOC; ++j) acc[j] = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) csl[j] = -1;
+      if (has)
+      {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) // the macro rows of r in cell 0 and in cell 1 both land in global row R
+          if (irow[m] >= 0)
+          {
+            const double* Tr = T + (int64_t)(irow[m] * BS + kc) * W + side * NLOC;
+#pragma unroll
+            for (int j = 0; j < NLOC; ++j) acc[j] += Tr[j];
+          }
+#pragma unroll
+        for (int j = 0; j < ND; ++j) csl[j] = find_slot(cols[side][j]);
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int b = 0; b < BS; ++b)
+            if (row_bc || (A.bc1 != nullptr && A.bc1[(int64_t)cols[side][j] * BS + b] != 0)) acc[j * BS + b] = 0.0;
+      }
+      if constexpr (ORDERED)
+      {
+        for (int turn = 0; turn < G; ++turn)
+        {
+          if (gl == turn)
+          {
+#pragma unroll
+            for (int j = 0; j < ND; ++j)
+              if (csl[j] >= 0)
+              {
+#pragma unroll
+                for (int b = 0; b < BS; ++b) s_val[grp][csl[j] * BS + b] += acc[j * BS + b];
+              }
+          }
+          __syncthreads();
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+          if (csl[j] >= 0)
+          {
+#pragma unroll
+            for (int b = 0; b < BS; ++b) atomicAdd(&s_val[grp][csl[j] * BS + b], acc[j * BS + b]);
+          }
+      }
+    }
+  }
   __syncthreads();
   for (int k = gl; k < lene; k += G) A.values[rb + k] += s_val[grp][k];
 }
@@ -2310,7 +2396,9 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
       const char* bg = getenv("CFX_BLOCK_GATHER");
       if ((bg && bg[0] == '0') || need > free_b / 2) return false;
     }
-    if (V->bs != V->mesh->tdim || plan.nfacets > 0 || P->max_row_len > 256) return false;
+    if (V->bs != V->mesh->tdim || P->max_row_len > 256) return false;
+    for (const auto& I : a->integrals) // facet items: the ghost-penalty gradient jump (extension pairs keep the entity path)
+      if (I.type == CFX_INTERIOR_FACET && I.kernel != CFX_K_GHOST_GRADJUMP) return false;
     if (V->mesh->tdim == 2)
       err = V->degree == 1 ? run_matrix_block<2, 1, 2>(a, P, bc0, bc1, values) : run_matrix_block<2, 2, 2>(a, P, bc0, bc1, values);
     else

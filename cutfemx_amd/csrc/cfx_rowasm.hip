@@ -584,6 +584,63 @@ __global__ void pattern_diag_kernel(int64_t ndofs, int bs, const uint8_t* __rest
     for (int b = 0; b < bs; ++b) indices[indptr[r * bs + a] + b] = (int32_t)(r * bs + b);
 }
 
+// indptr of the whole matrix in two passes over the rows, the inactive rows' diagonal blocks included: the length of
+// an active row comes from the pattern kernels (counts), an inactive row holds its bs x bs diagonal block
+// (assembler.h:538-560) -- no counts fill, no separate diagonal pass, one read of the row marks per pass.
+__global__ void __launch_bounds__(kBlock) indptr_reduce_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                                               const int32_t* __restrict__ counts, int64_t* __restrict__ tile_sums)
+{
+  const int64_t tile = (int64_t)blockIdx.x * kTile;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t R = tile + k * kBlock + threadIdx.x;
+    if (R < nrows) s += rowmark[R / bs] ? counts[R] : bs;
+  }
+  int64_t total;
+  (void)block_exclusive_scan<int64_t>(s, total);
+  if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                                              const int32_t* __restrict__ counts,
+                                                              const int64_t* __restrict__ tile_offsets,
+                                                              int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
+{
+  __shared__ int64_t s_v[kTile];
+  const int64_t tile = (int64_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    const int64_t R = tile + i;
+    s_v[i] = R < nrows ? (rowmark[R / bs] ? (int64_t)counts[R] : (int64_t)bs) : 0;
+  }
+  __syncthreads();
+  int64_t v[kScanItems], s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { v[k] = s_v[threadIdx.x * kScanItems + k]; s += v[k]; }
+  int64_t total;
+  int64_t off = block_exclusive_scan<int64_t>(s, total) + tile_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) { s_v[threadIdx.x * kScanItems + k] = off; off += v[k]; }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int i = k * kBlock + threadIdx.x;
+    const int64_t R = tile + i;
+    if (R >= nrows) continue;
+    const int64_t p = s_v[i];
+    indptr[R] = p;
+    const int64_t dof = R / bs;
+    if (!rowmark[dof])
+      for (int b = 0; b < bs; ++b) indices[p + b] = (int32_t)(dof * bs + b);
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) indptr[nrows] = tile_offsets[blockIdx.x] + total;
+}
+
 template <int T>
 __global__ void pattern_write_kernel(int64_t n_active, const int32_t* __restrict__ active_rows, int bs,
                                      const int32_t* __restrict__ tmp, const int32_t* __restrict__ len,
@@ -961,6 +1018,47 @@ __global__ void tile_ids_kernel(int64_t n, const int32_t* __restrict__ first, co
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ids[i] = rows[first[i]] / kRowTile;
+}
+
+// pass 2 by row tile (Stencil tiles, plan.plain_tile_first / _id): the rows of a tile are neighbours in the stencil
+// and in the CSR arrays.  A tile whose kRowTile rows are all plain and hold their whole stencil -- the bulk of the
+// domain -- is one contiguous copy nbr[st_off[r0] ...] -> indices[indptr[r0] ...]; other tiles go row by row.
+__global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(int64_t n_tiles, const int32_t* __restrict__ tile_first,
+                                                                    const int32_t* __restrict__ tile_id, int64_t n_plain,
+                                                                    const int32_t* __restrict__ rows,
+                                                                    const unsigned long long* __restrict__ masks,
+                                                                    const int64_t* __restrict__ off,
+                                                                    const int32_t* __restrict__ nbr,
+                                                                    const int64_t* __restrict__ indptr,
+                                                                    int32_t* __restrict__ indices, int64_t ndofs)
+{
+  constexpr int G = kWave / kRowTile;
+  const int lane = threadIdx.x, g = lane / G, gl = lane % G;
+  const int64_t w = blockIdx.x;
+  if (w >= n_tiles) return;
+  const int64_t i0 = tile_first[w], t = tile_id[w], r0 = t * kRowTile;
+  int32_t rl = -1;
+  if (lane < kRowTile && i0 + lane < n_plain) rl = rows[i0 + lane];
+  unsigned pm = (rl >= 0 && rl / kRowTile == t) ? 1u << (rl % kRowTile) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) pm |= __shfl_xor(pm, o, 64);
+  const int64_t rr = r0 + (lane < kRowTile ? lane : kRowTile);
+  const int64_t so = off[rr < ndofs ? rr : ndofs], io = indptr[rr < ndofs ? rr : ndofs];
+  const bool live = (pm >> g) & 1u;
+  const unsigned long long m = live ? masks[i0 + __popc(pm & ((1u << g) - 1u))] : 0ull;
+  const int64_t sb = __shfl(so, g, 64), ob = __shfl(io, g, 64);
+  const int slen = (int)(__shfl(so, g + 1, 64) - sb);
+  const bool full = live && (m & (m + 1ull)) == 0ull && __popcll(m) == slen;
+  const int64_t sb0 = __shfl(so, 0, 64), ob0 = __shfl(io, 0, 64);
+  const int nst = (int)(__shfl(so, kRowTile, 64) - sb0);
+  if (pm == 0xffffu && __ballot(!full) == 0ull && __shfl(io, kRowTile, 64) - ob0 == nst)
+  {
+    for (int j = lane; j < nst; j += kWave) indices[ob0 + j] = nbr[sb0 + j];
+    return;
+  }
+  if (!live) return;
+  for (int p = gl; p < slen; p += G)
+    if ((m >> p) & 1ull) indices[ob + __popcll(m & ((1ull << p) - 1ull))] = nbr[sb + p];
 }
 
 } // namespace
@@ -1402,7 +1500,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   P->nrows = V->ndofs * V->bs;
   DevArray<int32_t> counts(P->nrows), len(n_h), tmp;
   ZeroFlag overflow, maxlen;
-  launch("pattern_init", fill_i32_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, (int32_t)V->bs, counts.p);
+  // (the rows off the active set are never read from `counts`: indptr_*_kernel knows their length)
   S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
   int T = 64;
   if (n_h > 0)
@@ -1438,12 +1536,22 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
   P->indptr.alloc(P->nrows + 1);
-  exclusive_scan(counts.p, P->indptr.p, P->nrows);
-  P->nnz = read_scalar(P->indptr.p + P->nrows);
-  P->indices.alloc(P->nnz);
-  launch("pattern_diag", pattern_diag_kernel, grid_for(V->ndofs), dim3(kBlock), 0, V->ndofs, V->bs, plan.rowmark.p,
-         P->indptr.p, P->indices.p);
-  if (use_stencil)
+  {
+    const int64_t ntiles = (P->nrows + kTile - 1) / kTile;
+    DevArray<int64_t> sums(ntiles), offs(ntiles + 1);
+    launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
+           counts.p, sums.p);
+    exclusive_scan(sums.p, offs.p, ntiles);
+    P->nnz = read_scalar(offs.p + ntiles);
+    P->indices.alloc(P->nnz);
+    launch("pattern_indptr", indptr_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
+           counts.p, offs.p, P->indptr.p, P->indices.p);
+  }
+  if (use_stencil && space_stencil_tiles(V).tiles_usable && plan.n_plain_tiles > 0)
+    launch("pattern_plain_write", pattern_plain_tiles_kernel, wave_grid(plan.n_plain_tiles), dim3(kWave), 0, plan.n_plain_tiles,
+           plan.plain_tile_first.p, plan.plain_tile_id.p, plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p,
+           st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p, V->ndofs);
+  else if (use_stencil)
     launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows * CFX_PPW_LANES), dim3(kBlock), 0,
            plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
   if (n_h > 0)

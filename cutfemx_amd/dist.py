@@ -103,15 +103,38 @@ class DistComm:
         self._h = C.c_void_p()
         l = _lib.lib()
         self.rccl = dist.get_backend(group) == "nccl"
+        host_group = group
         if self.rccl:
+            # every rank must end up on the same transport: the ranks agree on whether RCCL came up everywhere,
+            # and fall back together to the host-staged mode over a gloo side group otherwise
+            ok, why = 1, ""
             buf = (C.c_char * 128)()
-            if self.rank == 0:
-                _lib.check(l.cfx_dist_unique_id(buf))
+            if self.rank == 0 and l.cfx_dist_unique_id(buf) != 0:
+                buf = (C.c_char * 128)()    # all zero: "no id", every rank then skips the RCCL communicator
             obj = [bytes(buf)]
             dist.broadcast_object_list(obj, src=0, group=group)
-            uid = (C.c_char * 128).from_buffer_copy(obj[0])
-            _lib.check(l.cfx_dist_comm_create(self.world, self.rank, uid, C.byref(self._h)))
-        else:
+            try:
+                if not any(obj[0]):
+                    raise RuntimeError("rank 0 could not make an ncclUniqueId: " + (l.cfx_last_error() or b"").decode())
+                uid = (C.c_char * 128).from_buffer_copy(obj[0])
+                _lib.check(l.cfx_dist_comm_create(self.world, self.rank, uid, C.byref(self._h)))
+            except Exception as e:          # noqa: BLE001 -- reported below, then the collective fallback
+                ok, why = 0, f"{type(e).__name__}: {e}"
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            if int(flag.item()) == 0:
+                import sys
+                print(f"cutfemx_amd.dist: RCCL communicator unavailable on some rank ({why or 'another rank'}); "
+                      "falling back to host-staged exchanges over gloo", file=sys.stderr)
+                if self._h:
+                    l.cfx_dist_comm_destroy(self._h)
+                    self._h = C.c_void_p()
+                self.rccl = False
+                host_group = dist.new_group(backend="gloo")
+        if not self.rccl:
+            group = host_group
+            self.group = group
+
             def exchange(_user, n, peers, send, send_bytes, recv, recv_bytes):
                 try:
                     ops, keep = [], []

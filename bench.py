@@ -371,15 +371,20 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # command, tools/profile_round.sh); only quoted for the mesh they were collected on
         traffic, tnote = None, "no PMC pass for this mesh in profiles/"
-        tfile = ROOT / "profiles" / "r01_traffic.json"
-        if tfile.exists():
-            t = json.loads(tfile.read_text())
+        tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+        if tfiles:
+            t = json.loads(tfiles[-1].read_text())      # the latest round's passes
             e = t["kernels"].get(dominant)
             if t.get("mesh") == n and e and "fetch_bytes_raw" in e and "write_bytes" in e:
-                traffic = e["fetch_bytes_raw"] + e["write_bytes"]
-                tnote = (f"FETCH_SIZE + WRITE_SIZE per launch from {t['source']} (raw counters; WRITE_SIZE equals the "
-                         "CSR value bytes written, and the gfx950 half-count of FETCH_SIZE applies to 16 B/lane "
-                         "streaming loads, not to this kernel's mix: DESIGN.md 4)")
+                # MI355X_MICROARCH.md, HBM: on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane coalesced
+                # streaming read -- doubled for the kernels whose fetches are such streams (classify: one int4
+                # dofmap row per lane); other access mixes are uncalibrated and quoted raw; WRITE_SIZE is exact
+                streaming = dominant in ("classify",)
+                traffic = (2.0 if streaming else 1.0) * e["fetch_bytes_raw"] + e["write_bytes"]
+                tnote = (f"FETCH_SIZE{' x 2 (gfx950 half-count of 16 B/lane streaming reads)' if streaming else ' (raw)'}"
+                         f" + WRITE_SIZE per launch from {t['source']} (separate rocprofv3 --pmc passes, "
+                         "tools/profile_round.sh); L2 hit rate "
+                         + (f"{e['l2_hit_rate']:.2f}" if "l2_hit_rate" in e else "n/a"))
         roofline = dict(bound="hbm", kernel=dominant, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=None if ach is None else ach / HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_us=k["avg_us"], algorithmic_bytes_per_launch=ab,

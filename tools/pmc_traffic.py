@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_pmc_summary.txt -> profiles/r01_traffic.json: HBM bytes per launch of every kernel
+"""profiles/<tag>_pmc_summary.txt -> profiles/<round>_traffic.json (usage: pmc_traffic.py <summary> <mesh> [round=r02]): HBM bytes per launch of every kernel
 (FETCH_SIZE and WRITE_SIZE are reported in KiB... rocprofv3 derives them as requests x 64 B / 1024)."""
 import json, re, sys
 src, mesh = sys.argv[1], sys.argv[2]
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
 out = {}
 for line in open(src):
     m = re.match(r"(\S.*?)\s+n=\s*\d+\s+(.*)", line)
@@ -18,5 +19,5 @@ for line in open(src):
     if "TCC_HIT_sum" in vals:
         e["l2_hit_rate"] = float(vals["TCC_HIT_sum"]) / (float(vals["TCC_HIT_sum"]) + float(vals["TCC_MISS_sum"]))
 out = {k: v for k, v in out.items() if "fetch_bytes_raw" in v or "write_bytes" in v}
-json.dump({"mesh": int(mesh), "source": src, "kernels": out}, open("profiles/r01_traffic.json", "w"), indent=1, sort_keys=True)
+json.dump({"mesh": int(mesh), "source": src, "kernels": out}, open(f"profiles/{rnd}_traffic.json", "w"), indent=1, sort_keys=True)
 print(len(out), "kernels")

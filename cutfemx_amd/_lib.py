@@ -94,6 +94,10 @@ SYMBOLS = [
     "cfx_dist_unique_id", "cfx_dist_comm_create", "cfx_dist_comm_create_host", "cfx_dist_comm_info", "cfx_dist_comm_destroy",
     "cfx_dist_scatter_forward", "cfx_dist_scatter_reverse_add", "cfx_dist_scatter_reverse_matrix", "cfx_dist_indicator_or",
     "cfx_dist_indicator_forward",
+    "cfx_mesh_create_f32", "cfx_cut_create_f32", "cfx_cut_update_f32", "cfx_rules_create_f32", "cfx_rules_view_get_f32",
+    "cfx_rules_physical_points_f32", "cfx_evaluate_normals_f32", "cfx_evaluate_values_f32", "cfx_widen_f32",
+    "cfx_assemble_matrix_f32", "cfx_assemble_matrix_zeroed_f32", "cfx_assemble_vector_f32", "cfx_apply_lifting_f32",
+    "cfx_set_bc_f32", "cfx_zero_rows_f32", "cfx_deactivate_outside_f32",
 ]
 
 _lib = None
@@ -197,7 +201,7 @@ def as_ptr(a, dtype, keep: list):
         return C.c_void_p(a.ptr)
     if is_torch(a):
         import torch
-        want = {np.float64: torch.float64, np.int32: torch.int32, np.int8: torch.int8}[dtype]
+        want = {np.float64: torch.float64, np.float32: torch.float32, np.int32: torch.int32, np.int8: torch.int8}[dtype]
         if a.dtype != want or not a.is_contiguous():
             a = a.to(want).contiguous()
         keep.append(a)
@@ -205,6 +209,19 @@ def as_ptr(a, dtype, keep: list):
     arr = np.ascontiguousarray(a, dtype=dtype)
     keep.append(arr)
     return arr.ctypes.data_as(C.c_void_p)
+
+
+def scalar_dtype(a):
+    """np.float32 for a float32 numpy array / torch tensor / DeviceBuffer, else np.float64: which instantiation
+    of the boundary (the reference's T of MatrixCSR<T> / Vector<T> / Function<T>) a container selects."""
+    if a is None:
+        return np.float64
+    if isinstance(a, DeviceBuffer):
+        return np.float32 if a.dtype == np.dtype(np.float32) else np.float64
+    if is_torch(a):
+        import torch
+        return np.float32 if a.dtype == torch.float32 else np.float64
+    return np.float32 if getattr(a, "dtype", None) == np.dtype(np.float32) else np.float64
 
 
 def release_cache():

@@ -348,6 +348,7 @@ struct cfx_rules_s
   int tdim = 0, gdim = 0;
   int64_t nq = 0, nr = 0;
   cfx::DevArray<double> points, weights;
+  cfx::DevArray<float> points_f32, weights_f32; // rounded copies behind cfx_rules_view_get_f32 (made on first use)
   cfx::DevArray<int32_t> offsets, parent_map;
   // rules hosted by facets (cut(level_set, facets, tdim-1)): tdim == mesh tdim - 1, points are coordinates of
   // the host facet's reference simplex spanned by host_verts, parent_map = the caller's facet ids

@@ -25,11 +25,15 @@ class RuntimeQuadratureRules:
 
     kind = "per_entity"
 
-    def __init__(self, handle, mesh: Mesh):
+    def __init__(self, handle, mesh: Mesh, dtype=np.float64):
         self._h = handle
         self.mesh = mesh
+        self.dtype = np.dtype(dtype)       # RuntimeQuadrature<T>: float32 rules come from a float32 cut / arrays
         v = _lib.RulesView()
-        _lib.check(_lib.lib().cfx_rules_view_get(handle, C.byref(v)))
+        if self.dtype == np.dtype(np.float32):   # same layout, points / weights are the rounded float copies
+            _lib.check(_lib.lib().cfx_rules_view_get_f32(handle, C.byref(v)))
+        else:
+            _lib.check(_lib.lib().cfx_rules_view_get(handle, C.byref(v)))
         self._view = v
         self.tdim, self.gdim = v.tdim, v.gdim
         self.total_points = int(v.nq)
@@ -43,6 +47,14 @@ class RuntimeQuadratureRules:
         keep: list = []
         nq, nr = len(weights), len(parent_map)
         h = C.c_void_p()
+        if _lib.scalar_dtype(points) == np.float32 and _lib.scalar_dtype(weights) == np.float32:
+            _lib.check(_lib.lib().cfx_rules_create_f32(
+                mesh._h, mesh.tdim, C.c_int64(nq), C.c_int64(nr), _lib.as_ptr(points, np.float32, keep),
+                _lib.as_ptr(weights, np.float32, keep), _lib.as_ptr(offsets, np.int32, keep),
+                _lib.as_ptr(parent_map, np.int32, keep), C.byref(h)))
+            r = cls(h, mesh, np.float32)
+            r._keep = [k for k in keep[2:] if _lib.is_device(k)]
+            return r
         _lib.check(_lib.lib().cfx_rules_create(
             mesh._h, mesh.tdim, C.c_int64(nq), C.c_int64(nr), _lib.as_ptr(points, np.float64, keep),
             _lib.as_ptr(weights, np.float64, keep), _lib.as_ptr(offsets, np.int32, keep),
@@ -59,11 +71,11 @@ class RuntimeQuadratureRules:
 
     @property
     def points(self):
-        return self._get("points", self._view.points, self.total_points * self.tdim, np.float64, (-1, self.tdim))
+        return self._get("points", self._view.points, self.total_points * self.tdim, self.dtype, (-1, self.tdim))
 
     @property
     def weights(self):
-        return self._get("weights", self._view.weights, self.total_points, np.float64)
+        return self._get("weights", self._view.weights, self.total_points, self.dtype)
 
     @property
     def offsets(self):
@@ -77,8 +89,10 @@ class RuntimeQuadratureRules:
     def physical_points(self):
         """(gdim, total_nq), as python/cutfemx/cut.py:25-49."""
         if "phys" not in self._cache:
-            out = np.empty((self.total_points, self.gdim))
-            _lib.check(_lib.lib().cfx_rules_physical_points(self._h, out.ctypes.data_as(C.c_void_p)))
+            out = np.empty((self.total_points, self.gdim), dtype=self.dtype)
+            fn = (_lib.lib().cfx_rules_physical_points_f32 if self.dtype == np.dtype(np.float32)
+                  else _lib.lib().cfx_rules_physical_points)
+            _lib.check(fn(self._h, out.ctypes.data_as(C.c_void_p)))
             self._cache["phys"] = np.ascontiguousarray(out.T)
         return self._cache["phys"]
 
@@ -101,7 +115,7 @@ class RuntimeQuadratureRules:
         (python/cutfemx/_runintgen_adapter.py:605-680)."""
         h = C.c_void_p()
         _lib.check(_lib.lib().cfx_facet_rules_to_cells(self._h, int(side), C.byref(h)))
-        return RuntimeQuadratureRules(h, self.mesh)
+        return RuntimeQuadratureRules(h, self.mesh, self.dtype)
 
     def slice_by_parent(self, cell_lo: int, cell_hi: int, device):
         """Zero-copy sub-rule-set of the rules whose parent cell lies in
@@ -142,6 +156,7 @@ class CutData:
         self._level_sets = tuple(level_sets)
         self._keep = list(keep)
         self._names = frozen_level_set_names([f.name for f in level_sets]) if names is None else tuple(names)
+        self.dtype = np.dtype(np.float64)     # scalar type of the level-set Functions the cut was made from
 
     def update(self) -> None:
         update(self)
@@ -269,11 +284,16 @@ def _normalise_level_sets(level_set) -> list[Function]:
     return level_sets
 
 
-def _value_ptrs(level_sets, keep):
+def _value_ptrs(level_sets, keep, dtype=np.float64):
     arr = (C.c_void_p * len(level_sets))()
     for i, f in enumerate(level_sets):
-        arr[i] = _lib.as_ptr(f.values, np.float64, keep)
+        arr[i] = _lib.as_ptr(f.values, dtype, keep)
     return arr
+
+
+def _level_set_dtype(level_sets):
+    """float32 when every level-set Function holds float32 values (declare_cut_api<float>), else float64."""
+    return np.float32 if all(_lib.scalar_dtype(f.values) == np.float32 for f in level_sets) else np.float64
 
 
 def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "auto",
@@ -303,7 +323,8 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
         raise ValueError("level-set function must be scalar")  # cut.cpp:445-460
     opt = _lib.CutOptions(cut_approximation_order, max_refinement_iterations, edge_max_depth, 0)
     keep: list = []
-    vals = _value_ptrs(level_sets, keep)
+    f32 = _level_set_dtype(level_sets) == np.float32 and not (entities is not None and entity_dim == tdim - 1)
+    vals = _value_ptrs(level_sets, keep, np.float32 if f32 else np.float64)
     h = C.c_void_p()
     if entities is not None and entity_dim == tdim - 1:
         # facets as hosts (cut.cpp:540-591, python/tests/test_cut_api.py:171-187, 349-367): the facets are their
@@ -332,9 +353,15 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
         cd._entity_dim = int(entity_dim)
         cd._host_rows = entities
         return cd
-    _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
-                                         C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
-    cd = CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
+    if f32:   # the engine widens the values into its own copy: nothing of the caller's is aliased
+        _lib.check(_lib.lib().cfx_cut_create_f32(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
+                                                 C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
+        cd = CutData(h, level_sets, keep=[V], names=names)
+        cd.dtype = np.dtype(np.float32)
+    else:
+        _lib.check(_lib.lib().cfx_cut_create(V.mesh._h, len(level_sets), V._dofmap_ptr, V.ndofs_cell,
+                                             C.c_int64(V.ndofs), vals, C.byref(opt), C.byref(h)))
+        cd = CutData(h, level_sets, keep=[k for k in keep if _lib.is_device(k)] + [V], names=names)
     if entities is not None:   # cell subset as host (python/tests/test_cut_api.py:160-168)
         cells = np.ascontiguousarray(np.asarray(entities, dtype=np.int32))
         _lib.check(_lib.lib().cfx_cut_restrict(h, cells.ctypes.data_as(C.c_void_p), C.c_int64(cells.size)))
@@ -345,6 +372,10 @@ def cut(level_set, entities=None, entity_dim=None, *, cut_approximation: str = "
 def update(cut_data: CutData) -> None:
     """Re-classify from the current level-set values (python/cutfemx/cut.py:252-254)."""
     keep: list = []
+    if cut_data.dtype == np.dtype(np.float32):
+        vals = _value_ptrs(cut_data._level_sets, keep, np.float32)
+        _lib.check(_lib.lib().cfx_cut_update_f32(cut_data._h, vals))
+        return
     vals = _value_ptrs(cut_data._level_sets, keep)
     _lib.check(_lib.lib().cfx_cut_update(cut_data._h, vals))
     cut_data._keep = [k for k in keep if _lib.is_device(k)] + [cut_data._level_sets[0].function_space]
@@ -382,7 +413,7 @@ def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: 
     h = C.c_void_p()
     _lib.check(_lib.lib().cfx_runtime_quadrature(cut_data._h, _engine_selector(cut_data, ls_part), int(order), backend.encode(),
                                                  C.byref(h)))
-    return RuntimeQuadratureRules(h, cut_data.mesh)
+    return RuntimeQuadratureRules(h, cut_data.mesh, cut_data.dtype)
 
 
 def runtime_quadratures(cut_data: CutData, ls_parts: Sequence[str], order: int, *, backend: str = "straight"):
@@ -459,7 +490,7 @@ def full_facet_rules(cut_data: CutData, ls_part: str | None, order: int) -> Runt
     h = C.c_void_p()
     sel = None if ls_part is None else _engine_selector(cut_data, ls_part)
     _lib.check(_lib.lib().cfx_full_facet_rules(cut_data._h, sel, int(order), C.byref(h)))
-    return RuntimeQuadratureRules(h, cut_data.mesh)
+    return RuntimeQuadratureRules(h, cut_data.mesh, cut_data.dtype)
 
 
 def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, include_ghosts: bool = False):
@@ -483,19 +514,23 @@ def normal(cut_data: CutData, rules: RuntimeQuadratureRules, level_set: int = 0,
            device: bool = False):
     """Unit normals grad(phi)/|grad(phi)| at the rule points, (nq, gdim)
     (cpp/cutfemx/level_set/normal.h:39-187).  device=True keeps them in HBM."""
+    f32 = rules.dtype == np.dtype(np.float32)
+    dt = np.float32 if f32 else np.float64
+    fn = _lib.lib().cfx_evaluate_normals_f32 if f32 else _lib.lib().cfx_evaluate_normals
+    sgn = C.c_float(sign) if f32 else C.c_double(sign)
     if device:
-        buf = _lib.DeviceBuffer(rules.total_points * rules.gdim, np.float64, (rules.total_points, rules.gdim))
-        _lib.check(_lib.lib().cfx_evaluate_normals(cut_data._h, level_set, rules._h, C.c_double(sign),
-                                                   C.c_void_p(buf.ptr)))
+        buf = _lib.DeviceBuffer(rules.total_points * rules.gdim, dt, (rules.total_points, rules.gdim))
+        _lib.check(fn(cut_data._h, level_set, rules._h, sgn, C.c_void_p(buf.ptr)))
         return buf
-    out = np.empty((rules.total_points, rules.gdim))
-    _lib.check(_lib.lib().cfx_evaluate_normals(cut_data._h, level_set, rules._h, C.c_double(sign),
-                                               out.ctypes.data_as(C.c_void_p)))
+    out = np.empty((rules.total_points, rules.gdim), dtype=dt)
+    _lib.check(fn(cut_data._h, level_set, rules._h, sgn, out.ctypes.data_as(C.c_void_p)))
     return out
 
 
 def level_set_value(cut_data: CutData, rules: RuntimeQuadratureRules, level_set: int = 0) -> np.ndarray:
     """phi at the rule points (cpp/cutfemx/level_set/value.h:34-119)."""
-    out = np.empty(rules.total_points)
-    _lib.check(_lib.lib().cfx_evaluate_values(cut_data._h, level_set, rules._h, out.ctypes.data_as(C.c_void_p)))
+    f32 = rules.dtype == np.dtype(np.float32)
+    out = np.empty(rules.total_points, dtype=np.float32 if f32 else np.float64)
+    fn = _lib.lib().cfx_evaluate_values_f32 if f32 else _lib.lib().cfx_evaluate_values
+    _lib.check(fn(cut_data._h, level_set, rules._h, out.ctypes.data_as(C.c_void_p)))
     return out

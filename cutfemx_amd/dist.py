@@ -385,7 +385,7 @@ class _DevView:
 
 def as_torch(ptr, n, dtype, device):
     import torch
-    typestr = {"int32": "<i4", "int64": "<i8", "float64": "<f8", "int8": "|i1"}[dtype]
+    typestr = {"int32": "<i4", "int64": "<i8", "float64": "<f8", "float32": "<f4", "int8": "|i1"}[dtype]
     if n == 0:
         return torch.empty(0, dtype=getattr(torch, dtype), device=device)
     return torch.as_tensor(_DevView(ptr, n, typestr), device=device)

@@ -74,14 +74,41 @@ class Integral:
         if self.point_data is not None:
             pdata = self.point_data
             stride = 1 if pdata.ndim == 1 else int(pdata.shape[1])
-            pd = _lib.as_ptr(pdata, np.float64, keep)
+            pd = _f64_ptr(pdata, keep)
         params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
         coeff = None
         if self.coefficient is not None:
             values = getattr(self.coefficient, "values", self.coefficient)   # a Function or its dof array
-            coeff = _lib.as_ptr(values, np.float64, keep)
+            coeff = _f64_ptr(values, keep)
         return _lib.Integral(itype, self.kernel, int(self.qdegree), stride, ent_ptr, n_ent,
                              self.rules._h if self.rules is not None else None, pd, params, coeff)
+
+
+class _Widened:
+    """fp64 HBM copy of a float32 device array (cfx_widen_f32), released with the integral that holds it."""
+
+    def __init__(self, ptr, n):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().cfx_widen_f32(C.c_void_p(ptr), C.c_int64(n), C.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.load().cfx_device_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def _f64_ptr(a, keep: list):
+    """Per-point data / coefficient values for a cfx_integral: float32 device arrays are widened in HBM."""
+    if _lib.scalar_dtype(a) == np.float32 and _lib.is_device(a):
+        n = a.size if isinstance(a, _lib.DeviceBuffer) else int(a.numel())
+        w = _Widened(a.ptr if isinstance(a, _lib.DeviceBuffer) else a.contiguous().data_ptr(), n)
+        keep.append(w)
+        return C.c_void_p(w.ptr)
+    return _lib.as_ptr(a, np.float64, keep)
 
 
 class CutForm:
@@ -149,9 +176,13 @@ def form(integrals, V: FunctionSpace, rank: int | None = None) -> CutForm:
 class MatrixCSR:
     """dolfinx.la.MatrixCSR stand-in: indptr (int64), indices (int32), data in HBM."""
 
-    def __init__(self, pattern_handle, V: FunctionSpace, values=None):
+    def __init__(self, pattern_handle, V: FunctionSpace, values=None, dtype=None):
         self._p = pattern_handle
         self.function_space = V
+        # scalar type T of la::MatrixCSR<T> (wrappers/fem.cpp:490-500): float64, or float32 through the *_f32 entry points
+        self.dtype = np.dtype(_lib.scalar_dtype(values) if dtype is None else dtype)
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError("MatrixCSR holds float64 or float32 values")
         v = _lib.PatternView()
         _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
         self._view = v
@@ -160,20 +191,21 @@ class MatrixCSR:
         self._zero_pending = False
         if values is None:
             p = C.c_void_p()
-            _lib.check(_lib.lib().cfx_device_alloc(C.byref(p), C.c_size_t(8 * max(self.nnz, 1))))
+            _lib.check(_lib.lib().cfx_device_alloc(C.byref(p), C.c_size_t(self.dtype.itemsize * max(self.nnz, 1))))
             self._vptr = p.value
             self.set_value(0.0)
         else:  # caller-owned HBM buffer: set_value / cfx_assemble_matrix write 8*nnz bytes through the raw pointer
             if isinstance(values, _lib.DeviceBuffer):
-                ok_type, count, ptr = values.dtype == np.dtype(np.float64), values.size, values.ptr
+                ok_type, count, ptr = values.dtype == self.dtype, values.size, values.ptr
             elif _lib.is_torch(values):
                 import torch
-                ok_type = values.dtype == torch.float64 and values.is_cuda and values.is_contiguous()
+                want = torch.float32 if self.dtype == np.dtype(np.float32) else torch.float64
+                ok_type = values.dtype == want and values.is_cuda and values.is_contiguous()
                 count, ptr = int(values.numel()), values.data_ptr()
             else:
                 raise TypeError("values must be a device torch tensor or a DeviceBuffer")
             if not ok_type:
-                raise TypeError("values must be a contiguous float64 buffer in HBM")
+                raise TypeError(f"values must be a contiguous {self.dtype} buffer in HBM")
             if count < self.nnz:
                 _lib.lib().cfx_pattern_destroy(self._p)
                 self._p = None
@@ -186,7 +218,7 @@ class MatrixCSR:
         """HBM address of the value array; a pending set_value(0) is carried out first."""
         if self._zero_pending:
             self._zero_pending = False
-            _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(self._vptr), 0, C.c_size_t(8 * self.nnz)))
+            _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(self._vptr), 0, C.c_size_t(self.dtype.itemsize * self.nnz)))
         return self._vptr
 
     @values_ptr.setter
@@ -200,7 +232,7 @@ class MatrixCSR:
             self._zero_pending = True
             return
         self._zero_pending = False
-        z = np.full(self.nnz, float(v))
+        z = np.full(self.nnz, float(v), dtype=self.dtype)
         _lib.check(_lib.lib().cfx_copy(C.c_void_p(self._vptr), z.ctypes.data_as(C.c_void_p),
                                        C.c_size_t(z.nbytes)))
 
@@ -209,7 +241,7 @@ class MatrixCSR:
         ip = _lib.download(self._view.indptr + 8 * lo, hi - lo + 1, np.int64)
         e0, e1 = int(ip[0]), int(ip[-1])
         ix = _lib.download(self._view.indices + 4 * e0, e1 - e0, np.int32)
-        va = _lib.download(self.values_ptr + 8 * e0, e1 - e0, np.float64)
+        va = _lib.download(self.values_ptr + self.dtype.itemsize * e0, e1 - e0, self.dtype)
         return ip - e0, ix, va
 
     def torch_views(self, device):
@@ -217,7 +249,7 @@ class MatrixCSR:
         from .dist import as_torch
         return (as_torch(self._view.indptr, self.nrows + 1, "int64", device),
                 as_torch(self._view.indices, self.nnz, "int32", device),
-                as_torch(self.values_ptr, self.nnz, "float64", device))
+                as_torch(self.values_ptr, self.nnz, self.dtype.name, device))
 
     @property
     def indptr(self):
@@ -229,7 +261,7 @@ class MatrixCSR:
 
     @property
     def data(self):
-        return _lib.download(self.values_ptr, self.nnz, np.float64)
+        return _lib.download(self.values_ptr, self.nnz, self.dtype)
 
     def scatter_reverse(self):
         """Serial: nothing to reduce (multi-GPU reduction lives in cutfemx_amd.dist)."""
@@ -254,12 +286,13 @@ class MatrixCSR:
             pass
 
 
-def create_matrix(a: CutForm, values=None) -> MatrixCSR:
+def create_matrix(a: CutForm, values=None, dtype=None) -> MatrixCSR:
     """Sparsity of a bilinear form incl. the all-rows diagonal
-    (python/cutfemx/fem.py:810-848 -> assembler.h:567-592)."""
+    (python/cutfemx/fem.py:810-848 -> assembler.h:567-592).  dtype (or a float32 `values` buffer) selects the
+    scalar type of the matrix: float64 (default) or float32."""
     p = C.c_void_p()
     _lib.check(_lib.lib().cfx_create_sparsity(a._h, C.byref(p)))
-    return MatrixCSR(p, a.function_space, values)
+    return MatrixCSR(p, a.function_space, values, dtype)
 
 
 def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixCSR:
@@ -272,24 +305,25 @@ def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixC
     if bcs is not None:
         b0, b1 = bcs if isinstance(bcs, tuple) else (bcs, bcs)
         bc0, bc1 = _lib.as_ptr(b0, np.int8, keep), _lib.as_ptr(b1, np.int8, keep)
+    l = _lib.lib()
+    f32 = A.dtype == np.dtype(np.float32)
     if A._zero_pending:     # A.set_value(0) + assemble_matrix(A, a, bcs) as one call
         A._zero_pending = False
-        _lib.check(_lib.lib().cfx_assemble_matrix_zeroed(a._h, A._p, bc0, bc1, C.c_void_p(A._vptr)))
+        fn = l.cfx_assemble_matrix_zeroed_f32 if f32 else l.cfx_assemble_matrix_zeroed
     else:
-        _lib.check(_lib.lib().cfx_assemble_matrix(a._h, A._p, bc0, bc1, C.c_void_p(A._vptr)))
+        fn = l.cfx_assemble_matrix_f32 if f32 else l.cfx_assemble_matrix
+    _lib.check(fn(a._h, A._p, bc0, bc1, C.c_void_p(A._vptr)))
     return A
 
 
-def assemble_vector(L: CutForm, b=None):
+def assemble_vector(L: CutForm, b=None, dtype=np.float64):
     """Assemble a linear form (python/cutfemx/fem.py:851-883).  Returns a numpy
-    vector, or accumulates into `b` (numpy array or device torch tensor)."""
+    vector, or accumulates into `b` (numpy array or device torch tensor; float64 or float32)."""
     V = L.function_space
     if b is None:
-        b = np.zeros(V.ndofs * V.bs)
-    if _lib.is_torch(b):
-        _lib.check(_lib.lib().cfx_assemble_vector(L._h, C.c_void_p(b.data_ptr())))
-    else:
-        _lib.check(_lib.lib().cfx_assemble_vector(L._h, b.ctypes.data_as(C.c_void_p)))
+        b = np.zeros(V.ndofs * V.bs, dtype=dtype)
+    fn = _lib.lib().cfx_assemble_vector_f32 if _lib.scalar_dtype(b) == np.float32 else _lib.lib().cfx_assemble_vector
+    _lib.check(fn(L._h, _vec_ptr(b)))
     return b
 
 
@@ -303,6 +337,11 @@ def apply_lifting(b, a: CutForm, bc_markers, bc_values, x0=None, alpha: float = 
     `bc_markers` (int8) / `bc_values` / `x0` hold one entry per dof; one bilinear form,
     i.e. one block of the reference's list-of-forms signature."""
     keep: list = []
+    if _lib.scalar_dtype(b) == np.float32:
+        _lib.check(_lib.lib().cfx_apply_lifting_f32(
+            a._h, _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float32, keep),
+            _lib.as_ptr(x0, np.float32, keep), C.c_float(alpha), _vec_ptr(b)))
+        return b
     _lib.check(_lib.lib().cfx_apply_lifting(
         a._h, _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float64, keep),
         _lib.as_ptr(x0, np.float64, keep), C.c_double(alpha), _vec_ptr(b)))
@@ -313,6 +352,11 @@ def set_bc(b, bc_markers, bc_values, x0=None, alpha: float = 1.0):
     """b[dofs] = alpha (g - x0) on the marked dofs (dolfinx.fem.set_bc / DirichletBC.set)."""
     keep: list = []
     n = b.numel() if _lib.is_torch(b) else b.size
+    if _lib.scalar_dtype(b) == np.float32:
+        _lib.check(_lib.lib().cfx_set_bc_f32(
+            C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float32, keep),
+            _lib.as_ptr(x0, np.float32, keep), C.c_float(alpha), _vec_ptr(b)))
+        return b
     _lib.check(_lib.lib().cfx_set_bc(
         C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float64, keep),
         _lib.as_ptr(x0, np.float64, keep), C.c_double(alpha), _vec_ptr(b)))
@@ -333,7 +377,10 @@ def assemble_scalar(M: CutForm) -> float:
 def zero_rows(A: MatrixCSR, *, tol: float = 0.0) -> np.ndarray:
     """Rows whose assembled entries are all <= tol in magnitude (python/cutfemx/fem.py:777-782)."""
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_zero_rows(A._p, C.c_void_p(A.values_ptr), C.c_double(tol), C.byref(p), C.byref(n)))
+    if A.dtype == np.dtype(np.float32):
+        _lib.check(_lib.lib().cfx_zero_rows_f32(A._p, C.c_void_p(A.values_ptr), C.c_float(tol), C.byref(p), C.byref(n)))
+    else:
+        _lib.check(_lib.lib().cfx_zero_rows(A._p, C.c_void_p(A.values_ptr), C.c_double(tol), C.byref(p), C.byref(n)))
     out = _lib.download(p.value, n.value, np.int32)
     _lib.check(_lib.lib().cfx_device_free(p))
     return out
@@ -394,6 +441,16 @@ def deactivate_outside(A: MatrixCSR | None, b, domain: ActiveDomain, diagonal: f
     bp = None
     if b is not None:
         bp = C.c_void_p(b.data_ptr()) if _lib.is_torch(b) else b.ctypes.data_as(C.c_void_p)
+    dts = {np.dtype(A.dtype)} if A is not None else set()
+    if b is not None:
+        dts.add(np.dtype(_lib.scalar_dtype(b)))
+    if len(dts) > 1:
+        raise TypeError("deactivate_outside: matrix and vector must have one scalar type")
+    if dts == {np.dtype(np.float32)}:
+        _lib.check(_lib.lib().cfx_deactivate_outside_f32(domain._h, A._p if A is not None else None,
+                                                         C.c_void_p(A.values_ptr) if A is not None else None, bp,
+                                                         C.c_float(diagonal), C.c_float(rhs_value)))
+        return domain
     _lib.check(_lib.lib().cfx_deactivate_outside(domain._h, A._p if A is not None else None,
                                                  C.c_void_p(A.values_ptr) if A is not None else None, bp,
                                                  C.c_double(diagonal), C.c_double(rhs_value)))

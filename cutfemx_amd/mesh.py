@@ -52,6 +52,7 @@ class Mesh:
         self.tdim, self.gdim = tdim, gdim
         self.num_nodes, self.num_cells = int(nnodes), int(ncells)
         self._keep = list(keep)
+        self.dtype = np.dtype(np.float64)      # geometry type of the arrays the mesh was made from
 
     @classmethod
     def from_arrays(cls, tdim: int, x, conn) -> "Mesh":
@@ -60,6 +61,14 @@ class Mesh:
         ncells = conn.shape[0]
         stride = conn.shape[1]
         h = C.c_void_p()
+        if _lib.scalar_dtype(x) == np.float32:
+            # geometry type U = float (wrappers/cut.cpp:403-407): the engine keeps a widened copy of its own
+            _lib.check(_lib.lib().cfx_mesh_create_f32(tdim, tdim, C.c_int64(nnodes), _lib.as_ptr(x, np.float32, keep),
+                                                      C.c_int64(ncells), _lib.as_ptr(conn, np.int32, keep), stride,
+                                                      C.byref(h)))
+            m = cls(h, tdim, tdim, nnodes, ncells, [k for k in keep[1:] if _lib.is_device(k)])
+            m.dtype = np.dtype(np.float32)
+            return m
         _lib.check(_lib.lib().cfx_mesh_create(tdim, tdim, C.c_int64(nnodes), _lib.as_ptr(x, np.float64, keep),
                                               C.c_int64(ncells), _lib.as_ptr(conn, np.int32, keep), stride,
                                               C.byref(h)))

@@ -381,6 +381,58 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t pattern, double* values
                            double* b /* or NULL */, double diagonal, double rhs_value);
 int cfx_active_destroy(cfx_active_t d);
 
+/* ---- float32 instantiation of the boundary --------------------------------------------------------------
+ * python/cutfemx/wrappers/fem.cpp:490-500 declares the runtime assembly for <T, U> in {float, double}^2 and
+ * wrappers/cut.cpp:403-407 the cut API for float and double: T = scalar type of MatrixCSR / Vector / Function,
+ * U = geometry type.  The *_f32 entry points below are the <float, float> row (a mixed <float, double> or
+ * <double, float> caller combines them with the fp64 ones: handles are shared, only the containers differ).
+ * f32 is the type of the containers that cross the boundary; every kernel computes in fp64: inputs are widened
+ * once on upload (exact), results rounded to nearest once on the way out -- see cutfemx_amd/csrc/cfx_f32.hip for
+ * why this engine does not carry a second set of f32-register kernels.  Pointers may be host or HBM as for the
+ * fp64 entry points; the accumulate semantics are the same (values += A, b += L, rounded once). */
+typedef struct
+{
+  int32_t tdim, gdim;
+  int64_t nq, nr;
+  const float* points;       /* [nq*tdim] (HBM), rounded copy owned by the rules handle */
+  const float* weights;      /* [nq] (HBM) */
+  const int32_t* offsets;    /* [nr+1] (HBM) */
+  const int32_t* parent_map; /* [nr] (HBM) */
+  int32_t host_width;
+  int32_t reserved;
+  const int32_t* host_rows;
+  const int32_t* host_verts;
+} cfx_rules_view_f32;
+/* mesh with float32 coordinates (U = float): x [nnodes*3] */
+int cfx_mesh_create_f32(int tdim, int gdim, int64_t nnodes, const float* x, int64_t ncells, const int32_t* conn,
+                        int cell_stride, cfx_mesh_t* out);
+/* cut() / update() with float32 level-set Functions (cut.h:104-181 for T = float).  The widened copies belong to
+ * the cut: a caller that changes its f32 values calls cfx_cut_update_f32 with the pointers again. */
+int cfx_cut_create_f32(cfx_mesh_t mesh, int n_level_sets, const int32_t* ls_dofmap, int ls_ndofs_cell,
+                       int64_t ls_ndofs, const float* const* ls_values, const cfx_cut_options* opt, cfx_cut_t* out);
+int cfx_cut_update_f32(cfx_cut_t cut, const float* const* ls_values);
+/* RuntimeQuadrature<float> fields (runtime_quadrature.h:223-231) */
+int cfx_rules_create_f32(cfx_mesh_t mesh, int tdim, int64_t nq, int64_t nr, const float* points, const float* weights,
+                         const int32_t* offsets, const int32_t* parent_map, cfx_rules_t* out);
+int cfx_rules_view_get_f32(cfx_rules_t r, cfx_rules_view_f32* view);
+int cfx_rules_physical_points_f32(cfx_rules_t r, float* out);
+int cfx_evaluate_normals_f32(cfx_cut_t cut, int level_set, cfx_rules_t rules, float sign, float* out);
+int cfx_evaluate_values_f32(cfx_cut_t cut, int level_set, cfx_rules_t rules, float* out);
+/* f32 per-point data / coefficient dof values for a cfx_integral: *out is an fp64 HBM copy to put into
+ * cfx_integral.point_data / .coefficient, released with cfx_device_free after the form is destroyed */
+int cfx_widen_f32(const float* src, int64_t n, double** out);
+/* assemble_matrix / assemble_vector / apply_lifting / set_bc / zero_rows / deactivate_outside for T = float */
+int cfx_assemble_matrix_f32(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0, const int8_t* bc1, float* values);
+int cfx_assemble_matrix_zeroed_f32(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0, const int8_t* bc1,
+                                   float* values);
+int cfx_assemble_vector_f32(cfx_form_t L, float* b);
+int cfx_apply_lifting_f32(cfx_form_t a, const int8_t* bc_markers, const float* bc_values, const float* x0, float alpha,
+                          float* b);
+int cfx_set_bc_f32(int64_t n, const int8_t* bc_markers, const float* bc_values, const float* x0, float alpha, float* b);
+int cfx_zero_rows_f32(cfx_pattern_t P, const float* values, float tol, int32_t** rows, int64_t* n_rows);
+int cfx_deactivate_outside_f32(cfx_active_t d, cfx_pattern_t pattern, float* values, float* b /* or NULL */,
+                               float diagonal, float rhs_value);
+
 /* ---- multi-GPU exchange steps (one rank per GPU; RCCL send/recv over xGMI between the ranks that share dofs) ----
  * The reference's collectives on this path (DOLFINx index maps, MPI neighbourhood exchanges):
  *   phi.x.scatter_forward()                      python/demo/demo_poisson.py:157       -> cfx_dist_scatter_forward

@@ -79,6 +79,8 @@ struct Context
   bool overlap = false;              // inside cfx_overlap_begin / cfx_overlap_end: block frees are deferred
   std::vector<void*> deferred_free;
   bool profile = false;
+  const char* last_launch = "(none)"; // name of the latest kernel launch (CFX_COUNT_SYNC=2 names the read-backs by it)
+  bool trace_sync = false;
   std::vector<ProfileEntry> entries;
   std::map<std::string, int> entry_index;
   struct Pending { int entry; hipEvent_t a, b; };
@@ -99,6 +101,7 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shm
 {
   Context& c = ctx();
   if (grid.x == 0) return;
+  c.last_launch = name;
   // HIP launches at most 2^32 - 1 work-items per dimension; a larger grid is cut short silently
   if ((uint64_t)grid.x * block.x > 0xffffffffull)
     throw Error(CFX_ERR_RUNTIME, std::string(name) + ": launch exceeds 2^32 threads");
@@ -221,13 +224,19 @@ inline DevArray<T> to_device(const T* src, int64_t n)
 
 int64_t& sync_counter(); // host round trips so far (cfx_runtime.hip), reported by CFX_COUNT_SYNC=1
 
+void* pinned_scratch(); // 256 B of page-locked host memory (cfx_runtime.hip): target of the size read-backs
+
 template <typename T>
 inline T read_scalar(const T* dev)
 {
-  T v;
-  CFX_HIP(hipMemcpyAsync(&v, dev, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  // into page-locked memory: a pageable destination makes hipMemcpyAsync stage the copy and block longer
+  static_assert(sizeof(T) <= 256, "read_scalar reads small values");
+  T* h = static_cast<T*>(pinned_scratch());
+  CFX_HIP(hipMemcpyAsync(h, dev, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
   CFX_HIP(hipStreamSynchronize(ctx().stream));
+  const T v = *h;
   ++sync_counter();
+  if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back after %s\n", ctx().last_launch);
   return v;
 }
 

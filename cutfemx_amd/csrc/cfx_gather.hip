@@ -2325,7 +2325,20 @@ __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_pla
   const int64_t o = live ? t2off[r] : -1; // -1: the row has no segment (it is in the plan's vec_slow_rows)
   double part = 0.0; // entries gl, gl + G, ... in ascending order, then a fixed tree: bitwise reproducible
   if (o >= 0)
-    for (int k = gl; k < nc; k += G) part += t2[o + k];
+  {
+    // the first Q entries of the lane are requested together (a Kuhn-mesh vertex has 24 cells: 6 per lane at G = 4)
+    constexpr int Q = 8;
+    double v[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+    {
+      const int k = gl + q * G;
+      v[q] = k < nc ? t2[o + k] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) part += v[q];
+    for (int k = gl + Q * G; k < nc; k += G) part += t2[o + k];
+  }
 #pragma unroll
   for (int d = G / 2; d >= 1; d >>= 1) part += __shfl_xor(part, d, G);
   if (live && gl == 0 && o >= 0) b[r] += part;

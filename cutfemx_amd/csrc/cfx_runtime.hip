@@ -87,12 +87,23 @@ size_t round_size(size_t bytes)
 }
 } // namespace
 
+void* pinned_scratch()
+{
+  static void* p = []() {
+    void* q = nullptr;
+    CFX_HIP(hipHostMalloc(&q, 256, hipHostMallocDefault));
+    return q;
+  }();
+  return p;
+}
+
 int64_t& sync_counter()
 {
   static int64_t n = 0;
   static const bool report = []() {
     const char* e = getenv("CFX_COUNT_SYNC");
-    if (e && e[0] == '1') atexit([]() { fprintf(stderr, "cutfemx_amd: %lld size read-backs\n", (long long)sync_counter()); });
+    if (e && e[0] == '2') ctx().trace_sync = true;
+    if (e && (e[0] == '1' || e[0] == '2')) atexit([]() { fprintf(stderr, "cutfemx_amd: %lld size read-backs\n", (long long)sync_counter()); });
     return true;
   }();
   (void)report;

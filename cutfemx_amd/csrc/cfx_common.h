@@ -314,6 +314,7 @@ struct Stencil
   DevArray<uint8_t> diagpos; // position of the dof in its own list
   DevArray<uint8_t> cpos;    // [ncells*nd]: position of the cell in the dof->cells list of its j-th dof
   bool built = false, usable = false;
+  bool lists = false; // offsets + nbr are valid (any space); usable: slot4 / diagpos / cpos too (P1 on the geometry dofmap)
   int max_len = 0; // longest neighbour list
   // Row tiles: kRowTile consecutive dofs.  Mesh-static per tile: the sorted union of its rows' neighbour lists
   // (tile_verts) and, parallel to nbr, the position of every neighbour in that union (st_loc).  The gather
@@ -402,6 +403,7 @@ struct cfx_space_s
   cfx::Adjacency d2c; // dof -> cells
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
+  bool lists_short_overflow = false; // a short-list row overflowed the 128-slot set once: hashed rows all go wide
   bool long_rows = false; // a sparsity build of this space overflowed the 63-entry row sets: start with the wide kernel
   const cfx::Adjacency& dof_cells()
   {

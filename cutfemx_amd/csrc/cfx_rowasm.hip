@@ -421,8 +421,10 @@ template <int G, int T>
 __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
 {
   constexpr int RPW = kWave / G;
+  constexpr int kSrc = G >= 16 ? 128 : 32; // source cells staged per row and chunk (degree-2 / vector / 2-D rows)
   __shared__ int32_t s_tab[RPW][T];
   __shared__ int32_t s_list[RPW][T];
+  __shared__ int32_t s_src[RPW][kSrc];
   __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   // one pass for every launch that fits HIP's 2^32-thread limit; the grid is capped beyond it
@@ -446,18 +448,7 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
       constexpr int R = G <= 4 ? 6 : (G <= 8 ? 4 : 2);
       const int64_t cb = P.d2c_off[r];
       const int nc = (int)(P.d2c_off[r + 1] - cb);
-      if (P.nd != 4)
-      {
-        // (cell, local dof) pairs spread over the lanes: a degree-2 row has 5-24 cells of 10 dofs,
-        // one lane per cell would leave most of a 64-lane group idle
-        const int npairs = nc * P.nd;
-        for (int t = gl; t < npairs; t += G)
-        {
-          const int q = t / P.nd;
-          const int64_t cell = P.d2c[cb + q];
-          if (P.all_cells || P.cellmark[cell]) ok = hash_insert<T>(tab, P.dofmap[cell * P.nd + (t - q * P.nd)]) && ok;
-        }
-      }
+      if (P.nd != 4) {} // handled below together with the facets (source cells staged in LDS)
       else
       for (int base = 0; base < nc; base += R * G)
       {
@@ -514,19 +505,52 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         }
       }
     }
-    else if (fpos >= 0)
+  }
+  if (P.nd != 4)
+  {
+    // Source cells of the row -- its marked incident cells, then both cells of its facets -- go to LDS first (two
+    // dependent gather levels, once, spread over the lanes); the (source, local dof) pairs are then one dofmap load
+    // each.  A lane that walks incidence -> mark / facet row -> dofmap per candidate pays three dependent levels
+    // per candidate: 33 ms instead of 17 ms for the 12 M short rows of BASELINE config 4.
+    int32_t* tab = s_tab[grp];
+    const bool cells_on = live && (P.cellmark || P.all_cells);
+    const int64_t cb = cells_on ? P.d2c_off[r] : 0;
+    const int nc = cells_on ? (int)(P.d2c_off[r + 1] - cb) : 0;
+    const int64_t fpos = (live && P.d2f_off && P.special_mark[r]) ? (int64_t)P.special_pos[r] : -1;
+    const int64_t fb = fpos >= 0 ? P.d2f_off[fpos] : 0;
+    const int nsrc = nc + (fpos >= 0 ? 2 * (int)(P.d2f_off[fpos + 1] - fb) : 0);
+    int nchunk = (nsrc + kSrc - 1) / kSrc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nchunk = max(nchunk, __shfl_xor(nchunk, o, 64)); // the groups loop together
+    for (int ch = 0; ch < nchunk; ++ch)
     {
-      // (facet, side, local dof) triples spread over the lanes
-      const int64_t fb = P.d2f_off[fpos];
-      const int per = 2 * P.nd;
-      const int ntr = (int)(P.d2f_off[fpos + 1] - fb) * per;
-      for (int t = gl; t < ntr; t += G)
+      const int base = ch * kSrc;
+      const int m = min(kSrc, nsrc - base);
+      for (int t = gl; t < m; t += G)
       {
-        const int q = t / per, u = t - q * per;
-        const int64_t f = P.d2f[fb + q];
-        const int64_t c = P.facet_rows[4 * f + 2 * (u / P.nd)];
-        ok = hash_insert<T>(tab, P.dofmap[c * P.nd + u % P.nd]) && ok;
+        const int idx = base + t;
+        int32_t cell;
+        if (idx < nc)
+        {
+          const int32_t c = P.d2c[cb + idx];
+          cell = (P.all_cells || P.cellmark[c]) ? c : -1;
+        }
+        else
+        {
+          const int64_t f = P.d2f[fb + ((idx - nc) >> 1)];
+          cell = P.facet_rows[4 * f + 2 * ((idx - nc) & 1)];
+        }
+        s_src[grp][t] = cell;
       }
+      __syncthreads();
+      const int npairs = max(m, 0) * P.nd;
+      for (int t = gl; t < npairs; t += G)
+      {
+        const int q = t / P.nd;
+        const int64_t cell = s_src[grp][q];
+        if (cell >= 0) ok = hash_insert<T>(tab, P.dofmap[cell * P.nd + (t - q * P.nd)]) && ok;
+      }
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -1061,6 +1085,86 @@ __global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(int64_t n_ti
     if ((m >> p) & 1ull) indices[ob + __popcll(m & ((1ull << p) - 1ull))] = nbr[sb + p];
 }
 
+// Spaces with neighbour lists only (degree 2, vector-valued, DG): a plain row whose incident cells are ALL uncut
+// entities of the form couples exactly its static list -- its columns are a copy, no hash set.  full[i] = 1 for
+// such rows (and their expanded row lengths go to counts); the others join the hashed rows.
+template <int G>
+__global__ void __launch_bounds__(kWave) plain_full_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+                                                            const int64_t* __restrict__ d2c_off, const int32_t* __restrict__ d2c,
+                                                            const uint8_t* __restrict__ cellmark,
+                                                            const int64_t* __restrict__ st_off, int bs,
+                                                            uint8_t* __restrict__ full, int32_t* __restrict__ counts)
+{
+  const int lane = threadIdx.x, gl = lane % G;
+  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
+  const bool live = i < n_plain;
+  const int64_t r = live ? rows[i] : 0;
+  const int64_t cb = live ? d2c_off[r] : 0;
+  const int nc = live ? (int)(d2c_off[r + 1] - cb) : 0;
+  int miss = 0;
+  for (int t = gl; t < nc; t += G) miss |= (cellmark[d2c[cb + t]] & 0x0Fu) == 0;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) miss |= __shfl_xor(miss, o, G);
+  if (!live || gl != 0) return;
+  const bool f = miss == 0 && nc > 0;
+  full[i] = f ? 1 : 0;
+  if (f)
+  {
+    const int len = (int)(st_off[r + 1] - st_off[r]);
+    for (int a = 0; a < bs; ++a) counts[r * bs + a] = len * bs;
+  }
+}
+
+struct StaticLenTest
+{
+  const int32_t* rows;
+  const int64_t* st_off;
+  int limit;
+  bool above;
+  __device__ bool operator()(int64_t i) const
+  {
+    const int64_t r = rows[i];
+    return ((int)(st_off[r + 1] - st_off[r]) > limit) == above;
+  }
+};
+
+struct FlagIsZero
+{
+  const uint8_t* f;
+  __device__ bool operator()(int64_t i) const { return f[i] == 0; }
+};
+
+template <int G>
+__global__ void __launch_bounds__(kBlock) pattern_plain_copy_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+                                                                    const uint8_t* __restrict__ full,
+                                                                    const int64_t* __restrict__ st_off,
+                                                                    const int32_t* __restrict__ nbr, int bs,
+                                                                    const int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t / G;
+  if (i >= n_plain || !full[i]) return;
+  const int gl = (int)(t - i * G);
+  const int64_t r = rows[i];
+  const int64_t sb = st_off[r];
+  const int len = (int)(st_off[r + 1] - sb);
+  if (bs == 1)
+  {
+    const int64_t ob = indptr[r];
+    for (int k = gl; k < len; k += G) indices[ob + k] = nbr[sb + k];
+    return;
+  }
+  for (int k = gl; k < len; k += G)
+  {
+    const int32_t col = nbr[sb + k];
+    for (int a = 0; a < bs; ++a)
+    {
+      const int64_t ob = indptr[r * bs + a] + (int64_t)k * bs;
+      for (int b = 0; b < bs; ++b) indices[ob + b] = col * bs + b;
+    }
+  }
+}
+
 } // namespace
 
 namespace cfx
@@ -1213,7 +1317,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     exclusive_scan(tcounts.p, toffs.p, ntiles);
     const int64_t totals = read_scalar(toffs.p + ntiles);
     const int64_t n_special = totals & 0xffffffffll, n_plain = totals >> 32;
-    const bool want_plain = space_stencil(V).usable;
+    const bool want_plain = space_stencil(V).lists;
+    if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: plan rows special %lld plain %lld of %lld dofs\n", (long long)n_special, (long long)n_plain, (long long)V->ndofs);
     P.n_active_rows = n_special + n_plain;
     P.n_special_rows = n_special;
     P.n_plain_rows = want_plain ? n_plain : 0;
@@ -1313,9 +1418,31 @@ const Stencil& space_stencil(cfx_space_s* V)
   S.built = true;
   const char* env = getenv("CFX_STENCIL");
   if (env && env[0] == '0') return S;
-  // P1 scalar space on the geometry dofmap (dofs are mesh vertices)
+  // P1 scalar space on the geometry dofmap (dofs are mesh vertices): lists + slots; every other space (degree 2,
+  // vector-valued, DG): the neighbour lists alone, which is what the sparsity of the plain rows needs
   if (V->degree != 1 || V->bs != 1 || V->ndofs_cell > 4 || V->dofmap.p != V->mesh->conn.p || V->ndofs != V->mesh->nnodes)
+  {
+    const char* le = getenv("CFX_STENCIL_LISTS");
+    if (le && le[0] == '0') return S;
+    const Adjacency& adj = V->dof_cells();
+    PatArgs A{};
+    A.n_active = V->ndofs; A.active_rows = nullptr; A.all_cells = 1;
+    A.nd = V->ndofs_cell; A.bs = 1; A.dofmap = V->dofmap.p; // lists of scalar dofs: a block space expands them by bs
+    A.d2c_off = adj.offsets.p; A.d2c = adj.cells.p;
+    DevArray<int32_t> counts(V->ndofs), len(V->ndofs);
+    ZeroFlag overflow, maxlen;
+    A.len = len.p; A.counts = counts.p; A.overflow = overflow.p; A.maxlen = maxlen.p;
+    launch("stencil_rows", pattern_rows_kernel<64, 512>, wave_grid(V->ndofs), dim3(kWave), 0, A);
+    if (read_scalar(overflow.p)) return S;
+    S.max_len = read_scalar(maxlen.p);
+    S.offsets.alloc(V->ndofs + 1);
+    exclusive_scan(counts.p, S.offsets.p, V->ndofs);
+    S.nbr.alloc(read_scalar(S.offsets.p + V->ndofs));
+    A.indptr = S.offsets.p; A.indices = S.nbr.p;
+    launch("stencil_rows_write", pattern_rows_kernel<64, 512>, wave_grid(V->ndofs), dim3(kWave), 0, A);
+    S.lists = true;
     return S;
+  }
   const Adjacency& adj = V->dof_cells();
   PatArgs A{};
   A.n_active = V->ndofs; A.active_rows = nullptr; A.all_cells = 1;
@@ -1339,6 +1466,7 @@ const Stencil& space_stencil(cfx_space_s* V)
   launch("stencil_slots", stencil_slots_kernel, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, V->ndofs, adj.offsets.p,
          adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slot4.p, S.diagpos.p, S.cpos.p);
   S.usable = true;
+  S.lists = true;
   return S;
 }
 
@@ -1482,8 +1610,36 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   // plain rows (uncut-cell items only) are subsets of the static stencil: mask + popcount;
   // the hash-set path then only sees the rows next to the interface
   const bool use_stencil = st.usable && plan.n_plain_rows > 0 && plan.any_cells;
-  const int64_t n_h = use_stencil ? plan.n_special_rows : plan.n_active_rows;
+  // lists only (degree 2, vector, DG spaces): the plain rows whose cells are all marked copy their static list
+  const bool use_lists = !st.usable && st.lists && plan.n_plain_rows > 0 && plan.any_cells;
+  int64_t n_h = use_stencil ? plan.n_special_rows : plan.n_active_rows;
   const int32_t* rows_h = use_stencil ? plan.special_rows.p : plan.active_rows.p;
+  P->nrows = V->ndofs * V->bs;
+  DevArray<int32_t> counts(P->nrows);
+  DevArray<uint8_t> full;
+  DevArray<int32_t> hashed;
+  bool any_full = false;
+  if (use_lists)
+  {
+    const Adjacency& adj = V->dof_cells();
+    constexpr int G = 4;
+    full.alloc(plan.n_plain_rows);
+    launch("pattern_plain_full", plain_full_kernel<G>, dim3((unsigned)((plan.n_plain_rows + kWave / G - 1) / (kWave / G))),
+           dim3(kWave), 0, plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, plan.cellmark.p, st.offsets.p,
+           V->bs, full.p, counts.p);
+    DevArray<int32_t> odd;
+    const int64_t n_odd = compact("pattern_plain_full", plan.n_plain_rows, FlagIsZero{full.p}, odd);
+    any_full = n_odd < plan.n_plain_rows;
+    n_h = plan.n_special_rows + n_odd;
+    hashed.alloc(n_h);
+    if (plan.n_special_rows > 0)
+      CFX_HIP(hipMemcpyAsync(hashed.p, plan.special_rows.p, sizeof(int32_t) * (size_t)plan.n_special_rows,
+                             hipMemcpyDeviceToDevice, ctx().stream));
+    if (n_odd > 0)
+      launch("pattern_plain_full", gather_i32_kernel, grid_for(n_odd), dim3(kBlock), 0, n_odd, odd.p, plan.plain_rows.p,
+             hashed.p + plan.n_special_rows);
+    rows_h = hashed.p;
+  }
   PatArgs S{};
   S.n_active = n_h; S.active_rows = rows_h;
   S.nd = V->ndofs_cell; S.bs = V->bs; S.dofmap = V->dofmap.p;
@@ -1497,13 +1653,48 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     S.d2f_off = plan.d2f_offsets.p; S.d2f = plan.d2f.p; S.facet_rows = plan.facet_rows.p;
     S.special_mark = plan.special_mark.p; S.special_pos = plan.special_pos.p;
   }
-  P->nrows = V->ndofs * V->bs;
-  DevArray<int32_t> counts(P->nrows), len(n_h), tmp;
+  DevArray<int32_t> len(n_h), tmp;
   ZeroFlag overflow, maxlen;
   // (the rows off the active set are never read from `counts`: indptr_*_kernel knows their length)
   S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
   int T = 64;
-  if (n_h > 0)
+  // lists path: the hashed rows split by the length of their static list -- short rows (the edge dofs of a degree-2
+  // space: ~85 % of the rows) take 16 lanes and a 128-slot set, 4 rows per wavefront, the others one wavefront and
+  // 512 slots; both count first and build each set again to write it in place
+  constexpr int kShortLen = 40;
+  DevArray<int32_t> short_rows, long_rows, short_idx, long_idx;
+  int64_t n_short = 0, n_long = 0;
+  bool split_hashed = false;
+  if (use_lists && n_h > 0 && !V->lists_short_overflow)
+  {
+    n_short = compact("pattern_split", n_h, StaticLenTest{rows_h, st.offsets.p, kShortLen, false}, short_idx);
+    n_long = n_h - n_short;
+    short_rows.alloc(n_short);
+    long_rows.alloc(n_long);
+    if (n_short > 0)
+      launch("pattern_split", gather_i32_kernel, grid_for(n_short), dim3(kBlock), 0, n_short, short_idx.p, rows_h, short_rows.p);
+    if (n_long > 0)
+    {
+      compact("pattern_split", n_h, StaticLenTest{rows_h, st.offsets.p, kShortLen, true}, long_idx);
+      launch("pattern_split", gather_i32_kernel, grid_for(n_long), dim3(kBlock), 0, n_long, long_idx.p, rows_h, long_rows.p);
+    }
+    split_hashed = true;
+    T = 512;
+    PatArgs S1 = S, S2 = S;
+    S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = nullptr;
+    S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = nullptr; S2.len = len.p + n_short;
+    if (n_short > 0) launch("pattern_rows_short", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
+    if (n_long > 0) launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
+    if (read_scalar(overflow.p))
+    {
+      // a short static list with more than 127 - 40 facet couplings, or a row beyond 511: all rows wide from now on
+      V->lists_short_overflow = true;
+      split_hashed = false;
+      overflow.zero();
+      maxlen.zero();
+    }
+  }
+  if (n_h > 0 && !split_hashed)
   {
     bool wide = V->long_rows;
     if (!wide)
@@ -1535,6 +1726,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
            plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
   }
   P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
+  if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list
   P->indptr.alloc(P->nrows + 1);
   {
     const int64_t ntiles = (P->nrows + kTile - 1) / kTile;
@@ -1554,7 +1746,18 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   else if (use_stencil)
     launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows * CFX_PPW_LANES), dim3(kBlock), 0,
            plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
-  if (n_h > 0)
+  if (any_full)
+    launch("pattern_plain_write", pattern_plain_copy_kernel<8>, grid_for(plan.n_plain_rows * 8), dim3(kBlock), 0,
+           plan.n_plain_rows, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, V->bs, P->indptr.p, P->indices.p);
+  if (split_hashed)
+  {
+    PatArgs S1 = S, S2 = S;
+    S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = nullptr; S1.indptr = P->indptr.p; S1.indices = P->indices.p;
+    S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = nullptr; S2.indptr = P->indptr.p; S2.indices = P->indices.p;
+    if (n_short > 0) launch("pattern_rows_short_write", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
+    if (n_long > 0) launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
+  }
+  else if (n_h > 0)
   {
     if (T == 64)
       launch("pattern_write", pattern_write_kernel<64>, grid_for(n_h * 8), dim3(kBlock), 0, n_h, rows_h, V->bs, tmp.p,

@@ -54,6 +54,10 @@ struct AsmArgs
   // over rule f - n_std (offsets / points / weights above, host vertices below); f0 = first entity of this launch
   int64_t n_std, f0, dump0; // dump0: entity written to slot 0 of `dump`
   const int32_t* host_verts;
+  // P1 facet tensors for the row gather: store the macro tensor folded over the dofs the two cells share --
+  // (ND + 1)^2 doubles per facet instead of (2 ND)^2 (plan.fold_ok: every facet joins two cells that share all dofs
+  // but one each).  Macro dofs: cell 0's, then the dof of cell 1 that cell 0 does not have.
+  int dump_fold;
 };
 
 // ---------------------------------------------------------------------------
@@ -251,6 +255,61 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
     for (int j = 0; j < NLOC; ++j) acc[j] *= factor;
   }
 
+  if constexpr (DEG == 1 && BS == 1 && TDIM == 3)
+  {
+    if (A.dump && A.dump_fold)
+    {
+      constexpr int WF = ND + 1;
+      constexpr int kWave = 64;
+      static_assert(kWave % NLOC == 0, "the 8 rows of a facet sit in 8 consecutive lanes of one wavefront");
+      int32_t d0[ND], d1[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { d0[j] = A.dofmap[c0 * ND + j]; d1[j] = A.dofmap[c1 * ND + j]; }
+      int p1[ND]; // local index in cell 0 of cell 1's j-th dof, -1 for the one cell 0 does not have
+      int q0 = -1; // this thread's partner: the local index in cell 1 of cell 0's dof I (threads I < ND)
+      int jfree = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        p1[j] = -1;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) p1[j] = d1[j] == d0[i] ? i : p1[j];
+        q0 = p1[j] == I ? j : q0;
+        jfree = p1[j] < 0 ? j : jfree;
+      }
+      // columns: cell 1's shared dofs onto cell 0's, the free one last
+      double accf[WF];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+      {
+        accf[i] = acc[i];
+#pragma unroll
+        for (int j = 0; j < ND; ++j) accf[i] += p1[j] == i ? acc[ND + j] : 0.0;
+      }
+      accf[ND] = 0.0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) accf[ND] += p1[j] < 0 ? acc[ND + j] : 0.0;
+      // rows: thread I < ND adds the row of its partner in cell 1 (lane + ND - I + q0); the thread of cell 1's free
+      // dof holds macro row ND as it is; the other threads of cell 1 have handed their rows over
+      const int lane = threadIdx.x % kWave;
+      const int src = (lane - I) + ND + (q0 >= 0 ? q0 : 0);
+      const bool add = I < ND && q0 >= 0;
+#pragma unroll
+      for (int k = 0; k < WF; ++k)
+      {
+        const double other = __shfl(accf[k], src, kWave);
+        accf[k] += add ? other : 0.0;
+      }
+      const int m = I < ND ? I : (I - ND == jfree ? ND : -1);
+      if (m >= 0)
+      {
+        double* out = A.dump + ((f - A.dump0) * WF + m) * WF;
+#pragma unroll
+        for (int k = 0; k < WF; ++k) out[k] = accf[k];
+      }
+      return;
+    }
+  }
   if (A.dump)
   {
     if constexpr (NLOC <= 16)
@@ -863,18 +922,154 @@ void collect_cell_marks(const cfx_form_s* a, bool include_facets, DevArray<uint8
 
 } // namespace
 
+namespace
+{
+// P1 gradient-jump ghost penalty, stage 1 for the row gather: the facet tensor gamma h_avg |F| [dn N_i][dn N_j] is
+// RANK ONE (P1 gradients are constant), and folded over the dofs the two cells share it is w jf jf^T with
+// jf = (jump of cell 0's basis i + that of its twin in cell 1, ..., jump of cell 1's free dof).  One thread per facet
+// writes the 64-byte record (jf[0..ND], w) instead of eight threads writing 64 (folded: 25) doubles; the gather
+// forms row r as w jf[m(r)] jf[.].  facet_local_row() is the generic statement of the same integrand.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const int32_t* __restrict__ rows,
+                                                               const double* __restrict__ x, const int32_t* __restrict__ conn,
+                                                               const int32_t* __restrict__ dofmap, double gamma, int qdegree,
+                                                               double* __restrict__ out, int* error)
+{
+  constexpr int ND = TDIM + 1;
+  const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (f >= n) return;
+  const int4 row4 = *reinterpret_cast<const int4*>(rows + 4 * f);
+  const int64_t c0 = row4.x, c1 = row4.z;
+  const int lf0 = row4.y;
+  Geo<TDIM> g0, g1;
+  load_cell<TDIM>(x, conn, c0, g0);
+  load_cell<TDIM>(x, conn, c1, g1);
+  jacobian<TDIM>(g0);
+  jacobian<TDIM>(g1);
+  const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
+  double nrm[TDIM], nn = 0.0;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) v -= g0.K[t][d] * ((lf0 == 0) ? -1.0 : ((lf0 - 1 == t) ? 1.0 : 0.0));
+    nrm[d] = v;
+    nn += v * v;
+  }
+  nn = sqrt(nn);
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) nrm[d] /= nn;
+  // measure of the facet: cell 0's vertices except lf0
+  double xf[TDIM][TDIM];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      if (i == lf0) continue;
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j)
+        if (j == k)
+        {
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) xf[j][d] = g0.x[i][d];
+        }
+      ++k;
+    }
+  }
+  double scale;
+  if constexpr (TDIM == 2)
+  {
+    const double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
+    scale = sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    scale = sqrt(cx * cx + cy * cy + cz * cz);
+  }
+  int nref;
+  const double* wref;
+  (void)ref_rule(TDIM - 1, qdegree, nref, wref);
+  double wsum = 0.0;
+  for (int q = 0; q < nref; ++q) wsum += wref[q];
+  // normal-derivative jumps of the macro basis: grad N_0 = -sum_t K[t][.], grad N_{t+1} = K[t][.]
+  double j0[ND], j1[ND];
+  j0[0] = 0.0; j1[0] = 0.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t)
+  {
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) { a += g0.K[t][d] * nrm[d]; b += g1.K[t][d] * nrm[d]; }
+    j0[t + 1] = a; j0[0] -= a;
+    j1[t + 1] = -b; j1[0] += b;
+  }
+  int32_t d0[ND], d1[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) { d0[j] = dofmap[c0 * ND + j]; d1[j] = dofmap[c1 * ND + j]; }
+  double jf[ND + 1];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) jf[i] = j0[i];
+  jf[ND] = 0.0;
+  int nfree = 0;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    bool shared = false;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const bool same = d1[j] == d0[i];
+      jf[i] += same ? j1[j] : 0.0;
+      shared = shared || same;
+    }
+    jf[ND] += shared ? 0.0 : j1[j];
+    nfree += shared ? 0 : 1;
+  }
+  if (error && nfree != 1) *error = 4; // not an interior facet of a conforming mesh with a continuous space
+  double rec[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) rec[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k <= ND; ++k) rec[k] = jf[k];
+  rec[ND + 1] = wsum * scale * gamma * havg;
+  double2* o = reinterpret_cast<double2*>(out + 8 * f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+}
+} // namespace
+
 namespace cfx
 {
 // local tensors of all standard (parts=1) or runtime (parts=2) entities of one
 // integral, written entity-major to `out` (used by the row-gather assembly)
-void dump_integral(cfx_form_s* a, int integral, int parts, double* out)
+void dump_integral(cfx_form_s* a, int integral, int parts, double* out, bool fold_facets)
 {
   cfx_space_s* V = a->V;
   ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.dump = out; A.error = err.p;
+  A.dump_fold = fold_facets ? 1 : 0;
   launch_integral(a, a->integrals[integral], A, -1, 0, parts);
+}
+// stage 1 of the P1 gradient-jump facets for the row gather: 8 doubles per facet (facet_jump_p1_kernel)
+void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
+{
+  cfx_space_s* V = a->V;
+  const cfx_integral_dev& I = a->integrals[integral];
+  if (I.n_entities == 0) return;
+  if (V->mesh->tdim == 2)
+    launch("assemble_facets", facet_jump_p1_kernel<2>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
+           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
+  else
+    launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
+           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
 }
 } // namespace cfx
 

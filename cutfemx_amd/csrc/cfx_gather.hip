@@ -25,7 +25,8 @@ using namespace cfx;
 
 namespace cfx
 {
-void dump_integral(cfx_form_s* a, int integral, int parts, double* out); // cfx_fem.hip
+void dump_integral(cfx_form_s* a, int integral, int parts, double* out, bool fold_facets = false); // cfx_fem.hip
+void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error);                    // cfx_fem.hip
 }
 
 namespace
@@ -875,6 +876,31 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
         i0 = cols[j] == (int32_t)r ? j : i0;
         i1 = cols[ND + j] == (int32_t)r ? ND + j : i1;
       }
+      if (DEG == 1 && A.fold_facets == 3)
+      {
+        // rank-one record of the gradient-jump term: (jf[0..ND], w); row m(r) of the folded tensor = w jf[m] jf[.]
+        const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * 8);
+        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+        const double jf[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+        const int m = i0 >= 0 ? i0 : ND;
+        double jm = 0.0;
+#pragma unroll
+        for (int j = 0; j <= ND; ++j) jm = (j == m) ? jf[j] : jm;
+        jm *= jf[ND + 1];
+#pragma unroll
+        for (int j = 0; j <= ND; ++j) acc[j] = jm * jf[j];
+      }
+      else if (DEG == 1 && A.fold_facets == 2)
+      {
+        // stage 1 stored the tensor folded over the shared dofs: macro row of r = its index in cell 0, or ND
+        // (the dof of cell 1 that cell 0 does not have); one row of ND + 1 entries, the free column last
+        constexpr int WF = ND + 1;
+        const double* T = A.facet_tensors + f * (WF * WF) + (i0 >= 0 ? i0 : ND) * WF;
+#pragma unroll
+        for (int j = 0; j < WF; ++j) acc[j] = T[j];
+      }
+      else
+      {
       const double* T = A.facet_tensors + f * (W * W);
       if (i0 >= 0)
       {
@@ -886,8 +912,39 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
 #pragma unroll
         for (int j = 0; j < W; ++j) acc[j] += T[i1 * W + j];
       }
+      }
     }
-    if (DEG == 1 && A.fold_facets)
+    if (DEG == 1 && A.fold_facets >= 2)
+    {
+     if constexpr (DEG == 1)
+     {
+      // columns: cell 0's dofs, then cell 1's free dof
+      int32_t c5[ND + 1];
+      double a5[ND + 1];
+      int s5[ND + 1];
+      int32_t ocol = -1;
+      int nfree = 0;
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+      {
+        bool shared = false;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) shared = shared || cols[ND + j] == cols[i];
+        if (has && !shared) { ocol = cols[ND + j]; ++nfree; }
+      }
+      if (has && nfree != 1) *A.error = 4;
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { c5[j] = cols[j]; a5[j] = acc[j]; s5[j] = -1; }
+      c5[ND] = ocol; a5[ND] = acc[ND]; s5[ND] = -1;
+      if (has)
+      {
+#pragma unroll
+        for (int j = 0; j <= ND; ++j) s5[j] = find_slot(c5[j]);
+      }
+      add_item(std::integral_constant<int, ND + 1>{}, has, c5, a5, s5);
+     }
+    }
+    else if (DEG == 1 && A.fold_facets)
     {
      if constexpr (DEG == 1)
      {
@@ -2089,13 +2146,28 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
   {
     A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
     A.special_mark = plan.special_mark.p; A.special_pos = plan.special_pos.p;
-    st.buffers.emplace_back(plan.nfacets * (int64_t)(4 * ND * ND));
+    // 3-D P1 scalar spaces: stage 1 stores the macro tensor already folded over the shared dofs, 25 doubles per
+    // facet instead of 64 (fold_facets = 2); elsewhere the P1 fold happens in the gather (1) or not at all (0)
+    const char* fe = getenv("CFX_FACET_FOLD_STAGE1");
+    if (TDIM == 3 && DEG == 1 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0')) A.fold_facets = 2;
+    // ... and when every facet term is the gradient jump over standard facets, the folded tensor is rank one:
+    // stage 1 stores its vector and weight (8 doubles per facet, fold_facets = 3)
+    bool rank_one = DEG == 1 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && (fe[0] == '0' || fe[0] == '2'));
+    for (int s = 0; s < plan.n_facet_slots; ++s)
+    {
+      const cfx_integral_dev& I = a->integrals[plan.facet_slot_integral[s]];
+      rank_one = rank_one && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std == I.n_entities;
+    }
+    if (rank_one) A.fold_facets = 3;
+    const int64_t fsize = A.fold_facets == 3 ? 8 : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
+    st.buffers.emplace_back(plan.nfacets * fsize);
     A.facet_tensors = st.buffers.back().p;
     int64_t o = 0;
     for (int s = 0; s < plan.n_facet_slots; ++s)
     {
       const int ii = plan.facet_slot_integral[s];
-      dump_integral(a, ii, 1, st.buffers.back().p + o * (4 * ND * ND));
+      if (A.fold_facets == 3) dump_facet_jumps_p1(a, ii, st.buffers.back().p + o * fsize, nullptr); // (a non-conforming row is reported by the gather)
+      else dump_integral(a, ii, 1, st.buffers.back().p + o * fsize, A.fold_facets == 2);
       o += a->integrals[ii].n_entities;
     }
   }

@@ -421,7 +421,7 @@ template <int G, int T>
 __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
 {
   constexpr int RPW = kWave / G;
-  constexpr int kSrc = G >= 16 ? 128 : 32; // source cells staged per row and chunk (degree-2 / vector / 2-D rows)
+  constexpr int kSrc = G >= 16 ? 128 : 8; // source cells staged per row and chunk (degree-2 / vector / 2-D rows)
   __shared__ int32_t s_tab[RPW][T];
   __shared__ int32_t s_list[RPW][T];
   __shared__ int32_t s_src[RPW][kSrc];

@@ -17,7 +17,7 @@ def profile(fn):
         _lib.check(l.cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
         if cnt.value: out[name.value.decode()] = round(ms.value, 2)
     _lib.check(l.cfx_profile_enable(0))
-    return dict(sorted(out.items(), key=lambda kv: -kv[1])[:8])
+    return dict(sorted(out.items(), key=lambda kv: -kv[1])[:int(__import__("os").environ.get("TOPK", "8"))])
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mesh = cfx.Mesh.create_box(3, n)
 Vphi = cfx.FunctionSpace(mesh, 1)

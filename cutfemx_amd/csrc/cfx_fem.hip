@@ -1042,6 +1042,158 @@ __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const 
 #pragma unroll
   for (int k = 0; k < 4; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
 }
+// Degree-2 gradient-jump ghost penalty, stage 1 for the row gather: at one quadrature point q the integrand is the
+// rank-one matrix w_q [dn N_i][dn N_j], so the facet tensor is a sum of nq rank-one terms (nq = 3 for degree-2
+// integrands on a triangle).  One thread per (facet, point) writes the record (jf_q[0..WF), w_q) with jf_q folded
+// over the dofs the two cells share: nq x 16 doubles per facet instead of (2 ND)^2 = 400, and the gather forms its row
+// as sum_q w_q jf_q[m] jf_q[.].  Macro dofs: cell 0's, then the dofs of cell 1 that cell 0 does not have in cell 1's
+// local order.  facet_local_row() is the generic statement of the same integrand.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int nq, const int32_t* __restrict__ rows,
+                                                                const double* __restrict__ x, const int32_t* __restrict__ conn,
+                                                                const int32_t* __restrict__ dofmap, double gamma, int qdegree,
+                                                                double* __restrict__ out)
+{
+  constexpr int ND = Elem<TDIM, 2>::ND, WF = Elem<TDIM, 2>::WF, NX = WF - ND;
+  static_assert(WF + 1 <= 16, "record of 16 doubles");
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t f = t / nq;
+  if (f >= n) return;
+  const int q = (int)(t - f * nq);
+  const int4 row4 = *reinterpret_cast<const int4*>(rows + 4 * f);
+  const int64_t c0 = row4.x, c1 = row4.z;
+  const int lf0 = row4.y;
+  Geo<TDIM> g0, g1;
+  load_cell<TDIM>(x, conn, c0, g0);
+  load_cell<TDIM>(x, conn, c1, g1);
+  jacobian<TDIM>(g0);
+  jacobian<TDIM>(g1);
+  const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
+  double nrm[TDIM], nn = 0.0;
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < TDIM; ++k) v -= g0.K[k][d] * ((lf0 == 0) ? -1.0 : ((lf0 - 1 == k) ? 1.0 : 0.0));
+    nrm[d] = v;
+    nn += v * v;
+  }
+  nn = sqrt(nn);
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d) nrm[d] /= nn;
+  double xf[TDIM][TDIM];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      if (i == lf0) continue;
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j)
+        if (j == k)
+        {
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) xf[j][d] = g0.x[i][d];
+        }
+      ++k;
+    }
+  }
+  double scale;
+  if constexpr (TDIM == 2)
+  {
+    const double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
+    scale = sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    scale = sqrt(cx * cx + cy * cy + cz * cz);
+  }
+  int nref;
+  const double* wref;
+  const double* pref = ref_rule(TDIM - 1, qdegree, nref, wref);
+  double l0 = 1.0, xq[TDIM];
+#pragma unroll
+  for (int k = 0; k < TDIM - 1; ++k) l0 -= pref[q * (TDIM - 1) + k];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double v = l0 * xf[0][d];
+#pragma unroll
+    for (int k = 0; k < TDIM - 1; ++k) v += pref[q * (TDIM - 1) + k] * xf[k + 1][d];
+    xq[d] = v;
+  }
+  double X0[TDIM], X1[TDIM], a0[TDIM], a1[TDIM];
+#pragma unroll
+  for (int k = 0; k < TDIM; ++k)
+  {
+    double u = 0.0, v = 0.0, p = 0.0, r = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      u += g0.K[k][d] * (xq[d] - g0.x[0][d]);
+      v += g1.K[k][d] * (xq[d] - g1.x[0][d]);
+      p += g0.K[k][d] * nrm[d];
+      r += g1.K[k][d] * nrm[d];
+    }
+    X0[k] = u; X1[k] = v; a0[k] = p; a1[k] = r;
+  }
+  double N[ND], dN[ND][TDIM], j0[ND], j1[ND];
+  tabulate<TDIM, 2>(X0, N, dN);
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < TDIM; ++k) v += a0[k] * dN[j][k];
+    j0[j] = v;
+  }
+  tabulate<TDIM, 2>(X1, N, dN);
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    double v = 0.0;
+#pragma unroll
+    for (int k = 0; k < TDIM; ++k) v += a1[k] * dN[j][k];
+    j1[j] = -v;
+  }
+  // fold: shared dofs of cell 1 onto cell 0's, the others behind them in cell 1's order
+  double jf[WF];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) jf[i] = j0[i];
+#pragma unroll
+  for (int e = 0; e < NX; ++e) jf[ND + e] = 0.0;
+  int nfree = 0;
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    const int32_t dj = dofmap[c1 * ND + j];
+    bool shared = false;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+    {
+      const bool same = dj == dofmap[c0 * ND + i];
+      jf[i] += same ? j1[j] : 0.0;
+      shared = shared || same;
+    }
+#pragma unroll
+    for (int e = 0; e < NX; ++e) jf[ND + e] += (!shared && nfree == e) ? j1[j] : 0.0;
+    nfree += shared ? 0 : 1;
+  }
+  double rec[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) rec[k] = 0.0;
+#pragma unroll
+  for (int k = 0; k < WF; ++k) rec[k] = jf[k];
+  rec[WF] = wref[q] * scale * gamma * havg;
+  double2* o = reinterpret_cast<double2*>(out + 16 * t);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+}
 } // namespace
 
 namespace cfx
@@ -1070,6 +1222,19 @@ void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
   else
     launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
            V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
+}
+// stage 1 of the degree-2 gradient-jump facets for the row gather: nq x 16 doubles per facet (facet_jumps_p2_kernel)
+void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out)
+{
+  cfx_space_s* V = a->V;
+  const cfx_integral_dev& I = a->integrals[integral];
+  if (I.n_entities == 0) return;
+  if (V->mesh->tdim == 2)
+    launch("assemble_facets", facet_jumps_p2_kernel<2>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
+           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out);
+  else
+    launch("assemble_facets", facet_jumps_p2_kernel<3>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
+           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out);
 }
 } // namespace cfx
 

@@ -27,6 +27,8 @@ namespace cfx
 {
 void dump_integral(cfx_form_s* a, int integral, int parts, double* out, bool fold_facets = false); // cfx_fem.hip
 void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error);                    // cfx_fem.hip
+void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out);                        // cfx_fem.hip
+int quad_npoints(int dim, int degree);                                                              // cfx_quadhost.cpp
 }
 
 namespace
@@ -81,7 +83,8 @@ constexpr bool kRowsInline = DEG == 1 || CFX_ROWS_INLINE_DEG2 != 0;
 struct RowIntegral
 {
   int kernel, qdegree, point_stride;
-  int std_inline;            // uncut entities: read std_tensors (0), generic inline row (1), P1 stiffness row from vertex coordinates (2)
+  int std_inline;            // uncut entities: read std_tensors (0), generic inline row (1), P1 stiffness row from vertex coordinates (2),
+                             // degree-2 stiffness row in closed form (3)
   const unsigned long long* std_bits; // bitset of the uncut entities
   const int32_t* std_rank;            // entities before each 64-cell word
   const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [ND][n_entities] (rank 1)
@@ -122,7 +125,9 @@ struct RowArgs
   int debug; // ablation switches (CFX_DEBUG_ROWS), 0 in production
   int iso_geometry; // the space's dofmap is the geometry dofmap (P1): dofs are vertex ids
   unsigned mark_mask;   // cell-mark bits this launch handles: 0x0F uncut entities, 0xF0 runtime rules (+ facets)
-  int fold_facets;      // every facet-type entity joins two cells across a shared facet (no extension pairs)
+  int fold_facets;      // every facet-type entity joins two cells across a shared facet (no extension pairs): 1 fold in the
+                        // gather (P1), 2 stage 1 stored the folded tensor (P1), 3 stage 1 stored rank-one records
+  int facet_nq;         // fold_facets = 3, degree 2: records (quadrature points) per facet
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
@@ -786,7 +791,18 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
             const RowIntegral& I = A.cell[i];
             if (STD && (mark & (1u << i)))
             {
-              if (kRowsInline<DEG> && I.std_inline)
+              if (DEG == 2 && I.std_inline == 3)
+              {
+                if constexpr (DEG == 2)
+                {
+                  // degree-2 stiffness on the affine cell in closed form (p2_stiffness_row): nothing staged
+                  Geo<TDIM> g;
+                  load_cell<TDIM>(A.x, A.conn, c, g);
+                  jacobian<TDIM>(g);
+                  p2_stiffness_row<TDIM>(g, lr, 1.0, acc);
+                }
+              }
+              else if (kRowsInline<DEG> && I.std_inline)
               {
                 if constexpr (kRowsInline<DEG>)
                 {
@@ -844,6 +860,68 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
     const int t = base + gl;
     const bool has = t < nfl;
     if (__ballot(has) == 0) break;
+    if (DEG == 2 && A.fold_facets == 3)
+    {
+      if constexpr (DEG == 2)
+      {
+        // degree-2 gradient jump: stage 1 stored facet_nq rank-one records (jf_q[0..WF), w_q) per facet, folded over
+        // the dofs the two cells share; row of macro dof m = sum_q w_q jf_q[m] jf_q[.], WF columns instead of 2 ND
+        constexpr int WF = Elem<TDIM, DEG>::WF, NX = WF - ND;
+        double acc[WF];
+        int32_t cm[WF];
+        int sl[WF];
+#pragma unroll
+        for (int j = 0; j < WF; ++j) { acc[j] = 0.0; cm[j] = -1; sl[j] = -1; }
+        if (has)
+        {
+          const int64_t f = A.d2f[fb + t];
+          const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
+          int32_t d1[ND];
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            cm[j] = A.dofmap[(int64_t)row4.x * ND + j];
+            d1[j] = A.dofmap[(int64_t)row4.z * ND + j];
+          }
+          int m = -1, nfree = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            bool shared = false;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) shared = shared || d1[j] == cm[i];
+#pragma unroll
+            for (int e = 0; e < NX; ++e) cm[ND + e] = (!shared && nfree == e) ? d1[j] : cm[ND + e];
+            m = (!shared && d1[j] == (int32_t)r) ? ND + nfree : m;
+            nfree += shared ? 0 : 1;
+          }
+#pragma unroll
+          for (int i = 0; i < ND; ++i) m = (cm[i] == (int32_t)r) ? i : m;
+          if (nfree != NX) *A.error = 4; // not an interior facet of a conforming mesh with a continuous space
+          const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * (int64_t)(A.facet_nq * 16));
+          for (int q = 0; q < A.facet_nq; ++q)
+          {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+            {
+              const double2 p = rec[q * 8 + k];
+              v[2 * k] = p.x; v[2 * k + 1] = p.y;
+            }
+            double jm = 0.0;
+#pragma unroll
+            for (int j = 0; j < WF; ++j) jm = (j == m) ? v[j] : jm;
+            jm *= v[WF];
+#pragma unroll
+            for (int j = 0; j < WF; ++j) acc[j] += jm * v[j];
+          }
+#pragma unroll
+          for (int j = 0; j < WF; ++j) sl[j] = find_slot(cm[j]);
+        }
+        add_item(std::integral_constant<int, WF>{}, has, cm, acc, sl);
+      }
+      continue;
+    }
     double acc[W];
     int32_t cols[W];
 #pragma unroll
@@ -2117,6 +2195,12 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     if (BS > 1 && !(inl && inl[0] == '1')) R.std_inline = 0; // block spaces stage their uncut tensors (see assemble_matrix_rows)
     if (R.std_inline && A.iso_geometry && !(inl && inl[0] == '1')) R.std_inline = 2;
     if (R.std_inline == 1) A.iso_geometry = 0; // a generic inline integral: the ISO kernel cannot serve this form
+    {
+      // degree-2 scalar stiffness without coefficient: closed-form row per item, no staged tensors
+      const char* cf = getenv("CFX_P2_CLOSED");
+      if (DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0 && !(cf && cf[0] == '0'))
+        R.std_inline = 3;
+    }
     if (!R.std_inline && I.n_entities > 0)
     {
       st.buffers.emplace_back(I.n_entities * tsize);
@@ -2159,14 +2243,31 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       rank_one = rank_one && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std == I.n_entities;
     }
     if (rank_one) A.fold_facets = 3;
-    const int64_t fsize = A.fold_facets == 3 ? 8 : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
+    // degree 2, scalar: nq rank-one records per facet when every facet term is the gradient jump at one degree
+    if (DEG == 2 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0'))
+    {
+      bool low = true;
+      int qd = -1;
+      for (int s = 0; s < plan.n_facet_slots; ++s)
+      {
+        const cfx_integral_dev& I = a->integrals[plan.facet_slot_integral[s]];
+        low = low && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std == I.n_entities
+              && (qd < 0 || qd == I.qdegree);
+        qd = I.qdegree;
+      }
+      const int nq = low ? quad_npoints(TDIM - 1, qd) : 0;
+      if (low && nq >= 1 && nq <= 6) { A.fold_facets = 3; A.facet_nq = nq; }
+    }
+    const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 16 * A.facet_nq : 8)
+                                             : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
     st.buffers.emplace_back(plan.nfacets * fsize);
     A.facet_tensors = st.buffers.back().p;
     int64_t o = 0;
     for (int s = 0; s < plan.n_facet_slots; ++s)
     {
       const int ii = plan.facet_slot_integral[s];
-      if (A.fold_facets == 3) dump_facet_jumps_p1(a, ii, st.buffers.back().p + o * fsize, nullptr); // (a non-conforming row is reported by the gather)
+      if (A.fold_facets == 3 && DEG == 2) dump_facet_jumps_p2(a, ii, A.facet_nq, st.buffers.back().p + o * fsize);
+      else if (A.fold_facets == 3) dump_facet_jumps_p1(a, ii, st.buffers.back().p + o * fsize, nullptr); // (a non-conforming row is reported by the gather)
       else dump_integral(a, ii, 1, st.buffers.back().p + o * fsize, A.fold_facets == 2);
       o += a->integrals[ii].n_entities;
     }

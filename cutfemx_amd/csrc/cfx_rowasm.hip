@@ -239,7 +239,7 @@ __global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ 
 // P1 facet folding (assemble_rows_kernel) needs every facet row to join two cells that share all dofs but one
 // each -- a continuous P1 space on a conforming mesh.  Flags bit 1 otherwise (DG spaces, extension pairs).
 __global__ void plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                       int nd, int* flag)
+                                       int nd, int nx, int* flag)
 {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
@@ -251,7 +251,7 @@ __global__ void plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ r
     for (int i = 0; i < nd; ++i) shared = shared || dofmap[c1 * nd + j] == dofmap[c0 * nd + i];
     nfree += shared ? 0 : 1;
   }
-  if (nfree != 1) atomicOr(flag, 2);
+  if (nfree != nx) atomicOr(flag, 2); // nx: dofs of a cell that are not on a given facet (continuous space)
 }
 
 // (counts / offsets / cursors are indexed by the dof's position in the special-row list: the
@@ -1400,9 +1400,13 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
-  if (P.nfacets > 0 && nd == V->mesh->tdim + 1 && nd > 4) // (nd <= 4: checked by plan_facet_rows_kernel)
+  if (P.nfacets > 0 && nd > 4 && V->degree == 2)
+  {
+    // degree 2: the two cells of a facet share the facet's dofs (6 in 3-D, 3 in 2-D) when the space is continuous
+    const int ns = V->mesh->tdim == 3 ? 6 : 3;
     launch("plan_check_fold", plan_check_fold_kernel, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
-           V->dofmap.p, nd, flag.p);
+           V->dofmap.p, nd, nd - ns, flag.p);
+  }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
   const int flags = read_scalar(flag.p);
   if (flags & 1) P.usable = false;

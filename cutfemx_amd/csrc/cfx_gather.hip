@@ -1953,6 +1953,89 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
     const int t = base + gl;
     const bool has = t < nf;
     const int64_t f = has ? (int64_t)A.d2f[fb + t] : 0;
+    if (DEG == 2 && A.fold_facets == 3)
+    {
+      if constexpr (DEG == 2)
+      {
+        // gradient jump, degree 2: facet_nq rank-one records per facet (assemble_rows_kernel has the scalar form);
+        // the vector term couples equal components only: row (dof, kc) receives columns (macro dof j, kc)
+        constexpr int WF = Elem<TDIM, DEG>::WF, NX = WF - ND;
+        double acc[WF];
+        int32_t cm[WF];
+#pragma unroll
+        for (int j = 0; j < WF; ++j) { acc[j] = 0.0; cm[j] = -1; }
+        if (has)
+        {
+          const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
+          int32_t d1[ND];
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            cm[j] = A.dofmap[(int64_t)row4.x * ND + j];
+            d1[j] = A.dofmap[(int64_t)row4.z * ND + j];
+          }
+          int m = -1, nfree = 0;
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+          {
+            bool shared = false;
+#pragma unroll
+            for (int i = 0; i < ND; ++i) shared = shared || d1[j] == cm[i];
+#pragma unroll
+            for (int e = 0; e < NX; ++e) cm[ND + e] = (!shared && nfree == e) ? d1[j] : cm[ND + e];
+            m = (!shared && d1[j] == (int32_t)r) ? ND + nfree : m;
+            nfree += shared ? 0 : 1;
+          }
+#pragma unroll
+          for (int i = 0; i < ND; ++i) m = (cm[i] == (int32_t)r) ? i : m;
+          if (nfree != NX) *A.error = 4;
+          const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * (int64_t)(A.facet_nq * 16));
+          for (int q = 0; q < A.facet_nq; ++q)
+          {
+            double v[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+            {
+              const double2 p = rec[q * 8 + k];
+              v[2 * k] = p.x; v[2 * k + 1] = p.y;
+            }
+            double jm = 0.0;
+#pragma unroll
+            for (int j = 0; j < WF; ++j) jm = (j == m) ? v[j] : jm;
+            jm *= v[WF];
+#pragma unroll
+            for (int j = 0; j < WF; ++j) acc[j] += jm * v[j];
+          }
+        }
+        int sl[WF];
+#pragma unroll
+        for (int j = 0; j < WF; ++j)
+        {
+          sl[j] = has ? find_slot(cm[j]) : -1;
+          if (has && (row_bc || (A.bc1 != nullptr && A.bc1[(int64_t)cm[j] * BS + kc] != 0))) acc[j] = 0.0;
+        }
+        if constexpr (ORDERED)
+        {
+          for (int turn = 0; turn < G; ++turn)
+          {
+            if (gl == turn)
+            {
+#pragma unroll
+              for (int j = 0; j < WF; ++j)
+                if (sl[j] >= 0) s_val[grp][sl[j] * BS + kc] += acc[j];
+            }
+            __syncthreads();
+          }
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < WF; ++j)
+            if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j] * BS + kc], acc[j]);
+        }
+      }
+      continue;
+    }
     int64_t fc[2] = {0, 0};
     int32_t cols[2][ND];
     int irow[2] = {-1, -1};
@@ -2244,7 +2327,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     }
     if (rank_one) A.fold_facets = 3;
     // degree 2, scalar: nq rank-one records per facet when every facet term is the gradient jump at one degree
-    if (DEG == 2 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0'))
+    if (DEG == 2 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0'))
     {
       bool low = true;
       int qd = -1;

@@ -315,6 +315,11 @@ struct Stencil
   DevArray<uint8_t> cpos;    // [ncells*nd]: position of the cell in the dof->cells list of its j-th dof
   bool built = false, usable = false;
   bool lists = false; // offsets + nbr are valid (any space); usable: slot4 / diagpos / cpos too (P1 on the geometry dofmap)
+  // degree-2 scalar spaces: per dof->cells entry a 12-byte record -- bytes 0..9 (0..5 in 2-D) the positions of the cell's
+  // dofs in the dof's neighbour list, byte 10 the local index of the dof in the cell (built on first use by
+  // cfx::space_stencil_slotn; needs every list shorter than 256)
+  DevArray<uint8_t> slotn;
+  bool slotn_built = false, slotn_ok = false;
   int max_len = 0; // longest neighbour list
   // Row tiles: kRowTile consecutive dofs.  Mesh-static per tile: the sorted union of its rows' neighbour lists
   // (tile_verts) and, parallel to nbr, the position of every neighbour in that union (st_loc).  The gather
@@ -500,6 +505,7 @@ namespace cfx
 {
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
+const Stencil& space_stencil_slotn(cfx_space_s* V);                     // cfx_rowasm.hip
 void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
@@ -519,6 +525,11 @@ struct cfx_pattern_s
   uint64_t split_plan = 0;
   cfx::DevArray<int32_t> short_rows, long_rows;
   int64_t n_short_rows = 0, n_long_rows = 0;
+  // degree-2 spaces with neighbour lists: the plain rows that copied their static list (every incident cell an uncut
+  // entity of the form's one stiffness integral); short_rows / long_rows then hold the other active rows only
+  uint64_t full_plan = 0;
+  cfx::DevArray<int32_t> full_rows;
+  int64_t n_full_rows = 0;
   cfx::DevArray<int64_t> indptr;
   cfx::DevArray<int32_t> indices;
 };

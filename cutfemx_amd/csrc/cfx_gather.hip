@@ -2188,6 +2188,95 @@ bool deterministic()
   return e && e[0] == '1';
 }
 
+// stage 2, bilinear forms, degree 2: the rows that copied their static neighbour list (cfx_pattern_s::full_rows --
+// every incident cell an uncut entity of the one stiffness integral).  An item = incidence entry + its 12-byte
+// slot record (cfx::Stencil::slotn): no marks, no dofmap row, no column search, no staged tensor -- the row of the
+// element tensor comes from p2_stiffness_row() and lands at the recorded positions of the row's LDS accumulators.
+// The row is stored when the matrix was just zeroed.
+struct P2PlainArgs
+{
+  int64_t n;
+  const int32_t* rows;
+  const double* x;
+  const int32_t* conn;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint8_t* slotn;
+  const int64_t* indptr;
+  double* values;
+  int fresh;
+  int* error;
+};
+
+template <int TDIM, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave, 4) assemble_rows_p2_plain_kernel(P2PlainArgs A)
+{
+  constexpr int ND = Elem<TDIM, 2>::ND, RPW = kWave / G;
+  __shared__ double s_val[RPW][CAP];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n;
+  const int64_t r = live ? A.rows[ri] : 0;
+  const int64_t rb = live ? A.indptr[r] : 0;
+  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+  for (int k = gl; k < len; k += G) s_val[grp][k] = 0.0;
+  __syncthreads();
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = (live && len > 0) ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  for (int base = 0;; base += G)
+  {
+    const int t = base + gl;
+    const bool has = t < nc;
+    if (__ballot(has) == 0) break;
+    double acc[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) acc[j] = 0.0;
+    uint32_t w0 = 0, w1 = 0, w2 = 0;
+    if (has)
+    {
+      const int64_t c = A.d2c[cb + t];
+      const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.slotn + (cb + t) * 12);
+      w0 = rec[0]; w1 = rec[1]; w2 = rec[2];
+      Geo<TDIM> g;
+      load_cell<TDIM>(A.x, A.conn, c, g);
+      jacobian<TDIM>(g);
+      p2_stiffness_row<TDIM>(g, (int)((w2 >> 16) & 0xffu), 1.0, acc);
+    }
+    int sl[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+    {
+      const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
+      sl[j] = has ? (int)((w >> (8 * (j & 3))) & 0xffu) : -1;
+    }
+    if constexpr (ORDERED)
+    {
+      for (int turn = 0; turn < G; ++turn)
+      {
+        if (gl == turn)
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j)
+            if (sl[j] >= 0) s_val[grp][sl[j]] += acc[j];
+        }
+        __syncthreads();
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
+    }
+  }
+  __syncthreads();
+  if (A.fresh)
+    for (int k = gl; k < len; k += G) A.values[rb + k] = s_val[grp][k];
+  else
+    for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k];
+}
+
 struct Stage1
 {
   std::vector<DevArray<double>> buffers;
@@ -2503,6 +2592,24 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   } while (0)
         CFX_LEAN(8, 64, P->short_rows.p, P->n_short_rows);
         CFX_LEAN(16, 256, P->long_rows.p, P->n_long_rows);
+        if (P->full_plan == plan.serial && P->n_full_rows > 0)
+        {
+          // the rows that copied their static list (not in the two lists above)
+          const Stencil& stn = a->V->stencil;
+          bool closed = !bc0 && !bc1 && stn.slotn_ok && stn.max_len <= 128;
+          for (int s = 0; s < A.n_cell; ++s) closed = closed && (A.cell[s].std_bits == nullptr || A.cell[s].std_inline == 3);
+          if (closed)
+          {
+            P2PlainArgs Q{};
+            Q.n = P->n_full_rows; Q.rows = P->full_rows.p; Q.x = A.x; Q.conn = A.conn; Q.d2c_off = A.d2c_off; Q.d2c = A.d2c;
+            Q.slotn = stn.slotn.p; Q.indptr = A.indptr; Q.values = A.values; Q.fresh = A.fresh; Q.error = A.error;
+            const dim3 grid = row_grid((Q.n + 7) / 8);
+            if (det) launch("assemble_rows_p2_plain", assemble_rows_p2_plain_kernel<TDIM, 8, 128, true>, grid, dim3(kWave), 0, Q);
+            else launch("assemble_rows_p2_plain", assemble_rows_p2_plain_kernel<TDIM, 8, 128, false>, grid, dim3(kWave), 0, Q);
+          }
+          else
+            CFX_LEAN(16, 256, P->full_rows.p, P->n_full_rows);
+        }
 #undef CFX_LEAN
         RowArgs S = A;
         S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;

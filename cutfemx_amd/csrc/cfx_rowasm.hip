@@ -1115,6 +1115,47 @@ __global__ void __launch_bounds__(kWave) plain_full_kernel(int64_t n_plain, cons
   }
 }
 
+// 12-byte slot records of a degree-2 scalar space (Stencil::slotn): 16 lanes per dof, the dof's neighbour list staged
+// in LDS, (incident cell, local dof) pairs spread over the lanes, one binary search each
+__global__ void __launch_bounds__(kWave) stencil_slotn_kernel(int64_t ndofs, const int64_t* __restrict__ d2c_off,
+                                                              const int32_t* __restrict__ d2c, const int32_t* __restrict__ dofmap, int nd,
+                                                              const int64_t* __restrict__ off, const int32_t* __restrict__ nbr,
+                                                              uint8_t* __restrict__ slotn)
+{
+  constexpr int G = 16, RPW = kWave / G;
+  __shared__ int32_t s_nbr[RPW][256];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  for (int64_t blk = blockIdx.x; blk * RPW < ndofs; blk += gridDim.x)
+  {
+    const int64_t r = blk * RPW + grp;
+    const bool live = r < ndofs;
+    const int64_t b = live ? off[r] : 0;
+    const int len = live ? (int)(off[r + 1] - b) : 0; // < 256 (space_stencil_slotn gives up otherwise)
+    for (int k = gl; k < len; k += G) s_nbr[grp][k] = nbr[b + k];
+    __syncthreads();
+    if (live)
+    {
+      const int64_t cb = d2c_off[r];
+      const int npairs = (int)(d2c_off[r + 1] - cb) * nd;
+      for (int t = gl; t < npairs; t += G)
+      {
+        const int q = t / nd, j = t - q * nd;
+        const int32_t v = dofmap[(int64_t)d2c[cb + q] * nd + j];
+        int lo = 0, hi = len;
+        while (lo < hi)
+        {
+          const int mid = (lo + hi) >> 1;
+          if (s_nbr[grp][mid] < v) lo = mid + 1; else hi = mid;
+        }
+        uint8_t* rec = slotn + (cb + q) * 12;
+        rec[j] = (uint8_t)lo;
+        if (v == (int32_t)r) rec[10] = (uint8_t)j;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 struct StaticLenTest
 {
   const int32_t* rows;
@@ -1126,6 +1167,12 @@ struct StaticLenTest
     const int64_t r = rows[i];
     return ((int)(st_off[r + 1] - st_off[r]) > limit) == above;
   }
+};
+
+struct FlagSet8
+{
+  const uint8_t* f;
+  __device__ bool operator()(int64_t i) const { return f[i] != 0; }
 };
 
 struct FlagIsZero
@@ -1502,6 +1549,23 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
   return S;
 }
 
+const Stencil& space_stencil_slotn(cfx_space_s* V)
+{
+  Stencil& S = const_cast<Stencil&>(space_stencil(V));
+  if (S.slotn_built) return S;
+  S.slotn_built = true;
+  const char* env = getenv("CFX_P2_PLAIN");
+  if ((env && env[0] == '0') || !S.lists || S.usable || V->degree != 2 || V->bs != 1 || V->ndofs_cell > 10 || S.max_len > 255)
+    return S;
+  const Adjacency& adj = V->dof_cells();
+  S.slotn.alloc(adj.cells.n * 12);
+  S.slotn.zero();
+  launch("stencil_slotn", stencil_slotn_kernel, wave_grid((V->ndofs + 3) / 4), dim3(kWave), 0, V->ndofs, adj.offsets.p,
+         adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slotn.p);
+  S.slotn_ok = true;
+  return S;
+}
+
 void plain_row_masks(cfx_form_s* a)
 {
   cfx_row_plan& plan = row_plan(a);
@@ -1775,16 +1839,42 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   P->stencil_plan = use_stencil ? plan.serial : 0;
   // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
   P->split_plan = 0;
+  P->full_plan = 0;
   if (P->max_row_len > 64 && V->bs == 1 && plan.n_active_rows > 0)
   {
-    P->n_short_rows = compact("pattern_short_rows", plan.n_active_rows,
-                              RowLenTest{plan.active_rows.p, P->indptr.p, 64, false}, P->short_rows);
-    P->n_long_rows = compact("pattern_long_rows", plan.n_active_rows,
-                             RowLenTest{plan.active_rows.p, P->indptr.p, 64, true}, P->long_rows);
+    // degree 2 with slot records, one uncut stiffness integral: the copied rows get their own gather kernel
+    // (assemble_rows_p2_plain_kernel); the split below then covers the other active rows only
+    const int32_t* base_rows = plan.active_rows.p;
+    int64_t n_base = plan.n_active_rows;
+    if (any_full && V->degree == 2)
+    {
+      int n_std = 0;
+      bool closed = true;
+      for (const auto& I : a->integrals)
+        if (I.type == CFX_CELL && I.n_entities > 0)
+        {
+          ++n_std;
+          closed = closed && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0;
+        }
+      const char* cf = getenv("CFX_P2_CLOSED");
+      if (n_std == 1 && closed && a->rank == 2 && !(cf && cf[0] == '0') && space_stencil_slotn(V).slotn_ok)
+      {
+        DevArray<int32_t> pos;
+        P->n_full_rows = compact("pattern_full_rows", plan.n_plain_rows, FlagSet8{full.p}, pos);
+        P->full_rows.alloc(P->n_full_rows);
+        launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
+               plan.plain_rows.p, P->full_rows.p);
+        P->full_plan = plan.serial;
+        base_rows = rows_h;
+        n_base = n_h;
+      }
+    }
+    P->n_short_rows = compact("pattern_short_rows", n_base, RowLenTest{base_rows, P->indptr.p, 64, false}, P->short_rows);
+    P->n_long_rows = compact("pattern_long_rows", n_base, RowLenTest{base_rows, P->indptr.p, 64, true}, P->long_rows);
     launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_short_rows), dim3(kBlock), 0, P->n_short_rows,
-           plan.active_rows.p, P->short_rows.p);
+           base_rows, P->short_rows.p);
     launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_long_rows), dim3(kBlock), 0, P->n_long_rows,
-           plan.active_rows.p, P->long_rows.p);
+           base_rows, P->long_rows.p);
     P->split_plan = plan.serial;
   }
 }

@@ -1055,7 +1055,7 @@ __global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int n
                                                                 double* __restrict__ out)
 {
   constexpr int ND = Elem<TDIM, 2>::ND, WF = Elem<TDIM, 2>::WF, NX = WF - ND;
-  static_assert(WF + 1 <= 16, "record of 16 doubles");
+  static_assert(WF + 1 <= 16 && WF <= 15, "record of 16 doubles, 16 column ids");
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t f = t / nq;
   if (f >= n) return;
@@ -1190,9 +1190,36 @@ __global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int n
 #pragma unroll
   for (int k = 0; k < WF; ++k) rec[k] = jf[k];
   rec[WF] = wref[q] * scale * gamma * havg;
-  double2* o = reinterpret_cast<double2*>(out + 16 * t);
+  // facet block: 16 int32 (the WF macro columns, -1 padding, entry 15 = number of cell 1's dofs cell 0 lacks),
+  // then nq records of 16 doubles
+  double* blk = out + f * (int64_t)(8 + 16 * nq);
+  double2* o = reinterpret_cast<double2*>(blk + 8 + 16 * q);
 #pragma unroll
   for (int k = 0; k < 8; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+  if (q == 0)
+  {
+    int32_t cm[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) cm[k] = -1;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) cm[i] = dofmap[c0 * ND + i];
+    int nf2 = 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+    {
+      const int32_t dj = dofmap[c1 * ND + j];
+      bool shared = false;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) shared = shared || dj == cm[i];
+#pragma unroll
+      for (int e = 0; e < NX; ++e) cm[ND + e] = (!shared && nf2 == e) ? dj : cm[ND + e];
+      nf2 += shared ? 0 : 1;
+    }
+    cm[15] = nf2;
+    int4* oc = reinterpret_cast<int4*>(blk);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) oc[k] = make_int4(cm[4 * k], cm[4 * k + 1], cm[4 * k + 2], cm[4 * k + 3]);
+  }
 }
 } // namespace
 

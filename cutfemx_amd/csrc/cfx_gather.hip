@@ -875,30 +875,16 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
         if (has)
         {
           const int64_t f = A.d2f[fb + t];
-          const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
-          int32_t d1[ND];
+          // the facet's block: its macro columns (16 int32), then the records
+          const double* blk = A.facet_tensors + f * (int64_t)(8 + 16 * A.facet_nq);
+          const int4* cmp = reinterpret_cast<const int4*>(blk);
+          const int4 q0 = cmp[0], q1 = cmp[1], q2 = cmp[2], q3 = cmp[3];
+          const int32_t c16[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+          int m = -1;
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            cm[j] = A.dofmap[(int64_t)row4.x * ND + j];
-            d1[j] = A.dofmap[(int64_t)row4.z * ND + j];
-          }
-          int m = -1, nfree = 0;
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            bool shared = false;
-#pragma unroll
-            for (int i = 0; i < ND; ++i) shared = shared || d1[j] == cm[i];
-#pragma unroll
-            for (int e = 0; e < NX; ++e) cm[ND + e] = (!shared && nfree == e) ? d1[j] : cm[ND + e];
-            m = (!shared && d1[j] == (int32_t)r) ? ND + nfree : m;
-            nfree += shared ? 0 : 1;
-          }
-#pragma unroll
-          for (int i = 0; i < ND; ++i) m = (cm[i] == (int32_t)r) ? i : m;
-          if (nfree != NX) *A.error = 4; // not an interior facet of a conforming mesh with a continuous space
-          const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * (int64_t)(A.facet_nq * 16));
+          for (int j = 0; j < WF; ++j) { cm[j] = c16[j]; m = (c16[j] == (int32_t)r) ? j : m; }
+          if (c16[15] != NX) *A.error = 4; // not an interior facet of a conforming mesh with a continuous space
+          const double2* rec = reinterpret_cast<const double2*>(blk + 8);
           for (int q = 0; q < A.facet_nq; ++q)
           {
             double v[16];
@@ -1964,32 +1950,17 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
         int32_t cm[WF];
 #pragma unroll
         for (int j = 0; j < WF; ++j) { acc[j] = 0.0; cm[j] = -1; }
+        const double* blk = A.facet_tensors + f * (int64_t)(8 + 16 * A.facet_nq);
         if (has)
         {
-          const int4 row4 = *reinterpret_cast<const int4*>(A.facet_rows + 4 * f);
-          int32_t d1[ND];
+          const int4* cmp = reinterpret_cast<const int4*>(blk);
+          const int4 q0 = cmp[0], q1 = cmp[1], q2 = cmp[2], q3 = cmp[3];
+          const int32_t c16[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+          int m = -1;
 #pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            cm[j] = A.dofmap[(int64_t)row4.x * ND + j];
-            d1[j] = A.dofmap[(int64_t)row4.z * ND + j];
-          }
-          int m = -1, nfree = 0;
-#pragma unroll
-          for (int j = 0; j < ND; ++j)
-          {
-            bool shared = false;
-#pragma unroll
-            for (int i = 0; i < ND; ++i) shared = shared || d1[j] == cm[i];
-#pragma unroll
-            for (int e = 0; e < NX; ++e) cm[ND + e] = (!shared && nfree == e) ? d1[j] : cm[ND + e];
-            m = (!shared && d1[j] == (int32_t)r) ? ND + nfree : m;
-            nfree += shared ? 0 : 1;
-          }
-#pragma unroll
-          for (int i = 0; i < ND; ++i) m = (cm[i] == (int32_t)r) ? i : m;
-          if (nfree != NX) *A.error = 4;
-          const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * (int64_t)(A.facet_nq * 16));
+          for (int j = 0; j < WF; ++j) { cm[j] = c16[j]; m = (c16[j] == (int32_t)r) ? j : m; }
+          if (c16[15] != NX) *A.error = 4;
+          const double2* rec = reinterpret_cast<const double2*>(blk + 8);
           for (int q = 0; q < A.facet_nq; ++q)
           {
             double v[16];
@@ -2430,7 +2401,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       const int nq = low ? quad_npoints(TDIM - 1, qd) : 0;
       if (low && nq >= 1 && nq <= 6) { A.fold_facets = 3; A.facet_nq = nq; }
     }
-    const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 16 * A.facet_nq : 8)
+    const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 8 + 16 * A.facet_nq : 8)
                                              : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
     st.buffers.emplace_back(plan.nfacets * fsize);
     A.facet_tensors = st.buffers.back().p;

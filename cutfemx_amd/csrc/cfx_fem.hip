@@ -927,8 +927,8 @@ namespace
 // P1 gradient-jump ghost penalty, stage 1 for the row gather: the facet tensor gamma h_avg |F| [dn N_i][dn N_j] is
 // RANK ONE (P1 gradients are constant), and folded over the dofs the two cells share it is w jf jf^T with
 // jf = (jump of cell 0's basis i + that of its twin in cell 1, ..., jump of cell 1's free dof).  One thread per facet
-// writes the 64-byte record (jf[0..ND], w) instead of eight threads writing 64 (folded: 25) doubles; the gather
-// forms row r as w jf[m(r)] jf[.].  facet_local_row() is the generic statement of the same integrand.
+// writes the 80-byte record (jf[0..ND], w, the macro column ids) instead of eight threads writing 64 (folded: 25)
+// doubles; the gather forms row r as w jf[m(r)] jf[.] without touching the facet row or the dofmap.  facet_local_row() is the generic statement of the same integrand.
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const int32_t* __restrict__ rows,
                                                                const double* __restrict__ x, const int32_t* __restrict__ conn,
@@ -1032,15 +1032,34 @@ __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const 
     nfree += shared ? 0 : 1;
   }
   if (error && nfree != 1) *error = 4; // not an interior facet of a conforming mesh with a continuous space
-  double rec[8];
+  // 80-byte record: 6 doubles (jf[0..ND], w; 2-D: one unused), then 8 int32: the ND + 1 macro columns (cell 0's dofs,
+  // cell 1's free dof), -1 padding, entry 7 = number of dofs of cell 1 that cell 0 lacks (1 on a conforming mesh)
+  double rec[6];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) rec[k] = 0.0;
+  for (int k = 0; k < 6; ++k) rec[k] = 0.0;
 #pragma unroll
   for (int k = 0; k <= ND; ++k) rec[k] = jf[k];
   rec[ND + 1] = wsum * scale * gamma * havg;
-  double2* o = reinterpret_cast<double2*>(out + 8 * f);
+  int32_t cm[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+  for (int k = 0; k < 8; ++k) cm[k] = -1;
+#pragma unroll
+  for (int i = 0; i < ND; ++i) cm[i] = d0[i];
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
+  {
+    bool shared = false;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) shared = shared || d1[j] == d0[i];
+    cm[ND] = shared ? cm[ND] : d1[j];
+  }
+  cm[7] = nfree;
+  double2* o = reinterpret_cast<double2*>(out + 10 * f);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) o[k] = make_double2(rec[2 * k], rec[2 * k + 1]);
+  int4* oc = reinterpret_cast<int4*>(out + 10 * f + 6);
+  oc[0] = make_int4(cm[0], cm[1], cm[2], cm[3]);
+  oc[1] = make_int4(cm[4], cm[5], cm[6], cm[7]);
 }
 // Degree-2 gradient-jump ghost penalty, stage 1 for the row gather: at one quadrature point q the integrand is the
 // rank-one matrix w_q [dn N_i][dn N_j], so the facet tensor is a sum of nq rank-one terms (nq = 3 for degree-2
@@ -1237,7 +1256,7 @@ void dump_integral(cfx_form_s* a, int integral, int parts, double* out, bool fol
   A.dump_fold = fold_facets ? 1 : 0;
   launch_integral(a, a->integrals[integral], A, -1, 0, parts);
 }
-// stage 1 of the P1 gradient-jump facets for the row gather: 8 doubles per facet (facet_jump_p1_kernel)
+// stage 1 of the P1 gradient-jump facets for the row gather: 10 doubles per facet (facet_jump_p1_kernel)
 void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
 {
   cfx_space_s* V = a->V;

@@ -860,6 +860,43 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
     const int t = base + gl;
     const bool has = t < nfl;
     if (__ballot(has) == 0) break;
+    if (DEG == 1 && A.fold_facets == 3)
+    {
+      if constexpr (DEG == 1)
+      {
+        // P1 gradient jump: one 80-byte record per facet -- (jf[0..ND], w) and the ND + 1 macro columns; row m(r) of
+        // the folded tensor = w jf[m] jf[.].  Neither the facet row nor the dofmap is read
+        constexpr int WF = ND + 1;
+        double acc[WF];
+        int32_t cm[WF];
+        int sl[WF];
+#pragma unroll
+        for (int j = 0; j < WF; ++j) { acc[j] = 0.0; cm[j] = -1; sl[j] = -1; }
+        if (has)
+        {
+          const int64_t f = A.d2f[fb + t];
+          const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * 10);
+          const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+          const int4 c0 = *reinterpret_cast<const int4*>(rec + 3), c1 = *reinterpret_cast<const int4*>(rec + 4);
+          const double jf[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
+          const int32_t c8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+          int m = -1;
+#pragma unroll
+          for (int j = 0; j < WF; ++j) { cm[j] = c8[j]; m = (c8[j] == (int32_t)r) ? j : m; }
+          if (c8[7] != 1) *A.error = 4; // not an interior facet of a conforming mesh with a continuous space
+          double jm = 0.0;
+#pragma unroll
+          for (int j = 0; j < WF; ++j) jm = (j == m) ? jf[j] : jm;
+          jm *= jf[ND + 1];
+#pragma unroll
+          for (int j = 0; j < WF; ++j) acc[j] = jm * jf[j];
+#pragma unroll
+          for (int j = 0; j < WF; ++j) sl[j] = find_slot(cm[j]);
+        }
+        add_item(std::integral_constant<int, WF>{}, has, cm, acc, sl);
+      }
+      continue;
+    }
     if (DEG == 2 && A.fold_facets == 3)
     {
       if constexpr (DEG == 2)
@@ -940,21 +977,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
         i0 = cols[j] == (int32_t)r ? j : i0;
         i1 = cols[ND + j] == (int32_t)r ? ND + j : i1;
       }
-      if (DEG == 1 && A.fold_facets == 3)
-      {
-        // rank-one record of the gradient-jump term: (jf[0..ND], w); row m(r) of the folded tensor = w jf[m] jf[.]
-        const double2* rec = reinterpret_cast<const double2*>(A.facet_tensors + f * 8);
-        const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-        const double jf[6] = {r0.x, r0.y, r1.x, r1.y, r2.x, r2.y};
-        const int m = i0 >= 0 ? i0 : ND;
-        double jm = 0.0;
-#pragma unroll
-        for (int j = 0; j <= ND; ++j) jm = (j == m) ? jf[j] : jm;
-        jm *= jf[ND + 1];
-#pragma unroll
-        for (int j = 0; j <= ND; ++j) acc[j] = jm * jf[j];
-      }
-      else if (DEG == 1 && A.fold_facets == 2)
+      if (DEG == 1 && A.fold_facets == 2)
       {
         // stage 1 stored the tensor folded over the shared dofs: macro row of r = its index in cell 0, or ND
         // (the dof of cell 1 that cell 0 does not have); one row of ND + 1 entries, the free column last
@@ -978,7 +1001,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
       }
       }
     }
-    if (DEG == 1 && A.fold_facets >= 2)
+    if (DEG == 1 && A.fold_facets == 2)
     {
      if constexpr (DEG == 1)
      {
@@ -2401,7 +2424,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       const int nq = low ? quad_npoints(TDIM - 1, qd) : 0;
       if (low && nq >= 1 && nq <= 6) { A.fold_facets = 3; A.facet_nq = nq; }
     }
-    const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 8 + 16 * A.facet_nq : 8)
+    const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 8 + 16 * A.facet_nq : 10)
                                              : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
     st.buffers.emplace_back(plan.nfacets * fsize);
     A.facet_tensors = st.buffers.back().p;

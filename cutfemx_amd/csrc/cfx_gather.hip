@@ -2476,7 +2476,8 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         if (A.cell[s].std_inline == 2) inline_bits |= 1u << s;
         else if (A.cell[s].std_bits) all_inline = false; // staged uncut tensors: generic path
       }
-      if (all_inline && inline_bits && 2 * plan.n_special_rows <= plan.n_active_rows)
+      const char* fs1 = getenv("CFX_ROWS_SPLIT");
+      if (all_inline && inline_bits && (2 * plan.n_special_rows <= plan.n_active_rows || (fs1 && fs1[0] == '1')))
       {
         split = true;
         RowArgs F = A;
@@ -2569,7 +2570,9 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       // degree 2: (a) the uncut items of every row with the lean kernel, short rows (<= 64 columns:
       // the edge dofs, ~5 cells each) 8 lanes per row, long rows 16; (b) rule + facet items of the
       // interface rows with the full kernel.  Needs the row partition made with the pattern.
-      if (P->split_plan == plan.serial && mr > 64 && mr <= 256 && plan.n_special_rows * 2 <= plan.n_active_rows)
+      const char* fs = getenv("CFX_ROWS_SPLIT"); // '1': split whatever the share of the interface rows (tests on small meshes)
+      if (P->split_plan == plan.serial && mr > 64 && mr <= 256
+          && (plan.n_special_rows * 2 <= plan.n_active_rows || (fs && fs[0] == '1')))
       {
         split = true;
 #define CFX_LEAN(GG, CAPP, ROWS, NROWS)                                                                              \

@@ -104,3 +104,25 @@ def oracle_dg_poisson(O, mesh, phi, degree=1, order=4, sigma=10.0, sigma_gamma=2
     return dict(V=V, dofmap=dofmap, ndofs=ndofs, domain=dom, inside=inside, active=active, vol=vol, itf=itf,
                 normals=normals, skeleton=skeleton, hosts=H, fdom=fdom, omega_facets=omega_facets,
                 facet_rules=facet_rules, ghost=ghost, a=a, L=L)
+
+
+def profiled(fn):
+    """fn() with the engine's per-kernel profile on: (result, {kernel name: launches})."""
+    import ctypes as C
+    from cutfemx_amd import _lib
+    l = _lib.lib()
+    _lib.check(l.cfx_profile_enable(1))
+    _lib.check(l.cfx_profile_reset())
+    try:
+        out = fn()
+        names = {}
+        for i in range(l.cfx_profile_count()):
+            name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
+            _lib.check(l.cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
+            if cnt.value:
+                names[name.value.decode()] = cnt.value
+    finally:
+        _lib.check(l.cfx_profile_enable(0))
+    return out, names
+
+

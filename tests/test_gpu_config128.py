@@ -6,7 +6,7 @@ The oracle needs ~10 s and ~3 GB of host memory at this size."""
 import numpy as np
 import pytest
 
-from helpers import level_set_values, oracle_poisson, rel_err
+from helpers import level_set_values, oracle_poisson, profiled, rel_err
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -88,3 +88,21 @@ def test_cfg128_csr_and_rhs(cfg):
     O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, bb)
     assert rel_err(A.data, vals) < RTOL and rel_err(b, bb) < RTOL
     assert np.all(b[ref["inactive"]] == 0.0)
+
+
+def test_cfg128_takes_the_specialised_kernels(cfg):
+    """The kernels the 512^3 numbers are measured on must be the ones that run here: row tiles for the plain rows,
+    facet records, the series source kernel, mask-based sparsity (a silent fall back to the generic paths would keep
+    every parity test green)."""
+    import cutfemx_amd as cfx
+
+    def run():
+        A = cfx.fem.create_matrix(cfg["sys"].a)
+        cfx.fem.assemble_matrix(cfg["sys"].a, A=A)
+        return A, cfx.fem.assemble_vector(cfg["sys"].L)
+    (A, b), names = profiled(run)
+    assert rel_err(A.data, cfg["ref"]["values"]) < RTOL and rel_err(b, cfg["ref"]["b"]) < RTOL
+    for k in ("assemble_tiles_plain", "assemble_rows_p1", "assemble_rows_cut", "assemble_facets", "vec_tensors_std",
+              "assemble_vec_plain", "pattern_plain_write", "pattern_rows"):   # (the plan and its masks are cached)
+        assert k in names, (k, sorted(names))
+    assert "assemble_rows_plain" not in names and "assemble_rows" not in names    # per-row fallback / unsplit path

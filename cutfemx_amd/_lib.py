@@ -83,7 +83,7 @@ SYMBOLS = [
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
     "cfx_cut_restrict", "cfx_cut_create_facets", "cfx_exterior_facets", "cfx_full_facet_rules",
     "cfx_facet_rules_to_cells", "cfx_cut_update", "cfx_cut_info", "cfx_cut_domain", "cfx_locate_entities",
-    "cfx_runtime_quadrature", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
+    "cfx_runtime_quadrature", "cfx_runtime_quadratures", "cfx_full_cell_rules", "cfx_rules_create", "cfx_rules_view_get",
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_interior_facets_for_cells", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",
     "cfx_cell_aggregation_destroy", "cfx_cut_destroy", "cfx_space_create",

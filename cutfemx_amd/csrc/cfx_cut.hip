@@ -717,13 +717,22 @@ static_assert(kEmitLanes >= 4 && 64 % kEmitLanes == 0, "lanes 0..tdim of a group
 // interface).  Volume parts: one rule per cut cell; interface: one rule per
 // sub-facet (cut.cpp:1286-1294).
 // ---------------------------------------------------------------------------
+struct EmitJobs
+{
+  int n;
+  int part[2];
+  const int64_t* packed_off[2];
+  double* points[2];
+  double* weights[2];
+  int32_t* offsets[2];
+  int32_t* parent_map[2];
+};
+
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     int64_t ncut, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
     const int32_t* __restrict__ conn, const int32_t* __restrict__ ls_dofmap, const double* __restrict__ phi_v,
-    int part, int degree, const int64_t* __restrict__ packed_off,
-    double* __restrict__ points, double* __restrict__ weights, int32_t* __restrict__ offsets,
-    int32_t* __restrict__ parent_map)
+    int degree, EmitJobs jobs)
 {
   constexpr int NV = TDIM + 1;
   // kEmitLanes lanes share one cut cell (16 cells per wavefront): a cell emits
@@ -755,7 +764,6 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     for (int d = 0; d < TDIM; ++d) g.x[v][d] = s_x[wave][v][d];
   }
   const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
-  const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
   // the cell's local points (vertices + edge cut points, at most 2 NV) once per cell: one lane each, so the
   // division of a cut point is done once instead of once per (quadrature point, sub-simplex vertex)
   __shared__ double s_P[kBlock / kEmitLanes][2 * NV][TDIM];
@@ -768,7 +776,18 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
       for (int d = 0; d < TDIM; ++d) s_P[wave][p][d] = X[d];
     }
   __syncthreads();
-  if (!live || ns == 0) return;
+  if (!live) return;
+  // one or two rule sets of the same cut (runtime_quadratures: e.g. "phi<0" and "phi=0"): the staging above is shared
+  for (int job = 0; job < jobs.n; ++job)
+  {
+  const int part = jobs.part[job];
+  const int64_t* __restrict__ packed_off = jobs.packed_off[job];
+  double* __restrict__ points = jobs.points[job];
+  double* __restrict__ weights = jobs.weights[job];
+  int32_t* __restrict__ offsets = jobs.offsets[job];
+  int32_t* __restrict__ parent_map = jobs.parent_map[job];
+  const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
+  if (ns == 0) continue;
   int nref;
   const double* wref;
   const double* pref = ref_points<TDIM>(part == PART_IF ? TDIM - 1 : TDIM, degree, nref, wref);
@@ -894,6 +913,7 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
       offsets[rbase + 1] = pbase + npts;
     }
   }
+  } // jobs
 }
 
 // whole-cell rules: reference points, weights * |detJ|
@@ -2129,6 +2149,75 @@ void multi_runtime_quadrature(cfx_cut_t cut, const Selector& sel, int order, cfx
 }
 } // namespace
 
+namespace
+{
+// runtime rules of one level set on cell hosts for one or two parts (PART_IN / PART_OUT / PART_IF) of the same cut:
+// one count + scan per part, ONE read-back of the totals, one emit launch that stages every cut cell once
+void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t* out)
+{
+  cfx_mesh_t mesh = cut->mesh;
+  const int tdim = mesh->tdim;
+  const DevArray<int32_t>& cutc = locate(cut, "phi=0");
+  const int64_t ncut = cutc.n;
+  const double* phi = cut->ls_values[0].p;
+  require(ncut < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
+  std::unique_ptr<cfx_rules_s> r[2];
+  DevArray<int64_t> packed[2], packed_off[2];
+  DevArray<int64_t> totals_dev(2);
+  for (int k = 0; k < n; ++k)
+  {
+    const int nref = quad_npoints(parts[k] == PART_IF ? tdim - 1 : tdim, order);
+    r[k] = std::make_unique<cfx_rules_s>();
+    r[k]->mesh = mesh; r[k]->tdim = tdim; r[k]->gdim = mesh->gdim;
+    packed[k].alloc(ncut);
+    packed_off[k].alloc(ncut + 1);
+    if (ncut > 0)
+    {
+      if (tdim == 2)
+        launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+               parts[k], nref, packed[k].p);
+      else
+        launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+               parts[k], nref, packed[k].p);
+    }
+    // one scan for both totals of a part: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so below
+    // 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
+    exclusive_scan(packed[k].p, packed_off[k].p, ncut);
+    CFX_HIP(hipMemcpyAsync(totals_dev.p + k, packed_off[k].p + ncut, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx().stream));
+  }
+  struct Two { int64_t v[2]; };
+  const Two totals = read_scalar(reinterpret_cast<const Two*>(totals_dev.p));
+  EmitJobs jobs{};
+  jobs.n = n;
+  for (int k = 0; k < n; ++k)
+  {
+    const int64_t nq = totals.v[k] & kPackMask, nr = totals.v[k] >> kPackShift;
+    // int32 offsets are part of the RuntimeQuadrature contract
+    require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
+    r[k]->nq = nq; r[k]->nr = nr;
+    r[k]->points.alloc(nq * tdim);
+    r[k]->weights.alloc(nq);
+    r[k]->offsets.alloc(nr + 1);
+    r[k]->parent_map.alloc(nr);
+    dev_fill(r[k]->offsets.p, 0, sizeof(int32_t));
+    jobs.part[k] = parts[k]; jobs.packed_off[k] = packed_off[k].p;
+    jobs.points[k] = r[k]->points.p; jobs.weights[k] = r[k]->weights.p;
+    jobs.offsets[k] = r[k]->offsets.p; jobs.parent_map[k] = r[k]->parent_map.p;
+  }
+  if (ncut > 0)
+  {
+    const dim3 grid((unsigned)((ncut + kBlock / kEmitLanes - 1) / (kBlock / kEmitLanes)));
+    if (tdim == 2)
+      launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+             cut->ls_dofmap.p, phi, order, jobs);
+    else
+      launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+             cut->ls_dofmap.p, phi, order, jobs);
+  }
+  for (int k = 0; k < n; ++k) out[k] = r[k].release();
+}
+} // namespace
+
 extern "C" {
 
 int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const char* backend, cfx_rules_t* out)
@@ -2157,50 +2246,49 @@ int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, const
   }
   const int m = sel.mask[0];
   const int part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
-  const int nref = quad_npoints(part == PART_IF ? tdim - 1 : tdim, order);
+  simple_rules(cut, 1, &part, order, out);
+  CFX_API_END
+}
 
-  const DevArray<int32_t>& cutc = locate(cut, "phi=0");
-  const int64_t ncut = cutc.n;
-  auto r = std::make_unique<cfx_rules_s>();
-  r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim;
-  DevArray<int64_t> packed(ncut), packed_off(ncut + 1);
-  const double* phi = cut->ls_values[0].p;
-  if (ncut > 0)
+int cfx_runtime_quadratures(cfx_cut_t cut, int n, const char* const* selectors, int order, const char* backend,
+                            cfx_rules_t* out)
+{
+  CFX_API_BEGIN
+  require(cut && selectors && out && n >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_runtime_quadratures: null argument");
+  for (int k = 0; k < n; ++k) out[k] = nullptr;
+  // pairs of plain selectors of one level set on cell hosts share one pass over the cut cells; everything else is
+  // the single call, selector by selector
+  int k = 0;
+  auto plain_part = [&](const char* text, int& part) -> bool
   {
-    if (tdim == 2)
-      launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
-             part, nref, packed.p);
-    else
-      launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
-             part, nref, packed.p);
-  }
-  // one scan, one read-back for both totals: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so
-  // below 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
-  // int32 offsets are part of the RuntimeQuadrature contract: the point total is checked against 2^31 below
-  require(ncut < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
-  exclusive_scan(packed.p, packed_off.p, ncut);
-  const int64_t totals = read_scalar(packed_off.p + ncut);
-  const int64_t nq = totals & kPackMask, nr = totals >> kPackShift;
-  require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
-  r->nq = nq; r->nr = nr;
-  r->points.alloc(nq * tdim);
-  r->weights.alloc(nq);
-  r->offsets.alloc(nr + 1);
-  r->parent_map.alloc(nr);
-  dev_fill(r->offsets.p, 0, sizeof(int32_t));
-  if (ncut > 0)
+    if (!text || cut->host_width != 0 || cut->nls != 1 || cut->ls_ndofs_cell != cut->mesh->tdim + 1) return false;
+    if (backend && strcmp(backend, "straight") != 0) return false;
+    if (order < 0 || order > CFX_QUAD_MAX_DEGREE) return false;
+    Selector sel;
+    try { sel = parse_selector(text, cut->nls); } catch (const Error&) { return false; }
+    if (sel.n != 1) return false;
+    const int m = sel.mask[0];
+    if (m != 1 && m != 2 && m != 4) return false; // "<", "=", ">" only: the unions keep the single call
+    part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
+    return true;
+  };
+  while (k < n)
   {
-    const dim3 grid((unsigned)((ncut + kBlock / kEmitLanes - 1) / (kBlock / kEmitLanes)));
-    if (tdim == 2)
-      launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
-             cut->ls_dofmap.p, phi, part, order, packed_off.p, r->points.p, r->weights.p, r->offsets.p,
-             r->parent_map.p);
-    else
-      launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
-             cut->ls_dofmap.p, phi, part, order, packed_off.p, r->points.p, r->weights.p, r->offsets.p,
-             r->parent_map.p);
+    int parts[2];
+    if (k + 1 < n && plain_part(selectors[k], parts[0]) && plain_part(selectors[k + 1], parts[1]))
+    {
+      simple_rules(cut, 2, parts, order, out + k);
+      k += 2;
+      continue;
+    }
+    const int rc = cfx_runtime_quadrature(cut, selectors[k], order, backend, out + k);
+    if (rc != CFX_OK)
+    {
+      for (int q = 0; q < k; ++q) { delete out[q]; out[q] = nullptr; }
+      return rc;
+    }
+    ++k;
   }
-  *out = r.release();
   CFX_API_END
 }
 

@@ -417,7 +417,14 @@ def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: 
 
 
 def runtime_quadratures(cut_data: CutData, ls_parts: Sequence[str], order: int, *, backend: str = "straight"):
-    return {str(p): runtime_quadrature(cut_data, str(p), order, backend=backend) for p in ls_parts}
+    """Rules of several selectors of one cut, {selector: rules} (python/cutfemx/cut.py runtime_quadratures,
+    cut.h:178-181).  One library call: pairs of plain selectors share the pass over the cut cells."""
+    parts = [str(p) for p in ls_parts]
+    sels = [_engine_selector(cut_data, p) for p in parts]
+    arr = (C.c_char_p * len(sels))(*sels)
+    out = (C.c_void_p * len(sels))()
+    _lib.check(_lib.lib().cfx_runtime_quadratures(cut_data._h, len(sels), arr, int(order), backend.encode(), out))
+    return {p: RuntimeQuadratureRules(C.c_void_p(out[i]), cut_data.mesh, cut_data.dtype) for i, p in enumerate(parts)}
 
 
 def full_cell_rules(mesh: Mesh, cells, order: int) -> RuntimeQuadratureRules:

@@ -403,7 +403,9 @@ class DistributedPoisson:
         if mode not in ("owner", "reduce"):
             raise ValueError("mode must be 'owner' or 'reduce'")
         self.mode = mode
-        self.comm = DistComm() if part.world > 1 else None
+        import torch.distributed as tdist
+        # (no process group: a single process timing one rank's slab, tools/rank_balance.py)
+        self.comm = DistComm() if part.world > 1 and tdist.is_available() and tdist.is_initialized() else None
         self.mesh = cfx.Mesh.create_slab(part.n, part.lz0, part.nz_local)
         self.V = cfx.FunctionSpace(self.mesh, 1)
         n = part.n

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import fem
 from .cut import (cut, ghost_penalty_facets, interior_facets_for_cells, locate_entities, locate_entities_device, normal,
-                  runtime_quadrature)
+                  runtime_quadrature, runtime_quadratures)
 from .mesh import FunctionSpace
 
 
@@ -35,8 +35,8 @@ def build_forms(V, cut_data, *, order: int = 4, gamma: float = 40.0, gamma_g: fl
                 ghost_penalty: bool = True, source_degree: int = 4) -> PoissonSystem:
     """locate -> runtime rules -> normals -> forms; everything stays in HBM."""
     inside = locate_entities_device(cut_data, "phi<0")
-    volume_rules = runtime_quadrature(cut_data, "phi<0", order)
-    interface_rules = runtime_quadrature(cut_data, "phi=0", order)
+    rules = runtime_quadratures(cut_data, ["phi<0", "phi=0"], order)     # one pass over the cut cells for both
+    volume_rules, interface_rules = rules["phi<0"], rules["phi=0"]
     normals = normal(cut_data, interface_rules, device=True)
     ghost = ghost_penalty_facets(cut_data, "phi<0") if ghost_penalty else None
     P = V.degree

@@ -229,6 +229,12 @@ int cfx_locate_entities(cfx_cut_t cut, const char* selector,
 /* runtime_quadrature(): cut.cpp:1311-1335 (backend "straight" only) */
 int cfx_runtime_quadrature(cfx_cut_t cut, const char* selector, int order,
                            const char* backend, cfx_rules_t* out);
+/* runtime_quadratures(): cut.h:178-181, python/cutfemx/cut.py runtime_quadratures(cut_data, ls_parts, order) -- one
+ * rule set per selector, out[n].  Pairs of plain selectors ("phi<0", "phi=0", "phi>0") of a single level set share
+ * one pass over the cut cells (each cell's vertices, level-set values and cut points are staged once) and one size
+ * read-back; any other selector takes the single call.  On error nothing is returned (out[] all NULL). */
+int cfx_runtime_quadratures(cfx_cut_t cut, int n, const char* const* selectors, int order,
+                            const char* backend, cfx_rules_t* out);
 /* rules over whole cells (reference points, weights*|detJ|): the test helper
  * python/tests/quadrature_utils.py:12-70 */
 int cfx_full_cell_rules(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int order,

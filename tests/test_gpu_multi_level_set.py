@@ -94,3 +94,29 @@ def test_multi_level_set_selector_errors(case):
         cfx.runtime_quadrature(cd, "phi=0 and phi1=0", 2)      # codimension 2
     with pytest.raises(ValueError):
         cfx.runtime_quadrature(cd, "phi<0 and phi2<0", 2)      # unknown level set
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 16), (3, 8)])
+def test_runtime_quadratures_plural_equals_the_single_calls(oracle, tdim, n):
+    """runtime_quadratures(cut_data, parts, order) (python/cutfemx/cut.py, cut.h:178-181): pairs of plain selectors
+    share one pass over the cut cells; the rule sets are the ones the single calls return, bit for bit, whatever the
+    mix of selectors."""
+    import cutfemx_amd as cfx
+    from helpers import level_set_values
+    om = oracle.mesh_box(tdim, n)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(V, level_set_values(om.x, tdim)))
+    parts = ["phi<0", "phi=0", "phi>0", "phi<=0", "phi=0"]
+    got = cfx.runtime_quadratures(cd, parts[:4], 3)
+    assert list(got) == parts[:4]
+    for p in parts[:4]:
+        one = cfx.runtime_quadrature(cd, p, 3)
+        r = got[p]
+        assert np.array_equal(r.offsets, one.offsets) and np.array_equal(r.parent_map, one.parent_map)
+        assert np.array_equal(r.points, one.points) and np.array_equal(r.weights, one.weights)
+    odd = cfx.runtime_quadratures(cd, ["phi>0"], 2)                     # a single selector: the single path
+    assert np.array_equal(odd["phi>0"].weights, cfx.runtime_quadrature(cd, "phi>0", 2).weights)
+    with pytest.raises(ValueError):
+        cfx.runtime_quadratures(cd, ["phi<0", "psi<0"], 2)              # unknown level set in the second selector
+    assert cfx.runtime_quadratures(cd, [], 2) == {}

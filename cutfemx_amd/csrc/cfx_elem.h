@@ -161,6 +161,99 @@ __device__ __forceinline__ void p2_stiffness_row(const Geo<TDIM>& g, int lr, dou
   }
 }
 
+// The same row over a CUT part of the cell: the integrals of the barycentric monomials over the cut part (a runtime
+// rule) take the place of the full-cell moments -- mom = (m0; m1_x, x < NV; m2_xy, x <= y row by row), 15 numbers in
+// 3-D, 10 in 2-D, with m0 = sum_q w_q, m1_x = sum_q w_q lam_x(q), m2_xy = sum_q w_q lam_x(q) lam_y(q) (the weights are
+// physical measures).  S_kl = grad(lam_k) . grad(lam_l) carries no volume factor here.
+//   vertex i, vertex j        S_ij (16 m2_ij - 4 m1_i - 4 m1_j + m0)
+//   vertex i, edge (c, d)     4 (S_ic (4 m2_id - m1_d) + S_id (4 m2_ic - m1_c))
+//   edge (a, b), edge (c, d)  16 (S_ac m2_bd + S_ad m2_bc + S_bc m2_ad + S_bd m2_ac)
+template <int TDIM>
+__device__ __forceinline__ void p2_stiffness_row_moments(const Geo<TDIM>& g, int lr, const double* mom, double* acc)
+{
+  constexpr int NV = TDIM + 1, NE = TDIM == 2 ? 3 : 6;
+  constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+  constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+  int a = lr, b = lr;
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+  {
+    const int ea = TDIM == 2 ? ea2[e % 3] : ea3[e], eb = TDIM == 2 ? eb2[e % 3] : eb3[e];
+    a = (lr == NV + e) ? ea : a;
+    b = (lr == NV + e) ? eb : b;
+  }
+  double G[NV][TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double s0 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) { G[t + 1][d] = g.K[t][d]; s0 -= g.K[t][d]; }
+    G[0][d] = s0;
+  }
+  double Ga[TDIM], Gb[TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { va = (a == k) ? G[k][d] : va; vb = (b == k) ? G[k][d] : vb; }
+    Ga[d] = va; Gb[d] = vb;
+  }
+  double Sa[NV], Sb[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k)
+  {
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) { va += Ga[d] * G[k][d]; vb += Gb[d] * G[k][d]; }
+    Sa[k] = va; Sb[k] = vb;
+  }
+  // rows a and b of the (symmetric) second-moment matrix, and the first moments of a and b
+  const double m0 = mom[0];
+  double Ma[NV], Mb[NV], m1a = 0.0, m1b = 0.0;
+#pragma unroll
+  for (int y = 0; y < NV; ++y) { Ma[y] = 0.0; Mb[y] = 0.0; }
+#pragma unroll
+  for (int x = 0; x < NV; ++x)
+  {
+    m1a = (a == x) ? mom[1 + x] : m1a;
+    m1b = (b == x) ? mom[1 + x] : m1b;
+#pragma unroll
+    for (int y = 0; y < NV; ++y)
+    {
+      // packed index of (min, max): rows of the upper triangle
+      const int lo = x < y ? x : y, hi = x < y ? y : x;
+      const int idx = 1 + NV + lo * NV - lo * (lo - 1) / 2 + (hi - lo);
+      Ma[y] = (a == x) ? mom[idx] : Ma[y];
+      Mb[y] = (b == x) ? mom[idx] : Mb[y];
+    }
+  }
+  if (lr < NV)
+  {
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += Sa[j] * (16.0 * Ma[j] - 4.0 * m1a - 4.0 * mom[1 + j] + m0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+    {
+      const int c = TDIM == 2 ? ea2[e % 3] : ea3[e], d = TDIM == 2 ? eb2[e % 3] : eb3[e];
+      acc[NV + e] += 4.0 * (Sa[c] * (4.0 * Ma[d] - mom[1 + d]) + Sa[d] * (4.0 * Ma[c] - mom[1 + c]));
+    }
+  }
+  else
+  {
+    // edge (a, b) against vertex j: 4 (S_ja (4 m2_jb - m1_b) + S_jb (4 m2_ja - m1_a))
+#pragma unroll
+    for (int j = 0; j < NV; ++j) acc[j] += 4.0 * (Sa[j] * (4.0 * Mb[j] - m1b) + Sb[j] * (4.0 * Ma[j] - m1a));
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+    {
+      const int c = TDIM == 2 ? ea2[e % 3] : ea3[e], d = TDIM == 2 ? eb2[e % 3] : eb3[e];
+      acc[NV + e] += 16.0 * (Sa[c] * Mb[d] + Sa[d] * Mb[c] + Sb[c] * Ma[d] + Sb[d] * Ma[c]);
+    }
+  }
+}
+
 __device__ __forceinline__ const double* ref_rule(int dim, int degree, int& n, const double*& w)
 {
   if (dim == 1)

@@ -1240,6 +1240,44 @@ __global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int n
     for (int k = 0; k < 4; ++k) oc[k] = make_int4(cm[4 * k], cm[4 * k + 1], cm[4 * k + 2], cm[4 * k + 3]);
   }
 }
+// Degree-2 stiffness on cut cells, stage 1 for the row gather: the moments of the barycentric coordinates over the
+// rule (m0, m1_x, m2_xy: 15 numbers in 3-D) -- p2_stiffness_row_moments() forms any row of the 10 x 10 tensor from
+// them, so a rule costs 16 doubles instead of 100 and one pass over its points instead of ten.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) cut_moments_kernel(int64_t nr, const int32_t* __restrict__ offsets,
+                                                             const double* __restrict__ points, const double* __restrict__ weights,
+                                                             double* __restrict__ out)
+{
+  constexpr int NV = TDIM + 1, NM = 1 + NV + NV * (NV + 1) / 2;
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nr) return;
+  double m[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) m[k] = 0.0;
+  const int32_t q0 = offsets[e], q1 = offsets[e + 1];
+  for (int32_t q = q0; q < q1; ++q)
+  {
+    double lam[NV];
+    lam[0] = 1.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) { lam[t + 1] = points[(int64_t)q * TDIM + t]; lam[0] -= lam[t + 1]; }
+    const double w = weights[q];
+    m[0] += w;
+    int idx = 1 + NV;
+#pragma unroll
+    for (int x = 0; x < NV; ++x)
+    {
+      const double wx = w * lam[x];
+      m[1 + x] += wx;
+#pragma unroll
+      for (int y = x; y < NV; ++y) m[idx++] += wx * lam[y];
+    }
+  }
+  static_assert(NM <= 16, "record of 16 doubles");
+  double2* o = reinterpret_cast<double2*>(out + 16 * e);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = make_double2(m[2 * k], m[2 * k + 1]);
+}
 } // namespace
 
 namespace cfx
@@ -1269,6 +1307,19 @@ void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
     launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
            V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
 }
+// stage 1 of a degree-2 stiffness integral over runtime rules: 16 doubles per rule (cut_moments_kernel)
+void dump_cut_moments(cfx_form_s* a, int integral, double* out)
+{
+  const cfx_integral_dev& I = a->integrals[integral];
+  if (!I.rules || I.rules->nr == 0) return;
+  if (a->V->mesh->tdim == 2)
+    launch("assemble_cells_cut", cut_moments_kernel<2>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+           I.rules->offsets.p, I.rules->points.p, I.rules->weights.p, out);
+  else
+    launch("assemble_cells_cut", cut_moments_kernel<3>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+           I.rules->offsets.p, I.rules->points.p, I.rules->weights.p, out);
+}
+
 // stage 1 of the degree-2 gradient-jump facets for the row gather: nq x 16 doubles per facet (facet_jumps_p2_kernel)
 void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out)
 {

@@ -28,6 +28,7 @@ namespace cfx
 void dump_integral(cfx_form_s* a, int integral, int parts, double* out, bool fold_facets = false); // cfx_fem.hip
 void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error);                    // cfx_fem.hip
 void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out);                        // cfx_fem.hip
+void dump_cut_moments(cfx_form_s* a, int integral, double* out);                                   // cfx_fem.hip
 int quad_npoints(int dim, int degree);                                                              // cfx_quadhost.cpp
 }
 
@@ -91,7 +92,8 @@ struct RowIntegral
   int64_t n_std;             // n_entities
   const int32_t* parent_map; // sorted rule parents
   int64_t nr;
-  const double* rule_tensors; // [nr][ND*ND] or [nr][ND]
+  const double* rule_tensors; // [nr][ND*ND] or [nr][ND]; rule_moments: [nr][16]
+  int rule_moments;           // degree-2 stiffness: rule_tensors holds the barycentric moments of every rule (cut_moments_kernel)
   const int32_t* rule_keys;   // parent cell -> first rule (open addressing, plan.rule_keys / rule_first)
   const int32_t* rule_first;
   unsigned rule_mask;
@@ -826,6 +828,29 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
             }
             if (CUTS && (mark & (16u << i)))
             {
+              if (DEG == 2 && I.rule_moments)
+              {
+                if constexpr (DEG == 2)
+                {
+                  // degree-2 stiffness over the cut part from the rule's moments (p2_stiffness_row_moments)
+                  Geo<TDIM> g;
+                  load_cell<TDIM>(A.x, A.conn, c, g);
+                  jacobian<TDIM>(g);
+                  for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+                  {
+                    const double2* mp = reinterpret_cast<const double2*>(I.rule_tensors + e * 16);
+                    double mom[16];
+#pragma unroll
+                    for (int k2 = 0; k2 < 8; ++k2)
+                    {
+                      const double2 v = mp[k2];
+                      mom[2 * k2] = v.x; mom[2 * k2 + 1] = v.y;
+                    }
+                    p2_stiffness_row_moments<TDIM>(g, lr, mom, acc);
+                  }
+                }
+              }
+              else
               for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
               {
                 const double* T = I.rule_tensors + (e * ND + lr) * ND;
@@ -2379,9 +2404,14 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     {
       R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
-      st.buffers.emplace_back(I.rules->nr * tsize);
+      const char* cm = getenv("CFX_P2_MOMENTS");
+      const bool moments = DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0
+                           && !(cm && cm[0] == '0');
+      st.buffers.emplace_back(I.rules->nr * (moments ? 16 : tsize));
       R.rule_tensors = st.buffers.back().p;
-      if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
+      R.rule_moments = moments ? 1 : 0;
+      if (moments) dump_cut_moments(a, ii, st.buffers.back().p);
+      else if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
       else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
     }
   }

@@ -1795,6 +1795,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
   if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list
+  if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: pattern max row length %d (static lists %d)\n", P->max_row_len, st.max_len);
   P->indptr.alloc(P->nrows + 1);
   {
     const int64_t ntiles = (P->nrows + kTile - 1) / kTile;

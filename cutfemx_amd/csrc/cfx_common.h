@@ -530,6 +530,8 @@ struct cfx_pattern_s
   uint64_t full_plan = 0;
   cfx::DevArray<int32_t> full_rows;
   int64_t n_full_rows = 0;
+  cfx::DevArray<int32_t> rest_rows; // vector-valued spaces: the active rows that are not in full_rows
+  int64_t n_rest_rows = 0;
   cfx::DevArray<int64_t> indptr;
   cfx::DevArray<int32_t> indices;
 };

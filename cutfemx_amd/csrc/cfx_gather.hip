@@ -524,12 +524,14 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
 #pragma unroll
         for (int k = 0; k <= DEGS; ++k) co[d][k] = ((k & 1) ? C[d] : S[d]) * inv[k];
       }
+      // be[0] is carried as F = sum_q f_q (N_0 = 1 - sum_t X_t: be_0 = F - sum_t be_{t+1}) and the cell's scale is
+      // applied once at the end: 4 instructions per point less in a kernel that is bound by FP64 issue
       for (int q = 0; q < npts; ++q) // (the point index is wave-uniform: points, weights and basis values are scalars)
       {
-        double X[TDIM], l0 = 1.0;
+        double X[TDIM];
 #pragma unroll
-        for (int t = 0; t < TDIM; ++t) { X[t] = pts[q * TDIM + t]; l0 -= X[t]; }
-        double f = wts[q] * cscale;
+        for (int t = 0; t < TDIM; ++t) X[t] = pts[q * TDIM + t];
+        double f = wts[q];
 #pragma unroll
         for (int d = 0; d < TDIM; ++d)
         {
@@ -541,10 +543,14 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
           for (int k = DEGS - 1; k >= 0; --k) p = fma(p, u, co[d][k]);
           f *= p;
         }
-        be[0] = fma(f, l0, be[0]);
+        be[0] += f;
 #pragma unroll
         for (int t = 0; t < TDIM; ++t) be[t + 1] = fma(f, X[t], be[t + 1]);
       }
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) be[0] -= be[t + 1];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) be[i] *= cscale;
     };
     if (umax <= 0.0065) series(std::integral_constant<int, 5>{});
     else series(std::integral_constant<int, 7>{});
@@ -2296,6 +2302,116 @@ __global__ void __launch_bounds__(kWave, 4) assemble_rows_p2_plain_kernel(P2Plai
     for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k];
 }
 
+// stage 2, bilinear forms, vector-valued degree 2: the dofs whose rows copied their static neighbour list
+// (cfx_pattern_s::full_rows), BS component rows at a time.  A group of G lanes owns a dof: the items (incident
+// cells: id, 12-byte slot record, entity index) are gathered first, one per lane, into LDS; then the group walks
+// the items together -- the BS rows of the staged tensor that belong to the dof are (BS x ND BS) contiguous doubles,
+// read coalesced, one entry per lane per pass, and added to the LDS rows at the recorded slots (distinct addresses
+// within an item, items in list order: no atomics, reproducible).  The generic block kernel repeats the item
+// traversal, the dofmap row and ND column searches for each of the BS component rows.
+#ifndef CFX_BLOCK_PLAIN_U
+#define CFX_BLOCK_PLAIN_U 8
+#endif
+struct BlockPlainArgs
+{
+  int64_t n;
+  const int32_t* rows;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint8_t* slotn;
+  const unsigned long long* std_bits;
+  const int32_t* std_rank;
+  const double* std_tensors;
+  const int64_t* indptr;
+  double* values;
+  int fresh;
+  int* error;
+};
+
+template <int TDIM, int BS, int G, int CAP>
+__global__ void __launch_bounds__(kWave) assemble_rows_block_plain_kernel(BlockPlainArgs A)
+{
+  constexpr int ND = Elem<TDIM, 2>::ND, NLOC = ND * BS, RPW = kWave / G, NE = BS * NLOC; // NE entries of an item
+  constexpr int ROW = CAP * BS;
+  __shared__ double s_val[RPW][BS][ROW];
+  __shared__ int64_t s_tb[RPW][G];      // per item: offset of its BS tensor rows
+  __shared__ uint32_t s_rec[RPW][G][3]; // ... and its slot record
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n;
+  const int64_t r = live ? A.rows[ri] : 0;
+  const int64_t rb0 = live ? A.indptr[r * BS] : 0;
+  int lene = live ? (int)(A.indptr[r * BS + 1] - rb0) : 0; // expanded row length (the BS rows of a dof are equally long)
+  if (lene > ROW) { *A.error = 2; lene = 0; }
+  for (int k = gl; k < BS * ROW; k += G) (&s_val[grp][0][0])[k] = 0.0;
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = (live && lene > 0) ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  int ncmax = nc;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ncmax = max(ncmax, __shfl_xor(ncmax, o, 64)); // the groups loop together
+  for (int base = 0; base < ncmax; base += G)
+  {
+    __syncthreads();
+    const int t = base + gl;
+    if (t < nc)
+    {
+      const int64_t c = A.d2c[cb + t];
+      const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.slotn + (cb + t) * 12);
+      const uint32_t w0 = rec[0], w1 = rec[1], w2 = rec[2];
+      const int64_t e = entity_index(A.std_bits, A.std_rank, c);
+      s_tb[grp][gl] = (e * NLOC + (int64_t)((w2 >> 16) & 0xffu) * BS) * NLOC;
+      s_rec[grp][gl][0] = w0; s_rec[grp][gl][1] = w1; s_rec[grp][gl][2] = w2;
+    }
+    __syncthreads();
+    const int m = min(G, nc - base);
+    // U items at a time: their tensor entries are requested together, then added in item order
+    constexpr int U = CFX_BLOCK_PLAIN_U, NP = (NE + G - 1) / G;
+    for (int it0 = 0; it0 < m; it0 += U)
+    {
+      double v[U][NP];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        const bool on = it0 + u < m;
+        const double* T = A.std_tensors + (on ? s_tb[grp][it0 + u] : 0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+          const int k = gl + p * G;
+          v[u][p] = (on && k < NE) ? T[k] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+      {
+        if (it0 + u >= m) break;
+        const uint32_t w0 = s_rec[grp][it0 + u][0], w1 = s_rec[grp][it0 + u][1], w2 = s_rec[grp][it0 + u][2];
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+        {
+          const int k = gl + p * G;
+          if (k < NE)
+          {
+            const int a = k / NLOC, jb = k - a * NLOC, j = jb / BS, b = jb - j * BS;
+            const uint32_t w = j < 4 ? w0 : (j < 8 ? w1 : w2);
+            const int slot = (int)((w >> (8 * (j & 3))) & 0xffu);
+            s_val[grp][a][slot * BS + b] += v[u][p];
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int a = 0; a < BS; ++a)
+  {
+    const int64_t rb = live ? A.indptr[r * BS + a] : 0;
+    if (A.fresh)
+      for (int k = gl; k < lene; k += G) A.values[rb + k] = s_val[grp][a][k];
+    else
+      for (int k = gl; k < lene; k += G) A.values[rb + k] += s_val[grp][a][k];
+  }
+}
+
 struct Stage1
 {
   std::vector<DevArray<double>> buffers;
@@ -2665,7 +2781,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
 }
 
 template <int TDIM, int DEG, int BS>
-int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values)
+int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG, BS>(a, st);
@@ -2688,9 +2804,33 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
     else if (inl) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, true>, grid, dim3(kWave), 0, A);  \
     else launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, false>, grid, dim3(kWave), 0, A);          \
   } while (0)
+    // degree 2: the dofs whose rows copied their static list, all BS component rows at a time
+    if constexpr (DEG == 2)
+    {
+      cfx_row_plan& plan = row_plan(a);
+      const Stencil& stn = a->V->stencil;
+      const char* bp = getenv("CFX_BLOCK_PLAIN");
+      int slot = -1, n_std = 0;
+      for (int s = 0; s < A.n_cell; ++s)
+        if (A.cell[s].std_bits) { slot = s; ++n_std; }
+      if (P->full_plan == plan.serial && P->n_full_rows > 0 && !bc0 && !bc1 && !det && stn.slotn_ok && stn.max_len <= 72
+          && n_std == 1 && A.cell[slot].std_tensors && !A.cell[slot].std_inline && !(bp && bp[0] == '0'))
+      {
+        BlockPlainArgs Q{};
+        Q.n = P->n_full_rows; Q.rows = P->full_rows.p; Q.d2c_off = A.d2c_off; Q.d2c = A.d2c; Q.slotn = stn.slotn.p;
+        Q.std_bits = A.cell[slot].std_bits; Q.std_rank = A.cell[slot].std_rank; Q.std_tensors = A.cell[slot].std_tensors;
+        Q.indptr = A.indptr; Q.values = A.values; Q.fresh = fresh ? 1 : 0; Q.error = A.error;
+        launch("assemble_rows_block_plain", assemble_rows_block_plain_kernel<TDIM, BS, 32, 72>, row_grid((Q.n + 1) / 2),
+               dim3(kWave), 0, Q);
+        A.n_active = P->n_rest_rows; A.active_rows = P->rest_rows.p;
+      }
+    }
+    if (A.n_active > 0)
+    {
     if (mr <= 32) CFX_BLOCK(8, 32);
     else if (mr <= 128) CFX_BLOCK(16, 128);
     else CFX_BLOCK(32, 256);
+    }
 #undef CFX_BLOCK
   }
   return read_scalar(err.p);
@@ -2803,9 +2943,9 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
     for (const auto& I : a->integrals) // facet items: the ghost-penalty gradient jump (extension pairs keep the entity path)
       if (I.type == CFX_INTERIOR_FACET && I.kernel != CFX_K_GHOST_GRADJUMP) return false;
     if (V->mesh->tdim == 2)
-      err = V->degree == 1 ? run_matrix_block<2, 1, 2>(a, P, bc0, bc1, values) : run_matrix_block<2, 2, 2>(a, P, bc0, bc1, values);
+      err = V->degree == 1 ? run_matrix_block<2, 1, 2>(a, P, bc0, bc1, values, fresh) : run_matrix_block<2, 2, 2>(a, P, bc0, bc1, values, fresh);
     else
-      err = V->degree == 1 ? run_matrix_block<3, 1, 3>(a, P, bc0, bc1, values) : run_matrix_block<3, 2, 3>(a, P, bc0, bc1, values);
+      err = V->degree == 1 ? run_matrix_block<3, 1, 3>(a, P, bc0, bc1, values, fresh) : run_matrix_block<3, 2, 3>(a, P, bc0, bc1, values, fresh);
   }
   else if (V->degree == 1)
     err = V->mesh->tdim == 2 ? run_matrix<2, 1>(a, P, bc0, bc1, values, fresh) : run_matrix<3, 1>(a, P, bc0, bc1, values, fresh);

@@ -1555,7 +1555,7 @@ const Stencil& space_stencil_slotn(cfx_space_s* V)
   if (S.slotn_built) return S;
   S.slotn_built = true;
   const char* env = getenv("CFX_P2_PLAIN");
-  if ((env && env[0] == '0') || !S.lists || S.usable || V->degree != 2 || V->bs != 1 || V->ndofs_cell > 10 || S.max_len > 255)
+  if ((env && env[0] == '0') || !S.lists || S.usable || V->degree != 2 || V->ndofs_cell > 10 || S.max_len > 255)
     return S;
   const Adjacency& adj = V->dof_cells();
   S.slotn.alloc(adj.cells.n * 12);
@@ -1841,6 +1841,27 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
   P->split_plan = 0;
   P->full_plan = 0;
+  if (any_full && V->degree == 2 && V->bs > 1 && a->rank == 2)
+  {
+    // vector-valued degree 2 with slot records and one uncut cell integral: the copied rows (dofs) take
+    // assemble_rows_block_plain_kernel, the other active rows keep the searching block kernel
+    int n_std = 0;
+    for (const auto& I : a->integrals)
+      if (I.type == CFX_CELL && I.n_entities > 0) ++n_std;
+    if (n_std == 1 && space_stencil_slotn(V).slotn_ok)
+    {
+      DevArray<int32_t> pos;
+      P->n_full_rows = compact("pattern_full_rows", plan.n_plain_rows, FlagSet8{full.p}, pos);
+      P->full_rows.alloc(P->n_full_rows);
+      launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
+             plan.plain_rows.p, P->full_rows.p);
+      P->n_rest_rows = n_h;
+      P->rest_rows.alloc(n_h);
+      if (n_h > 0)
+        CFX_HIP(hipMemcpyAsync(P->rest_rows.p, rows_h, sizeof(int32_t) * (size_t)n_h, hipMemcpyDeviceToDevice, ctx().stream));
+      P->full_plan = plan.serial;
+    }
+  }
   if (P->max_row_len > 64 && V->bs == 1 && plan.n_active_rows > 0)
   {
     // degree 2 with slot records, one uncut stiffness integral: the copied rows get their own gather kernel

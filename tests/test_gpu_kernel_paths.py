@@ -49,11 +49,11 @@ def test_p2_poisson_takes_the_list_and_slot_kernels(oracle, monkeypatch):
 
 
 def test_vector_p2_elasticity_takes_the_mfma_and_record_kernels(oracle):
-    """configs[4] at 6^3: 30 x 30 tensors on the FP64 matrix cores, vector ghost penalty from the facet records."""
+    """configs[4] at 12^3: 30 x 30 tensors on the FP64 matrix cores, vector ghost penalty from the facet records."""
     import cutfemx_amd as cfx
     from cutfemx_amd import fem
     from test_gpu_spaces import elasticity_problem, setup
-    s = setup(oracle, 3, 6, 2, 3)
+    s = setup(oracle, 3, 12, 2, 3)
     O, om, oV = s["O"], s["om"], s["oV"]
     inside, oa, ga = elasticity_problem(s, 2)
     ip, ix = O.create_sparsity(om, oV, oa)
@@ -62,5 +62,6 @@ def test_vector_p2_elasticity_takes_the_mfma_and_record_kernels(oracle):
     A, names = profiled(lambda: fem.assemble_matrix(a))
     assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
     assert rel_err(A.data, want) < 1e-12
-    for k in ("elasticity_tensors_mfma", "assemble_rows_block", "assemble_facets"):
+    for k in ("elasticity_tensors_mfma", "assemble_rows_block", "assemble_rows_block_plain", "assemble_facets",
+              "pattern_plain_full"):
         assert k in names, (k, sorted(names))

@@ -1730,7 +1730,8 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   // space: ~85 % of the rows) take 16 lanes and a 128-slot set, 4 rows per wavefront, the others one wavefront and
   // 512 slots; both count first and build each set again to write it in place
   constexpr int kShortLen = 40;
-  DevArray<int32_t> short_rows, long_rows, short_idx, long_idx;
+  DevArray<int32_t> short_rows, long_rows, short_idx, long_idx, tmp_short, tmp_long;
+  bool staged_sets = false;
   int64_t n_short = 0, n_long = 0;
   bool split_hashed = false;
   if (use_lists && n_h > 0 && !V->lists_short_overflow)
@@ -1749,8 +1750,19 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     split_hashed = true;
     T = 512;
     PatArgs S1 = S, S2 = S;
-    S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = nullptr;
-    S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = nullptr; S2.len = len.p + n_short;
+    // one pass: every set is ranked into a staging row (128 / 512 columns per row: 6 + 4.5 GB at BASELINE config 4),
+    // copied into the CSR arrays once the row offsets are known -- building each set a second time cost as much again
+    size_t free_b = 0, total_b = 0;
+    CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t need = ((size_t)n_short * 128 + (size_t)n_long * 512) * sizeof(int32_t);
+    staged_sets = need < free_b / 2;
+    if (staged_sets)
+    {
+      tmp_short.alloc(n_short * 128);
+      tmp_long.alloc(n_long * 512);
+    }
+    S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = staged_sets ? tmp_short.p : nullptr;
+    S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = staged_sets ? tmp_long.p : nullptr; S2.len = len.p + n_short;
     if (n_short > 0) launch("pattern_rows_short", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
     if (n_long > 0) launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
     if (read_scalar(overflow.p))
@@ -1818,7 +1830,16 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   if (any_full)
     launch("pattern_plain_write", pattern_plain_copy_kernel<8>, grid_for(plan.n_plain_rows * 8), dim3(kBlock), 0,
            plan.n_plain_rows, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, V->bs, P->indptr.p, P->indices.p);
-  if (split_hashed)
+  if (split_hashed && staged_sets)
+  {
+    if (n_short > 0)
+      launch("pattern_write", pattern_write_kernel<128>, grid_for(n_short * 8), dim3(kBlock), 0, n_short, short_rows.p, V->bs,
+             tmp_short.p, len.p, P->indptr.p, P->indices.p);
+    if (n_long > 0)
+      launch("pattern_write", pattern_write_kernel<512>, grid_for(n_long * 8), dim3(kBlock), 0, n_long, long_rows.p, V->bs,
+             tmp_long.p, len.p + n_short, P->indptr.p, P->indices.p);
+  }
+  else if (split_hashed)
   {
     PatArgs S1 = S, S2 = S;
     S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = nullptr; S1.indptr = P->indptr.p; S1.indices = P->indices.p;

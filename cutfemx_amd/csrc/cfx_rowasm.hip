@@ -238,17 +238,23 @@ __global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ 
 
 // P1 facet folding (assemble_rows_kernel) needs every facet row to join two cells that share all dofs but one
 // each -- a continuous P1 space on a conforming mesh.  Flags bit 1 otherwise (DG spaces, extension pairs).
-__global__ void plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                       int nd, int nx, int* flag)
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ rows,
+                                                                 const int32_t* __restrict__ dofmap, int nx, int* flag)
 {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int64_t c0 = rows[4 * f], c1 = rows[4 * f + 2];
+  int32_t d0[ND], d1[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) { d0[j] = dofmap[c0 * ND + j]; d1[j] = dofmap[c1 * ND + j]; }
   int nfree = 0;
-  for (int j = 0; j < nd; ++j)
+#pragma unroll
+  for (int j = 0; j < ND; ++j)
   {
     bool shared = false;
-    for (int i = 0; i < nd; ++i) shared = shared || dofmap[c1 * nd + j] == dofmap[c0 * nd + i];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) shared = shared || d1[j] == d0[i];
     nfree += shared ? 0 : 1;
   }
   if (nfree != nx) atomicOr(flag, 2); // nx: dofs of a cell that are not on a given facet (continuous space)
@@ -1447,17 +1453,24 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
+  bool no_fold = false;
   if (P.nfacets > 0 && nd > 4 && V->degree == 2)
   {
     // degree 2: the two cells of a facet share the facet's dofs (6 in 3-D, 3 in 2-D) when the space is continuous
     const int ns = V->mesh->tdim == 3 ? 6 : 3;
-    launch("plan_check_fold", plan_check_fold_kernel, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
-           V->dofmap.p, nd, nd - ns, flag.p);
+    if (nd == 10)
+      launch("plan_check_fold", plan_check_fold_kernel<10>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+             V->dofmap.p, nd - ns, flag.p);
+    else if (nd == 6)
+      launch("plan_check_fold", plan_check_fold_kernel<6>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+             V->dofmap.p, nd - ns, flag.p);
+    else
+      no_fold = true;
   }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
   const int flags = read_scalar(flag.p);
   if (flags & 1) P.usable = false;
-  P.fold_ok = !(flags & 2);
+  P.fold_ok = !(flags & 2) && !no_fold;
   P.built = true;
   return P;
 }

@@ -35,4 +35,5 @@ for it in range(2):
     if it == 1:
         print(' matrix kernels', profile(lambda: fem.assemble_matrix(s.a, A=A)), flush=True)
         print(' sparsity kernels', profile(lambda: fem.create_matrix(s.a)), flush=True)
+        print(' forms + plan + sparsity kernels', profile(lambda: fem.create_matrix(poisson.build_forms(V, cd, order=4).a)), flush=True)
     del A, s, b

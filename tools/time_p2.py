@@ -35,5 +35,6 @@ for it in range(2):
     if it == 1:
         print(' matrix kernels', profile(lambda: fem.assemble_matrix(s.a, A=A)), flush=True)
         print(' sparsity kernels', profile(lambda: fem.create_matrix(s.a)), flush=True)
+        print(' vector kernels', profile(lambda: fem.assemble_vector(s.L, b)), flush=True)
         print(' forms + plan + sparsity kernels', profile(lambda: fem.create_matrix(poisson.build_forms(V, cd, order=4).a)), flush=True)
     del A, s, b

@@ -65,3 +65,28 @@ def test_vector_p2_elasticity_takes_the_mfma_and_record_kernels(oracle):
     for k in ("elasticity_tensors_mfma", "assemble_rows_block", "assemble_rows_block_plain", "assemble_facets",
               "pattern_plain_full"):
         assert k in names, (k, sorted(names))
+
+
+def test_static_table_bytes_and_form_prepare(oracle):
+    """cfx_space_static_bytes reports what the first assembly built (the bench's `setup` record), cfx_form_prepare
+    builds a form's derived tables ahead of the first assembly call and changes no result."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem, poisson
+    O, n = oracle, 12
+    om = O.mesh_box(3, n)
+    phi = level_set_values(om.x, 3)
+    ref = oracle_poisson(O, om, phi)
+    mesh = cfx.Mesh.create_box(3, n)
+    V = cfx.FunctionSpace(mesh, 1)
+    before = V.static_table_bytes()
+    assert set(before) == {"dof_cells", "row_stencil", "row_tiles", "cell_neighbours"} and before["row_stencil"] == 0
+    cd = cfx.cut(cfx.Function(V, phi))
+    s = poisson.build_forms(V, cd, order=4)
+    s.a.prepare()
+    s.L.prepare()
+    after = V.static_table_bytes()
+    assert after["dof_cells"] > 0 and after["row_stencil"] > 0 and after["row_tiles"] > 0 and after["cell_neighbours"] > 0
+    A = fem.assemble_matrix(s.a)
+    b = fem.assemble_vector(s.L)
+    assert np.array_equal(A.indices, ref["indices"]) and rel_err(A.data, ref["values"]) < 1e-12 and rel_err(b, ref["b"]) < 1e-12
+    assert V.static_table_bytes() == after          # nothing mesh-static is built twice

@@ -195,8 +195,9 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
 // `bytes` must be 16-byte aligned
 // `tile_counts` (optional): matches per tile of kByteTile bytes already known to the caller
 template <typename ByteTest>
+// `known_total` (optional): the number of matches when the caller already has it on the host -- no size read-back
 inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, ByteTest test, DevArray<int32_t>& out,
-                             const int32_t* tile_counts = nullptr)
+                             const int32_t* tile_counts = nullptr, int64_t known_total = -1)
 {
   const int64_t ntiles = (n + kByteTile - 1) / kByteTile;
   if (ntiles == 0) { out.alloc(0); return 0; }
@@ -209,7 +210,7 @@ inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, 
            counts.p);
   }
   exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles);
-  const int64_t total = read_scalar(offsets.p + ntiles);
+  const int64_t total = known_total >= 0 ? known_total : read_scalar(offsets.p + ntiles);
   out.alloc(total);
   launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
          offsets.p, out.p);

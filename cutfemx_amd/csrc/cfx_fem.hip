@@ -1730,8 +1730,9 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
       launch("inactive_dofs", inactive_tile_counts_kernel, grid_for(ntiles), dim3(kBlock), 0, ntiles, nrows,
              plan.row_tile_counts.p, zeros.p);
     }
+    // (the plan knows how many rows are marked: the list is sized without a read-back)
     d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
-                                  zeros.n > 0 ? zeros.p : nullptr);
+                                  zeros.n > 0 ? zeros.p : nullptr, plan.built ? nrows - plan.n_active_rows : -1);
   }
   else
   {

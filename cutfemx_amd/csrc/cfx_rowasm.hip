@@ -1175,6 +1175,11 @@ struct StaticLenTest
   }
 };
 
+__global__ void gather3_kernel(const int* a, const int* b, const int64_t* c, int64_t* out)
+{
+  out[0] = *a; out[1] = *b; out[2] = *c;
+}
+
 struct FlagSet8
 {
   const uint8_t* f;
@@ -1787,6 +1792,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       maxlen.zero();
     }
   }
+  bool deferred = false;
   if (n_h > 0 && !split_hashed)
   {
     bool wide = V->long_rows;
@@ -1795,7 +1801,10 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       tmp.alloc(n_h * 64);
       S.tmp = tmp.p;
       launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((n_h + 15) / 16), dim3(kWave), 0, S);
-      wide = read_scalar(overflow.p) != 0;
+      // stencil path (P1): the overflow flag travels with the longest row and nnz in ONE read-back further down; an
+      // overflow (a row with more than 63 columns) then restarts the build on the wide path
+      if (use_stencil) deferred = true;
+      else wide = read_scalar(overflow.p) != 0;
     }
     if (wide)
     {
@@ -1818,7 +1827,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows), dim3(kBlock), 0, plan.n_plain_rows,
            plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
   }
-  P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
+  if (!deferred) P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
   if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list
   if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: pattern max row length %d (static lists %d)\n", P->max_row_len, st.max_len);
   P->indptr.alloc(P->nrows + 1);
@@ -1828,7 +1837,23 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
            counts.p, sums.p);
     exclusive_scan(sums.p, offs.p, ntiles);
-    P->nnz = read_scalar(offs.p + ntiles);
+    if (deferred)
+    {
+      DevArray<int64_t> three(3);
+      launch("pattern_indptr", gather3_kernel, dim3(1), dim3(1), 0, overflow.p, maxlen.p, offs.p + ntiles, three.p);
+      struct Three { int64_t v[3]; };
+      const Three t = read_scalar(reinterpret_cast<const Three*>(three.p));
+      if (t.v[0] != 0)
+      {
+        V->long_rows = true; // rows beyond 63 columns: build again, wide
+        build_pattern(a, P);
+        return;
+      }
+      P->max_row_len = std::max((int)t.v[1], 1);
+      P->nnz = t.v[2];
+    }
+    else
+      P->nnz = read_scalar(offs.p + ntiles);
     P->indices.alloc(P->nnz);
     launch("pattern_indptr", indptr_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
            counts.p, offs.p, P->indptr.p, P->indices.p);

@@ -192,12 +192,19 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
   for (int i = threadIdx.x; i < total; i += kBlock) out[o + i] = s_out[i];
 }
 
+__global__ inline void ride_along_kernel(const int64_t* a, const int* b, int64_t* out)
+{
+  out[0] = *a; out[1] = *b;
+}
+
 // `bytes` must be 16-byte aligned
 // `tile_counts` (optional): matches per tile of kByteTile bytes already known to the caller
 template <typename ByteTest>
 // `known_total` (optional): the number of matches when the caller already has it on the host -- no size read-back
+// `ride_flag` / `ride_out` (optional): a device int the caller wants on the host as well -- it rides on the size read-back
 inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, ByteTest test, DevArray<int32_t>& out,
-                             const int32_t* tile_counts = nullptr, int64_t known_total = -1)
+                             const int32_t* tile_counts = nullptr, int64_t known_total = -1, const int* ride_flag = nullptr,
+                             int* ride_out = nullptr)
 {
   const int64_t ntiles = (n + kByteTile - 1) / kByteTile;
   if (ntiles == 0) { out.alloc(0); return 0; }
@@ -210,7 +217,18 @@ inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, 
            counts.p);
   }
   exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles);
-  const int64_t total = known_total >= 0 ? known_total : read_scalar(offsets.p + ntiles);
+  int64_t total;
+  if (known_total >= 0) total = known_total;
+  else if (ride_flag)
+  {
+    DevArray<int64_t> two(2);
+    launch(name, ride_along_kernel, dim3(1), dim3(1), 0, offsets.p + ntiles, ride_flag, two.p);
+    struct Two { int64_t v[2]; };
+    const Two t = read_scalar(reinterpret_cast<const Two*>(two.p));
+    total = t.v[0];
+    *ride_out = (int)t.v[1];
+  }
+  else total = read_scalar(offsets.p + ntiles);
   out.alloc(total);
   launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
          offsets.p, out.p);

@@ -1693,19 +1693,20 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   cfx_row_plan& plan = row_plan(a);
   const int64_t nc = V->mesh->ncells;
   bool facets_covered = plan.nfacets == 0;
+  ZeroFlag uncovered;
+  int uncovered_host = 0;
   if (!facets_covered)
   {
     // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty
-    // band lies in the cut and inside cells): then the cell marks alone are the indicator
-    ZeroFlag uncovered;
+    // band lies in the cut and inside cells): then the cell marks alone are the indicator.  The flag rides on the
+    // size read-back of the compaction below; should a facet cell be uncovered, that list is rebuilt
     launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets * 2), dim3(kBlock), 0, plan.nfacets,
            plan.facet_rows.p, plan.cellmark.p, uncovered.p);
-    facets_covered = read_scalar(uncovered.p) == 0;
   }
-  if (facets_covered)
-    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
-                                plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr);
-  else
+  d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
+                              plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr,
+                              -1, facets_covered ? nullptr : uncovered.p, &uncovered_host);
+  if (uncovered_host != 0)
   {
     // facet integrals contribute both of their cells (deactivate.h:138-146)
     DevArray<uint8_t> mark((nc + 3) & ~3LL);

@@ -1175,6 +1175,11 @@ struct StaticLenTest
   }
 };
 
+__global__ void gather2_kernel(const int64_t* a, const int* b, int64_t* out)
+{
+  out[0] = *a; out[1] = *b;
+}
+
 __global__ void gather3_kernel(const int* a, const int* b, const int64_t* c, int64_t* out)
 {
   out[0] = *a; out[1] = *b; out[2] = *c;
@@ -1274,6 +1279,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   DevArray<uint8_t> special(V->ndofs); // rows touched by a runtime-rule cell or a facet
   special.zero();
   ZeroFlag flag;
+  int plan_flags = 0; // the flag word, read together with the row totals
   P.nfacets = 0;
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
@@ -1367,13 +1373,33 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       o += I.n_entities;
     }
   }
+  bool no_fold = false;
+  if (P.nfacets > 0 && nd > 4 && V->degree == 2)
+  {
+    // degree 2: the two cells of a facet share the facet's dofs (6 in 3-D, 3 in 2-D) when the space is continuous
+    const int ns = V->mesh->tdim == 3 ? 6 : 3;
+    if (nd == 10)
+      launch("plan_check_fold", plan_check_fold_kernel<10>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+             V->dofmap.p, nd - ns, flag.p);
+    else if (nd == 6)
+      launch("plan_check_fold", plan_check_fold_kernel<6>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+             V->dofmap.p, nd - ns, flag.p);
+    else
+      no_fold = true;
+  }
   {
     const int64_t ntiles = (V->ndofs + kByteTile - 1) / kByteTile;
     DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
     launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, tcounts.p);
     exclusive_scan(tcounts.p, toffs.p, ntiles);
-    const int64_t totals = read_scalar(toffs.p + ntiles);
+    // the row totals and the plan's flag word (every kernel that sets a flag has been launched) in one read-back
+    DevArray<int64_t> two(2);
+    launch("plan_row_lists", gather2_kernel, dim3(1), dim3(1), 0, toffs.p + ntiles, flag.p, two.p);
+    struct Two { int64_t v[2]; };
+    const Two tf = read_scalar(reinterpret_cast<const Two*>(two.p));
+    const int64_t totals = tf.v[0];
+    plan_flags = (int)tf.v[1];
     const int64_t n_special = totals & 0xffffffffll, n_plain = totals >> 32;
     const bool want_plain = space_stencil(V).lists;
     if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: plan rows special %lld plain %lld of %lld dofs\n", (long long)n_special, (long long)n_plain, (long long)V->ndofs);
@@ -1458,22 +1484,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
-  bool no_fold = false;
-  if (P.nfacets > 0 && nd > 4 && V->degree == 2)
-  {
-    // degree 2: the two cells of a facet share the facet's dofs (6 in 3-D, 3 in 2-D) when the space is continuous
-    const int ns = V->mesh->tdim == 3 ? 6 : 3;
-    if (nd == 10)
-      launch("plan_check_fold", plan_check_fold_kernel<10>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
-             V->dofmap.p, nd - ns, flag.p);
-    else if (nd == 6)
-      launch("plan_check_fold", plan_check_fold_kernel<6>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
-             V->dofmap.p, nd - ns, flag.p);
-    else
-      no_fold = true;
-  }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
-  const int flags = read_scalar(flag.p);
+  const int flags = plan_flags;
   if (flags & 1) P.usable = false;
   P.fold_ok = !(flags & 2) && !no_fold;
   P.built = true;

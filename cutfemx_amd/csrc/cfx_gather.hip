@@ -131,6 +131,7 @@ struct RowArgs
                         // gather (P1), 2 stage 1 stored the folded tensor (P1), 3 stage 1 stored rank-one records
   int facet_nq;         // fold_facets = 3, degree 2: records (quadrature points) per facet
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
+  const uint8_t* slotn;    // degree 2: 12-byte slot records per (dof, cell) entry (cfx::Stencil::slotn), or null
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
   const int64_t* st_off;
@@ -2166,6 +2167,8 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
       const int t = base + k * G + gl;
       cell[k] = t < nc ? (int64_t)A.d2c[cb + t] : -1;
       s4[k] = (A.slot4 && t < nc) ? A.slot4[cb + t] : 0u; // static stencil: local index without the dofmap row
+      // degree 2: byte 10 of the slot record is the local index
+      if (DEG == 2 && A.slotn && t < nc) s4[k] = reinterpret_cast<const uint32_t*>(A.slotn + (cb + t) * 12)[2];
     }
 #pragma unroll
     for (int k = 0; k < R; ++k) mk[k] = cell[k] >= 0 ? A.cellmark[cell[k]] : (uint8_t)0;
@@ -2174,7 +2177,8 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
     {
       lr[k] = 0;
       if (!mk[k]) continue;
-      if (A.slot4)
+      if (DEG == 2 && A.slotn) lr[k] = (int)((s4[k] >> 16) & 0xffu);
+      else if (A.slot4)
       {
 #pragma unroll
         for (int j = 0; j < ND; ++j) lr[k] = (((s4[k] >> (8 * j)) & 0xffu) == dpos) ? j : lr[k];
@@ -2898,6 +2902,11 @@ void run_vector(cfx_form_s* L, double* b)
   {
     const Stencil& stn = space_stencil(L->V);
     if (stn.usable) { A.slot4 = stn.slot4.p; A.diagpos = stn.diagpos.p; }
+  }
+  else
+  {
+    const Stencil& stn = space_stencil_slotn(L->V); // local index of the row's dof in every incident cell
+    if (stn.slotn_ok && L->V->bs == 1) A.slotn = stn.slotn.p;
   }
   if (st.vec_t2)
   {

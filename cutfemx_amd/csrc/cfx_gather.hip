@@ -1546,7 +1546,10 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
 // row's stencil segment.  With `fresh` the rows are stored, not read back.
 // ---------------------------------------------------------------------------
 #ifndef CFX_TILE_WAVES
-#define CFX_TILE_WAVES 4
+#define CFX_TILE_WAVES 5
+#endif
+#ifndef CFX_TILE_R
+#define CFX_TILE_R 3 // items per lane and pass (measured with 5 waves per SIMD: 2 -> 2.17 ms, 3 -> 2.17, 4 -> 2.42, 6 -> 3.23; with 4: 6 -> 2.26)
 #endif
 #ifndef CFX_TILE_ABLATE
 #define CFX_TILE_ABLATE 0 // timing-only builds (wrong results): 1 no LDS atomics, 2 no coordinate reads, 4 no stiffness arithmetic, 8 no items
@@ -1585,13 +1588,14 @@ struct TileArgs
 // separate __shared__ objects so that the compiler knows the accumulator atomics cannot alias the staged tables
 // and is free to run the LDS reads of the next items ahead of them.
 template <int CLS> struct TileCap;
-template <> struct TileCap<0> { static constexpr int V = 192, S = 256, I = 384; };   // Kuhn box meshes: 162 / 240 / 384
-template <> struct TileCap<1> { static constexpr int V = 512, S = 512, I = 1024; };
+template <> struct TileCap<0> { static constexpr int V = 192, S = 256, I = 384, VL = 168; };   // Kuhn box meshes: 162 / 240 / 384
+// (VL: vertices held in LDS -- 168 keeps a wavefront at 8128 B, 20 wavefronts per CU; V: the register staging width)
+template <> struct TileCap<1> { static constexpr int V = 512, S = 512, I = 1024, VL = 512; };
 inline int tile_class(const Stencil& st)
 {
   for (int c = 0; c < 2; ++c)
   {
-    const int V = c == 0 ? TileCap<0>::V : TileCap<1>::V, S = c == 0 ? TileCap<0>::S : TileCap<1>::S,
+    const int V = c == 0 ? TileCap<0>::VL : TileCap<1>::VL, S = c == 0 ? TileCap<0>::S : TileCap<1>::S,
               I = c == 0 ? TileCap<0>::I : TileCap<1>::I;
     if (st.max_tile_verts <= V && st.max_tile_st <= S && st.max_tile_items <= I) return c;
   }
@@ -1612,11 +1616,12 @@ __device__ __forceinline__ uint32_t other_positions(uint32_t s4, uint32_t dpos4)
 template <int TDIM, bool ORDERED, int CLS>
 __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_kernel(TileArgs A)
 {
-  constexpr int G = 4, R = 6;
+  constexpr int G = 4, R = CFX_TILE_R;
   constexpr int CAPV = TileCap<CLS>::V, CAPS = TileCap<CLS>::S, CAPI = TileCap<CLS>::I;
   constexpr int VR = CAPV / kWave, SR = CAPS / kWave, IR = CAPI / kWave;
   static_assert(kWave / G == kRowTile, "one lane group per row of the tile");
-  __shared__ double s_x[CAPV * TDIM];
+  constexpr int CAPVL = TileCap<CLS>::VL;
+  __shared__ double s_x[CAPVL * TDIM];
   __shared__ double s_val[CAPS]; // row g accumulates at its stencil segment
   __shared__ uint32_t s_s4[CAPI];
   __shared__ uint16_t s_loc[CAPS];
@@ -1653,7 +1658,7 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
   const int st_rel = (int)(__shfl(so, g, 64) - sb0);
   const int c_rel = (int)(__shfl(co, g, 64) - cb0);
   int nc = (int)(__shfl(co, g + 1, 64) - __shfl(co, g, 64));
-  if (nst > CAPS || nit > CAPI || nv > CAPV) { *A.error = 2; return; }
+  if (nst > CAPS || nit > CAPI || nv > CAPVL) { *A.error = 2; return; }
   uint32_t s4r[IR];
 #pragma unroll
   for (int q = 0; q < IR; ++q) s4r[q] = lane + q * kWave < nit ? A.slot4[cb0 + lane + q * kWave] : 0u;
@@ -1681,8 +1686,11 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
   }
 #pragma unroll
   for (int q = 0; q < VR; ++q)
+    if (lane + q * kWave < CAPVL)
+    {
 #pragma unroll
-    for (int d = 0; d < TDIM; ++d) s_x[(lane + q * kWave) * TDIM + d] = xv[q][d];
+      for (int d = 0; d < TDIM; ++d) s_x[(lane + q * kWave) * TDIM + d] = xv[q][d];
+    }
   int len = live ? (int)(re - rb) : 0;
   if (live && len > 0 && __popcll(mask) != len) { *A.error = 5; len = 0; }
   if (!live || len == 0) nc = 0;

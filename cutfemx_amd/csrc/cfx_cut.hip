@@ -1144,12 +1144,43 @@ __global__ void __launch_bounds__(kBlock) cell_neighbours_kernel(int64_t ncells,
   constexpr int NV = TDIM + 1;
   const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (c >= ncells) return;
-  for (int lf = 0; lf < NV; ++lf)
+  // All facets of the cell from TWO incidence lists instead of one list per facet: a cell that shares NV - 1
+  // vertices with c is its neighbour across the facet opposite the vertex it lacks; every facet but the one opposite
+  // vertex 0 contains vertex 0 (candidates: the cells around vertex 0), that one contains vertex 1.
+  int32_t cv[NV], out[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) { cv[i] = conn[c * NV + i]; out[i] = -1; }
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass)
   {
-    int32_t nb;
-    int nlf;
-    c2c[c * NV + lf] = facet_neighbour<TDIM>(conn, v2c_off, v2c, c, lf, nb, nlf) ? nb : -1;
+    const int32_t pivot = cv[pass];
+    for (int64_t k = v2c_off[pivot]; k < v2c_off[pivot + 1]; ++k)
+    {
+      const int32_t o = v2c[k];
+      if (o == c) continue;
+      int32_t ov[NV];
+#pragma unroll
+      for (int i = 0; i < NV; ++i) ov[i] = conn[(int64_t)o * NV + i];
+      int shared = 0, missing = 0;
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+      {
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) found = found || (ov[j] == cv[i]);
+        shared += found ? 1 : 0;
+        missing = found ? missing : i;
+      }
+      // pass 0 settles the facets that contain vertex 0, pass 1 the one opposite to it
+      if (shared == NV - 1 && (pass == 0 ? missing != 0 : missing == 0))
+      {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) out[i] = (i == missing && out[i] < 0) ? o : out[i];
+      }
+    }
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) c2c[c * NV + i] = out[i];
 }
 
 template <int TDIM>

@@ -445,12 +445,38 @@ __global__ void adj_fill_kernel(const int32_t* __restrict__ map, int64_t nentrie
   cells[offsets[item] + pos] = (int32_t)(i / width);
 }
 
-__global__ void adj_sort_kernel(int64_t nitems, const int64_t* __restrict__ offsets, int32_t* cells)
+// Every item's list in ascending order (the fill above went through an atomic cursor).  One wavefront per 64
+// consecutive items: their lists are one contiguous run of `cells`, staged in LDS with coalesced loads, sorted there
+// (insertion sort: the lists are short and nearly sorted, cells were issued in ascending order) and written back
+// coalesced; a thread sorting its own list in global memory touched 64 different lines per load (80 ms at 512^3).
+constexpr int kAdjSortCap = 4096;
+__global__ void __launch_bounds__(64) adj_sort_kernel(int64_t nitems, const int64_t* __restrict__ offsets, int32_t* cells)
 {
-  const int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= nitems) return;
-  const int64_t b = offsets[it], e = offsets[it + 1];
-  for (int64_t i = b + 1; i < e; ++i) // insertion sort, segments are short (vertex valence)
+  __shared__ int32_t s_c[kAdjSortCap];
+  const int lane = threadIdx.x;
+  const int64_t it0 = (int64_t)blockIdx.x * 64;
+  const int64_t it = it0 + lane;
+  const int64_t last = it0 + 64 < nitems ? it0 + 64 : nitems;
+  const int64_t base = offsets[it0], end = offsets[last];
+  const int span = (int)(end - base);
+  const int64_t b = it < nitems ? offsets[it] : end, e = it < nitems ? offsets[it + 1] : end;
+  if (span <= kAdjSortCap)
+  {
+    for (int k = lane; k < span; k += 64) s_c[k] = cells[base + k];
+    __syncthreads();
+    const int lb = (int)(b - base), le = (int)(e - base);
+    for (int i = lb + 1; i < le; ++i)
+    {
+      const int32_t v = s_c[i];
+      int j = i - 1;
+      while (j >= lb && s_c[j] > v) { s_c[j + 1] = s_c[j]; --j; }
+      s_c[j + 1] = v;
+    }
+    __syncthreads();
+    for (int k = lane; k < span; k += 64) cells[base + k] = s_c[k];
+    return;
+  }
+  for (int64_t i = b + 1; i < e; ++i) // (very long lists: in place)
   {
     const int32_t v = cells[i];
     int64_t j = i - 1;
@@ -471,7 +497,7 @@ void build_adjacency(const int32_t* map, int64_t ncells, int width, int64_t nite
   counts.zero();
   launch("adj_fill", adj_fill_kernel, grid_for(nentries), dim3(kBlock), 0, map, nentries, width,
          adj.offsets.p, counts.p, adj.cells.p);
-  launch("adj_sort", adj_sort_kernel, grid_for(nitems), dim3(kBlock), 0, nitems, adj.offsets.p, adj.cells.p);
+  launch("adj_sort", adj_sort_kernel, dim3((unsigned)((nitems + 63) / 64)), dim3(64), 0, nitems, adj.offsets.p, adj.cells.p);
   adj.built = true;
 }
 

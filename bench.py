@@ -555,11 +555,80 @@ def secondary_elasticity_share(torch, device, n=256, z0=89, nz=32):
                 phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=_kernel_times(step))
 
 
+def launcher_command(args, port=None):
+    """The command line of the N-rank job `python3 bench.py --gpus N` starts when nobody launched the ranks for it
+    (WORLD_SIZE unset): one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--mesh", str(args.n), "--order", str(args.order), "--cpu-n", str(args.cpu_n)]
+    if args.no_cpu:
+        cmd.append("--no-cpu")
+    if args.no_secondary:
+        cmd.append("--no-secondary")
+    return cmd
+
+
+def launch_ranks(args):
+    """`python3 bench.py --gpus N` with WORLD_SIZE unset: start the N ranks as a CHILD process (never exec: nothing
+    in this process has touched HIP or imported torch yet, and it stays that way), relay the child's output -- rank 0
+    prints the one JSON line -- and return its exit code."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(launcher_command(args), env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+def projected_scaling(torch, device, n, order, one_gpu_ms, worlds=(2, 4, 8)):
+    """PROJECTION, not a measurement: every rank's slab of the N-rank owner-computes partition timed one after the
+    other on this one GPU with the halo level-set values already in place (no exchange, no RCCL): the slowest rank
+    bounds the N-GPU step from below.  No scaling curve over real GPUs exists until the driver's 8-GPU run."""
+    import gc
+
+    from cutfemx_amd import _lib
+    from cutfemx_amd.dist import DistributedPoisson, SlabPartition
+    out = {}
+    for world in worlds:
+        per_rank = []
+        for r in range(world):
+            part = SlabPartition.create_owner(n, world, r)
+            dp = DistributedPoisson(part, device, order=order, mode="owner")
+            dp.part.world = 1            # skip the exchange: the analytic halo values are already in place
+            for _ in range(2):
+                dp.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                dp.step()
+            torch.cuda.synchronize()
+            per_rank.append(round(1e3 * (time.perf_counter() - t0) / 4, 3))
+            del dp
+            gc.collect(); _lib.release_cache(); torch.cuda.empty_cache()
+        out[str(world)] = dict(slowest_rank_ms=max(per_rank), per_rank_ms=per_rank,
+                               projected_speedup=one_gpu_ms / max(per_rank))
+    return dict(kind="projection from one GPU (each rank's slab run alone, no exchange); NOT a measured scaling curve",
+                one_gpu_ms=one_gpu_ms, by_world=out,
+                exchange_not_included="level-set halo: 2 vertex planes per neighbour per step "
+                                      f"({2 * 8 * (n + 1) ** 2 / 1e6:.1f} MB), RCCL point-to-point over xGMI")
+
+
 def main():
     args = parse()
     if args.cpu_worker:
         cpu_slab_worker(*args.cpu_worker)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -644,6 +713,11 @@ def main():
                     "classify_box_achieved_GBs": None if not k else alg / (k["avg_us"] * 1e-6) / 1e9}
             finally:
                 os.environ.pop("CFX_IMPLICIT_BOX", None)
+        if not args.no_secondary:
+            try:
+                out["projected_scaling"] = projected_scaling(torch, device, n, args.order, m["ms_per_step"])
+            except Exception as e:
+                out["projected_scaling"] = {"error": f"{type(e).__name__}: {e}"}
         out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
         out["cpu_baseline_all_cores"] = None if args.no_cpu else cpu_baseline_all_cores(args.cpu_n, args.order)
     elif rank == 0:

@@ -77,7 +77,7 @@ class PatternView(C.Structure):
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
     "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
-    "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_profile_enable", "cfx_profile_reset",
+    "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_device_memory_stats", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
     "cfx_mesh_info", "cfx_mesh_destroy", "cfx_cut_options_default", "cfx_cut_create",
@@ -227,6 +227,13 @@ def scalar_dtype(a):
 def release_cache():
     """Give the engine's cached HBM blocks back to the driver (they are reused between steps otherwise)."""
     check(lib().cfx_device_cache_release())
+
+
+def memory_stats(reset_peak: bool = False) -> dict:
+    """HBM held by the engine's block cache (bytes): handed out, cached, high-water mark of their sum."""
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    check(lib().cfx_device_memory_stats(C.byref(a), C.byref(b), C.byref(c), 1 if reset_peak else 0))
+    return dict(in_use=a.value, cached=b.value, peak=c.value)
 
 
 def download(ptr, n: int, dtype) -> np.ndarray:

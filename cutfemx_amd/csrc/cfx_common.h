@@ -94,6 +94,11 @@ struct Context
 };
 
 Context& ctx();
+// A table that is built lazily and then shared (incidence lists, row stencils, tiles, slot records, the row plan of
+// two forms) is enqueued on the lane that first needs it while the host flag says "built" at once: inside an
+// overlap section the OTHER lane must not run ahead of that build.  Call after enqueuing the build: the other
+// lane waits (device-side) for everything queued so far on this one.  No-op outside overlap sections.
+void publish_across_lanes();
 
 // launch with optional HIP-event bracketing on the library stream
 template <typename K, typename... Args>
@@ -144,6 +149,17 @@ inline dim3 grid_for(int64_t n, int block = 256)
 void* dev_alloc(size_t bytes);
 void dev_free(void* p);
 void dev_cache_release(); // hipFree every cached block
+// Identity of library-owned device arrays and handles.  Every block handed out by dev_alloc carries a serial number
+// that is never reused: a list that was released and rebuilt at the same address (cfx_cut_update drops the located
+// lists of a cut) has a different serial, so a row plan keyed on it cannot be adopted by mistake and a form that
+// still points at the old list is refused instead of reading recycled memory.  0 = not a live library block
+// (caller-owned memory: identity by address, the caller keeps it unchanged while a form refers to it).
+uint64_t dev_block_serial(const void* p);
+uint64_t next_serial();                    // process-wide counter shared by blocks, rules handles and plans
+void rules_serial_live(uint64_t s, bool live);
+bool rules_serial_is_live(uint64_t s);
+void device_memory_stats(size_t& live, size_t& cached, size_t& peak); // bytes held from HIP: in use / cached / high-water
+void device_memory_reset_peak();
 
 // ---------------------------------------------------------------------------
 // device arrays: owning (cached blocks) or aliasing a caller pointer
@@ -359,6 +375,11 @@ struct cfx_mesh_s
 
 struct cfx_rules_s
 {
+  const uint64_t serial = cfx::next_serial(); // identity of this handle (row-plan keys, stale-form detection)
+  cfx_rules_s() { cfx::rules_serial_live(serial, true); }
+  ~cfx_rules_s() { cfx::rules_serial_live(serial, false); }
+  cfx_rules_s(const cfx_rules_s&) = delete;
+  cfx_rules_s& operator=(const cfx_rules_s&) = delete;
   cfx_mesh_t mesh = nullptr;
   int tdim = 0, gdim = 0;
   int64_t nq = 0, nr = 0;
@@ -425,6 +446,7 @@ struct cfx_integral_dev
   cfx::DevArray<int32_t> entities;
   int64_t n_entities = 0;
   cfx_rules_t rules = nullptr;
+  uint64_t entities_serial = 0, rules_serial = 0; // identity at form creation (0: caller-owned entity array)
   int64_t n_std = 0; // interior-facet integrals with facet-hosted rules: entities [n_std, n_entities) are the rules' rows
   cfx::DevArray<double> point_data;
   cfx::DevArray<double> coefficient; // dof values of a CFX_F_COEFFICIENT field
@@ -487,10 +509,10 @@ struct cfx_row_plan
   uint32_t rule_mask[4] = {0, 0, 0, 0};
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};
-  // identity of the entity lists the plan was built from: (integral index, entities ptr, count,
-  // rules handle, rules count) per integral.  Forms of one space whose cell integrals have the same
-  // identity share the plan (e.g. the bilinear and the linear form of one problem).
-  std::vector<std::array<int64_t, 5>> key_cells, key_facets;
+  // identity of the entity lists the plan was built from: (integral index, entities ptr, count, rules handle,
+  // rules count, serial of the entity block, serial of the rules handle) per integral.  Forms of one space whose
+  // cell integrals have the same identity share the plan (e.g. the bilinear and the linear form of one problem).
+  std::vector<std::array<int64_t, 7>> key_cells, key_facets;
 };
 
 struct cfx_form_s
@@ -504,6 +526,7 @@ struct cfx_form_s
 namespace cfx
 {
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
+void validate_form(const cfx_form_s* a);                                // cfx_rowasm.hip: stale entity lists / rules -> Error
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 const Stencil& space_stencil_slotn(cfx_space_s* V);                     // cfx_rowasm.hip
 void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip

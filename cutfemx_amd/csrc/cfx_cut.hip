@@ -2303,22 +2303,34 @@ int cfx_runtime_quadratures(cfx_cut_t cut, int n, const char* const* selectors, 
     part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
     return true;
   };
-  while (k < n)
+  // the handles produced so far are released on EVERY error path (a status code of the single call, or an exception
+  // of the pair path: too many points, order out of range)
+  auto release = [&]() { for (int q = 0; q < n; ++q) { delete out[q]; out[q] = nullptr; } };
+  for (int q = 0; q < n; ++q) out[q] = nullptr;
+  try
   {
-    int parts[2];
-    if (k + 1 < n && plain_part(selectors[k], parts[0]) && plain_part(selectors[k + 1], parts[1]))
+    while (k < n)
     {
-      simple_rules(cut, 2, parts, order, out + k);
-      k += 2;
-      continue;
+      int parts[2];
+      if (k + 1 < n && plain_part(selectors[k], parts[0]) && plain_part(selectors[k + 1], parts[1]))
+      {
+        simple_rules(cut, 2, parts, order, out + k);
+        k += 2;
+        continue;
+      }
+      const int rc = cfx_runtime_quadrature(cut, selectors[k], order, backend, out + k);
+      if (rc != CFX_OK)
+      {
+        release();
+        return rc;
+      }
+      ++k;
     }
-    const int rc = cfx_runtime_quadrature(cut, selectors[k], order, backend, out + k);
-    if (rc != CFX_OK)
-    {
-      for (int q = 0; q < k; ++q) { delete out[q]; out[q] = nullptr; }
-      return rc;
-    }
-    ++k;
+  }
+  catch (...)
+  {
+    release();
+    throw;
   }
   CFX_API_END
 }
@@ -2701,6 +2713,7 @@ const cfx::DevArray<int32_t>& cfx_mesh_s::cell_neighbours()
              adj.cells.p, c2c.p);
   }
   c2c_built = true;
+  cfx::publish_across_lanes();
   return c2c;
 }
 

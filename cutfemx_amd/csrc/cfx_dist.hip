@@ -48,27 +48,31 @@ Rccl& rccl()
 {
   static Rccl r;
   if (r.handle) return r;
+  // resolved into a local table and published (handle included) only when every symbol was found: a failed attempt
+  // leaves `r` empty, so the next call tries again and reports the same error instead of handing out null pointers
+  Rccl t;
   // a process that already holds RCCL (PyTorch-ROCm bundles one under the same soname) keeps its copy
   for (const char* name : {"librccl.so.1", "librccl.so"})
   {
-    r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
-    if (!r.handle) r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (r.handle) break;
+    t.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (!t.handle) t.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (t.handle) break;
   }
-  if (!r.handle) throw Error(CFX_ERR_RUNTIME, std::string("cfx_dist: cannot load librccl.so.1: ") + dlerror());
+  if (!t.handle) throw Error(CFX_ERR_RUNTIME, std::string("cfx_dist: cannot load librccl.so.1: ") + dlerror());
   auto sym = [&](const char* n) {
-    void* p = dlsym(r.handle, n);
+    void* p = dlsym(t.handle, n);
     if (!p) throw Error(CFX_ERR_RUNTIME, std::string("cfx_dist: RCCL symbol missing: ") + n);
     return p;
   };
-  r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
-  r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
-  r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
-  r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
-  r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
-  r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
-  r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
-  r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+  t.GetUniqueId = reinterpret_cast<decltype(t.GetUniqueId)>(sym("ncclGetUniqueId"));
+  t.CommInitRank = reinterpret_cast<decltype(t.CommInitRank)>(sym("ncclCommInitRank"));
+  t.CommDestroy = reinterpret_cast<decltype(t.CommDestroy)>(sym("ncclCommDestroy"));
+  t.Send = reinterpret_cast<decltype(t.Send)>(sym("ncclSend"));
+  t.Recv = reinterpret_cast<decltype(t.Recv)>(sym("ncclRecv"));
+  t.GroupStart = reinterpret_cast<decltype(t.GroupStart)>(sym("ncclGroupStart"));
+  t.GroupEnd = reinterpret_cast<decltype(t.GroupEnd)>(sym("ncclGroupEnd"));
+  t.GetErrorString = reinterpret_cast<decltype(t.GetErrorString)>(sym("ncclGetErrorString"));
+  r = t;
   return r;
 }
 
@@ -80,6 +84,26 @@ void nccl_check(int rc, const char* what)
 
 } // namespace
 
+// page-locked staging buffer of the host-staged transport: grows on demand, lives with its communicator
+struct PinnedBuf
+{
+  void* p = nullptr;
+  size_t cap = 0;
+  PinnedBuf() = default;
+  PinnedBuf(const PinnedBuf&) = delete;
+  PinnedBuf& operator=(const PinnedBuf&) = delete;
+  PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+  ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+  void* reserve(size_t bytes)
+  {
+    if (bytes <= cap) return p;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    CFX_HIP(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    cap = bytes;
+    return p;
+  }
+};
+
 struct cfx_comm_s
 {
   int world = 1, rank = 0;
@@ -87,6 +111,7 @@ struct cfx_comm_s
   ncclComm_t comm = nullptr;
   cfx_host_exchange_fn host_fn = nullptr;
   void* host_user = nullptr;
+  std::vector<PinnedBuf> stage_send, stage_recv; // per segment slot of an exchange, reused by every later exchange
 };
 
 namespace
@@ -139,10 +164,12 @@ void transport(cfx_comm_s* c, std::vector<Segment>& seg)
     nccl_check(r.GroupEnd(), "ncclGroupEnd");
     return;
   }
-  // host-staged: device -> pinned host, the caller's callback (MPI / gloo), pinned host -> device
+  // host-staged: device -> pinned host, the caller's callback (MPI / gloo), pinned host -> device.  The staging
+  // buffers belong to the communicator (RAII: an exception below leaks nothing, and a step allocates nothing new)
   const int n = (int)seg.size();
-  std::vector<void*> hs(n, nullptr), hr(n, nullptr);
-  std::vector<const void*> sp(n);
+  if ((int)c->stage_send.size() < n) { c->stage_send.resize(n); c->stage_recv.resize(n); }
+  std::vector<void*> hr(n, nullptr);
+  std::vector<const void*> sp(n, nullptr);
   std::vector<int32_t> peers(n);
   std::vector<int64_t> sb(n), rb(n);
   for (int i = 0; i < n; ++i)
@@ -150,23 +177,18 @@ void transport(cfx_comm_s* c, std::vector<Segment>& seg)
     peers[i] = seg[i].peer; sb[i] = seg[i].send_bytes; rb[i] = seg[i].recv_bytes;
     if (sb[i] > 0)
     {
-      CFX_HIP(hipHostMalloc(&hs[i], (size_t)sb[i], hipHostMallocDefault));
-      CFX_HIP(hipMemcpyAsync(hs[i], seg[i].send, (size_t)sb[i], hipMemcpyDeviceToHost, cx.stream));
+      void* h = c->stage_send[i].reserve((size_t)sb[i]);
+      CFX_HIP(hipMemcpyAsync(h, seg[i].send, (size_t)sb[i], hipMemcpyDeviceToHost, cx.stream));
+      sp[i] = h;
     }
-    if (rb[i] > 0) CFX_HIP(hipHostMalloc(&hr[i], (size_t)rb[i], hipHostMallocDefault));
-    sp[i] = hs[i];
+    if (rb[i] > 0) hr[i] = c->stage_recv[i].reserve((size_t)rb[i]);
   }
   CFX_HIP(hipStreamSynchronize(cx.stream));
   const int rc = c->host_fn(c->host_user, n, peers.data(), sp.data(), sb.data(), hr.data(), rb.data());
-  for (int i = 0; i < n; ++i)
-    if (rc == 0 && rb[i] > 0) CFX_HIP(hipMemcpyAsync(seg[i].recv, hr[i], (size_t)rb[i], hipMemcpyHostToDevice, cx.stream));
-  CFX_HIP(hipStreamSynchronize(cx.stream));
-  for (int i = 0; i < n; ++i)
-  {
-    if (hs[i]) (void)hipHostFree(hs[i]);
-    if (hr[i]) (void)hipHostFree(hr[i]);
-  }
   if (rc != 0) throw Error(CFX_ERR_RUNTIME, "cfx_dist: the host exchange callback failed");
+  for (int i = 0; i < n; ++i)
+    if (rb[i] > 0) CFX_HIP(hipMemcpyAsync(seg[i].recv, hr[i], (size_t)rb[i], hipMemcpyHostToDevice, cx.stream));
+  CFX_HIP(hipStreamSynchronize(cx.stream)); // the buffers are reused by the next exchange
 }
 
 // One exchange step on an array of T: send my [send] parts, combine what arrives into my [recv] parts.
@@ -322,23 +344,25 @@ int cfx_dist_scatter_reverse_matrix(cfx_comm_t c, cfx_pattern_t P, double* value
     e[i].recv_offset = ptr[4 * i + 2]; e[i].recv_count = ptr[4 * i + 3] - ptr[4 * i + 2];
   }
   // both sides built the rows of a shared plane from the same entities (DOLFINx keeps the ghost rows' sparsity
-  // on both ranks), so the slices must have equal lengths: the counts travel first and are compared
+  // on both ranks), so the slices must have equal lengths.  Each side sends BOTH of its counts and checks both
+  // directions against the peer's pair: a mismatch in either direction is seen by both ranks, which then raise
+  // together -- a one-sided check would let the other rank go on into a value exchange nobody answers
   {
-    DevArray<double> cnt(2 * (int64_t)std::max(n, 1));
-    std::vector<double> h(2 * (size_t)std::max(n, 1), 0.0);
-    for (int i = 0; i < n; ++i) h[2 * i] = (double)e[i].send_count;
+    DevArray<double> cnt(4 * (int64_t)std::max(n, 1));
+    std::vector<double> h(4 * (size_t)std::max(n, 1), 0.0);
+    for (int i = 0; i < n; ++i) { h[4 * i] = (double)e[i].send_count; h[4 * i + 1] = (double)e[i].recv_count; }
     CFX_HIP(hipMemcpyAsync(cnt.p, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, ctx().stream));
     std::vector<cfx_dist_exchange> ce(n);
     for (int i = 0; i < n; ++i)
     {
       ce[i] = cfx_dist_exchange{};
-      ce[i].peer = ex[i].peer; ce[i].send_offset = 2 * i; ce[i].send_count = 1; ce[i].recv_offset = 2 * i + 1; ce[i].recv_count = 1;
+      ce[i].peer = ex[i].peer; ce[i].send_offset = 4 * i; ce[i].send_count = 2; ce[i].recv_offset = 4 * i + 2; ce[i].recv_count = 2;
     }
     exchange_apply<double>(c, cnt.p, n, ce.data(), 0);
     CFX_HIP(hipMemcpyAsync(h.data(), cnt.p, sizeof(double) * h.size(), hipMemcpyDeviceToHost, ctx().stream));
     CFX_HIP(hipStreamSynchronize(ctx().stream));
     for (int i = 0; i < n; ++i)
-      require((int64_t)h[2 * i + 1] == e[i].recv_count, CFX_ERR_RUNTIME,
+      require((int64_t)h[4 * i + 2] == e[i].recv_count && (int64_t)h[4 * i + 3] == e[i].send_count, CFX_ERR_RUNTIME,
               "cfx_dist_scatter_reverse_matrix: the peer's rows hold a different number of entries (sparsity of the "
               "shared rows must be built from the same entities on both ranks)");
   }

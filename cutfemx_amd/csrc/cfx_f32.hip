@@ -136,9 +136,15 @@ int cfx_cut_update_f32(cfx_cut_t cut, const float* const* ls_values)
 {
   CFX_API_BEGIN
   require(cut != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_update_f32: null handle");
-  if (ls_values)
-    for (int k = 0; k < cut->nls; ++k)
-      if (ls_values[k]) cut->ls_values[k] = widen(ls_values[k], cut->ls_ndofs);
+  // the cut holds widened COPIES of float32 level sets (not aliases of the caller's arrays, as the f64 path does):
+  // "reuse what you have" would silently re-classify stale values, so the arrays must be passed again
+  require(ls_values != nullptr, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_cut_update_f32: pass the float32 level-set arrays again (the cut keeps widened copies, not aliases)");
+  for (int k = 0; k < cut->nls; ++k)
+  {
+    require(ls_values[k] != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_cut_update_f32: null level-set values");
+    cut->ls_values[k] = widen(ls_values[k], cut->ls_ndofs);
+  }
   return cfx_cut_update(cut, nullptr);
   CFX_API_END
 }

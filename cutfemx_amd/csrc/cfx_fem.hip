@@ -1476,6 +1476,8 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
     else if (in.kernel == CFX_K_EXTENSION_L2 && in.point_data)
       I.point_data = to_device(in.point_data, in.n_entities); // one factor per pair (cellwise beta)
     for (int k = 0; k < 8; ++k) I.params[k] = in.params[k];
+    I.entities_serial = I.n_entities > 0 ? dev_block_serial(I.entities.p) : 0;
+    I.rules_serial = I.rules ? I.rules->serial : 0;
     a->integrals.push_back(std::move(I));
   }
   *out = a.release();
@@ -1486,6 +1488,7 @@ int cfx_form_prepare(cfx_form_t a)
 {
   CFX_API_BEGIN
   require(a != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_form_prepare: null argument");
+  validate_form(a);
   if (!force_atomic()) prepare_form_tables(a);
   CFX_API_END
 }
@@ -1503,6 +1506,7 @@ int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out)
   require(a && out, CFX_ERR_INVALID_ARGUMENT, "cfx_create_sparsity: null argument");
   // assembler.h:570-574
   require(a->rank == 2, CFX_ERR_RUNTIME, "Cannot create sparsity pattern. Form is not a bilinear.");
+  validate_form(a);
   auto P = std::make_unique<cfx_pattern_s>();
   build_pattern(a, P.get());
   CFX_HIP(hipStreamSynchronize(ctx().stream));
@@ -1532,6 +1536,7 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
 {
   require(a && P && values, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: null argument");
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: form is not bilinear");
+  validate_form(a);
   cfx_space_s* V = a->V;
   require(P->nrows == V->ndofs * V->bs, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: pattern/space size mismatch");
   DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->nrows : 0);
@@ -1569,6 +1574,7 @@ int cfx_assemble_vector(cfx_form_t L, double* b)
   CFX_API_BEGIN
   require(L && b, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_vector: null argument");
   require(L->rank == 1, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_vector: form is not linear");
+  validate_form(L);
   cfx_space_s* V = L->V;
   OutArray<double> out(b, V->ndofs * V->bs, true);
   ZeroFlag err;
@@ -1588,6 +1594,7 @@ int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_v
   CFX_API_BEGIN
   require(a && bc_markers && bc_values && b, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting: null argument");
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting: form is not bilinear");
+  validate_form(a);
   cfx_space_s* V = a->V;
   const int64_t n = V->ndofs * V->bs;
   DevArray<int8_t> dm = to_device(bc_markers, n);
@@ -1662,6 +1669,7 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
   CFX_API_BEGIN
   require(a && Ae, CFX_ERR_INVALID_ARGUMENT, "cfx_tabulate_entity: null argument");
   require(integral >= 0 && integral < (int)a->integrals.size(), CFX_ERR_OUT_OF_RANGE, "integral index out of range");
+  validate_form(a);
   const cfx_integral_dev& I = a->integrals[integral];
   cfx_space_s* V = a->V;
   const int64_t limit = (I.type == CFX_CELL && use_rule) ? (I.rules ? I.rules->nr : 0) : I.n_entities;
@@ -1684,6 +1692,7 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   require(a && out, CFX_ERR_INVALID_ARGUMENT, "cfx_active_domain: null argument");
   // deactivate.h:80-85
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain requires a rank-2 bilinear CutForm");
+  validate_form(a);
   cfx_space_s* V = a->V;
   auto d = std::make_unique<cfx_active_s>();
   d->V = V;

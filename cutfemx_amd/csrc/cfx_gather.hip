@@ -2990,8 +2990,14 @@ void prepare_form_tables(cfx_form_s* a)
 {
   cfx_row_plan& plan = row_plan(a);
   cfx_space_s* V = a->V;
-  if (!plan.usable || V->degree != 1 || V->bs != 1) return;
+  // space-level tables of every degree and block size: the incidence lists, the neighbour lists and (degree 2) the
+  // slot records -- built here so that an overlap section finds them in place (a table that is still built lazily
+  // inside a section is published to the other lane, cfx::publish_across_lanes)
+  (void)V->dof_cells();
   const Stencil& stn = space_stencil(V);
+  if (V->degree == 2) (void)space_stencil_slotn(V);
+  if (plan.nfacets > 0) (void)V->mesh->cell_neighbours();
+  if (!plan.usable || V->degree != 1 || V->bs != 1) return;
   if (!stn.usable) return;
   (void)space_stencil_tiles(V);
   plain_row_masks(a);

@@ -1233,23 +1233,40 @@ __global__ void __launch_bounds__(kBlock) pattern_plain_copy_kernel(int64_t n_pl
 namespace cfx
 {
 
+// A form points at entity lists and rules it does not own.  Lists that live in library blocks (located lists, ghost
+// rows: dropped by cfx_cut_update) and rules handles carry serial numbers taken at form creation: if the block was
+// released or handed out again, or the rules handle destroyed, the form is stale and every use of it is refused.
+void validate_form(const cfx_form_s* a)
+{
+  for (const cfx_integral_dev& I : a->integrals)
+  {
+    if (I.entities_serial != 0 && I.n_entities > 0 && !I.entities.owned && dev_block_serial(I.entities.p) != I.entities_serial)
+      throw Error(CFX_ERR_RUNTIME, "stale form: an entity list it refers to was released or rebuilt (cfx_cut_update drops the "
+                                   "located lists and ghost rows of a cut); create the form again from the new lists");
+    if (I.rules_serial != 0 && !rules_serial_is_live(I.rules_serial))
+      throw Error(CFX_ERR_RUNTIME, "stale form: the runtime rules it refers to were destroyed; create the form again");
+  }
+}
+
 cfx_row_plan& row_plan(cfx_form_s* a)
 {
   if (a->plan) return *a->plan;
   cfx_space_s* V = a->V;
-  // identity of this form's entity lists
-  std::vector<std::array<int64_t, 5>> key_cells, key_facets;
+  // identity of this form's entity lists: address and count, plus the serial of the library block behind the address
+  // and of the rules handle -- serials are never reused, so a list rebuilt at a recycled address is a different key
+  std::vector<std::array<int64_t, 7>> key_cells, key_facets;
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
-    const std::array<int64_t, 5> k{(int64_t)ii, I.n_entities > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, I.n_entities,
-                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr : 0};
+    const std::array<int64_t, 7> k{(int64_t)ii, I.n_entities > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, I.n_entities,
+                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr : 0,
+                                   I.n_entities > 0 ? (int64_t)I.entities_serial : 0, (int64_t)I.rules_serial};
     (I.type == CFX_CELL ? key_cells : key_facets).push_back(k);
   }
-  // Share the plan of another LIVE form of this space built from the same lists
-  // (entity arrays must not change while a form that references them is alive,
-  // so pointer identity implies content identity).  A form without facet
-  // integrals may use a plan that has some: the extra active rows receive zeros.
+  // Share the plan of another LIVE form of this space built from the same lists (caller-owned entity arrays,
+  // serial 0, must not change while a form that references them is alive: for them address identity stands for
+  // content identity).  A form without facet integrals may use a plan that has some: the extra active rows receive
+  // zeros.
   for (auto it = V->plans.begin(); it != V->plans.end();)
   {
     std::shared_ptr<cfx_row_plan> p = it->lock();
@@ -1264,8 +1281,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   }
   a->plan = std::make_shared<cfx_row_plan>();
   cfx_row_plan& P = *a->plan;
-  static uint64_t next_serial = 0;
-  P.serial = ++next_serial;
+  P.serial = next_serial();
   P.key_cells = key_cells;
   P.key_facets = key_facets;
   V->plans.push_back(a->plan);
@@ -1489,6 +1505,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   if (flags & 1) P.usable = false;
   P.fold_ok = !(flags & 2) && !no_fold;
   P.built = true;
+  publish_across_lanes(); // a second form on the other lane may adopt this plan
   return P;
 }
 
@@ -1522,6 +1539,7 @@ const Stencil& space_stencil(cfx_space_s* V)
     A.indptr = S.offsets.p; A.indices = S.nbr.p;
     launch("stencil_rows_write", pattern_rows_kernel<64, 512>, wave_grid(V->ndofs), dim3(kWave), 0, A);
     S.lists = true;
+    publish_across_lanes();
     return S;
   }
   const Adjacency& adj = V->dof_cells();
@@ -1548,6 +1566,7 @@ const Stencil& space_stencil(cfx_space_s* V)
          adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slot4.p, S.diagpos.p, S.cpos.p);
   S.usable = true;
   S.lists = true;
+  publish_across_lanes();
   return S;
 }
 
@@ -1576,6 +1595,7 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
   launch("stencil_tiles_write", stencil_tiles_kernel<true>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
          adj.offsets.p, (int32_t*)nullptr, S.tile_voff.p, S.tile_verts.p, S.st_loc.p, maxima.p);
   S.tiles_usable = true;
+  publish_across_lanes();
   return S;
 }
 
@@ -1593,6 +1613,7 @@ const Stencil& space_stencil_slotn(cfx_space_s* V)
   launch("stencil_slotn", stencil_slotn_kernel, wave_grid((V->ndofs + 3) / 4), dim3(kWave), 0, V->ndofs, adj.offsets.p,
          adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slotn.p);
   S.slotn_ok = true;
+  publish_across_lanes();
   return S;
 }
 
@@ -1621,6 +1642,7 @@ void plain_row_masks(cfx_form_s* a)
     launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles), dim3(kBlock), 0, plan.n_plain_tiles,
            plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
   }
+  publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
 }
 
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:
@@ -1697,6 +1719,7 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
            plan.vec_slow_rows.p + plan.n_special_rows);
   plan.vec_t2_total = total;
   plan.vec_fast = 1;
+  publish_across_lanes();
   return true;
 }
 

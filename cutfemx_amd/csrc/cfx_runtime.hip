@@ -38,6 +38,17 @@ hipEvent_t Context::get_event()
   return e;
 }
 
+void publish_across_lanes()
+{
+  Context& c = ctx();
+  if (!c.overlap || !c.side_stream) return;
+  hipStream_t other = c.stream == c.main_stream ? c.side_stream : c.main_stream;
+  hipEvent_t e = c.get_event();
+  CFX_HIP(hipEventRecord(e, c.stream));
+  CFX_HIP(hipStreamWaitEvent(other, e, 0));
+  c.event_pool.push_back(e);
+}
+
 int Context::entry(const char* name)
 {
   auto it = entry_index.find(name);
@@ -69,11 +80,18 @@ void Context::flush_profile()
 // ---------------------------------------------------------------------------
 namespace
 {
+struct LiveBlock { size_t size; uint64_t serial; };
 struct BlockCache
 {
   std::multimap<size_t, void*> free_blocks; // size -> block
-  std::map<void*, size_t> live;             // block -> size
-  size_t cached = 0;
+  std::map<void*, LiveBlock> live;          // block -> size, serial of this hand-out
+  size_t cached = 0, in_use = 0, peak = 0;  // bytes: cached, handed out, high-water of (in_use + cached)
+  void hand_out(void* p, size_t size)
+  {
+    live[p] = LiveBlock{size, next_serial()};
+    in_use += size;
+    peak = std::max(peak, in_use + cached);
+  }
 };
 BlockCache& cache()
 {
@@ -119,9 +137,10 @@ void* dev_alloc(size_t bytes)
   if (it != c.free_blocks.end() && it->first <= want + want / 2 + ((size_t)4 << 20))
   {
     void* p = it->second;
-    c.live[p] = it->first;
-    c.cached -= it->first;
+    const size_t size = it->first;
+    c.cached -= size;
     c.free_blocks.erase(it);
+    c.hand_out(p, size);
     return p;
   }
   void* p = nullptr;
@@ -133,7 +152,7 @@ void* dev_alloc(size_t bytes)
     e = hipMalloc(&p, want);
     if (e != hipSuccess) throw Error(CFX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
   }
-  c.live[p] = want;
+  c.hand_out(p, want);
   return p;
 }
 
@@ -146,9 +165,48 @@ void dev_free(void* p)
   BlockCache& c = cache();
   auto it = c.live.find(p);
   if (it == c.live.end()) return; // not ours
-  c.free_blocks.emplace(it->second, p);
-  c.cached += it->second;
+  c.free_blocks.emplace(it->second.size, p);
+  c.cached += it->second.size;
+  c.in_use -= it->second.size;
   c.live.erase(it);
+}
+
+uint64_t next_serial()
+{
+  static uint64_t n = 0;
+  return ++n;
+}
+
+uint64_t dev_block_serial(const void* p)
+{
+  BlockCache& c = cache();
+  auto it = c.live.find(const_cast<void*>(p));
+  return it == c.live.end() ? 0 : it->second.serial;
+}
+
+namespace
+{
+std::map<uint64_t, bool>& live_rules()
+{
+  static std::map<uint64_t, bool> m;
+  return m;
+}
+} // namespace
+void rules_serial_live(uint64_t s, bool live)
+{
+  if (live) live_rules()[s] = true; else live_rules().erase(s);
+}
+bool rules_serial_is_live(uint64_t s) { return live_rules().count(s) != 0; }
+
+void device_memory_stats(size_t& live, size_t& cached, size_t& peak)
+{
+  BlockCache& c = cache();
+  live = c.in_use; cached = c.cached; peak = c.peak;
+}
+void device_memory_reset_peak()
+{
+  BlockCache& c = cache();
+  c.peak = c.in_use + c.cached;
 }
 
 void dev_cache_release()
@@ -499,6 +557,7 @@ void build_adjacency(const int32_t* map, int64_t ncells, int width, int64_t nite
          adj.offsets.p, counts.p, adj.cells.p);
   launch("adj_sort", adj_sort_kernel, dim3((unsigned)((nitems + 63) / 64)), dim3(64), 0, nitems, adj.offsets.p, adj.cells.p);
   adj.built = true;
+  publish_across_lanes();
 }
 
 } // namespace cfx
@@ -679,6 +738,18 @@ int cfx_device_cache_release(void)
   CFX_API_BEGIN
   ctx().ensure();
   dev_cache_release();
+  CFX_API_END
+}
+
+int cfx_device_memory_stats(size_t* in_use, size_t* cached, size_t* peak, int reset_peak)
+{
+  CFX_API_BEGIN
+  size_t a = 0, b = 0, c = 0;
+  device_memory_stats(a, b, c);
+  if (in_use) *in_use = a;
+  if (cached) *cached = b;
+  if (peak) *peak = c;
+  if (reset_peak) device_memory_reset_peak();
   CFX_API_END
 }
 

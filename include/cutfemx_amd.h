@@ -175,6 +175,10 @@ int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on t
 int cfx_device_alloc(void** ptr, size_t bytes);
 int cfx_device_free(void* ptr);
 int cfx_device_cache_release(void); /* hand the library's cached (free) HBM blocks back to the driver */
+/* HBM held by the library's block cache: bytes handed out, bytes cached (free), and the high-water mark of their sum
+ * since start-up or the last call with reset_peak != 0 (mesh-static tables + temporaries of a step; caller-owned
+ * arrays are not counted).  No reference counterpart: the measurement side of SURVEY 8d. */
+int cfx_device_memory_stats(size_t* in_use, size_t* cached, size_t* peak, int reset_peak);
 int cfx_device_memset(void* ptr, int byte, size_t bytes); /* la::MatrixCSR::set_value(0) / la::Vector zeroing, on the stream */
 /* per-kernel HIP-event timing of the launches made by this library */
 int cfx_profile_enable(int on);
@@ -413,7 +417,9 @@ typedef struct
 int cfx_mesh_create_f32(int tdim, int gdim, int64_t nnodes, const float* x, int64_t ncells, const int32_t* conn,
                         int cell_stride, cfx_mesh_t* out);
 /* cut() / update() with float32 level-set Functions (cut.h:104-181 for T = float).  The widened copies belong to
- * the cut: a caller that changes its f32 values calls cfx_cut_update_f32 with the pointers again. */
+ * the cut: a caller that changes its f32 values calls cfx_cut_update_f32 with the pointers again (NULL is refused:
+ * there is no aliased array to re-read, unlike cfx_cut_update).  Likewise float32 coefficient / point_data arrays
+ * are widened once by the binding when a form is created: rebuild the form after changing them in place. */
 int cfx_cut_create_f32(cfx_mesh_t mesh, int n_level_sets, const int32_t* ls_dofmap, int ls_ndofs_cell,
                        int64_t ls_ndofs, const float* const* ls_values, const cfx_cut_options* opt, cfx_cut_t* out);
 int cfx_cut_update_f32(cfx_cut_t cut, const float* const* ls_values);

@@ -606,3 +606,88 @@ def test_vector_valued_source_coefficient(oracle, tdim, n, degree):
     assert rel_err(b, 1.5 * (M @ f)) < 1e-11
     with pytest.raises(ValueError):                          # an analytic scalar field cannot source a vector space
         cfx.fem.form([cfx.fem.Integral(cfx.fem.SOURCE, cells=inside, params=(cfx.fem.F_ONE, 1.0))], s["V"])
+
+
+def test_form_alive_across_update_is_refused_and_new_forms_get_new_plans(oracle):
+    """A form points at the located lists / rules of its cut.  cfx_cut_update drops them (their HBM blocks go back to
+    the block cache and are handed out again at the same address): the old form must raise instead of assembling
+    from recycled memory, and a form built afterwards must not adopt the old form's row plan (plans are keyed on
+    block / handle serial numbers, cfx_rowasm.hip row_plan)."""
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    n = 10
+    om = oracle.mesh_box(3, n)
+    mesh = cfx.Mesh.from_arrays(3, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    xt = torch.tensor(om.x, device="cuda")
+    phi = torch.empty(om.nnodes, device="cuda", dtype=torch.float64)
+    f = cfx.Function(V, phi)
+
+    def move(c):
+        centre = torch.tensor(c, device="cuda", dtype=torch.float64)
+        phi.copy_(torch.linalg.norm(xt - centre, dim=1) - 0.27)
+    move([0.40, 0.45, 0.50])
+    cd = cfx.cut(f)
+    old = poisson.build_forms(V, cd, order=4)
+    A0 = cfx.fem.assemble_matrix(old.a)          # builds and caches the plan of `old`
+    move([0.55, 0.50, 0.42])
+    cfx.update(cd)                               # the lists `old` points at are gone
+    new = poisson.build_forms(V, cd, order=4)    # same sizes class, recycled addresses
+    A1 = cfx.fem.assemble_matrix(new.a)
+    b1 = cfx.fem.assemble_vector(new.L)
+    ref = oracle_poisson(oracle, om, phi.cpu().numpy())
+    assert np.array_equal(A1.indptr, ref["indptr"]) and np.array_equal(A1.indices, ref["indices"])
+    assert rel_err(A1.data, ref["values"]) < RTOL and rel_err(b1, ref["b"]) < RTOL
+    assert A0.nnz != A1.nnz or not np.array_equal(A0.indices, A1.indices)
+    for use in (lambda: cfx.fem.assemble_matrix(old.a), lambda: cfx.fem.create_matrix(old.a),
+                lambda: cfx.fem.assemble_vector(old.L), lambda: cfx.fem.active_domain(old.a)):
+        with pytest.raises(RuntimeError, match="stale form"):
+            use()
+
+
+@pytest.mark.parametrize("degree,bs", [(1, 1), (2, 1), (2, 3)])
+def test_overlap_without_prepare(oracle, degree, bs):
+    """Two lanes with NOTHING pre-built (no prepare(), fresh spaces: incidence lists, neighbour lists, slot records and
+    the shared row plan are built lazily inside the section by whichever lane needs them first and published to the
+    other, cfx::publish_across_lanes): same matrix and vector as the oracle, degree 1 / 2 and vector degree 2."""
+    import torch
+
+    import cutfemx_amd as cfx
+    fem = cfx.fem
+    for rep in range(2):     # second repetition: fresh space again, block cache warm (recycled addresses)
+        s = setup(oracle, 3, 6, degree, bs)
+        O, om, dom, cd = s["O"], s["om"], s["dom"], s["cd"]
+        inside = O.locate_entities(dom, "phi<0")
+        ovol = O.runtime_quadrature(om, om.conn, s["phi"], dom, "phi<0", 2)
+        oghost = O.ghost_penalty_facets(om, dom, "phi<0")
+        vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+        if bs == 1:
+            oa = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=ovol, qdegree=2),
+                  O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.1,), qdegree=2)]
+            ga = [fem.Integral(fem.STIFFNESS, cells=inside, rules=vol, qdegree=2),
+                  fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)]
+            oL = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=ovol, params=(O.F_SINPROD, 1.0), qdegree=4)]
+            gL = [fem.Integral(fem.SOURCE, cells=inside, rules=vol, params=(fem.F_SINPROD, 1.0), qdegree=4)]
+        else:
+            oa = [O.Integral(O.CELL, O.K_ELASTICITY, entities=inside, rules=ovol, params=(10.0, 0.3), qdegree=2),
+                  O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.1,), qdegree=2)]
+            ga = [fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(10.0, 0.3), qdegree=2),
+                  fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)]
+            w = np.random.default_rng(5).standard_normal(s["oV"].ndofs * bs)
+            oL = [O.Integral(O.CELL, O.L_SOURCE, entities=inside, rules=ovol, params=(O.F_COEFFICIENT, 1.0), qdegree=4,
+                             coefficient=w)]
+            gL = [fem.Integral(fem.SOURCE, cells=inside, rules=vol, params=(fem.F_COEFFICIENT, 1.0), qdegree=4,
+                               coefficient=w)]
+        a, L = fem.form(ga, s["V"]), fem.form(gL, s["V"], rank=1)
+        b = torch.zeros(s["oV"].ndofs * bs, device="cuda", dtype=torch.float64)
+        with fem.overlap() as lanes:
+            lanes.side(lambda: fem.assemble_vector(L, b))
+            A = fem.create_matrix(a)
+            fem.assemble_matrix(a, A=A)
+        ip, ix = O.create_sparsity(om, s["oV"], oa)
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
+        assert rel_err(A.data, O.assemble_matrix(om, s["oV"], oa, ip, ix)) < RTOL
+        assert rel_err(b.cpu().numpy(), O.assemble_vector(om, s["oV"], oL)) < RTOL

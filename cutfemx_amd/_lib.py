@@ -8,10 +8,13 @@ from __future__ import annotations
 import ctypes as C
 from pathlib import Path
 
+import os
+
 import numpy as np
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libcutfemx_amd.so"
+# CFX_LIB: another build of the same engine (timing-ablation / variant builds under build/, tools/*_variants.sh)
+LIB_PATH = Path(os.environ["CFX_LIB"]).resolve() if os.environ.get("CFX_LIB") else _HERE / "libcutfemx_amd.so"
 
 OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_OUT_OF_RANGE, ERR_HIP = 0, -1, -2, -3, -4
 

@@ -553,6 +553,7 @@ struct cfx_pattern_s
   uint64_t full_plan = 0;
   cfx::DevArray<int32_t> full_rows;
   int64_t n_full_rows = 0;
+  int64_t n_full_short = 0; // vector-valued spaces: full_rows = [dofs with at most 32 neighbours | the others] (0: not split)
   cfx::DevArray<int32_t> rest_rows; // vector-valued spaces: the active rows that are not in full_rows
   int64_t n_rest_rows = 0;
   cfx::DevArray<int64_t> indptr;

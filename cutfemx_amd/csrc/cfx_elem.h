@@ -254,6 +254,114 @@ __device__ __forceinline__ void p2_stiffness_row_moments(const Geo<TDIM>& g, int
   }
 }
 
+// Vector-valued degree 2 on an affine simplex: the gradient Gram blocks H_ij[a][b] = int d_a N_i d_b N_j of row dof
+// `lr` against every column dof j, in closed form.  With g_k = grad(lam_k) (constant on the cell),
+//   d N_i = sum_m (dN_i / d lam_m) g_m,  vertex i: (4 lam_i - 1) g_i;  edge (a, b): 4 (lam_b g_a + lam_a g_b),
+// every block is |K| (g_a (x) ua_j + g_b (x) ub_j) with ua_j, ub_j fixed combinations of the g_k whose coefficients are
+// the same barycentric moments as in p2_stiffness_row() -- that function is the trace of this one:
+//   row vertex a:        col vertex j: ua = vv_aj g_j;                 col edge (c, d): ua = 4 (s_ad g_c + s_ac g_d)
+//   row edge (a, b):     col vertex j: ua = 4 s_jb g_j, ub = 4 s_ja g_j;
+//                        col edge (c, d): ua = 16 (m_bd g_c + m_bc g_d), ub = 16 (m_ad g_c + m_ac g_d)
+// (m_xy = int lam_x lam_y / |K|, s_xy = 4 m_xy - 1 / (n + 1), vv_xy = 16 m_xy - 8 / (n + 1) + 1).  Exact for the affine
+// cell: the same numbers as a quadrature rule of degree >= 2.  sink(j, H) is called for j = 0 .. ND - 1 with j a
+// compile-time constant in the unrolled loop.  The elasticity block (python/demo/demo_elasticity.py:167-238) is
+// Ae[(i, a), (j, b)] = lambda H[a][b] + mu H[b][a] + mu delta_ab tr(H); 30 x 30 staged doubles per uncut cell become
+// ~50 flops per block.
+template <int TDIM, typename Sink>
+__device__ __forceinline__ void p2_gradient_gram_row(const Geo<TDIM>& g, int lr, Sink&& sink)
+{
+  constexpr int NV = TDIM + 1, NE = TDIM == 2 ? 3 : 6;
+  constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+  constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+  constexpr double m_d = TDIM == 2 ? 1.0 / 12.0 : 1.0 / 20.0, m_s = 2.0 * m_d;
+  constexpr double inv = 1.0 / (TDIM + 1);
+  constexpr double vv_d = 16.0 * m_d - 8.0 * inv + 1.0, vv_s = 16.0 * m_s - 8.0 * inv + 1.0;
+  constexpr double s_d = 4.0 * m_d - inv, s_s = 4.0 * m_s - inv;
+  const bool vertex = lr < NV;
+  int a = lr, b = lr;
+#pragma unroll
+  for (int e = 0; e < NE; ++e)
+  {
+    const int ea = TDIM == 2 ? ea2[e % 3] : ea3[e], eb = TDIM == 2 ? eb2[e % 3] : eb3[e];
+    a = (lr == NV + e) ? ea : a;
+    b = (lr == NV + e) ? eb : b;
+  }
+  double G[NV][TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double s0 = 0.0;
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) { G[t + 1][d] = g.K[t][d]; s0 -= g.K[t][d]; }
+    G[0][d] = s0;
+  }
+  const double vol = fabs(g.detJ) * (TDIM == 2 ? 0.5 : 1.0 / 6.0);
+  double Ga[TDIM], Gb[TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    double va = 0.0, vb = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { va = (a == k) ? G[k][d] : va; vb = (b == k) ? G[k][d] : vb; }
+    Ga[d] = va * vol;
+    Gb[d] = vertex ? 0.0 : vb * vol; // a vertex row has one gradient: its ub terms vanish
+  }
+#pragma unroll
+  for (int j = 0; j < NV + NE; ++j)
+  {
+    double ua[TDIM], ub[TDIM];
+    if (j < NV)
+    {
+      const double ka = vertex ? ((j == a) ? vv_s : vv_d) : 4.0 * ((j == b) ? s_s : s_d);
+      const double kb = 4.0 * ((j == a) ? s_s : s_d);
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) { ua[d] = ka * G[j < NV ? j : 0][d]; ub[d] = kb * G[j < NV ? j : 0][d]; }
+    }
+    else
+    {
+      const int e = j - NV;
+      const int c = TDIM == 2 ? ea2[(e >= 0 ? e : 0) % 3] : ea3[(e >= 0 && e < 6) ? e : 0];
+      const int dd = TDIM == 2 ? eb2[(e >= 0 ? e : 0) % 3] : eb3[(e >= 0 && e < 6) ? e : 0];
+      // coefficients of g_c and g_dd in ua / ub
+      const double kac = vertex ? 4.0 * ((a == dd) ? s_s : s_d) : 16.0 * ((b == dd) ? m_s : m_d);
+      const double kad = vertex ? 4.0 * ((a == c) ? s_s : s_d) : 16.0 * ((b == c) ? m_s : m_d);
+      const double kbc = 16.0 * ((a == dd) ? m_s : m_d), kbd = 16.0 * ((a == c) ? m_s : m_d);
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        ua[d] = kac * G[c][d] + kad * G[dd][d];
+        ub[d] = kbc * G[c][d] + kbd * G[dd][d];
+      }
+    }
+    double H[TDIM][TDIM];
+#pragma unroll
+    for (int p = 0; p < TDIM; ++p)
+#pragma unroll
+      for (int q = 0; q < TDIM; ++q) H[p][q] = Ga[p] * ua[q] + Gb[p] * ub[q];
+    sink(j, H);
+  }
+}
+
+// component row kc of dof lr of the degree-2 elasticity tensor of an affine simplex: acc[j * TDIM + b], closed form
+template <int TDIM>
+__device__ __forceinline__ void p2_elasticity_row(const Geo<TDIM>& g, int lr, int kc, double lmbda, double mu, double* acc)
+{
+  p2_gradient_gram_row<TDIM>(g, lr, [&](int j, const double (&H)[TDIM][TDIM])
+  {
+    double tr = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) tr += H[d][d];
+#pragma unroll
+    for (int b = 0; b < TDIM; ++b)
+    {
+      double hab = 0.0, hba = 0.0; // H[kc][b], H[b][kc] through select chains (kc is a runtime index)
+#pragma unroll
+      for (int p = 0; p < TDIM; ++p) { hab = (p == kc) ? H[p][b] : hab; hba = (p == kc) ? H[b][p] : hba; }
+      acc[j * TDIM + b] += lmbda * hab + mu * hba + ((b == kc) ? mu * tr : 0.0);
+    }
+  });
+}
+
 __device__ __forceinline__ const double* ref_rule(int dim, int degree, int& n, const double*& w)
 {
   if (dim == 1)

@@ -1546,10 +1546,11 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.bc0 = bc0 ? dbc0.p : nullptr; A.bc1 = bc1 ? dbc1.p : nullptr;
   A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = out.dev; A.dump = nullptr; A.error = err.p;
-  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
-  // row-gather path (deterministic, no global atomics) when the form allows it;
-  // otherwise the entity-parallel kernels with FP64 atomics
+  // row-gather path (deterministic, no global atomics) when the form allows it (with zero_first it does the zeroing
+  // itself: rows with a single writer are stored, only the rest is filled); otherwise the whole fill and the
+  // entity-parallel kernels with FP64 atomics
   if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev, zero_first)) { out.finish(); return; }
+  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
   for (const auto& I : a->integrals) launch_integral(a, I, A);
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
   out.finish();

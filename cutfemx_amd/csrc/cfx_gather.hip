@@ -1855,8 +1855,10 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
 // ---------------------------------------------------------------------------
 // INLINE = false (default): uncut tensors are staged, the elasticity arithmetic is not compiled in
 // and the kernel fits 4 waves/SIMD.
-template <int TDIM, int DEG, int BS, int G, int CAP, bool ORDERED, bool INLINE>
-__global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_rows_block_kernel(RowArgs A)
+// INLINE: how the uncut items get their row -- 0 staged tensors, 1 quadrature row (cell_local_row), 2 closed-form
+// degree-2 elasticity row (p2_elasticity_row: std_inline == 3)
+template <int TDIM, int DEG, int BS, int G, int CAP, bool ORDERED, int INLINE>
+__global__ void __launch_bounds__(kWave, INLINE == 1 ? 2 : CFX_BLOCK_WAVES) assemble_rows_block_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int NLOC = ND * BS;
@@ -1917,6 +1919,18 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
       }
 #pragma unroll
       for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[j]);
+      // zero BC rows / columns (assemble_matrix_impl.h:151-185): bit j BS + b set = entry dropped.  The mask is taken
+      // BEFORE the integrals: with the closed-form row inlined between the dofmap reads and a bc loop placed after it,
+      // hipcc 7.2 (gfx950, TDIM = 2) paired the markers with the wrong columns (tests/test_gpu_spaces.py
+      // test_vector_elasticity_with_ghost_penalty_and_lifting[2-8-2-*] caught it; the 3-D instantiation was right)
+      uint32_t zmask = row_bc ? 0xffffffffu : 0u;
+      if (A.bc1 != nullptr)
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+#pragma unroll
+          for (int b = 0; b < BS; ++b) zmask |= A.bc1[(int64_t)cd[j] * BS + b] != 0 ? (1u << (j * BS + b)) : 0u;
+      }
       for (int i = 0; i < A.n_cell; ++i)
       {
         const RowIntegral& I = A.cell[i];
@@ -1924,7 +1938,15 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
         {
           if (INLINE && I.std_inline)
           {
-            if constexpr (INLINE)
+            if constexpr (INLINE == 2 && DEG == 2 && BS == TDIM)
+            {
+              Geo<TDIM> g;
+              load_cell<TDIM>(A.x, A.conn, c, g);
+              jacobian<TDIM>(g);
+              const double E = I.params[0], nu = I.params[1];
+              p2_elasticity_row<TDIM>(g, lr, kc, E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)), E / (2.0 * (1.0 + nu)), acc);
+            }
+            else if constexpr (INLINE == 1)
             {
               Geo<TDIM> g;
               load_cell<TDIM>(A.x, A.conn, c, g);
@@ -1954,12 +1976,9 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
           }
         }
       }
-      // zero BC rows / columns (assemble_matrix_impl.h:151-185)
+      static_assert(NLOC <= 32, "one bit per entry of the local row");
 #pragma unroll
-      for (int j = 0; j < ND; ++j)
-#pragma unroll
-        for (int b = 0; b < BS; ++b)
-          if (row_bc || (A.bc1 != nullptr && A.bc1[(int64_t)cd[j] * BS + b] != 0)) acc[j * BS + b] = 0.0;
+      for (int k = 0; k < NLOC; ++k) acc[k] = ((zmask >> k) & 1u) ? 0.0 : acc[k];
     }
     if constexpr (ORDERED)
     {
@@ -2144,7 +2163,19 @@ __global__ void __launch_bounds__(kWave, INLINE ? 2 : CFX_BLOCK_WAVES) assemble_
     }
   }
   __syncthreads();
-  for (int k = gl; k < lene; k += G) A.values[rb + k] += s_val[grp][k];
+  if (A.fresh) // single writer on a matrix that holds no earlier contributions: stored, the zero fill skipped these rows
+    for (int k = gl; k < lene; k += G) A.values[rb + k] = s_val[grp][k];
+  else
+    for (int k = gl; k < lene; k += G) A.values[rb + k] += s_val[grp][k];
+}
+
+// la::MatrixCSR::set_value(0) restricted to the rows no gather kernel writes: the inactive rows (their diagonal entry)
+__global__ void __launch_bounds__(kBlock) zero_inactive_rows_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                                                    const int64_t* __restrict__ indptr, double* __restrict__ values)
+{
+  const int64_t R = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (R >= nrows || rowmark[R / bs]) return;
+  for (int64_t k = indptr[R]; k < indptr[R + 1]; ++k) values[k] = 0.0;
 }
 
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
@@ -2424,6 +2455,329 @@ __global__ void __launch_bounds__(kWave) assemble_rows_block_plain_kernel(BlockP
   }
 }
 
+// stage 2, bilinear forms, vector-valued degree 2, elasticity on uncut cells WITHOUT staged tensors: the dofs whose
+// rows copied their static neighbour list, all BS component rows at a time.  An item = incidence entry + 12-byte slot
+// record, one item per lane; the lane forms the BS x (ND BS) block row of the element tensor in closed form from the
+// cell's four vertices (p2_gradient_gram_row: ~50 flops per 3 x 3 block) and adds it to the dof's LDS rows at the
+// recorded slots.  Replaces elasticity_tensors_mfma (7.2 KB written per uncut cell) + assemble_rows_block_plain (the
+// same bytes read back): the only HBM traffic left is the incidence / slot / geometry gathers and the stored rows.
+struct BlockP2Args
+{
+  int64_t n;
+  const int32_t* rows;
+  const double* x;
+  const int32_t* conn;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint8_t* slotn;
+  const int64_t* indptr;
+  double* values;
+  double lmbda, mu;
+  int fresh;
+  int* error;
+};
+
+#ifndef CFX_BLOCK_P2_WAVES
+#define CFX_BLOCK_P2_WAVES 2
+#endif
+#ifndef CFX_BP2_ABLATE
+#define CFX_BP2_ABLATE 0 // timing-only builds (wrong results): 1 no phase 2, 2 no stores, 4 no phase 1, 8 no gathers, 16 no LDS zeroing
+#endif
+// 3 x 3 (2 x 2) gradient Gram block of one (row dof, column dof) pair with RUNTIME indices: the row is described by its
+// barycentric pair (a, b) (a vertex row: a == b, Gb = 0), the column by (jc, jd) likewise; Gs = grad(lam_k), Ga / Gb =
+// |K| grad(lam_a / lam_b).  Same numbers as p2_gradient_gram_row(), whose column index is a compile-time constant.
+template <int TDIM>
+__device__ __forceinline__ void p2_gradient_gram_block(const double* __restrict__ Gs, const double* __restrict__ Ga,
+                                                       const double* __restrict__ Gb, int a, int b, bool rvert, int jc, int jd,
+                                                       bool jvert, double (&H)[TDIM][TDIM])
+{
+  constexpr double m_d = TDIM == 2 ? 1.0 / 12.0 : 1.0 / 20.0, m_s = 2.0 * m_d;
+  constexpr double inv = 1.0 / (TDIM + 1);
+  constexpr double vv_d = 16.0 * m_d - 8.0 * inv + 1.0, vv_s = 16.0 * m_s - 8.0 * inv + 1.0;
+  constexpr double s_d = 4.0 * m_d - inv, s_s = 4.0 * m_s - inv;
+  double kac, kad, kbc, kbd;
+  if (rvert)
+  {
+    kac = jvert ? ((a == jc) ? vv_s : vv_d) : 4.0 * ((a == jd) ? s_s : s_d);
+    kad = jvert ? 0.0 : 4.0 * ((a == jc) ? s_s : s_d);
+    kbc = 0.0; kbd = 0.0;
+  }
+  else
+  {
+    kac = jvert ? 4.0 * ((jc == b) ? s_s : s_d) : 16.0 * ((b == jd) ? m_s : m_d);
+    kad = jvert ? 0.0 : 16.0 * ((b == jc) ? m_s : m_d);
+    kbc = jvert ? 4.0 * ((jc == a) ? s_s : s_d) : 16.0 * ((a == jd) ? m_s : m_d);
+    kbd = jvert ? 0.0 : 16.0 * ((a == jc) ? m_s : m_d);
+  }
+  double ua[TDIM], ub[TDIM];
+#pragma unroll
+  for (int d = 0; d < TDIM; ++d)
+  {
+    const double gc = Gs[jc * TDIM + d], gd = Gs[jd * TDIM + d];
+    ua[d] = kac * gc + kad * gd;
+    ub[d] = kbc * gc + kbd * gd;
+  }
+#pragma unroll
+  for (int p = 0; p < TDIM; ++p)
+#pragma unroll
+    for (int q = 0; q < TDIM; ++q) H[p][q] = Ga[p] * ua[q] + Gb[p] * ub[q];
+}
+
+// A wavefront takes 64 consecutive dofs of the list (one lane each reads the dof's row pointers and incidence range
+// into LDS), then walks them RPW = 64 / G at a time.  A group of G lanes owns a dof: phase 1 (one item per lane)
+// turns the cell's vertices into grad(lam_k) and the row-side gradients in LDS; phase 2 (one item at a time, one
+// COLUMN dof per lane) forms the block of column j and adds its BS x BS entries to the dof's LDS rows with plain
+// read-modify-writes -- the columns of an item have distinct slots and the items follow each other in list order, so
+// there are no atomics (FP64 LDS atomics from sixteen lanes onto shared slots: 13.7 ms for this kernel) and the
+// result is reproducible.  The gathers are three dependent hops (incidence entry -> connectivity row -> vertices)
+// at ~2 us each with a handful of wavefronts per CU (the dof's BS x 3 len accumulators bound the occupancy), so they
+// run as a software pipeline across the groups of dofs: while group i is in phase 2, the vertices of i + 1, the
+// connectivity rows of i + 2 and the incidence entries of i + 3 are in flight; every load is unconditional (clamped
+// indices) so that nothing drains the vector-memory counter early.  A dof with more than G incident cells takes
+// extra, unpipelined passes.
+template <int TDIM, int G, int CAP>
+__global__ void __launch_bounds__(kWave, CFX_BLOCK_P2_WAVES) assemble_rows_block_p2_kernel(BlockP2Args A)
+{
+  constexpr int BS = TDIM, NV = TDIM + 1, ND = Elem<TDIM, 2>::ND, RPW = kWave / G, ROW = CAP * BS;
+  constexpr int NGEO = NV * TDIM + 2 * TDIM;
+  static_assert(G >= ND, "one lane per column dof");
+  __shared__ __align__(16) double s_val[RPW][BS * ROW]; // the dof's BS rows back to back (row stride = its row length):
+                                                        // the image of its contiguous run of the CSR value array
+  __shared__ double s_geo[RPW][G][NGEO]; // per staged item: grad(lam_k) [NV][TDIM], Ga, Gb
+  __shared__ uint32_t s_rec[RPW][G][4];  // ... its slot record and (a | b << 8 | vertex << 16)
+  __shared__ int64_t s_rb[kWave], s_cb[kWave];
+  __shared__ int32_t s_len[kWave], s_nc[kWave];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t i0 = CFX_ROW_BLOCK * kWave;
+  if (i0 >= A.n) return;
+  {
+    const int64_t i = i0 + lane;
+    const bool live = i < A.n;
+    const int64_t r = A.rows[live ? i : A.n - 1];
+    const int64_t rb = A.indptr[r * BS];
+    int len = (int)(A.indptr[r * BS + 1] - rb); // expanded row length (the BS rows of a dof are consecutive and equally long)
+    const int64_t cb = A.d2c_off[r];
+    int nc = (int)(A.d2c_off[r + 1] - cb);
+    if (len > ROW) { *A.error = 2; len = 0; }
+    if (!live || len == 0) { len = 0; nc = 0; }
+    s_rb[lane] = rb; s_cb[lane] = cb; s_len[lane] = len; s_nc[lane] = nc;
+  }
+  __syncthreads();
+  const int nd_here = (int)min((int64_t)kWave, A.n - i0);
+  const int nq = (nd_here + RPW - 1) / RPW;
+  const double lmbda = A.lmbda, mu = A.mu;
+  // this lane's column dof j = gl: its barycentric pair
+  constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+  constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+  const bool jcol = gl < ND, jvert = gl < NV;
+  int jc = jvert ? gl : 0, jd = jc;
+#pragma unroll
+  for (int e = 0; e < ND - NV; ++e)
+  {
+    jc = (gl == NV + e) ? (TDIM == 2 ? ea2[e % 3] : ea3[e % 6]) : jc;
+    jd = (gl == NV + e) ? (TDIM == 2 ? eb2[e % 3] : eb3[e % 6]) : jd;
+  }
+  // ---- the three load stages (unconditional: a lane without an item reads the dof's first item again)
+  struct Item { int32_t c; uint32_t w0, w1, w2; };
+  auto load_item = [&](int q, int t) -> Item
+  {
+    const int d = min(q, nq - 1) * RPW + grp;
+    const int nc = s_nc[d];
+    const int64_t e = s_cb[d] + ((t < nc) ? t : 0);
+    const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.slotn + e * 12);
+    Item it;
+    it.c = A.d2c[e]; it.w0 = rec[0]; it.w1 = rec[1]; it.w2 = rec[2];
+    return it;
+  };
+  struct Conn { int32_t v[NV]; };
+  auto load_conn = [&](int32_t c) -> Conn
+  {
+    Conn k;
+    if constexpr (TDIM == 3)
+    {
+      const int4 r4 = *reinterpret_cast<const int4*>(A.conn + (int64_t)c * 4);
+      k.v[0] = r4.x; k.v[1] = r4.y; k.v[2] = r4.z; k.v[3] = r4.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) k.v[i] = A.conn[(int64_t)c * NV + i];
+    }
+    return k;
+  };
+  struct Coords { double x[NV][TDIM]; };
+  auto load_coords = [&](const Conn& k) -> Coords
+  {
+    Coords X;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) X.x[i][d] = A.x[3 * (int64_t)k.v[i] + d];
+    return X;
+  };
+  // phase 1 of one item: geometry -> LDS
+  auto stage_item = [&](const Item& it, const Coords& X)
+  {
+    const int lr = (int)((it.w2 >> 16) & 0xffu);
+    Geo<TDIM> g;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) g.x[i][d] = X.x[i][d];
+    jacobian<TDIM>(g);
+    int a = lr, b = lr;
+#pragma unroll
+    for (int e = 0; e < ND - NV; ++e)
+    {
+      a = (lr == NV + e) ? (TDIM == 2 ? ea2[e % 3] : ea3[e % 6]) : a;
+      b = (lr == NV + e) ? (TDIM == 2 ? eb2[e % 3] : eb3[e % 6]) : b;
+    }
+    const bool rvert = lr < NV;
+    double Gs[NV][TDIM];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double s0 = 0.0;
+#pragma unroll
+      for (int k = 0; k < TDIM; ++k) { Gs[k + 1][d] = g.K[k][d]; s0 -= g.K[k][d]; }
+      Gs[0][d] = s0;
+    }
+    const double vol = fabs(g.detJ) * (TDIM == 2 ? 0.5 : 1.0 / 6.0);
+    double* geo = s_geo[grp][gl];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) geo[k * TDIM + d] = Gs[k][d];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double va = 0.0, vb = 0.0;
+#pragma unroll
+      for (int k = 0; k < NV; ++k) { va = (a == k) ? Gs[k][d] : va; vb = (b == k) ? Gs[k][d] : vb; }
+      geo[NV * TDIM + d] = va * vol;
+      geo[NV * TDIM + TDIM + d] = rvert ? 0.0 : vb * vol;
+    }
+    s_rec[grp][gl][0] = it.w0; s_rec[grp][gl][1] = it.w1; s_rec[grp][gl][2] = it.w2;
+    s_rec[grp][gl][3] = (uint32_t)a | ((uint32_t)b << 8) | (rvert ? 0x10000u : 0u);
+  };
+  // phase 2: the m staged items of this group, one at a time, one column dof per lane
+  auto add_items = [&](int m, int lene)
+  {
+    int mmax = m;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mmax = max(mmax, __shfl_xor(mmax, o, 64)); // the groups loop together
+    for (int it = 0; it < mmax; ++it)
+    {
+      if (it < m && jcol)
+      {
+        const uint32_t w3 = s_rec[grp][it][3];
+        const uint32_t w = s_rec[grp][it][gl >> 2];
+        const int slot = (int)((w >> (8 * (gl & 3))) & 0xffu);
+        const double* geo = s_geo[grp][it];
+        double H[TDIM][TDIM];
+        p2_gradient_gram_block<TDIM>(geo, geo + NV * TDIM, geo + NV * TDIM + TDIM, (int)(w3 & 0xffu), (int)((w3 >> 8) & 0xffu),
+                                     (w3 & 0x10000u) != 0, jc, jd, jvert, H);
+        double tr = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) tr += H[d][d];
+        tr *= mu;
+        double* row = &s_val[grp][0] + slot * BS;
+#pragma unroll
+        for (int a = 0; a < BS; ++a)
+#pragma unroll
+          for (int b = 0; b < BS; ++b) row[a * lene + b] += lmbda * H[a][b] + mu * H[b][a] + (a == b ? tr : 0.0);
+      }
+    }
+  };
+  // ---- prologue: items of groups 0, 1, 2; connectivity of 0, 1; vertices of 0
+  Item itA = load_item(0, gl), itB = load_item(1, gl), itC = load_item(2, gl);
+  Conn cnA = load_conn(itA.c), cnB = load_conn(itB.c);
+  Coords xA = load_coords(cnA);
+  for (int q = 0; q < nq; ++q)
+  {
+    const int d = q * RPW + grp;
+    const bool dlive = d < nd_here;
+    const int nc = dlive ? s_nc[d] : 0;
+    const int lene = dlive ? s_len[d] : 0;
+#if !(CFX_BP2_ABLATE & 16)
+    for (int k = gl; k < BS * lene; k += G) s_val[grp][k] = 0.0;
+#endif
+#if !(CFX_BP2_ABLATE & 4)
+    if (gl < nc) stage_item(itA, xA);
+#endif
+    // next stages: vertices of q + 1, connectivity of q + 2, incidence entries of q + 3 -- in flight during phase 2
+#if (CFX_BP2_ABLATE & 8)
+    const Coords xN = xA; const Conn cnN = cnB; const Item itN = itC;
+#else
+    const Coords xN = load_coords(cnB);
+    const Conn cnN = load_conn(itC.c);
+    const Item itN = load_item(q + 3, gl);
+#endif
+    __syncthreads();
+#if !(CFX_BP2_ABLATE & 1)
+    add_items(min(G, nc), lene);
+#endif
+    for (int base = G; base < nc; base += G) // (rare: more incident cells than lanes)
+    {
+      __syncthreads();
+      const int t = base + gl;
+      if (t < nc)
+      {
+        const Item it = load_item(q, t);
+        stage_item(it, load_coords(load_conn(it.c)));
+      }
+      __syncthreads();
+      add_items(min(G, nc - base), lene);
+    }
+    __syncthreads();
+    // the BS rows of a dof are one contiguous run of BS x lene values: the whole wavefront streams the runs of the
+    // RPW dofs one after the other, 16 B per lane (groups of G lanes storing 8 B each left the matrix write at
+    // 1.4 TB/s: 8.4 ms of this kernel's 13.3 at BASELINE config 5's share)
+#if (CFX_BP2_ABLATE & 2)
+    if (lmbda == 1.2345e300)
+#endif
+#pragma unroll
+    for (int g2 = 0; g2 < RPW; ++g2)
+    {
+      const int d2 = q * RPW + g2;
+      if (d2 >= nd_here) break;
+      const int n2 = BS * s_len[d2];
+      double* out = A.values + s_rb[d2];
+      const double* src = s_val[g2];
+      // head: one value if the run starts on an odd index (16 B stores need 16 B alignment), then pairs, then the tail
+      const int head = (int)((reinterpret_cast<uintptr_t>(out) >> 3) & 1) & (n2 > 0 ? 1 : 0);
+      if (A.fresh)
+      {
+        if (lane == 0 && head) out[0] = src[0];
+        const int npair = (n2 - head) >> 1;
+        for (int k = lane; k < npair; k += kWave)
+        {
+          double2 v;
+          v.x = src[head + 2 * k]; v.y = src[head + 2 * k + 1];
+          *reinterpret_cast<double2*>(out + head + 2 * k) = v;
+        }
+        if (lane == 0 && ((n2 - head) & 1)) out[n2 - 1] = src[n2 - 1];
+      }
+      else
+        for (int k = lane; k < n2; k += kWave) out[k] += src[k];
+    }
+    __syncthreads(); // s_val / s_geo are reused by the next group
+    itA = itB; itB = itC; itC = itN;
+    cnA = cnB; cnB = cnN;
+    xA = xN;
+  }
+}
+
+// degree-2 elasticity on a vector space without coefficient, integrated exactly (qdegree >= 2): the uncut cells need
+// no staged tensors -- closed-form rows (p2_gradient_gram_row).  CFX_P2_CLOSED=0 keeps the staged MFMA tensors.
+inline bool p2_elasticity_closed(const cfx_form_s* a, const cfx_integral_dev& I)
+{
+  const cfx_space_s* V = a->V;
+  const char* cf = getenv("CFX_P2_CLOSED");
+  return a->rank == 2 && V->degree == 2 && V->bs == V->mesh->tdim && I.type == CFX_CELL && I.kernel == CFX_K_ELASTICITY
+         && I.coefficient.n == 0 && I.qdegree >= 2 && !(cf && cf[0] == '0');
+}
+
 struct Stage1
 {
   std::vector<DevArray<double>> buffers;
@@ -2517,8 +2871,11 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
     {
       // degree-2 scalar stiffness without coefficient: closed-form row per item, no staged tensors
       const char* cf = getenv("CFX_P2_CLOSED");
-      if (DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0 && !(cf && cf[0] == '0'))
+      if (DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0 && I.qdegree >= 2
+          && !(cf && cf[0] == '0'))
         R.std_inline = 3;
+      // ... and the vector-valued elasticity term likewise (closed-form block rows)
+      if (DEG == 2 && BS == TDIM && p2_elasticity_closed(a, I)) R.std_inline = 3;
     }
     if (!R.std_inline && I.n_entities > 0)
     {
@@ -2602,6 +2959,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
 template <int TDIM, int DEG>
 int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
+  if (fresh) dev_fill(values, 0, sizeof(double) * (size_t)P->nnz); // (the plain rows are stored on top; see run_matrix_block)
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG>(a, st);
   A.fresh = fresh ? 1 : 0;
@@ -2801,20 +3159,36 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   A.mark_mask = 0xFFu;
   ZeroFlag err;
   A.error = err.p;
+  // `fresh` = MatrixCSR.set_value(0) fused into this call: every active row is written by exactly one kernel below
+  // (the dof-at-a-time kernel or the searching one), which then STORES its rows; only the inactive rows (one
+  // diagonal entry each) are zeroed -- the full fill of the value array was 1.8 of 10.8 ms at BASELINE config 5's share
+  A.fresh = fresh ? 1 : 0;
+  if (fresh)
+  {
+    cfx_row_plan& plan0 = row_plan(a);
+    launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, BS, plan0.rowmark.p,
+           P->indptr.p, values);
+  }
   if (A.n_active > 0)
   {
     const bool det = deterministic();
     const int mr = P->max_row_len; // scalar columns per row
-    bool inl = false;
-    for (int s = 0; s < A.n_cell; ++s) inl = inl || A.cell[s].std_inline != 0;
+    bool inl = false, closed = false;
+    for (int s = 0; s < A.n_cell; ++s)
+    {
+      inl = inl || (A.cell[s].std_inline != 0 && A.cell[s].std_inline != 3);
+      closed = closed || A.cell[s].std_inline == 3;
+    }
+    require(!(inl && closed), CFX_ERR_RUNTIME, "assemble_matrix: mixed inline modes on a block space");
+#define CFX_BLOCK_V(GG, CAPP, ORD, INL) \
+  launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, ORD, INL>, grid, dim3(kWave), 0, A)
 #define CFX_BLOCK(GG, CAPP)                                                                                          \
   do                                                                                                                 \
   {                                                                                                                  \
     const dim3 grid = row_grid((A.n_active * BS + (kWave / GG) - 1) / (kWave / GG));                                 \
-    if (det && inl) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true, true>, grid, dim3(kWave), 0, A);    \
-    else if (det) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, true, false>, grid, dim3(kWave), 0, A);  \
-    else if (inl) launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, true>, grid, dim3(kWave), 0, A);  \
-    else launch("assemble_rows_block", assemble_rows_block_kernel<TDIM, DEG, BS, GG, CAPP, false, false>, grid, dim3(kWave), 0, A);          \
+    if (closed) { if (det) CFX_BLOCK_V(GG, CAPP, true, 2); else CFX_BLOCK_V(GG, CAPP, false, 2); }                   \
+    else if (inl) { if (det) CFX_BLOCK_V(GG, CAPP, true, 1); else CFX_BLOCK_V(GG, CAPP, false, 1); }                 \
+    else { if (det) CFX_BLOCK_V(GG, CAPP, true, 0); else CFX_BLOCK_V(GG, CAPP, false, 0); }                          \
   } while (0)
     // degree 2: the dofs whose rows copied their static list, all BS component rows at a time
     if constexpr (DEG == 2)
@@ -2825,8 +3199,38 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
       int slot = -1, n_std = 0;
       for (int s = 0; s < A.n_cell; ++s)
         if (A.cell[s].std_bits) { slot = s; ++n_std; }
-      if (P->full_plan == plan.serial && P->n_full_rows > 0 && !bc0 && !bc1 && !det && stn.slotn_ok && stn.max_len <= 72
-          && n_std == 1 && A.cell[slot].std_tensors && !A.cell[slot].std_inline && !(bp && bp[0] == '0'))
+      const bool full_ok = P->full_plan == plan.serial && P->n_full_rows > 0 && !bc0 && !bc1 && !det && stn.slotn_ok
+                           && stn.max_len <= 72 && n_std == 1 && !(bp && bp[0] == '0');
+      if (full_ok && A.cell[slot].std_inline == 3)
+      {
+        if constexpr (BS == TDIM)
+        {
+          // closed-form block rows from the cells' vertices: no staged tensors at all for these dofs
+          BlockP2Args Q{};
+          Q.n = P->n_full_rows; Q.rows = P->full_rows.p; Q.x = A.x; Q.conn = A.conn; Q.d2c_off = A.d2c_off; Q.d2c = A.d2c;
+          Q.slotn = stn.slotn.p; Q.indptr = A.indptr; Q.values = A.values; Q.fresh = fresh ? 1 : 0; Q.error = A.error;
+          const double E = A.cell[slot].params[0], nu = A.cell[slot].params[1];
+          Q.lmbda = E * nu / ((1.0 + nu) * (1.0 - 2.0 * nu)); Q.mu = E / (2.0 * (1.0 + nu));
+          // lanes per dof >= dofs per cell (one column dof per lane) and >= incident cells (one item per lane and pass):
+          // short lists (edge dofs: 4 - 6 cells) 16 lanes and 32 columns, the others (vertex dofs: 24 cells) 32 and 72
+          constexpr int GS = TDIM == 3 ? 16 : 8, GL = TDIM == 3 ? 32 : 16;
+          const int64_t ns = P->n_full_short, nl = P->n_full_rows - ns;
+          if (ns > 0)
+          {
+            Q.n = ns; Q.rows = P->full_rows.p;
+            launch("assemble_rows_block_p2", assemble_rows_block_p2_kernel<TDIM, GS, 32>, row_grid((ns + kWave - 1) / kWave),
+                   dim3(kWave), 0, Q);
+          }
+          if (nl > 0)
+          {
+            Q.n = nl; Q.rows = P->full_rows.p + ns;
+            launch("assemble_rows_block_p2", assemble_rows_block_p2_kernel<TDIM, GL, 72>, row_grid((nl + kWave - 1) / kWave),
+                   dim3(kWave), 0, Q);
+          }
+          A.n_active = P->n_rest_rows; A.active_rows = P->rest_rows.p;
+        }
+      }
+      else if (full_ok && A.cell[slot].std_tensors && !A.cell[slot].std_inline)
       {
         BlockPlainArgs Q{};
         Q.n = P->n_full_rows; Q.rows = P->full_rows.p; Q.d2c_off = A.d2c_off; Q.d2c = A.d2c; Q.slotn = stn.slotn.p;
@@ -2843,6 +3247,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
     else if (mr <= 128) CFX_BLOCK(16, 128);
     else CFX_BLOCK(32, 256);
     }
+#undef CFX_BLOCK_V
 #undef CFX_BLOCK
   }
   return read_scalar(err.p);
@@ -2950,8 +3355,8 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
     {
       const int nloc = V->ndofs_cell * V->bs;
       size_t need = 0, free_b = 0, total_b = 0;
-      for (const auto& I : a->integrals)
-        need += (size_t)(I.n_entities + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
+      for (const auto& I : a->integrals) // (closed-form uncut cells stage nothing)
+        need += (size_t)((p2_elasticity_closed(a, I) ? 0 : I.n_entities) + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
       CFX_HIP(hipMemGetInfo(&free_b, &total_b));
       const char* bg = getenv("CFX_BLOCK_GATHER");
       if ((bg && bg[0] == '0') || need > free_b / 2) return false;

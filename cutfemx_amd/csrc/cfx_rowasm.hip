@@ -1949,6 +1949,23 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       P->full_rows.alloc(P->n_full_rows);
       launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
              plan.plain_rows.p, P->full_rows.p);
+      // ... split by the length of the static list: the edge dofs of a degree-2 space (7 of 8 dofs, at most 27
+      // neighbours on Kuhn meshes) need a third of the LDS accumulators of the vertex dofs (65) -- more dofs in flight
+      P->n_full_short = 0;
+      if (P->n_full_rows > 0)
+      {
+        DevArray<int32_t> idx_s, idx_l, sorted(P->n_full_rows);
+        const int64_t ns = compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, false}, idx_s);
+        if (ns > 0 && ns < P->n_full_rows)
+        {
+          (void)compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, true}, idx_l);
+          launch("pattern_full_rows", gather_i32_kernel, grid_for(ns), dim3(kBlock), 0, ns, idx_s.p, P->full_rows.p, sorted.p);
+          launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows - ns), dim3(kBlock), 0, P->n_full_rows - ns,
+                 idx_l.p, P->full_rows.p, sorted.p + ns);
+          P->full_rows = std::move(sorted);
+        }
+        P->n_full_short = ns;
+      }
       P->n_rest_rows = n_h;
       P->rest_rows.alloc(n_h);
       if (n_h > 0)

@@ -48,8 +48,10 @@ def test_p2_poisson_takes_the_list_and_slot_kernels(oracle, monkeypatch):
     assert "assemble_rows_p2_plain" not in names_bc
 
 
-def test_vector_p2_elasticity_takes_the_mfma_and_record_kernels(oracle):
-    """configs[4] at 12^3: 30 x 30 tensors on the FP64 matrix cores, vector ghost penalty from the facet records."""
+def test_vector_p2_elasticity_takes_the_closed_form_mfma_and_record_kernels(oracle, monkeypatch):
+    """configs[4] at 12^3.  Default: closed-form block rows for the uncut cells (no staged 30 x 30 tensors:
+    `elasticity_tensors_mfma` must NOT run), 30 x 30 tensors of the CUT cells on the FP64 matrix cores, vector ghost
+    penalty from the facet records.  CFX_P2_CLOSED=0: the staged path (MFMA tensors for every cell + the block gather)."""
     import cutfemx_amd as cfx
     from cutfemx_amd import fem
     from test_gpu_spaces import elasticity_problem, setup
@@ -62,9 +64,19 @@ def test_vector_p2_elasticity_takes_the_mfma_and_record_kernels(oracle):
     A, names = profiled(lambda: fem.assemble_matrix(a))
     assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
     assert rel_err(A.data, want) < 1e-12
-    for k in ("elasticity_tensors_mfma", "assemble_rows_block", "assemble_rows_block_plain", "assemble_facets",
+    for k in ("assemble_rows_block_p2", "elasticity_tensors_mfma_cut", "assemble_rows_block", "assemble_facets",
               "pattern_plain_full"):
         assert k in names, (k, sorted(names))
+    assert "elasticity_tensors_mfma" not in names and "assemble_rows_block_plain" not in names, sorted(names)
+    # accumulate on top of what is there (not a fresh matrix): twice the values
+    fem.assemble_matrix(a, A=A)
+    assert rel_err(A.data, 2.0 * want) < 1e-12
+    monkeypatch.setenv("CFX_P2_CLOSED", "0")
+    a2 = fem.form(ga, s["V"])
+    A2, names2 = profiled(lambda: fem.assemble_matrix(a2))
+    assert rel_err(A2.data, want) < 1e-12
+    for k in ("elasticity_tensors_mfma", "assemble_rows_block_plain"):
+        assert k in names2, (k, sorted(names2))
 
 
 def test_static_table_bytes_and_form_prepare(oracle):

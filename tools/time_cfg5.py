@@ -26,11 +26,11 @@ for it in range(3):
         import ctypes as C
         from cutfemx_amd import _lib
         l = _lib.lib(); _lib.check(l.cfx_profile_enable(1)); _lib.check(l.cfx_profile_reset())
-        fem.assemble_matrix(a, A=A)
+        fem.assemble_matrix(a, A=fem.create_matrix(a))   # a fresh matrix: the set_value(0) + assemble path the timing loop takes
         out = {}
         for i in range(l.cfx_profile_count()):
             name, ms, cnt = C.c_char_p(), C.c_double(), C.c_int64()
             _lib.check(l.cfx_profile_get(i, C.byref(name), C.byref(ms), C.byref(cnt)))
             if cnt.value: out[name.value.decode()] = round(ms.value, 2)
-        print(' kernels', dict(sorted(out.items(), key=lambda kv: -kv[1])[:6]))
+        print(' kernels', {k: v for k, v in sorted(out.items(), key=lambda kv: -kv[1]) if k.startswith(('assemble', 'elasticity', 'fill', 'zero'))})
     del A, a

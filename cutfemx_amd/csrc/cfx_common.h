@@ -574,4 +574,6 @@ struct cfx_active_s
   cfx_space_t V = nullptr;
   cfx::DevArray<int32_t> active_cells, inactive_dofs;
   int64_t n_active = 0, n_inactive = 0;
+  cfx::DevArray<int32_t> tile_zeros; // scalar spaces: inactive rows per tile of kByteTile rows (empty: not counted)
+  cfx::DevArray<int64_t> tile_zero_off; // ... and their exclusive scan: where a tile's rows start in inactive_dofs
 };

@@ -27,6 +27,19 @@ inline dim3 xcd_grid(int64_t nblocks)
   return dim3((unsigned)g);
 }
 
+// the block's threads fill the contiguous run p[0..n) with v: 16 B per lane (8 B stores reach about half the write
+// rate), one value ahead of the pairs when the run starts on an odd index
+__device__ __forceinline__ void block_fill_run(double* __restrict__ p, int n, double v)
+{
+  const int head = (int)((reinterpret_cast<uintptr_t>(p) >> 3) & 1) & (n > 0 ? 1 : 0);
+  if (threadIdx.x == 0 && head) p[0] = v;
+  const int npair = (n - head) >> 1;
+  double2* q = reinterpret_cast<double2*>(p + head);
+  const double2 vv = make_double2(v, v);
+  for (int k = threadIdx.x; k < npair; k += blockDim.x) q[k] = vv;
+  if (threadIdx.x == 0 && ((n - head) & 1)) p[n - 1] = v;
+}
+
 // 32-bit finaliser (murmur3): cell ids of a structured mesh are arithmetic progressions, which a
 // bare multiplicative hash maps onto a few residues of a power-of-two table (measured: 2x longer
 // probe chains on one of eight slabs)

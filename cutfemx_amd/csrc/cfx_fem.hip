@@ -870,6 +870,39 @@ __global__ void deactivate_kernel(int64_t n, const int32_t* __restrict__ rows, c
   if (b) b[r] = rhs_value;
 }
 
+// A tile of kByteTile rows that are ALL inactive (most inactive rows: the region outside the domain) holds one entry per
+// row, its diagonal (assembler.h:538-560: the all-rows diagonal of every pattern this library builds; one entry per row
+// is checked here through the tile's two row pointers): row r0 + k sits k entries behind the tile's first row pointer,
+// so the tile is two contiguous fills -- no row list, no per-row pointers, no column check.  The rows of the other
+// tiles keep deactivate_kernel.
+__global__ void __launch_bounds__(kBlock) deactivate_tiles_kernel(int64_t nrows, const int32_t* __restrict__ tile_zeros,
+                                                                  const int64_t* __restrict__ tile_zero_off,
+                                                                  const int32_t* __restrict__ rows,
+                                                                  const int64_t* __restrict__ indptr,
+                                                                  const int32_t* __restrict__ indices, double* __restrict__ values,
+                                                                  double* __restrict__ b, double diagonal, double rhs_value, int* error)
+{
+  const int64_t r0 = (int64_t)blockIdx.x * kByteTile;
+  const int tl = (int)min((int64_t)kByteTile, nrows - r0);
+  const int nz = tile_zeros[blockIdx.x];
+  if (nz == tl && indptr[r0 + tl] - indptr[r0] == tl)
+  {
+    block_fill_run(values + indptr[r0], tl, diagonal);
+    if (b) block_fill_run(b + r0, tl, rhs_value);
+    return;
+  }
+  // a tile with active rows: its inactive rows one by one from the tile's slice of the list
+  const int64_t o = tile_zero_off[blockIdx.x];
+  for (int k = threadIdx.x; k < nz; k += kBlock)
+  {
+    const int32_t r = rows[o + k];
+    const int64_t rb = indptr[r], re = indptr[r + 1];
+    const int64_t pos = (re - rb == 1 && indices[rb] == r) ? rb : csr_find(indices, rb, re, r);
+    if (pos < 0) *error = 1; else values[pos] = diagonal;
+    if (b) b[r] = rhs_value;
+  }
+}
+
 __global__ void inactive_tile_counts_kernel(int64_t ntiles, int64_t n, const int64_t* __restrict__ active, int32_t* __restrict__ zeros)
 {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1744,6 +1777,12 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
     // (the plan knows how many rows are marked: the list is sized without a read-back)
     d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
                                   zeros.n > 0 ? zeros.p : nullptr, plan.built ? nrows - plan.n_active_rows : -1);
+    if (zeros.n > 0)
+    {
+      d->tile_zero_off.alloc(zeros.n + 1);
+      exclusive_scan(zeros.p, d->tile_zero_off.p, zeros.n);
+    }
+    d->tile_zeros = std::move(zeros);
   }
   else
   {
@@ -1781,9 +1820,21 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t P, double* values, doub
   if (b) ob = std::make_unique<OutArray<double>>(b, nrows, true);
   ZeroFlag err;
   if (d->n_inactive > 0)
-    launch("deactivate", deactivate_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
-           d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,
-           b ? ob->dev : nullptr, diagonal, rhs_value, err.p);
+  {
+    // the tile shortcut is sound for patterns whose rows hold nothing but the diagonal in fully inactive tiles: true of
+    // every pattern this library builds (nnz of a fully inactive tile == its row count is checked on the spot)
+    const int64_t ntiles = (nrows + kByteTile - 1) / kByteTile;
+    const bool tiles = values && P && d->V->bs == 1 && d->tile_zeros.n == ntiles && d->tile_zero_off.n == ntiles + 1
+                       && P->nrows == nrows;
+    if (tiles)
+      launch("deactivate", deactivate_tiles_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nrows, d->tile_zeros.p,
+             d->tile_zero_off.p, d->inactive_dofs.p, P->indptr.p, P->indices.p, ov->dev, b ? ob->dev : (double*)nullptr, diagonal,
+             rhs_value, err.p);
+    else
+      launch("deactivate", deactivate_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
+             d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,
+             b ? ob->dev : nullptr, diagonal, rhs_value, err.p);
+  }
   // deactivate.h: validate_matrix_rows
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "Deactivated matrix row has no diagonal entry.");
   if (ov) ov->finish();

@@ -1280,6 +1280,18 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
     }
   }
   __syncthreads();
+  if (A.fresh == 2)
+  {
+    // first writer of these rows on a matrix that holds nothing yet (set_value(0) fused, run_matrix): stored -- the
+    // zero fill skipped them, the rule / facet items are added by the kernel that follows
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len) A.values[rb + k] = s_val[grp][k];
+    }
+    return;
+  }
   double myval[KMAX];
 #pragma unroll
   for (int q = 0; q < KMAX; ++q)
@@ -2178,6 +2190,24 @@ __global__ void __launch_bounds__(kBlock) zero_inactive_rows_kernel(int64_t nrow
   for (int64_t k = indptr[R]; k < indptr[R + 1]; ++k) values[k] = 0.0;
 }
 
+// ... scalar spaces with the plan's per-tile row counts: a tile of kByteTile rows without an active row is kByteTile
+// consecutive diagonal entries -- one contiguous fill from the tile's first row pointer, no per-row reads
+__global__ void __launch_bounds__(kBlock) zero_inactive_tiles_kernel(int64_t nrows, const uint8_t* __restrict__ rowmark,
+                                                                     const int64_t* __restrict__ tile_counts,
+                                                                     const int64_t* __restrict__ indptr, double* __restrict__ values)
+{
+  const int64_t r0 = (int64_t)blockIdx.x * kByteTile;
+  const int n = (int)min((int64_t)kByteTile, nrows - r0);
+  if (tile_counts[blockIdx.x] == 0)
+  {
+    block_fill_run(values + indptr[r0], n, 0.0);
+    return;
+  }
+  for (int k = threadIdx.x; k < n; k += kBlock)
+    if (!rowmark[r0 + k])
+      for (int64_t e = indptr[r0 + k]; e < indptr[r0 + k + 1]; ++e) values[e] = 0.0;
+}
+
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
 template <int TDIM, int DEG, int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
@@ -2959,7 +2989,6 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
 template <int TDIM, int DEG>
 int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
-  if (fresh) dev_fill(values, 0, sizeof(double) * (size_t)P->nnz); // (the plain rows are stored on top; see run_matrix_block)
   Stage1 st;
   RowArgs A = prepare<TDIM, DEG>(a, st);
   A.fresh = fresh ? 1 : 0;
@@ -2967,6 +2996,13 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   ZeroFlag err;
   A.error = err.p;
   if (const char* dbg = getenv("CFX_DEBUG_ROWS")) A.debug = atoi(dbg);
+  // `fresh` = MatrixCSR.set_value(0) fused into this call (nothing has written to `values` yet: stage 1 fills its own
+  // buffers).  P1 on the split path: every active row has a FIRST writer that stores (the tile / plain kernels their
+  // rows, assemble_rows_p1 the rows it is given), so only the inactive rows (one diagonal entry each) are zeroed --
+  // 0.2 instead of 0.7 ms at 512^3; every other path fills the whole array first.  CFX_LAZY_ZERO=0: always fill.
+  bool lazy_zero = false;
+  auto fill_all = [&]() { if (fresh) dev_fill(values, 0, sizeof(double) * (size_t)P->nnz); };
+  if (A.n_active == 0) fill_all();
   if (A.n_active > 0)
   {
     const bool det = deterministic();
@@ -2993,11 +3029,26 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         else if (A.cell[s].std_bits) all_inline = false; // staged uncut tensors: generic path
       }
       const char* fs1 = getenv("CFX_ROWS_SPLIT");
-      if (all_inline && inline_bits && (2 * plan.n_special_rows <= plan.n_active_rows || (fs1 && fs1[0] == '1')))
+      const bool split_p1 = all_inline && inline_bits && (2 * plan.n_special_rows <= plan.n_active_rows || (fs1 && fs1[0] == '1'));
+      const char* lz = getenv("CFX_LAZY_ZERO");
+      lazy_zero = fresh && split_p1 && !(lz && lz[0] == '0');
+      if (!lazy_zero) fill_all();
+      if (split_p1)
       {
         split = true;
         RowArgs F = A;
         F.inline_bits = inline_bits;
+        if (lazy_zero)
+        {
+          F.fresh = 2; // assemble_rows_p1 is the first writer of the rows it is given (all active rows, or the interface rows)
+          const int64_t nr = P->nrows, ntiles = (nr + kByteTile - 1) / kByteTile;
+          if (plan.row_tile_counts.n == ntiles)
+            launch("zero_inactive_rows", zero_inactive_tiles_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nr, plan.rowmark.p,
+                   plan.row_tile_counts.p, P->indptr.p, values);
+          else
+            launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(nr), dim3(kBlock), 0, nr, 1, plan.rowmark.p,
+                   P->indptr.p, values);
+        }
         // rows laid out as stencil subsets by build_pattern from this very plan: slots by popcount
         const Stencil& stn = a->V->stencil;
         if (stn.usable && plan.n_plain_rows > 0 && P->stencil_plan == plan.serial)
@@ -3083,6 +3134,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     }
     if constexpr (DEG > 1)
     {
+      fill_all();
       // degree 2: (a) the uncut items of every row with the lean kernel, short rows (<= 64 columns:
       // the edge dofs, ~5 cells each) 8 lanes per row, long rows 16; (b) rule + facet items of the
       // interface rows with the full kernel.  Needs the row partition made with the pattern.

@@ -507,6 +507,14 @@ struct cfx_row_plan
   // consecutive); keys -1 = empty, size = mask + 1 >= 2 * distinct parents
   cfx::DevArray<int32_t> rule_keys[4], rule_first[4];
   uint32_t rule_mask[4] = {0, 0, 0, 0};
+  // cells that host a runtime rule of any cell integral (cellmark & 0xF0), ascending, with the bitset + rank
+  // structure that maps a cell to its position in the list (built on first use by cfx::plan_cut_cells): the key of
+  // the per-cut-cell tensors of the degree-2 gather
+  cfx::DevArray<int32_t> cut_cells;
+  int64_t n_cut_cells = 0;
+  cfx::DevArray<int64_t> cut_bits;
+  cfx::DevArray<int32_t> cut_rank;
+  bool cut_cells_built = false;
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};
   // identity of the entity lists the plan was built from: (integral index, entities ptr, count, rules handle,
@@ -530,6 +538,7 @@ void validate_form(const cfx_form_s* a);                                // cfx_r
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 const Stencil& space_stencil_slotn(cfx_space_s* V);                     // cfx_rowasm.hip
 void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
+void plan_cut_cells(cfx_form_s* a);                                     // cfx_rowasm.hip
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
@@ -554,6 +563,11 @@ struct cfx_pattern_s
   cfx::DevArray<int32_t> full_rows;
   int64_t n_full_rows = 0;
   int64_t n_full_short = 0; // vector-valued spaces: full_rows = [dofs with at most 32 neighbours | the others] (0: not split)
+  // degree-2 scalar spaces: the hashed rows that are not interface rows (plain rows that could not copy their list);
+  // odd_plan = serial of the plan they were split for: the interface rows then take ONE gather pass of their own
+  uint64_t odd_plan = 0;
+  cfx::DevArray<int32_t> odd_rows;
+  int64_t n_odd_rows = 0;
   cfx::DevArray<int32_t> rest_rows; // vector-valued spaces: the active rows that are not in full_rows
   int64_t n_rest_rows = 0;
   cfx::DevArray<int64_t> indptr;

@@ -139,6 +139,11 @@ struct RowArgs
   const unsigned long long* plain_masks; // plan.plain_masks / plain_uniform, indexed like active_rows
   const uint8_t* plain_uniform;
   int fresh; // values holds zeros on entry (cfx_assemble_matrix_zeroed): single-writer rows are stored, not accumulated
+  // degree 2, scalar: ONE tensor per cut cell, summed over every rule of every cell integral (cut_tensors_p2_kernel),
+  // keyed by the cell's position in plan.cut_cells (bitset + rank); null: per-integral rule tensors / moments
+  const double* cut_tensors;
+  const unsigned long long* cut_bits;
+  const int32_t* cut_rank;
 };
 
 // index of cell c in the sorted entity list described by (bits, rank)
@@ -636,8 +641,10 @@ __global__ void __launch_bounds__(kBlock) vec_source_sin_p1_kernel(VecArgs A)
 // items of every row of a degree-2 space (the facet section alone holds 100 registers there).
 // STD = false compiles the uncut-cell items out: the form that serves only the rule / facet items
 // of the interface rows (mark_mask 0xF0) next to a lean kernel for everything else.
-template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true, bool STD = true>
-__global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
+// CUTT: the cut cells' contributions come as one staged tensor per cut cell (A.cut_tensors): the per-integral rule
+// lookups, the moments and the closed-form code are not compiled in (degree 2: 157 -> under 128 VGPRs)
+template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true, bool STD = true, bool CUTT = false>
+__global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4) : 2) : 3) : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row
@@ -833,7 +840,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
                 for (int j = 0; j < ND; ++j) acc[j] += T[j];
               }
             }
-            if (CUTS && (mark & (16u << i)))
+            if (CUTS && !CUTT && (mark & (16u << i)))
             {
               if (DEG == 2 && I.rule_moments)
               {
@@ -863,6 +870,21 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
                 const double* T = I.rule_tensors + (e * ND + lr) * ND;
 #pragma unroll
                 for (int j = 0; j < ND; ++j) acc[j] += T[j];
+              }
+            }
+          }
+          if constexpr (CUTS && CUTT)
+          {
+            if (mark & 0xF0u)
+            {
+              const int64_t e = entity_index(A.cut_bits, A.cut_rank, c);
+              const double2* T = reinterpret_cast<const double2*>(A.cut_tensors + (e * ND + lr) * ND);
+              static_assert(ND % 2 == 0, "rows of the cut tensors are read as 16 B pairs");
+#pragma unroll
+              for (int j = 0; j < ND / 2; ++j)
+              {
+                const double2 v = T[j];
+                acc[2 * j] += v.x; acc[2 * j + 1] += v.y;
               }
             }
           }
@@ -1106,6 +1128,17 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? 2 : 3) : CFX_ROWS_WAV
     }
   }
   __syncthreads();
+  if (A.fresh == 2)
+  {
+    // first and only writer of these rows on a matrix that holds nothing yet (set_value(0) fused): stored
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len) A.values[rb + k] = s_val[grp][k];
+    }
+    return;
+  }
   // Row epilogue: values[row] += reduced row, loads batched
   double myval[KMAX];
 #pragma unroll
@@ -2808,6 +2841,179 @@ inline bool p2_elasticity_closed(const cfx_form_s* a, const cfx_integral_dev& I)
          && I.coefficient.n == 0 && I.qdegree >= 2 && !(cf && cf[0] == '0');
 }
 
+// ---------------------------------------------------------------------------
+// stage 1 of the cut cells of a degree-2 scalar space: ONE ND x ND tensor per cut cell, summed over every runtime rule
+// of every cell integral of the form (stiffness over the volume rule + Nitsche over the interface rule of the same
+// cell, ...).  kCutLanes2 lanes per cut cell share the points of each rule; mass and Nitsche terms accumulate the
+// symmetric tensor point by point (N_i and the normal derivatives dn_i straight from the barycentric coordinates:
+// vertex (4 lam_i - 1) alpha_i, edge 4 (lam_b alpha_a + lam_a alpha_b), alpha_k = grad(lam_k) . n), stiffness terms
+// accumulate the 15 barycentric moments and take the closed form (p2_stiffness_row_moments) at the end.  The gather then
+// reads one 80-byte row per (row, cut cell) item -- before: a hash probe, a moment record, a Nitsche tensor row and the
+// closed form per integral and item, with the generic tabulation kernel (one thread per rule and row) behind it
+// (assemble_cells_cut 12 ms + ~half of assemble_rows_cut's 47 ms at BASELINE config 4).
+// ---------------------------------------------------------------------------
+struct CutSlot
+{
+  int kernel, point_stride;
+  double params[2];
+  const int32_t* offsets;
+  const int32_t* parent_map;
+  int64_t nr;
+  const double* points;
+  const double* weights;
+  const double* point_data;
+  const int32_t* rule_keys;
+  const int32_t* rule_first;
+  unsigned rule_mask;
+};
+struct CutTensorArgs
+{
+  int64_t n;
+  const int32_t* cut_cells;
+  const uint8_t* cellmark;
+  const double* x;
+  const int32_t* conn;
+  int n_slots;
+  CutSlot slot[4];
+  double* out;
+};
+constexpr int kCutLanes2 = 4;
+
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock, 2) cut_tensors_p2_kernel(CutTensorArgs A)
+{
+  constexpr int NV = TDIM + 1, NE = TDIM == 2 ? 3 : 6, ND = NV + NE, NP = ND * (ND + 1) / 2;
+  constexpr int NM = 1 + NV + NV * (NV + 1) / 2, NO = (NP + kCutLanes2 - 1) / kCutLanes2;
+  constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+  constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+  __shared__ double s_T[kBlock / kCutLanes2][NP + 1];
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t k0 = tid / kCutLanes2;
+  const int sub = (int)(tid - k0 * kCutLanes2);
+  const bool live = k0 < A.n;
+  const int64_t k = live ? k0 : A.n - 1;
+  const int ci = threadIdx.x / kCutLanes2;
+  const int64_t c = A.cut_cells[k];
+  const uint8_t mark = live ? A.cellmark[c] : (uint8_t)0;
+  Geo<TDIM> g;
+  load_cell<TDIM>(A.x, A.conn, c, g);
+  jacobian<TDIM>(g);
+  const double h = cell_diameter<TDIM>(g);
+  // The kCutLanes2 lanes of a cell walk ALL points of its rules (the tabulation of N and dn is ~100 flops) and
+  // share the ND (ND + 1) / 2 entries of the symmetric tensor: entry p belongs to lane p mod kCutLanes2.  (One lane
+  // per share of the POINTS with the whole tensor in registers needed 480 VGPRs.)  Every lane keeps the 15 moments.
+  double To[NO], mom[16];
+#pragma unroll
+  for (int p = 0; p < NO; ++p) To[p] = 0.0;
+#pragma unroll
+  for (int p = 0; p < 16; ++p) mom[p] = 0.0;
+  for (int i = 0; i < A.n_slots; ++i)
+  {
+    if (!(mark & (16u << i))) continue;
+    const CutSlot& S = A.slot[i];
+    for (int64_t e = first_rule(S.rule_keys, S.rule_first, S.rule_mask, (int32_t)c); e < S.nr && S.parent_map[e] == c; ++e)
+    {
+      const int32_t q0 = S.offsets[e], q1 = S.offsets[e + 1];
+      for (int32_t q = q0; q < q1; ++q)
+      {
+        double lam[NV];
+        lam[0] = 1.0;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) { lam[t + 1] = S.points[(int64_t)q * TDIM + t]; lam[0] -= lam[t + 1]; }
+        const double w = S.weights[q];
+        if (S.kernel == CFX_K_STIFFNESS)
+        {
+          mom[0] += w;
+          int idx = 1 + NV;
+#pragma unroll
+          for (int a = 0; a < NV; ++a)
+          {
+            const double wa = w * lam[a];
+            mom[1 + a] += wa;
+#pragma unroll
+            for (int b = a; b < NV; ++b) mom[idx++] += wa * lam[b];
+          }
+          continue;
+        }
+        double N[ND], dn[ND];
+#pragma unroll
+        for (int a = 0; a < NV; ++a) N[a] = lam[a] * (2.0 * lam[a] - 1.0);
+#pragma unroll
+        for (int e2 = 0; e2 < NE; ++e2)
+        {
+          const int a = TDIM == 2 ? ea2[e2 % 3] : ea3[e2 % 6], b = TDIM == 2 ? eb2[e2 % 3] : eb3[e2 % 6];
+          N[NV + e2] = 4.0 * lam[a] * lam[b];
+        }
+        double gam = 0.0;
+        if (S.kernel == CFX_K_NITSCHE) // -dn(u) v - dn(v) u + gamma / h u v with the per-point normal
+        {
+          const double* nrm = S.point_data + (int64_t)q * S.point_stride;
+          double al[NV]; // alpha_k = grad(lam_k) . n,  grad(lam_0) = -sum_t K[t][.], grad(lam_{t+1}) = K[t][.]
+          al[0] = 0.0;
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int d = 0; d < TDIM; ++d) v += g.K[t][d] * nrm[d];
+            al[t + 1] = v; al[0] -= v;
+          }
+#pragma unroll
+          for (int a = 0; a < NV; ++a) dn[a] = (4.0 * lam[a] - 1.0) * al[a];
+#pragma unroll
+          for (int e2 = 0; e2 < NE; ++e2)
+          {
+            const int a = TDIM == 2 ? ea2[e2 % 3] : ea3[e2 % 6], b = TDIM == 2 ? eb2[e2 % 3] : eb3[e2 % 6];
+            dn[NV + e2] = 4.0 * (lam[b] * al[a] + lam[a] * al[b]);
+          }
+          gam = S.params[0] / h;
+        }
+        else // CFX_K_MASS: the same accumulation with gamma = 1 and no normal derivatives
+        {
+#pragma unroll
+          for (int a = 0; a < ND; ++a) dn[a] = 0.0;
+          gam = 1.0;
+        }
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < ND; ++a)
+        {
+          const double ga = gam * N[a] - dn[a]; // (gamma N_a - dn_a) N_b - N_a dn_b
+#pragma unroll
+          for (int b = a; b < ND; ++b)
+          {
+            const double v = w * (ga * N[b] - N[a] * dn[b]);
+            To[p / kCutLanes2] += ((p % kCutLanes2) == sub) ? v : 0.0;
+            ++p;
+          }
+        }
+      }
+    }
+  }
+  // the symmetric sums go through LDS: a row picks its entries with a runtime index
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+    if ((p % kCutLanes2) == sub) s_T[ci][p] = To[p / kCutLanes2];
+  __syncthreads();
+  if (!live) return;
+  // rows sub, sub + kCutLanes2, ... per lane: the sums plus the stiffness row from the moments
+  double* out = A.out + k * (int64_t)(ND * ND);
+  for (int i = sub; i < ND; i += kCutLanes2)
+  {
+    double row[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j)
+    {
+      const int a = i < j ? i : j, b = i < j ? j : i;
+      row[j] = s_T[ci][a * ND - a * (a - 1) / 2 + (b - a)];
+    }
+    if (mom[0] != 0.0) p2_stiffness_row_moments<TDIM>(g, i, mom, row);
+    double2* o2 = reinterpret_cast<double2*>(out + i * ND);
+#pragma unroll
+    for (int j = 0; j < ND / 2; ++j) o2[j] = make_double2(row[2 * j], row[2 * j + 1]);
+  }
+}
+
 struct Stage1
 {
   std::vector<DevArray<double>> buffers;
@@ -2858,8 +3064,24 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
 }
 
 // stage 1 + RowArgs for a form
+// the rule integrals of a degree-2 scalar bilinear form that cut_tensors_p2_kernel can sum into one tensor per cut cell
+inline bool p2_cut_tensors_ok(const cfx_form_s* a)
+{
+  const char* e = getenv("CFX_P2_CUT_TENSORS");
+  if (e && e[0] == '0') return false;
+  if (a->rank != 2 || a->V->degree != 2 || a->V->bs != 1) return false;
+  bool any = false;
+  for (const auto& I : a->integrals)
+    if (I.type == CFX_CELL && I.rules && I.rules->nr > 0)
+    {
+      if (!(I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS || I.kernel == CFX_K_NITSCHE) || I.coefficient.n > 0) return false;
+      any = true;
+    }
+  return any;
+}
+
 template <int TDIM, int DEG, int BS = 1>
-RowArgs prepare(cfx_form_s* a, Stage1& st)
+RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND * BS; // local tensor dimension (scalar dofs x block size)
   cfx_row_plan& plan = row_plan(a);
@@ -2915,7 +3137,13 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
       else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p, st.vec_t2);
     }
-    if (I.rules && I.rules->nr > 0)
+    if (I.rules && I.rules->nr > 0 && combine_cuts)
+    {
+      // (the rule lookups stay valid for the kernels that ask for them; nothing is staged per integral)
+      R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
+      R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
+    }
+    else if (I.rules && I.rules->nr > 0)
     {
       R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
@@ -2928,6 +3156,38 @@ RowArgs prepare(cfx_form_s* a, Stage1& st)
       if (moments) dump_cut_moments(a, ii, st.buffers.back().p);
       else if (a->rank == 2) dump_integral(a, ii, 2, st.buffers.back().p);
       else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, true, st.buffers.back().p);
+    }
+  }
+  if constexpr (DEG == 2 && BS == 1)
+  {
+    if (combine_cuts)
+    {
+      plan_cut_cells(a);
+      if (plan.n_cut_cells > 0)
+      {
+        CutTensorArgs C{};
+        C.n = plan.n_cut_cells; C.cut_cells = plan.cut_cells.p; C.cellmark = plan.cellmark.p;
+        C.x = A.x; C.conn = A.conn; C.n_slots = plan.n_cell_slots;
+        for (int s = 0; s < plan.n_cell_slots; ++s)
+        {
+          const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[s]];
+          CutSlot& S = C.slot[s];
+          S.kernel = I.kernel; S.point_stride = I.point_stride; S.params[0] = I.params[0]; S.params[1] = I.params[1];
+          if (I.rules && I.rules->nr > 0)
+          {
+            S.offsets = I.rules->offsets.p; S.parent_map = I.rules->parent_map.p; S.nr = I.rules->nr;
+            S.points = I.rules->points.p; S.weights = I.rules->weights.p;
+            S.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
+            S.rule_keys = plan.rule_keys[s].p; S.rule_first = plan.rule_first[s].p; S.rule_mask = plan.rule_mask[s];
+          }
+        }
+        st.buffers.emplace_back(plan.n_cut_cells * (int64_t)(ND * ND));
+        C.out = st.buffers.back().p;
+        launch("cut_tensors_p2", cut_tensors_p2_kernel<TDIM>, grid_for(C.n * kCutLanes2), dim3(kBlock), 0, C);
+        A.cut_tensors = C.out;
+        A.cut_bits = reinterpret_cast<const unsigned long long*>(plan.cut_bits.p);
+        A.cut_rank = plan.cut_rank.p;
+      }
     }
   }
   bool has_facets = false;
@@ -2990,7 +3250,18 @@ template <int TDIM, int DEG>
 int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {
   Stage1 st;
-  RowArgs A = prepare<TDIM, DEG>(a, st);
+  // degree 2: the split path (below) takes the cut cells' contributions as one tensor per cut cell
+  bool combine_cuts = false;
+  if constexpr (DEG == 2)
+  {
+    cfx_row_plan& plan0 = row_plan(a);
+    const char* fs0 = getenv("CFX_ROWS_SPLIT");
+    const int mr0 = P->max_row_len;
+    combine_cuts = P->split_plan == plan0.serial && mr0 > 64 && mr0 <= 256
+                   && (plan0.n_special_rows * 2 <= plan0.n_active_rows || (fs0 && fs0[0] == '1')) && plan0.n_special_rows > 0
+                   && p2_cut_tensors_ok(a);
+  }
+  RowArgs A = prepare<TDIM, DEG>(a, st, combine_cuts);
   A.fresh = fresh ? 1 : 0;
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
   ZeroFlag err;
@@ -3134,7 +3405,16 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     }
     if constexpr (DEG > 1)
     {
-      fill_all();
+      // one pass over the interface rows (uncut + cut-cell + facet items in one kernel, rows stored) when the cut
+      // cells come as combined tensors and the pattern kept the other hashed rows apart: then every active row has
+      // exactly one writer and only the inactive rows are zeroed
+      const bool one_pass = combine_cuts && A.cut_tensors != nullptr && P->odd_plan == plan.serial && P->full_plan == plan.serial;
+      const char* lz = getenv("CFX_LAZY_ZERO");
+      lazy_zero = fresh && one_pass && !(lz && lz[0] == '0');
+      if (!lazy_zero) fill_all();
+      else
+        launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, 1, plan.rowmark.p,
+               P->indptr.p, values);
       // degree 2: (a) the uncut items of every row with the lean kernel, short rows (<= 64 columns:
       // the edge dofs, ~5 cells each) 8 lanes per row, long rows 16; (b) rule + facet items of the
       // interface rows with the full kernel.  Needs the row partition made with the pattern.
@@ -3147,7 +3427,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   do                                                                                                                 \
   {                                                                                                                  \
     RowArgs Q = A;                                                                                                   \
-    Q.mark_mask = 0x0Fu; Q.active_rows = (ROWS); Q.n_active = (NROWS);                                               \
+    Q.mark_mask = 0x0Fu; Q.active_rows = (ROWS); Q.n_active = (NROWS); Q.fresh = lazy_zero ? 2 : Q.fresh;           \
     const dim3 grid = row_grid((Q.n_active + (kWave / GG) - 1) / (kWave / GG));                                      \
     if (Q.n_active > 0)                                                                                              \
     {                                                                                                                \
@@ -3155,8 +3435,13 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       else launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, Q);     \
     }                                                                                                                \
   } while (0)
-        CFX_LEAN(8, 64, P->short_rows.p, P->n_short_rows);
-        CFX_LEAN(16, 256, P->long_rows.p, P->n_long_rows);
+        if (one_pass)
+          CFX_LEAN(16, 256, P->odd_rows.p, P->n_odd_rows);
+        else
+        {
+          CFX_LEAN(8, 64, P->short_rows.p, P->n_short_rows);
+          CFX_LEAN(16, 256, P->long_rows.p, P->n_long_rows);
+        }
         if (P->full_plan == plan.serial && P->n_full_rows > 0)
         {
           // the rows that copied their static list (not in the two lists above)
@@ -3181,7 +3466,18 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         if (S.n_active > 0)
         {
           const dim3 grid = row_grid((S.n_active + 3) / 4);
-          if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, false>, grid, dim3(kWave), 0, S);
+          if (one_pass)
+          {
+            S.mark_mask = 0xFFu; S.fresh = lazy_zero ? 2 : S.fresh;
+            if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, true, true>, grid, dim3(kWave), 0, S);
+            else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, false, true, true, true>, grid, dim3(kWave), 0, S);
+          }
+          else if (combine_cuts && S.cut_tensors)
+          {
+            if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, false, true>, grid, dim3(kWave), 0, S);
+            else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, false, true, false, true>, grid, dim3(kWave), 0, S);
+          }
+          else if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, false>, grid, dim3(kWave), 0, S);
           else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, false, true, false>, grid, dim3(kWave), 0, S);
         }
       }

@@ -1645,6 +1645,28 @@ void plain_row_masks(cfx_form_s* a)
   publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
 }
 
+struct ByteRuleMark
+{
+  __device__ bool operator()(uint8_t v) const { return (v & 0xF0u) != 0; }
+};
+
+void plan_cut_cells(cfx_form_s* a)
+{
+  cfx_row_plan& plan = row_plan(a);
+  if (plan.cut_cells_built) return;
+  plan.cut_cells_built = true;
+  const int64_t nc = a->V->mesh->ncells;
+  plan.n_cut_cells = compact_bytes("plan_cut_cells", nc, plan.cellmark.p, ByteRuleMark{}, plan.cut_cells);
+  const int64_t nwords = (nc + 63) / 64;
+  plan.cut_bits.alloc(nwords);
+  plan.cut_rank.alloc(nwords + 1);
+  DevArray<int32_t> pop(nwords);
+  launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, plan.cellmark.p, (uint8_t)0xF0u,
+         reinterpret_cast<unsigned long long*>(plan.cut_bits.p), pop.p, (int32_t*)nullptr);
+  exclusive_scan(pop.p, plan.cut_rank.p, nwords);
+  publish_across_lanes();
+}
+
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:
 // rows at the edge of a restricted entity list, e.g. a rank's owned cells, keep the per-cell records)
 __global__ void vec_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
@@ -1935,6 +1957,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
   P->split_plan = 0;
   P->full_plan = 0;
+  P->odd_plan = 0;
   if (any_full && V->degree == 2 && V->bs > 1 && a->rank == 2)
   {
     // vector-valued degree 2 with slot records and one uncut cell integral: the copied rows (dofs) take
@@ -2000,6 +2023,13 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
         P->full_plan = plan.serial;
         base_rows = rows_h;
         n_base = n_h;
+        // rows_h = [interface rows | plain rows without a copied list]: the second part on its own
+        P->n_odd_rows = n_h - plan.n_special_rows;
+        P->odd_rows.alloc(P->n_odd_rows);
+        if (P->n_odd_rows > 0)
+          CFX_HIP(hipMemcpyAsync(P->odd_rows.p, rows_h + plan.n_special_rows, sizeof(int32_t) * (size_t)P->n_odd_rows,
+                                 hipMemcpyDeviceToDevice, ctx().stream));
+        P->odd_plan = plan.serial;
       }
     }
     P->n_short_rows = compact("pattern_short_rows", n_base, RowLenTest{base_rows, P->indptr.p, 64, false}, P->short_rows);

@@ -53,11 +53,12 @@ B_VECTOR_PER_ROW_CELL = 16.0    # element-vector entry written once + read once 
 B_DEACTIVATE_PER_ROW = 16.0     # diagonal write + rhs write per inactive row (a11)
 FP64_VALU_PEAK_TFLOPS = 78.6    # MI355X FP64 vector = FP32 vector (157.3 TF, MI355X_MICROARCH.md) / 2; FP64 MFMA: the same rate
 # flops of the source-term stage 1 per uncut cell: per point 3 x (5 offset + 2 x 5 series) + 3 products
-# + 8 basis updates = 56, 14 points, + ~250 per cell (edges, determinant, 3 sincospi, 18 coefficients)
-FLOP_SOURCE_PER_CELL = 14 * 56 + 250
+# + 8 basis updates = 56, 11 points, + ~250 per cell (edges, determinant, 3 sincospi, 18 coefficients)
+FLOP_SOURCE_PER_CELL = 11 * 56 + 250
 # reference-equivalent quadrature size: Basix 0.11's default simplex scheme (Xiao-Gimbutas) has 11 points at degree 4
-# on a tetrahedron where this engine's positive symmetric rule has 14; 6 = 6 on triangles
-NQ_REF_PER_ENGINE_VOLUME, NQ_REF_PER_ENGINE_INTERFACE = 11.0 / 14.0, 1.0
+# on a tetrahedron and so has this engine's rule since round 3 (tools/gen_quadrature_tables.py: 11 positive interior
+# points, symmetric about one vertex; rounds 1-2 used a 14-point rule); 6 = 6 on triangles
+NQ_REF_PER_ENGINE_VOLUME, NQ_REF_PER_ENGINE_INTERFACE = 1.0, 1.0
 
 
 def parse():
@@ -399,7 +400,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         roofline_longest = dict(kernel=longest, bound="fp64-valu", achieved=ach, peak=FP64_VALU_PEAK_TFLOPS, unit="TFLOP/s",
                                 frac=ach / FP64_VALU_PEAK_TFLOPS, avg_launch_us=kernels[longest]["avg_us"],
                                 algorithmic_flops_per_launch=fl,
-                                note="source term f v on the uncut cells: 14 points x (3 offsets + 3 short sine series) per "
+                                note="source term f v on the uncut cells: 11 points x (3 offsets + 3 short sine series) per "
                                      "tet; 4 scattered 8 B stores per cell on top (DESIGN.md 3)")
     elif longest is not None and longest in roof:
         roofline_longest = dict(kernel=longest, bound="hbm", achieved=roof[longest]["achieved_GBs"], peak=HBM_PEAK_GBS,
@@ -436,8 +437,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
                    points_per_s=(nq_ref * (nq_total / max(info["nq_volume"] + info["nq_interface"], 1))
                                  / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
                                  if "cut" in phases_ms else None),
-                   note="the engine's degree-4 tetrahedron rule has 14 points, Basix's (the reference's) 11: the same cut "
-                        "cells would carry 11/14 of the volume points there; interface triangles 6 = 6"),
+                   note="the engine's degree-4 tetrahedron rule has 11 points, as Basix's (the reference's): the point "
+                        "counts are the reference's (the points themselves are not: parity unpinned below integral level)"),
                cut_quadrature_points_per_s=(nq_total / (1e-3 * (phases_ms["cut"] + phases_ms["rules+facets+forms"]))
                                             if "cut" in phases_ms else None),
                assemble_matrix_dofs_per_s=(active_total / (1e-3 * phases_ms["assemble_matrix"])

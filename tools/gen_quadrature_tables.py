@@ -8,7 +8,11 @@ fully symmetric, positive-weight, interior rules from their moment equations
 instead of copying a table:
 
   1. pick an orbit structure (centroid / S21 / S111 for triangles,
-     S4 / S31 / S22 / S211 for tetrahedra),
+     S4 / S31 / S22 / S211 for tetrahedra; degree 4 on tetrahedra: no positive rule with 11 points -- the size of the
+     reference's Basix / Xiao-Gimbutas rule -- has the full symmetry (the only fully symmetric structure with 11
+     points, S4 + S31 + S22, has a negative weight: Keast's rule), so that rule keeps the symmetry about ONE vertex
+     only: orbits A1 / A3 of the permutations of barycentric coordinates 1..3, a two-parameter family of positive
+     interior 11-point rules, pinned by fixing the two axis points),
   2. solve "all monomials of degree <= d are integrated exactly" with
      scipy.least_squares from many random starts (double precision),
   3. polish the solution with mpmath Newton at 40 digits,
@@ -74,6 +78,15 @@ def orbit_points(tdim: int, kind: str, params):
             a, b = params
             base = (a, a, b, 1 - 2 * a - b)
             return sorted(set(itertools.permutations(base)), key=_key)
+        # symmetry about vertex 0 only (permutations of barycentric coordinates 1, 2, 3)
+        if kind == "A1":      # on the axis through vertex 0 and the centroid of the opposite facet
+            a = params[0]
+            r = (1 - a) / 3
+            return [(a, r, r, r)]
+        if kind == "A3":      # (a; b, b, c): three points
+            a, b = params
+            c = 1 - a - 2 * b
+            return [(a, b, b, c), (a, b, c, b), (a, c, b, b)]
     raise ValueError(kind)
 
 
@@ -84,8 +97,8 @@ def _key(t):
     return tuple(float(v) for v in t)
 
 
-NPARAM = {"S3": 0, "S21": 1, "S111": 2, "S4": 0, "S31": 1, "S22": 1, "S211": 2}
-NPTS = {"S3": 1, "S21": 3, "S111": 6, "S4": 1, "S31": 4, "S22": 6, "S211": 12}
+NPARAM = {"S3": 0, "S21": 1, "S111": 2, "S4": 0, "S31": 1, "S22": 1, "S211": 2, "A1": 1, "A3": 2}
+NPTS = {"S3": 1, "S21": 3, "S111": 6, "S4": 1, "S31": 4, "S22": 6, "S211": 12, "A1": 1, "A3": 3}
 
 
 def unpack(tdim, orbits, z):
@@ -266,6 +279,95 @@ def polish(tdim, orbits, degree, z):
 
 
 # ---------------------------------------------------------------------------
+# rules symmetric about one vertex (orbits A1 / A3): the axis parameters are fixed, the rest is solved
+# ---------------------------------------------------------------------------
+AXIS_RULES = {
+    # (tdim, degree): (orbits, {index of z: fixed value}) -- z = [w, params...] per orbit as in unpack()
+    (3, 4): (["A1", "A1", "A3", "A3", "A3"], {1: 0.06, 3: 0.75}),
+}
+
+
+def solve_axis(tdim, degree, seed=0, tries=400):
+    orbits, fixed = AXIS_RULES[(tdim, degree)]
+    nz = sum(1 + NPARAM[k] for k in orbits)
+    free = [i for i in range(nz) if i not in fixed]
+
+    def full(y, cast=float):
+        z = [None] * nz
+        for i, v in fixed.items():
+            z[i] = cast(v)
+        for i, v in zip(free, y):
+            z[i] = v
+        return z
+    mons = monomials(tdim, degree)
+    exact = np.array([float(exact_moment(e)) for e in mons])
+    E = np.array(mons)
+
+    def fres(y):
+        pts, wts = unpack(tdim, orbits, full(list(y)))
+        P = np.array([[float(v) for v in b[1:]] for b in pts])
+        W = np.array([float(w) for w in wts])
+        M = np.prod(P[:, None, :] ** E[None, :, :], axis=2)
+        return (W @ M - exact) / np.maximum(exact, 1e-3)
+    rng = np.random.default_rng(seed)
+    vol = 1.0 / math.factorial(tdim)
+    npts = sum(NPTS[k] for k in orbits)
+    best = None
+    found = 0
+    for _ in range(tries):
+        z0 = []
+        for kind in orbits:
+            z0.append(vol / npts * rng.uniform(0.3, 2.0))
+            if kind == "A1":
+                z0.append(rng.uniform(0.02, 0.9))
+            else:
+                a = rng.uniform(0.02, 0.8)
+                z0 += [a, rng.uniform(0.02, (1 - a) / 2 * 0.95)]
+        y0 = np.array([z0[i] for i in free])
+        try:
+            sol = least_squares(fres, y0, xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=300)
+        except Exception:
+            continue
+        if np.max(np.abs(sol.fun)) > 1e-12:
+            continue
+        pts, wts = unpack(tdim, orbits, full(list(sol.x)))
+        if min(wts) <= 1e-3 * vol / npts or min(min(b) for b in pts) <= 0.02:
+            continue
+        score = min(min(wts) * npts / vol, 10 * min(min(b) for b in pts))
+        found += 1
+        if best is None or score > best[0]:
+            best = (score, sol.x.copy())
+        if found >= 6:
+            break
+    if best is None:
+        return None
+    # Newton on the free unknowns at 40 digits (the moment equations are redundant: normal equations)
+    y = mp.matrix([mp.mpf(float(v)) for v in best[1]])
+    n = len(y)
+    for _ in range(30):
+        r = mp.matrix(residual(tdim, orbits, degree, full(list(y), mp.mpf), use_mp=True))
+        if max(abs(v) for v in r) < mp.mpf(10) ** (-36):
+            break
+        m = len(r)
+        J = mp.zeros(m, n)
+        hstep = mp.mpf(10) ** (-20)
+        for j in range(n):
+            yp, ym = y.copy(), y.copy()
+            yp[j] += hstep
+            ym[j] -= hstep
+            rp = mp.matrix(residual(tdim, orbits, degree, full(list(yp), mp.mpf), use_mp=True))
+            rm = mp.matrix(residual(tdim, orbits, degree, full(list(ym), mp.mpf), use_mp=True))
+            for i in range(m):
+                J[i, j] = (rp[i] - rm[i]) / (2 * hstep)
+        y = y + mp.lu_solve(J.T * J, -(J.T * r))
+    r = residual(tdim, orbits, degree, full(list(y), mp.mpf), use_mp=True)
+    if max(abs(v) for v in r) > mp.mpf(10) ** (-30):
+        return None
+    pts, wts = unpack(tdim, orbits, full(list(y), mp.mpf))
+    return ([[float(v) for v in b[1:]] for b in pts], [float(w) for w in wts])
+
+
+# ---------------------------------------------------------------------------
 # Gauss-Jacobi conical product (fallback, any degree)
 # ---------------------------------------------------------------------------
 def gauss_jacobi_01(n, alpha):
@@ -374,7 +476,11 @@ def build():
                 raw[(tdim, d)] = (cache[key]["points"], cache[key]["weights"])
                 continue
             rule = None
-            if tdim > 1 and (tdim, d) in SYMMETRIC:
+            if (tdim, d) in AXIS_RULES:
+                rule = solve_axis(tdim, d, seed=100 * tdim + d)
+                if rule is None:
+                    print(f"  tdim={tdim} degree={d}: axis-symmetric solve failed", file=sys.stderr)
+            if rule is None and tdim > 1 and (tdim, d) in SYMMETRIC:
                 rule = solve_symmetric(tdim, SYMMETRIC[(tdim, d)], d, seed=100 * tdim + d)
                 if rule is None:
                     print(f"  tdim={tdim} degree={d}: symmetric solve failed -> conical",

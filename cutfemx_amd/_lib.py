@@ -24,6 +24,7 @@ K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
 K_JUMP = 9
 K_SIP = 10
+K_DIV_TEST, K_DIV_TRIAL = 20, 21
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
@@ -74,7 +75,7 @@ HOST_EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32
 
 class PatternView(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("nnz", C.c_int64), ("indptr", C.c_void_p),
-                ("indices", C.c_void_p)]
+                ("indices", C.c_void_p), ("ncols", C.c_int64)]
 
 
 # every symbol declared in include/cutfemx_amd.h
@@ -90,7 +91,7 @@ SYMBOLS = [
     "cfx_rules_physical_points", "cfx_rules_destroy", "cfx_evaluate_normals",
     "cfx_evaluate_values", "cfx_ghost_penalty_facets", "cfx_interior_facets_for_cells", "cfx_cell_aggregation_create", "cfx_cell_aggregation_view_get",
     "cfx_cell_aggregation_destroy", "cfx_cut_destroy", "cfx_space_create",
-    "cfx_space_static_bytes", "cfx_space_destroy", "cfx_form_create", "cfx_form_destroy", "cfx_form_prepare", "cfx_create_sparsity",
+    "cfx_space_static_bytes", "cfx_space_destroy", "cfx_form_create", "cfx_form_create2", "cfx_form_destroy", "cfx_form_prepare", "cfx_create_sparsity",
     "cfx_pattern_view_get", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_matrix_zeroed", "cfx_assemble_vector",
     "cfx_apply_lifting", "cfx_set_bc", "cfx_zero_rows", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
     "cfx_active_destroy",

@@ -54,6 +54,20 @@ extern thread_local std::string g_last_error;
     return CFX_ERR_RUNTIME;                                           \
   }
 
+// closes a CFX_API_BEGIN block whose success path continues below it (argument checks ahead of a delegated call)
+#define CFX_API_END_NO_RETURN                                         \
+  }                                                                   \
+  catch (const ::cfx::Error& e)                                       \
+  {                                                                   \
+    ::cfx::g_last_error = e.what();                                   \
+    return e.code;                                                    \
+  }                                                                   \
+  catch (const std::exception& e)                                     \
+  {                                                                   \
+    ::cfx::g_last_error = e.what();                                   \
+    return CFX_ERR_RUNTIME;                                           \
+  }
+
 inline void require(bool ok, int code, const char* msg)
 {
   if (!ok) throw Error(code, msg);
@@ -525,7 +539,9 @@ struct cfx_row_plan
 
 struct cfx_form_s
 {
-  cfx_space_t V = nullptr;
+  cfx_space_t V = nullptr;  // test space (the space of a linear form)
+  cfx_space_t V1 = nullptr; // trial space: V for square forms, another space for cfx_form_create2 forms
+  bool rectangular() const { return V1 != nullptr && V1 != V; }
   int rank = 2;
   std::vector<cfx_integral_dev> integrals;
   std::shared_ptr<cfx_row_plan> plan; // built lazily, possibly shared with another live form
@@ -542,6 +558,7 @@ void plan_cut_cells(cfx_form_s* a);                                     // cfx_r
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
+void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P);        // cfx_rowasm.hip
 void prepare_form_tables(cfx_form_s* a);                                // cfx_gather.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values,
                           bool fresh = false);
@@ -551,6 +568,7 @@ bool assemble_vector_rows(cfx_form_s* L, double* b);
 struct cfx_pattern_s
 {
   int64_t nrows = 0, nnz = 0;
+  int64_t ncols = 0; // = nrows unless the form is rectangular
   int max_row_len = 0; // upper bound on the scalar-dof row length
   uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)
   // long-row spaces: the plan's active rows split by row length (<= 64 columns / longer)

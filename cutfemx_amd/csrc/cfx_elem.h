@@ -762,7 +762,8 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
     double N0[ND], dN0[ND][TDIM], N1[ND], dN1[ND][TDIM];
     tabulate<TDIM, DEG>(X0, N0, dN0);
     tabulate<TDIM, DEG>(X1, N1, dN1);
-    const double w = wref[q] * scale * params[0] * havg;
+    // gamma h_avg^(1 + params[1]) (GHOST_GRADJUMP; the other kernels of this function read params[0] alone)
+    const double w = wref[q] * scale * params[0] * havg * ((KC == 0 && params[1] != 0.0) ? pow(havg, params[1]) : 1.0);
     // normal-derivative jump of every macro basis function
     double jn[2 * ND];
 #pragma unroll

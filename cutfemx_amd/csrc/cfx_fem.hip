@@ -816,6 +816,227 @@ void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Cell integrals of a form whose test and trial spaces differ (cfx_form_create2; assemble_matrix_impl.h:68-189 with
+// dofmap0 / bs0 != dofmap1 / bs1).  One thread per (entity, test row): row (ia, ik) of the [(nd0 bs0) x (nd1 bs1)]
+// element tensor in registers (acc[j][b], fixed strides: the sizes are run-time values here -- one kernel serves
+// every pair of Lagrange spaces instead of one instantiation per pair), scattered into its CSR row with one search
+// per trial dof and FP64 atomics, or contracted with the Dirichlet data (lifting), or dumped (tabulate_entity).
+// ---------------------------------------------------------------------------
+struct RectArgs
+{
+  const int32_t* dofmap1;
+  int deg0, bs0, nd0, deg1, bs1, nd1;
+};
+
+template <int TDIM, bool RUNTIME>
+__global__ void __launch_bounds__(kBlock) assemble_cells2_kernel(AsmArgs A, RectArgs R)
+{
+  constexpr int MAXND = TDIM == 2 ? 6 : 10, MAXBS = TDIM;
+  const int nloc0 = R.nd0 * R.bs0, nloc1 = R.nd1 * R.bs1;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = tid / nloc0;
+  if (e >= A.n) return;
+  const int I0 = (int)(tid - e * nloc0);
+  const int ia = I0 / R.bs0, ik = I0 - ia * R.bs0;
+  const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
+  const int32_t* d1 = R.dofmap1 + cell * R.nd1;
+  if (A.lift_markers)
+  {
+    bool any = false;
+    for (int j = 0; j < R.nd1; ++j)
+      for (int b = 0; b < R.bs1; ++b) any = any || A.lift_markers[R.bs1 * d1[j] + b] != 0;
+    if (!any) return;
+  }
+  Geo<TDIM> g;
+  load_cell<TDIM>(A.x, A.conn, cell, g);
+  jacobian<TDIM>(g);
+  int npts;
+  const double* pts;
+  const double* wts;
+  double wscale = 1.0;
+  if constexpr (RUNTIME)
+  {
+    const int32_t q0 = A.offsets[e], q1 = A.offsets[e + 1];
+    npts = q1 - q0;
+    pts = A.points + (int64_t)q0 * TDIM;
+    wts = A.weights + q0;
+  }
+  else
+  {
+    pts = ref_rule(TDIM, A.qdegree, npts, wts);
+    wscale = fabs(g.detJ);
+  }
+  double acc[MAXND][MAXBS];
+#pragma unroll
+  for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+    for (int b = 0; b < MAXBS; ++b) acc[j][b] = 0.0;
+  const double scale = A.params[0];
+  for (int q = 0; q < npts; ++q)
+  {
+    double X[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
+    const double w = wts[q] * wscale;
+    double N[MAXND], dN[MAXND][TDIM];
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+    {
+      N[j] = 0.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) dN[j][t] = 0.0;
+    }
+    // the row's basis function of the test element: value and physical gradient
+    if (R.deg0 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
+    double Ni = 0.0, Gi[TDIM];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) Gi[d] = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+      if (j == ia)
+      {
+        Ni = N[j];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
+          Gi[d] = v;
+        }
+      }
+    double Gia = 0.0; // component ik of the row gradient (DIV_TEST)
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) Gia = (d == ik) ? Gi[d] : Gia;
+    // the trial element
+    if (R.deg1 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+    {
+      if (j >= R.nd1) continue;
+      double Gj[TDIM];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
+        Gj[d] = v;
+      }
+      switch (A.kernel)
+      {
+      case CFX_K_MASS:
+#pragma unroll
+        for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * Ni * N[j] : 0.0;
+        break;
+      case CFX_K_STIFFNESS:
+      {
+        double sgg = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d) sgg += Gi[d] * Gj[d];
+#pragma unroll
+        for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * sgg : 0.0;
+        break;
+      }
+      case CFX_K_DIV_TEST: // v = N0_i e_ik, p = N1_j
+        acc[j][0] += w * scale * Gia * N[j];
+        break;
+      case CFX_K_DIV_TRIAL: // q = N0_i, u = N1_j e_b
+#pragma unroll
+        for (int b = 0; b < MAXBS; ++b) acc[j][b] += w * scale * Ni * Gj[b];
+        break;
+      default: break;
+      }
+    }
+  }
+  if (A.dump)
+  {
+    double* out = A.dump + (e * nloc0 + I0) * (int64_t)nloc1;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+      for (int b = 0; b < MAXBS; ++b)
+        if (j < R.nd1 && b < R.bs1) out[j * R.bs1 + b] = acc[j][b];
+    return;
+  }
+  const int32_t row = R.bs0 * A.dofmap[cell * R.nd0 + ia] + ik;
+  if (A.lift_markers)
+  {
+    double sum = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+      for (int b = 0; b < MAXBS; ++b)
+        if (j < R.nd1 && b < R.bs1)
+        {
+          const int32_t col = R.bs1 * d1[j] + b;
+          if (A.lift_markers[col])
+          {
+            sum += acc[j][b] * A.lift_alpha * (A.lift_values[col] - (A.lift_x0 ? A.lift_x0[col] : 0.0));
+            any = true;
+          }
+        }
+    if (any) atomicAdd(A.values + row, -sum);
+    return;
+  }
+  const bool row_bc = A.bc0 && A.bc0[row];
+  const int64_t rb = A.indptr[row], re = A.indptr[row + 1];
+#pragma unroll
+  for (int j = 0; j < MAXND; ++j)
+  {
+    if (j >= R.nd1) continue;
+    const int32_t col0 = R.bs1 * d1[j];
+    const int64_t pos = csr_find(A.indices, rb, re, col0);
+    if (pos < 0) { *A.error = 1; continue; }
+#pragma unroll
+    for (int b = 0; b < MAXBS; ++b)
+      if (b < R.bs1)
+      {
+        double v = acc[j][b];
+        if (row_bc || (A.bc1 && A.bc1[col0 + b])) v = 0.0;
+        atomicAdd(A.values + pos + b, v);
+      }
+  }
+}
+
+// every integral of a rectangular form, or one entity of one of them (only_index >= 0)
+void launch_rectangular(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index = -1, int use_rule = 0)
+{
+  const cfx_space_s* V0 = a->V;
+  const cfx_space_s* V1 = a->V1;
+  RectArgs R{V1->dofmap.p, V0->degree, V0->bs, V0->ndofs_cell, V1->degree, V1->bs, V1->ndofs_cell};
+  A.kernel = I.kernel; A.qdegree = I.qdegree;
+  for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
+  const bool single = only_index >= 0;
+  const int nloc0 = R.nd0 * R.bs0;
+  const int tdim = V0->mesh->tdim;
+  if (!single || !use_rule)
+  {
+    A.n = single ? 1 : I.n_entities;
+    A.entities = I.entities.p + (single ? only_index : 0);
+    if (A.n > 0)
+    {
+      if (tdim == 2) launch("assemble_cells2_std", assemble_cells2_kernel<2, false>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+      else launch("assemble_cells2_std", assemble_cells2_kernel<3, false>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+    }
+  }
+  if (I.rules && (!single || use_rule))
+  {
+    const cfx_rules_s* Q = I.rules;
+    A.n = single ? 1 : Q->nr;
+    A.offsets = Q->offsets.p + (single ? only_index : 0);
+    A.parent_map = Q->parent_map.p + (single ? only_index : 0);
+    A.points = Q->points.p; A.weights = Q->weights.p;
+    if (A.n > 0)
+    {
+      if (tdim == 2) launch("assemble_cells2_cut", assemble_cells2_kernel<2, true>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+      else launch("assemble_cells2_cut", assemble_cells2_kernel<3, true>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+    }
+  }
+}
+
 __global__ void mark_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride, uint8_t* mark)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -965,8 +1186,8 @@ namespace
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const int32_t* __restrict__ rows,
                                                                const double* __restrict__ x, const int32_t* __restrict__ conn,
-                                                               const int32_t* __restrict__ dofmap, double gamma, int qdegree,
-                                                               double* __restrict__ out, int* error)
+                                                               const int32_t* __restrict__ dofmap, double gamma, double hpow,
+                                                               int qdegree, double* __restrict__ out, int* error)
 {
   constexpr int ND = TDIM + 1;
   const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1072,7 +1293,7 @@ __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const 
   for (int k = 0; k < 6; ++k) rec[k] = 0.0;
 #pragma unroll
   for (int k = 0; k <= ND; ++k) rec[k] = jf[k];
-  rec[ND + 1] = wsum * scale * gamma * havg;
+  rec[ND + 1] = wsum * scale * gamma * havg * (hpow != 0.0 ? pow(havg, hpow) : 1.0);
   int32_t cm[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) cm[k] = -1;
@@ -1103,8 +1324,8 @@ __global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const 
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int nq, const int32_t* __restrict__ rows,
                                                                 const double* __restrict__ x, const int32_t* __restrict__ conn,
-                                                                const int32_t* __restrict__ dofmap, double gamma, int qdegree,
-                                                                double* __restrict__ out)
+                                                                const int32_t* __restrict__ dofmap, double gamma, double hpow,
+                                                                int qdegree, double* __restrict__ out)
 {
   constexpr int ND = Elem<TDIM, 2>::ND, WF = Elem<TDIM, 2>::WF, NX = WF - ND;
   static_assert(WF + 1 <= 16 && WF <= 15, "record of 16 doubles, 16 column ids");
@@ -1241,7 +1462,7 @@ __global__ void __launch_bounds__(kBlock) facet_jumps_p2_kernel(int64_t n, int n
   for (int k = 0; k < 16; ++k) rec[k] = 0.0;
 #pragma unroll
   for (int k = 0; k < WF; ++k) rec[k] = jf[k];
-  rec[WF] = wref[q] * scale * gamma * havg;
+  rec[WF] = wref[q] * scale * gamma * havg * (hpow != 0.0 ? pow(havg, hpow) : 1.0);
   // facet block: 16 int32 (the WF macro columns, -1 padding, entry 15 = number of cell 1's dofs cell 0 lacks),
   // then nq records of 16 doubles
   double* blk = out + f * (int64_t)(8 + 16 * nq);
@@ -1335,10 +1556,10 @@ void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
   if (I.n_entities == 0) return;
   if (V->mesh->tdim == 2)
     launch("assemble_facets", facet_jump_p1_kernel<2>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
-           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
+           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out, error);
   else
     launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
-           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out, error);
+           V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out, error);
 }
 // stage 1 of a degree-2 stiffness integral over runtime rules: 16 doubles per rule (cut_moments_kernel)
 void dump_cut_moments(cfx_form_s* a, int integral, double* out)
@@ -1361,10 +1582,10 @@ void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out)
   if (I.n_entities == 0) return;
   if (V->mesh->tdim == 2)
     launch("assemble_facets", facet_jumps_p2_kernel<2>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
-           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out);
+           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out);
   else
     launch("assemble_facets", facet_jumps_p2_kernel<3>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
-           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.qdegree, out);
+           I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out);
 }
 } // namespace cfx
 
@@ -1409,14 +1630,33 @@ int cfx_space_destroy(cfx_space_t V)
   CFX_API_END
 }
 
+static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integrals, const cfx_integral* integrals,
+                            cfx_form_t* out);
+
 int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral* integrals, cfx_form_t* out)
+{
+  return form_create_impl(V, V, rank, n_integrals, integrals, out);
+}
+
+int cfx_form_create2(cfx_space_t V_test, cfx_space_t V_trial, int n_integrals, const cfx_integral* integrals, cfx_form_t* out)
+{
+  CFX_API_BEGIN
+  require(V_test && V_trial, CFX_ERR_INVALID_ARGUMENT, "cfx_form_create2: null argument");
+  require(V_test->mesh == V_trial->mesh, CFX_ERR_INVALID_ARGUMENT, "cfx_form_create2: the two spaces live on different meshes");
+  CFX_API_END_NO_RETURN
+  return form_create_impl(V_test, V_trial, 2, n_integrals, integrals, out);
+}
+
+static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integrals, const cfx_integral* integrals,
+                            cfx_form_t* out)
 {
   CFX_API_BEGIN
   ctx().ensure();
   require(V && out && (integrals || n_integrals == 0), CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: null argument");
   require(rank == 1 || rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: rank must be 1 or 2");
   auto a = std::make_unique<cfx_form_s>();
-  a->V = V; a->rank = rank;
+  a->V = V; a->V1 = V1; a->rank = rank;
+  const bool rect = V1 != V;
   for (int i = 0; i < n_integrals; ++i)
   {
     const cfx_integral& in = integrals[i];
@@ -1447,8 +1687,26 @@ int cfx_form_create(cfx_space_t V, int rank, int n_integrals, const cfx_integral
                   "cfx_facet_rules_to_cells)");
     else
       require(in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS || in.kernel == CFX_K_NITSCHE
-                  || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS,
-              CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: unknown cell kernel id");
+                  || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS
+                  || (rect && (in.kernel == CFX_K_DIV_TEST || in.kernel == CFX_K_DIV_TRIAL)),
+              CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: unknown cell kernel id (the divergence blocks need different test and trial spaces: "
+              "cfx_form_create2)");
+    if (rect)
+    {
+      // test space != trial space: cell integrals of the kernels assemble_cells2_kernel knows, shapes that match
+      require(in.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "cfx_form_create2: cell integrals only");
+      require(in.coefficient == nullptr && in.point_data == nullptr, CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create2: coefficients / per-point data are not supported on rectangular blocks");
+      const int gd = V->mesh->gdim;
+      if (in.kernel == CFX_K_DIV_TEST)
+        require(V->bs == gd && V1->bs == 1, CFX_ERR_INVALID_ARGUMENT, "div(v) p: vector test space, scalar trial space");
+      else if (in.kernel == CFX_K_DIV_TRIAL)
+        require(V->bs == 1 && V1->bs == gd, CFX_ERR_INVALID_ARGUMENT, "q div(u): scalar test space, vector trial space");
+      else
+        require((in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS) && V->bs == V1->bs, CFX_ERR_INVALID_ARGUMENT,
+                "cfx_form_create2: mass / stiffness blocks need equal block sizes; other kernels are square-only");
+    }
     if (in.kernel == CFX_K_NITSCHE || in.kernel == CFX_L_NITSCHE_RHS)
     {
       require(V->bs == 1, CFX_ERR_INVALID_ARGUMENT, "Nitsche kernels are scalar");
@@ -1522,7 +1780,7 @@ int cfx_form_prepare(cfx_form_t a)
   CFX_API_BEGIN
   require(a != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_form_prepare: null argument");
   validate_form(a);
-  if (!force_atomic()) prepare_form_tables(a);
+  if (!force_atomic() && !a->rectangular()) prepare_form_tables(a);
   CFX_API_END
 }
 
@@ -1551,7 +1809,7 @@ int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* v)
 {
   CFX_API_BEGIN
   require(p && v, CFX_ERR_INVALID_ARGUMENT, "cfx_pattern_view_get: null argument");
-  v->nrows = p->nrows; v->nnz = p->nnz; v->indptr = p->indptr.p; v->indices = p->indices.p;
+  v->nrows = p->nrows; v->nnz = p->nnz; v->indptr = p->indptr.p; v->indices = p->indices.p; v->ncols = p->ncols;
   CFX_API_END
 }
 
@@ -1571,8 +1829,9 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: form is not bilinear");
   validate_form(a);
   cfx_space_s* V = a->V;
-  require(P->nrows == V->ndofs * V->bs, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix: pattern/space size mismatch");
-  DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->nrows : 0);
+  require(P->nrows == V->ndofs * V->bs && P->ncols == a->V1->ndofs * a->V1->bs, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_assemble_matrix: pattern/space size mismatch");
+  DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->ncols : 0);
   OutArray<double> out(values, P->nnz, !zero_first);
   ZeroFlag err;
   AsmArgs A{};
@@ -1582,6 +1841,15 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   // row-gather path (deterministic, no global atomics) when the form allows it (with zero_first it does the zeroing
   // itself: rows with a single writer are stored, only the rest is filled); otherwise the whole fill and the
   // entity-parallel kernels with FP64 atomics
+  if (a->rectangular())
+  {
+    // test space != trial space: the entity-parallel kernel of the rectangular blocks (no row gather yet)
+    if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
+    for (const auto& I : a->integrals) launch_rectangular(a, I, A);
+    require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
+    out.finish();
+    return;
+  }
   if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev, zero_first)) { out.finish(); return; }
   if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
   for (const auto& I : a->integrals) launch_integral(a, I, A);
@@ -1630,16 +1898,20 @@ int cfx_apply_lifting(cfx_form_t a, const int8_t* bc_markers, const double* bc_v
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting: form is not bilinear");
   validate_form(a);
   cfx_space_s* V = a->V;
-  const int64_t n = V->ndofs * V->bs;
-  DevArray<int8_t> dm = to_device(bc_markers, n);
-  DevArray<double> dv = to_device(bc_values, n), dx0 = to_device(x0, x0 ? n : 0);
+  const int64_t n = V->ndofs * V->bs;               // b lives on the test space,
+  const int64_t n1 = a->V1->ndofs * a->V1->bs;      // the Dirichlet data on the trial space (lift_bc_impl: columns)
+  DevArray<int8_t> dm = to_device(bc_markers, n1);
+  DevArray<double> dv = to_device(bc_values, n1), dx0 = to_device(x0, x0 ? n1 : 0);
   OutArray<double> out(b, n, true);
   ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.values = out.dev; A.error = err.p;
   A.lift_markers = dm.p; A.lift_values = dv.p; A.lift_x0 = x0 ? dx0.p : nullptr; A.lift_alpha = alpha;
-  for (const auto& I : a->integrals) launch_integral(a, I, A);
+  for (const auto& I : a->integrals)
+  {
+    if (a->rectangular()) launch_rectangular(a, I, A); else launch_integral(a, I, A);
+  }
   out.finish();
   CFX_API_END
 }
@@ -1709,13 +1981,14 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
   const int64_t limit = (I.type == CFX_CELL && use_rule) ? (I.rules ? I.rules->nr : 0) : I.n_entities;
   require(index >= 0 && index < limit, CFX_ERR_OUT_OF_RANGE, "entity index out of range");
   const int nloc = V->ndofs_cell * V->bs * (I.type == CFX_INTERIOR_FACET ? 2 : 1);
-  const int64_t n = a->rank == 2 ? (int64_t)nloc * nloc : nloc;
+  const int nloc1 = a->rectangular() ? a->V1->ndofs_cell * a->V1->bs : nloc;
+  const int64_t n = a->rank == 2 ? (int64_t)nloc * nloc1 : nloc;
   OutArray<double> out(Ae, n, false);
   ZeroFlag err;
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.dump = out.dev; A.error = err.p;
-  launch_integral(a, I, A, index, use_rule);
+  if (a->rectangular()) launch_rectangular(a, I, A, index, use_rule); else launch_integral(a, I, A, index, use_rule);
   out.finish();
   CFX_API_END
 }
@@ -1726,6 +1999,8 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   require(a && out, CFX_ERR_INVALID_ARGUMENT, "cfx_active_domain: null argument");
   // deactivate.h:80-85
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain requires a rank-2 bilinear CutForm");
+  require(!a->rectangular(), CFX_ERR_INVALID_ARGUMENT,
+          "active_domain / deactivation act on square systems: the form's test and trial spaces differ");
   validate_form(a);
   cfx_space_s* V = a->V;
   auto d = std::make_unique<cfx_active_s>();

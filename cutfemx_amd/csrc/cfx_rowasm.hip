@@ -397,6 +397,9 @@ struct PatArgs
   int32_t* counts;  // [ndofs*bs] expanded row lengths
   int* overflow;
   int* maxlen;      // longest scalar-dof row
+  // rectangular forms (test space != trial space): the row dof is a dof of another space -- it is not a column of its
+  // own row (no_self), and a column dof expands to bs_col entries while a row dof owns bs rows (bs_col = 0: bs)
+  int no_self, bs_col;
 };
 
 template <int T>
@@ -446,7 +449,7 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   if (live)
   {
     int32_t* tab = s_tab[grp];
-    if (gl == 0) ok = hash_insert<T>(tab, (int32_t)r);
+    if (gl == 0 && !P.no_self) ok = hash_insert<T>(tab, (int32_t)r);
     if (P.cellmark || P.all_cells)
     {
       // R incident cells per lane per pass; incidence, marks and dof rows of a pass
@@ -578,9 +581,10 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
       if (P.indices)
       {
         // second pass of the wide path: the row goes straight into the CSR arrays
+        const int bc = P.bs_col ? P.bs_col : P.bs;
         for (int a = 0; a < P.bs; ++a)
-          for (int b = 0; b < P.bs; ++b)
-            P.indices[P.indptr[r * P.bs + a] + (int64_t)rank * P.bs + b] = v * P.bs + b;
+          for (int b = 0; b < bc; ++b)
+            P.indices[P.indptr[r * P.bs + a] + (int64_t)rank * bc + b] = v * bc + b;
       }
       else
         P.tmp[ri * T + rank] = v;
@@ -592,7 +596,7 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
     // a racy pre-check keeps 10^7 rows from serialising on one address
     if (cnt > *reinterpret_cast<volatile int*>(P.maxlen)) atomicMax(P.maxlen, cnt);
     P.len[ri] = cnt;
-    for (int a = 0; a < P.bs; ++a) P.counts[r * P.bs + a] = cnt * P.bs;
+    for (int a = 0; a < P.bs; ++a) P.counts[r * P.bs + a] = cnt * (P.bs_col ? P.bs_col : P.bs);
   }
   __syncthreads(); // the LDS tables are reused by the next pass
   }
@@ -1745,8 +1749,58 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   return true;
 }
 
+__global__ void mark_cells_u8_kernel(int64_t n, const int32_t* __restrict__ cells, uint8_t* mark)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) mark[cells[i]] = 1;
+}
+
+// Sparsity of a form whose test and trial spaces differ (assembler.h:442-529 with two dofmaps): row dof r of the test
+// space couples to the trial-space dofs of every cell of a cell integral (standard entity or rule parent) that
+// contains r.  No all-rows diagonal (assembler.h:537-560: only when the two index maps coincide).  One wavefront per
+// test-space dof, a 512-slot LDS set of trial dofs, count pass + write pass: the rectangular blocks are a small part
+// of a system's assembly, the kernel is the general one of the square patterns.
+void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
+{
+  cfx_space_s* V0 = a->V;
+  cfx_space_s* V1 = a->V1;
+  const int64_t nc = V0->mesh->ncells;
+  DevArray<uint8_t> mark((nc + 3) & ~3LL);
+  mark.zero();
+  for (const auto& I : a->integrals)
+  {
+    require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "forms with different test and trial spaces take cell integrals");
+    if (I.n_entities > 0)
+      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p, mark.p);
+    if (I.rules && I.rules->nr > 0)
+      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr, I.rules->parent_map.p,
+             mark.p);
+  }
+  const Adjacency& adj = V0->dof_cells();
+  P->nrows = V0->ndofs * V0->bs;
+  P->ncols = V1->ndofs * V1->bs;
+  PatArgs S{};
+  S.n_active = V0->ndofs; S.active_rows = nullptr;
+  S.nd = V1->ndofs_cell; S.bs = V0->bs; S.bs_col = V1->bs; S.no_self = 1; S.dofmap = V1->dofmap.p;
+  S.d2c_off = adj.offsets.p; S.d2c = adj.cells.p; S.cellmark = mark.p;
+  DevArray<int32_t> counts(P->nrows), len(V0->ndofs);
+  ZeroFlag overflow, maxlen;
+  S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
+  launch("pattern2_rows", pattern_rows_kernel<64, 512>, wave_grid(V0->ndofs), dim3(kWave), 0, S);
+  require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 511 dofs");
+  P->max_row_len = std::max(read_scalar(maxlen.p), 1);
+  P->indptr.alloc(P->nrows + 1);
+  exclusive_scan(counts.p, P->indptr.p, P->nrows);
+  P->nnz = read_scalar(P->indptr.p + P->nrows);
+  P->indices.alloc(P->nnz);
+  S.indptr = P->indptr.p; S.indices = P->indices.p;
+  launch("pattern2_rows_write", pattern_rows_kernel<64, 512>, wave_grid(V0->ndofs), dim3(kWave), 0, S);
+  P->stencil_plan = 0; P->split_plan = 0; P->full_plan = 0; P->odd_plan = 0;
+}
+
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
 {
+  if (a->rectangular()) { build_pattern_rectangular(a, P); return; }
   cfx_space_s* V = a->V;
   cfx_row_plan& plan = row_plan(a);
   const Stencil& st = space_stencil(V);
@@ -1758,6 +1812,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   int64_t n_h = use_stencil ? plan.n_special_rows : plan.n_active_rows;
   const int32_t* rows_h = use_stencil ? plan.special_rows.p : plan.active_rows.p;
   P->nrows = V->ndofs * V->bs;
+  P->ncols = P->nrows;
   DevArray<int32_t> counts(P->nrows);
   DevArray<uint8_t> full;
   DevArray<int32_t> hashed;

@@ -30,6 +30,7 @@ EXTENSION_L2 = _lib.K_EXTENSION_L2
 JUMP = _lib.K_JUMP
 SIP = _lib.K_SIP
 SOURCE, NITSCHE_RHS = _lib.L_SOURCE, _lib.L_NITSCHE_RHS
+DIV_TEST, DIV_TRIAL = _lib.K_DIV_TEST, _lib.K_DIV_TRIAL   # rectangular blocks: scale div(v) p / scale q div(u)
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = _lib.F_ONE, _lib.F_SINPROD, _lib.F_POISSON_RHS, _lib.F_COEFFICIENT
 
 
@@ -114,12 +115,19 @@ def _f64_ptr(a, keep: list):
 class CutForm:
     """Compiled form handle (python/cutfemx/fem.py CutForm)."""
 
-    def __init__(self, V: FunctionSpace, integrals, rank: int):
+    def __init__(self, V: FunctionSpace, integrals, rank: int, trial_space: FunctionSpace | None = None):
         self.function_space, self.rank = V, rank
+        # Form::function_spaces() = [test, trial] (Form.h:119-178): the same space twice unless `trial_space` is given
+        self.trial_space = V if trial_space is None else trial_space
         self.integrals = list(integrals)
         arr = (_lib.Integral * len(self.integrals))(*[i._cstruct() for i in self.integrals])
         self._h = C.c_void_p()
-        _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(self._h)))
+        if self.trial_space is not V:
+            if rank != 2:
+                raise ValueError("a trial space goes with a bilinear form")
+            _lib.check(_lib.lib().cfx_form_create2(V._h, self.trial_space._h, len(self.integrals), arr, C.byref(self._h)))
+        else:
+            _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(self._h)))
 
     def prepare(self):
         """Build the form's derived tables now (cfx_form_prepare) instead of inside the first assembly call."""
@@ -162,15 +170,17 @@ class overlap:
         return False
 
 
-def form(integrals, V: FunctionSpace, rank: int | None = None) -> CutForm:
-    """Create a form from integral descriptors (stands in for cutfemx.fem.form)."""
+def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: FunctionSpace | None = None) -> CutForm:
+    """Create a form from integral descriptors (stands in for cutfemx.fem.form).  `V` is the test space; a bilinear
+    form whose trial space differs (the off-diagonal blocks of a Stokes system, test_assembly_stokes.py:34-95) names it
+    with `trial_space`."""
     integrals = list(integrals)
     if rank is None:
         ranks = {2 if i.kernel < 100 else 1 for i in integrals}
         if len(ranks) != 1:
             raise ValueError("all integrals of a form must have the same rank")
         rank = ranks.pop()
-    return CutForm(V, integrals, rank)
+    return CutForm(V, integrals, rank, trial_space)
 
 
 class MatrixCSR:
@@ -186,7 +196,7 @@ class MatrixCSR:
         v = _lib.PatternView()
         _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
         self._view = v
-        self.nrows, self.nnz = int(v.nrows), int(v.nnz)
+        self.nrows, self.nnz, self.ncols = int(v.nrows), int(v.nnz), int(v.ncols)
         self._owns_values = values is None
         self._zero_pending = False
         if values is None:
@@ -268,7 +278,7 @@ class MatrixCSR:
 
     def to_scipy(self):
         import scipy.sparse as sp
-        return sp.csr_matrix((self.data, self.indices, self.indptr), shape=(self.nrows, self.nrows))
+        return sp.csr_matrix((self.data, self.indices, self.indptr), shape=(self.nrows, self.ncols))
 
     def to_dense(self):
         return self.to_scipy().toarray()
@@ -392,7 +402,9 @@ def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np
     I = a.integrals[integral]
     facet_type = I.facets is not None or (I.rules is not None and I.rules.host_width == 4)
     nloc = V.ndofs_cell * V.bs * (2 if facet_type else 1)
-    Ae = np.zeros((nloc, nloc) if a.rank == 2 else (nloc,))
+    V1 = getattr(a, "trial_space", V)
+    nloc1 = nloc if V1 is V else V1.ndofs_cell * V1.bs      # [(nd0 bs0) x (nd1 bs1)] row-major for rectangular forms
+    Ae = np.zeros((nloc, nloc1) if a.rank == 2 else (nloc,))
     _lib.check(_lib.lib().cfx_tabulate_entity(a._h, integral, C.c_int64(index), int(use_rule),
                                               Ae.ctypes.data_as(C.c_void_p)))
     return Ae

@@ -57,7 +57,8 @@ extern "C" {
 #define CFX_K_STIFFNESS 2       /* grad u . grad v                             */
 #define CFX_K_NITSCHE 3         /* -dn(u) v - dn(v) u + gamma/h u v; params[0]=gamma;
                                    point_data = unit normals (gdim per point)  */
-#define CFX_K_GHOST_GRADJUMP 4  /* gamma_g h_avg [dn u][dn v]; params[0]=gamma_g */
+#define CFX_K_GHOST_GRADJUMP 4  /* gamma_g h_avg^(1 + e) [dn u][dn v]; params[0]=gamma_g, params[1]=e (0: the usual
+                                   ghost penalty; 2: the pressure term avg(h)^3 of test_assembly_stokes.py:123-131) */
 #define CFX_K_ELASTICITY 5      /* sigma(u):eps(v); params[0]=E, params[1]=nu  */
 /* extension penalty pair block, beta (v|bad - E v|root)(u|bad - E u|root) over the full bad cell
  * (cpp/cutfemx/extensions/extension_penalty.cpp:191-369): an interior-facet-TYPE integral whose
@@ -69,6 +70,11 @@ extern "C" {
 #define CFX_K_SIP 10             /* interior facets: symmetric interior penalty of DG Poisson,
                                    -{dn u}[v] - {dn v}[u] + sigma / h_avg [u][v] (python/demo/demo_dg_poisson.py:262-265);
                                    params[0]=sigma */
+/* rectangular blocks (test space != trial space, cfx_form_create2): the off-diagonal blocks of Stokes and friends.
+ * assemble_matrix_impl.h:68-189 takes dofmap0 / bs0 and dofmap1 / bs1 separately; invariants
+ * python/tests/test_assembly_stokes.py:34-95.  CFX_K_MASS / CFX_K_STIFFNESS are also accepted there (bs0 == bs1) */
+#define CFX_K_DIV_TEST 20        /* scale div(v) p: test vector (bs = gdim), trial scalar; params[0] = scale */
+#define CFX_K_DIV_TRIAL 21       /* scale q div(u): test scalar, trial vector (bs = gdim); params[0] = scale  */
 #define CFX_L_SOURCE 101        /* f v; params[0]=field id, params[1]=scale    */
 #define CFX_L_NITSCHE_RHS 102   /* -dn(v) g + gamma/h g v; params[0]=gamma,
                                    params[1]=field id of g, params[2]=scale    */
@@ -151,6 +157,7 @@ typedef struct
   int64_t nnz;
   const int64_t* indptr;  /* [nrows+1] (HBM), DOLFINx MatrixCSR row_ptr type */
   const int32_t* indices; /* [nnz] sorted per row (HBM)                       */
+  int64_t ncols;          /* = nrows for square forms; trial-space dofs x bs for cfx_form_create2 forms */
 } cfx_pattern_view;
 
 /* ---- runtime ------------------------------------------------------------- */
@@ -344,6 +351,14 @@ int cfx_space_destroy(cfx_space_t V);
  *      python/cutfemx/wrappers/fem.cpp:124-172 ------------------------------- */
 int cfx_form_create(cfx_space_t V, int rank, int n_integrals,
                     const cfx_integral* integrals, cfx_form_t* out);
+/* Bilinear form with DIFFERENT test and trial spaces on one mesh (Form::function_spaces() = {V_test, V_trial},
+ * Form.h:119-178; the cell loop takes both dofmaps, assemble_matrix_impl.h:68-189, the sparsity both index maps and no
+ * all-rows diagonal, assembler.h:442-560).  Cell integrals (standard entities and / or runtime rules) with kernels
+ * CFX_K_DIV_TEST, CFX_K_DIV_TRIAL, CFX_K_MASS, CFX_K_STIFFNESS; the element tensor is [(nd0 bs0) x (nd1 bs1)] row-major
+ * (cfx_tabulate_entity), bc0 marks test-space rows, bc1 trial-space columns, cfx_apply_lifting takes trial-space data
+ * and a test-space vector.  cfx_active_domain / deactivation are for square systems and refuse such forms. */
+int cfx_form_create2(cfx_space_t V_test, cfx_space_t V_trial, int n_integrals, const cfx_integral* integrals,
+                     cfx_form_t* out);
 int cfx_form_destroy(cfx_form_t a);
 /* build the form's derived tables now (row plan: cell / row marks, row classes, rule maps, facet incidence, stencil
  * masks, the row-ordered staging layout of a linear form) instead of inside the first assembly call that needs them */

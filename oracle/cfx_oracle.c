@@ -1443,7 +1443,9 @@ static void facet_kernel(const orc_mesh* m, const orc_space* V, const orc_integr
     double N0[MAXND], dN0[MAXND][3], N1[MAXND], dN1[MAXND][3];
     tabulate(tdim, V->degree, X0, N0, dN0);
     tabulate(tdim, V->degree, X1, N1, dN1);
-    const double w = wref[q] * scale * I->params[0] * havg;
+    /* gamma h_avg^(1 + params[1]): params[1] = 0 is the velocity-type term avg(h) [dn u][dn v], 2 the pressure-type
+       term avg(h)^3 [dn p][dn q] of python/tests/test_assembly_stokes.py:123-131 */
+    const double w = wref[q] * scale * I->params[0] * havg * (I->params[1] != 0.0 ? pow(havg, I->params[1]) : 1.0);
     if (I->kernel == ORC_K_GHOST_GRADJUMP)
     {
       double jn[2 * MAXND]; /* normal-derivative jump of each macro basis fn */
@@ -1882,4 +1884,201 @@ void orc_deactivate(const int32_t* inactive, int64_t n, int bs_unused,
       if (indices[k] == r) values[k] = diagonal;
     if (b) b[r] = rhs_value;
   }
+}
+
+/* ------------------------------------------------------------------------ */
+/* rectangular bilinear forms: test space V0 (rows), trial space V1 (cols).  */
+/* ref: assemble_matrix_impl.h:68-189 (dofmap0 / bs0 and dofmap1 / bs1 are   */
+/* separate arguments of the cell loop), assembler.h:442-529 (sparsity from  */
+/* both dofmaps), :537-560 (no diagonal unless the index maps coincide).     */
+/* ------------------------------------------------------------------------ */
+static void cell_kernel2(const orc_mesh* m, const orc_space* V0, const orc_space* V1, const orc_integral* I,
+                         int64_t cell, int npts, const double* pts, const double* wts, double wscale, double* Ae)
+{
+  const int tdim = m->tdim, gdim = m->gdim;
+  const int nd0 = V0->ndofs_cell, bs0 = V0->bs, nd1 = V1->ndofs_cell, bs1 = V1->bs, n1 = nd1 * bs1;
+  double xc[MAXV][3], J[3][3], K[3][3];
+  cell_coords(m, cell, xc);
+  jacobian(tdim, xc, J, K);
+  for (int q = 0; q < npts; ++q)
+  {
+    const double* X = pts + (int64_t)q * tdim;
+    const double w = wts[q] * wscale;
+    double N0[MAXND], dN0[MAXND][3], G0[MAXND][3], N1[MAXND], dN1[MAXND][3], G1[MAXND][3];
+    tabulate(tdim, V0->degree, X, N0, dN0);
+    tabulate(tdim, V1->degree, X, N1, dN1);
+    for (int d = 0; d < gdim; ++d)
+    {
+      for (int i = 0; i < nd0; ++i)
+      {
+        G0[i][d] = 0.0;
+        for (int t = 0; t < tdim; ++t) G0[i][d] += K[t][d] * dN0[i][t];
+      }
+      for (int j = 0; j < nd1; ++j)
+      {
+        G1[j][d] = 0.0;
+        for (int t = 0; t < tdim; ++t) G1[j][d] += K[t][d] * dN1[j][t];
+      }
+    }
+    switch (I->kernel)
+    {
+    case ORC_K_MASS:
+      for (int i = 0; i < nd0; ++i)
+        for (int j = 0; j < nd1; ++j)
+          for (int k = 0; k < bs0; ++k) Ae[(i * bs0 + k) * n1 + j * bs1 + k] += w * N0[i] * N1[j];
+      break;
+    case ORC_K_STIFFNESS:
+      for (int i = 0; i < nd0; ++i)
+        for (int j = 0; j < nd1; ++j)
+        {
+          double s = 0.0;
+          for (int d = 0; d < gdim; ++d) s += G0[i][d] * G1[j][d];
+          for (int k = 0; k < bs0; ++k) Ae[(i * bs0 + k) * n1 + j * bs1 + k] += w * s;
+        }
+      break;
+    case ORC_K_DIV_TEST: /* v = N0_i e_a, p = N1_j */
+      for (int i = 0; i < nd0; ++i)
+        for (int a = 0; a < bs0; ++a)
+          for (int j = 0; j < nd1; ++j) Ae[(i * bs0 + a) * n1 + j] += w * I->params[0] * G0[i][a] * N1[j];
+      break;
+    case ORC_K_DIV_TRIAL: /* q = N0_i, u = N1_j e_b */
+      for (int i = 0; i < nd0; ++i)
+        for (int j = 0; j < nd1; ++j)
+          for (int b = 0; b < bs1; ++b) Ae[i * n1 + j * bs1 + b] += w * I->params[0] * N0[i] * G1[j][b];
+      break;
+    default: break;
+    }
+  }
+}
+
+int orc_tabulate_entity2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* I,
+                         int64_t idx, int use_rule, double* Ae)
+{
+  if (I->type != ORC_CELL) return -1;
+  if (use_rule)
+  {
+    const orc_rules* R = I->rules;
+    const int32_t q0 = R->offsets[idx], q1 = R->offsets[idx + 1];
+    cell_kernel2(mesh, V0, V1, I, R->parent_map[idx], q1 - q0, R->points + (int64_t)q0 * R->tdim, R->weights + q0, 1.0, Ae);
+    return 0;
+  }
+  int n; const double *p, *w;
+  standard_rule(mesh, I, &n, &p, &w);
+  double xc[MAXV][3], J[3][3], K[3][3];
+  cell_coords(mesh, I->entities[idx], xc);
+  const double detJ = fabs(jacobian(mesh->tdim, xc, J, K));
+  cell_kernel2(mesh, V0, V1, I, I->entities[idx], n, p, w, detJ, Ae);
+  return 0;
+}
+
+static int cell_dofs(const orc_space* V, int64_t c, int32_t* dofs)
+{
+  int n = 0;
+  for (int i = 0; i < V->ndofs_cell; ++i)
+    for (int k = 0; k < V->bs; ++k) dofs[n++] = V->bs * V->dofmap[c * V->ndofs_cell + i] + k;
+  return n;
+}
+
+int orc_create_sparsity2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* integrals,
+                         int n_integrals, int64_t** indptr_out, int32_t** indices_out)
+{
+  (void)mesh;
+  const int64_t nrows = V0->ndofs * V0->bs;
+  int64_t* cnt = (int64_t*)calloc((size_t)nrows + 1, sizeof(int64_t));
+  int32_t r[MAXLOC], c[MAXLOC];
+  int64_t* ptr = NULL; int32_t* cols = NULL; int64_t* fill = NULL;
+  for (int pass = 0; pass < 2; ++pass)
+  {
+    if (pass == 1)
+    {
+      ptr = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nrows + 1));
+      ptr[0] = 0;
+      for (int64_t k = 0; k < nrows; ++k) ptr[k + 1] = ptr[k] + cnt[k];
+      cols = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ptr[nrows] + 1));
+      fill = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nrows + 1));
+      for (int64_t k = 0; k < nrows; ++k) fill[k] = ptr[k];
+    }
+    for (int ii = 0; ii < n_integrals; ++ii)
+    {
+      const orc_integral* I = &integrals[ii];
+      if (I->type != ORC_CELL) { free(cnt); return -1; }
+      for (int part = 0; part < 2; ++part)
+      {
+        const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+        for (int64_t e = 0; e < ne; ++e)
+        {
+          const int64_t cell = part ? I->rules->parent_map[e] : I->entities[e];
+          const int n0 = cell_dofs(V0, cell, r), n1 = cell_dofs(V1, cell, c);
+          for (int i = 0; i < n0; ++i)
+          {
+            if (pass == 0) cnt[r[i]] += n1;
+            else
+              for (int j = 0; j < n1; ++j) cols[fill[r[i]]++] = c[j];
+          }
+        }
+      }
+    }
+  }
+  int64_t* indptr = (int64_t*)malloc(sizeof(int64_t) * (size_t)(nrows + 1));
+  int64_t nnz = 0;
+  indptr[0] = 0;
+  for (int64_t k = 0; k < nrows; ++k)
+  {
+    int32_t* row = cols + ptr[k];
+    const int64_t len = fill[k] - ptr[k];
+    qsort(row, (size_t)len, sizeof(int32_t), i32_cmp);
+    int64_t u = 0;
+    for (int64_t j = 0; j < len; ++j)
+      if (j == 0 || row[j] != row[j - 1]) cols[nnz + u++] = row[j];
+    nnz += u;
+    indptr[k + 1] = nnz;
+  }
+  int32_t* indices = (int32_t*)malloc(sizeof(int32_t) * (size_t)(nnz + 1));
+  memcpy(indices, cols, sizeof(int32_t) * (size_t)nnz);
+  free(cols); free(ptr); free(fill); free(cnt);
+  *indptr_out = indptr; *indices_out = indices;
+  return 0;
+}
+
+int orc_assemble_matrix2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* integrals,
+                         int n_integrals, const int8_t* bc0, const int8_t* bc1, const int64_t* indptr,
+                         const int32_t* indices, double* values)
+{
+  double Ae[MAXLOC * MAXLOC];
+  int32_t r[MAXLOC], c[MAXLOC];
+  for (int ii = 0; ii < n_integrals; ++ii)
+  {
+    const orc_integral* I = &integrals[ii];
+    for (int part = 0; part < 2; ++part)
+    {
+      const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);
+      for (int64_t e = 0; e < ne; ++e)
+      {
+        const int64_t cell = part ? I->rules->parent_map[e] : I->entities[e];
+        const int n0 = cell_dofs(V0, cell, r), n1 = cell_dofs(V1, cell, c);
+        memset(Ae, 0, sizeof(double) * (size_t)(n0 * n1));
+        if (orc_tabulate_entity2(mesh, V0, V1, I, e, part, Ae) != 0) return -2;
+        /* zero BC rows (test side) and columns (trial side): assemble_matrix_impl.h:151-185 */
+        for (int i = 0; i < n0; ++i)
+          for (int j = 0; j < n1; ++j)
+            if ((bc0 && bc0[r[i]]) || (bc1 && bc1[c[j]])) Ae[i * n1 + j] = 0.0;
+        for (int i = 0; i < n0; ++i)
+        {
+          const int64_t b = indptr[r[i]], en = indptr[r[i] + 1];
+          for (int j = 0; j < n1; ++j)
+          {
+            int64_t lo = b, hi = en;
+            while (lo < hi)
+            {
+              const int64_t mid = (lo + hi) / 2;
+              if (indices[mid] < c[j]) lo = mid + 1; else hi = mid;
+            }
+            if (lo == en || indices[lo] != c[j]) return -1;
+            values[lo] += Ae[i * n1 + j];
+          }
+        }
+      }
+    }
+  }
+  return 0;
 }

@@ -46,6 +46,11 @@ enum {
                                interior-facet-type entities; params[0]=beta, point_data (stride 1) = per-pair factor */
   ORC_K_JUMP = 9,           /* interior facets: gamma / h_avg [u][v]  (params[0]=gamma)         */
   ORC_K_SIP = 10,           /* interior facets: -{dn u}[v] - {dn v}[u] + sigma/h_avg [u][v]  (params[0]=sigma) */
+  /* rectangular blocks (test space != trial space): the off-diagonal blocks of Stokes and friends.
+     ref: assemble_matrix_impl.h:68-189 takes dofmap0/bs0 and dofmap1/bs1 separately; invariants
+     python/tests/test_assembly_stokes.py:34-95 */
+  ORC_K_DIV_TEST = 20,      /* scale div(v) p : test vector (bs0 = gdim), trial scalar; params[0] = scale */
+  ORC_K_DIV_TRIAL = 21,     /* scale q div(u) : test scalar, trial vector (bs1 = gdim); params[0] = scale  */
   ORC_L_SOURCE = 101,       /* f v, f = analytic id params[0], scale params[1] */
   ORC_L_NITSCHE_RHS = 102   /* -dn(v) g + gamma/h g v, gamma=params[0], g id params[1], scale params[2] */
 };
@@ -99,6 +104,18 @@ typedef struct {
   int64_t ndofs;          /* scalar dofs in the space                        */
   const int32_t* dofmap;  /* [ncells*ndofs_cell]                             */
 } orc_space;
+
+/* rectangular forms: test space V0 (rows), trial space V1 (columns); cell integrals with kernels ORC_K_MASS /
+   ORC_K_STIFFNESS (bs0 == bs1, any degrees), ORC_K_DIV_TEST, ORC_K_DIV_TRIAL.  Ae is [(nd0 bs0) x (nd1 bs1)] row-major.
+   The sparsity has NO all-rows diagonal (insert_deactivation_diagonal returns when the two index maps differ,
+   assembler.h:537-560). */
+int orc_tabulate_entity2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* I,
+                         int64_t idx, int use_rule, double* Ae);
+int orc_create_sparsity2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* integrals,
+                         int n_integrals, int64_t** indptr_out, int32_t** indices_out);
+int orc_assemble_matrix2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* integrals,
+                         int n_integrals, const int8_t* bc0, const int8_t* bc1, const int64_t* indptr,
+                         const int32_t* indices, double* values);
 
 void orc_free(void* p);
 void orc_rules_free(orc_rules* r);

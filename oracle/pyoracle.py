@@ -22,6 +22,7 @@ K_MASS, K_STIFFNESS, K_NITSCHE, K_GHOST_GRADJUMP, K_ELASTICITY = 1, 2, 3, 4, 5
 K_EXTENSION_L2 = 8
 K_JUMP = 9
 K_SIP = 10
+K_DIV_TEST, K_DIV_TRIAL = 20, 21   # rectangular blocks: scale div(v) p / scale q div(u)
 L_SOURCE, L_NITSCHE_RHS = 101, 102
 F_ONE, F_SINPROD, F_POISSON_RHS, F_COEFFICIENT = 0, 1, 2, 3
 
@@ -366,6 +367,41 @@ def assemble_matrix(mesh, V: Space, integrals, indptr, indices, bc0=None, bc1=No
     if rc != 0:
         raise RuntimeError("entry not in sparsity pattern")
     return values
+
+
+# ---- rectangular forms (test space V0, trial space V1): assemble_matrix_impl.h:68-189, assembler.h:442-560 ----
+def create_sparsity2(mesh, V0: Space, V1: Space, integrals):
+    arr = _integral_array(integrals)
+    ip, ix = C.c_void_p(), C.c_void_p()
+    rc = lib().orc_create_sparsity2(C.byref(mesh.c), C.byref(V0.c), C.byref(V1.c), arr, len(integrals), C.byref(ip), C.byref(ix))
+    if rc != 0:
+        raise ValueError("rectangular forms take cell integrals")
+    nrows = V0.ndofs * V0.bs
+    indptr = np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_int64)), shape=(nrows + 1,)).copy()
+    nnz = int(indptr[-1])
+    indices = np.ctypeslib.as_array(C.cast(ix, C.POINTER(C.c_int32)), shape=(max(nnz, 1),)).copy()[:nnz]
+    lib().orc_free(ip)
+    lib().orc_free(ix)
+    return indptr, indices
+
+
+def assemble_matrix2(mesh, V0: Space, V1: Space, integrals, indptr, indices, bc0=None, bc1=None):
+    arr = _integral_array(integrals)
+    values = np.zeros(indices.size)
+    b0 = None if bc0 is None else np.ascontiguousarray(bc0, dtype=np.int8)
+    b1 = None if bc1 is None else np.ascontiguousarray(bc1, dtype=np.int8)
+    rc = lib().orc_assemble_matrix2(C.byref(mesh.c), C.byref(V0.c), C.byref(V1.c), arr, len(integrals), _p(b0), _p(b1),
+                                    _p(indptr), _p(indices), _p(values))
+    if rc != 0:
+        raise RuntimeError("entry not in sparsity pattern" if rc == -1 else "unsupported integral")
+    return values
+
+
+def tabulate_entity2(mesh, V0: Space, V1: Space, integral: Integral, idx: int, use_rule: bool):
+    ic = integral.cstruct()
+    Ae = np.zeros((V0.dofmap.shape[1] * V0.bs, V1.dofmap.shape[1] * V1.bs))
+    lib().orc_tabulate_entity2(C.byref(mesh.c), C.byref(V0.c), C.byref(V1.c), C.byref(ic), C.c_int64(idx), int(use_rule), _p(Ae))
+    return Ae
 
 
 def assemble_vector(mesh, V: Space, integrals):

@@ -1,0 +1,200 @@
+"""Forms whose test and trial spaces differ (assemble_matrix_impl.h:68-189 with dofmap0 / bs0 != dofmap1 / bs1,
+assembler.h:442-560): the off-diagonal blocks of a Stokes system.  The oracle is pinned by the invariants the
+reference's own tests hold (python/tests/test_assembly_stokes.py:34-95: runtime quadrature == standard quadrature to
+1e-9 on the P2-P1 Stokes form; :98-142: the mixed ghost penalty is the sum of a velocity and a pressure gradient-jump
+block) plus closed forms; the engine is then compared with the oracle through the C ABI (cfx_form_create2)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from helpers import level_set_values, rel_err
+
+
+def spaces(O, tdim, n):
+    import cutfemx_amd.mesh as M
+    om = O.mesh_box(tdim, n)
+    dm2, nd2 = M.lagrange_dofmap(tdim, om.conn, om.nnodes, 2)
+    return om, dm2, nd2, O.Space(dm2, nd2, 2, tdim), O.Space(om.conn, om.nnodes, 1, 1), O.Space(dm2, nd2, 2, 1)
+
+
+def dof_points(om, dm2, nd2, tdim):
+    x = np.zeros((nd2, 3))
+    x[:om.nnodes] = om.x
+    edges = [(1, 2), (0, 2), (0, 1)] if tdim == 2 else [(2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1)]
+    for k, (p, q) in enumerate(edges):
+        x[dm2[:, tdim + 1 + k]] = 0.5 * (om.x[om.conn[:, p]] + om.x[om.conn[:, q]])
+    return x
+
+
+@pytest.mark.parametrize("tdim,n", [(2, 4), (3, 3)])
+def test_oracle_stokes_blocks_runtime_equals_standard(oracle, tdim, n):
+    """test_assembly_stokes.py:34-95: the same form over runtime rules that cover every cell whole (order 4) and over
+    the standard rule agree to 1e-9 -- here block by block; B is the transpose of B^T; closed forms for div."""
+    O = oracle
+    om, dm2, nd2, VU, VP, _ = spaces(O, tdim, n)
+    cells = np.arange(om.ncells, dtype=np.int32)
+    full = O.full_cell_rules(om, cells, 4)
+    none = np.zeros(0, dtype=np.int32)
+    mats = {}
+    for name, (V0, V1, kern) in {"Bt": (VU, VP, O.K_DIV_TEST), "B": (VP, VU, O.K_DIV_TRIAL)}.items():
+        std = [O.Integral(O.CELL, kern, entities=cells, params=(-1.0,), qdegree=3)]
+        run = [O.Integral(O.CELL, kern, entities=none, rules=full, params=(-1.0,), qdegree=3)]
+        ip, ix = O.create_sparsity2(om, V0, V1, std)
+        ip2, ix2 = O.create_sparsity2(om, V0, V1, run)
+        assert np.array_equal(ip, ip2) and np.array_equal(ix, ix2)
+        a, b = O.assemble_matrix2(om, V0, V1, std, ip, ix), O.assemble_matrix2(om, V0, V1, run, ip, ix)
+        assert np.linalg.norm(a - b) < 1e-9 * max(1.0, np.linalg.norm(a))
+        mats[name] = sp.csr_matrix((a, ix, ip), shape=(V0.ndofs * V0.bs, V1.ndofs * V1.bs))
+        # no all-rows diagonal: every row holds trial dofs of its cells only
+        assert ix.max() < V1.ndofs * V1.bs
+    assert abs(mats["Bt"] - mats["B"].T).max() < 1e-14
+    # -int div(v) p with v = (x, 0[, 0]) interpolated (exact in P2), p = 1: -|Omega| = -1
+    xd = dof_points(om, dm2, nd2, tdim)
+    v = np.zeros(nd2 * tdim)
+    v[0::tdim] = xd[:, 0]
+    assert abs(v @ (mats["Bt"] @ np.ones(om.nnodes)) + 1.0) < 1e-12
+    # v = (y^2, x y [, 0]): div v = x; p = x (P1-exact): -int x^2 = -1/3
+    v = np.zeros(nd2 * tdim)
+    v[0::tdim] = xd[:, 1] ** 2
+    v[1::tdim] = xd[:, 0] * xd[:, 1]
+    assert abs(v @ (mats["Bt"] @ om.x[:, 0]) + 1.0 / 3.0) < 1e-12
+
+
+def test_oracle_mixed_degree_mass_and_bc(oracle):
+    """P2 test x P1 trial mass block: 1^T M 1 = |Omega|; M p for p linear is the P2 load vector of p; Dirichlet markers
+    zero rows on the test side and columns on the trial side (assemble_matrix_impl.h:151-185)."""
+    O = oracle
+    om, dm2, nd2, _, VP, VS = spaces(O, 2, 4)
+    cells = np.arange(om.ncells, dtype=np.int32)
+    a = [O.Integral(O.CELL, O.K_MASS, entities=cells, qdegree=3)]
+    ip, ix = O.create_sparsity2(om, VS, VP, a)
+    vals = O.assemble_matrix2(om, VS, VP, a, ip, ix)
+    M = sp.csr_matrix((vals, ix, ip), shape=(nd2, om.nnodes))
+    assert abs(np.ones(nd2) @ (M @ np.ones(om.nnodes)) - 1.0) < 1e-13
+    L = O.assemble_vector(om, VS, [O.Integral(O.CELL, O.L_SOURCE, entities=cells, params=(O.F_COEFFICIENT, 1.0), qdegree=3,
+                                              coefficient=dof_points(om, dm2, nd2, 2)[:, 0])])
+    assert np.abs(M @ om.x[:, 0] - L).max() < 1e-13
+    rng = np.random.default_rng(2)
+    bc0, bc1 = (rng.random(nd2) < 0.2).astype(np.int8), (rng.random(om.nnodes) < 0.2).astype(np.int8)
+    Mb = sp.csr_matrix((O.assemble_matrix2(om, VS, VP, a, ip, ix, bc0, bc1), ix, ip), shape=M.shape).toarray()
+    want = M.toarray()
+    want[bc0 == 1, :] = 0.0
+    want[:, bc1 == 1] = 0.0
+    assert np.abs(Mb - want).max() < 1e-15
+
+
+def test_oracle_pressure_ghost_penalty_power(oracle):
+    """test_assembly_stokes.py:98-142: avg(h) [dn u][dn v] + avg(h)^3 [dn p][dn q] over the interior facets = a velocity
+    block and a pressure block; the pressure block is the scalar gradient jump with params[1] = 2 extra powers of h_avg
+    (on a uniform mesh: h^2 times the plain block) and annihilates affine pressures."""
+    O = oracle
+    om = O.mesh_box(2, 5)
+    VP = O.Space(om.conn, om.nnodes, 1, 1)
+    facets = O.interior_facets_for_cells(om, np.arange(om.ncells, dtype=np.int32))
+    a1 = [O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=facets, params=(1.0,), qdegree=0)]
+    a3 = [O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=facets, params=(1.0, 2.0), qdegree=0)]
+    ip, ix = O.create_sparsity(om, VP, a1)
+    v1, v3 = O.assemble_matrix(om, VP, a1, ip, ix), O.assemble_matrix(om, VP, a3, ip, ix)
+    h = np.sqrt(2.0) / 5
+    assert rel_err(v3, h * h * v1) < 1e-13
+    G = sp.csr_matrix((v3, ix, ip), shape=(om.nnodes, om.nnodes))
+    assert np.abs(G @ (1.0 + 2.0 * om.x[:, 0] - om.x[:, 1])).max() < 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n", [(2, 8), (3, 5)])
+def test_gpu_stokes_blocks_on_a_cut_domain(oracle, tdim, n):
+    """B^T = -(div v, p) and B = -(q, div u) over [inside cells, cut-cell rules] of a sphere cut, P2 vector x P1: sparsity
+    bit-exact (indptr, indices: no diagonal, trial-space columns), values 1e-12, local tensors, Dirichlet markers per
+    side, lifting through the rectangular block, and the refusals."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om, dm2, nd2, oVU, oVP, oVS = spaces(O, tdim, n)
+    phi = level_set_values(om.x, tdim)
+    dom = O.classify(om.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", 4)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    VU = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2, bs=tdim)
+    VS = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2)
+    VP = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(VP, phi))
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    rng = np.random.default_rng(4)
+    cases = {"Bt": (oVU, oVP, VU, VP, O.K_DIV_TEST, fem.DIV_TEST, (-1.0,)), "B": (oVP, oVU, VP, VU, O.K_DIV_TRIAL, fem.DIV_TRIAL, (-1.0,)),
+             "M21": (oVS, oVP, VS, VP, O.K_MASS, fem.MASS, ()), "K12": (oVP, oVS, VP, VS, O.K_STIFFNESS, fem.STIFFNESS, ())}
+    for name, (o0, o1, g0, g1, ok, gk, par) in cases.items():
+        oa = [O.Integral(O.CELL, ok, entities=inside, rules=ovol, params=par, qdegree=3)]
+        ga = [fem.Integral(gk, cells=inside, rules=vol, params=par, qdegree=3)]
+        a = fem.form(ga, g0, trial_space=g1)
+        ip, ix = O.create_sparsity2(om, o0, o1, oa)
+        want = O.assemble_matrix2(om, o0, o1, oa, ip, ix)
+        A = fem.assemble_matrix(a)
+        assert (A.nrows, A.ncols) == (o0.ndofs * o0.bs, o1.ndofs * o1.bs), name
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), name
+        assert rel_err(A.data, want) < 1e-12, name
+        fem.assemble_matrix(a, A=A)                     # accumulates
+        assert rel_err(A.data, 2.0 * want) < 1e-12, name
+        # one standard entity, one rule
+        for idx, use_rule in ((len(inside) // 2, False), (ovol.offsets.size // 2, True)):
+            got = fem.tabulate_entity(a, 0, idx, use_rule)
+            ref = O.tabulate_entity2(om, o0, o1, oa[0], idx, use_rule)
+            assert got.shape == ref.shape and rel_err(got, ref) < 1e-12, (name, use_rule)
+        # markers per side
+        bc0 = (rng.random(o0.ndofs * o0.bs) < 0.1).astype(np.int8)
+        bc1 = (rng.random(o1.ndofs * o1.bs) < 0.1).astype(np.int8)
+        Ab = fem.assemble_matrix(a, bcs=(bc0, bc1))
+        assert rel_err(Ab.data, O.assemble_matrix2(om, o0, o1, oa, ip, ix, bc0, bc1)) < 1e-12, name
+        # lifting: b (test space) -= A (g - x0) over the marked trial-space columns
+        g, x0, b0 = rng.standard_normal(o1.ndofs * o1.bs), rng.standard_normal(o1.ndofs * o1.bs), rng.standard_normal(o0.ndofs * o0.bs)
+        Msp = sp.csr_matrix((want, ix, ip), shape=(A.nrows, A.ncols))
+        got = fem.apply_lifting(b0.copy(), a, bc1, g, x0=x0, alpha=0.7)
+        assert rel_err(got, b0 - Msp @ np.where(bc1 == 1, 0.7 * (g - x0), 0.0)) < 1e-11, name
+        with pytest.raises(ValueError, match="square systems"):
+            fem.active_domain(a)
+    # B^T is the transpose of B
+    Bt = fem.assemble_matrix(fem.form([fem.Integral(fem.DIV_TEST, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VU, trial_space=VP))
+    B = fem.assemble_matrix(fem.form([fem.Integral(fem.DIV_TRIAL, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VP, trial_space=VU))
+    assert abs(Bt.to_scipy() - B.to_scipy().T).max() < 1e-12 * abs(B.to_scipy()).max()
+    # refusals: divergence blocks on one space, wrong shapes, facet integrals, another mesh
+    with pytest.raises(ValueError):
+        fem.form([fem.Integral(fem.DIV_TEST, cells=inside, qdegree=3)], VU)
+    with pytest.raises(ValueError, match="vector test space"):
+        fem.form([fem.Integral(fem.DIV_TEST, cells=inside, qdegree=3)], VP, trial_space=VU)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    with pytest.raises(ValueError, match="cell integrals"):
+        fem.form([fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)], VS, trial_space=VP)
+    other = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    with pytest.raises(ValueError, match="different meshes"):
+        fem.form([fem.Integral(fem.MASS, cells=inside, qdegree=3)], VS, trial_space=cfx.FunctionSpace(other, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n", [(2, 8), (3, 4)])
+def test_gpu_pressure_ghost_penalty_power(oracle, tdim, n):
+    """The pressure block of test_assembly_stokes.py:98-142: gamma h_avg^(1 + params[1]) [dn p][dn q], P1, all modes of the
+    facet path (rank-one records included)."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    dom = O.classify(om.conn, phi)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(V, phi))
+    oV = O.Space(om.conn, om.nnodes, 1, 1)
+    inside = O.locate_entities(dom, "phi<0")
+    oghost, ghost = O.ghost_penalty_facets(om, dom, "phi<0"), cfx.ghost_penalty_facets(cd, "phi<0")
+    oa = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, qdegree=0),
+          O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=oghost, params=(0.3, 2.0), qdegree=0)]
+    ga = [fem.Integral(fem.STIFFNESS, cells=inside, qdegree=0),
+          fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.3, 2.0), qdegree=0)]
+    ip, ix = O.create_sparsity(om, oV, oa)
+    want = O.assemble_matrix(om, oV, oa, ip, ix)
+    A = fem.assemble_matrix(fem.form(ga, V))
+    assert np.array_equal(A.indices, ix) and rel_err(A.data, want) < 1e-12
+    got = fem.tabulate_entity(fem.form(ga, V), 1, len(oghost) // 2, False)
+    assert rel_err(got, O.tabulate_entity(om, oV, oa[1], len(oghost) // 2, False)) < 1e-12

@@ -102,6 +102,8 @@ SYMBOLS = [
     "cfx_rules_physical_points_f32", "cfx_evaluate_normals_f32", "cfx_evaluate_values_f32", "cfx_widen_f32",
     "cfx_assemble_matrix_f32", "cfx_assemble_matrix_zeroed_f32", "cfx_assemble_vector_f32", "cfx_apply_lifting_f32",
     "cfx_set_bc_f32", "cfx_zero_rows_f32", "cfx_deactivate_outside_f32",
+    "cfx_assemble_matrix_c128", "cfx_assemble_vector_c128", "cfx_apply_lifting_c128", "cfx_set_bc_c128",
+    "cfx_deactivate_outside_c128",
 ]
 
 _lib = None
@@ -220,6 +222,8 @@ def scalar_dtype(a):
     of the boundary (the reference's T of MatrixCSR<T> / Vector<T> / Function<T>) a container selects."""
     if a is None:
         return np.float64
+    if getattr(a, "dtype", None) == np.dtype(np.complex128):
+        return np.complex128                       # host numpy vectors of the complex128 instantiation (cfx_*_c128)
     if isinstance(a, DeviceBuffer):
         return np.float32 if a.dtype == np.dtype(np.float32) else np.float64
     if is_torch(a):

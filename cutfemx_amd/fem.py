@@ -45,10 +45,23 @@ class Integral:
     params: tuple = ()
     qdegree: int = 2                          # quadrature degree on the standard entities
     coefficient: object = None                # Function / dof values of the form's space (field id F_COEFFICIENT)
+    scale: complex = 1.0                      # constant that multiplies the integrand (fem.Constant kappa in `kappa * ... * dx`,
+                                              # test_complex_assembly.py:55-91): a complex value makes the form complex128
     _keep: list = field(default_factory=list, repr=False)
 
-    def _cstruct(self) -> _lib.Integral:
-        keep = self._keep = []
+    def _coefficient_values(self):
+        return None if self.coefficient is None else getattr(self.coefficient, "values", self.coefficient)
+
+    def _complex_coefficient(self) -> bool:
+        v = self._coefficient_values()
+        return v is not None and np.iscomplexobj(v)
+
+    def _cstruct(self, part: str = "re") -> _lib.Integral:
+        keep = []
+        if part == "re":
+            self._keep = keep          # what the form of the real parts aliases lives as long as this descriptor ...
+        else:
+            self._keep_im = keep       # ... and so does what the form of the imaginary parts aliases
         itype = _lib.CELL
         ent_ptr, n_ent = None, 0
         if self.facets is None and self.rules is not None and self.rules.host_width == 4 and self.kernel in (
@@ -79,7 +92,9 @@ class Integral:
         params = (C.c_double * 8)(*([float(v) for v in self.params] + [0.0] * (8 - len(self.params))))
         coeff = None
         if self.coefficient is not None:
-            values = getattr(self.coefficient, "values", self.coefficient)   # a Function or its dof array
+            values = self._coefficient_values()   # a Function or its dof array
+            if np.iscomplexobj(values):           # complex Function: its real / imaginary parts feed two real forms
+                values = np.ascontiguousarray(np.real(values) if part == "re" else np.imag(values), dtype=np.float64)
             coeff = _f64_ptr(values, keep)
         return _lib.Integral(itype, self.kernel, int(self.qdegree), stride, ent_ptr, n_ent,
                              self.rules._h if self.rules is not None else None, pd, params, coeff)
@@ -115,19 +130,55 @@ def _f64_ptr(a, keep: list):
 class CutForm:
     """Compiled form handle (python/cutfemx/fem.py CutForm)."""
 
-    def __init__(self, V: FunctionSpace, integrals, rank: int, trial_space: FunctionSpace | None = None):
+    def __init__(self, V: FunctionSpace, integrals, rank: int, trial_space: FunctionSpace | None = None, dtype=None):
         self.function_space, self.rank = V, rank
         # Form::function_spaces() = [test, trial] (Form.h:119-178): the same space twice unless `trial_space` is given
         self.trial_space = V if trial_space is None else trial_space
         self.integrals = list(integrals)
-        arr = (_lib.Integral * len(self.integrals))(*[i._cstruct() for i in self.integrals])
-        self._h = C.c_void_p()
-        if self.trial_space is not V:
-            if rank != 2:
-                raise ValueError("a trial space goes with a bilinear form")
-            _lib.check(_lib.lib().cfx_form_create2(V._h, self.trial_space._h, len(self.integrals), arr, C.byref(self._h)))
-        else:
-            _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(self._h)))
+        # scalar type T of the form (cutfemx.fem.form(..., dtype=), wrappers/fem.cpp:490-500): complex128 when asked for,
+        # or when a constant / coefficient of an integral is complex; real forms with unit constants stay on the
+        # float64 entry points
+        cplx = any(isinstance(i.scale, complex) and i.scale.imag != 0.0 for i in self.integrals) \
+            or any(i._complex_coefficient() for i in self.integrals)
+        if dtype is not None and np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.complex128)):
+            raise TypeError("forms are float64 (float32 containers) or complex128")
+        if cplx and dtype is not None and np.dtype(dtype) != np.dtype(np.complex128):
+            raise TypeError("a complex constant or coefficient needs dtype=complex128")
+        self.dtype = np.dtype(np.complex128) if (cplx or (dtype is not None and np.dtype(dtype) == np.dtype(np.complex128))) \
+            else np.dtype(np.float64)
+        self._scaled = any(complex(i.scale) != 1.0 for i in self.integrals)
+        if self._scaled and self.dtype != np.dtype(np.complex128):
+            raise TypeError("Integral.scale belongs to complex128 forms (fold a real constant into `params`)")
+        self._h_im = None
+
+        def create(part):
+            # (the arrays an Integral hands over live until its next _cstruct call: each form is created -- and its host
+            # arrays uploaded -- before the next one is described)
+            arr = (_lib.Integral * len(self.integrals))(*[i._cstruct(part) for i in self.integrals])
+            h = C.c_void_p()
+            if self.trial_space is not V:
+                if rank != 2:
+                    raise ValueError("a trial space goes with a bilinear form")
+                _lib.check(_lib.lib().cfx_form_create2(V._h, self.trial_space._h, len(self.integrals), arr, C.byref(h)))
+            else:
+                _lib.check(_lib.lib().cfx_form_create(V._h, rank, len(self.integrals), arr, C.byref(h)))
+            return h
+        self._h = None
+        self._h = create("re")
+        if any(i._complex_coefficient() for i in self.integrals):
+            # the imaginary parts of the complex coefficients: a second real form, assembled with the constants i s_k
+            # for the integrals that carry one and 0 for the others
+            self._h_im = create("im")
+
+    def _parts(self):
+        """(form handle, interleaved complex constants) of the real forms that make up this complex128 form."""
+        n = len(self.integrals)
+        s = np.array([complex(i.scale) for i in self.integrals])
+        out = [(self._h, (C.c_double * (2 * n))(*np.column_stack([s.real, s.imag]).ravel()))]
+        if self._h_im is not None:
+            t = np.array([1j * complex(i.scale) if i._complex_coefficient() else 0.0 for i in self.integrals])
+            out.append((self._h_im, (C.c_double * (2 * n))(*np.column_stack([t.real, t.imag]).ravel())))
+        return out
 
     def prepare(self):
         """Build the form's derived tables now (cfx_form_prepare) instead of inside the first assembly call."""
@@ -139,6 +190,9 @@ class CutForm:
             if self._h:
                 _lib.load().cfx_form_destroy(self._h)
                 self._h = None
+            if getattr(self, "_h_im", None):
+                _lib.load().cfx_form_destroy(self._h_im)
+                self._h_im = None
         except Exception:
             pass
 
@@ -170,7 +224,7 @@ class overlap:
         return False
 
 
-def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: FunctionSpace | None = None) -> CutForm:
+def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: FunctionSpace | None = None, dtype=None) -> CutForm:
     """Create a form from integral descriptors (stands in for cutfemx.fem.form).  `V` is the test space; a bilinear
     form whose trial space differs (the off-diagonal blocks of a Stokes system, test_assembly_stokes.py:34-95) names it
     with `trial_space`."""
@@ -180,7 +234,7 @@ def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: Func
         if len(ranks) != 1:
             raise ValueError("all integrals of a form must have the same rank")
         rank = ranks.pop()
-    return CutForm(V, integrals, rank, trial_space)
+    return CutForm(V, integrals, rank, trial_space, dtype)
 
 
 class MatrixCSR:
@@ -191,8 +245,8 @@ class MatrixCSR:
         self.function_space = V
         # scalar type T of la::MatrixCSR<T> (wrappers/fem.cpp:490-500): float64, or float32 through the *_f32 entry points
         self.dtype = np.dtype(_lib.scalar_dtype(values) if dtype is None else dtype)
-        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-            raise TypeError("MatrixCSR holds float64 or float32 values")
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.complex128)):
+            raise TypeError("MatrixCSR holds float64, float32 or complex128 values")
         v = _lib.PatternView()
         _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
         self._view = v
@@ -238,11 +292,11 @@ class MatrixCSR:
     def set_value(self, v: float):
         """la::MatrixCSR::set_value.  Zeroing is deferred to the next use of the values: assemble_matrix then
         clears and assembles in one library call (cfx_assemble_matrix_zeroed)."""
-        if float(v) == 0.0:
+        if complex(v) == 0.0:
             self._zero_pending = True
             return
         self._zero_pending = False
-        z = np.full(self.nnz, float(v), dtype=self.dtype)
+        z = np.full(self.nnz, v if self.dtype == np.dtype(np.complex128) else float(v), dtype=self.dtype)
         _lib.check(_lib.lib().cfx_copy(C.c_void_p(self._vptr), z.ctypes.data_as(C.c_void_p),
                                        C.c_size_t(z.nbytes)))
 
@@ -302,6 +356,8 @@ def create_matrix(a: CutForm, values=None, dtype=None) -> MatrixCSR:
     scalar type of the matrix: float64 (default) or float32."""
     p = C.c_void_p()
     _lib.check(_lib.lib().cfx_create_sparsity(a._h, C.byref(p)))
+    if dtype is None and values is None and a.dtype == np.dtype(np.complex128):
+        dtype = np.complex128
     return MatrixCSR(p, a.function_space, values, dtype)
 
 
@@ -316,6 +372,15 @@ def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixC
         b0, b1 = bcs if isinstance(bcs, tuple) else (bcs, bcs)
         bc0, bc1 = _lib.as_ptr(b0, np.int8, keep), _lib.as_ptr(b1, np.int8, keep)
     l = _lib.lib()
+    if A.dtype == np.dtype(np.complex128):
+        zero = 1 if A._zero_pending else 0
+        A._zero_pending = False
+        for h, scales in a._parts():
+            _lib.check(l.cfx_assemble_matrix_c128(h, A._p, bc0, bc1, scales, zero, C.c_void_p(A._vptr)))
+            zero = 0
+        return A
+    if a.dtype == np.dtype(np.complex128):
+        raise TypeError("a complex128 form assembles into a complex128 matrix (create_matrix(a) makes one)")
     f32 = A.dtype == np.dtype(np.float32)
     if A._zero_pending:     # A.set_value(0) + assemble_matrix(A, a, bcs) as one call
         A._zero_pending = False
@@ -331,7 +396,13 @@ def assemble_vector(L: CutForm, b=None, dtype=np.float64):
     vector, or accumulates into `b` (numpy array or device torch tensor; float64 or float32)."""
     V = L.function_space
     if b is None:
-        b = np.zeros(V.ndofs * V.bs, dtype=dtype)
+        b = np.zeros(V.ndofs * V.bs, dtype=np.complex128 if L.dtype == np.dtype(np.complex128) else dtype)
+    if _lib.scalar_dtype(b) == np.complex128:
+        for h, scales in L._parts():
+            _lib.check(_lib.lib().cfx_assemble_vector_c128(h, scales, _vec_ptr(b)))
+        return b
+    if L.dtype == np.dtype(np.complex128):
+        raise TypeError("a complex128 form assembles into a complex128 vector")
     fn = _lib.lib().cfx_assemble_vector_f32 if _lib.scalar_dtype(b) == np.float32 else _lib.lib().cfx_assemble_vector
     _lib.check(fn(L._h, _vec_ptr(b)))
     return b
@@ -347,6 +418,15 @@ def apply_lifting(b, a: CutForm, bc_markers, bc_values, x0=None, alpha: float = 
     `bc_markers` (int8) / `bc_values` / `x0` hold one entry per dof; one bilinear form,
     i.e. one block of the reference's list-of-forms signature."""
     keep: list = []
+    if _lib.scalar_dtype(b) == np.complex128:
+        g = np.ascontiguousarray(bc_values, dtype=np.complex128)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+        al = complex(alpha)
+        for h, scales in a._parts():
+            _lib.check(_lib.lib().cfx_apply_lifting_c128(
+                h, _lib.as_ptr(bc_markers, np.int8, keep), g.ctypes.data_as(C.c_void_p),
+                None if x is None else x.ctypes.data_as(C.c_void_p), C.c_double(al.real), C.c_double(al.imag), scales, _vec_ptr(b)))
+        return b
     if _lib.scalar_dtype(b) == np.float32:
         _lib.check(_lib.lib().cfx_apply_lifting_f32(
             a._h, _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float32, keep),
@@ -362,6 +442,14 @@ def set_bc(b, bc_markers, bc_values, x0=None, alpha: float = 1.0):
     """b[dofs] = alpha (g - x0) on the marked dofs (dolfinx.fem.set_bc / DirichletBC.set)."""
     keep: list = []
     n = b.numel() if _lib.is_torch(b) else b.size
+    if _lib.scalar_dtype(b) == np.complex128:
+        g = np.ascontiguousarray(bc_values, dtype=np.complex128)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+        al = complex(alpha)
+        _lib.check(_lib.lib().cfx_set_bc_c128(C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), g.ctypes.data_as(C.c_void_p),
+                                             None if x is None else x.ctypes.data_as(C.c_void_p), C.c_double(al.real),
+                                             C.c_double(al.imag), _vec_ptr(b)))
+        return b
     if _lib.scalar_dtype(b) == np.float32:
         _lib.check(_lib.lib().cfx_set_bc_f32(
             C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), _lib.as_ptr(bc_values, np.float32, keep),
@@ -381,7 +469,7 @@ def assemble_scalar(M: CutForm) -> float:
     if M.rank != 1 or any(i.kernel != SOURCE for i in M.integrals):
         raise ValueError("assemble_scalar takes a linear form made of SOURCE integrals (f dx)")
     b = assemble_vector(M)
-    return float(b.sum())
+    return complex(b.sum()) if M.dtype == np.dtype(np.complex128) else float(b.sum())
 
 
 def zero_rows(A: MatrixCSR, *, tol: float = 0.0) -> np.ndarray:
@@ -458,6 +546,12 @@ def deactivate_outside(A: MatrixCSR | None, b, domain: ActiveDomain, diagonal: f
         dts.add(np.dtype(_lib.scalar_dtype(b)))
     if len(dts) > 1:
         raise TypeError("deactivate_outside: matrix and vector must have one scalar type")
+    if dts == {np.dtype(np.complex128)}:
+        d, r = complex(diagonal), complex(rhs_value)
+        _lib.check(_lib.lib().cfx_deactivate_outside_c128(domain._h, A._p if A is not None else None,
+                                                          C.c_void_p(A.values_ptr) if A is not None else None, bp,
+                                                          C.c_double(d.real), C.c_double(d.imag), C.c_double(r.real), C.c_double(r.imag)))
+        return domain
     if dts == {np.dtype(np.float32)}:
         _lib.check(_lib.lib().cfx_deactivate_outside_f32(domain._h, A._p if A is not None else None,
                                                          C.c_void_p(A.values_ptr) if A is not None else None, bp,

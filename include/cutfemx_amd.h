@@ -459,6 +459,24 @@ int cfx_set_bc_f32(int64_t n, const int8_t* bc_markers, const float* bc_values, 
 int cfx_zero_rows_f32(cfx_pattern_t P, const float* values, float tol, int32_t** rows, int64_t* n_rows);
 int cfx_deactivate_outside_f32(cfx_active_t d, cfx_pattern_t pattern, float* values, float* b /* or NULL */,
                                float diagonal, float rhs_value);
+/* ---- complex128 scalars: the <std::complex<double>, double> rows of python/cutfemx/wrappers/fem.cpp:490-500;
+ *      invariants python/tests/test_complex_assembly.py:24-95.  Values, vectors and Dirichlet data are interleaved
+ *      (re, im) doubles; geometry, rules and integrands stay real.  `scales` = the complex constant of every integral
+ *      of the form ([2 * n_integrals] re, im; NULL: all 1): kappa in `kappa inner(grad u, grad v) dx`.  A complex
+ *      coefficient FUNCTION enters linearly: assemble a form of its real parts with scale s and one of its imaginary
+ *      parts with scale i s into the same array (the Python binding does).  Same accumulate semantics as the float64
+ *      entry points; zero_first != 0 = MatrixCSR.set_value(0) first. ---------------------------------------------- */
+int cfx_assemble_matrix_c128(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0, const int8_t* bc1, const double* scales,
+                             int zero_first, double* values /* [2 nnz] */);
+int cfx_assemble_vector_c128(cfx_form_t L, const double* scales, double* b /* [2 n] */);
+int cfx_apply_lifting_c128(cfx_form_t a, const int8_t* bc_markers, const double* bc_values /* [2 n1] */,
+                           const double* x0 /* [2 n1] or NULL */, double alpha_re, double alpha_im, const double* scales,
+                           double* b /* [2 n] */);
+int cfx_set_bc_c128(int64_t n, const int8_t* bc_markers, const double* bc_values, const double* x0, double alpha_re,
+                    double alpha_im, double* b);
+int cfx_deactivate_outside_c128(cfx_active_t domain, cfx_pattern_t pattern, double* values, double* b, double diag_re,
+                                double diag_im, double rhs_re, double rhs_im);
+
 
 /* ---- multi-GPU exchange steps (one rank per GPU; RCCL send/recv over xGMI between the ranks that share dofs) ----
  * The reference's collectives on this path (DOLFINx index maps, MPI neighbourhood exchanges):

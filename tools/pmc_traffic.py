@@ -3,7 +3,7 @@
 (FETCH_SIZE and WRITE_SIZE are reported in KiB... rocprofv3 derives them as requests x 64 B / 1024)."""
 import json, re, sys
 src, mesh = sys.argv[1], sys.argv[2]
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 out = {}
 for line in open(src):
     m = re.match(r"(\S.*?)\s+n=\s*\d+\s+(.*)", line)

@@ -1156,6 +1156,284 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
 }
 
 // ---------------------------------------------------------------------------
+// stage 2, bilinear forms, degree 2 (scalar): the INTERFACE rows in one pass -- the uncut items (closed-form stiffness
+// row), the cut-cell items (one row of the cell's combined tensor, cut_tensors_p2_kernel) and the gradient-jump facet
+// items (rank-one records) of a row, stored when the matrix holds nothing yet.  assemble_rows_kernel walks the cell
+// items and then the facet items, and inside an item one load after the other as the branches ask for them: at three
+// wavefronts per SIMD that kernel spent two thirds of its time parked on ~8 + 4 dependent gathers per pass (47 -> 40 ms
+// at BASELINE config 4).  Here a lane takes the t-th cell item AND the t-th facet item of its row in the same pass and
+// everything that depends on the same index is requested together:
+//   row -> {row pointer, incidence ranges} -> {cell id, facet id} -> {mark, dof row, connectivity row, cut bit word /
+//   rank, facet column ids} -> {vertices, tensor row} -> cell item -> {facet records} -> facet item.
+// ---------------------------------------------------------------------------
+template <int TDIM, int G, int CAP, bool ORDERED>
+__global__ void __launch_bounds__(kWave, 3) assemble_rows_p2_interface_kernel(RowArgs A)
+{
+  constexpr int DEG = 2, ND = Elem<TDIM, DEG>::ND, NV = TDIM + 1, WF = Elem<TDIM, DEG>::WF, NX = WF - ND;
+  constexpr int RPW = kWave / G;
+  // the row's columns as an open-addressing hash map column -> CSR slot (2 CAP keys per row: load factor <= 1/2): a
+  // lookup is a hash and one or two LDS reads where the binary search over the sorted column list took 8 dependent
+  // compare steps -- 24 lookups per pass were 770 of the ~1000 VALU instructions of a pass, and the kernel's VALU
+  // issue alone was half its run time (profiles/r03: 2964 VALU wave-instructions per wavefront)
+  constexpr int HS = 2 * CAP;
+  static_assert((HS & (HS - 1)) == 0, "power of two");
+  constexpr int kHashShift = HS == 128 ? 25 : (HS == 256 ? 24 : (HS == 512 ? 23 : 22)); // multiplicative hash: the top log2(HS) bits
+  static_assert(HS == 128 || HS == 256 || HS == 512 || HS == 1024, "hash shift");
+  __shared__ int32_t s_key[RPW][HS];
+  __shared__ uint16_t s_slot[RPW][HS];
+  __shared__ double s_val[RPW][CAP + 1];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
+  const bool live = ri < A.n_active;
+  const int64_t r = live ? A.active_rows[ri] : 0;
+  const int64_t rb = live ? A.indptr[r] : 0;
+  int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+  const int64_t cb = live ? A.d2c_off[r] : 0;
+  const int nc = (live && len > 0) ? (int)(A.d2c_off[r + 1] - cb) : 0;
+  const bool facets = live && len > 0 && A.d2f_off != nullptr;
+  const int64_t fpos = (facets && A.special_mark[r]) ? (int64_t)A.special_pos[r] : -1;
+  const int64_t fb = fpos >= 0 ? A.d2f_off[fpos] : 0;
+  const int nf = fpos >= 0 ? (int)(A.d2f_off[fpos + 1] - fb) : 0;
+  constexpr int KMAX = CAP / G;
+  for (int k = gl; k < HS; k += G) s_key[grp][k] = -1;
+  __syncthreads();
+  {
+    int32_t mycol[KMAX];
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      mycol[q] = k < len ? A.indices[rb + k] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len)
+      {
+        s_val[grp][k] = 0.0;
+        unsigned h = ((uint32_t)mycol[q] * 2654435761u) >> kHashShift;
+        while (atomicCAS(&s_key[grp][h], -1, mycol[q]) != -1) h = (h + 1) & (HS - 1); // (columns of a row are distinct)
+        s_slot[grp][h] = (uint16_t)k;
+      }
+    }
+  }
+  __syncthreads();
+  const bool row_bc = live && A.bc0 && A.bc0[r];
+  const bool diag_bc = row_bc || (live && A.bc1 != nullptr && A.bc1[r] != 0);
+  double dsum = 0.0;
+  auto find_slot = [&](int32_t col) -> int
+  {
+    unsigned h = ((uint32_t)col * 2654435761u) >> kHashShift;
+    for (int probe = 0; probe < HS; ++probe)
+    {
+      const int32_t key = s_key[grp][h];
+      if (key == col) return (int)s_slot[grp][h];
+      if (key == -1) break;
+      h = (h + 1) & (HS - 1);
+    }
+    *A.error = 1;
+    return -1;
+  };
+  auto add_item = [&](auto nc_tag, bool has, const int32_t* cols, const double* acc, const int* sl)
+  {
+    constexpr int NC = decltype(nc_tag)::value;
+    double v[NC];
+    int sidx[NC];
+#pragma unroll
+    for (int j = 0; j < NC; ++j)
+    {
+      sidx[j] = has ? sl[j] : -1;
+      const bool bc = has && (row_bc || (A.bc1 != nullptr && A.bc1[cols[j]] != 0));
+      v[j] = bc ? 0.0 : acc[j];
+    }
+    if constexpr (ORDERED)
+    {
+      for (int turn = 0; turn < G; ++turn)
+      {
+        if (gl == turn)
+        {
+#pragma unroll
+          for (int j = 0; j < NC; ++j)
+            if (sidx[j] >= 0) s_val[grp][sidx[j]] += v[j];
+        }
+        __syncthreads();
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NC; ++j)
+        if (sidx[j] >= 0) atomicAdd(&s_val[grp][sidx[j]], v[j]);
+    }
+  };
+  int npass = max((nc + G - 1) / G, (nf + G - 1) / G);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) npass = max(npass, __shfl_xor(npass, o, 64)); // (ORDERED: the groups' barriers match)
+  const int64_t last_c = nc > 0 ? cb : 0; // a valid incidence entry for the lanes without an item
+  for (int p = 0; p < npass; ++p)
+  {
+    const int t = p * G + gl;
+    const bool hasc = t < nc, hasf = t < nf;
+    // ---- level 1: the item ids (lanes without an item re-read a valid entry: every load below is unconditional)
+    const int64_t c = A.d2c[hasc ? cb + t : last_c];
+    const int64_t f = hasf ? (int64_t)A.d2f[fb + t] : 0;
+    // ---- level 2: everything addressed by the ids
+    const uint8_t mark = hasc ? (uint8_t)(A.cellmark[c] & A.mark_mask) : (uint8_t)0;
+    int32_t cd[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) cd[j] = A.dofmap[c * ND + j];
+    int32_t cn[NV];
+    if constexpr (TDIM == 3)
+    {
+      const int4 v4 = *reinterpret_cast<const int4*>(A.conn + c * 4);
+      cn[0] = v4.x; cn[1] = v4.y; cn[2] = v4.z; cn[3] = v4.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) cn[i] = A.conn[c * NV + i];
+    }
+    const unsigned long long bw = A.cut_bits ? A.cut_bits[c >> 6] : 0ull;
+    const int32_t rk = A.cut_rank ? A.cut_rank[c >> 6] : 0;
+    const double* blk = A.facet_tensors + f * (int64_t)(8 + 16 * A.facet_nq);
+    int32_t cm[WF];
+    int nfree = NX;
+    if (nf > 0) // (wave-divergent only between rows with and without facets)
+    {
+      const int4* cmp = reinterpret_cast<const int4*>(blk);
+      const int4 q0 = cmp[0], q1 = cmp[1], q2 = cmp[2], q3 = cmp[3];
+      const int32_t c16[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+      for (int j = 0; j < WF; ++j) cm[j] = c16[j];
+      nfree = c16[15];
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < WF; ++j) cm[j] = -1;
+    }
+    // ---- level 3: vertices of the cell, the row of the cut cell's tensor
+    int lr = 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) lr = (cd[j] == (int32_t)r) ? j : lr;
+    Geo<TDIM> g;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) g.x[i][d] = A.x[3 * (int64_t)cn[i] + d];
+    const bool is_cut = (mark & 0xF0u) != 0;
+    const int64_t e = (int64_t)rk + __popcll(bw & ((1ull << (c & 63)) - 1ull));
+    double trow[ND];
+    {
+      // (a lane whose cell is not cut reads row 0 of tensor 0: the load stays unconditional)
+      const double2* T = reinterpret_cast<const double2*>(A.cut_tensors + (is_cut ? (e * ND + lr) * ND : 0));
+#pragma unroll
+      for (int j = 0; j < ND / 2; ++j)
+      {
+        const double2 v = T[j];
+        trow[2 * j] = v.x; trow[2 * j + 1] = v.y;
+      }
+    }
+    // ---- the cell item
+    {
+      double acc[ND];
+      int csl[ND];
+#pragma unroll
+      for (int j = 0; j < ND; ++j) { acc[j] = 0.0; csl[j] = -1; }
+      if (mark)
+      {
+#pragma unroll
+        for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[j]);
+        if (mark & 0x0Fu)
+        {
+          jacobian<TDIM>(g);
+          p2_stiffness_row<TDIM>(g, lr, 1.0, acc);
+        }
+        if (is_cut)
+        {
+#pragma unroll
+          for (int j = 0; j < ND; ++j) acc[j] += trow[j];
+        }
+#pragma unroll
+        for (int j = 0; j < ND; ++j)
+          if (j == lr) { dsum += diag_bc ? 0.0 : acc[j]; csl[j] = -1; }
+      }
+      add_item(std::integral_constant<int, ND>{}, mark != 0, cd, acc, csl);
+    }
+    // ---- the facet item: facet_nq rank-one records (jf_q[0..WF), w_q); row of macro dof m = sum_q w_q jf_q[m] jf_q[.]
+    {
+      double acc[WF];
+      int sl[WF];
+#pragma unroll
+      for (int j = 0; j < WF; ++j) { acc[j] = 0.0; sl[j] = -1; }
+      if (hasf)
+      {
+        int m = -1;
+#pragma unroll
+        for (int j = 0; j < WF; ++j) m = (cm[j] == (int32_t)r) ? j : m;
+        if (nfree != NX) *A.error = 4; // not an interior facet of a conforming mesh with a continuous space
+        const double2* rec = reinterpret_cast<const double2*>(blk + 8);
+        for (int q = 0; q < A.facet_nq; ++q)
+        {
+          double v[16];
+#pragma unroll
+          for (int k = 0; k < 8; ++k)
+          {
+            const double2 pq = rec[q * 8 + k];
+            v[2 * k] = pq.x; v[2 * k + 1] = pq.y;
+          }
+          double jm = 0.0;
+#pragma unroll
+          for (int j = 0; j < WF; ++j) jm = (j == m) ? v[j] : jm;
+          jm *= v[WF];
+#pragma unroll
+          for (int j = 0; j < WF; ++j) acc[j] += jm * v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < WF; ++j) sl[j] = find_slot(cm[j]);
+      }
+      if (nf > 0 || ORDERED) add_item(std::integral_constant<int, WF>{}, hasf, cm, acc, sl);
+    }
+  }
+  {
+    double d = dsum;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
+    if (live && gl == 0 && len > 0 && nc > 0)
+    {
+      const int slot = find_slot((int32_t)r);
+      if (slot >= 0) atomicAdd(&s_val[grp][slot], d);
+    }
+  }
+  __syncthreads();
+  if (A.fresh == 2)
+  {
+#pragma unroll
+    for (int q = 0; q < KMAX; ++q)
+    {
+      const int k = gl + q * G;
+      if (k < len) A.values[rb + k] = s_val[grp][k];
+    }
+    return;
+  }
+  double myval[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    myval[q] = k < len ? A.values[rb + k] : 0.0;
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+  {
+    const int k = gl + q * G;
+    if (k < len) A.values[rb + k] = myval[q] + s_val[grp][k];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // stage 2, bilinear forms, the uncut P1 cells alone.  P1 space on the geometry dofmap:
 // an item is the row's vertex plus the TDIM other vertices of the cell, its row of the
 // stiffness tensor comes from p1_stiffness_row() (6 coordinate loads, no Jacobian
@@ -3435,7 +3713,14 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       else launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, Q);     \
     }                                                                                                                \
   } while (0)
-        if (one_pass)
+        // (decided here, used below: the dedicated interface kernel takes the pattern's short / long lists whole)
+        bool lean_ok = one_pass && (plan.nfacets == 0 || (A.fold_facets == 3 && A.facet_tensors != nullptr));
+        for (int q = 0; q < A.n_cell; ++q)
+          lean_ok = lean_ok && (A.cell[q].std_bits == nullptr || A.cell[q].std_inline == 3);
+        if (const char* li = getenv("CFX_P2_INTERFACE")) lean_ok = lean_ok && li[0] != '0';
+
+        if (lean_ok) {}
+        else if (one_pass)
           CFX_LEAN(16, 256, P->odd_rows.p, P->n_odd_rows);
         else
         {
@@ -3466,7 +3751,31 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         if (S.n_active > 0)
         {
           const dim3 grid = row_grid((S.n_active + 3) / 4);
-          if (one_pass)
+          // every uncut-cell integral the closed-form stiffness row, every facet term as rank-one records (or none):
+          // the dedicated interface kernel; else the general one
+          if (lean_ok)
+          {
+            S.mark_mask = 0xFFu; S.fresh = lazy_zero ? 2 : S.fresh;
+            if (plan.nfacets == 0) { S.d2f_off = nullptr; S.facet_nq = 0; }
+            // the rows of at most 64 columns (edge dofs: most of them) 8 lanes per row with a quarter of the LDS, the
+            // others 16 lanes and 256 columns; the two lists hold every hashed row, the few plain ones among them included
+            RowArgs S1 = S, S2 = S;
+            S1.n_active = P->n_short_rows; S1.active_rows = P->short_rows.p;
+            S2.n_active = P->n_long_rows; S2.active_rows = P->long_rows.p;
+            const dim3 g1 = row_grid((S1.n_active + 7) / 8), g2 = row_grid((S2.n_active + 3) / 4);
+            if (S1.n_active > 0)
+            {
+              if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 8, 64, true>, g1, dim3(kWave), 0, S1);
+              else launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 8, 64, false>, g1, dim3(kWave), 0, S1);
+            }
+            if (S2.n_active > 0)
+            {
+              if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 256, true>, g2, dim3(kWave), 0, S2);
+              else launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 256, false>, g2, dim3(kWave), 0, S2);
+            }
+
+          }
+          else if (one_pass)
           {
             S.mark_mask = 0xFFu; S.fresh = lazy_zero ? 2 : S.fresh;
             if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, 16, 256, true, true, true, true>, grid, dim3(kWave), 0, S);

@@ -548,16 +548,46 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         {
           const int64_t f = P.d2f[fb + ((idx - nc) >> 1)];
           cell = P.facet_rows[4 * f + 2 * ((idx - nc) & 1)];
+          // a facet cell that is a marked incident cell of the row is a source already (on the facets that contain
+          // the row's dof both cells are: ~36 of the ~60 ghost facets around a vertex dof of a Kuhn mesh, the cell
+          // on the row's side of the other 24 as well -- 1440 candidate columns shrink to ~480)
+          if (cells_on)
+          {
+            int lo = 0, hi = nc;
+            while (lo < hi)
+            {
+              const int mid = (lo + hi) >> 1;
+              if (P.d2c[cb + mid] < cell) lo = mid + 1; else hi = mid;
+            }
+            if (lo < nc && P.d2c[cb + lo] == cell && (P.all_cells || P.cellmark[cell])) cell = -1;
+          }
         }
         s_src[grp][t] = cell;
       }
       __syncthreads();
+      // the (source, local dof) pairs, lane after lane: the pair index advances by G, (q, j) follow without a division
+      // (t / nd with a run-time nd was ~20 instructions per candidate).  kU dof-row entries are requested together and
+      // inserted afterwards: with one load per loop trip every trip waited for its own gather (~30 trips x 1.5 us for
+      // a vertex dof of a degree-2 space)
+      constexpr int kU = 8;
       const int npairs = max(m, 0) * P.nd;
-      for (int t = gl; t < npairs; t += G)
+      int q = gl / P.nd, j = gl - q * P.nd;
+      const int dq = G / P.nd, dj = G - dq * P.nd;
+      for (int t0 = gl; t0 < npairs; t0 += G * kU)
       {
-        const int q = t / P.nd;
-        const int64_t cell = s_src[grp][q];
-        if (cell >= 0) ok = hash_insert<T>(tab, P.dofmap[cell * P.nd + (t - q * P.nd)]) && ok;
+        int32_t dv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+        {
+          const bool in = t0 + u * G < npairs;
+          const int64_t cell = in ? (int64_t)s_src[grp][q] : -1;
+          dv[u] = cell >= 0 ? P.dofmap[cell * P.nd + j] : -1;
+          q += dq; j += dj;
+          if (j >= P.nd) { j -= P.nd; ++q; }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+          if (dv[u] >= 0) ok = hash_insert<T>(tab, dv[u]) && ok;
       }
       __syncthreads();
     }

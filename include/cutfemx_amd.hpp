@@ -15,6 +15,7 @@
 // std::invalid_argument, std::runtime_error, std::out_of_range.
 #pragma once
 
+#include <complex>
 #include <cstdint>
 #include <memory>
 #include <span>
@@ -374,6 +375,19 @@ struct Form
   int rank = 2;
   static Form create(const FunctionSpace& V, int rank, std::span<const Integral> integrals)
   {
+    return create_impl(V, nullptr, rank, integrals);
+  }
+  /// bilinear form with different test and trial spaces (Form::function_spaces() = {V_test, V_trial}, Form.h:119-178;
+  /// assemble_matrix_impl.h:68-189): the off-diagonal blocks of a Stokes system (CFX_K_DIV_TEST / CFX_K_DIV_TRIAL),
+  /// mass / stiffness between spaces of different degree
+  static Form create(const FunctionSpace& V_test, const FunctionSpace& V_trial, std::span<const Integral> integrals)
+  {
+    return create_impl(V_test, &V_trial, 2, integrals);
+  }
+
+private:
+  static Form create_impl(const FunctionSpace& V, const FunctionSpace* V_trial, int rank, std::span<const Integral> integrals)
+  {
     std::vector<cfx_integral> raw(integrals.size());
     for (std::size_t i = 0; i < integrals.size(); ++i)
     {
@@ -389,7 +403,8 @@ struct Form
       for (std::size_t k = 0; k < in.params.size() && k < 8; ++k) r.params[k] = in.params[k];
     }
     cfx_form_t h = nullptr;
-    check(cfx_form_create(V.handle.h, rank, static_cast<int>(raw.size()), raw.data(), &h));
+    if (V_trial) check(cfx_form_create2(V.handle.h, V_trial->handle.h, static_cast<int>(raw.size()), raw.data(), &h));
+    else check(cfx_form_create(V.handle.h, rank, static_cast<int>(raw.size()), raw.data(), &h));
     Form a;
     a.handle = detail::Handle<cfx_form_t, cfx_form_destroy>(h);
     a.rank = rank;
@@ -403,6 +418,7 @@ struct SparsityPattern
   detail::Handle<cfx_pattern_t, cfx_pattern_destroy> handle;
   cfx_pattern_view view{};
   std::int64_t num_rows() const { return view.nrows; }
+  std::int64_t num_cols() const { return view.ncols; }
   std::int64_t num_nonzeros() const { return view.nnz; }
   std::vector<std::int64_t> row_ptr() const { return download(view.indptr, view.nrows + 1); }
   std::vector<std::int32_t> cols() const { return download(view.indices, view.nnz); }
@@ -439,6 +455,23 @@ inline void assemble_matrix_zeroed(std::span<double> values, const Form& a, cons
 
 /// assemble_vector(): assembler.h:252-262
 inline void assemble_vector(std::span<double> b, const Form& L) { check(cfx_assemble_vector(L.handle.h, b.data())); }
+
+/// complex128 instantiation (T = std::complex<double>, wrappers/fem.cpp:490-500; test_complex_assembly.py:24-95):
+/// `scales` = the complex constant of every integral of the form (empty: all 1); accumulates into `values` / `b`
+inline void assemble_matrix(std::span<std::complex<double>> values, const Form& a, const SparsityPattern& pattern,
+                            std::span<const std::complex<double>> scales = {}, std::span<const std::int8_t> bc0 = {},
+                            std::span<const std::int8_t> bc1 = {})
+{
+  check(cfx_assemble_matrix_c128(a.handle.h, pattern.handle.h, bc0.empty() ? nullptr : bc0.data(),
+                                 bc1.empty() ? nullptr : bc1.data(),
+                                 scales.empty() ? nullptr : reinterpret_cast<const double*>(scales.data()), 0,
+                                 reinterpret_cast<double*>(values.data())));
+}
+inline void assemble_vector(std::span<std::complex<double>> b, const Form& L, std::span<const std::complex<double>> scales = {})
+{
+  check(cfx_assemble_vector_c128(L.handle.h, scales.empty() ? nullptr : reinterpret_cast<const double*>(scales.data()),
+                                 reinterpret_cast<double*>(b.data())));
+}
 
 /// apply_lifting(): b <- b - alpha A (g - x0) over the Dirichlet columns
 /// (cpp/dolfinx_custom_data/fem/assemble_vector_impl.h:383-436); one form, markers/values per dof

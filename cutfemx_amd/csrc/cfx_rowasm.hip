@@ -400,6 +400,10 @@ struct PatArgs
   // rectangular forms (test space != trial space): the row dof is a dof of another space -- it is not a column of its
   // own row (no_self), and a column dof expands to bs_col entries while a row dof owns bs rows (bs_col = 0: bs)
   int no_self, bs_col;
+  // position of active_rows[i] in the list whose first n_first entries are the plan's special rows in plan order (the
+  // dof -> facets incidence is indexed by that position): saves the special_mark -> special_pos hops; or null
+  const int32_t* row_pos;
+  int64_t n_first;
 };
 
 template <int T>
@@ -432,8 +436,11 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   constexpr int RPW = kWave / G;
   constexpr int kSrc = G >= 16 ? 128 : 8; // source cells staged per row and chunk (degree-2 / vector / 2-D rows)
   __shared__ int32_t s_tab[RPW][T];
-  __shared__ int32_t s_list[RPW][T];
+  __shared__ __align__(16) int32_t s_list[RPW][T];
   __shared__ int32_t s_src[RPW][kSrc];
+  constexpr int kInc = 32; // incident cells kept for the facet cells' look-up (rows with more skip the look-up beyond)
+  __shared__ int32_t s_inc[RPW][kInc];
+  __shared__ uint8_t s_incm[RPW][kInc];
   __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   // one pass for every launch that fits HIP's 2^32-thread limit; the grid is capped beyond it
@@ -525,9 +532,26 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
     const bool cells_on = live && (P.cellmark || P.all_cells);
     const int64_t cb = cells_on ? P.d2c_off[r] : 0;
     const int nc = cells_on ? (int)(P.d2c_off[r + 1] - cb) : 0;
-    const int64_t fpos = (live && P.d2f_off && P.special_mark[r]) ? (int64_t)P.special_pos[r] : -1;
+    int64_t fpos = -1;
+    if (live && P.d2f_off)
+    {
+      if (P.row_pos) { const int32_t rp = P.row_pos[ri]; fpos = rp < P.n_first ? (int64_t)rp : -1; }
+      else if (P.special_mark[r]) fpos = (int64_t)P.special_pos[r];
+    }
     const int64_t fb = fpos >= 0 ? P.d2f_off[fpos] : 0;
     const int nsrc = nc + (fpos >= 0 ? 2 * (int)(P.d2f_off[fpos + 1] - fb) : 0);
+    // the row's incident cells (ascending), kept for the facet cells to look themselves up in: a facet cell that is a
+    // marked incident cell of the row is a source already (on the facets that contain the row's dof both cells are,
+    // ~36 of the ~60 ghost facets around a vertex dof of a Kuhn mesh, the cell on the row's side of the other 24 as
+    // well: 1440 candidate columns shrink to ~480)
+    const int ninc = min(nc, kInc);
+    for (int t = gl; t < ninc; t += G)
+    {
+      const int32_t c = P.d2c[cb + t];
+      s_inc[grp][t] = c;
+      s_incm[grp][t] = (P.all_cells || P.cellmark[c]) ? 1 : 0;
+    }
+    __syncthreads();
     int nchunk = (nsrc + kSrc - 1) / kSrc;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) nchunk = max(nchunk, __shfl_xor(nchunk, o, 64)); // the groups loop together
@@ -541,26 +565,24 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
         int32_t cell;
         if (idx < nc)
         {
-          const int32_t c = P.d2c[cb + idx];
-          cell = (P.all_cells || P.cellmark[c]) ? c : -1;
+          if (idx < ninc) cell = s_incm[grp][idx] ? s_inc[grp][idx] : -1;
+          else
+          {
+            const int32_t c = P.d2c[cb + idx];
+            cell = (P.all_cells || P.cellmark[c]) ? c : -1;
+          }
         }
         else
         {
           const int64_t f = P.d2f[fb + ((idx - nc) >> 1)];
           cell = P.facet_rows[4 * f + 2 * ((idx - nc) & 1)];
-          // a facet cell that is a marked incident cell of the row is a source already (on the facets that contain
-          // the row's dof both cells are: ~36 of the ~60 ghost facets around a vertex dof of a Kuhn mesh, the cell
-          // on the row's side of the other 24 as well -- 1440 candidate columns shrink to ~480)
-          if (cells_on)
+          int lo = 0, hi = ninc;
+          while (lo < hi)
           {
-            int lo = 0, hi = nc;
-            while (lo < hi)
-            {
-              const int mid = (lo + hi) >> 1;
-              if (P.d2c[cb + mid] < cell) lo = mid + 1; else hi = mid;
-            }
-            if (lo < nc && P.d2c[cb + lo] == cell && (P.all_cells || P.cellmark[cell])) cell = -1;
+            const int mid = (lo + hi) >> 1;
+            if (s_inc[grp][mid] < cell) lo = mid + 1; else hi = mid;
           }
+          if (lo < ninc && s_inc[grp][lo] == cell && s_incm[grp][lo]) cell = -1;
         }
         s_src[grp][t] = cell;
       }
@@ -602,12 +624,24 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   }
   __syncthreads();
   const int cnt = s_cnt[grp];
+  // rank = number of smaller entries, four entries per LDS read and trip (the list is padded with INT_MAX to a multiple
+  // of four): the scalar loop -- one read, one compare, one add, counter and branch per entry -- was a third of the
+  // kernel's ~4000 instructions per wavefront, and the kernel is bound by VALU + SALU issue (profiles/r03: 1917 vector
+  // and 1771 scalar instructions per wavefront against 34 vector-memory ones)
+  if (cnt < T)
+    for (int k = cnt + gl; k < ((cnt + 3) & ~3); k += G) s_list[grp][k] = 0x7fffffff;
+  __syncthreads();
   if (P.tmp || P.indices)
     for (int k = gl; k < cnt; k += G)
     {
       const int32_t v = s_list[grp][k];
       int rank = 0;
-      for (int m = 0; m < cnt; ++m) rank += (s_list[grp][m] < v) ? 1 : 0;
+      const int4* l4 = reinterpret_cast<const int4*>(s_list[grp]);
+      for (int m = 0; m < (cnt + 3) / 4; ++m)
+      {
+        const int4 q4 = l4[m];
+        rank += (q4.x < v ? 1 : 0) + (q4.y < v ? 1 : 0) + (q4.z < v ? 1 : 0) + (q4.w < v ? 1 : 0);
+      }
       if (P.indices)
       {
         // second pass of the wide path: the row goes straight into the CSR arrays
@@ -1923,6 +1957,12 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     }
     S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = staged_sets ? tmp_short.p : nullptr;
     S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = staged_sets ? tmp_long.p : nullptr; S2.len = len.p + n_short;
+    // rows_h = [the plan's special rows in plan order | other rows]: the position in rows_h is the facet-incidence index
+    if (rows_h == hashed.p && plan.nfacets > 0)
+    {
+      S1.row_pos = short_idx.p; S1.n_first = plan.n_special_rows;
+      if (n_long > 0) { S2.row_pos = long_idx.p; S2.n_first = plan.n_special_rows; }
+    }
     if (n_short > 0) launch("pattern_rows_short", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
     if (n_long > 0) launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
     if (read_scalar(overflow.p))

@@ -528,6 +528,7 @@ struct cfx_row_plan
   int64_t n_cut_cells = 0;
   cfx::DevArray<int64_t> cut_bits;
   cfx::DevArray<int32_t> cut_rank;
+  cfx::DevArray<int32_t> cut_first[4]; // per cell slot: first rule of every cut cell of the list (-1: none), [n_cut_cells]
   bool cut_cells_built = false;
   int cell_slot_integral[4] = {0, 0, 0, 0};
   int facet_slot_integral[2] = {0, 0};

@@ -3143,6 +3143,7 @@ struct CutSlot
   const int32_t* rule_keys;
   const int32_t* rule_first;
   unsigned rule_mask;
+  const int32_t* cut_first; // [n cut cells]: first rule of the k-th cut cell in this integral, -1 none (plan.cut_first)
 };
 struct CutTensorArgs
 {
@@ -3172,7 +3173,11 @@ __global__ void __launch_bounds__(kBlock, 2) cut_tensors_p2_kernel(CutTensorArgs
   const int64_t k = live ? k0 : A.n - 1;
   const int ci = threadIdx.x / kCutLanes2;
   const int64_t c = A.cut_cells[k];
-  const uint8_t mark = live ? A.cellmark[c] : (uint8_t)0;
+  // the first rule of the cell in every integral comes from a table parallel to the cut-cell list (coalesced, and in
+  // flight together with the cell id) instead of a hash probe behind the cell mark
+  int32_t efirst[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) efirst[i] = (live && i < A.n_slots && A.slot[i].cut_first) ? A.slot[i].cut_first[k] : -1;
   Geo<TDIM> g;
   load_cell<TDIM>(A.x, A.conn, c, g);
   jacobian<TDIM>(g);
@@ -3185,11 +3190,12 @@ __global__ void __launch_bounds__(kBlock, 2) cut_tensors_p2_kernel(CutTensorArgs
   for (int p = 0; p < NO; ++p) To[p] = 0.0;
 #pragma unroll
   for (int p = 0; p < 16; ++p) mom[p] = 0.0;
-  for (int i = 0; i < A.n_slots; ++i)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
   {
-    if (!(mark & (16u << i))) continue;
+    if (i >= A.n_slots || efirst[i] < 0) continue;
     const CutSlot& S = A.slot[i];
-    for (int64_t e = first_rule(S.rule_keys, S.rule_first, S.rule_mask, (int32_t)c); e < S.nr && S.parent_map[e] == c; ++e)
+    for (int64_t e = efirst[i]; e < S.nr && (e == efirst[i] || S.parent_map[e] == c); ++e)
     {
       const int32_t q0 = S.offsets[e], q1 = S.offsets[e + 1];
       for (int32_t q = q0; q < q1; ++q)
@@ -3457,6 +3463,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
             S.points = I.rules->points.p; S.weights = I.rules->weights.p;
             S.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
             S.rule_keys = plan.rule_keys[s].p; S.rule_first = plan.rule_first[s].p; S.rule_mask = plan.rule_mask[s];
+            S.cut_first = plan.cut_first[s].p;
           }
         }
         st.buffers.emplace_back(plan.n_cut_cells * (int64_t)(ND * ND));

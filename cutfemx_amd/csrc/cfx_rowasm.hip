@@ -1713,6 +1713,19 @@ void plain_row_masks(cfx_form_s* a)
   publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
 }
 
+// first rule of every cut cell: rule e opens a new parent -> slot of that parent in the cut-cell list
+__global__ void __launch_bounds__(kBlock) plan_cut_first_kernel(int64_t nr, const int32_t* __restrict__ parent,
+                                                                const unsigned long long* __restrict__ bits,
+                                                                const int32_t* __restrict__ rank, int32_t* __restrict__ first)
+{
+  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (e >= nr) return;
+  const int32_t c = parent[e];
+  if (e > 0 && parent[e - 1] == c) return;
+  const int64_t w = c >> 6;
+  first[(int64_t)rank[w] + __popcll(bits[w] & ((1ull << (c & 63)) - 1ull))] = (int32_t)e;
+}
+
 struct ByteRuleMark
 {
   __device__ bool operator()(uint8_t v) const { return (v & 0xF0u) != 0; }
@@ -1732,6 +1745,15 @@ void plan_cut_cells(cfx_form_s* a)
   launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, plan.cellmark.p, (uint8_t)0xF0u,
          reinterpret_cast<unsigned long long*>(plan.cut_bits.p), pop.p, (int32_t*)nullptr);
   exclusive_scan(pop.p, plan.cut_rank.p, nwords);
+  for (int slot = 0; slot < plan.n_cell_slots; ++slot)
+  {
+    const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[slot]];
+    if (!I.rules || I.rules->nr == 0 || plan.n_cut_cells == 0) continue;
+    plan.cut_first[slot].alloc(plan.n_cut_cells);
+    dev_fill(plan.cut_first[slot].p, 0xff, sizeof(int32_t) * (size_t)plan.n_cut_cells);
+    launch("plan_cut_cells", plan_cut_first_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr, I.rules->parent_map.p,
+           reinterpret_cast<const unsigned long long*>(plan.cut_bits.p), plan.cut_rank.p, plan.cut_first[slot].p);
+  }
   publish_across_lanes();
 }
 
@@ -2078,6 +2100,24 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(n_h), dim3(kWave), 0, S);
     }
   }
+  // full_rows = [dofs with at most 32 neighbours | the others]: the edge dofs of a degree-2 space (7 of 8 dofs, at most
+  // 27 neighbours on Kuhn meshes) need a third of the LDS accumulators of the vertex dofs (65) -- more dofs in flight
+  auto split_full_rows = [&]()
+  {
+    P->n_full_short = 0;
+    if (P->n_full_rows == 0) return;
+    DevArray<int32_t> idx_s, idx_l, sorted(P->n_full_rows);
+    const int64_t ns = compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, false}, idx_s);
+    if (ns > 0 && ns < P->n_full_rows)
+    {
+      (void)compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, true}, idx_l);
+      launch("pattern_full_rows", gather_i32_kernel, grid_for(ns), dim3(kBlock), 0, ns, idx_s.p, P->full_rows.p, sorted.p);
+      launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows - ns), dim3(kBlock), 0, P->n_full_rows - ns,
+             idx_l.p, P->full_rows.p, sorted.p + ns);
+      P->full_rows = std::move(sorted);
+    }
+    P->n_full_short = ns;
+  };
   P->stencil_plan = use_stencil ? plan.serial : 0;
   // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
   P->split_plan = 0;
@@ -2097,23 +2137,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       P->full_rows.alloc(P->n_full_rows);
       launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
              plan.plain_rows.p, P->full_rows.p);
-      // ... split by the length of the static list: the edge dofs of a degree-2 space (7 of 8 dofs, at most 27
-      // neighbours on Kuhn meshes) need a third of the LDS accumulators of the vertex dofs (65) -- more dofs in flight
-      P->n_full_short = 0;
-      if (P->n_full_rows > 0)
-      {
-        DevArray<int32_t> idx_s, idx_l, sorted(P->n_full_rows);
-        const int64_t ns = compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, false}, idx_s);
-        if (ns > 0 && ns < P->n_full_rows)
-        {
-          (void)compact("pattern_full_rows", P->n_full_rows, StaticLenTest{P->full_rows.p, st.offsets.p, 32, true}, idx_l);
-          launch("pattern_full_rows", gather_i32_kernel, grid_for(ns), dim3(kBlock), 0, ns, idx_s.p, P->full_rows.p, sorted.p);
-          launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows - ns), dim3(kBlock), 0, P->n_full_rows - ns,
-                 idx_l.p, P->full_rows.p, sorted.p + ns);
-          P->full_rows = std::move(sorted);
-        }
-        P->n_full_short = ns;
-      }
+      split_full_rows();
       P->n_rest_rows = n_h;
       P->rest_rows.alloc(n_h);
       if (n_h > 0)

@@ -1166,8 +1166,11 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
 //   row -> {row pointer, incidence ranges} -> {cell id, facet id} -> {mark, dof row, connectivity row, cut bit word /
 //   rank, facet column ids} -> {vertices, tensor row} -> cell item -> {facet records} -> facet item.
 // ---------------------------------------------------------------------------
+#ifndef CFX_IFC_WAVES
+#define CFX_IFC_WAVES 3 // waves per SIMD the interface kernel is compiled for
+#endif
 template <int TDIM, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave, 3) assemble_rows_p2_interface_kernel(RowArgs A)
+__global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interface_kernel(RowArgs A)
 {
   constexpr int DEG = 2, ND = Elem<TDIM, DEG>::ND, NV = TDIM + 1, WF = Elem<TDIM, DEG>::WF, NX = WF - ND;
   constexpr int RPW = kWave / G;

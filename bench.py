@@ -412,7 +412,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         # HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc runs of this
         # command, tools/profile_round.sh); only quoted for the mesh they were collected on
         traffic, tnote = None, "no PMC pass for this mesh in profiles/"
-        tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+        tfiles = sorted((ROOT / "profiles").glob("r[0-9][0-9]_traffic.json"))
         if tfiles:
             t = json.loads(tfiles[-1].read_text())      # the latest round's passes
             e = t["kernels"].get(dominant)

@@ -363,6 +363,24 @@ struct Stencil
 };
 constexpr int kRowTile = 16;
 
+// Cell blocks of a space (mesh-static, built on first use by cfx::space_vec_blocks): B consecutive cells and the
+// sorted union of their dofs.  A linear form's element vectors are summed per (block, dof) in LDS and leave the
+// block as one partial per dof of the union -- coalesced 8 B stores instead of one scattered store (or gather) per
+// (cell, local dof) pair -- and a row adds the partials of the few blocks around it.  Every order is static: the
+// entries of a dof inside a block in ascending (cell, local index) order, a row's partials in ascending block order.
+struct VecBlocks
+{
+  bool built = false, usable = false;
+  int B = 0;                  // cells per block: B * ndofs_cell <= 2048 entries
+  int64_t nblocks = 0, u_total = 0;
+  DevArray<int64_t> u_off;    // [nblocks+1] first dof of each block's union
+  DevArray<uint16_t> slot;    // [ncells*nd] position of entry (cell, j) in its block's list sorted by (dof, entry)
+  DevArray<uint16_t> seg;     // [u_total] first sorted position of each dof of the union
+  DevArray<int64_t> p_off;    // [ndofs+1] dof -> its (block, dof of the union) pairs
+  DevArray<int64_t> p_pos;    // (block << 11) | position in the union, ascending
+};
+constexpr int kVbEntries = 2048;
+
 } // namespace cfx
 
 struct cfx_mesh_s
@@ -443,6 +461,7 @@ struct cfx_space_s
   cfx::Adjacency d2c; // dof -> cells
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
+  cfx::VecBlocks vblocks; // built on first use by cfx::space_vec_blocks()
   bool lists_short_overflow = false; // a short-list row overflowed the 128-slot set once: hashed rows all go wide
   bool long_rows = false; // a sparsity build of this space overflowed the 63-entry row sets: start with the wide kernel
   const cfx::Adjacency& dof_cells()
@@ -502,6 +521,15 @@ struct cfx_row_plan
   int64_t vec_t2_total = 0;
   int vec_fast = -1;
   uint8_t vec_mark = 0;
+  // linear forms by cell block (cfx::vec_block_plan, VecBlocks): the blocks that hold a cell with mark `vb_mark`, and
+  // for every block the first of its partials in the step's compact partial array (-1: no such cell, no partials)
+  cfx::DevArray<int32_t> vb_active; // blocks with an uncut entity
+  cfx::DevArray<int32_t> vb_cut;    // blocks with a rule parent (bit 31: no uncut entity in the block)
+  cfx::DevArray<int64_t> vb_base;
+  int64_t n_vb_active = 0, n_vb_cut = 0, vb_total = 0;
+  int vb_state = -1; // -1 not decided, 0 no, 1 yes
+  uint8_t vb_mark = 0;
+  bool vb_merged = false; // vb_active lists every block with a marked cell (one pass), vb_cut is empty
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
   int64_t nfacets = 0;
@@ -558,6 +586,8 @@ void plain_row_masks(cfx_form_s* a);                                    // cfx_r
 void plan_cut_cells(cfx_form_s* a);                                     // cfx_rowasm.hip
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
+const VecBlocks& space_vec_blocks(cfx_space_s* V);                      // cfx_rowasm.hip
+bool vec_block_plan(cfx_form_s* L, uint8_t mark, bool merged);          // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
 void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P);        // cfx_rowasm.hip
 void prepare_form_tables(cfx_form_s* a);                                // cfx_gather.hip

@@ -90,6 +90,7 @@ struct RowIntegral
   const int32_t* std_rank;            // entities before each 64-cell word
   const double* std_tensors; // [n_entities][ND*ND] (rank 2) or [ND][n_entities] (rank 1)
   int64_t n_std;             // n_entities
+  int std_by_cell;           // rank 1: std_tensors is [ND][ncells], indexed by the cell itself (n_std = ncells; unmarked cells unwritten)
   const int32_t* parent_map; // sorted rule parents
   int64_t nr;
   const double* rule_tensors; // [nr][ND*ND] or [nr][ND]; rule_moments: [nr][16]
@@ -271,7 +272,8 @@ struct VecArgs
   double params[8];
   const int32_t* dofmap;
   const double* coeff; // dof values of a CFX_F_COEFFICIENT source, or null
-  double* out; // runtime rules: [n][ND]; uncut entities: [ND][n]
+  double* out; // runtime rules: [n][ND]; uncut entities: [ND][n], or [ND][out_cells] indexed by the cell when out_cells > 0
+  int64_t out_cells;
   // P1 row-ordered staging (cfx_row_plan::vec_t2off): entry i of the cell goes to t2[t2off[dof_i] + cpos[cell][i]]
   // when dof_i is a plain row; the per-cell record is only written for cells with a dof off the plain rows
   const int32_t* t2off;
@@ -304,25 +306,20 @@ __device__ __forceinline__ void store_std_vector(const VecArgs& A, int64_t e, in
   }
   if (record)
   {
+    const int64_t stride = A.out_cells > 0 ? A.out_cells : A.n, at = A.out_cells > 0 ? cell : e;
 #pragma unroll
-    for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + e] = be[i];
+    for (int i = 0; i < ND; ++i) A.out[(int64_t)i * stride + at] = be[i];
   }
 }
 
 // LANES > 1 (runtime rules): a group of lanes shares one rule, the points of the rule are dealt
 // round-robin to the lanes (coalesced point / weight / normal reads, balanced 6-42 point rules) and
 // the ND partial sums are folded with shuffles.
-template <int TDIM, int DEG, bool RUNTIME, int LANES = 1>
-__global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
+// element vector of one entity (an uncut cell, or rule e of a cut cell): lane `sub` of LANES takes the points sub, sub + LANES, ...
+template <int TDIM, int DEG, bool RUNTIME, int LANES>
+__device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64_t cell, int sub, double* be)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
-  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t e = tid / LANES;
-  // LANES == 1: the point index is the same in every lane, so the rule's points / weights (and the P1 basis
-  // values) are scalar loads and scalar operands
-  const int sub = LANES == 1 ? 0 : (int)(tid - e * LANES);
-  if (e >= A.n) return;
-  const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
   Geo<TDIM> g;
   load_cell<TDIM>(A.x, A.conn, cell, g);
   jacobian<TDIM>(g);
@@ -344,7 +341,6 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
     pts = ref_rule(TDIM, A.qdegree, npts, wts);
     wscale = fabs(g.detJ);
   }
-  double be[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) be[i] = 0.0;
   // edges from vertex 0: x(X) = x_0 + sum_t X_t (x_{t+1} - x_0), TDIM fused multiply-adds per coordinate
@@ -405,6 +401,21 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
       }
     }
   }
+}
+
+template <int TDIM, int DEG, bool RUNTIME, int LANES = 1>
+__global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = tid / LANES;
+  // LANES == 1: the point index is the same in every lane, so the rule's points / weights (and the P1 basis
+  // values) are scalar loads and scalar operands
+  const int sub = LANES == 1 ? 0 : (int)(tid - e * LANES);
+  if (e >= A.n) return;
+  const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
+  double be[ND];
+  entity_vector<TDIM, DEG, RUNTIME, LANES>(A, e, cell, sub, be);
   if constexpr (LANES > 1)
   {
 #pragma unroll
@@ -473,7 +484,11 @@ __device__ __forceinline__ void source_load_vertices(const VecArgs& A, SourceCel
 #pragma unroll
   for (int i = 0; i <= TDIM; ++i)
   {
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 4)
+    for (int d = 0; d < TDIM; ++d) c.x[i][d] = 1e-9 * (double)((c.v[i] >> (9 * d)) & 511) + (i == d + 1 ? 1e-3 : 0.0); // ablation: no vertex gathers
+#else
     load_vertex<TDIM>(A.x, c.v[i], c.x[i]);
+#endif
 #if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 2)
     c.t2o[i] = c.v[i]; // ablation: no segment-offset gathers
 #else
@@ -483,8 +498,8 @@ __device__ __forceinline__ void source_load_vertices(const VecArgs& A, SourceCel
 }
 
 template <int TDIM>
-__device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCell<TDIM>& c, bool valid, int npts,
-                                               const double* __restrict__ pts, const double* __restrict__ wts, double fscale)
+__device__ __forceinline__ void source_vector(const SourceCell<TDIM>& c, int npts, const double* __restrict__ pts,
+                                              const double* __restrict__ wts, double fscale, double* be)
 {
   constexpr int ND = TDIM + 1;
   double ed[TDIM][TDIM]; // (x_{t+1} - x_0)_d
@@ -503,7 +518,6 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
     det = ed[0][0] * (ed[1][1] * ed[2][2] - ed[1][2] * ed[2][1]) - ed[0][1] * (ed[1][0] * ed[2][2] - ed[1][2] * ed[2][0])
           + ed[0][2] * (ed[1][0] * ed[2][1] - ed[1][1] * ed[2][0]);
   const double cscale = fscale * fabs(det);
-  double be[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) be[i] = 0.0;
   const double umax = kPi * hmax;
@@ -582,12 +596,26 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
       for (int t = 0; t < TDIM; ++t) be[t + 1] = fma(f, X[t], be[t + 1]);
     }
   }
+}
+
+template <int TDIM>
+__device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCell<TDIM>& c, bool valid, int npts,
+                                               const double* __restrict__ pts, const double* __restrict__ wts, double fscale)
+{
+  constexpr int ND = TDIM + 1;
+  double be[ND];
+  source_vector<TDIM>(c, npts, pts, wts, fscale, be);
   if (!valid) return;
 #if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 1)
   if (be[0] != 1.2345e300) return; // ablation: no stores
 #endif
   // entry i to the segment of row dof_i (store_std_vector, with the gathers already in registers)
   bool record = A.t2 == nullptr;
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 16)
+  for (int i = 0; i < 2; ++i) // ablation: the same bytes in half as many (16 B) stores
+    if (c.t2o[i] >= 0) *reinterpret_cast<cfx_d2u*>(A.t2 + (int64_t)c.t2o[i] + ((c.cp >> (8 * i)) & 0xffu)) = cfx_d2u{be[i], be[i + 2]};
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < ND; ++i)
   {
@@ -597,12 +625,15 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
   if (record)
   {
 #pragma unroll
-    for (int i = 0; i < ND; ++i) A.out[(int64_t)i * A.n + c.e] = be[i];
+    for (int i = 0; i < ND; ++i) A.out[A.out_cells > 0 ? (int64_t)i * A.out_cells + c.cell : (int64_t)i * A.n + c.e] = be[i];
   }
 }
 
+#ifndef CFX_SOURCE_WAVES
+#define CFX_SOURCE_WAVES 3
+#endif
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) vec_source_sin_p1_kernel(VecArgs A)
+__global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_source_sin_p1_kernel(VecArgs A)
 {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -610,6 +641,9 @@ __global__ void __launch_bounds__(kBlock) vec_source_sin_p1_kernel(VecArgs A)
   int npts;
   const double* wts;
   const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 8)
+  npts = 1; // ablation: one point
+#endif
   const double fscale = A.params[1] * ((int)A.params[0] == CFX_F_POISSON_RHS ? (double)TDIM * kPi * kPi : 1.0);
   auto ent = [&](int64_t e) { return A.entities[e < last ? e : last]; }; // (clamped: the tail of the pipeline loads the last cell again)
   SourceCell<TDIM> a, b;
@@ -631,6 +665,233 @@ __global__ void __launch_bounds__(kBlock) vec_source_sin_p1_kernel(VecArgs A)
     b = c;
     cell_c = cell_d;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Linear forms by cell block (cfx::VecBlocks): a workgroup takes B consecutive cells, one per thread, puts their
+// element vectors at the entries' sorted slots in LDS, and thread t adds up the segment of the t-th dof of the
+// block's union -- one partial per (block, dof), stored coalesced.  The rows then add the partials of the blocks
+// around them (vec_blocks_rows_kernel).  Cells without the integral's mark contribute zeros.
+// ---------------------------------------------------------------------------
+struct VecBlockArgs
+{
+  int64_t n_active;          // blocks with a marked cell
+  const int32_t* active;
+  const int64_t* base;       // [nblocks] first partial of the block
+  const int64_t* u_off;
+  const uint16_t* slot;
+  const uint16_t* seg;
+  const uint8_t* cellmark;
+  uint8_t mark;              // the uncut entities of the one integral that has them (0: none)
+  int64_t ncells;
+  double* part;
+  // the runtime rules of cell slot s (mark bit 16 << s): staged element vectors [nr][ND], rules of a cell consecutive
+  struct Rules
+  {
+    const int32_t* parent_map;
+    int64_t nr;
+    const double* tensors;
+    const int32_t* keys;
+    const int32_t* first;
+    unsigned mask;
+  } rules[4];
+  int n_slots;
+};
+
+// ... plus the staged vectors of the cell's runtime rules, slot by slot, rule by rule
+template <int ND>
+__device__ __forceinline__ void add_rule_vectors(const VecBlockArgs& P, int64_t c, unsigned cm, double* be)
+{
+  if ((cm & 0xF0u) == 0) return;
+  for (int s = 0; s < P.n_slots; ++s)
+    if (cm & (16u << s))
+    {
+      const VecBlockArgs::Rules& R = P.rules[s];
+      for (int64_t e = first_rule(R.keys, R.first, R.mask, (int32_t)c); e < R.nr && R.parent_map[e] == c; ++e)
+#pragma unroll
+        for (int j = 0; j < ND; ++j) be[j] += R.tensors[e * ND + j];
+    }
+}
+
+template <int B, int ND, bool ADD>
+__device__ __forceinline__ void block_partials(const VecBlockArgs& P, int64_t k, int nb, const double* s_val)
+{
+  const int64_t ub = P.u_off[k], pb = P.base[k];
+  const int nu = (int)(P.u_off[k + 1] - ub);
+  for (int t = threadIdx.x; t < nu; t += B)
+  {
+    const int s0 = P.seg[ub + t], s1 = t + 1 < nu ? (int)P.seg[ub + t + 1] : nb * ND;
+    double sum = 0.0;
+    for (int q = s0; q < s1; ++q) sum += s_val[q];
+    if (ADD) P.part[pb + t] += sum; else P.part[pb + t] = sum;
+  }
+}
+
+// RULES = 0: the uncut entities (mark P.mark) of the blocks of P.active; RULES = 1: the staged rule vectors of
+// the blocks that hold a rule parent, added to the block's partials (stored when the block holds no uncut entity:
+// bit 31 of the list entry) -- the partials of a block belong to that block alone, so the second pass is race-free;
+// RULES = 2: both in one pass (a cell is an uncut entity or a rule parent)
+template <int TDIM, int DEG, int B, int RULES>
+__global__ void __launch_bounds__(B) vec_blocks_kernel(VecArgs A, VecBlockArgs P)
+{
+  constexpr int ND = Elem<TDIM, DEG>::ND;
+  __shared__ double s_val[B * ND];
+  const int32_t entry = P.active[blockIdx.x];
+  const int64_t k = entry & 0x7fffffff;
+  const int64_t c = k * B + threadIdx.x;
+  const int nb = (int)min((int64_t)B, P.ncells - k * B);
+  const bool inb = threadIdx.x < nb;
+  uint16_t sl[ND];
+  if (inb)
+  {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) sl[j] = P.slot[c * ND + j];
+  }
+  double be[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) be[j] = 0.0;
+  const unsigned cm = inb ? P.cellmark[c] : 0u;
+  if constexpr (RULES != 0) add_rule_vectors<ND>(P, c, cm, be);
+  if constexpr (RULES != 1)
+  {
+    if (cm & P.mark) entity_vector<TDIM, DEG, false, 1>(A, 0, c, 0, be);
+  }
+  if (inb)
+  {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) s_val[sl[j]] = be[j];
+  }
+  __syncthreads();
+  if (RULES == 1 && entry >= 0) block_partials<B, ND, true>(P, k, nb, s_val);
+  else block_partials<B, ND, false>(P, k, nb, s_val);
+}
+
+// ... the sin-product source term on a P1 space (vec_source_sin_p1_kernel's arithmetic and software pipeline: the
+// workgroup walks its blocks with the vertices + segment bounds of the next block and the connectivity + offsets of
+// the one after in flight; the LDS values are double-buffered, one barrier per block)
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_blocks_sin_p1_kernel(VecArgs A, VecBlockArgs P)
+{
+  constexpr int ND = TDIM + 1, B = kBlock;
+  __shared__ double s_val[2][B * ND];
+  int npts;
+  const double* wts;
+  const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 8)
+  npts = 1; // ablation: one point
+#endif
+  const double fscale = A.params[1] * ((int)A.params[0] == CFX_F_POISSON_RHS ? (double)TDIM * kPi * kPi : 1.0);
+  const int64_t nt = P.n_active, stride = gridDim.x, last = P.ncells - 1;
+  auto blk = [&](int64_t i) { return (int64_t)P.active[i < nt ? i : nt - 1]; }; // (clamped: the tail loads the last block again)
+  struct Extra
+  {
+    bool on;
+    uint16_t sl[ND];
+    int64_t k, ub, pb; // block, first dof of its union, first partial
+    int nu, nb, s0, s1; // dofs of the union, cells of the block, this thread's segment
+  };
+  auto stage = [&](int64_t k, SourceCell<TDIM>& c, Extra& x)
+  {
+    const int64_t cell = k * B + threadIdx.x;
+    c.cell = (int32_t)(cell < last ? cell : last);
+    source_load_conn<TDIM>(A, c);
+    x.on = cell <= last && (P.cellmark[c.cell] & P.mark) != 0;
+#pragma unroll
+    for (int j = 0; j < ND; ++j) x.sl[j] = P.slot[(int64_t)c.cell * ND + j];
+    x.k = k; x.ub = P.u_off[k]; x.nu = (int)(P.u_off[k + 1] - x.ub); x.pb = P.base[k];
+    x.nb = (int)min((int64_t)B, P.ncells - k * B);
+  };
+  auto stage2 = [&](SourceCell<TDIM>& c, Extra& x)
+  {
+    source_load_vertices<TDIM>(A, c);
+    const int t = threadIdx.x;
+    x.s0 = t < x.nu ? (int)P.seg[x.ub + t] : 0;
+    x.s1 = t + 1 < x.nu ? (int)P.seg[x.ub + t + 1] : x.nb * ND;
+  };
+  SourceCell<TDIM> a, b;
+  Extra xa, xb;
+  const int64_t i0 = blockIdx.x;
+  int64_t k_c = blk(i0 + 2 * stride);
+  stage(blk(i0), a, xa);
+  stage(blk(i0 + stride), b, xb);
+  stage2(a, xa);
+  int buf = 0;
+  for (int64_t i = i0; i < nt; i += stride)
+  {
+    const int64_t k_d = blk(i + 3 * stride);
+    SourceCell<TDIM> c;
+    Extra xc;
+    stage(k_c, c, xc);
+    stage2(b, xb);
+    double be[ND];
+#pragma unroll
+    for (int j = 0; j < ND; ++j) be[j] = 0.0;
+    if (__ballot(xa.on) != 0) source_vector<TDIM>(a, npts, pts, wts, fscale, be); // (a wavefront without a marked cell: the ends of a block)
+    double* sv = s_val[buf];
+    if ((int)threadIdx.x < xa.nb)
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) sv[xa.sl[j]] = xa.on ? be[j] : 0.0;
+    }
+#if !(defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 32))
+    __syncthreads(); // (the other buffer is written by the next trip: its readers of the previous trip have passed this barrier)
+#endif
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 64)
+    if (be[0] == 1.2345e300) // ablation: no segment sums, no partial stores
+#endif
+    if ((int)threadIdx.x < xa.nu)
+    {
+      double sum = 0.0;
+      for (int q = xa.s0; q < xa.s1; ++q) sum += sv[q];
+      P.part[xa.pb + threadIdx.x] = sum;
+    }
+    for (int t = threadIdx.x + B; t < xa.nu; t += B) // a union longer than the block (not on box meshes)
+    {
+      const int s0 = P.seg[xa.ub + t], s1 = t + 1 < xa.nu ? (int)P.seg[xa.ub + t + 1] : xa.nb * ND;
+      double sum = 0.0;
+      for (int q = s0; q < s1; ++q) sum += sv[q];
+      P.part[xa.pb + t] = sum;
+    }
+    buf ^= 1;
+    a = b; xa = xb;
+    b = c; xb = xc;
+    k_c = k_d;
+  }
+}
+
+// stage 2: b[r] += the partials of the blocks around row r, in ascending block order (then a fixed tree over the
+// row's lanes: bitwise reproducible).  base[] = -1 for a block without a marked cell (nothing was written for it)
+template <int G>
+__global__ void __launch_bounds__(kWave) vec_blocks_rows_kernel(int64_t n, const int32_t* __restrict__ rows,
+                                                                const int64_t* __restrict__ p_off,
+                                                                const int64_t* __restrict__ p_pos,
+                                                                const int64_t* __restrict__ base,
+                                                                const double* __restrict__ part, double* __restrict__ b)
+{
+  const int lane = threadIdx.x, gl = lane % G;
+  const int64_t i = CFX_ROW_BLOCK * (kWave / G) + lane / G;
+  const bool live = i < n;
+  const int64_t r = live ? rows[i] : 0;
+  const int64_t o0 = live ? p_off[r] : 0;
+  const int np = live ? (int)(p_off[r + 1] - o0) : 0;
+  double sum = 0.0;
+  constexpr int Q = 2; // the first Q entries of the lane are requested together
+  int64_t e[Q], bb[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) e[q] = gl + q * G < np ? p_pos[o0 + gl + q * G] : -1;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) bb[q] = e[q] >= 0 ? base[e[q] >> 11] : -1;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (bb[q] >= 0) sum += part[bb[q] + (e[q] & 2047)];
+  for (int q = gl + Q * G; q < np; q += G)
+  {
+    const int64_t ee = p_pos[o0 + q], b0 = base[ee >> 11];
+    if (b0 >= 0) sum += part[b0 + (ee & 2047)];
+  }
+#pragma unroll
+  for (int d = G / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, G);
+  if (live && gl == 0) b[r] += sum;
 }
 
 // ---------------------------------------------------------------------------
@@ -2580,8 +2841,8 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
       for (int i = 0; i < A.n_cell; ++i)
       {
         const RowIntegral& I = A.cell[i];
-        if (mk[k] & (1u << i))
-          part += I.std_tensors[(int64_t)lr[k] * I.n_std + entity_index(I.std_bits, I.std_rank, c)];
+        if ((mk[k] & (1u << i)) && I.std_tensors)
+          part += I.std_tensors[(int64_t)lr[k] * I.n_std + (I.std_by_cell ? c : entity_index(I.std_bits, I.std_rank, c))];
         if (mk[k] & (16u << i))
           for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
             part += I.rule_tensors[e * ND + lr[k]];
@@ -3306,30 +3567,87 @@ struct Stage1
   std::vector<DevArray<double>> buffers;
   DevArray<double> t2;      // linear forms, P1: row-ordered staging of the uncut cells (run_vector), else empty
   double* vec_t2 = nullptr;
+  bool vec_blocks = false;  // linear forms: the uncut cells go by cell block (run_vector), nothing is staged per cell
+  DevArray<double> part;    // ... the partials of the step
 };
 
-template <int TDIM, int DEG>
-void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out, double* t2 = nullptr)
+inline VecArgs vec_args(cfx_form_s* L, const cfx_integral_dev& I)
 {
   cfx_space_s* V = L->V;
   VecArgs A{};
-  if (t2 && !runtime)
-  {
-    A.t2 = t2; A.t2off = row_plan(L).vec_t2off.p; A.cpos = space_stencil(V).cpos.p;
-  }
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p;
   A.kernel = I.kernel; A.qdegree = I.qdegree; A.point_stride = I.point_stride;
   for (int k = 0; k < 8; ++k) A.params[k] = I.params[k];
   A.dofmap = V->dofmap.p;
   A.coeff = I.coefficient.n > 0 ? I.coefficient.p : nullptr;
+  return A;
+}
+
+// the sin-product source term on a P1 space over the geometry dofmap: the series kernels serve it
+template <int DEG>
+inline bool source_series_ok(const cfx_space_s* V, const cfx_integral_dev& I)
+{
+  const int field = (int)I.params[0];
+  const char* fs = getenv("CFX_SOURCE_SERIES");
+  return DEG == 1 && I.kernel == CFX_L_SOURCE && I.coefficient.n == 0 && (field == CFX_F_SINPROD || field == CFX_F_POISSON_RHS)
+         && V->dofmap.p == V->mesh->conn.p && !(fs && fs[0] == '0');
+}
+
+// stage 1 of a linear form by cell block: the partials of the uncut cells of integral I (mark bit `mark`)
+template <int TDIM, int DEG>
+void vec_block_partials(cfx_form_s* L, const cfx_integral_dev* Istd, uint8_t mark, const RowArgs& R, double* part)
+{
+  cfx_space_s* V = L->V;
+  cfx_row_plan& plan = row_plan(L);
+  const VecBlocks& S = space_vec_blocks(V);
+  constexpr int ND = Elem<TDIM, DEG>::ND, B = ND <= 8 ? 256 : 128;
+  if (S.B != B) throw Error(CFX_ERR_RUNTIME, "vec_block_partials: block size of the space's cell blocks");
+  VecArgs A{};
+  if (Istd) A = vec_args(L, *Istd);
+  VecBlockArgs P{};
+  P.n_active = plan.n_vb_active; P.active = plan.vb_active.p; P.base = plan.vb_base.p; P.u_off = S.u_off.p;
+  P.slot = S.slot.p; P.seg = S.seg.p; P.cellmark = plan.cellmark.p; P.mark = mark; P.ncells = V->mesh->ncells; P.part = part;
+  P.n_slots = R.n_cell;
+  for (int s = 0; s < R.n_cell; ++s)
+  {
+    const RowIntegral& I = R.cell[s];
+    P.rules[s] = {I.parent_map, I.rule_tensors ? I.nr : 0, I.rule_tensors, I.rule_keys, I.rule_first, I.rule_mask};
+  }
+  if (P.n_active == 0) {}
+  else if (Istd && source_series_ok<DEG>(V, *Istd))
+  {
+    if constexpr (DEG == 1)
+    {
+      const int64_t blocks = std::min<int64_t>(P.n_active, 256 * CFX_SOURCE_BLOCKS_PER_CU);
+      launch("vec_blocks_std", vec_blocks_sin_p1_kernel<TDIM>, dim3((unsigned)blocks), dim3(kBlock), 0, A, P);
+    }
+  }
+  else if (plan.vb_merged)
+    launch("vec_blocks_std", vec_blocks_kernel<TDIM, DEG, B, 2>, dim3((unsigned)P.n_active), dim3(B), 0, A, P);
+  else
+    launch("vec_blocks_std", vec_blocks_kernel<TDIM, DEG, B, 0>, dim3((unsigned)P.n_active), dim3(B), 0, A, P);
+  if (plan.n_vb_cut > 0)
+  {
+    P.n_active = plan.n_vb_cut; P.active = plan.vb_cut.p;
+    launch("vec_blocks_cut", vec_blocks_kernel<TDIM, DEG, B, 1>, dim3((unsigned)P.n_active), dim3(B), 0, A, P);
+  }
+}
+
+template <int TDIM, int DEG>
+void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out, double* t2 = nullptr, int64_t out_cells = 0)
+{
+  cfx_space_s* V = L->V;
+  VecArgs A = vec_args(L, I);
+  A.out_cells = out_cells;
+  if (t2 && !runtime)
+  {
+    A.t2 = t2; A.t2off = row_plan(L).vec_t2off.p; A.cpos = space_stencil(V).cpos.p;
+  }
   A.out = out;
   if (!runtime)
   {
     A.n = I.n_entities; A.entities = I.entities.p;
-    const int field = (int)I.params[0];
-    const char* fs = getenv("CFX_SOURCE_SERIES");
-    if (DEG == 1 && I.kernel == CFX_L_SOURCE && !A.coeff && (field == CFX_F_SINPROD || field == CFX_F_POISSON_RHS)
-        && V->dofmap.p == V->mesh->conn.p && !(fs && fs[0] == '0'))
+    if (source_series_ok<DEG>(V, I))
     {
       if constexpr (DEG == 1)
       {
@@ -3416,13 +3734,20 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
       // ... and the vector-valued elasticity term likewise (closed-form block rows)
       if (DEG == 2 && BS == TDIM && p2_elasticity_closed(a, I)) R.std_inline = 3;
     }
-    if (!R.std_inline && I.n_entities > 0)
+    if (a->rank == 1 && st.vec_blocks && I.n_entities > 0)
+      R.std_tensors = nullptr; // (the uncut cells reach the rows as block partials, run_vector)
+    else if (!R.std_inline && I.n_entities > 0)
     {
-      st.buffers.emplace_back(I.n_entities * tsize);
+      // linear forms whose entity list covers a good part of the mesh stage [ND][ncells]: the rows index the record by
+      // the cell they hold anyway, without the bitset + rank lookup of the entity index (two gathers per item)
+      const char* bc = getenv("CFX_VEC_BY_CELL");
+      const bool by_cell = a->rank == 1 && BS == 1 && !st.vec_t2 && I.n_entities * 4 >= V->mesh->ncells && !(bc && bc[0] == '0');
+      st.buffers.emplace_back((by_cell ? V->mesh->ncells : I.n_entities) * tsize);
       R.std_tensors = st.buffers.back().p;
-      R.n_std = I.n_entities;
+      R.n_std = by_cell ? V->mesh->ncells : I.n_entities;
+      R.std_by_cell = by_cell ? 1 : 0;
       if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
-      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p, st.vec_t2);
+      else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p, st.vec_t2, by_cell ? V->mesh->ncells : 0);
     }
     if (I.rules && I.rules->nr > 0 && combine_cuts)
     {
@@ -3925,6 +4250,9 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 #ifndef CFX_VEC_PLAIN_G
 #define CFX_VEC_PLAIN_G 4
 #endif
+#ifndef CFX_VEC_BLOCK_G
+#define CFX_VEC_BLOCK_G 4 // lanes per row of vec_blocks_rows_kernel
+#endif
 template <int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
                                                                    const int64_t* __restrict__ d2c_off,
@@ -3958,19 +4286,52 @@ __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_pla
   if (live && gl == 0 && o >= 0) b[r] += part;
 }
 
+// Which way the uncut cells and rules of a linear form reach the rows.  The series source term on a P1 space keeps the
+// row-ordered staging when the plan offers it (512^3: 2.65 + 0.73 ms against 2.8 + 0.55 ms by cell block, and the
+// rule items by row 0.6 ms against 0.85 ms by block); every other form goes by cell block, uncut entities and rule
+// parents in one pass.  CFX_VEC_BLOCKS=0: never by block; =2: always.
+struct BlockChoice { bool use, merged; };
+template <int DEG>
+BlockChoice vec_block_choice(cfx_form_s* L, cfx_row_plan& plan, int slot, int count)
+{
+  const char* e = getenv("CFX_VEC_BLOCKS");
+  if ((e && e[0] == '0') || count > 1 || L->V->bs != 1 || !plan.usable) return {false, false};
+  const bool series = count == 1 && source_series_ok<DEG>(L->V, L->integrals[plan.cell_slot_integral[slot]]);
+  if (series && !(e && e[0] == '2'))
+  {
+    const char* ro = getenv("CFX_VEC_ROWORDER");
+    if (!(ro && ro[0] == '0') && plain_vec_offsets(L, (uint8_t)(1u << slot))) return {false, false};
+  }
+  return {true, !series};
+}
+
 template <int TDIM, int DEG>
 void run_vector(cfx_form_s* L, double* b)
 {
   Stage1 st;
   cfx_row_plan& plan = row_plan(L);
+  // one integral with uncut entities (the volume term)
+  int slot = -1, count = 0;
+  for (int s = 0; s < plan.n_cell_slots; ++s)
+    if (L->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+  // ... by cell block: partials per (block, dof) of the uncut cells and the runtime rules, then the rows add the
+  // partials of the blocks around them
+  const uint8_t std_mark = count == 1 ? (uint8_t)(1u << slot) : (uint8_t)0;
+  uint8_t rule_marks = 0;
+  for (int s = 0; s < plan.n_cell_slots; ++s)
+  {
+    const cfx_integral_dev& I = L->integrals[plan.cell_slot_integral[s]];
+    if (I.rules && I.rules->nr > 0) rule_marks |= (uint8_t)(16u << s);
+  }
+  const BlockChoice bc = vec_block_choice<DEG>(L, plan, slot, count);
+  if (bc.use && (std_mark | rule_marks) != 0 && vec_block_plan(L, (uint8_t)(std_mark | rule_marks), bc.merged))
+    st.vec_blocks = true;
   if constexpr (DEG == 1)
   {
-    // one integral with uncut entities (the volume term): its element vectors go to the plain rows directly
-    int slot = -1, count = 0;
-    for (int s = 0; s < plan.n_cell_slots; ++s)
-      if (L->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+    // ... or (CFX_VEC_BLOCKS=0) its element vectors go to the plain rows directly
     const char* ro = getenv("CFX_VEC_ROWORDER");
-    if (count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0') && plain_vec_offsets(L, (uint8_t)(1u << slot)))
+    if (!st.vec_blocks && count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0')
+        && plain_vec_offsets(L, (uint8_t)(1u << slot)))
     {
       st.t2.alloc(plan.vec_t2_total);
       st.vec_t2 = st.t2.p;
@@ -3978,6 +4339,19 @@ void run_vector(cfx_form_s* L, double* b)
   }
   RowArgs A = prepare<TDIM, DEG>(L, st);
   A.values = b;
+  if (st.vec_blocks)
+  {
+    st.part.alloc(plan.vb_total);
+    vec_block_partials<TDIM, DEG>(L, count == 1 ? &L->integrals[plan.cell_slot_integral[slot]] : nullptr, std_mark, A, st.part.p);
+    if (plan.n_active_rows > 0 && plan.vb_total > 0)
+    {
+      const VecBlocks& S = space_vec_blocks(L->V);
+      constexpr int G = CFX_VEC_BLOCK_G;
+      launch("vec_blocks_rows", vec_blocks_rows_kernel<G>, row_grid((plan.n_active_rows + (kWave / G) - 1) / (kWave / G)), dim3(kWave),
+             0, plan.n_active_rows, plan.active_rows.p, S.p_off.p, S.p_pos.p, plan.vb_base.p, st.part.p, b);
+    }
+    return;
+  }
   if constexpr (DEG == 1)
   {
     const Stencil& stn = space_stencil(L->V);
@@ -4069,6 +4443,23 @@ void prepare_form_tables(cfx_form_s* a)
   const Stencil& stn = space_stencil(V);
   if (V->degree == 2) (void)space_stencil_slotn(V);
   if (plan.nfacets > 0) (void)V->mesh->cell_neighbours();
+  if (a->rank == 1 && plan.usable && V->bs == 1)
+  {
+    int slot = -1, count = 0;
+    for (int s = 0; s < plan.n_cell_slots; ++s)
+      if (a->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+    uint8_t marks = count == 1 ? (uint8_t)(1u << slot) : (uint8_t)0;
+    for (int s = 0; s < plan.n_cell_slots; ++s)
+    {
+      const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[s]];
+      if (I.rules && I.rules->nr > 0) marks |= (uint8_t)(16u << s);
+    }
+    if (count <= 1 && marks != 0)
+    {
+      const BlockChoice bc = V->degree == 1 ? vec_block_choice<1>(a, plan, slot, count) : vec_block_choice<2>(a, plan, slot, count);
+      if (bc.use && vec_block_plan(a, marks, bc.merged)) return;
+    }
+  }
   if (!plan.usable || V->degree != 1 || V->bs != 1) return;
   if (!stn.usable) return;
   (void)space_stencil_tiles(V);

@@ -1835,6 +1835,223 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   return true;
 }
 
+// ---------------------------------------------------------------------------
+// Cell blocks (VecBlocks): one workgroup per block sorts the block's (dof, entry) pairs in LDS (bitonic, up to
+// kVbEntries keys); the sorted position of an entry is its slot, the first position of every dof its segment.
+// Pass 1 counts the dofs of each union, pass 2 writes slot / seg / the union itself.
+// ---------------------------------------------------------------------------
+template <bool WRITE>
+__global__ void __launch_bounds__(kBlock) vec_blocks_kernel(int64_t ncells, int nd, int B, const int32_t* __restrict__ dofmap,
+                                                            int32_t* __restrict__ counts, const int64_t* __restrict__ u_off,
+                                                            int32_t* __restrict__ u_dofs, uint16_t* __restrict__ slot,
+                                                            uint16_t* __restrict__ seg)
+{
+  __shared__ unsigned long long s_key[kVbEntries];
+  const int tid = threadIdx.x;
+  const int64_t k = blockIdx.x, c0 = k * B;
+  const int nb = (int)min((int64_t)B, ncells - c0), n = nb * nd;
+  int N = kBlock; // keys sorted: a power of two >= n (and >= the block, every thread owns N / kBlock of them)
+  while (N < n) N <<= 1;
+  for (int e = tid; e < N; e += kBlock)
+    s_key[e] = e < n ? (((unsigned long long)(uint32_t)dofmap[c0 * nd + e] << 11) | (unsigned)e) : ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= N; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1)
+    {
+      for (int i = tid; i < N / 2; i += kBlock)
+      {
+        const int pos = 2 * i - (i & (stride - 1)), other = pos + stride;
+        const unsigned long long a = s_key[pos], b = s_key[other];
+        const bool up = (pos & size) == 0;
+        if ((a > b) == up) { s_key[pos] = b; s_key[other] = a; }
+      }
+      __syncthreads();
+    }
+  // heads of the runs of equal dofs; thread t owns the sorted positions [t E, (t + 1) E)
+  const int E = N / kBlock;
+  int heads = 0;
+  for (int q = 0; q < E; ++q)
+  {
+    const int e = tid * E + q;
+    if (e < n && (e == 0 || (s_key[e] >> 11) != (s_key[e - 1] >> 11))) ++heads;
+  }
+  int total;
+  int t = block_exclusive_scan<int>(heads, total);
+  if constexpr (!WRITE)
+  {
+    if (tid == 0) counts[k] = total;
+  }
+  else
+  {
+    const int64_t ub = u_off[k];
+    for (int q = 0; q < E; ++q)
+    {
+      const int e = tid * E + q;
+      if (e >= n) break;
+      const unsigned long long key = s_key[e];
+      slot[c0 * nd + (int)(key & 2047u)] = (uint16_t)e;
+      if (e == 0 || (key >> 11) != (s_key[e - 1] >> 11))
+      {
+        seg[ub + t] = (uint16_t)e;
+        u_dofs[ub + t] = (int32_t)(key >> 11);
+        ++t;
+      }
+    }
+  }
+}
+
+__global__ void vb_count_kernel(int64_t n, const int32_t* __restrict__ u_dofs, int32_t* __restrict__ cnt)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&cnt[u_dofs[i]], 1);
+}
+
+__global__ void __launch_bounds__(kBlock) vb_fill_kernel(const int64_t* __restrict__ u_off, const int32_t* __restrict__ u_dofs,
+                                                         const int64_t* __restrict__ p_off, int32_t* __restrict__ cursor,
+                                                         int64_t* __restrict__ p_pos)
+{
+  const int64_t k = blockIdx.x, ub = u_off[k];
+  const int nu = (int)(u_off[k + 1] - ub);
+  for (int t = threadIdx.x; t < nu; t += kBlock)
+  {
+    const int32_t dof = u_dofs[ub + t];
+    p_pos[p_off[dof] + atomicAdd(&cursor[dof], 1)] = (k << 11) | t;
+  }
+}
+
+// the pairs of a dof in ascending block order (the fill above is in arrival order); the lists are a handful long
+__global__ void vb_sort_kernel(int64_t ndofs, const int64_t* __restrict__ p_off, int64_t* __restrict__ p_pos)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= ndofs) return;
+  const int64_t b = p_off[r], e = p_off[r + 1];
+  for (int64_t i = b + 1; i < e; ++i)
+  {
+    const int64_t v = p_pos[i];
+    int64_t j = i;
+    while (j > b && p_pos[j - 1] > v) { p_pos[j] = p_pos[j - 1]; --j; }
+    p_pos[j] = v;
+  }
+}
+
+const VecBlocks& space_vec_blocks(cfx_space_s* V)
+{
+  VecBlocks& S = V->vblocks;
+  if (S.built) return S;
+  S.built = true;
+  const char* env = getenv("CFX_VEC_BLOCKS");
+  if (env && env[0] == '0') return S;
+  const int nd = V->ndofs_cell;
+  const int64_t nc = V->mesh->ncells;
+  if (V->bs != 1 || nc == 0) return S;
+  int B = 256;
+  while (B * nd > kVbEntries) B >>= 1;
+  if (B < 32) return S;
+  S.B = B;
+  S.nblocks = (nc + B - 1) / B;
+  if (S.nblocks > 0x7fffffffLL) return S;
+  DevArray<int32_t> counts(S.nblocks);
+  launch("vec_blocks", vec_blocks_kernel<false>, dim3((unsigned)S.nblocks), dim3(kBlock), 0, nc, nd, B, V->dofmap.p, counts.p,
+         (const int64_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, (uint16_t*)nullptr);
+  S.u_off.alloc(S.nblocks + 1);
+  exclusive_scan(counts.p, S.u_off.p, S.nblocks);
+  S.u_total = read_scalar(S.u_off.p + S.nblocks);
+  DevArray<int32_t> u_dofs(S.u_total);
+  S.slot.alloc(nc * nd);
+  S.seg.alloc(S.u_total);
+  launch("vec_blocks_write", vec_blocks_kernel<true>, dim3((unsigned)S.nblocks), dim3(kBlock), 0, nc, nd, B, V->dofmap.p,
+         (int32_t*)nullptr, S.u_off.p, u_dofs.p, S.slot.p, S.seg.p);
+  // dof -> (block, position in the union) pairs: count, scan, fill, order
+  DevArray<int32_t> cnt(V->ndofs);
+  dev_fill(cnt.p, 0, sizeof(int32_t) * (size_t)V->ndofs);
+  launch("vec_blocks_lists", vb_count_kernel, grid_for(S.u_total), dim3(kBlock), 0, S.u_total, u_dofs.p, cnt.p);
+  S.p_off.alloc(V->ndofs + 1);
+  exclusive_scan(cnt.p, S.p_off.p, V->ndofs);
+  S.p_pos.alloc(S.u_total);
+  dev_fill(cnt.p, 0, sizeof(int32_t) * (size_t)V->ndofs);
+  launch("vec_blocks_lists", vb_fill_kernel, dim3((unsigned)S.nblocks), dim3(kBlock), 0, S.u_off.p, u_dofs.p, S.p_off.p, cnt.p,
+         S.p_pos.p);
+  launch("vec_blocks_lists", vb_sort_kernel, grid_for(V->ndofs), dim3(kBlock), 0, V->ndofs, S.p_off.p, S.p_pos.p);
+  S.usable = true;
+  publish_across_lanes();
+  return S;
+}
+
+// per block: the size of its union if one of its cells carries a bit of `mark`, else 0, and which kinds of cells it
+// holds (bit 0: uncut entities, mark & 0x0F; bit 1: parents of runtime rules, mark & 0xF0); one wavefront per block
+__global__ void __launch_bounds__(kBlock) vb_flag_kernel(int64_t nblocks, int B, int64_t ncells, const uint8_t* __restrict__ cellmark,
+                                                         uint8_t mark, const int64_t* __restrict__ u_off, int32_t* __restrict__ len,
+                                                         uint8_t* __restrict__ kind)
+{
+  const int lane = threadIdx.x & 63;
+  const int64_t k = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+  if (k >= nblocks) return;
+  const int64_t c0 = k * B;
+  uint32_t acc = 0;
+  for (int o = lane * 4; o < B; o += kWave * 4) // B is a multiple of 32 and the cell array of a block 4 B aligned
+  {
+    uint32_t w = 0;
+    if (c0 + o + 4 <= ncells) w = *reinterpret_cast<const uint32_t*>(cellmark + c0 + o);
+    else
+      for (int q = 0; q < 4; ++q)
+        if (c0 + o + q < ncells) w |= (uint32_t)cellmark[c0 + o + q] << (8 * q);
+    acc |= w & (0x01010101u * mark);
+  }
+  const bool has_std = __ballot((acc & 0x0F0F0F0Fu) != 0) != 0, has_cut = __ballot((acc & 0xF0F0F0F0u) != 0) != 0;
+  if (lane == 0)
+  {
+    len[k] = (has_std || has_cut) ? (int32_t)(u_off[k + 1] - u_off[k]) : 0;
+    kind[k] = (uint8_t)((has_std ? 1 : 0) | (has_cut ? 2 : 0));
+  }
+}
+
+// base[k] = -1 for the blocks without partials; a block of the cut list that holds no uncut entity gets bit 31 (its
+// partials are stored, not added to the ones of the uncut cells)
+__global__ void vb_base_kernel(int64_t nblocks, const int32_t* __restrict__ len, int64_t* __restrict__ base, int64_t n_cut,
+                               int32_t* __restrict__ cut_list, const uint8_t* __restrict__ kind)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nblocks && len[k] == 0) base[k] = -1;
+  if (k < n_cut && !(kind[cut_list[k]] & 1)) cut_list[k] |= (int32_t)0x80000000;
+}
+
+struct KindBit
+{
+  const uint8_t* kind;
+  uint8_t bit;
+  __device__ bool operator()(int64_t i) const { return (kind[i] & bit) != 0; }
+};
+
+// The blocks a linear form runs over this step (uncut entities with mark bits `mark & 0x0F`, rule parents with
+// `mark & 0xF0`) and where their partials go
+bool vec_block_plan(cfx_form_s* L, uint8_t mark, bool merged)
+{
+  cfx_row_plan& plan = row_plan(L);
+  if (plan.vb_state >= 0 && plan.vb_mark == mark && plan.vb_merged == merged) return plan.vb_state == 1;
+  plan.vb_mark = mark;
+  plan.vb_merged = merged;
+  plan.vb_state = 0;
+  cfx_space_s* V = L->V;
+  if (!plan.usable || !plan.any_cells) return false;
+  const VecBlocks& S = space_vec_blocks(V);
+  if (!S.usable) return false;
+  DevArray<int32_t> len(S.nblocks);
+  DevArray<uint8_t> kind(S.nblocks);
+  launch("vec_block_plan", vb_flag_kernel, dim3((unsigned)((S.nblocks + 3) / 4)), dim3(kBlock), 0, S.nblocks, S.B, V->mesh->ncells,
+         plan.cellmark.p, mark, S.u_off.p, len.p, kind.p);
+  plan.vb_base.alloc(S.nblocks + 1);
+  exclusive_scan(len.p, plan.vb_base.p, S.nblocks);
+  // merged: one list, a block's uncut entities and rule parents in one pass; else the two kinds of blocks apart
+  plan.n_vb_active = compact("vec_block_plan", S.nblocks, KindBit{kind.p, (uint8_t)(merged ? 3 : 1)}, plan.vb_active);
+  plan.n_vb_cut = (!merged && (mark & 0xF0u)) ? compact("vec_block_plan", S.nblocks, KindBit{kind.p, 2}, plan.vb_cut) : 0;
+  plan.vb_total = read_scalar(plan.vb_base.p + S.nblocks);
+  launch("vec_block_plan", vb_base_kernel, grid_for(S.nblocks), dim3(kBlock), 0, S.nblocks, len.p, plan.vb_base.p, plan.n_vb_cut,
+         plan.vb_cut.p, kind.p);
+  plan.vb_state = 1;
+  publish_across_lanes();
+  return true;
+}
+
 __global__ void mark_cells_u8_kernel(int64_t n, const int32_t* __restrict__ cells, uint8_t* mark)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

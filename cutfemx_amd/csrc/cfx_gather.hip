@@ -713,6 +713,38 @@ __device__ __forceinline__ void add_rule_vectors(const VecBlockArgs& P, int64_t 
     }
 }
 
+// the ND sorted slots of a cell (2 B each; an even ND is read as 4 B or 8 B words)
+template <int ND>
+__device__ __forceinline__ void load_slots(const uint16_t* __restrict__ slot, int64_t c, uint16_t* sl)
+{
+  if constexpr (ND % 4 == 0)
+  {
+    const uint2* w = reinterpret_cast<const uint2*>(slot + c * ND);
+#pragma unroll
+    for (int j = 0; j < ND / 4; ++j)
+    {
+      const uint2 v = w[j];
+      sl[4 * j] = (uint16_t)(v.x & 0xffffu); sl[4 * j + 1] = (uint16_t)(v.x >> 16);
+      sl[4 * j + 2] = (uint16_t)(v.y & 0xffffu); sl[4 * j + 3] = (uint16_t)(v.y >> 16);
+    }
+  }
+  else if constexpr (ND % 2 == 0)
+  {
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(slot + c * ND);
+#pragma unroll
+    for (int j = 0; j < ND / 2; ++j)
+    {
+      const uint32_t v = w[j];
+      sl[2 * j] = (uint16_t)(v & 0xffffu); sl[2 * j + 1] = (uint16_t)(v >> 16);
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < ND; ++j) sl[j] = slot[c * ND + j];
+  }
+}
+
 template <int B, int ND, bool ADD>
 __device__ __forceinline__ void block_partials(const VecBlockArgs& P, int64_t k, int nb, const double* s_val)
 {
@@ -742,11 +774,7 @@ __global__ void __launch_bounds__(B) vec_blocks_kernel(VecArgs A, VecBlockArgs P
   const int nb = (int)min((int64_t)B, P.ncells - k * B);
   const bool inb = threadIdx.x < nb;
   uint16_t sl[ND];
-  if (inb)
-  {
-#pragma unroll
-    for (int j = 0; j < ND; ++j) sl[j] = P.slot[c * ND + j];
-  }
+  if (inb) load_slots<ND>(P.slot, c, sl);
   double be[ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j) be[j] = 0.0;
@@ -796,8 +824,7 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_blocks_sin_p1_ke
     c.cell = (int32_t)(cell < last ? cell : last);
     source_load_conn<TDIM>(A, c);
     x.on = cell <= last && (P.cellmark[c.cell] & P.mark) != 0;
-#pragma unroll
-    for (int j = 0; j < ND; ++j) x.sl[j] = P.slot[(int64_t)c.cell * ND + j];
+    load_slots<ND>(P.slot, c.cell, x.sl);
     x.k = k; x.ub = P.u_off[k]; x.nu = (int)(P.u_off[k + 1] - x.ub); x.pb = P.base[k];
     x.nb = (int)min((int64_t)B, P.ncells - k * B);
   };
@@ -4251,7 +4278,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 #define CFX_VEC_PLAIN_G 4
 #endif
 #ifndef CFX_VEC_BLOCK_G
-#define CFX_VEC_BLOCK_G 4 // lanes per row of vec_blocks_rows_kernel
+#define CFX_VEC_BLOCK_G 1 // lanes per row of vec_blocks_rows_kernel (configs[3]: 2.13 ms at 4, 1.51 at 2, 1.35 at 1)
 #endif
 template <int G>
 __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_plain, const int32_t* __restrict__ rows,

@@ -1618,7 +1618,9 @@ int cfx_space_static_bytes(cfx_space_t V, int64_t bytes[4])
   bytes[0] = adj.built ? 8 * adj.offsets.n + 4 * adj.cells.n : 0;
   const cfx::Stencil& S = V->stencil;
   bytes[1] = 8 * S.offsets.n + 4 * S.nbr.n + 4 * S.slot4.n + S.diagpos.n + S.cpos.n + S.slotn.n; // (slotn: degree-2 slot records)
-  bytes[2] = 8 * S.tile_voff.n + 4 * S.tile_verts.n + 2 * S.st_loc.n;
+  const cfx::VecBlocks& B = V->vblocks;
+  bytes[2] = 8 * S.tile_voff.n + 4 * S.tile_verts.n + 2 * S.st_loc.n
+             + 8 * B.u_off.n + 2 * B.slot.n + 2 * B.seg.n + 8 * B.p_off.n + 8 * B.p_pos.n; // (+ the cell blocks of the linear forms)
   bytes[3] = V->mesh->c2c_built ? 4 * V->mesh->c2c.n : 0;
   CFX_API_END
 }

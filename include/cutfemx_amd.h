@@ -343,7 +343,8 @@ int cfx_space_create(cfx_mesh_t mesh, int degree, int bs, int64_t ndofs,
 /* HBM held by the mesh-static tables that the first assembly on a space builds and every later step reuses
  * (the reference holds the same information inside dolfinx::mesh::Topology / fem::DofMap): bytes[0] dof -> cells
  * incidence, [1] row stencil of a P1 space (neighbour lists, slot4, diagpos, cpos), [2] its row tiles (tile vertex
- * unions, st_loc), [3] the mesh's cell -> cell table (built by the first ghost-penalty query). */
+ * unions, st_loc) and the cell blocks a linear form is summed over (slots, segments, dof -> partials lists), [3] the
+ * mesh's cell -> cell table (built by the first ghost-penalty query). */
 int cfx_space_static_bytes(cfx_space_t V, int64_t bytes[4]);
 int cfx_space_destroy(cfx_space_t V);
 

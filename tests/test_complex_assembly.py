@@ -144,6 +144,10 @@ def test_gpu_complex_form_of_real_constants(oracle):
     ac = fem.form([fem.Integral(fem.MASS, cells=cells, qdegree=2)], V, dtype=np.complex128)
     assert ar.dtype == np.dtype(np.float64) and ac.dtype == np.dtype(np.complex128)
     Ar, Ac = fem.assemble_matrix(ar), fem.assemble_matrix(ac)
-    assert np.array_equal(Ac.data.real, Ar.data) and not Ac.data.imag.any()
+    import os
+    if os.environ.get("CFX_ASSEMBLY") == "atomic":   # FP64 atomics: the order of the additions differs from run to run
+        assert np.allclose(Ac.data.real, Ar.data, rtol=1e-14, atol=0.0) and not Ac.data.imag.any()
+    else:
+        assert np.array_equal(Ac.data.real, Ar.data) and not Ac.data.imag.any()
     with pytest.raises(TypeError):
         fem.form([fem.Integral(fem.MASS, cells=cells, qdegree=2, scale=2j)], V, dtype=np.float64)

@@ -77,6 +77,71 @@ __device__ __forceinline__ void tabulate(const double* X, double* N, double (*dN
   }
 }
 
+// The values alone, and the values with the derivative along a reference-space direction k (dk_i = sum_t dN_i/dX_t
+// k_t): what a linear form needs (N for f v, N and n . grad N = (K n) . dN/dX for the Nitsche datum) -- 2 ND numbers
+// instead of the ND (1 + TDIM) of tabulate(): the degree-2 rule kernel drops from 180 registers to under 128
+template <int TDIM, int DEG>
+__device__ __forceinline__ void tabulate_values(const double* X, double* N)
+{
+  double lam[TDIM + 1];
+  lam[0] = 1.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) { lam[0] -= X[t]; lam[t + 1] = X[t]; }
+  if constexpr (DEG == 1)
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i) N[i] = lam[i];
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i) N[i] = lam[i] * (2.0 * lam[i] - 1.0);
+    constexpr int NE = TDIM == 2 ? 3 : 6;
+    constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+    constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+    {
+      const int a = TDIM == 2 ? ea2[e % 3] : ea3[e], b = TDIM == 2 ? eb2[e % 3] : eb3[e];
+      N[TDIM + 1 + e] = 4.0 * lam[a] * lam[b];
+    }
+  }
+}
+
+template <int TDIM, int DEG>
+__device__ __forceinline__ void tabulate_dot(const double* X, const double* k, double* N, double* dk)
+{
+  double lam[TDIM + 1], gk[TDIM + 1]; // gk_i = d lam_i / dX . k
+  lam[0] = 1.0;
+  gk[0] = 0.0;
+#pragma unroll
+  for (int t = 0; t < TDIM; ++t) { lam[0] -= X[t]; lam[t + 1] = X[t]; gk[0] -= k[t]; gk[t + 1] = k[t]; }
+  if constexpr (DEG == 1)
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i) { N[i] = lam[i]; dk[i] = gk[i]; }
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      N[i] = lam[i] * (2.0 * lam[i] - 1.0);
+      dk[i] = (4.0 * lam[i] - 1.0) * gk[i];
+    }
+    constexpr int NE = TDIM == 2 ? 3 : 6;
+    constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+    constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+    {
+      const int a = TDIM == 2 ? ea2[e % 3] : ea3[e], b = TDIM == 2 ? eb2[e % 3] : eb3[e];
+      N[TDIM + 1 + e] = 4.0 * lam[a] * lam[b];
+      dk[TDIM + 1 + e] = 4.0 * (lam[a] * gk[b] + gk[a] * lam[b]);
+    }
+  }
+}
+
 // Row `lr` of the degree-2 Lagrange stiffness tensor of an affine simplex in closed form.  grad(phi_p) is linear
 // in the barycentric coordinates -- vertex i: (4 lam_i - 1) grad(lam_i); edge (a, b): 4 (lam_b grad(lam_a) +
 // lam_a grad(lam_b)) -- so every entry is a combination of the P1 stiffness entries S_kl = |K| grad(lam_k) .

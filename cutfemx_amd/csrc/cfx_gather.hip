@@ -316,14 +316,25 @@ __device__ __forceinline__ void store_std_vector(const VecArgs& A, int64_t e, in
 // round-robin to the lanes (coalesced point / weight / normal reads, balanced 6-42 point rules) and
 // the ND partial sums are folded with shuffles.
 // element vector of one entity (an uncut cell, or rule e of a cut cell): lane `sub` of LANES takes the points sub, sub + LANES, ...
-template <int TDIM, int DEG, bool RUNTIME, int LANES>
-__device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64_t cell, int sub, double* be)
+// vids: the cell's vertex ids when the caller has them already (its connectivity row was requested ahead)
+// KSEL: the integrand is known when the kernel is compiled (1 the source term, 2 the Nitsche datum; 0: A.kernel) -- the
+// source term then holds neither K nor the derivatives (degree 2, runtime rules: 158 -> under 128 registers)
+template <int TDIM, int DEG, bool RUNTIME, int LANES, int KSEL = 0>
+__device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64_t cell, int sub, double* be,
+                                              const int32_t* vids = nullptr)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
+  const int kern = KSEL == 0 ? A.kernel : (KSEL == 1 ? CFX_L_SOURCE : CFX_L_NITSCHE_RHS);
   Geo<TDIM> g;
-  load_cell<TDIM>(A.x, A.conn, cell, g);
-  jacobian<TDIM>(g);
-  const bool nitsche = A.kernel == CFX_L_NITSCHE_RHS;
+  if (vids)
+  {
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i) load_vertex<TDIM>(A.x, vids[i], g.x[i]);
+  }
+  else
+    load_cell<TDIM>(A.x, A.conn, cell, g);
+  const bool nitsche = kern == CFX_L_NITSCHE_RHS;
+  if (!RUNTIME || nitsche) jacobian<TDIM>(g); // (runtime rules carry physical weights: the source term needs no Jacobian)
   const double h = nitsche ? cell_diameter<TDIM>(g) : 1.0; // only the Nitsche datum needs h (and K)
   int npts;
   const double *pts, *wts, *pdata = nullptr;
@@ -363,10 +374,10 @@ __device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64
       xq[d] = v;
     }
     const double w = wts[q] * wscale;
-    double N[ND], dN[ND][TDIM];
-    tabulate<TDIM, DEG>(X, N, dN);
-    if (A.kernel == CFX_L_SOURCE)
+    double N[ND];
+    if (kern == CFX_L_SOURCE)
     {
+      tabulate_values<TDIM, DEG>(X, N);
       double fv;
       if (A.coeff)
       {
@@ -380,31 +391,30 @@ __device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64
 #pragma unroll
       for (int i = 0; i < ND; ++i) be[i] += f * N[i];
     }
-    else if (A.kernel == CFX_L_NITSCHE_RHS)
+    else if (kern == CFX_L_NITSCHE_RHS)
     {
       const double* nrm = pdata + (int64_t)q * A.point_stride;
       const double gam = A.params[0] / h;
       const double gv = A.params[2] * field_eval<TDIM>((int)A.params[1], xq);
+      // n . grad N_i = sum_d n_d sum_t K[t][d] dN_i/dX_t = (K n) . dN_i/dX
+      double kn[TDIM], dn[ND];
 #pragma unroll
-      for (int i = 0; i < ND; ++i)
+      for (int t = 0; t < TDIM; ++t)
       {
-        double dni = 0.0;
+        double v = 0.0;
 #pragma unroll
-        for (int d = 0; d < TDIM; ++d)
-        {
-          double G = 0.0;
-#pragma unroll
-          for (int t = 0; t < TDIM; ++t) G += g.K[t][d] * dN[i][t];
-          dni += G * nrm[d];
-        }
-        be[i] += w * (-dni * gv + gam * gv * N[i]);
+        for (int d = 0; d < TDIM; ++d) v += g.K[t][d] * nrm[d];
+        kn[t] = v;
       }
+      tabulate_dot<TDIM, DEG>(X, kn, N, dn);
+#pragma unroll
+      for (int i = 0; i < ND; ++i) be[i] += w * (-dn[i] * gv + gam * gv * N[i]);
     }
   }
 }
 
-template <int TDIM, int DEG, bool RUNTIME, int LANES = 1>
-__global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
+template <int TDIM, int DEG, bool RUNTIME, int LANES = 1, int KSEL = 0>
+__global__ void __launch_bounds__(kBlock, (DEG == 2 && RUNTIME && KSEL != 0) ? 4 : 1) vec_tensors_kernel(VecArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -415,7 +425,7 @@ __global__ void __launch_bounds__(kBlock) vec_tensors_kernel(VecArgs A)
   if (e >= A.n) return;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
   double be[ND];
-  entity_vector<TDIM, DEG, RUNTIME, LANES>(A, e, cell, sub, be);
+  entity_vector<TDIM, DEG, RUNTIME, LANES, KSEL>(A, e, cell, sub, be);
   if constexpr (LANES > 1)
   {
 #pragma unroll
@@ -745,26 +755,15 @@ __device__ __forceinline__ void load_slots(const uint16_t* __restrict__ slot, in
   }
 }
 
-template <int B, int ND, bool ADD>
-__device__ __forceinline__ void block_partials(const VecBlockArgs& P, int64_t k, int nb, const double* s_val)
-{
-  const int64_t ub = P.u_off[k], pb = P.base[k];
-  const int nu = (int)(P.u_off[k + 1] - ub);
-  for (int t = threadIdx.x; t < nu; t += B)
-  {
-    const int s0 = P.seg[ub + t], s1 = t + 1 < nu ? (int)P.seg[ub + t + 1] : nb * ND;
-    double sum = 0.0;
-    for (int q = s0; q < s1; ++q) sum += s_val[q];
-    if (ADD) P.part[pb + t] += sum; else P.part[pb + t] = sum;
-  }
-}
-
 // RULES = 0: the uncut entities (mark P.mark) of the blocks of P.active; RULES = 1: the staged rule vectors of
 // the blocks that hold a rule parent, added to the block's partials (stored when the block holds no uncut entity:
 // bit 31 of the list entry) -- the partials of a block belong to that block alone, so the second pass is race-free;
 // RULES = 2: both in one pass (a cell is an uncut entity or a rule parent)
+#ifndef CFX_VB_WAVES
+#define CFX_VB_WAVES 5 // wavefronts per SIMD the degree-2 block kernel is compiled for
+#endif
 template <int TDIM, int DEG, int B, int RULES>
-__global__ void __launch_bounds__(B) vec_blocks_kernel(VecArgs A, VecBlockArgs P)
+__global__ void __launch_bounds__(B, DEG == 2 ? CFX_VB_WAVES : 1) vec_blocks_kernel(VecArgs A, VecBlockArgs P)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   __shared__ double s_val[B * ND];
@@ -772,26 +771,100 @@ __global__ void __launch_bounds__(B) vec_blocks_kernel(VecArgs A, VecBlockArgs P
   const int64_t k = entry & 0x7fffffff;
   const int64_t c = k * B + threadIdx.x;
   const int nb = (int)min((int64_t)B, P.ncells - k * B);
-  const bool inb = threadIdx.x < nb;
-  uint16_t sl[ND];
-  if (inb) load_slots<ND>(P.slot, c, sl);
+  const bool inb = (int)threadIdx.x < nb;
+  // Everything addressed by the block number alone is requested here, in one batch: the union's offsets and the first
+  // partial (scalar loads), the cell's slots, mark and connectivity row.  The kernel is bound by the length of its
+  // chain of dependent loads x the blocks a CU holds (configs[3]: 786 k blocks of 2 wavefronts, ~10 resident per CU),
+  // not by bytes or arithmetic: block -> {mark, slots} -> connectivity -> vertices -> ... -> offsets -> segment bounds
+  // was six levels, this is three
+  const int64_t ub = P.u_off[k], pb = P.base[k];
+  const int nu = (int)(P.u_off[k + 1] - ub);
+  // (the slots stay packed two to a register until they are used: 100 -> 96 registers is a fifth wavefront per SIMD)
+  constexpr int NW = (ND + 1) / 2;
+  uint32_t slw[NW];
+  if (inb)
+  {
+    if constexpr (ND % 2 == 0)
+    {
+      const uint32_t* w = reinterpret_cast<const uint32_t*>(P.slot + c * ND);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) slw[j] = w[j];
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < NW; ++j)
+        slw[j] = (uint32_t)P.slot[c * ND + 2 * j] | (2 * j + 1 < ND ? (uint32_t)P.slot[c * ND + 2 * j + 1] << 16 : 0u);
+    }
+  }
+  const unsigned cm = inb ? P.cellmark[c] : 0u;
+  int32_t vids[TDIM + 1];
+  if constexpr (RULES != 1)
+  {
+    if constexpr (TDIM == 3)
+    {
+      const int4 r = *reinterpret_cast<const int4*>(A.conn + (inb ? c : k * B) * 4);
+      vids[0] = r.x; vids[1] = r.y; vids[2] = r.z; vids[3] = r.w;
+    }
+    else
+    {
+#pragma unroll
+      for (int i = 0; i <= TDIM; ++i) vids[i] = A.conn[(inb ? c : k * B) * (TDIM + 1) + i];
+    }
+  }
+  // the segment of this thread's first dof of the union (the later rounds are requested after the arithmetic, when
+  // registers are free)
+  const int t0 = threadIdx.x;
+  const uint32_t f01 = (t0 < nu ? (uint32_t)P.seg[ub + t0] : 0u) | ((t0 + 1 < nu ? (uint32_t)P.seg[ub + t0 + 1] : (uint32_t)(nb * ND)) << 16);
   double be[ND];
 #pragma unroll
   for (int j = 0; j < ND; ++j) be[j] = 0.0;
-  const unsigned cm = inb ? P.cellmark[c] : 0u;
   if constexpr (RULES != 0) add_rule_vectors<ND>(P, c, cm, be);
   if constexpr (RULES != 1)
   {
-    if (cm & P.mark) entity_vector<TDIM, DEG, false, 1>(A, 0, c, 0, be);
+    if (cm & P.mark) entity_vector<TDIM, DEG, false, 1>(A, 0, c, 0, be, vids);
   }
   if (inb)
   {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) s_val[sl[j]] = be[j];
+    for (int j = 0; j < ND; ++j) s_val[(slw[j / 2] >> (16 * (j & 1))) & 0xffffu] = be[j];
   }
   __syncthreads();
-  if (RULES == 1 && entry >= 0) block_partials<B, ND, true>(P, k, nb, s_val);
-  else block_partials<B, ND, false>(P, k, nb, s_val);
+  const bool add = RULES == 1 && entry >= 0;
+  const int f0 = (int)(f01 & 0xffffu), f1 = (int)(f01 >> 16);
+  constexpr int T = 3; // further rounds whose bounds are requested together
+  int g0[T], g1[T];
+#pragma unroll
+  for (int q = 0; q < T; ++q)
+  {
+    const int t = t0 + (q + 1) * B;
+    g0[q] = t < nu ? (int)P.seg[ub + t] : 0;
+    g1[q] = t + 1 < nu ? (int)P.seg[ub + t + 1] : nb * ND;
+  }
+  if (t0 < nu)
+  {
+    double sum = 0.0;
+    for (int i = f0; i < f1; ++i) sum += s_val[i];
+    if (add) P.part[pb + t0] += sum; else P.part[pb + t0] = sum;
+  }
+#pragma unroll
+  for (int q = 0; q < T; ++q)
+  {
+    const int t = t0 + (q + 1) * B;
+    if (t < nu)
+    {
+      double sum = 0.0;
+      for (int i = g0[q]; i < g1[q]; ++i) sum += s_val[i];
+      if (add) P.part[pb + t] += sum; else P.part[pb + t] = sum;
+    }
+  }
+  for (int t = t0 + (T + 1) * B; t < nu; t += B)
+  {
+    const int a0 = P.seg[ub + t], a1 = t + 1 < nu ? (int)P.seg[ub + t + 1] : nb * ND;
+    double sum = 0.0;
+    for (int i = a0; i < a1; ++i) sum += s_val[i];
+    if (add) P.part[pb + t] += sum; else P.part[pb + t] = sum;
+  }
 }
 
 // ... the sin-product source term on a P1 space (vec_source_sin_p1_kernel's arithmetic and software pipeline: the
@@ -3691,7 +3764,13 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
     const cfx_rules_s* R = I.rules;
     A.n = R->nr; A.offsets = R->offsets.p; A.parent_map = R->parent_map.p; A.points = R->points.p;
     A.weights = R->weights.p; A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-    launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES>, grid_for(A.n * CFX_VEC_CUT_LANES), dim3(kBlock), 0, A);
+    const dim3 grid = grid_for(A.n * CFX_VEC_CUT_LANES);
+    if (I.kernel == CFX_L_SOURCE)
+      launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES, 1>, grid, dim3(kBlock), 0, A);
+    else if (I.kernel == CFX_L_NITSCHE_RHS)
+      launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES, 2>, grid, dim3(kBlock), 0, A);
+    else
+      launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES>, grid, dim3(kBlock), 0, A);
   }
 }
 

@@ -3703,6 +3703,7 @@ void vec_block_partials(cfx_form_s* L, const cfx_integral_dev* Istd, uint8_t mar
   constexpr int ND = Elem<TDIM, DEG>::ND, B = ND <= 8 ? 256 : 128;
   if (S.B != B) throw Error(CFX_ERR_RUNTIME, "vec_block_partials: block size of the space's cell blocks");
   VecArgs A{};
+  A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; // (a form of rule integrals alone: the kernel still requests the connectivity rows)
   if (Istd) A = vec_args(L, *Istd);
   VecBlockArgs P{};
   P.n_active = plan.n_vb_active; P.active = plan.vb_active.p; P.base = plan.vb_base.p; P.u_off = S.u_off.p;

@@ -270,6 +270,20 @@ inline T read_scalar(const T* dev)
   return v;
 }
 
+// two scalars, one round trip
+template <typename T>
+inline void read_two(const T* dev_a, const T* dev_b, T& a, T& b)
+{
+  static_assert(2 * sizeof(T) <= 256, "read_two reads small values");
+  T* h = static_cast<T*>(pinned_scratch());
+  CFX_HIP(hipMemcpyAsync(h, dev_a, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  CFX_HIP(hipMemcpyAsync(h + 1, dev_b, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  a = h[0]; b = h[1];
+  ++sync_counter();
+  if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back after %s\n", ctx().last_launch);
+}
+
 template <typename T>
 inline std::vector<T> download(const T* dev, int64_t n)
 {

@@ -1972,7 +1972,8 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
       DevArray<int64_t> off_in(ntiles + 1), off_cut(ntiles + 1);
       exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
       exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles);
-      const int64_t n_in = read_scalar(off_in.p + ntiles), n_cut = read_scalar(off_cut.p + ntiles);
+      int64_t n_in = 0, n_cut = 0;
+      read_two(off_in.p + ntiles, off_cut.p + ntiles, n_in, n_cut); // (both totals in one round trip)
       DevArray<int32_t> l_in(n_in), l_cut(n_cut);
       launch("locate_entities", locate_inside_cut_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nh, bytes, off_in.p,
              off_cut.p, l_in.p, l_cut.p);

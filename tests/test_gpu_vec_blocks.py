@@ -83,7 +83,8 @@ def test_shuffled_cells_by_block_and_by_record(oracle, tdim, n, degree):
         with env(CFX_VEC_BLOCKS="0"):
             b0 = cfx.fem.assemble_vector(cfx.fem.form(gL, c["V"], rank=1))
         assert rel_err(b1, want) < RTOL and rel_err(b0, want) < RTOL
-        assert np.array_equal(b1, b2)
+        if os.environ.get("CFX_ASSEMBLY") != "atomic":   # (the entity-parallel FP64-atomic kernels add in arrival order)
+            assert np.array_equal(b1, b2)
 
 
 @pytest.mark.parametrize("tdim,n,degree", [(3, 6, 1), (3, 5, 2)])

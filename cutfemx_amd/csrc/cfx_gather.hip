@@ -3012,7 +3012,19 @@ __global__ void __launch_bounds__(kWave, 4) assemble_rows_p2_plain_kernel(P2Plai
       const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.slotn + (cb + t) * 12);
       w0 = rec[0]; w1 = rec[1]; w2 = rec[2];
       Geo<TDIM> g;
+#if defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 3
+      for (int i = 0; i <= TDIM; ++i) // ablation: no connectivity row, no vertices
+        for (int d = 0; d < TDIM; ++d) g.x[i][d] = 1e-9 * (double)((c >> (7 * d)) & 127) + (i == d + 1 ? 1e-3 : 0.0);
+#elif defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 4
+      {
+        const int4 vv = *reinterpret_cast<const int4*>(A.conn + c * 4); // ablation: no vertex gathers
+        const int vq[4] = {vv.x, vv.y, vv.z, vv.w};
+        for (int i = 0; i <= TDIM; ++i)
+          for (int d = 0; d < TDIM; ++d) g.x[i][d] = 1e-9 * (double)((vq[i] >> (7 * d)) & 127) + (i == d + 1 ? 1e-3 : 0.0);
+      }
+#else
       load_cell<TDIM>(A.x, A.conn, c, g);
+#endif
       jacobian<TDIM>(g);
       p2_stiffness_row<TDIM>(g, (int)((w2 >> 16) & 0xffu), 1.0, acc);
     }
@@ -3038,9 +3050,17 @@ __global__ void __launch_bounds__(kWave, 4) assemble_rows_p2_plain_kernel(P2Plai
     }
     else
     {
+#if defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 1
+#pragma unroll
+      for (int j = 0; j < ND; ++j)
+        if (sl[j] >= 0) s_val[grp][sl[j]] = acc[j]; // ablation: plain LDS stores
+#elif defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 2
+      if (acc[0] == 1.2345e300 && sl[0] >= 0) *A.error = 3; // ablation: no LDS traffic
+#else
 #pragma unroll
       for (int j = 0; j < ND; ++j)
         if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
+#endif
     }
   }
   __syncthreads();

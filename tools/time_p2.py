@@ -33,7 +33,10 @@ for it in range(2):
     T('assemble_vector', lambda: fem.assemble_vector(s.L, b), acc)
     print('cfg4 P2 gyroid', n, acc, 'nnz', A.nnz, 'inside', s.inside_cells[1], flush=True)
     if it == 1:
-        print(' matrix kernels', profile(lambda: fem.assemble_matrix(s.a, A=A)), flush=True)
+        def fresh():   # A = 0 then assemble: the fused path the bench step takes (rows stored, not read-modified-written)
+            A.set_value(0.0)
+            fem.assemble_matrix(s.a, A=A)
+        print(' matrix kernels', profile(fresh), flush=True)
         print(' sparsity kernels', profile(lambda: fem.create_matrix(s.a)), flush=True)
         print(' vector kernels', profile(lambda: fem.assemble_vector(s.L, b)), flush=True)
         print(' forms + plan + sparsity kernels', profile(lambda: fem.create_matrix(poisson.build_forms(V, cd, order=4).a)), flush=True)

@@ -1589,6 +1589,9 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
   double dsum = 0.0;
   auto find_slot = [&](int32_t col) -> int
   {
+#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 1)
+    return (int)((unsigned)col % (unsigned)(len > 0 ? len : 1)); // ablation: no probe
+#endif
     unsigned h = ((uint32_t)col * 2654435761u) >> kHashShift;
     for (int probe = 0; probe < HS; ++probe)
     {
@@ -1603,6 +1606,10 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
   auto add_item = [&](auto nc_tag, bool has, const int32_t* cols, const double* acc, const int* sl)
   {
     constexpr int NC = decltype(nc_tag)::value;
+#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 8)
+    if (has && acc[0] == 1.2345e300) *A.error = 3; // ablation: no LDS accumulation
+    return;
+#endif
     double v[NC];
     int sidx[NC];
 #pragma unroll
@@ -1710,11 +1717,13 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
       {
 #pragma unroll
         for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[j]);
+#if !(defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 4)) // (ablation: no closed-form row)
         if (mark & 0x0Fu)
         {
           jacobian<TDIM>(g);
           p2_stiffness_row<TDIM>(g, lr, 1.0, acc);
         }
+#endif
         if (is_cut)
         {
 #pragma unroll
@@ -1732,7 +1741,11 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
       int sl[WF];
 #pragma unroll
       for (int j = 0; j < WF; ++j) { acc[j] = 0.0; sl[j] = -1; }
+#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 2)
+      if (false) // ablation: no facet items
+#else
       if (hasf)
+#endif
       {
         int m = -1;
 #pragma unroll

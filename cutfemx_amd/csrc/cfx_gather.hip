@@ -1528,7 +1528,8 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
 //   rank, facet column ids} -> {vertices, tensor row} -> cell item -> {facet records} -> facet item.
 // ---------------------------------------------------------------------------
 #ifndef CFX_IFC_WAVES
-#define CFX_IFC_WAVES 3 // waves per SIMD the interface kernel is compiled for
+#define CFX_IFC_WAVES 4 // waves per SIMD the interface kernel is compiled for (128 registers, 11 spilled: 25.4 -> 24.6 ms; the
+                        // form with the probe loops alone was indifferent to 2 / 3 / 4)
 #endif
 template <int TDIM, int G, int CAP, bool ORDERED>
 __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interface_kernel(RowArgs A)
@@ -1664,8 +1665,18 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
     // ---- level 2: everything addressed by the ids
     const uint8_t mark = hasc ? (uint8_t)(A.cellmark[c] & A.mark_mask) : (uint8_t)0;
     int32_t cd[ND];
+    if constexpr (ND % 2 == 0)
+    {
+      // (a dof row of an even number of entries starts on an 8 B boundary: half as many load instructions)
+      const int2* d2 = reinterpret_cast<const int2*>(A.dofmap + c * ND);
 #pragma unroll
-    for (int j = 0; j < ND; ++j) cd[j] = A.dofmap[c * ND + j];
+      for (int j = 0; j < ND / 2; ++j) { const int2 v2 = d2[j]; cd[2 * j] = v2.x; cd[2 * j + 1] = v2.y; }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < ND; ++j) cd[j] = A.dofmap[c * ND + j];
+    }
     int32_t cn[NV];
     if constexpr (TDIM == 3)
     {
@@ -1702,9 +1713,7 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
     for (int j = 0; j < ND; ++j) lr = (cd[j] == (int32_t)r) ? j : lr;
     Geo<TDIM> g;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d) g.x[i][d] = A.x[3 * (int64_t)cn[i] + d];
+    for (int i = 0; i < NV; ++i) load_vertex<TDIM>(A.x, cn[i], g.x[i]);
     const bool is_cut = (mark & 0xF0u) != 0;
     const int64_t e = (int64_t)rk + __popcll(bw & ((1ull << (c & 63)) - 1ull));
     double trow[ND];

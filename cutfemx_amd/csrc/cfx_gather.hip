@@ -3575,8 +3575,11 @@ struct CutTensorArgs
 };
 constexpr int kCutLanes2 = 4;
 
+#ifndef CFX_CUTT_WAVES
+#define CFX_CUTT_WAVES 2
+#endif
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock, 2) cut_tensors_p2_kernel(CutTensorArgs A)
+__global__ void __launch_bounds__(kBlock, CFX_CUTT_WAVES) cut_tensors_p2_kernel(CutTensorArgs A)
 {
   constexpr int NV = TDIM + 1, NE = TDIM == 2 ? 3 : 6, ND = NV + NE, NP = ND * (ND + 1) / 2;
   constexpr int NM = 1 + NV + NV * (NV + 1) / 2, NO = (NP + kCutLanes2 - 1) / kCutLanes2;

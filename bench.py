@@ -126,11 +126,23 @@ def hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer=None,
         run("assemble_matrix", lambda: cfx.fem.assemble_matrix(system.a, A=A))
         run("assemble_vector", lambda: cfx.fem.assemble_vector(system.L, b_buf))
     dom = run("deactivate", lambda: cfx.fem.deactivate_outside(A, b_buf, cfx.fem.active_domain(system.a)))
-    return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz,
-                n_inside=system.inside_cells[1], n_cut=system.interface_rules.num_rules,
-                nq_volume=system.volume_rules.total_points, nq_interface=system.interface_rules.total_points,
-                n_vol_rules=system.volume_rules.num_rules,
-                n_ghost=0 if system.ghost_facets is None else system.ghost_facets.size)
+    return StepResult(system, A, dom)
+
+
+class StepResult:
+    """What a step leaves behind; its counters are read from the engine on request -- after the step: inside a
+    sync-free step (cutfemx_amd.run_step) the sizes are still in HBM and reading one would cost a round trip."""
+
+    def __init__(self, system, A, dom):
+        self.system, self.A, self.dom = system, A, dom
+
+    def counts(self):
+        system, A, dom = self.system, self.A, self.dom
+        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz,
+                    n_inside=system.inside_cells.size, n_cut=system.interface_rules.num_rules,
+                    nq_volume=system.volume_rules.total_points, nq_interface=system.interface_rules.total_points,
+                    n_vol_rules=system.volume_rules.num_rules,
+                    n_ghost=0 if system.ghost_facets is None else system.ghost_facets.size)
 
 
 def cpu_baseline(n, order):
@@ -274,8 +286,17 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         values_buf = torch.zeros(nnz_cap, device=device, dtype=torch.float64)
         b_buf = torch.zeros(mesh.num_nodes, device=device, dtype=torch.float64)
 
+        # the timed step is a sync-free step of the moving-domain loop (cfx_step_begin / cfx_step_end): the sizes of its
+        # lists stay in HBM, buffers are sized by the previous step's counts, one read-back ends it
+        # (CFX_BENCH_STEP=0: every size read back where it is produced, as rounds 1-3 timed it)
+        use_steps = os.environ.get("CFX_BENCH_STEP", "1") != "0"
+        step_stats = {}
+
         def step(timer=None, overlap=True):
-            return hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer, overlap)
+            if timer is not None or not use_steps:
+                return hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, timer, overlap)
+            return cfx.run_step(lambda: hot_path_step(cfx, poisson, V, phi_fn, values_buf, b_buf, order, None, overlap),
+                                key=f"bench-{n}", info=step_stats)
     else:
         # z-slabs weighted by active cells, one rank per GPU, RCCL point-to-point row reduction
         from cutfemx_amd import dist as cdist
@@ -325,6 +346,8 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     elapsed = time.perf_counter() - t0
     if world > 1:
         info = dp.counters(info)       # owned-share counts of the last step, outside the timed region
+    else:
+        info = info.counts()
     info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
     if world > 1:
         cdev = device if dist.get_backend() == "nccl" else "cpu"

@@ -16,7 +16,12 @@ _HERE = Path(__file__).resolve().parent
 # CFX_LIB: another build of the same engine (timing-ablation / variant builds under build/, tools/*_variants.sh)
 LIB_PATH = Path(os.environ["CFX_LIB"]).resolve() if os.environ.get("CFX_LIB") else _HERE / "libcutfemx_amd.so"
 
-OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_OUT_OF_RANGE, ERR_HIP = 0, -1, -2, -3, -4
+OK, ERR_INVALID_ARGUMENT, ERR_RUNTIME, ERR_OUT_OF_RANGE, ERR_HIP, ERR_STEP_VOID = 0, -1, -2, -3, -4, -5
+
+
+class StepVoid(RuntimeError):
+    """Raised inside a cutfemx_amd.step whose capacities (taken from the previous step) did not fit: the results of
+    the step are void; `cutfemx_amd.run_step` ends it and repeats the body."""
 
 INSIDE, INTERSECTED, OUTSIDE = -1, 0, 1
 CELL, EXTERIOR_FACET, INTERIOR_FACET = 0, 1, 2
@@ -80,7 +85,8 @@ class PatternView(C.Structure):
 
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
-    "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
+    "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_step_begin", "cfx_step_end", "cfx_step_resolve", "cfx_step_abort",
+    "cfx_step_set_margin", "cfx_step_forget", "cfx_sync_count", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
     "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_device_memory_stats", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",
@@ -157,6 +163,8 @@ def check(code: int):
         raise ValueError(msg)
     if code == ERR_OUT_OF_RANGE:
         raise IndexError(msg)
+    if code == ERR_STEP_VOID:
+        raise StepVoid(msg)
     raise RuntimeError(msg)
 
 
@@ -242,6 +250,23 @@ def memory_stats(reset_peak: bool = False) -> dict:
     a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
     check(lib().cfx_device_memory_stats(C.byref(a), C.byref(b), C.byref(c), 1 if reset_peak else 0))
     return dict(in_use=a.value, cached=b.value, peak=c.value)
+
+
+_step_open = False   # a cutfemx_amd.step is open in this process: counts of library lists may still be in HBM
+
+
+def resolve_counts():
+    """Inside a sync-free step: fetch the counts published so far (cfx_step_resolve), so that sizes read from the
+    library right after are exact -- what a copy of a list to the host needs.  No-op outside a step."""
+    if _step_open:
+        check(lib().cfx_step_resolve())
+
+
+def sync_count() -> int:
+    """Host round trips (size / error read-backs) the engine has made so far."""
+    n = C.c_int64()
+    check(lib().cfx_sync_count(C.byref(n)))
+    return n.value
 
 
 def download(ptr, n: int, dtype) -> np.ndarray:

@@ -100,9 +100,12 @@ DevArray<T> alias(const DevArray<T>& a)
   return o;
 }
 
-// the integrals `which` of form a as a form of their own (arrays aliased: it must not outlive a)
-std::unique_ptr<cfx_form_s> sub_form(const cfx_form_s* a, const std::vector<int>& which)
+// the integrals `which` of form a as a form of their own (arrays aliased: it lives in a's cache and dies with a, so
+// that its row plan -- and the tables keyed on it -- serve every later assembly of the same group)
+cfx_form_s* sub_form(cfx_form_s* a, const std::vector<int>& which)
 {
+  auto hit = a->sub_forms.find(which);
+  if (hit != a->sub_forms.end()) return hit->second.get();
   auto f = std::make_unique<cfx_form_s>();
   f->V = a->V; f->V1 = a->V1; f->rank = a->rank;
   for (int i : which)
@@ -116,7 +119,9 @@ std::unique_ptr<cfx_form_s> sub_form(const cfx_form_s* a, const std::vector<int>
     for (int k = 0; k < 8; ++k) J.params[k] = I.params[k];
     f->integrals.push_back(std::move(J));
   }
-  return f;
+  cfx_form_s* out = f.get();
+  a->sub_forms[which] = std::move(f);
+  return out;
 }
 
 // integrals grouped by their complex constant; a zero constant drops its integrals
@@ -142,16 +147,17 @@ int cfx_assemble_matrix_c128(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, c
   CFX_API_BEGIN
   require(a && P && values, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix_c128: null argument");
   require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix_c128: form is not bilinear");
-  OutArray<double> out(values, 2 * P->nnz, !zero_first);
-  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * 2 * (size_t)P->nnz);
-  DevArray<double> tmp(P->nnz);
+  const int64_t nnz = P->nnz.value(); // (the complex boundary works with exact lengths)
+  OutArray<double> out(values, 2 * nnz, !zero_first);
+  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * 2 * (size_t)nnz);
+  DevArray<double> tmp(nnz);
   for (const auto& kv : groups(a, scales))
   {
     const bool whole = kv.second.size() == a->integrals.size();
-    std::unique_ptr<cfx_form_s> sub = whole ? nullptr : sub_form(a, kv.second);
-    const int rc = cfx_assemble_matrix_zeroed(whole ? a : sub.get(), P, bc0, bc1, tmp.p);
+    cfx_form_s* sub = whole ? nullptr : sub_form(a, kv.second);
+    const int rc = cfx_assemble_matrix_zeroed(whole ? a : sub, P, bc0, bc1, tmp.p);
     if (rc != CFX_OK) return rc;
-    launch("axpy_c128", axpy_c128_kernel, grid_for(P->nnz), dim3(kBlock), 0, P->nnz, (const double*)tmp.p, kv.first.first,
+    launch("axpy_c128", axpy_c128_kernel, grid_for(nnz), dim3(kBlock), 0, nnz, (const double*)tmp.p, kv.first.first,
            kv.first.second, reinterpret_cast<double2*>(out.dev));
   }
   out.finish();
@@ -169,9 +175,9 @@ int cfx_assemble_vector_c128(cfx_form_t L, const double* scales, double* b)
   for (const auto& kv : groups(L, scales))
   {
     const bool whole = kv.second.size() == L->integrals.size();
-    std::unique_ptr<cfx_form_s> sub = whole ? nullptr : sub_form(L, kv.second);
+    cfx_form_s* sub = whole ? nullptr : sub_form(L, kv.second);
     tmp.zero();
-    const int rc = cfx_assemble_vector(whole ? L : sub.get(), tmp.p);
+    const int rc = cfx_assemble_vector(whole ? L : sub, tmp.p);
     if (rc != CFX_OK) return rc;
     launch("axpy_c128", axpy_c128_kernel, grid_for(n), dim3(kBlock), 0, n, (const double*)tmp.p, kv.first.first, kv.first.second,
            reinterpret_cast<double2*>(out.dev));
@@ -205,11 +211,11 @@ int cfx_apply_lifting_c128(cfx_form_t a, const int8_t* bc_markers, const double*
   for (const auto& kv : groups(a, scales))
   {
     const bool whole = kv.second.size() == a->integrals.size();
-    std::unique_ptr<cfx_form_s> sub = whole ? nullptr : sub_form(a, kv.second);
+    cfx_form_s* sub = whole ? nullptr : sub_form(a, kv.second);
     for (int p = 0; p < 2; ++p)
     {
       t[p].zero();
-      const int rc = cfx_apply_lifting(whole ? a : sub.get(), dm.p, part[p].p, x0 ? xpart[p].p : nullptr, 1.0, t[p].p);
+      const int rc = cfx_apply_lifting(whole ? a : sub, dm.p, part[p].p, x0 ? xpart[p].p : nullptr, 1.0, t[p].p);
       if (rc != CFX_OK) return rc;
     }
     // t = -A_k (g - x0) (real, imaginary part); b += s_k alpha t
@@ -243,11 +249,12 @@ int cfx_deactivate_outside_c128(cfx_active_t d, cfx_pattern_t P, double* values,
   require(d && (values == nullptr || P), CFX_ERR_INVALID_ARGUMENT, "cfx_deactivate_outside_c128: null argument");
   const int64_t nrows = d->V->ndofs * d->V->bs;
   std::unique_ptr<OutArray<double>> ov, ob;
-  if (values) ov = std::make_unique<OutArray<double>>(values, 2 * P->nnz, true);
+  if (values) ov = std::make_unique<OutArray<double>>(values, 2 * P->nnz.value(), true);
   if (b) ob = std::make_unique<OutArray<double>>(b, 2 * nrows, true);
   ZeroFlag err;
-  if (d->n_inactive > 0)
-    launch("deactivate", deactivate_c128_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
+  const int64_t n_inactive = d->n_inactive.value();
+  if (n_inactive > 0)
+    launch("deactivate", deactivate_c128_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
            (const int32_t*)d->inactive_dofs.p, P ? (const int64_t*)P->indptr.p : (const int64_t*)nullptr,
            P ? (const int32_t*)P->indices.p : (const int32_t*)nullptr, values ? reinterpret_cast<double2*>(ov->dev) : (double2*)nullptr,
            b ? reinterpret_cast<double2*>(ob->dev) : (double2*)nullptr, make_double2(diag_re, diag_im), make_double2(rhs_re, rhs_im), err.p);

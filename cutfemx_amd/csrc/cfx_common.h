@@ -30,6 +30,10 @@ struct Error : std::runtime_error
 };
 
 extern thread_local std::string g_last_error;
+// An error raised while a sync-free step is open may be an artefact of a VOID step (a count did not fit: every kernel
+// after that point did nothing, and whatever the host then reads back -- an empty active-cell list, say -- is not a
+// property of the problem).  The status of such a call becomes CFX_ERR_STEP_VOID: end the step, repeat it.
+int error_in_step(int code);
 
 #define CFX_HIP(expr)                                                                   \
   do                                                                                    \
@@ -46,12 +50,12 @@ extern thread_local std::string g_last_error;
   catch (const ::cfx::Error& e)                                       \
   {                                                                   \
     ::cfx::g_last_error = e.what();                                   \
-    return e.code;                                                    \
+    return ::cfx::error_in_step(e.code);                              \
   }                                                                   \
   catch (const std::exception& e)                                     \
   {                                                                   \
     ::cfx::g_last_error = e.what();                                   \
-    return CFX_ERR_RUNTIME;                                           \
+    return ::cfx::error_in_step(CFX_ERR_RUNTIME);                     \
   }
 
 // closes a CFX_API_BEGIN block whose success path continues below it (argument checks ahead of a delegated call)
@@ -60,12 +64,12 @@ extern thread_local std::string g_last_error;
   catch (const ::cfx::Error& e)                                       \
   {                                                                   \
     ::cfx::g_last_error = e.what();                                   \
-    return e.code;                                                    \
+    return ::cfx::error_in_step(e.code);                              \
   }                                                                   \
   catch (const std::exception& e)                                     \
   {                                                                   \
     ::cfx::g_last_error = e.what();                                   \
-    return CFX_ERR_RUNTIME;                                           \
+    return ::cfx::error_in_step(CFX_ERR_RUNTIME);                     \
   }
 
 inline void require(bool ok, int code, const char* msg)
@@ -176,6 +180,117 @@ void device_memory_stats(size_t& live, size_t& cached, size_t& peak); // bytes h
 void device_memory_reset_peak();
 
 // ---------------------------------------------------------------------------
+// Lengths that live in HBM (sync-free steps).
+//
+// Inside cfx_step_begin / cfx_step_end the size of a data-dependent list (located cells, rule points, ghost facets,
+// row classes, nnz ...) is not read back where it is produced: the producer PUBLISHES it in a slot of a small device
+// pool, the host continues with a capacity taken from the same site's count in the previous step of the loop
+// (x 1.125 + slack), every consumer sizes its grid by the capacity and takes the length from the slot.  One read-back
+// at cfx_step_end fetches all slots: it resolves the counts on the host, feeds the next step's capacities and says
+// whether some count did not fit (then the step is void and the caller repeats it; the repeat sizes everything by
+// read-backs, like the first step of a loop).  A count that does not fit sets the pool's POISON word: every kernel
+// that takes a DevN sees length 0 from then on, so the rest of a void step touches no memory beyond what was sized.
+// Outside a step -- and at every site that has not been taught to wait -- a count is read back at once as before.
+// ---------------------------------------------------------------------------
+struct DevN
+{
+  int64_t cap = 0;              // host bound: the exact length when dev == nullptr
+  const int64_t* dev = nullptr; // published length (entry of the count pool), or nullptr
+  DevN() = default;
+  DevN(int64_t n) : cap(n) {}
+  DevN(int64_t c, const int64_t* d) : cap(c), dev(d) {}
+};
+constexpr int kCountEntries = 1024;                          // pool entries of {published, raw} pairs; entry 0 = poison
+constexpr uintptr_t kCountPoolBytes = kCountEntries * 16;    // the pool is aligned to its size: poison = base of any slot
+constexpr int kCountFirstSlot = 128;                         // entries 1..127: error words of the step's assembly calls
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t dev_n(const DevN& nn)
+{
+  if (nn.dev == nullptr) return nn.cap;
+  const int64_t* base = reinterpret_cast<const int64_t*>(reinterpret_cast<uintptr_t>(nn.dev) & ~(kCountPoolBytes - 1));
+  if (*base != 0) return 0;
+  const int64_t v = *nn.dev;
+  return v < nn.cap ? v : nn.cap;
+}
+// the same without the poison check: for lengths read inside a kernel whose own length (dev_n) already vouched for the step
+__device__ __forceinline__ int64_t dev_len(const DevN& nn)
+{
+  if (nn.dev == nullptr) return nn.cap;
+  const int64_t v = *nn.dev;
+  return v < nn.cap ? v : nn.cap;
+}
+#endif
+
+struct CountCell
+{
+  int slot = -1;          // pool entry while the value is only on the device
+  int64_t cap = 0;        // capacity the host works with until then
+  int64_t hint = 0;       // the same site's value in the previous step (what host-side heuristics compare)
+  int64_t value = 0;      // exact value once resolved
+  bool resolved = true;
+  ~CountCell();
+};
+
+// the length of a library-owned list: exact on the host, or capacity + device slot until the step ends
+struct Count
+{
+  std::shared_ptr<CountCell> cell;
+  int64_t exact_n = 0; // used when cell == nullptr
+  Count() = default;
+  Count(int64_t n) : exact_n(n) {}
+  bool pending() const { return cell && !cell->resolved; }
+  int64_t cap() const { return cell ? (cell->resolved ? cell->value : cell->cap) : exact_n; } // allocation / grid bound
+  int64_t hint() const { return cell ? (cell->resolved ? cell->value : cell->hint) : exact_n; } // best guess of the value
+  int64_t value() const;        // exact: a pending count is read back now (one counted round trip)
+  DevN devn() const;            // what kernels take
+  operator DevN() const { return devn(); }
+};
+
+// what a site hands to publish: where queued work leaves the total, and how to read it
+enum CountKind { kCountI64 = 0, kCountI32 = 1, kCountPackedLo = 2, kCountPackedHi = 3,
+                 kCountLo32 = 4, kCountHi32 = 5, kCountSum32 = 6 }; // halves of an int64 of two packed 32-bit totals, their sum
+constexpr int kCountPackShift = 34; // packed totals: low bits | high bits << kCountPackShift (the rule scans of cfx_cut.hip)
+// how a site's capacity follows from its value in the previous step: a length that may grow (x margin + slack), or a
+// quantity the host branches on (a flag word, a size class) that has to come out EQUAL or the step is void
+// kCountSizeClass: a maximum the host only compares with 32 / 64 / 128 / 256 (row-length classes that select kernel
+// instantiations): the capacity is the class bound of the previous value
+enum CountMode { kCountUpTo = 0, kCountMustEqual = 1, kCountSizeClass = 2 };
+struct CountSource
+{
+  const void* src = nullptr;
+  int kind = kCountI64;
+  int mode = kCountUpTo;
+  const int64_t* plus = nullptr; // value = read(src, kind) + *plus + add (lengths of concatenated lists); src may be null
+  int64_t add = 0;
+};
+// n sites at once (one read-back outside a step / one publish launch inside one); `names` identify the sites in the
+// step's history (the k-th site of a step must be the k-th site of the previous one, else it reads back as before)
+void count_sites(int n, const char* const* names, const CountSource* src, Count* out);
+inline Count count_site(const char* name, const void* src, int kind = kCountI64, int mode = kCountUpTo)
+{
+  CountSource s{src, kind, mode};
+  Count c;
+  count_sites(1, &name, &s, &c);
+  return c;
+}
+// library lists whose length is still in HBM, by address: the ABI hands (pointer, capacity) out and gets it back in
+// cfx_integral / cfx_cut_* arguments -- the library recognises its own list and takes the published length
+void list_register(const void* p, const Count& c);
+void list_unregister(const void* p);
+Count list_lookup(const void* p, int64_t n_given);
+void step_record(const char* name, int64_t value); // a total the host obtained by other means: keeps the step's site
+                                                   // sequence equal to the one of a step that publishes it
+// a count that must not be zero: checked now when it is on the host, else when the step's read-back resolves it
+void step_require_positive(const Count& c, int code, const char* message);
+Count count_sum(const char* name, const Count& a, const Count& b); // a + b: exact, or published when one is pending
+bool step_speculative();      // inside a step whose sizes come from the previous one
+const int64_t* step_poison(); // the pool's poison word (nullptr outside speculative steps)
+// error words of assembly calls: inside a step they are read with the slots at cfx_step_end (the call returns at
+// once), outside they are read back by the caller as before
+int* step_error_flag(int code, const char* message, void (*decode)(int) = nullptr); // nullptr outside a step
+
+// ---------------------------------------------------------------------------
 // device arrays: owning (cached blocks) or aliasing a caller pointer
 // ---------------------------------------------------------------------------
 // memset on the library stream in ONE launch (hipMemsetAsync splits unaligned sizes into up to three fill kernels,
@@ -196,38 +311,44 @@ template <typename T>
 struct DevArray
 {
   T* p = nullptr;
-  int64_t n = 0;
+  int64_t n = 0;   // elements allocated; the length of the list unless `count` says otherwise
   bool owned = false;
+  Count count;     // lists sized by a previous step: n is their capacity, count the published length
+  DevN devn(int64_t per = 1) const { return count.cell ? count.devn() : DevN(n / per); }
 
   DevArray() = default;
-  explicit DevArray(int64_t count) { alloc(count); }
+  explicit DevArray(int64_t elements) { alloc(elements); }
   DevArray(const DevArray&) = delete;
   DevArray& operator=(const DevArray&) = delete;
-  DevArray(DevArray&& o) noexcept : p(o.p), n(o.n), owned(o.owned) { o.p = nullptr; o.n = 0; o.owned = false; }
+  DevArray(DevArray&& o) noexcept : p(o.p), n(o.n), owned(o.owned), count(std::move(o.count))
+  {
+    o.p = nullptr; o.n = 0; o.owned = false; o.count = Count();
+  }
   DevArray& operator=(DevArray&& o) noexcept
   {
     if (this != &o)
     {
       release();
-      p = o.p; n = o.n; owned = o.owned;
-      o.p = nullptr; o.n = 0; o.owned = false;
+      p = o.p; n = o.n; owned = o.owned; count = std::move(o.count);
+      o.p = nullptr; o.n = 0; o.owned = false; o.count = Count();
     }
     return *this;
   }
   ~DevArray() { release(); }
 
-  void alloc(int64_t count)
+  void alloc(int64_t elements)
   {
     release();
-    n = count;
+    n = elements;
     owned = true;
     // never hand out a null pointer for an empty array
-    p = static_cast<T*>(dev_alloc(sizeof(T) * (size_t)(count > 0 ? count : 1)));
+    p = static_cast<T*>(dev_alloc(sizeof(T) * (size_t)(elements > 0 ? elements : 1)));
   }
   void release()
   {
+    if (p && count.cell) list_unregister(p);
     if (p && owned) dev_free(p);
-    p = nullptr; n = 0; owned = false;
+    p = nullptr; n = 0; owned = false; count = Count();
   }
   void zero() { if (n > 0) dev_fill(p, 0, sizeof(T) * (size_t)n); }
   T* get() const { return p; }
@@ -251,6 +372,22 @@ inline DevArray<T> to_device(const T* src, int64_t n)
   CFX_HIP(hipStreamSynchronize(ctx().stream)); // the host buffer may die right after the call
   return a;
 }
+
+// error word of an assembly call (an entry missing from the pattern, a deactivated row without a diagonal ...): read
+// back by check() outside a step; inside a step it is one of the step's error words, read with the slots at
+// cfx_step_end, which raises the error -- the call itself returns without waiting
+struct ErrorFlag
+{
+  int* p;
+  bool deferred;
+  // decode (optional): raises the error that a non-zero value of the word stands for
+  ErrorFlag(int code, const char* message, void (*decode)(int) = nullptr);
+  void check(int code, const char* message) const;
+};
+// count of a caller-supplied output buffer: the capacity serves for HBM destinations (written in place up to the
+// published length), a host destination is filled from a staging copy and needs the exact count
+int64_t count_for_buffer(const Count& c, const void* user);
+void end_of_call_sync(); // stream synchronisation at the end of an API call -- skipped inside a step
 
 int64_t& sync_counter(); // host round trips so far (cfx_runtime.hip), reported by CFX_COUNT_SYNC=1
 
@@ -428,7 +565,7 @@ struct cfx_rules_s
   cfx_rules_s& operator=(const cfx_rules_s&) = delete;
   cfx_mesh_t mesh = nullptr;
   int tdim = 0, gdim = 0;
-  int64_t nq = 0, nr = 0;
+  cfx::Count nq, nr; // total points / rules (capacities while a step is open, see cfx::Count)
   cfx::DevArray<double> points, weights;
   cfx::DevArray<float> points_f32, weights_f32; // rounded copies behind cfx_rules_view_get_f32 (made on first use)
   cfx::DevArray<int32_t> offsets, parent_map;
@@ -491,10 +628,10 @@ struct cfx_integral_dev
 {
   int type = 0, kernel = 0, qdegree = 0, point_stride = 0;
   cfx::DevArray<int32_t> entities;
-  int64_t n_entities = 0;
+  cfx::Count n_entities;
   cfx_rules_t rules = nullptr;
   uint64_t entities_serial = 0, rules_serial = 0; // identity at form creation (0: caller-owned entity array)
-  int64_t n_std = 0; // interior-facet integrals with facet-hosted rules: entities [n_std, n_entities) are the rules' rows
+  int64_t n_std = -1; // interior-facet integrals with facet-hosted rules: entities [n_std, n_entities) are the rules' rows (-1: none)
   cfx::DevArray<double> point_data;
   cfx::DevArray<double> coefficient; // dof values of a CFX_F_COEFFICIENT field
   double params[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -509,14 +646,14 @@ struct cfx_row_plan
   cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
   cfx::DevArray<uint8_t> rowmark;  // dof touched by any entity of the form
   cfx::DevArray<int32_t> active_rows;
-  int64_t n_active_rows = 0;
+  cfx::Count n_active_rows;
   cfx::DevArray<int32_t> special_rows; // active rows next to the interface: touched by a runtime-rule cell or a facet
-  int64_t n_special_rows = 0;
+  cfx::Count n_special_rows;
   cfx::DevArray<uint8_t> special_mark; // [ndofs] 1 on the special rows
   cfx::DevArray<int32_t> special_pos;  // [ndofs] position of a special row in special_rows (undefined elsewhere);
                                        // the dof->facets incidence (d2f_offsets) is indexed by that position
   cfx::DevArray<int32_t> plain_rows;   // the other active rows: uncut-cell items only
-  int64_t n_plain_rows = 0;
+  cfx::Count n_plain_rows;
   uint64_t serial = 0;                 // identity of this plan (a pattern remembers the plan it was built from)
   // per plain row (built on first use by cfx::plain_row_masks): its stencil mask, and the mark byte that ALL
   // its incident cells carry (0 if they differ or one is unmarked) -- such rows need no mark gathers
@@ -525,14 +662,14 @@ struct cfx_row_plan
   bool plain_masks_built = false;
   // positions in plain_rows where a new row tile (dof id / kRowTile) starts: the work list of the tile kernels
   cfx::DevArray<int32_t> plain_tile_first, plain_tile_id; // ... and the tile's number
-  int64_t n_plain_tiles = 0;
+  cfx::Count n_plain_tiles;
   // linear forms, P1: the element vectors of the uncut cells are staged in the order the plain rows read them
   // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
   // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
   cfx::DevArray<int32_t> vec_t2off;
   cfx::DevArray<int32_t> vec_slow_rows; // active rows without a segment: they gather the per-cell records
-  int64_t n_vec_slow_rows = 0;
-  int64_t vec_t2_total = 0;
+  cfx::Count n_vec_slow_rows;
+  cfx::Count vec_t2_total;
   int vec_fast = -1;
   uint8_t vec_mark = 0;
   // linear forms by cell block (cfx::vec_block_plan, VecBlocks): the blocks that hold a cell with mark `vb_mark`, and
@@ -546,7 +683,7 @@ struct cfx_row_plan
   bool vb_merged = false; // vb_active lists every block with a marked cell (one pass), vb_cut is empty
   bool any_cells = false;
   // interior facets of all facet integrals, concatenated
-  int64_t nfacets = 0;
+  cfx::Count nfacets;
   cfx::DevArray<int32_t> cell_tile_counts; // marked cells per compaction tile of the cells (empty: not counted)
   cfx::DevArray<int64_t> row_tile_counts; // per compaction tile of the dofs: special rows | plain rows << 32
   bool fold_ok = true;                // P1: every facet row shares all dofs but one per cell (continuous space)
@@ -588,6 +725,9 @@ struct cfx_form_s
   int rank = 2;
   std::vector<cfx_integral_dev> integrals;
   std::shared_ptr<cfx_row_plan> plan; // built lazily, possibly shared with another live form
+  // complex128 forms: the integrals that share one complex constant as a real form of their own (cfx_c128.hip), kept
+  // so that the group's row plan survives from one assembly to the next
+  std::map<std::vector<int>, std::unique_ptr<cfx_form_s>> sub_forms;
 };
 
 namespace cfx
@@ -612,9 +752,12 @@ bool assemble_vector_rows(cfx_form_s* L, double* b);
 
 struct cfx_pattern_s
 {
-  int64_t nrows = 0, nnz = 0;
+  int64_t nrows = 0;
+  cfx::Count nnz;
   int64_t ncols = 0; // = nrows unless the form is rectangular
   int max_row_len = 0; // upper bound on the scalar-dof row length
+  uint64_t built_plan = 0; // serial of the plan the pattern was built from (0: rectangular).  Only then are the rows off
+                           // that plan's active set known to hold one diagonal entry each (the fused zero fill relies on it)
   uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)
   // long-row spaces: the plan's active rows split by row length (<= 64 columns / longer)
   uint64_t split_plan = 0;
@@ -650,7 +793,7 @@ struct cfx_active_s
 {
   cfx_space_t V = nullptr;
   cfx::DevArray<int32_t> active_cells, inactive_dofs;
-  int64_t n_active = 0, n_inactive = 0;
+  cfx::Count n_active, n_inactive;
   cfx::DevArray<int32_t> tile_zeros; // scalar spaces: inactive rows per tile of kByteTile rows (empty: not counted)
   cfx::DevArray<int64_t> tile_zero_off; // ... and their exclusive scan: where a tile's rows start in inactive_dofs
 };

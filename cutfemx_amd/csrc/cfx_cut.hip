@@ -365,18 +365,23 @@ __device__ __forceinline__ int sign_mask(const double* phi)
   return m;
 }
 
-constexpr int kPackShift = 34; // (points, rules) of a cut cell packed into one int64 (see cfx_runtime_quadrature)
+constexpr int kPackShift = cfx::kCountPackShift; // (points, rules) of a cut cell packed into one int64 (see cfx_runtime_quadrature)
 constexpr int64_t kPackMask = (1ll << kPackShift) - 1;
 
 // per cut cell: number of rules and points it will emit for `part`
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) cut_count_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
+__global__ void __launch_bounds__(kBlock) cut_count_kernel(DevN ncut_d, const int32_t* __restrict__ cut_cells,
                                                            const int32_t* __restrict__ ls_dofmap,
                                                            const double* __restrict__ phi_v, int part, int nref,
                                                            int64_t* __restrict__ packed)
 {
+  const int64_t ncut = dev_n(ncut_d);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= ncut) return;
+  if (i >= ncut)
+  {
+    if (i < ncut_d.cap) packed[i] = 0; // list shorter than its capacity: the scan runs over the capacity
+    return;
+  }
   const int64_t c = cut_cells[i];
   double phi[TDIM + 1];
 #pragma unroll
@@ -730,10 +735,11 @@ struct EmitJobs
 
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
-    int64_t ncut, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
+    DevN ncut_d, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
     const int32_t* __restrict__ conn, const int32_t* __restrict__ ls_dofmap, const double* __restrict__ phi_v,
     int degree, EmitJobs jobs)
 {
+  const int64_t ncut = dev_n(ncut_d);
   constexpr int NV = TDIM + 1;
   // kEmitLanes lanes share one cut cell (16 cells per wavefront): a cell emits
   // 6-42 points; measured at 256^3: 64 lanes 705 us, 32 -> 445, 16 -> 293, 8 -> 247: more cells in
@@ -965,13 +971,14 @@ __device__ __forceinline__ int64_t rule_of_point(const int32_t* __restrict__ off
 // one thread per rule: the normal of a P1 level set over P1 geometry is constant on the parent cell,
 // so it is formed once per rule and written to the rule's points (no search of the rule, one cell load)
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) normals_rule_kernel(int64_t nr, const int32_t* __restrict__ offsets,
+__global__ void __launch_bounds__(kBlock) normals_rule_kernel(DevN nr_d, const int32_t* __restrict__ offsets,
                                                               const int32_t* __restrict__ parent_map,
                                                               const double* __restrict__ x, const int32_t* __restrict__ conn,
                                                               const int32_t* __restrict__ ls_dofmap,
                                                               const double* __restrict__ phi_v, double sign,
                                                               double* __restrict__ out)
 {
+  const int64_t nr = dev_n(nr_d);
   const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (r >= nr) return;
   const int64_t c = parent_map[r];
@@ -1184,12 +1191,13 @@ __global__ void __launch_bounds__(kBlock) cell_neighbours_kernel(int64_t ncells,
 }
 
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(int64_t ncut, const int32_t* __restrict__ cut_cells,
+__global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(DevN ncut_d, const int32_t* __restrict__ cut_cells,
                                                                    const int32_t* __restrict__ conn,
                                                                    const int32_t* __restrict__ c2c,
                                                                    const int8_t* __restrict__ domain, SelectorPred sel,
                                                                    int32_t* __restrict__ counts, int32_t* __restrict__ cand)
 {
+  const int64_t ncut = dev_n(ncut_d);
   constexpr int NV = TDIM + 1;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (t >= ncut * NV) return;
@@ -1212,10 +1220,11 @@ __global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(int64_t ncut,
 }
 
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) ghost_facets_pack_kernel(int64_t ncut, const int32_t* __restrict__ cand,
+__global__ void __launch_bounds__(kBlock) ghost_facets_pack_kernel(DevN ncut_d, const int32_t* __restrict__ cand,
                                                                    const int64_t* __restrict__ offs,
                                                                    int32_t* __restrict__ rows)
 {
+  const int64_t ncut = dev_n(ncut_d);
   constexpr int NV = TDIM + 1;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncut) return;
@@ -1926,8 +1935,11 @@ void classify(cfx_cut_t cut)
 __global__ void __launch_bounds__(kBlock) locate_inside_cut_kernel(int64_t n, const uint8_t* __restrict__ bytes,
                                                                    const int64_t* __restrict__ off_in,
                                                                    const int64_t* __restrict__ off_cut,
-                                                                   int32_t* __restrict__ out_in, int32_t* __restrict__ out_cut)
+                                                                   int32_t* __restrict__ out_in, int32_t* __restrict__ out_cut,
+                                                                   DevN n_in_d, DevN n_cut_d)
 {
+  // (lists sized by the previous step: nothing is written when a total did not fit -- dev_n is 0 in a void step)
+  const int64_t n_in = dev_n(n_in_d), n_cut = dev_n(n_cut_d);
   const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
   unsigned f_in = 0, f_cut = 0;
   if (base < n)
@@ -1946,11 +1958,12 @@ __global__ void __launch_bounds__(kBlock) locate_inside_cut_kernel(int64_t n, co
   for (int k = 0; k < kByteItems; ++k)
   {
     if (f_in & (1u << k)) s_in[o_in++] = (int32_t)(base + k);
-    if (f_cut & (1u << k)) out_cut[b++] = (int32_t)(base + k);
+    if (f_cut & (1u << k)) { if (b < n_cut) out_cut[b] = (int32_t)(base + k); ++b; }
   }
   __syncthreads();
   const int64_t a = off_in[blockIdx.x];
-  for (int i = threadIdx.x; i < total_in; i += kBlock) out_in[a + i] = s_in[i];
+  for (int i = threadIdx.x; i < total_in; i += kBlock)
+    if (a + i < n_in) out_in[a + i] = s_in[i];
 }
 
 const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
@@ -1972,11 +1985,17 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
       DevArray<int64_t> off_in(ntiles + 1), off_cut(ntiles + 1);
       exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
       exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles);
-      int64_t n_in = 0, n_cut = 0;
-      read_two(off_in.p + ntiles, off_cut.p + ntiles, n_in, n_cut); // (both totals in one round trip)
-      DevArray<int32_t> l_in(n_in), l_cut(n_cut);
+      // (both totals in one round trip -- or none: inside a step they stay in HBM and the lists are sized by the last step)
+      const char* names[2] = {"locate.inside", "locate.cut"};
+      const CountSource src[2] = {{off_in.p + ntiles, kCountI64, kCountUpTo}, {off_cut.p + ntiles, kCountI64, kCountUpTo}};
+      Count cnt[2];
+      count_sites(2, names, src, cnt);
+      DevArray<int32_t> l_in(cnt[0].cap()), l_cut(cnt[1].cap());
+      l_in.count = cnt[0]; l_cut.count = cnt[1];
       launch("locate_entities", locate_inside_cut_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nh, bytes, off_in.p,
-             off_cut.p, l_in.p, l_cut.p);
+             off_cut.p, l_in.p, l_cut.p, l_in.devn(), l_cut.devn());
+      list_register(l_in.p, l_in.count);
+      list_register(l_cut.p, l_cut.count);
       cut->located.emplace("phi<0", std::move(l_in));
       cut->located.emplace("phi=0", std::move(l_cut));
       return cut->located.find(selector)->second;
@@ -1990,6 +2009,19 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
     compact("locate_entities", nh, pred, out);
   auto res = cut->located.emplace(selector, std::move(out));
   return res.first->second;
+}
+
+// the list with its exact length on the host (callers that size host-side work by it)
+const DevArray<int32_t>& locate_exact(cfx_cut_t cut, const std::string& selector)
+{
+  DevArray<int32_t>& a = const_cast<DevArray<int32_t>&>(locate(cut, selector));
+  if (a.count.cell)
+  {
+    a.n = a.count.value();
+    list_unregister(a.p);
+    a.count = Count();
+  }
+  return a;
 }
 
 void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bool whole_hosts, cfx_rules_t* out);
@@ -2091,6 +2123,7 @@ int cfx_locate_entities(cfx_cut_t cut, const char* selector, const int32_t** ent
 {
   CFX_API_BEGIN
   require(cut && selector && entities && n, CFX_ERR_INVALID_ARGUMENT, "cfx_locate_entities: null argument");
+  if (cut->host_width != 0) (void)locate_exact(cut, selector);
   const DevArray<int32_t>& a = locate(cut, selector);
   if (cut->host_width != 0)
   {
@@ -2108,7 +2141,7 @@ int cfx_locate_entities(cfx_cut_t cut, const char* selector, const int32_t** ent
     return CFX_OK;
   }
   *entities = a.p;
-  *n = a.n;
+  *n = a.count.cell ? a.count.cap() : a.n; // (a capacity while the step that made the list is open, cutfemx_amd.h)
   CFX_API_END
 }
 
@@ -2190,12 +2223,12 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
   cfx_mesh_t mesh = cut->mesh;
   const int tdim = mesh->tdim;
   const DevArray<int32_t>& cutc = locate(cut, "phi=0");
-  const int64_t ncut = cutc.n;
+  const DevN ncut_d = cutc.devn();
+  const int64_t ncut = ncut_d.cap; // (the capacity of the list while its length is still in HBM: grids and scans run over it)
   const double* phi = cut->ls_values[0].p;
   require(ncut < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
   std::unique_ptr<cfx_rules_s> r[2];
   DevArray<int64_t> packed[2], packed_off[2];
-  DevArray<int64_t> totals_dev(2);
   for (int k = 0; k < n; ++k)
   {
     const int nref = quad_npoints(parts[k] == PART_IF ? tdim - 1 : tdim, order);
@@ -2206,27 +2239,34 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     if (ncut > 0)
     {
       if (tdim == 2)
-        launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+        launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi,
                parts[k], nref, packed[k].p);
       else
-        launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cutc.p, cut->ls_dofmap.p, phi,
+        launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi,
                parts[k], nref, packed[k].p);
     }
     // one scan for both totals of a part: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so below
     // 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
     exclusive_scan(packed[k].p, packed_off[k].p, ncut);
-    CFX_HIP(hipMemcpyAsync(totals_dev.p + k, packed_off[k].p + ncut, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx().stream));
   }
-  struct Two { int64_t v[2]; };
-  const Two totals = read_scalar(reinterpret_cast<const Two*>(totals_dev.p));
+  // the totals of all parts in one round trip (none inside a step: they stay in HBM)
+  const char* names[4] = {"rules.points.0", "rules.rules.0", "rules.points.1", "rules.rules.1"};
+  CountSource src[4];
+  Count totals[4];
+  for (int k = 0; k < n; ++k)
+  {
+    src[2 * k] = CountSource{packed_off[k].p + ncut, kCountPackedLo, kCountUpTo};
+    src[2 * k + 1] = CountSource{packed_off[k].p + ncut, kCountPackedHi, kCountUpTo};
+  }
+  count_sites(2 * n, names, src, totals);
   EmitJobs jobs{};
   jobs.n = n;
   for (int k = 0; k < n; ++k)
   {
-    const int64_t nq = totals.v[k] & kPackMask, nr = totals.v[k] >> kPackShift;
+    const int64_t nq = totals[2 * k].cap(), nr = totals[2 * k + 1].cap();
     // int32 offsets are part of the RuntimeQuadrature contract
     require(nq < 2147483647LL, CFX_ERR_RUNTIME, "runtime quadrature: more than 2^31 points (int32 offsets)");
-    r[k]->nq = nq; r[k]->nr = nr;
+    r[k]->nq = totals[2 * k]; r[k]->nr = totals[2 * k + 1];
     r[k]->points.alloc(nq * tdim);
     r[k]->weights.alloc(nq);
     r[k]->offsets.alloc(nr + 1);
@@ -2240,10 +2280,10 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
   {
     const dim3 grid((unsigned)((ncut + kBlock / kEmitLanes - 1) / (kBlock / kEmitLanes)));
     if (tdim == 2)
-      launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+      launch("cut_emit", cut_emit_kernel<2>, grid, dim3(kBlock), 0, ncut_d, cutc.p, mesh->x.p, mesh->conn.p,
              cut->ls_dofmap.p, phi, order, jobs);
     else
-      launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut, cutc.p, mesh->x.p, mesh->conn.p,
+      launch("cut_emit", cut_emit_kernel<3>, grid, dim3(kBlock), 0, ncut_d, cutc.p, mesh->x.p, mesh->conn.p,
              cut->ls_dofmap.p, phi, order, jobs);
   }
   for (int k = 0; k < n; ++k) out[k] = r[k].release();
@@ -2347,7 +2387,7 @@ int cfx_full_cell_rules(cfx_mesh_t mesh, const int32_t* cells, int64_t n, int or
   DevArray<int32_t> dcells = to_device(cells, n);
   auto r = std::make_unique<cfx_rules_s>();
   r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = n; r->nq = n * nref;
-  r->points.alloc(r->nq * tdim); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
+  r->points.alloc(n * nref * tdim); r->weights.alloc(n * nref); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
   dev_fill(r->offsets.p, 0, sizeof(int32_t));
   if (n > 0)
   {
@@ -2384,7 +2424,8 @@ int cfx_rules_view_get(cfx_rules_t r, cfx_rules_view* v)
 {
   CFX_API_BEGIN
   require(r && v, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_view_get: null argument");
-  v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq; v->nr = r->nr;
+  // (capacities while the step that made the rules is open: the arrays are at least that long, cutfemx_amd.h)
+  v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq.cap(); v->nr = r->nr.cap();
   v->points = r->points.p; v->weights = r->weights.p; v->offsets = r->offsets.p; v->parent_map = r->parent_map.p;
   v->host_width = r->host_width; v->reserved = 0;
   v->host_rows = r->host_width ? r->host_rows.p : nullptr;
@@ -2396,24 +2437,25 @@ int cfx_rules_physical_points(cfx_rules_t r, double* out)
 {
   CFX_API_BEGIN
   require(r && out, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_physical_points: null argument");
-  OutArray<double> o(out, r->nq * r->gdim, false);
-  if (r->nq > 0 && r->host_width != 0)
+  const int64_t nq = r->nq.value(), nr = r->nr.value(); // (a host array of nq points: the exact count)
+  OutArray<double> o(out, nq * r->gdim, false);
+  if (nq > 0 && r->host_width != 0)
   {
     // physical_points_for_host_mesh (cut.cpp:1344-1345)
     if (r->mesh->tdim == 2)
-      launch("physical_points", facet_physical_points_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+      launch("physical_points", facet_physical_points_kernel<2>, grid_for(nq), dim3(kBlock), 0, nq, nr,
              r->offsets.p, r->host_verts.p, r->points.p, r->mesh->x.p, o.dev);
     else
-      launch("physical_points", facet_physical_points_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+      launch("physical_points", facet_physical_points_kernel<3>, grid_for(nq), dim3(kBlock), 0, nq, nr,
              r->offsets.p, r->host_verts.p, r->points.p, r->mesh->x.p, o.dev);
   }
-  else if (r->nq > 0)
+  else if (nq > 0)
   {
     if (r->tdim == 2)
-      launch("physical_points", physical_points_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+      launch("physical_points", physical_points_kernel<2>, grid_for(nq), dim3(kBlock), 0, nq, nr,
              r->offsets.p, r->parent_map.p, r->points.p, r->mesh->x.p, r->mesh->conn.p, o.dev);
     else
-      launch("physical_points", physical_points_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr,
+      launch("physical_points", physical_points_kernel<3>, grid_for(nq), dim3(kBlock), 0, nq, nr,
              r->offsets.p, r->parent_map.p, r->points.p, r->mesh->x.p, r->mesh->conn.p, o.dev);
   }
   o.finish();
@@ -2435,14 +2477,17 @@ int cfx_evaluate_normals(cfx_cut_t cut, int ls, cfx_rules_t r, double sign, doub
   require(r->tdim == cut->mesh->tdim, CFX_ERR_RUNTIME, "Normal evaluation points must have cell reference dimension.");
   require(cut->ls_ndofs_cell == cut->mesh->tdim + 1, CFX_ERR_INVALID_ARGUMENT,
           "normal evaluation is implemented for P1 level sets");
-  OutArray<double> o(out, r->nq * r->gdim, false);
-  if (r->nq > 0)
+  // a device destination takes the rules' capacity (nq.cap() doubles per component) while their length is in HBM;
+  // a host destination needs the exact count
+  if (!is_device_pointer(out)) (void)r->nq.value();
+  OutArray<double> o(out, r->nq.cap() * r->gdim, false);
+  if (r->nq.cap() > 0)
   {
     if (r->tdim == 2)
-      launch("evaluate_normals", normals_rule_kernel<2>, grid_for(r->nr), dim3(kBlock), 0, r->nr, r->offsets.p,
+      launch("evaluate_normals", normals_rule_kernel<2>, grid_for(r->nr.cap()), dim3(kBlock), 0, r->nr, r->offsets.p,
              r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
     else
-      launch("evaluate_normals", normals_rule_kernel<3>, grid_for(r->nr), dim3(kBlock), 0, r->nr, r->offsets.p,
+      launch("evaluate_normals", normals_rule_kernel<3>, grid_for(r->nr.cap()), dim3(kBlock), 0, r->nr, r->offsets.p,
              r->parent_map.p, cut->mesh->x.p, cut->mesh->conn.p, cut->ls_dofmap.p, cut->ls_values[ls].p, sign, o.dev);
   }
   o.finish();
@@ -2456,14 +2501,15 @@ int cfx_evaluate_values(cfx_cut_t cut, int ls, cfx_rules_t r, double* out)
   require(ls >= 0 && ls < cut->nls, CFX_ERR_OUT_OF_RANGE, "level-set index out of range");
   require(cut->ls_ndofs_cell == cut->mesh->tdim + 1, CFX_ERR_INVALID_ARGUMENT,
           "value evaluation is implemented for P1 level sets");
-  OutArray<double> o(out, r->nq, false);
-  if (r->nq > 0)
+  const int64_t nq = r->nq.value(), nr = r->nr.value();
+  OutArray<double> o(out, nq, false);
+  if (nq > 0)
   {
     if (r->tdim == 2)
-      launch("evaluate_values", values_kernel<2>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+      launch("evaluate_values", values_kernel<2>, grid_for(nq), dim3(kBlock), 0, nq, nr, r->offsets.p,
              r->parent_map.p, r->points.p, cut->ls_dofmap.p, cut->ls_values[ls].p, o.dev);
     else
-      launch("evaluate_values", values_kernel<3>, grid_for(r->nq), dim3(kBlock), 0, r->nq, r->nr, r->offsets.p,
+      launch("evaluate_values", values_kernel<3>, grid_for(nq), dim3(kBlock), 0, nq, nr, r->offsets.p,
              r->parent_map.p, r->points.p, cut->ls_dofmap.p, cut->ls_values[ls].p, o.dev);
   }
   o.finish();
@@ -2481,43 +2527,50 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
     if (it != cut->ghost_rows.end())
     {
       *rows = it->second.p;
-      *n = it->second.n / 4;
+      *n = it->second.count.cell ? it->second.count.cap() : it->second.n / 4;
       return CFX_OK;
     }
   }
   SelectorPred pred{cut->domain.p, mesh->ncells, parse_selector(selector, cut->nls)};
   const DevArray<int32_t>& cutc = locate(cut, "phi=0");
-  const int64_t ncut = cutc.n;
+  const DevN ncut_d = cutc.devn();
+  const int64_t ncut = ncut_d.cap; // (capacity while the list's length is in HBM: the counts behind it stay zero)
   const DevArray<int32_t>& c2c = mesh->cell_neighbours();
   DevArray<int32_t> counts(ncut), cand(ncut * (int64_t)(mesh->tdim + 1) * 4);
   DevArray<int64_t> offs(ncut + 1);
-  int64_t total = 0;
+  Count total(0);
   if (ncut > 0)
   {
     counts.zero();
     const int64_t nthreads = ncut * (mesh->tdim + 1);
     if (mesh->tdim == 2)
-      launch("ghost_facets_find", ghost_facets_find_kernel<2>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
+      launch("ghost_facets_find", ghost_facets_find_kernel<2>, grid_for(nthreads), dim3(kBlock), 0, ncut_d, cutc.p,
              mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);
     else
-      launch("ghost_facets_find", ghost_facets_find_kernel<3>, grid_for(nthreads), dim3(kBlock), 0, ncut, cutc.p,
+      launch("ghost_facets_find", ghost_facets_find_kernel<3>, grid_for(nthreads), dim3(kBlock), 0, ncut_d, cutc.p,
              mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);
     exclusive_scan(counts.p, offs.p, ncut);
-    total = read_scalar(offs.p + ncut);
+    total = count_site("ghost_facets", offs.p + ncut);
   }
   DevArray<int32_t>& grows = cut->ghost_rows[selector];
-  grows.alloc(total * 4);
-  if (total > 0)
+  grows.alloc(total.cap() * 4);
+  if (total.cap() > 0)
   {
+    // (a total beyond the capacity voids the step before this launch: ncut_d then reads 0 and nothing is written)
     if (mesh->tdim == 2)
-      launch("ghost_facets_pack", ghost_facets_pack_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut, cand.p, offs.p,
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cand.p, offs.p,
              grows.p);
     else
-      launch("ghost_facets_pack", ghost_facets_pack_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut, cand.p, offs.p,
+      launch("ghost_facets_pack", ghost_facets_pack_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cand.p, offs.p,
              grows.p);
   }
+  if (total.cell)
+  {
+    grows.count = total;
+    list_register(grows.p, total);
+  }
   *rows = grows.p;
-  *n = total;
+  *n = total.cap();
   CFX_API_END
 }
 
@@ -2595,13 +2648,14 @@ int cfx_cell_aggregation_create(cfx_cut_t cut, const char* selector, double thre
     const int rc = cfx_runtime_quadrature(cut, selector, 1, "straight", &rules);
     if (rc != CFX_OK) throw Error(rc, cfx_last_error());
     std::unique_ptr<cfx_rules_s> guard(rules);
-    if (rules->nr > 0)
+    const int64_t nrules = rules->nr.value();
+    if (nrules > 0)
     {
       if (tdim == 2)
-        launch("agg_fraction", agg_fraction_kernel<2>, grid_for(rules->nr), dim3(kBlock), 0, rules->nr, rules->offsets.p,
+        launch("agg_fraction", agg_fraction_kernel<2>, grid_for(nrules), dim3(kBlock), 0, nrules, rules->offsets.p,
                rules->parent_map.p, rules->weights.p, mesh->x.p, mesh->conn.p, A->fraction.p);
       else
-        launch("agg_fraction", agg_fraction_kernel<3>, grid_for(rules->nr), dim3(kBlock), 0, rules->nr, rules->offsets.p,
+        launch("agg_fraction", agg_fraction_kernel<3>, grid_for(nrules), dim3(kBlock), 0, nrules, rules->offsets.p,
                rules->parent_map.p, rules->weights.p, mesh->x.p, mesh->conn.p, A->fraction.p);
     }
     CFX_HIP(hipStreamSynchronize(ctx().stream)); // the rules die here
@@ -2734,12 +2788,12 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
   const double* phi = cut->ls_values[0].p;
   if (whole_hosts)
   {
-    const DevArray<int32_t>* hosts = selector ? &locate(cut, selector) : nullptr;
+    const DevArray<int32_t>* hosts = selector ? &locate_exact(cut, selector) : nullptr;
     const int64_t n = hosts ? hosts->n : cut->n_hosts;
     const int nref = quad_npoints(hd, order);
     require(n * nref < 2147483647LL, CFX_ERR_RUNTIME, "too many points for int32 offsets");
     r->nr = n; r->nq = n * nref;
-    r->points.alloc(r->nq * hd); r->weights.alloc(r->nq); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
+    r->points.alloc(n * nref * hd); r->weights.alloc(n * nref); r->offsets.alloc(n + 1); r->parent_map.alloc(n);
     rule_host.alloc(n);
     dev_fill(r->offsets.p, 0, sizeof(int32_t));
     if (n > 0)
@@ -2762,7 +2816,7 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
     const int part = (m == 2) ? PART_IF : ((m & 1) ? PART_IN : PART_OUT);
     // phi = 0 on a facet: a point (segment hosts) or a straight segment (triangle hosts)
     const int nref = part == PART_IF ? (hd == 1 ? 1 : quad_npoints(1, order)) : quad_npoints(hd, order);
-    const DevArray<int32_t>& cuth = locate(cut, "phi=0");
+    const DevArray<int32_t>& cuth = locate_exact(cut, "phi=0");
     const int64_t ncut = cuth.n;
     DevArray<int32_t> n_rules(ncut), n_points(ncut), rule_off(ncut + 1), point_off(ncut + 1);
     if (ncut > 0)
@@ -2798,13 +2852,14 @@ void facet_runtime_quadrature(cfx_cut_t cut, const char* selector, int order, bo
     }
   }
   // the rules carry their hosts' rows and vertices: they outlive the cut object
-  r->host_rows.alloc(r->nr * cut->host_width);
-  r->host_verts.alloc(r->nr * tdim);
-  if (r->nr > 0)
+  const int64_t nrh = r->nr.value();
+  r->host_rows.alloc(nrh * cut->host_width);
+  r->host_verts.alloc(nrh * tdim);
+  if (nrh > 0)
   {
-    launch("facet_gather_rows", gather_rows_kernel, grid_for(r->nr * cut->host_width), dim3(kBlock), 0, r->nr, rule_host.p,
+    launch("facet_gather_rows", gather_rows_kernel, grid_for(nrh * cut->host_width), dim3(kBlock), 0, nrh, rule_host.p,
            cut->host_width, cut->host_rows.p, r->host_rows.p);
-    launch("facet_gather_rows", gather_rows_kernel, grid_for(r->nr * tdim), dim3(kBlock), 0, r->nr, rule_host.p, tdim,
+    launch("facet_gather_rows", gather_rows_kernel, grid_for(nrh * tdim), dim3(kBlock), 0, nrh, rule_host.p, tdim,
            cut->host_verts.p, r->host_verts.p);
   }
   CFX_HIP(hipStreamSynchronize(ctx().stream));
@@ -2939,7 +2994,7 @@ int cfx_facet_rules_to_cells(cfx_rules_t R, int side, cfx_rules_t* out)
           "cfx_facet_rules_to_cells: side is 0, or 1 for interior-facet rows");
   cfx_mesh_t mesh = R->mesh;
   const int tdim = mesh->tdim;
-  const int64_t nr = R->nr, nq = R->nq;
+  const int64_t nr = R->nr.value(), nq = R->nq.value();
   auto r = std::make_unique<cfx_rules_s>();
   r->mesh = mesh; r->tdim = tdim; r->gdim = mesh->gdim; r->nr = nr; r->nq = nq;
   r->points.alloc(nq * tdim); r->weights.alloc(nq); r->offsets.alloc(nr + 1); r->parent_map.alloc(nr);

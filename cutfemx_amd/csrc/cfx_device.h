@@ -147,6 +147,69 @@ inline int64_t compact(const char* name, int64_t n, Pred pred, DevArray<int32_t>
   return total;
 }
 
+// the same compaction over a list whose own length may still be in HBM (`n`), the total a count site (cfx_common.h)
+template <typename Pred>
+__global__ void __launch_bounds__(kBlock) compact_count_n_kernel(DevN n_d, Pred pred, int32_t* tile_counts)
+{
+  const int64_t n = dev_n(n_d);
+  const int64_t base = (int64_t)blockIdx.x * kTile;
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+    if (i < n && pred(i)) ++c;
+  }
+  int total;
+  (void)block_exclusive_scan<int>(c, total);
+  if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+template <typename Pred>
+__global__ void __launch_bounds__(kBlock) compact_write_n_kernel(DevN n_d, Pred pred, const int64_t* tile_offsets,
+                                                                 int32_t* out, DevN out_n)
+{
+  const int64_t n = dev_n(n_d);
+  const int64_t cap = out_n.dev ? dev_n(out_n) : INT64_MAX;
+  const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kScanItems;
+  bool f[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + k;
+    f[k] = (i < n) && pred(i);
+    c += f[k] ? 1 : 0;
+  }
+  int total;
+  int off = block_exclusive_scan<int>(c, total);
+  int64_t o = tile_offsets[blockIdx.x] + off;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (f[k]) { if (o < cap) out[o] = (int32_t)(base + k); ++o; }
+}
+
+template <typename Pred>
+inline Count compact_count(const char* name, const char* site, DevN n, Pred pred, DevArray<int32_t>& out)
+{
+  const int64_t ntiles = (n.cap + kTile - 1) / kTile;
+  if (ntiles == 0)
+  {
+    out.alloc(0);
+    step_record(site, 0);
+    return Count(0);
+  }
+  DevArray<int32_t> counts(ntiles);
+  DevArray<int64_t> offsets(ntiles + 1);
+  launch(name, compact_count_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, counts.p);
+  exclusive_scan(counts.p, offsets.p, ntiles);
+  const Count total = count_site(site, offsets.p + ntiles);
+  out.alloc(total.cap());
+  if (total.cell) out.count = total;
+  launch(name, compact_write_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, offsets.p, out.p, total.devn());
+  return total;
+}
+
 // ---------------------------------------------------------------------------
 // compaction of a byte array (classification codes, flags): 16 B per lane per
 // load, so a wave streams 1 KiB per instruction instead of 64 B.
@@ -188,8 +251,10 @@ template <typename ByteTest>
 __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, const uint8_t* __restrict__ bytes,
                                                                      ByteTest test,
                                                                      const int64_t* __restrict__ tile_offsets,
-                                                                     int32_t* __restrict__ out)
+                                                                     int32_t* __restrict__ out, DevN out_n)
 {
+  // (a list sized by the previous step: nothing beyond its published length -- 0 in a void step -- is written)
+  const int64_t cap = out_n.dev ? dev_n(out_n) : INT64_MAX;
   // the tile's hits are packed in LDS first: the global stores are then one contiguous, coalesced run per tile
   // (direct stores leave every lane with its own short run: 64 partial sectors per store instruction)
   __shared__ int32_t s_out[kByteTile];
@@ -202,7 +267,8 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
     if (f & (1u << k)) s_out[off++] = (int32_t)(base + k);
   __syncthreads();
   const int64_t o = tile_offsets[blockIdx.x];
-  for (int i = threadIdx.x; i < total; i += kBlock) out[o + i] = s_out[i];
+  for (int i = threadIdx.x; i < total; i += kBlock)
+    if (o + i < cap) out[o + i] = s_out[i];
 }
 
 __global__ inline void ride_along_kernel(const int64_t* a, const int* b, int64_t* out)
@@ -244,7 +310,38 @@ inline int64_t compact_bytes(const char* name, int64_t n, const uint8_t* bytes, 
   else total = read_scalar(offsets.p + ntiles);
   out.alloc(total);
   launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
-         offsets.p, out.p);
+         offsets.p, out.p, DevN());
+  return total;
+}
+
+// the same compaction for lists that the kernels of a sync-free step consume: the total is a count site (`site`: its
+// name in the step's history) -- read back at once outside a step, left in HBM inside one, where `out` is sized by the
+// previous step's total and carries the published length (out.count)
+template <typename ByteTest>
+inline Count compact_bytes_count(const char* name, const char* site, int64_t n, const uint8_t* bytes, ByteTest test,
+                                 DevArray<int32_t>& out, const int32_t* tile_counts = nullptr)
+{
+  const int64_t ntiles = (n + kByteTile - 1) / kByteTile;
+  if (ntiles == 0)
+  {
+    out.alloc(0);
+    step_record(site, 0);
+    return Count(0);
+  }
+  DevArray<int32_t> counts;
+  DevArray<int64_t> offsets(ntiles + 1);
+  if (!tile_counts)
+  {
+    counts.alloc(ntiles);
+    launch(name, compact_bytes_count_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
+           counts.p);
+  }
+  exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles);
+  const Count total = count_site(site, offsets.p + ntiles);
+  out.alloc(total.cap());
+  if (total.cell) out.count = total;
+  launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
+         offsets.p, out.p, total.devn());
   return total;
 }
 

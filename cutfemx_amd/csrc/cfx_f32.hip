@@ -175,7 +175,7 @@ int cfx_rules_view_get_f32(cfx_rules_t r, cfx_rules_view_f32* v)
     narrow<false>(r->points.p, r->points_f32.p, r->points.n);
     narrow<false>(r->weights.p, r->weights_f32.p, r->weights.n);
   }
-  v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq; v->nr = r->nr;
+  v->tdim = r->tdim; v->gdim = r->gdim; v->nq = r->nq.value(); v->nr = r->nr.value(); // (the float32 boundary works with exact lengths)
   v->points = r->points_f32.p; v->weights = r->weights_f32.p;
   v->offsets = r->offsets.p; v->parent_map = r->parent_map.p;
   v->host_width = r->host_width; v->reserved = 0;
@@ -188,7 +188,7 @@ int cfx_rules_physical_points_f32(cfx_rules_t r, float* out)
 {
   CFX_API_BEGIN
   require(r && out, CFX_ERR_INVALID_ARGUMENT, "cfx_rules_physical_points_f32: null argument");
-  DevArray<double> tmp(r->nq * r->gdim);
+  DevArray<double> tmp(r->nq.value() * r->gdim);
   const int rc = cfx_rules_physical_points(r, tmp.p);
   if (rc != CFX_OK) return rc;
   narrow<false>(tmp.p, out, tmp.n);
@@ -199,7 +199,7 @@ int cfx_evaluate_normals_f32(cfx_cut_t cut, int level_set, cfx_rules_t rules, fl
 {
   CFX_API_BEGIN
   require(cut && rules && out, CFX_ERR_INVALID_ARGUMENT, "cfx_evaluate_normals_f32: null argument");
-  DevArray<double> tmp(rules->nq * rules->gdim);
+  DevArray<double> tmp(rules->nq.value() * rules->gdim);
   const int rc = cfx_evaluate_normals(cut, level_set, rules, (double)sign, tmp.p);
   if (rc != CFX_OK) return rc;
   narrow<false>(tmp.p, out, tmp.n);
@@ -210,7 +210,7 @@ int cfx_evaluate_values_f32(cfx_cut_t cut, int level_set, cfx_rules_t rules, flo
 {
   CFX_API_BEGIN
   require(cut && rules && out, CFX_ERR_INVALID_ARGUMENT, "cfx_evaluate_values_f32: null argument");
-  DevArray<double> tmp(rules->nq);
+  DevArray<double> tmp(rules->nq.value());
   const int rc = cfx_evaluate_values(cut, level_set, rules, tmp.p);
   if (rc != CFX_OK) return rc;
   narrow<false>(tmp.p, out, tmp.n);
@@ -232,10 +232,11 @@ static int assemble_matrix_f32(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0,
 {
   CFX_API_BEGIN
   require(a && P && values, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix_f32: null argument");
-  DevArray<double> tmp(P->nnz);
+  const int64_t nnz = P->nnz.value();
+  DevArray<double> tmp(nnz);
   const int rc = cfx_assemble_matrix_zeroed(a, P, bc0, bc1, tmp.p);
   if (rc != CFX_OK) return rc;
-  if (add) narrow<true>(tmp.p, values, P->nnz); else narrow<false>(tmp.p, values, P->nnz);
+  if (add) narrow<true>(tmp.p, values, nnz); else narrow<false>(tmp.p, values, nnz);
   CFX_API_END
 }
 
@@ -295,7 +296,7 @@ int cfx_zero_rows_f32(cfx_pattern_t P, const float* values, float tol, int32_t**
 {
   CFX_API_BEGIN
   require(P && values && rows && n_rows, CFX_ERR_INVALID_ARGUMENT, "cfx_zero_rows_f32: null argument");
-  DevArray<float> dv = to_device(values, P->nnz);
+  DevArray<float> dv = to_device(values, P->nnz.value());
   DevArray<int32_t> list;
   const int64_t n = compact("zero_rows", P->nrows, RowAllZero32{P->indptr.p, dv.p, tol}, list);
   int32_t* out = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
@@ -313,11 +314,12 @@ int cfx_deactivate_outside_f32(cfx_active_t d, cfx_pattern_t P, float* values, f
   require(d && (values == nullptr || P), CFX_ERR_INVALID_ARGUMENT, "cfx_deactivate_outside_f32: null argument");
   const int64_t nrows = d->V->ndofs * d->V->bs;
   std::unique_ptr<OutArray<float>> ov, ob;
-  if (values) ov = std::make_unique<OutArray<float>>(values, P->nnz, true);
+  if (values) ov = std::make_unique<OutArray<float>>(values, P->nnz.value(), true);
   if (b) ob = std::make_unique<OutArray<float>>(b, nrows, true);
   ZeroFlag err;
-  if (d->n_inactive > 0)
-    launch("deactivate", deactivate_f32_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
+  const int64_t n_inactive = d->n_inactive.value();
+  if (n_inactive > 0)
+    launch("deactivate", deactivate_f32_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
            d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,
            b ? ob->dev : nullptr, diagonal, rhs_value, err.p);
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "Deactivated matrix row has no diagonal entry.");

@@ -24,7 +24,7 @@ struct AsmArgs
   const int32_t* conn;
   const int32_t* dofmap;
   // entity description
-  int64_t n;                 // entities in this launch
+  DevN n;                    // entities in this launch (length in HBM inside a sync-free step)
   const int32_t* entities;   // standard: cell ids / facet rows
   const int32_t* offsets;    // runtime rules
   const int32_t* parent_map;
@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(kBlock) assemble_cells_kernel(AsmArgs A)
   constexpr int NLOC = ND * BS;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e = tid / NLOC;
-  if (e >= A.n) return;
+  if (e >= dev_n(A.n)) return;
   const int i = (int)(tid - e * NLOC);
   const int ia = i / BS, ik = i - ia * BS;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
   constexpr int NLOC = 2 * ND * BS;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t fl = tid / NLOC;
-  if (fl >= A.n) return;
+  if (fl >= dev_n(A.n)) return;
   const int I = (int)(tid - fl * NLOC);
   const int ia = I / BS, ik = I - ia * BS; // macro basis index, component
   const int64_t f = fl + A.f0;            // entity of the integral; A.entities / point_data / dump are indexed by it
@@ -321,7 +321,7 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
       for (int j = 0; j < NLOC; ++j) s_row[threadIdx.x * NLOC + j] = acc[j];
       __syncthreads(); // (threads past the end of the launch have left: the barrier counts the live waves)
       const int64_t first = ((int64_t)blockIdx.x * kBlock + (A.f0 - A.dump0) * NLOC) * NLOC;
-      const int nthreads = (int)min((int64_t)kBlock, A.n * NLOC - (int64_t)blockIdx.x * kBlock); // threads 0..nthreads-1 are here
+      const int nthreads = (int)min((int64_t)kBlock, dev_n(A.n) * NLOC - (int64_t)blockIdx.x * kBlock); // threads 0..nthreads-1 are here
       for (int i = threadIdx.x; i < nthreads * NLOC; i += nthreads) A.dump[first + i] = s_row[i];
     }
     else
@@ -395,7 +395,7 @@ __global__ void __launch_bounds__(kBlock) cut_tensors_p1_kernel(AsmArgs A)
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e = tid / kCutLanes;
   const int sub = (int)(tid - e * kCutLanes);
-  if (e >= A.n) return;
+  if (e >= dev_n(A.n)) return;
   const int64_t cell = A.parent_map[e];
   Geo<TDIM> g;
   load_cell<TDIM>(A.x, A.conn, cell, g);
@@ -535,7 +535,9 @@ __global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
   // cell id -> connectivity row -> vertex coordinates are three dependent loads: a software pipeline three deep
   // keeps them ahead of the arithmetic (cell e is computed while the coordinates of e + nwaves, the connectivity
   // row of e + 2 nwaves and the id of e + 3 nwaves are in flight); indices past the end load the last entity again
-  const int64_t last = A.n - 1;
+  const int64_t An = dev_n(A.n);
+  if (An == 0) return;
+  const int64_t last = An - 1;
   auto cell_of = [&](int64_t i) { i = i < last ? i : last; return RUNTIME ? A.parent_map[i] : A.entities[i]; };
   auto conn_of = [&](int32_t c, int32_t* v)
   {
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int d = 0; d < 3; ++d) xa[i][d] = A.x[3 * (int64_t)va[i] + d];
-  for (int64_t e = blockIdx.x; e < A.n; e += nwaves)
+  for (int64_t e = blockIdx.x; e < An; e += nwaves)
   {
     const int32_t cell_d = cell_of(e + 3 * nwaves);
     int32_t vc[4];
@@ -704,33 +706,46 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
     require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "interior-facet integrals are implemented for bilinear forms");
     A.entities = I.entities.p;
     A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr; // per-pair factors
-    A.n_std = I.n_std;
+    A.n_std = I.n_std < 0 ? INT64_MAX : I.n_std; // (no facet-hosted rules: every entity is a standard facet)
     A.dump0 = single ? only_index : 0;
     if (I.rules)
     {
       A.offsets = I.rules->offsets.p; A.points = I.rules->points.p; A.weights = I.rules->weights.p;
       A.host_verts = I.rules->host_verts.p;
     }
-    // standard entities [0, n_std), then the rules' entities [n_std, n_entities)
-    const int64_t lo = single ? only_index : 0, hi = single ? only_index + 1 : I.n_entities;
-    const int64_t mid = std::min(std::max(I.n_std, lo), hi);
     const bool dg = A.kernel == CFX_K_JUMP || A.kernel == CFX_K_SIP;
+    if (!single && !I.rules)
+    {
+      // standard facets only (the ghost-penalty band): the whole list, whose length may still be in HBM
+      A.f0 = 0; A.n = I.n_entities;
+      if (A.n.cap > 0)
+      {
+        if (dg)
+          launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 1>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock), 0, A);
+        else
+          launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 0>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock), 0, A);
+      }
+      return;
+    }
+    // standard entities [0, n_std), then the rules' entities [n_std, n_entities)
+    const int64_t lo = single ? only_index : 0, hi = single ? only_index + 1 : I.n_entities.value();
+    const int64_t mid = std::min(std::max(I.n_std < 0 ? hi : I.n_std, lo), hi);
     if (mid > lo)
     {
       A.f0 = lo; A.n = mid - lo;
       if (dg)
-        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 1>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
+        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 1>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock), 0, A);
       else
-        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 0>, grid_for(A.n * 2 * ND * BS), dim3(kBlock), 0, A);
+        launch("assemble_facets", assemble_facets_kernel<TDIM, DEG, BS, false, 0>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock), 0, A);
     }
     if (hi > mid)
     {
       A.f0 = mid; A.n = hi - mid;
       if (dg)
-        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 1>, grid_for(A.n * 2 * ND * BS), dim3(kBlock),
+        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 1>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock),
                0, A);
       else
-        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 0>, grid_for(A.n * 2 * ND * BS), dim3(kBlock),
+        launch("assemble_facets_cut", assemble_facets_kernel<TDIM, DEG, BS, true, 0>, grid_for(A.n.cap * 2 * ND * BS), dim3(kBlock),
                0, A);
     }
     return;
@@ -743,51 +758,51 @@ void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A
   auto mfma_grid = [](int64_t n) { return dim3((unsigned)std::min<int64_t>(n, 256 * 32)); };
   if ((parts & 1) && (!single || !use_rule))
   {
-    A.n = single ? 1 : I.n_entities;
+    A.n = single ? DevN(1) : I.n_entities.devn();
     A.entities = I.entities.p + (single ? only_index : 0);
-    if (A.n > 0)
+    if (A.n.cap > 0)
     {
       if (mfma_tensors)
       {
         if constexpr (TDIM == 3 && BS == 3)
-          launch("elasticity_tensors_mfma", elasticity_tensors_mfma_kernel<DEG, false>, mfma_grid(A.n), dim3(64), 0, A);
+          launch("elasticity_tensors_mfma", elasticity_tensors_mfma_kernel<DEG, false>, mfma_grid(A.n.cap), dim3(64), 0, A);
       }
       else if (a->rank == 2)
-        launch("assemble_cells_std", assemble_cells_kernel<TDIM, DEG, BS, 2, false>, grid_for(A.n * ND * BS),
+        launch("assemble_cells_std", assemble_cells_kernel<TDIM, DEG, BS, 2, false>, grid_for(A.n.cap * ND * BS),
                dim3(kBlock), 0, A);
       else
-        launch("assemble_vec_std", assemble_cells_kernel<TDIM, DEG, BS, 1, false>, grid_for(A.n * ND * BS),
+        launch("assemble_vec_std", assemble_cells_kernel<TDIM, DEG, BS, 1, false>, grid_for(A.n.cap * ND * BS),
                dim3(kBlock), 0, A);
     }
   }
   if ((parts & 2) && I.rules && (!single || use_rule))
   {
     const cfx_rules_s* R = I.rules;
-    A.n = single ? 1 : R->nr;
+    A.n = single ? DevN(1) : R->nr.devn();
     A.offsets = R->offsets.p + (single ? only_index : 0);
     A.parent_map = R->parent_map.p + (single ? only_index : 0);
     A.points = R->points.p;
     A.weights = R->weights.p;
     A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-    if (A.n > 0)
+    if (A.n.cap > 0)
     {
       const char* spec = getenv("CFX_CUT_TENSORS_P1");
       if (a->rank == 2 && DEG == 1 && BS == 1 && A.dump && !single && !A.coeff && !(spec && spec[0] == '0')
           && (A.kernel == CFX_K_STIFFNESS || A.kernel == CFX_K_MASS || A.kernel == CFX_K_NITSCHE))
       {
         if constexpr (DEG == 1 && BS == 1)
-          launch("cut_tensors_p1", cut_tensors_p1_kernel<TDIM>, grid_for(A.n * kCutLanes), dim3(kBlock), 0, A);
+          launch("cut_tensors_p1", cut_tensors_p1_kernel<TDIM>, grid_for(A.n.cap * kCutLanes), dim3(kBlock), 0, A);
       }
       else if (mfma_tensors)
       {
         if constexpr (TDIM == 3 && BS == 3)
-          launch("elasticity_tensors_mfma_cut", elasticity_tensors_mfma_kernel<DEG, true>, mfma_grid(A.n), dim3(64), 0, A);
+          launch("elasticity_tensors_mfma_cut", elasticity_tensors_mfma_kernel<DEG, true>, mfma_grid(A.n.cap), dim3(64), 0, A);
       }
       else if (a->rank == 2)
-        launch("assemble_cells_cut", assemble_cells_kernel<TDIM, DEG, BS, 2, true>, grid_for(A.n * ND * BS),
+        launch("assemble_cells_cut", assemble_cells_kernel<TDIM, DEG, BS, 2, true>, grid_for(A.n.cap * ND * BS),
                dim3(kBlock), 0, A);
       else
-        launch("assemble_vec_cut", assemble_cells_kernel<TDIM, DEG, BS, 1, true>, grid_for(A.n * ND * BS),
+        launch("assemble_vec_cut", assemble_cells_kernel<TDIM, DEG, BS, 1, true>, grid_for(A.n.cap * ND * BS),
                dim3(kBlock), 0, A);
     }
   }
@@ -836,7 +851,7 @@ __global__ void __launch_bounds__(kBlock) assemble_cells2_kernel(AsmArgs A, Rect
   const int nloc0 = R.nd0 * R.bs0, nloc1 = R.nd1 * R.bs1;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e = tid / nloc0;
-  if (e >= A.n) return;
+  if (e >= dev_n(A.n)) return;
   const int I0 = (int)(tid - e * nloc0);
   const int ia = I0 / R.bs0, ik = I0 - ia * R.bs0;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
@@ -1014,31 +1029,32 @@ void launch_rectangular(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs 
   const int tdim = V0->mesh->tdim;
   if (!single || !use_rule)
   {
-    A.n = single ? 1 : I.n_entities;
+    A.n = single ? 1 : I.n_entities.value();
     A.entities = I.entities.p + (single ? only_index : 0);
-    if (A.n > 0)
+    if (A.n.cap > 0)
     {
-      if (tdim == 2) launch("assemble_cells2_std", assemble_cells2_kernel<2, false>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
-      else launch("assemble_cells2_std", assemble_cells2_kernel<3, false>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+      if (tdim == 2) launch("assemble_cells2_std", assemble_cells2_kernel<2, false>, grid_for(A.n.cap * nloc0), dim3(kBlock), 0, A, R);
+      else launch("assemble_cells2_std", assemble_cells2_kernel<3, false>, grid_for(A.n.cap * nloc0), dim3(kBlock), 0, A, R);
     }
   }
   if (I.rules && (!single || use_rule))
   {
     const cfx_rules_s* Q = I.rules;
-    A.n = single ? 1 : Q->nr;
+    A.n = single ? 1 : Q->nr.value();
     A.offsets = Q->offsets.p + (single ? only_index : 0);
     A.parent_map = Q->parent_map.p + (single ? only_index : 0);
     A.points = Q->points.p; A.weights = Q->weights.p;
-    if (A.n > 0)
+    if (A.n.cap > 0)
     {
-      if (tdim == 2) launch("assemble_cells2_cut", assemble_cells2_kernel<2, true>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
-      else launch("assemble_cells2_cut", assemble_cells2_kernel<3, true>, grid_for(A.n * nloc0), dim3(kBlock), 0, A, R);
+      if (tdim == 2) launch("assemble_cells2_cut", assemble_cells2_kernel<2, true>, grid_for(A.n.cap * nloc0), dim3(kBlock), 0, A, R);
+      else launch("assemble_cells2_cut", assemble_cells2_kernel<3, true>, grid_for(A.n.cap * nloc0), dim3(kBlock), 0, A, R);
     }
   }
 }
 
-__global__ void mark_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride, uint8_t* mark)
+__global__ void mark_cells_kernel(DevN n_d, const int32_t* __restrict__ cells, int stride, uint8_t* mark)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) mark[cells[i * stride]] = 1;
 }
@@ -1074,10 +1090,11 @@ struct FlagClear
   __device__ bool operator()(int64_t i) const { return f[i] == 0; }
 };
 
-__global__ void deactivate_kernel(int64_t n, const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
+__global__ void deactivate_kernel(DevN n_d, const int32_t* __restrict__ rows, const int64_t* __restrict__ indptr,
                                   const int32_t* __restrict__ indices, double* values, double* b, double diagonal,
                                   double rhs_value, int* error)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int32_t r = rows[i];
@@ -1101,16 +1118,27 @@ __global__ void __launch_bounds__(kBlock) deactivate_tiles_kernel(int64_t nrows,
                                                                   const int32_t* __restrict__ rows,
                                                                   const int64_t* __restrict__ indptr,
                                                                   const int32_t* __restrict__ indices, double* __restrict__ values,
-                                                                  double* __restrict__ b, double diagonal, double rhs_value, int* error)
+                                                                  double* __restrict__ b, double diagonal, double rhs_value, int* error,
+                                                                  DevN n_inactive_d, DevN nnz_d)
 {
+  // (lengths still in HBM: nothing to do in a void step -- the row pointers may then point beyond the arrays)
+  if (n_inactive_d.dev && dev_n(n_inactive_d) == 0) return;
+  if (nnz_d.dev && dev_n(nnz_d) == 0) return;
   const int64_t r0 = (int64_t)blockIdx.x * kByteTile;
   const int tl = (int)min((int64_t)kByteTile, nrows - r0);
   const int nz = tile_zeros[blockIdx.x];
   if (nz == tl && indptr[r0 + tl] - indptr[r0] == tl)
   {
-    block_fill_run(values + indptr[r0], tl, diagonal);
-    if (b) block_fill_run(b + r0, tl, rhs_value);
-    return;
+    // one entry per row -- and each is its row's diagonal (a coalesced read): the tile is two contiguous fills
+    const int64_t e0 = indptr[r0];
+    int ok = 1;
+    for (int k = threadIdx.x; k < tl; k += kBlock) ok &= indices[e0 + k] == (int32_t)(r0 + k) ? 1 : 0;
+    if (__syncthreads_and(ok))
+    {
+      block_fill_run(values + e0, tl, diagonal);
+      if (b) block_fill_run(b + r0, tl, rhs_value);
+      return;
+    }
   }
   // a tile with active rows: its inactive rows one by one from the tile's slice of the list
   const int64_t o = tile_zero_off[blockIdx.x];
@@ -1132,9 +1160,10 @@ __global__ void inactive_tile_counts_kernel(int64_t ntiles, int64_t n, const int
   zeros[t] = (int32_t)(len - (active[t] & 0xffffffffll) - (active[t] >> 32));
 }
 
-__global__ void facet_cells_covered_kernel(int64_t nf, const int32_t* __restrict__ rows, const uint8_t* __restrict__ cellmark,
+__global__ void facet_cells_covered_kernel(DevN nf_d, const int32_t* __restrict__ rows, const uint8_t* __restrict__ cellmark,
                                            int* uncovered)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * nf) return;
   if (cellmark[rows[4 * (i >> 1) + 2 * (i & 1)]] == 0) atomicOr(uncovered, 1);
@@ -1150,24 +1179,24 @@ void collect_cell_marks(const cfx_form_s* a, bool include_facets, DevArray<uint8
   {
     if (I.type == CFX_CELL)
     {
-      if (I.n_entities > 0)
+      if (I.n_entities.cap() > 0)
       {
-        launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p, 1,
+        launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities.cap()), dim3(kBlock), 0, I.n_entities, I.entities.p, 1,
                mark.p);
         any = true;
       }
-      if (I.rules && I.rules->nr > 0)
+      if (I.rules && I.rules->nr.cap() > 0)
       {
-        launch("mark_cells", mark_cells_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+        launch("mark_cells", mark_cells_kernel, grid_for(I.rules->nr.cap()), dim3(kBlock), 0, I.rules->nr,
                I.rules->parent_map.p, 1, mark.p);
         any = true;
       }
     }
-    else if (include_facets && I.type == CFX_INTERIOR_FACET && I.n_entities > 0)
+    else if (include_facets && I.type == CFX_INTERIOR_FACET && I.n_entities.cap() > 0)
     {
-      launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p, 4,
+      launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities.cap()), dim3(kBlock), 0, I.n_entities, I.entities.p, 4,
              mark.p);
-      launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+      launch("mark_cells", mark_cells_kernel, grid_for(I.n_entities.cap()), dim3(kBlock), 0, I.n_entities,
              I.entities.p + 2, 4, mark.p);
       any = true;
     }
@@ -1184,11 +1213,12 @@ namespace
 // writes the 80-byte record (jf[0..ND], w, the macro column ids) instead of eight threads writing 64 (folded: 25)
 // doubles; the gather forms row r as w jf[m(r)] jf[.] without touching the facet row or the dofmap.  facet_local_row() is the generic statement of the same integrand.
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(int64_t n, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kBlock) facet_jump_p1_kernel(DevN n_d, const int32_t* __restrict__ rows,
                                                                const double* __restrict__ x, const int32_t* __restrict__ conn,
                                                                const int32_t* __restrict__ dofmap, double gamma, double hpow,
                                                                int qdegree, double* __restrict__ out, int* error)
 {
+  const int64_t n = dev_n(n_d);
   constexpr int ND = TDIM + 1;
   const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (f >= n) return;
@@ -1553,24 +1583,25 @@ void dump_facet_jumps_p1(cfx_form_s* a, int integral, double* out, int* error)
 {
   cfx_space_s* V = a->V;
   const cfx_integral_dev& I = a->integrals[integral];
-  if (I.n_entities == 0) return;
+  if (I.n_entities.cap() == 0) return;
   if (V->mesh->tdim == 2)
-    launch("assemble_facets", facet_jump_p1_kernel<2>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
+    launch("assemble_facets", facet_jump_p1_kernel<2>, grid_for(I.n_entities.cap()), dim3(kBlock), 0, I.n_entities, I.entities.p,
            V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out, error);
   else
-    launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p,
+    launch("assemble_facets", facet_jump_p1_kernel<3>, grid_for(I.n_entities.cap()), dim3(kBlock), 0, I.n_entities, I.entities.p,
            V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out, error);
 }
 // stage 1 of a degree-2 stiffness integral over runtime rules: 16 doubles per rule (cut_moments_kernel)
 void dump_cut_moments(cfx_form_s* a, int integral, double* out)
 {
   const cfx_integral_dev& I = a->integrals[integral];
-  if (!I.rules || I.rules->nr == 0) return;
+  if (!I.rules || I.rules->nr.value() == 0) return;
+  const int64_t nrl = I.rules->nr.value();
   if (a->V->mesh->tdim == 2)
-    launch("assemble_cells_cut", cut_moments_kernel<2>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+    launch("assemble_cells_cut", cut_moments_kernel<2>, grid_for(nrl), dim3(kBlock), 0, nrl,
            I.rules->offsets.p, I.rules->points.p, I.rules->weights.p, out);
   else
-    launch("assemble_cells_cut", cut_moments_kernel<3>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+    launch("assemble_cells_cut", cut_moments_kernel<3>, grid_for(nrl), dim3(kBlock), 0, nrl,
            I.rules->offsets.p, I.rules->points.p, I.rules->weights.p, out);
 }
 
@@ -1579,12 +1610,13 @@ void dump_facet_jumps_p2(cfx_form_s* a, int integral, int nq, double* out)
 {
   cfx_space_s* V = a->V;
   const cfx_integral_dev& I = a->integrals[integral];
-  if (I.n_entities == 0) return;
+  const int64_t nf = I.n_entities.value();
+  if (nf == 0) return;
   if (V->mesh->tdim == 2)
-    launch("assemble_facets", facet_jumps_p2_kernel<2>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
+    launch("assemble_facets", facet_jumps_p2_kernel<2>, grid_for(nf * nq), dim3(kBlock), 0, nf, nq,
            I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out);
   else
-    launch("assemble_facets", facet_jumps_p2_kernel<3>, grid_for(I.n_entities * nq), dim3(kBlock), 0, I.n_entities, nq,
+    launch("assemble_facets", facet_jumps_p2_kernel<3>, grid_for(nf * nq), dim3(kBlock), 0, nf, nq,
            I.entities.p, V->mesh->x.p, V->mesh->conn.p, V->dofmap.p, I.params[0], I.params[1], I.qdegree, out);
 }
 } // namespace cfx
@@ -1740,16 +1772,20 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
               "cfx_form_create: `coefficient` goes with the field id CFX_F_COEFFICIENT (and only with it)");
       if (wants) I.coefficient = to_device(in.coefficient, V->ndofs * V->bs); // vector spaces: bs values per dof
     }
-    I.n_entities = in.n_entities;
+    // (a library list whose length is still in HBM comes back by address with the capacity the ABI returned)
+    I.n_entities = list_lookup(in.entities, in.n_entities);
     const int64_t width = in.type == CFX_INTERIOR_FACET ? 4 : 1;
     I.entities = to_device(in.entities, in.n_entities * width);
     I.rules = in.rules;
-    I.n_std = in.n_entities;
+    I.n_std = -1; // all entities are standard ones (see below: facet-hosted rules append theirs)
     if (in.rules && in.type == CFX_INTERIOR_FACET)
     {
       // one entity list for the pattern / row plan / staging: [standard rows, the rules' rows]
       require(in.rules->mesh == V->mesh, CFX_ERR_INVALID_ARGUMENT, "rules belong to a different mesh");
-      const int64_t nr = in.rules->nr;
+      const int64_t nr = in.rules->nr.value();
+      const int64_t n_in = I.n_entities.value(); // (a concatenated list: exact lengths)
+      require(n_in == in.n_entities || !I.n_entities.cell, CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: end the step before mixing a pending facet list with facet-hosted rules");
       DevArray<int32_t> all((in.n_entities + nr) * 4);
       if (in.n_entities > 0)
         CFX_HIP(hipMemcpyAsync(all.p, I.entities.p, sizeof(int32_t) * 4 * (size_t)in.n_entities, hipMemcpyDeviceToDevice,
@@ -1760,16 +1796,17 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
       CFX_HIP(hipStreamSynchronize(ctx().stream));
       I.entities = std::move(all);
       I.n_entities = in.n_entities + nr;
+      I.n_std = in.n_entities;
     }
     else if (in.rules)
     {
       require(in.rules->mesh == V->mesh, CFX_ERR_INVALID_ARGUMENT, "rules belong to a different mesh");
-      if (in.point_data) I.point_data = to_device(in.point_data, in.rules->nq * (int64_t)in.point_stride);
+      if (in.point_data) I.point_data = to_device(in.point_data, in.rules->nq.cap() * (int64_t)in.point_stride);
     }
     else if (in.kernel == CFX_K_EXTENSION_L2 && in.point_data)
       I.point_data = to_device(in.point_data, in.n_entities); // one factor per pair (cellwise beta)
     for (int k = 0; k < 8; ++k) I.params[k] = in.params[k];
-    I.entities_serial = I.n_entities > 0 ? dev_block_serial(I.entities.p) : 0;
+    I.entities_serial = I.n_entities.cap() > 0 ? dev_block_serial(I.entities.p) : 0;
     I.rules_serial = I.rules ? I.rules->serial : 0;
     a->integrals.push_back(std::move(I));
   }
@@ -1802,7 +1839,7 @@ int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out)
   validate_form(a);
   auto P = std::make_unique<cfx_pattern_s>();
   build_pattern(a, P.get());
-  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  end_of_call_sync();
   *out = P.release();
   CFX_API_END
 }
@@ -1811,7 +1848,7 @@ int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* v)
 {
   CFX_API_BEGIN
   require(p && v, CFX_ERR_INVALID_ARGUMENT, "cfx_pattern_view_get: null argument");
-  v->nrows = p->nrows; v->nnz = p->nnz; v->indptr = p->indptr.p; v->indices = p->indices.p; v->ncols = p->ncols;
+  v->nrows = p->nrows; v->nnz = p->nnz.cap(); v->indptr = p->indptr.p; v->indices = p->indices.p; v->ncols = p->ncols;
   CFX_API_END
 }
 
@@ -1834,8 +1871,9 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   require(P->nrows == V->ndofs * V->bs && P->ncols == a->V1->ndofs * a->V1->bs, CFX_ERR_INVALID_ARGUMENT,
           "cfx_assemble_matrix: pattern/space size mismatch");
   DevArray<int8_t> dbc0 = to_device(bc0, bc0 ? P->nrows : 0), dbc1 = to_device(bc1, bc1 ? P->ncols : 0);
-  OutArray<double> out(values, P->nnz, !zero_first);
-  ZeroFlag err;
+  OutArray<double> out(values, count_for_buffer(P->nnz, values), !zero_first);
+  const char* kMissing = "assemble_matrix: entry not in the sparsity pattern";
+  ErrorFlag err(CFX_ERR_RUNTIME, kMissing);
   AsmArgs A{};
   A.x = V->mesh->x.p; A.conn = V->mesh->conn.p; A.dofmap = V->dofmap.p;
   A.bc0 = bc0 ? dbc0.p : nullptr; A.bc1 = bc1 ? dbc1.p : nullptr;
@@ -1846,16 +1884,17 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   if (a->rectangular())
   {
     // test space != trial space: the entity-parallel kernel of the rectangular blocks (no row gather yet)
-    if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
+    if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz.value());
     for (const auto& I : a->integrals) launch_rectangular(a, I, A);
-    require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
+    err.check(CFX_ERR_RUNTIME, kMissing);
     out.finish();
     return;
   }
   if (!force_atomic() && assemble_matrix_rows(a, P, A.bc0, A.bc1, out.dev, zero_first)) { out.finish(); return; }
-  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz);
+  // (entity-parallel kernels: a pattern whose nnz is still in HBM is filled up to its capacity)
+  if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz.cap());
   for (const auto& I : a->integrals) launch_integral(a, I, A);
-  require(!read_scalar(err.p), CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
+  err.check(CFX_ERR_RUNTIME, kMissing);
   out.finish();
 }
 
@@ -1961,7 +2000,7 @@ int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** r
 {
   CFX_API_BEGIN
   require(P && values && rows && n_rows, CFX_ERR_INVALID_ARGUMENT, "cfx_zero_rows: null argument");
-  DevArray<double> dv = to_device(values, P->nnz);
+  DevArray<double> dv = to_device(values, P->nnz.value());
   DevArray<int32_t> list;
   const int64_t n = compact("zero_rows", P->nrows, RowAllZero{P->indptr.p, dv.p, tol}, list);
   int32_t* out = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1)));
@@ -1980,7 +2019,7 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
   validate_form(a);
   const cfx_integral_dev& I = a->integrals[integral];
   cfx_space_s* V = a->V;
-  const int64_t limit = (I.type == CFX_CELL && use_rule) ? (I.rules ? I.rules->nr : 0) : I.n_entities;
+  const int64_t limit = (I.type == CFX_CELL && use_rule) ? (I.rules ? I.rules->nr.value() : 0) : I.n_entities.value();
   require(index >= 0 && index < limit, CFX_ERR_OUT_OF_RANGE, "entity index out of range");
   const int nloc = V->ndofs_cell * V->bs * (I.type == CFX_INTERIOR_FACET ? 2 : 1);
   const int nloc1 = a->rectangular() ? a->V1->ndofs_cell * a->V1->bs : nloc;
@@ -2012,7 +2051,7 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   // entity) -- collect_active_cells / build_active_indicator of deactivate.h:103-183.
   cfx_row_plan& plan = row_plan(a);
   const int64_t nc = V->mesh->ncells;
-  bool facets_covered = plan.nfacets == 0;
+  bool facets_covered = plan.nfacets.cap() == 0;
   ZeroFlag uncovered;
   int uncovered_host = 0;
   if (!facets_covered)
@@ -2020,25 +2059,44 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
     // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty
     // band lies in the cut and inside cells): then the cell marks alone are the indicator.  The flag rides on the
     // size read-back of the compaction below; should a facet cell be uncovered, that list is rebuilt
-    launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets * 2), dim3(kBlock), 0, plan.nfacets,
+    launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets.cap() * 2), dim3(kBlock), 0, plan.nfacets,
            plan.facet_rows.p, plan.cellmark.p, uncovered.p);
   }
-  d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
-                              plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr,
-                              -1, facets_covered ? nullptr : uncovered.p, &uncovered_host);
+  const int32_t* known_tiles = plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr;
+  if (step_speculative())
+  {
+    // the list's length stays in HBM; "every facet cell is covered" is taken from the previous step and checked at the
+    // end of this one (a must-equal site: another answer voids the step, the repeat takes the branch below)
+    const Count unc = count_site("active.uncovered", uncovered.p, kCountI32, kCountMustEqual);
+    uncovered_host = (int)unc.cap();
+    if (uncovered_host == 0)
+      d->n_active = compact_bytes_count("active_cells", "active.cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
+                                        known_tiles);
+  }
+  else
+  {
+    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells, known_tiles,
+                                -1, facets_covered ? nullptr : uncovered.p, &uncovered_host);
+    // (the two totals a later step of this loop takes from HBM)
+    step_record("active.uncovered", uncovered_host);
+    if (uncovered_host == 0) step_record("active.cells", d->n_active.cap());
+  }
   if (uncovered_host != 0)
   {
     // facet integrals contribute both of their cells (deactivate.h:138-146)
     DevArray<uint8_t> mark((nc + 3) & ~3LL);
     CFX_HIP(hipMemcpyAsync(mark.p, plan.cellmark.p, (size_t)nc, hipMemcpyDeviceToDevice, ctx().stream));
-    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets), dim3(kBlock), 0, plan.nfacets, plan.facet_rows.p, 4,
+    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets.cap()), dim3(kBlock), 0, plan.nfacets, plan.facet_rows.p, 4,
            mark.p);
-    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets), dim3(kBlock), 0, plan.nfacets,
+    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets.cap()), dim3(kBlock), 0, plan.nfacets,
            plan.facet_rows.p + 2, 4, mark.p);
-    d->n_active = compact_bytes("active_cells", nc, mark.p, ByteNonZero{}, d->active_cells);
+    d->n_active = compact_bytes_count("active_cells", "active.cells2", nc, mark.p, ByteNonZero{}, d->active_cells);
   }
-  // deactivate.h:155-160
-  require(d->n_active > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
+  // deactivate.h:155-160 (a count still in HBM is checked when the step ends: step_require_positive)
+  if (d->n_active.pending()) step_require_positive(d->n_active, CFX_ERR_INVALID_ARGUMENT,
+                                                   "cutfemx.fem.active_domain found no active background cells");
+  else
+    require(d->n_active.cap() > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
   const int64_t nrows = V->ndofs * V->bs;
   if (V->bs == 1)
   {
@@ -2051,9 +2109,16 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
       launch("inactive_dofs", inactive_tile_counts_kernel, grid_for(ntiles), dim3(kBlock), 0, ntiles, nrows,
              plan.row_tile_counts.p, zeros.p);
     }
-    // (the plan knows how many rows are marked: the list is sized without a read-back)
-    d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
-                                  zeros.n > 0 ? zeros.p : nullptr, plan.built ? nrows - plan.n_active_rows : -1);
+    if (plan.n_active_rows.pending())
+      d->n_inactive = compact_bytes_count("inactive_dofs", "active.inactive_dofs", nrows, plan.rowmark.p, ByteZero{},
+                                          d->inactive_dofs, zeros.n > 0 ? zeros.p : nullptr);
+    else
+    {
+      // (the plan knows how many rows are marked: the list is sized without a read-back)
+      d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
+                                    zeros.n > 0 ? zeros.p : nullptr, plan.built ? nrows - plan.n_active_rows.cap() : -1);
+      step_record("active.inactive_dofs", d->n_inactive.cap());
+    }
     if (zeros.n > 0)
     {
       d->tile_zero_off.alloc(zeros.n + 1);
@@ -2065,11 +2130,12 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   {
     DevArray<uint8_t> ind(nrows);
     ind.zero();
-    launch("mark_dofs", mark_dofs_kernel, grid_for(d->n_active * V->ndofs_cell), dim3(kBlock), 0, d->n_active,
+    const int64_t nact = d->n_active.value();
+    launch("mark_dofs", mark_dofs_kernel, grid_for(nact * V->ndofs_cell), dim3(kBlock), 0, nact,
            d->active_cells.p, V->dofmap.p, V->ndofs_cell, V->bs, ind.p);
     d->n_inactive = compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs);
   }
-  CFX_HIP(hipStreamSynchronize(ctx().stream));
+  end_of_call_sync();
   *out = d.release();
   CFX_API_END
 }
@@ -2080,9 +2146,9 @@ int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_act
   CFX_API_BEGIN
   require(d != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_active_view: null handle");
   if (active_cells) *active_cells = d->active_cells.p;
-  if (n_active) *n_active = d->n_active;
+  if (n_active) *n_active = d->n_active.cap(); // (capacities while the step that made the lists is open)
   if (inactive_dofs) *inactive_dofs = d->inactive_dofs.p;
-  if (n_inactive) *n_inactive = d->n_inactive;
+  if (n_inactive) *n_inactive = d->n_inactive.cap();
   CFX_API_END
 }
 
@@ -2093,10 +2159,11 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t P, double* values, doub
   require(d && (values == nullptr || P), CFX_ERR_INVALID_ARGUMENT, "cfx_deactivate_outside: null argument");
   const int64_t nrows = d->V->ndofs * d->V->bs;
   std::unique_ptr<OutArray<double>> ov, ob;
-  if (values) ov = std::make_unique<OutArray<double>>(values, P->nnz, true);
+  if (values) ov = std::make_unique<OutArray<double>>(values, count_for_buffer(P->nnz, values), true);
   if (b) ob = std::make_unique<OutArray<double>>(b, nrows, true);
-  ZeroFlag err;
-  if (d->n_inactive > 0)
+  const char* kNoDiag = "Deactivated matrix row has no diagonal entry.";
+  ErrorFlag err(CFX_ERR_RUNTIME, kNoDiag);
+  if (d->n_inactive.cap() > 0)
   {
     // the tile shortcut is sound for patterns whose rows hold nothing but the diagonal in fully inactive tiles: true of
     // every pattern this library builds (nnz of a fully inactive tile == its row count is checked on the spot)
@@ -2106,14 +2173,14 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t P, double* values, doub
     if (tiles)
       launch("deactivate", deactivate_tiles_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nrows, d->tile_zeros.p,
              d->tile_zero_off.p, d->inactive_dofs.p, P->indptr.p, P->indices.p, ov->dev, b ? ob->dev : (double*)nullptr, diagonal,
-             rhs_value, err.p);
+             rhs_value, err.p, d->n_inactive.devn(), P->nnz.devn());
     else
-      launch("deactivate", deactivate_kernel, grid_for(d->n_inactive), dim3(kBlock), 0, d->n_inactive,
+      launch("deactivate", deactivate_kernel, grid_for(d->n_inactive.cap()), dim3(kBlock), 0, d->n_inactive,
              d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,
              b ? ob->dev : nullptr, diagonal, rhs_value, err.p);
   }
   // deactivate.h: validate_matrix_rows
-  require(!read_scalar(err.p), CFX_ERR_RUNTIME, "Deactivated matrix row has no diagonal entry.");
+  err.check(CFX_ERR_RUNTIME, kNoDiag);
   if (ov) ov->finish();
   if (ob) ob->finish();
   CFX_API_END

@@ -92,7 +92,7 @@ struct RowIntegral
   int64_t n_std;             // n_entities
   int std_by_cell;           // rank 1: std_tensors is [ND][ncells], indexed by the cell itself (n_std = ncells; unmarked cells unwritten)
   const int32_t* parent_map; // sorted rule parents
-  int64_t nr;
+  DevN nr;                   // (length in HBM inside a sync-free step: the entries behind it are not rules)
   const double* rule_tensors; // [nr][ND*ND] or [nr][ND]; rule_moments: [nr][16]
   int rule_moments;           // degree-2 stiffness: rule_tensors holds the barycentric moments of every rule (cut_moments_kernel)
   const int32_t* rule_keys;   // parent cell -> first rule (open addressing, plan.rule_keys / rule_first)
@@ -106,7 +106,7 @@ struct RowArgs
   const double* x;
   const int32_t* conn;
   const int32_t* dofmap;
-  int64_t n_active;
+  DevN n_active;             // rows of this launch (length in HBM inside a sync-free step)
   const int32_t* active_rows;
   const int64_t* d2c_off;
   const int32_t* d2c;
@@ -261,7 +261,7 @@ struct VecArgs
 {
   const double* x;
   const int32_t* conn;
-  int64_t n;
+  DevN n;                    // entities of this launch (n.cap: the stride of the [ND][n] layout)
   const int32_t* entities;   // uncut: cells
   const int32_t* offsets;    // runtime
   const int32_t* parent_map;
@@ -306,7 +306,7 @@ __device__ __forceinline__ void store_std_vector(const VecArgs& A, int64_t e, in
   }
   if (record)
   {
-    const int64_t stride = A.out_cells > 0 ? A.out_cells : A.n, at = A.out_cells > 0 ? cell : e;
+    const int64_t stride = A.out_cells > 0 ? A.out_cells : A.n.cap, at = A.out_cells > 0 ? cell : e;
 #pragma unroll
     for (int i = 0; i < ND; ++i) A.out[(int64_t)i * stride + at] = be[i];
   }
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(kBlock, (DEG == 2 && RUNTIME && KSEL != 0) ? 4
   // LANES == 1: the point index is the same in every lane, so the rule's points / weights (and the P1 basis
   // values) are scalar loads and scalar operands
   const int sub = LANES == 1 ? 0 : (int)(tid - e * LANES);
-  if (e >= A.n) return;
+  if (e >= dev_n(A.n)) return;
   const int64_t cell = RUNTIME ? A.parent_map[e] : A.entities[e];
   double be[ND];
   entity_vector<TDIM, DEG, RUNTIME, LANES, KSEL>(A, e, cell, sub, be);
@@ -635,7 +635,7 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
   if (record)
   {
 #pragma unroll
-    for (int i = 0; i < ND; ++i) A.out[A.out_cells > 0 ? (int64_t)i * A.out_cells + c.cell : (int64_t)i * A.n + c.e] = be[i];
+    for (int i = 0; i < ND; ++i) A.out[A.out_cells > 0 ? (int64_t)i * A.out_cells + c.cell : (int64_t)i * A.n.cap + c.e] = be[i];
   }
 }
 
@@ -647,7 +647,9 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_source_sin_p1_ke
 {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const int64_t e0 = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t last = A.n - 1;
+  const int64_t An = dev_n(A.n);
+  if (An == 0) return;
+  const int64_t last = An - 1;
   int npts;
   const double* wts;
   const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
@@ -663,7 +665,7 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_source_sin_p1_ke
   source_load_conn<TDIM>(A, a);
   source_load_conn<TDIM>(A, b);
   source_load_vertices<TDIM>(A, a);
-  for (int64_t e = e0; e < A.n; e += stride)
+  for (int64_t e = e0; e < An; e += stride)
   {
     cell_d = ent(e + 3 * stride);
     SourceCell<TDIM> c;
@@ -699,7 +701,7 @@ struct VecBlockArgs
   struct Rules
   {
     const int32_t* parent_map;
-    int64_t nr;
+    DevN nr;
     const double* tensors;
     const int32_t* keys;
     const int32_t* first;
@@ -717,7 +719,7 @@ __device__ __forceinline__ void add_rule_vectors(const VecBlockArgs& P, int64_t 
     if (cm & (16u << s))
     {
       const VecBlockArgs::Rules& R = P.rules[s];
-      for (int64_t e = first_rule(R.keys, R.first, R.mask, (int32_t)c); e < R.nr && R.parent_map[e] == c; ++e)
+      for (int64_t e = first_rule(R.keys, R.first, R.mask, (int32_t)c); e < dev_len(R.nr) && R.parent_map[e] == c; ++e)
 #pragma unroll
         for (int j = 0; j < ND; ++j) be[j] += R.tensors[e * ND + j];
     }
@@ -962,12 +964,13 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_blocks_sin_p1_ke
 // stage 2: b[r] += the partials of the blocks around row r, in ascending block order (then a fixed tree over the
 // row's lanes: bitwise reproducible).  base[] = -1 for a block without a marked cell (nothing was written for it)
 template <int G>
-__global__ void __launch_bounds__(kWave) vec_blocks_rows_kernel(int64_t n, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kWave) vec_blocks_rows_kernel(DevN n_d, const int32_t* __restrict__ rows,
                                                                 const int64_t* __restrict__ p_off,
                                                                 const int64_t* __restrict__ p_pos,
                                                                 const int64_t* __restrict__ base,
                                                                 const double* __restrict__ part, double* __restrict__ b)
 {
+  const int64_t n = dev_n(n_d);
   const int lane = threadIdx.x, gl = lane % G;
   const int64_t i = CFX_ROW_BLOCK * (kWave / G) + lane / G;
   const bool live = i < n;
@@ -1016,7 +1019,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
   __shared__ double s_val[RPW][CAP + 1];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active;
+  const bool live = ri < dev_n(A.n_active);
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t rb = live ? A.indptr[r] : 0;
   int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
@@ -1211,7 +1214,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
                   Geo<TDIM> g;
                   load_cell<TDIM>(A.x, A.conn, c, g);
                   jacobian<TDIM>(g);
-                  for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+                  for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < dev_len(I.nr) && I.parent_map[e] == c; ++e)
                   {
                     const double2* mp = reinterpret_cast<const double2*>(I.rule_tensors + e * 16);
                     double mom[16];
@@ -1226,7 +1229,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
                 }
               }
               else
-              for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+              for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < dev_len(I.nr) && I.parent_map[e] == c; ++e)
               {
                 const double* T = I.rule_tensors + (e * ND + lr) * ND;
 #pragma unroll
@@ -1549,7 +1552,7 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
   __shared__ double s_val[RPW][CAP + 1];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active;
+  const bool live = ri < dev_n(A.n_active);
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t rb = live ? A.indptr[r] : 0;
   int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
@@ -1854,7 +1857,7 @@ __global__ void __launch_bounds__(kWave, CFX_P1_WAVES) assemble_rows_p1_kernel(R
   __shared__ double s_val[RPW][CAP + 1];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active;
+  const bool live = ri < dev_n(A.n_active);
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t rb = live ? A.indptr[r] : 0;
   int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
@@ -2049,7 +2052,7 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
   __shared__ double s_x[STAGE ? RPW : 1][STAGE ? SX + 1 : 1][TDIM];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active;
+  const bool live = ri < dev_n(A.n_active);
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t rb = live ? A.indptr[r] : 0;
   int len = live ? (int)(A.indptr[r + 1] - rb) : 0;
@@ -2277,10 +2280,10 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
 struct TileArgs
 {
   const double* x;
-  int64_t n_tiles;
+  DevN n_tiles;
   const int32_t* tile_first; // position of the tile's first plain row in `rows`
   const int32_t* tile_id;
-  int64_t n_plain;
+  DevN n_plain;
   const int32_t* rows;
   const unsigned long long* masks;
   const uint8_t* uniform;
@@ -2347,13 +2350,13 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
   __shared__ uint16_t s_loc[CAPS];
   const int lane = threadIdx.x, g = lane / G, gl = lane % G;
   const int64_t w = CFX_ROW_BLOCK;
-  if (w >= A.n_tiles) return;
+  if (w >= dev_n(A.n_tiles)) return;
   const int64_t i0 = A.tile_first[w];
   const int64_t t = A.tile_id[w];
   const int64_t r0 = t * kRowTile;
   // ---- every load that does not depend on another one is issued here, ahead of the first wait
   int32_t rl = -1;
-  if (lane < kRowTile && i0 + lane < A.n_plain) rl = A.rows[i0 + lane];
+  if (lane < kRowTile && i0 + lane < dev_n(A.n_plain)) rl = A.rows[i0 + lane];
   const int64_t rr = r0 + (lane < kRowTile ? lane : kRowTile);
   const int64_t so = A.st_off[rr < A.ndofs ? rr : A.ndofs], co = A.d2c_off[rr < A.ndofs ? rr : A.ndofs];
   const int64_t vb = A.tile_voff[t];
@@ -2587,7 +2590,7 @@ __global__ void __launch_bounds__(kWave, INLINE == 1 ? 2 : CFX_BLOCK_WAVES) asse
   __shared__ double s_val[RPW][CAP * BS + 1];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active * BS;
+  const bool live = ri < dev_n(A.n_active) * BS;
   const int64_t rr = live ? ri / BS : 0;
   const int kc = live ? (int)(ri - rr * BS) : 0;
   const int64_t r = live ? A.active_rows[rr] : 0;
@@ -2688,7 +2691,7 @@ __global__ void __launch_bounds__(kWave, INLINE == 1 ? 2 : CFX_BLOCK_WAVES) asse
         }
         if (mark & (16u << i))
         {
-          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < dev_len(I.nr) && I.parent_map[e] == c; ++e)
           {
             const double* T = I.rule_tensors + (e * NLOC + lr * BS + kc) * NLOC;
 #pragma unroll
@@ -2924,7 +2927,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   constexpr int RPW = kWave / G;
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < A.n_active && A.cellmark != nullptr;
+  const bool live = ri < dev_n(A.n_active) && A.cellmark != nullptr;
   const int64_t r = live ? A.active_rows[ri] : 0;
   const int64_t cb = live ? A.d2c_off[r] : 0;
   const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
@@ -2977,7 +2980,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
         if ((mk[k] & (1u << i)) && I.std_tensors)
           part += I.std_tensors[(int64_t)lr[k] * I.n_std + (I.std_by_cell ? c : entity_index(I.std_bits, I.std_rank, c))];
         if (mk[k] & (16u << i))
-          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < I.nr && I.parent_map[e] == c; ++e)
+          for (int64_t e = first_rule(I.rule_keys, I.rule_first, I.rule_mask, (int32_t)c); e < dev_len(I.nr) && I.parent_map[e] == c; ++e)
             part += I.rule_tensors[e * ND + lr[k]];
       }
     }
@@ -3768,7 +3771,7 @@ void vec_block_partials(cfx_form_s* L, const cfx_integral_dev* Istd, uint8_t mar
   for (int s = 0; s < R.n_cell; ++s)
   {
     const RowIntegral& I = R.cell[s];
-    P.rules[s] = {I.parent_map, I.rule_tensors ? I.nr : 0, I.rule_tensors, I.rule_keys, I.rule_first, I.rule_mask};
+    P.rules[s] = {I.parent_map, I.rule_tensors ? I.nr : DevN(0), I.rule_tensors, I.rule_keys, I.rule_first, I.rule_mask};
   }
   if (P.n_active == 0) {}
   else if (Istd && source_series_ok<DEG>(V, *Istd))
@@ -3809,19 +3812,19 @@ void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double*
       if constexpr (DEG == 1)
       {
         // a resident grid: every thread walks ~n / (256 CUs x blocks x 256) cells through its software pipeline
-        const int64_t blocks = std::min<int64_t>((A.n + kBlock - 1) / kBlock, 256 * CFX_SOURCE_BLOCKS_PER_CU);
+        const int64_t blocks = std::min<int64_t>((A.n.cap + kBlock - 1) / kBlock, 256 * CFX_SOURCE_BLOCKS_PER_CU);
         launch("vec_tensors_std", vec_source_sin_p1_kernel<TDIM>, dim3((unsigned)blocks), dim3(kBlock), 0, A);
       }
     }
     else
-      launch("vec_tensors_std", vec_tensors_kernel<TDIM, DEG, false>, grid_for(A.n), dim3(kBlock), 0, A);
+      launch("vec_tensors_std", vec_tensors_kernel<TDIM, DEG, false>, grid_for(A.n.cap), dim3(kBlock), 0, A);
   }
   else
   {
     const cfx_rules_s* R = I.rules;
     A.n = R->nr; A.offsets = R->offsets.p; A.parent_map = R->parent_map.p; A.points = R->points.p;
     A.weights = R->weights.p; A.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
-    const dim3 grid = grid_for(A.n * CFX_VEC_CUT_LANES);
+    const dim3 grid = grid_for(A.n.cap * CFX_VEC_CUT_LANES);
     if (I.kernel == CFX_L_SOURCE)
       launch("vec_tensors_cut", vec_tensors_kernel<TDIM, DEG, true, CFX_VEC_CUT_LANES, 1>, grid, dim3(kBlock), 0, A);
     else if (I.kernel == CFX_L_NITSCHE_RHS)
@@ -3840,7 +3843,7 @@ inline bool p2_cut_tensors_ok(const cfx_form_s* a)
   if (a->rank != 2 || a->V->degree != 2 || a->V->bs != 1) return false;
   bool any = false;
   for (const auto& I : a->integrals)
-    if (I.type == CFX_CELL && I.rules && I.rules->nr > 0)
+    if (I.type == CFX_CELL && I.rules && I.rules->nr.cap() > 0)
     {
       if (!(I.kernel == CFX_K_STIFFNESS || I.kernel == CFX_K_MASS || I.kernel == CFX_K_NITSCHE) || I.coefficient.n > 0) return false;
       any = true;
@@ -3872,7 +3875,8 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     RowIntegral& R = A.cell[s];
     R.kernel = I.kernel; R.qdegree = I.qdegree; R.point_stride = I.point_stride;
     for (int k = 0; k < 8; ++k) R.params[k] = I.params[k];
-    if (I.n_entities > 0)
+    const int64_t n_ent = I.n_entities.cap(); // (capacity while the list's length is in HBM: strides and buffers)
+    if (n_ent > 0)
     {
       R.std_bits = reinterpret_cast<const unsigned long long*>(plan.std_bits[s].p);
       R.std_rank = plan.std_rank[s].p;
@@ -3897,35 +3901,36 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
       // ... and the vector-valued elasticity term likewise (closed-form block rows)
       if (DEG == 2 && BS == TDIM && p2_elasticity_closed(a, I)) R.std_inline = 3;
     }
-    if (a->rank == 1 && st.vec_blocks && I.n_entities > 0)
+    if (a->rank == 1 && st.vec_blocks && n_ent > 0)
       R.std_tensors = nullptr; // (the uncut cells reach the rows as block partials, run_vector)
-    else if (!R.std_inline && I.n_entities > 0)
+    else if (!R.std_inline && n_ent > 0)
     {
       // linear forms whose entity list covers a good part of the mesh stage [ND][ncells]: the rows index the record by
       // the cell they hold anyway, without the bitset + rank lookup of the entity index (two gathers per item)
       const char* bc = getenv("CFX_VEC_BY_CELL");
-      const bool by_cell = a->rank == 1 && BS == 1 && !st.vec_t2 && I.n_entities * 4 >= V->mesh->ncells && !(bc && bc[0] == '0');
-      st.buffers.emplace_back((by_cell ? V->mesh->ncells : I.n_entities) * tsize);
+      const bool by_cell = a->rank == 1 && BS == 1 && !st.vec_t2 && n_ent * 4 >= V->mesh->ncells && !(bc && bc[0] == '0');
+      st.buffers.emplace_back((by_cell ? V->mesh->ncells : n_ent) * tsize);
       R.std_tensors = st.buffers.back().p;
-      R.n_std = by_cell ? V->mesh->ncells : I.n_entities;
+      R.n_std = by_cell ? V->mesh->ncells : n_ent;
       R.std_by_cell = by_cell ? 1 : 0;
       if (a->rank == 2) dump_integral(a, ii, 1, st.buffers.back().p);
       else if constexpr (BS == 1) vec_tensors<TDIM, DEG>(a, I, false, st.buffers.back().p, st.vec_t2, by_cell ? V->mesh->ncells : 0);
     }
-    if (I.rules && I.rules->nr > 0 && combine_cuts)
+    const int64_t n_rules = I.rules ? I.rules->nr.cap() : 0;
+    if (n_rules > 0 && combine_cuts)
     {
       // (the rule lookups stay valid for the kernels that ask for them; nothing is staged per integral)
       R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
     }
-    else if (I.rules && I.rules->nr > 0)
+    else if (n_rules > 0)
     {
       R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
       const char* cm = getenv("CFX_P2_MOMENTS");
       const bool moments = DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0
                            && !(cm && cm[0] == '0');
-      st.buffers.emplace_back(I.rules->nr * (moments ? 16 : tsize));
+      st.buffers.emplace_back(n_rules * (moments ? 16 : tsize));
       R.rule_tensors = st.buffers.back().p;
       R.rule_moments = moments ? 1 : 0;
       if (moments) dump_cut_moments(a, ii, st.buffers.back().p);
@@ -3948,9 +3953,9 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
           const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[s]];
           CutSlot& S = C.slot[s];
           S.kernel = I.kernel; S.point_stride = I.point_stride; S.params[0] = I.params[0]; S.params[1] = I.params[1];
-          if (I.rules && I.rules->nr > 0)
+          if (I.rules && I.rules->nr.value() > 0)
           {
-            S.offsets = I.rules->offsets.p; S.parent_map = I.rules->parent_map.p; S.nr = I.rules->nr;
+            S.offsets = I.rules->offsets.p; S.parent_map = I.rules->parent_map.p; S.nr = I.rules->nr.value();
             S.points = I.rules->points.p; S.weights = I.rules->weights.p;
             S.point_data = I.point_data.n > 0 ? I.point_data.p : nullptr;
             S.rule_keys = plan.rule_keys[s].p; S.rule_first = plan.rule_first[s].p; S.rule_mask = plan.rule_mask[s];
@@ -3973,7 +3978,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     has_facets = has_facets || I.type == CFX_INTERIOR_FACET;
     if (I.type == CFX_INTERIOR_FACET && I.kernel == CFX_K_EXTENSION_L2) A.fold_facets = 0; // (bad, root) pairs
   }
-  if (has_facets && plan.nfacets > 0)
+  if (has_facets && plan.nfacets.cap() > 0)
   {
     A.d2f_off = plan.d2f_offsets.p; A.d2f = plan.d2f.p; A.facet_rows = plan.facet_rows.p;
     A.special_mark = plan.special_mark.p; A.special_pos = plan.special_pos.p;
@@ -3987,7 +3992,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     for (int s = 0; s < plan.n_facet_slots; ++s)
     {
       const cfx_integral_dev& I = a->integrals[plan.facet_slot_integral[s]];
-      rank_one = rank_one && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std == I.n_entities;
+      rank_one = rank_one && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std < 0;
     }
     if (rank_one) A.fold_facets = 3;
     // degree 2, scalar: nq rank-one records per facet when every facet term is the gradient jump at one degree
@@ -3998,7 +4003,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
       for (int s = 0; s < plan.n_facet_slots; ++s)
       {
         const cfx_integral_dev& I = a->integrals[plan.facet_slot_integral[s]];
-        low = low && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std == I.n_entities
+        low = low && I.kernel == CFX_K_GHOST_GRADJUMP && I.rules == nullptr && I.n_std < 0
               && (qd < 0 || qd == I.qdegree);
         qd = I.qdegree;
       }
@@ -4007,7 +4012,7 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     }
     const int64_t fsize = A.fold_facets == 3 ? (DEG == 2 ? 8 + 16 * A.facet_nq : 10)
                                              : (A.fold_facets == 2 ? (ND + 1) * (ND + 1) : 4 * ND * ND);
-    st.buffers.emplace_back(plan.nfacets * fsize);
+    st.buffers.emplace_back(plan.nfacets.cap() * fsize);
     A.facet_tensors = st.buffers.back().p;
     int64_t o = 0;
     for (int s = 0; s < plan.n_facet_slots; ++s)
@@ -4016,10 +4021,21 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
       if (A.fold_facets == 3 && DEG == 2) dump_facet_jumps_p2(a, ii, A.facet_nq, st.buffers.back().p + o * fsize);
       else if (A.fold_facets == 3) dump_facet_jumps_p1(a, ii, st.buffers.back().p + o * fsize, nullptr); // (a non-conforming row is reported by the gather)
       else dump_integral(a, ii, 1, st.buffers.back().p + o * fsize, A.fold_facets == 2);
-      o += a->integrals[ii].n_entities;
+      o += a->integrals[ii].n_entities.cap(); // (several facet lists: exact lengths, cfx::row_plan)
     }
   }
   return A;
+}
+
+// the gather kernels' error word: what each value means (raised at once, or by cfx_step_end inside a step)
+constexpr const char* kEntryMissing = "assemble_matrix: entry not in the sparsity pattern";
+inline void raise_gather_error(int err)
+{
+  require(err != 1, CFX_ERR_RUNTIME, kEntryMissing);
+  require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
+  require(err != 5, CFX_ERR_RUNTIME, "assemble_matrix: a stencil-subset row does not match its sparsity pattern");
+  require(err != 4, CFX_ERR_INVALID_ARGUMENT, "assemble_matrix: a facet row does not join two cells across a shared facet");
+  require(err == 0, CFX_ERR_RUNTIME, "assemble_matrix: the row gather reported an error");
 }
 
 template <int TDIM, int DEG>
@@ -4034,13 +4050,14 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     const char* fs0 = getenv("CFX_ROWS_SPLIT");
     const int mr0 = P->max_row_len;
     combine_cuts = P->split_plan == plan0.serial && mr0 > 64 && mr0 <= 256
-                   && (plan0.n_special_rows * 2 <= plan0.n_active_rows || (fs0 && fs0[0] == '1')) && plan0.n_special_rows > 0
+                   && (plan0.n_special_rows.value() * 2 <= plan0.n_active_rows.value() || (fs0 && fs0[0] == '1'))
+                   && plan0.n_special_rows.value() > 0
                    && p2_cut_tensors_ok(a);
   }
   RowArgs A = prepare<TDIM, DEG>(a, st, combine_cuts);
   A.fresh = fresh ? 1 : 0;
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
-  ZeroFlag err;
+  ErrorFlag err(CFX_ERR_RUNTIME, kEntryMissing, raise_gather_error);
   A.error = err.p;
   if (const char* dbg = getenv("CFX_DEBUG_ROWS")) A.debug = atoi(dbg);
   // `fresh` = MatrixCSR.set_value(0) fused into this call (nothing has written to `values` yet: stage 1 fills its own
@@ -4048,9 +4065,16 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   // rows, assemble_rows_p1 the rows it is given), so only the inactive rows (one diagonal entry each) are zeroed --
   // 0.2 instead of 0.7 ms at 512^3; every other path fills the whole array first.  CFX_LAZY_ZERO=0: always fill.
   bool lazy_zero = false;
-  auto fill_all = [&]() { if (fresh) dev_fill(values, 0, sizeof(double) * (size_t)P->nnz); };
-  if (A.n_active == 0) fill_all();
-  if (A.n_active > 0)
+  auto fill_all = [&]() { if (fresh) dev_fill(values, 0, sizeof(double) * (size_t)P->nnz.cap()); };
+  if constexpr (DEG > 1)
+  {
+    // degree 2: the host sizes work by the row counts -- read them back if they are still in HBM
+    cfx_row_plan& pl = row_plan(a);
+    (void)pl.n_active_rows.value(); (void)pl.n_special_rows.value(); (void)pl.n_plain_rows.value();
+    A.n_active = pl.n_active_rows;
+  }
+  if (A.n_active.cap == 0) fill_all();
+  if (A.n_active.cap > 0)
   {
     const bool det = deterministic();
     const int mr = P->max_row_len;
@@ -4058,7 +4082,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
 #define CFX_ROWS(GG, CAPP, NAME, ARGS)                                                                    \
   do                                                                                                      \
   {                                                                                                       \
-    const dim3 grid = row_grid(((ARGS).n_active + (kWave / GG) - 1) / (kWave / GG));                      \
+    const dim3 grid = row_grid(((ARGS).n_active.cap + (kWave / GG) - 1) / (kWave / GG));                  \
     if (det) launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, true>, grid, dim3(kWave), 0, ARGS);   \
     else launch(NAME, assemble_rows_kernel<TDIM, DEG, GG, CAPP, false>, grid, dim3(kWave), 0, ARGS);      \
   } while (0)
@@ -4076,9 +4100,11 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         else if (A.cell[s].std_bits) all_inline = false; // staged uncut tensors: generic path
       }
       const char* fs1 = getenv("CFX_ROWS_SPLIT");
-      const bool split_p1 = all_inline && inline_bits && (2 * plan.n_special_rows <= plan.n_active_rows || (fs1 && fs1[0] == '1'));
+      const bool split_p1 = all_inline && inline_bits && (2 * plan.n_special_rows.hint() <= plan.n_active_rows.hint() || (fs1 && fs1[0] == '1'));
       const char* lz = getenv("CFX_LAZY_ZERO");
-      lazy_zero = fresh && split_p1 && !(lz && lz[0] == '0');
+      // (only when P was laid out from this very plan: a pattern of a larger form -- several forms assembled into one
+      // matrix -- has full-length rows where this plan has none, and they must all be zeroed)
+      lazy_zero = fresh && split_p1 && P->built_plan == plan.serial && !(lz && lz[0] == '0');
       if (!lazy_zero) fill_all();
       if (split_p1)
       {
@@ -4098,7 +4124,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         }
         // rows laid out as stencil subsets by build_pattern from this very plan: slots by popcount
         const Stencil& stn = a->V->stencil;
-        if (stn.usable && plan.n_plain_rows > 0 && P->stencil_plan == plan.serial)
+        if (stn.usable && plan.n_plain_rows.cap() > 0 && P->stencil_plan == plan.serial)
         {
           RowArgs Q = F;
           Q.n_active = plan.n_plain_rows; Q.active_rows = plan.plain_rows.p;
@@ -4108,7 +4134,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           // row tiles (coalesced staging of the mesh-static tables), when every tile fits an LDS capacity class
           const Stencil& stt = space_stencil_tiles(a->V);
           const int tcls = stt.tiles_usable ? tile_class(stt) : -1;
-          const bool use_tiles = tcls >= 0 && plan.n_plain_tiles > 0;
+          const bool use_tiles = tcls >= 0 && plan.n_plain_tiles.cap() > 0;
           if (use_tiles)
           {
             TileArgs T{};
@@ -4119,7 +4145,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
             T.tile_voff = stt.tile_voff.p; T.tile_verts = stt.tile_verts.p;
             T.indptr = Q.indptr; T.values = Q.values; T.bc0 = Q.bc0; T.bc1 = Q.bc1;
             T.inline_bits = inline_bits; T.fresh = Q.fresh; T.error = Q.error; T.ndofs = a->V->ndofs;
-            const dim3 gt = row_grid(plan.n_plain_tiles);
+            const dim3 gt = row_grid(plan.n_plain_tiles.cap());
             if (tcls == 0)
             {
               if (det) launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, true, 0>, gt, dim3(kWave), 0, T);
@@ -4131,7 +4157,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
               else launch("assemble_tiles_plain", assemble_tiles_plain_kernel<TDIM, false, 1>, gt, dim3(kWave), 0, T);
             }
           }
-          const dim3 gq = row_grid((Q.n_active + (kWave / CFX_PLAIN_G) - 1) / (kWave / CFX_PLAIN_G));
+          const dim3 gq = row_grid((Q.n_active.cap + (kWave / CFX_PLAIN_G) - 1) / (kWave / CFX_PLAIN_G));
           const char* stage_env = getenv("CFX_PLAIN_STAGE");
           const bool stage = stn.max_len <= 32 && !(stage_env && stage_env[0] == '0');
           // plain rows are subsets of their stencil: the LDS footprint follows the longest stencil
@@ -4151,7 +4177,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           // the uncut items of the interface rows keep the searching kernel
           F.n_active = plan.n_special_rows; F.active_rows = plan.special_rows.p;
         }
-        const dim3 grid = row_grid((F.n_active + 7) / 8);
+        const dim3 grid = row_grid((F.n_active.cap + 7) / 8);
         if (mr <= 32)
         {
           if (det) launch("assemble_rows_p1", assemble_rows_p1_kernel<TDIM, 8, 32, true>, grid, dim3(kWave), 0, F);
@@ -4164,12 +4190,12 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         }
         RowArgs S = A;
         S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
-        if (S.n_active > 0)
+        if (S.n_active.cap > 0)
         {
 #define CFX_ROWS_CUT(GG, CAPP)                                                                                       \
   do                                                                                                                 \
   {                                                                                                                  \
-    const dim3 grid = row_grid((S.n_active + (kWave / GG) - 1) / (kWave / GG));                                      \
+    const dim3 grid = row_grid((S.n_active.cap + (kWave / GG) - 1) / (kWave / GG));                                  \
     if (det) launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, true, false>, grid, dim3(kWave), 0, S);   \
     else launch("assemble_rows_cut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, true, false>, grid, dim3(kWave), 0, S);      \
   } while (0)
@@ -4186,7 +4212,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       // exactly one writer and only the inactive rows are zeroed
       const bool one_pass = combine_cuts && A.cut_tensors != nullptr && P->odd_plan == plan.serial && P->full_plan == plan.serial;
       const char* lz = getenv("CFX_LAZY_ZERO");
-      lazy_zero = fresh && one_pass && !(lz && lz[0] == '0');
+      lazy_zero = fresh && one_pass && P->built_plan == plan.serial && !(lz && lz[0] == '0');
       if (!lazy_zero) fill_all();
       else
         launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, 1, plan.rowmark.p,
@@ -4196,7 +4222,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       // interface rows with the full kernel.  Needs the row partition made with the pattern.
       const char* fs = getenv("CFX_ROWS_SPLIT"); // '1': split whatever the share of the interface rows (tests on small meshes)
       if (P->split_plan == plan.serial && mr > 64 && mr <= 256
-          && (plan.n_special_rows * 2 <= plan.n_active_rows || (fs && fs[0] == '1')))
+          && (plan.n_special_rows.value() * 2 <= plan.n_active_rows.value() || (fs && fs[0] == '1')))
       {
         split = true;
 #define CFX_LEAN(GG, CAPP, ROWS, NROWS)                                                                              \
@@ -4204,15 +4230,15 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   {                                                                                                                  \
     RowArgs Q = A;                                                                                                   \
     Q.mark_mask = 0x0Fu; Q.active_rows = (ROWS); Q.n_active = (NROWS); Q.fresh = lazy_zero ? 2 : Q.fresh;           \
-    const dim3 grid = row_grid((Q.n_active + (kWave / GG) - 1) / (kWave / GG));                                      \
-    if (Q.n_active > 0)                                                                                              \
+    const dim3 grid = row_grid((Q.n_active.cap + (kWave / GG) - 1) / (kWave / GG));                                  \
+    if (Q.n_active.cap > 0)                                                                                          \
     {                                                                                                                \
       if (det) launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, true, false>, grid, dim3(kWave), 0, Q);  \
       else launch("assemble_rows_uncut", assemble_rows_kernel<TDIM, DEG, GG, CAPP, false, false>, grid, dim3(kWave), 0, Q);     \
     }                                                                                                                \
   } while (0)
         // (decided here, used below: the dedicated interface kernel takes the pattern's short / long lists whole)
-        bool lean_ok = one_pass && (plan.nfacets == 0 || (A.fold_facets == 3 && A.facet_tensors != nullptr));
+        bool lean_ok = one_pass && (plan.nfacets.value() == 0 || (A.fold_facets == 3 && A.facet_tensors != nullptr));
         for (int q = 0; q < A.n_cell; ++q)
           lean_ok = lean_ok && (A.cell[q].std_bits == nullptr || A.cell[q].std_inline == 3);
         if (const char* li = getenv("CFX_P2_INTERFACE")) lean_ok = lean_ok && li[0] != '0';
@@ -4259,27 +4285,27 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
 #undef CFX_LEAN
         RowArgs S = A;
         S.n_active = plan.n_special_rows; S.active_rows = plan.special_rows.p; S.mark_mask = 0xF0u;
-        if (S.n_active > 0)
+        if (S.n_active.cap > 0)
         {
-          const dim3 grid = row_grid((S.n_active + 3) / 4);
+          const dim3 grid = row_grid((S.n_active.cap + 3) / 4);
           // every uncut-cell integral the closed-form stiffness row, every facet term as rank-one records (or none):
           // the dedicated interface kernel; else the general one
           if (lean_ok)
           {
             S.mark_mask = 0xFFu; S.fresh = lazy_zero ? 2 : S.fresh;
-            if (plan.nfacets == 0) { S.d2f_off = nullptr; S.facet_nq = 0; }
+            if (plan.nfacets.value() == 0) { S.d2f_off = nullptr; S.facet_nq = 0; }
             // the rows of at most 64 columns (edge dofs: most of them) 8 lanes per row with a quarter of the LDS, the
             // others 16 lanes and 256 columns; the two lists hold every hashed row, the few plain ones among them included
             RowArgs S1 = S, S2 = S;
             S1.n_active = P->n_short_rows; S1.active_rows = P->short_rows.p;
             S2.n_active = P->n_long_rows; S2.active_rows = P->long_rows.p;
-            const dim3 g1 = row_grid((S1.n_active + 7) / 8), g2 = row_grid((S2.n_active + 3) / 4);
-            if (S1.n_active > 0)
+            const dim3 g1 = row_grid((S1.n_active.cap + 7) / 8), g2 = row_grid((S2.n_active.cap + 3) / 4);
+            if (S1.n_active.cap > 0)
             {
               if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 8, 64, true>, g1, dim3(kWave), 0, S1);
               else launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 8, 64, false>, g1, dim3(kWave), 0, S1);
             }
-            if (S2.n_active > 0)
+            if (S2.n_active.cap > 0)
             {
               if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 256, true>, g2, dim3(kWave), 0, S2);
               else launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 256, false>, g2, dim3(kWave), 0, S2);
@@ -4315,7 +4341,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
     }
 #undef CFX_ROWS
   }
-  return read_scalar(err.p);
+  return err.deferred ? 0 : read_scalar(err.p);
 }
 
 template <int TDIM, int DEG, int BS>
@@ -4325,8 +4351,14 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   RowArgs A = prepare<TDIM, DEG, BS>(a, st);
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
   A.mark_mask = 0xFFu;
-  ZeroFlag err;
+  ErrorFlag err(CFX_ERR_RUNTIME, kEntryMissing, raise_gather_error);
   A.error = err.p;
+  {
+    // block spaces: the host sizes work by the row counts -- read them back if they are still in HBM
+    cfx_row_plan& pl = row_plan(a);
+    (void)pl.n_active_rows.value(); (void)pl.n_special_rows.value(); (void)pl.n_plain_rows.value();
+    A.n_active = pl.n_active_rows;
+  }
   // `fresh` = MatrixCSR.set_value(0) fused into this call: every active row is written by exactly one kernel below
   // (the dof-at-a-time kernel or the searching one), which then STORES its rows; only the inactive rows (one
   // diagonal entry each) are zeroed -- the full fill of the value array was 1.8 of 10.8 ms at BASELINE config 5's share
@@ -4334,10 +4366,15 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
   if (fresh)
   {
     cfx_row_plan& plan0 = row_plan(a);
-    launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, BS, plan0.rowmark.p,
-           P->indptr.p, values);
+    // (a pattern built from another, larger form: its rows off this plan's active set are not single diagonal
+    // entries written by nobody -- fill everything)
+    if (P->built_plan == plan0.serial)
+      launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, BS, plan0.rowmark.p,
+             P->indptr.p, values);
+    else
+      dev_fill(values, 0, sizeof(double) * (size_t)P->nnz.value());
   }
-  if (A.n_active > 0)
+  if (A.n_active.cap > 0)
   {
     const bool det = deterministic();
     const int mr = P->max_row_len; // scalar columns per row
@@ -4353,7 +4390,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 #define CFX_BLOCK(GG, CAPP)                                                                                          \
   do                                                                                                                 \
   {                                                                                                                  \
-    const dim3 grid = row_grid((A.n_active * BS + (kWave / GG) - 1) / (kWave / GG));                                 \
+    const dim3 grid = row_grid((A.n_active.cap * BS + (kWave / GG) - 1) / (kWave / GG));                             \
     if (closed) { if (det) CFX_BLOCK_V(GG, CAPP, true, 2); else CFX_BLOCK_V(GG, CAPP, false, 2); }                   \
     else if (inl) { if (det) CFX_BLOCK_V(GG, CAPP, true, 1); else CFX_BLOCK_V(GG, CAPP, false, 1); }                 \
     else { if (det) CFX_BLOCK_V(GG, CAPP, true, 0); else CFX_BLOCK_V(GG, CAPP, false, 0); }                          \
@@ -4409,7 +4446,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
         A.n_active = P->n_rest_rows; A.active_rows = P->rest_rows.p;
       }
     }
-    if (A.n_active > 0)
+    if (A.n_active.cap > 0)
     {
     if (mr <= 32) CFX_BLOCK(8, 32);
     else if (mr <= 128) CFX_BLOCK(16, 128);
@@ -4418,7 +4455,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 #undef CFX_BLOCK_V
 #undef CFX_BLOCK
   }
-  return read_scalar(err.p);
+  return err.deferred ? 0 : read_scalar(err.p);
 }
 
 // stage 2 of a linear form on the plain rows of a P1 space: the row's entries are contiguous in the
@@ -4430,11 +4467,12 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
 #define CFX_VEC_BLOCK_G 1 // lanes per row of vec_blocks_rows_kernel (configs[3]: 2.13 ms at 4, 1.51 at 2, 1.35 at 1)
 #endif
 template <int G>
-__global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
                                                                    const int64_t* __restrict__ d2c_off,
                                                                    const int32_t* __restrict__ t2off,
                                                                    const double* __restrict__ t2, double* __restrict__ b)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   const int lane = threadIdx.x, gl = lane % G;
   const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
   const bool live = i < n_plain;
@@ -4489,7 +4527,7 @@ void run_vector(cfx_form_s* L, double* b)
   // one integral with uncut entities (the volume term)
   int slot = -1, count = 0;
   for (int s = 0; s < plan.n_cell_slots; ++s)
-    if (L->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+    if (L->integrals[plan.cell_slot_integral[s]].n_entities.cap() > 0) { slot = s; ++count; }
   // ... by cell block: partials per (block, dof) of the uncut cells and the runtime rules, then the rows add the
   // partials of the blocks around them
   const uint8_t std_mark = count == 1 ? (uint8_t)(1u << slot) : (uint8_t)0;
@@ -4497,7 +4535,7 @@ void run_vector(cfx_form_s* L, double* b)
   for (int s = 0; s < plan.n_cell_slots; ++s)
   {
     const cfx_integral_dev& I = L->integrals[plan.cell_slot_integral[s]];
-    if (I.rules && I.rules->nr > 0) rule_marks |= (uint8_t)(16u << s);
+    if (I.rules && I.rules->nr.cap() > 0) rule_marks |= (uint8_t)(16u << s);
   }
   const BlockChoice bc = vec_block_choice<DEG>(L, plan, slot, count);
   if (bc.use && (std_mark | rule_marks) != 0 && vec_block_plan(L, (uint8_t)(std_mark | rule_marks), bc.merged))
@@ -4509,7 +4547,7 @@ void run_vector(cfx_form_s* L, double* b)
     if (!st.vec_blocks && count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0')
         && plain_vec_offsets(L, (uint8_t)(1u << slot)))
     {
-      st.t2.alloc(plan.vec_t2_total);
+      st.t2.alloc(plan.vec_t2_total.cap());
       st.vec_t2 = st.t2.p;
     }
   }
@@ -4519,11 +4557,11 @@ void run_vector(cfx_form_s* L, double* b)
   {
     st.part.alloc(plan.vb_total);
     vec_block_partials<TDIM, DEG>(L, count == 1 ? &L->integrals[plan.cell_slot_integral[slot]] : nullptr, std_mark, A, st.part.p);
-    if (plan.n_active_rows > 0 && plan.vb_total > 0)
+    if (plan.n_active_rows.cap() > 0 && plan.vb_total > 0)
     {
       const VecBlocks& S = space_vec_blocks(L->V);
       constexpr int G = CFX_VEC_BLOCK_G;
-      launch("vec_blocks_rows", vec_blocks_rows_kernel<G>, row_grid((plan.n_active_rows + (kWave / G) - 1) / (kWave / G)), dim3(kWave),
+      launch("vec_blocks_rows", vec_blocks_rows_kernel<G>, row_grid((plan.n_active_rows.cap() + (kWave / G) - 1) / (kWave / G)), dim3(kWave),
              0, plan.n_active_rows, plan.active_rows.p, S.p_off.p, S.p_pos.p, plan.vb_base.p, st.part.p, b);
     }
     return;
@@ -4542,13 +4580,13 @@ void run_vector(cfx_form_s* L, double* b)
   {
     constexpr int G = CFX_VEC_PLAIN_G;
     launch("assemble_vec_plain", assemble_vec_plain_kernel<G>,
-           dim3((unsigned)((plan.n_plain_rows + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
+           dim3((unsigned)((plan.n_plain_rows.cap() + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
            plan.plain_rows.p, A.d2c_off, plan.vec_t2off.p, st.vec_t2, b);
     A.n_active = plan.n_vec_slow_rows; A.active_rows = plan.vec_slow_rows.p; // the rows next to the interface, mostly
   }
-  if (A.n_active > 0)
+  if (A.n_active.cap > 0)
     launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,
-           row_grid((A.n_active + (kWave / CFX_VEC_G) - 1) / (kWave / CFX_VEC_G)), dim3(kWave), 0,
+           row_grid((A.n_active.cap + (kWave / CFX_VEC_G) - 1) / (kWave / CFX_VEC_G)), dim3(kWave), 0,
            A);
 }
 
@@ -4573,7 +4611,7 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
       const int nloc = V->ndofs_cell * V->bs;
       size_t need = 0, free_b = 0, total_b = 0;
       for (const auto& I : a->integrals) // (closed-form uncut cells stage nothing)
-        need += (size_t)((p2_elasticity_closed(a, I) ? 0 : I.n_entities) + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
+        need += (size_t)((p2_elasticity_closed(a, I) ? 0 : I.n_entities.cap()) + (I.rules ? I.rules->nr.cap() : 0)) * nloc * nloc * sizeof(double);
       CFX_HIP(hipMemGetInfo(&free_b, &total_b));
       const char* bg = getenv("CFX_BLOCK_GATHER");
       if ((bg && bg[0] == '0') || need > free_b / 2) return false;
@@ -4593,17 +4631,14 @@ bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, co
              size_t need = 0, free_b = 0, total_b = 0;
              const int nloc = V->ndofs_cell;
              for (const auto& I : a->integrals)
-               if (I.type == CFX_CELL) need += (size_t)(I.n_entities + (I.rules ? I.rules->nr : 0)) * nloc * nloc * sizeof(double);
+               if (I.type == CFX_CELL) need += (size_t)(I.n_entities.cap() + (I.rules ? I.rules->nr.cap() : 0)) * nloc * nloc * sizeof(double);
              CFX_HIP(hipMemGetInfo(&free_b, &total_b));
              return need > free_b / 2;
            }())
     return false;
   else
     err = V->mesh->tdim == 2 ? run_matrix<2, 2>(a, P, bc0, bc1, values, fresh) : run_matrix<3, 2>(a, P, bc0, bc1, values, fresh);
-  require(err != 1, CFX_ERR_RUNTIME, "assemble_matrix: entry not in the sparsity pattern");
-  require(err != 2, CFX_ERR_RUNTIME, "assemble_matrix: row longer than the gather kernel's capacity");
-  require(err != 5, CFX_ERR_RUNTIME, "assemble_matrix: a stencil-subset row does not match its sparsity pattern");
-  require(err != 4, CFX_ERR_INVALID_ARGUMENT, "assemble_matrix: a facet row does not join two cells across a shared facet");
+  raise_gather_error(err);
   return true;
 }
 
@@ -4618,17 +4653,17 @@ void prepare_form_tables(cfx_form_s* a)
   (void)V->dof_cells();
   const Stencil& stn = space_stencil(V);
   if (V->degree == 2) (void)space_stencil_slotn(V);
-  if (plan.nfacets > 0) (void)V->mesh->cell_neighbours();
+  if (plan.nfacets.cap() > 0) (void)V->mesh->cell_neighbours();
   if (a->rank == 1 && plan.usable && V->bs == 1)
   {
     int slot = -1, count = 0;
     for (int s = 0; s < plan.n_cell_slots; ++s)
-      if (a->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+      if (a->integrals[plan.cell_slot_integral[s]].n_entities.cap() > 0) { slot = s; ++count; }
     uint8_t marks = count == 1 ? (uint8_t)(1u << slot) : (uint8_t)0;
     for (int s = 0; s < plan.n_cell_slots; ++s)
     {
       const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[s]];
-      if (I.rules && I.rules->nr > 0) marks |= (uint8_t)(16u << s);
+      if (I.rules && I.rules->nr.cap() > 0) marks |= (uint8_t)(16u << s);
     }
     if (count <= 1 && marks != 0)
     {
@@ -4644,7 +4679,7 @@ void prepare_form_tables(cfx_form_s* a)
   {
     int slot = -1, count = 0;
     for (int s = 0; s < plan.n_cell_slots; ++s)
-      if (a->integrals[plan.cell_slot_integral[s]].n_entities > 0) { slot = s; ++count; }
+      if (a->integrals[plan.cell_slot_integral[s]].n_entities.cap() > 0) { slot = s; ++count; }
     if (count == 1) (void)plain_vec_offsets(a, (uint8_t)(1u << slot));
   }
 }

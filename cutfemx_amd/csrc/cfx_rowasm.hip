@@ -25,9 +25,10 @@ constexpr int kWave = 64;
 // ---------------------------------------------------------------------------
 // plan construction
 // ---------------------------------------------------------------------------
-__global__ void plan_mark_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride, uint8_t bit,
+__global__ void plan_mark_cells_kernel(DevN n_d, const int32_t* __restrict__ cells, int stride, uint8_t bit,
                                        uint8_t* mark)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // Launches are serialised on the stream and every thread of one launch ORs the
@@ -88,10 +89,11 @@ __global__ void __launch_bounds__(kBlock) plan_pack_bits_kernel(int64_t ncells, 
 // uncut entities of a cell integral, nd <= 4 dofs per cell, in one pass over the list: cell mark, row marks
 // (dofmap row as one 16 B load when nd == 4) and the ascending check
 template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(int64_t n, const int32_t* __restrict__ cells,
+__global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(DevN n_d, const int32_t* __restrict__ cells,
                                                                     const int32_t* __restrict__ dofmap, uint8_t bit,
                                                                     uint8_t* mark, uint8_t* rowmark, int* flag)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   const int64_t c = cells[i];
@@ -115,11 +117,12 @@ __global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(int64_t n, c
 // runtime rules of a cell integral, nd <= 4: one pass over the parent list -- ascending check, and at the first
 // rule of every parent its cell mark, row marks (special rows) and hash-map entry parent -> first rule
 template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_rules_kernel(int64_t nr, const int32_t* __restrict__ parent,
+__global__ void __launch_bounds__(kBlock) plan_rules_kernel(DevN nr_d, const int32_t* __restrict__ parent,
                                                             const int32_t* __restrict__ dofmap, uint8_t bit, uint8_t* mark,
                                                             uint8_t* rowmark, uint8_t* special, uint32_t hmask,
                                                             int32_t* __restrict__ keys, int32_t* __restrict__ first, int* flag)
 {
+  const int64_t nr = dev_n(nr_d);
   const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (e >= nr) return;
   const int32_t c = parent[e];
@@ -149,10 +152,11 @@ __global__ void __launch_bounds__(kBlock) plan_rules_kernel(int64_t nr, const in
 
 // interior-facet entities, nd <= 4: row marks (special rows) of both cells of every row
 template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(int64_t nf, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(DevN nf_d, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, uint8_t* rowmark,
                                                                  uint8_t* special, int* flag)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (f >= nf) return;
   const int4 r = *reinterpret_cast<const int4*>(rows + 4 * f);
@@ -178,10 +182,11 @@ __global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(int64_t nf, con
 }
 
 // `special` (may be null): rows that receive something other than uncut-cell items
-__global__ void plan_mark_rows_cells_kernel(int64_t n, const int32_t* __restrict__ cells, int stride,
+__global__ void plan_mark_rows_cells_kernel(DevN n_d, const int32_t* __restrict__ cells, int stride,
                                             const int32_t* __restrict__ dofmap, int nd, uint8_t* rowmark,
                                             uint8_t* special)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n * nd) return;
   const int64_t c = cells[(i / nd) * stride];
@@ -205,16 +210,18 @@ struct RowLenTest
 };
 
 // positions in the active-row list -> row ids, in place
-__global__ void map_rows_kernel(int64_t n, const int32_t* __restrict__ rows, int32_t* __restrict__ idx)
+__global__ void map_rows_kernel(DevN n_d, const int32_t* __restrict__ rows, int32_t* __restrict__ idx)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) idx[i] = rows[idx[i]];
 }
 
 // hash map parent cell -> first rule index (one entry per run of equal parents)
-__global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ parent, uint32_t mask,
+__global__ void plan_rule_hash_kernel(DevN nr_d, const int32_t* __restrict__ parent, uint32_t mask,
                                       int32_t* __restrict__ keys, int32_t* __restrict__ first)
 {
+  const int64_t nr = dev_n(nr_d);
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nr) return;
   const int32_t c = parent[e];
@@ -230,8 +237,9 @@ __global__ void plan_rule_hash_kernel(int64_t nr, const int32_t* __restrict__ pa
 }
 
 // flags a list that is not ascending (strict: not strictly ascending)
-__global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ a, int strict, int* flag)
+__global__ void plan_check_sorted_kernel(DevN n_d, const int32_t* __restrict__ a, int strict, int* flag)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i + 1 < n && (a[i] > a[i + 1] || (strict && a[i] == a[i + 1]))) atomicOr(flag, 1);
 }
@@ -239,9 +247,10 @@ __global__ void plan_check_sorted_kernel(int64_t n, const int32_t* __restrict__ 
 // P1 facet folding (assemble_rows_kernel) needs every facet row to join two cells that share all dofs but one
 // each -- a continuous P1 space on a conforming mesh.  Flags bit 1 otherwise (DG spaces, extension pairs).
 template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_check_fold_kernel(int64_t nf, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kBlock) plan_check_fold_kernel(DevN nf_d, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, int nx, int* flag)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= nf) return;
   const int64_t c0 = rows[4 * f], c1 = rows[4 * f + 2];
@@ -262,8 +271,9 @@ __global__ void __launch_bounds__(kBlock) plan_check_fold_kernel(int64_t nf, con
 
 // (counts / offsets / cursors are indexed by the dof's position in the special-row list: the
 // incidence only exists next to the interface, a scan over all dofs would cost more than the rest)
-__global__ void plan_scatter_pos_kernel(int64_t n, const int32_t* __restrict__ rows, int32_t* __restrict__ pos)
+__global__ void plan_scatter_pos_kernel(DevN n_d, const int32_t* __restrict__ rows, int32_t* __restrict__ pos)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) pos[rows[i]] = (int32_t)i;
 }
@@ -311,13 +321,19 @@ __global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ ro
 // of both cells once: the cell-1 copy gets the sentinel key `nkeys`, which sorts behind everything).  A stable radix
 // sort over the few key bits replaces ~35 M returning integer atomics on ~2 M counters (count + fill passes) and
 // leaves every list in ascending facet order, whatever the schedule.
-__global__ void __launch_bounds__(kBlock) facet_dof_pairs_kernel(int64_t nf, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kBlock) facet_dof_pairs_kernel(DevN nf_d, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, int nd,
                                                                  const int32_t* __restrict__ pos, int32_t nkeys,
                                                                  int32_t* __restrict__ keys, int32_t* __restrict__ vals)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nf * 2 * nd) return;
+  if (i >= nf * 2 * nd)
+  {
+    // (a facet list shorter than its capacity: the sort runs over the capacity, the tail sorts behind everything)
+    if (i < nf_d.cap * 2 * nd) { keys[i] = nkeys; vals[i] = 0; }
+    return;
+  }
   const int64_t f = i / (2 * nd);
   const int k = (int)(i - f * 2 * nd);
   const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
@@ -333,9 +349,10 @@ __global__ void __launch_bounds__(kBlock) facet_dof_pairs_kernel(int64_t nf, con
 }
 
 // offsets[k] = first sorted position whose key is >= k (k = 0 .. nkeys)
-__global__ void __launch_bounds__(kBlock) sorted_key_offsets_kernel(int64_t nkeys, int64_t n, const int32_t* __restrict__ keys,
+__global__ void __launch_bounds__(kBlock) sorted_key_offsets_kernel(DevN nkeys_d, int64_t n, const int32_t* __restrict__ keys,
                                                                     int64_t* __restrict__ offsets)
 {
+  const int64_t nkeys = dev_n(nkeys_d);
   const int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k > nkeys) return;
   int64_t lo = 0, hi = n;
@@ -348,8 +365,9 @@ __global__ void __launch_bounds__(kBlock) sorted_key_offsets_kernel(int64_t nkey
 }
 
 // sort each listed dof's facet list so the gather order is reproducible
-__global__ void seg_sort_kernel(int64_t nseg, const int64_t* __restrict__ offsets, int32_t* vals)
+__global__ void seg_sort_kernel(DevN nseg_d, const int64_t* __restrict__ offsets, int32_t* vals)
 {
+  const int64_t nseg = dev_n(nseg_d);
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nseg) return;
   const int64_t b = offsets[r], e = offsets[r + 1];
@@ -377,7 +395,7 @@ struct FlagSetU8
 // ---------------------------------------------------------------------------
 struct PatArgs
 {
-  int64_t n_active;
+  DevN n_active;    // rows of this launch (length in HBM inside a sync-free step)
   const int32_t* active_rows;
   int nd, bs;
   const int32_t* dofmap;
@@ -446,10 +464,11 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   __shared__ int s_cnt[RPW];
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   // one pass for every launch that fits HIP's 2^32-thread limit; the grid is capped beyond it
-  for (int64_t blk = blockIdx.x; blk * RPW < P.n_active; blk += gridDim.x)
+  const int64_t n_active = dev_n(P.n_active);
+  for (int64_t blk = blockIdx.x; blk * RPW < n_active; blk += gridDim.x)
   {
   const int64_t ri = blk * RPW + grp; // (XCD-contiguous chunks measured slower: 5.95 vs 6.0 ms here, 12.6 vs 14.5 ms in the gather)
-  const bool live = ri < P.n_active;
+  const bool live = ri < n_active;
   const int64_t r = live ? (P.active_rows ? (int64_t)P.active_rows[ri] : ri) : 0;
   for (int k = gl; k < T; k += G) s_tab[grp][k] = -1;
   if (gl == 0) s_cnt[grp] = 0;
@@ -706,8 +725,11 @@ __global__ void __launch_bounds__(kBlock) indptr_reduce_kernel(int64_t nrows, in
 __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
                                                               const int32_t* __restrict__ counts,
                                                               const int64_t* __restrict__ tile_offsets,
-                                                              int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
+                                                              int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                              DevN nnz_d)
 {
+  // (indices sized by the previous step's nnz: nothing is written beyond the published total -- 0 in a void step)
+  const int64_t nnz_cap = nnz_d.dev ? dev_n(nnz_d) : INT64_MAX;
   __shared__ int64_t s_v[kTile];
   const int64_t tile = (int64_t)blockIdx.x * kTile;
 #pragma unroll
@@ -735,17 +757,18 @@ __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int
     const int64_t p = s_v[i];
     indptr[R] = p;
     const int64_t dof = R / bs;
-    if (!rowmark[dof])
+    if (!rowmark[dof] && p + bs <= nnz_cap)
       for (int b = 0; b < bs; ++b) indices[p + b] = (int32_t)(dof * bs + b);
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) indptr[nrows] = tile_offsets[blockIdx.x] + total;
 }
 
 template <int T>
-__global__ void pattern_write_kernel(int64_t n_active, const int32_t* __restrict__ active_rows, int bs,
+__global__ void pattern_write_kernel(DevN n_active_d, const int32_t* __restrict__ active_rows, int bs,
                                      const int32_t* __restrict__ tmp, const int32_t* __restrict__ len,
                                      const int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
 {
+  const int64_t n_active = dev_n(n_active_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t ri = i / 8;
   if (ri >= n_active) return;
@@ -839,8 +862,11 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
                                                                       const int64_t* __restrict__ tile_offsets,
                                                                       int32_t* __restrict__ active,
                                                                       int32_t* __restrict__ special_rows,
-                                                                      int32_t* __restrict__ plain_rows)
+                                                                      int32_t* __restrict__ plain_rows, DevN n_special_d,
+                                                                      DevN n_plain_d)
 {
+  // (lists sized by the previous step: nothing is written beyond their published lengths -- 0 in a void step)
+  const int64_t cap_s = n_special_d.dev ? dev_n(n_special_d) : INT64_MAX, cap_p = n_plain_d.dev ? dev_n(n_plain_d) : INT64_MAX;
   const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
   unsigned fa = 0, fs = 0;
   if (base < n)
@@ -858,8 +884,8 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
   for (int k = 0; k < kByteItems; ++k)
   {
     const int32_t row = (int32_t)(base + k);
-    if (fs & (1u << k)) { active[s + p] = row; special_rows[s++] = row; }
-    else if (fp & (1u << k)) { active[s + p] = row; if (plain_rows) plain_rows[p] = row; ++p; }
+    if (fs & (1u << k)) { if (s < cap_s && p <= cap_p) { active[s + p] = row; special_rows[s] = row; } ++s; }
+    else if (fp & (1u << k)) { if (p < cap_p && s <= cap_s) { active[s + p] = row; if (plain_rows) plain_rows[p] = row; } ++p; }
   }
 }
 
@@ -882,7 +908,7 @@ struct ByteIs
 #endif
 // stencil mask of a plain row: OR over its marked incident cells of the positions of their dofs, and
 // the mark byte shared by all its incident cells (0: not uniform).  G lanes per row.
-__global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
                                                             const int64_t* __restrict__ d2c_off,
                                                             const int32_t* __restrict__ d2c,
                                                             const uint32_t* __restrict__ slot4,
@@ -891,6 +917,7 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
                                                             unsigned long long* __restrict__ masks,
                                                             uint8_t* __restrict__ uniform)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   constexpr int G = CFX_MASKS_G;
   const int lane = threadIdx.x, gl = lane % G;
   const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
@@ -981,10 +1008,11 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(int64_t n_plain, con
 }
 
 // sparsity of the plain rows, pass 1: row length = popcount of the mask
-__global__ void pattern_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+__global__ void pattern_plain_len_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
                                          const unsigned long long* __restrict__ masks, int32_t* __restrict__ counts,
                                          int* maxlen)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_plain) return;
   const int cnt = __popcll(masks[i]);
@@ -996,13 +1024,14 @@ __global__ void pattern_plain_len_kernel(int64_t n_plain, const int32_t* __restr
 #ifndef CFX_PPW_LANES
 #define CFX_PPW_LANES 4 // lanes per plain row (512^3: 16 -> 1304 us, 8 -> 933, 4 -> 793, 2 -> 1457)
 #endif
-__global__ void __launch_bounds__(kBlock) pattern_plain_write_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
+__global__ void __launch_bounds__(kBlock) pattern_plain_write_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
                                                                      const unsigned long long* __restrict__ masks,
                                                                      const int64_t* __restrict__ off,
                                                                      const int32_t* __restrict__ nbr,
                                                                      const int64_t* __restrict__ indptr,
                                                                      int32_t* __restrict__ indices)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t i = t / CFX_PPW_LANES;
   if (i >= n_plain) return;
@@ -1113,9 +1142,10 @@ struct TileStart
   __device__ bool operator()(int64_t i) const { return i == 0 || (rows[i] / kRowTile) != (rows[i - 1] / kRowTile); }
 };
 
-__global__ void tile_ids_kernel(int64_t n, const int32_t* __restrict__ first, const int32_t* __restrict__ rows,
+__global__ void tile_ids_kernel(DevN n_d, const int32_t* __restrict__ first, const int32_t* __restrict__ rows,
                                 int32_t* __restrict__ ids)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) ids[i] = rows[first[i]] / kRowTile;
 }
@@ -1123,8 +1153,8 @@ __global__ void tile_ids_kernel(int64_t n, const int32_t* __restrict__ first, co
 // pass 2 by row tile (Stencil tiles, plan.plain_tile_first / _id): the rows of a tile are neighbours in the stencil
 // and in the CSR arrays.  A tile whose kRowTile rows are all plain and hold their whole stencil -- the bulk of the
 // domain -- is one contiguous copy nbr[st_off[r0] ...] -> indices[indptr[r0] ...]; other tiles go row by row.
-__global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(int64_t n_tiles, const int32_t* __restrict__ tile_first,
-                                                                    const int32_t* __restrict__ tile_id, int64_t n_plain,
+__global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(DevN n_tiles_d, const int32_t* __restrict__ tile_first,
+                                                                    const int32_t* __restrict__ tile_id, DevN n_plain_d,
                                                                     const int32_t* __restrict__ rows,
                                                                     const unsigned long long* __restrict__ masks,
                                                                     const int64_t* __restrict__ off,
@@ -1132,6 +1162,8 @@ __global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(int64_t n_ti
                                                                     const int64_t* __restrict__ indptr,
                                                                     int32_t* __restrict__ indices, int64_t ndofs)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
+  const int64_t n_tiles = dev_n(n_tiles_d);
   constexpr int G = kWave / kRowTile;
   const int lane = threadIdx.x, g = lane / G, gl = lane % G;
   const int64_t w = blockIdx.x;
@@ -1348,7 +1380,7 @@ void validate_form(const cfx_form_s* a)
 {
   for (const cfx_integral_dev& I : a->integrals)
   {
-    if (I.entities_serial != 0 && I.n_entities > 0 && !I.entities.owned && dev_block_serial(I.entities.p) != I.entities_serial)
+    if (I.entities_serial != 0 && I.n_entities.cap() > 0 && !I.entities.owned && dev_block_serial(I.entities.p) != I.entities_serial)
       throw Error(CFX_ERR_RUNTIME, "stale form: an entity list it refers to was released or rebuilt (cfx_cut_update drops the "
                                    "located lists and ghost rows of a cut); create the form again from the new lists");
     if (I.rules_serial != 0 && !rules_serial_is_live(I.rules_serial))
@@ -1366,9 +1398,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
-    const std::array<int64_t, 7> k{(int64_t)ii, I.n_entities > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, I.n_entities,
-                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr : 0,
-                                   I.n_entities > 0 ? (int64_t)I.entities_serial : 0, (int64_t)I.rules_serial};
+    const int64_t ne = I.n_entities.cap();
+    const std::array<int64_t, 7> k{(int64_t)ii, ne > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, ne,
+                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr.cap() : 0,
+                                   ne > 0 ? (int64_t)I.entities_serial : 0, (int64_t)I.rules_serial};
     (I.type == CFX_CELL ? key_cells : key_facets).push_back(k);
   }
   // Share the plan of another LIVE form of this space built from the same lists (caller-owned entity arrays,
@@ -1404,59 +1437,63 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   special.zero();
   ZeroFlag flag;
   int plan_flags = 0; // the flag word, read together with the row totals
-  P.nfacets = 0;
+  // Entity counts may still be in HBM (lists made inside a sync-free step): grids then cover the capacity of a list
+  // and the kernels take its length from the device (DevN).
+  int n_facet_lists = 0;
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
+    const int64_t ne = I.n_entities.cap();
     if (I.type == CFX_CELL)
     {
       if (P.n_cell_slots >= 4) { P.usable = false; continue; }
       const int slot = P.n_cell_slots++;
       P.cell_slot_integral[slot] = (int)ii;
-      if (I.n_entities > 0)
+      if (ne > 0)
       {
         if (nd == 4)
-          launch("plan_mark_entities", plan_mark_entities_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+          launch("plan_mark_entities", plan_mark_entities_kernel<4>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                  I.entities.p, V->dofmap.p, (uint8_t)(1u << slot), P.cellmark.p, P.rowmark.p, flag.p);
         else if (nd == 3)
-          launch("plan_mark_entities", plan_mark_entities_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+          launch("plan_mark_entities", plan_mark_entities_kernel<3>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                  I.entities.p, V->dofmap.p, (uint8_t)(1u << slot), P.cellmark.p, P.rowmark.p, flag.p);
         else
         {
-          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                  I.entities.p, 1, (uint8_t)(1u << slot), P.cellmark.p);
-          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(ne * nd), dim3(kBlock), 0,
                  I.n_entities, I.entities.p, 1, V->dofmap.p, nd, P.rowmark.p, (uint8_t*)nullptr);
-          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                  I.entities.p, 1, flag.p);
         }
         P.any_cells = true;
       }
-      if (I.rules && I.rules->nr > 0)
+      const int64_t nr = I.rules ? I.rules->nr.cap() : 0;
+      if (nr > 0)
       {
         uint32_t size = 64;
-        while (size < 2 * (uint64_t)I.rules->nr) size <<= 1;
+        while (size < 2 * (uint64_t)nr) size <<= 1;
         P.rule_mask[slot] = size - 1;
         P.rule_keys[slot].alloc(size);
         P.rule_first[slot].alloc(size);
         dev_fill(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size);
         if (nd == 4)
-          launch("plan_rules", plan_rules_kernel<4>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+          launch("plan_rules", plan_rules_kernel<4>, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
                  P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
         else if (nd == 3)
-          launch("plan_rules", plan_rules_kernel<3>, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+          launch("plan_rules", plan_rules_kernel<3>, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
                  P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
         else
         {
-          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+          launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, 1, (uint8_t)(16u << slot), P.cellmark.p);
-          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.rules->nr * nd), dim3(kBlock), 0,
+          launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(nr * nd), dim3(kBlock), 0,
                  I.rules->nr, I.rules->parent_map.p, 1, V->dofmap.p, nd, P.rowmark.p, special.p);
-          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+          launch("plan_check_sorted", plan_check_sorted_kernel, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, 0, flag.p);
-          launch("plan_rule_hash", plan_rule_hash_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr,
+          launch("plan_rule_hash", plan_rule_hash_kernel, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p);
         }
         P.any_cells = true;
@@ -1466,118 +1503,147 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     {
       if (P.n_facet_slots >= 2) { P.usable = false; continue; }
       P.facet_slot_integral[P.n_facet_slots++] = (int)ii;
-      P.nfacets += I.n_entities;
+      if (ne > 0) ++n_facet_lists;
     }
   }
-  if (P.nfacets > 0)
+  // the facet rows of all facet integrals, concatenated: one list keeps its (possibly pending) length, several are
+  // joined at their exact lengths
+  P.nfacets = Count(0);
+  if (n_facet_lists == 1)
   {
-    P.facet_rows.alloc(P.nfacets * 4);
-    P.facet_slot.alloc(P.nfacets);
+    for (int s = 0; s < P.n_facet_slots; ++s)
+      if (a->integrals[P.facet_slot_integral[s]].n_entities.cap() > 0) P.nfacets = a->integrals[P.facet_slot_integral[s]].n_entities;
+  }
+  else if (n_facet_lists > 1)
+  {
+    int64_t total = 0;
+    for (int s = 0; s < P.n_facet_slots; ++s) total += a->integrals[P.facet_slot_integral[s]].n_entities.value();
+    P.nfacets = Count(total);
+  }
+  const int64_t nf_cap = P.nfacets.cap();
+  if (nf_cap > 0)
+  {
+    P.facet_rows.alloc(nf_cap * 4);
+    P.facet_slot.alloc(nf_cap);
     int64_t o = 0;
     for (int s = 0; s < P.n_facet_slots; ++s)
     {
       const cfx_integral_dev& I = a->integrals[P.facet_slot_integral[s]];
-      if (I.n_entities == 0) continue;
-      CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)I.n_entities,
+      const int64_t ne = I.n_entities.cap(); // (exact unless this is the only list)
+      if (ne == 0) continue;
+      CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)ne,
                              hipMemcpyDeviceToDevice, ctx().stream));
-      dev_fill(P.facet_slot.p + o, s, (size_t)I.n_entities);
+      dev_fill(P.facet_slot.p + o, s, (size_t)ne);
       if (nd == 4)
-        launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+        launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
       else if (nd == 3)
-        launch("plan_facet_rows", plan_facet_rows_kernel<3>, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities,
+        launch("plan_facet_rows", plan_facet_rows_kernel<3>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
       else
       {
-        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(ne * nd), dim3(kBlock), 0,
                I.n_entities, I.entities.p, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
-        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(I.n_entities * nd), dim3(kBlock), 0,
+        launch("plan_mark_rows", plan_mark_rows_cells_kernel, grid_for(ne * nd), dim3(kBlock), 0,
                I.n_entities, I.entities.p + 2, 4, V->dofmap.p, nd, P.rowmark.p, special.p);
       }
-      o += I.n_entities;
+      o += ne;
     }
   }
   bool no_fold = false;
-  if (P.nfacets > 0 && nd > 4 && V->degree == 2)
+  if (nf_cap > 0 && nd > 4 && V->degree == 2)
   {
     // degree 2: the two cells of a facet share the facet's dofs (6 in 3-D, 3 in 2-D) when the space is continuous
     const int ns = V->mesh->tdim == 3 ? 6 : 3;
     if (nd == 10)
-      launch("plan_check_fold", plan_check_fold_kernel<10>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+      launch("plan_check_fold", plan_check_fold_kernel<10>, grid_for(nf_cap), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
              V->dofmap.p, nd - ns, flag.p);
     else if (nd == 6)
-      launch("plan_check_fold", plan_check_fold_kernel<6>, grid_for(P.nfacets), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
+      launch("plan_check_fold", plan_check_fold_kernel<6>, grid_for(nf_cap), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
              V->dofmap.p, nd - ns, flag.p);
     else
       no_fold = true;
   }
+  Count n_plain_all;
   {
     const int64_t ntiles = (V->ndofs + kByteTile - 1) / kByteTile;
     DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
     launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, tcounts.p);
     exclusive_scan(tcounts.p, toffs.p, ntiles);
-    // the row totals and the plan's flag word (every kernel that sets a flag has been launched) in one read-back
-    DevArray<int64_t> two(2);
-    launch("plan_row_lists", gather2_kernel, dim3(1), dim3(1), 0, toffs.p + ntiles, flag.p, two.p);
-    struct Two { int64_t v[2]; };
-    const Two tf = read_scalar(reinterpret_cast<const Two*>(two.p));
-    const int64_t totals = tf.v[0];
-    plan_flags = (int)tf.v[1];
-    const int64_t n_special = totals & 0xffffffffll, n_plain = totals >> 32;
+    // the row totals and the plan's flag word (every kernel that sets a flag has been launched) in one read-back --
+    // or, inside a step, left in HBM: the flag word (what the host branches on) must then repeat the last step's
+    const char* names[4] = {"plan.special_rows", "plan.plain_rows", "plan.active_rows", "plan.flags"};
+    CountSource src[4];
+    src[0].src = toffs.p + ntiles; src[0].kind = kCountLo32;
+    src[1].src = toffs.p + ntiles; src[1].kind = kCountHi32;
+    src[2].src = toffs.p + ntiles; src[2].kind = kCountSum32;
+    src[3].src = flag.p; src[3].kind = kCountI32; src[3].mode = kCountMustEqual;
+    Count tot[4];
+    count_sites(4, names, src, tot);
+    plan_flags = (int)tot[3].cap();
     const bool want_plain = space_stencil(V).lists;
-    if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: plan rows special %lld plain %lld of %lld dofs\n", (long long)n_special, (long long)n_plain, (long long)V->ndofs);
-    P.n_active_rows = n_special + n_plain;
-    P.n_special_rows = n_special;
-    P.n_plain_rows = want_plain ? n_plain : 0;
-    P.active_rows.alloc(P.n_active_rows);
-    P.special_rows.alloc(n_special);
-    if (want_plain) P.plain_rows.alloc(n_plain);
+    if (getenv("CFX_PLAN_DEBUG"))
+      fprintf(stderr, "cutfemx_amd: plan rows special %lld plain %lld of %lld dofs\n", (long long)tot[0].cap(),
+              (long long)tot[1].cap(), (long long)V->ndofs);
+    P.n_special_rows = tot[0];
+    n_plain_all = tot[1];
+    P.n_active_rows = tot[2];
+    P.n_plain_rows = want_plain ? tot[1] : Count(0);
+    // (the active list holds both classes: its capacity is the sum of theirs)
+    P.active_rows.alloc(tot[0].cap() + tot[1].cap());
+    P.special_rows.alloc(tot[0].cap());
+    if (want_plain) P.plain_rows.alloc(tot[1].cap());
     launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
-           special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr);
+           special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr,
+           tot[0].devn(), tot[1].devn());
     P.row_tile_counts = std::move(tcounts); // the inactive dofs of a tile are the rest (cfx_active_domain)
   }
   P.special_mark = std::move(special);
-  if (P.nfacets > 0)
+  const int64_t ns_cap = P.n_special_rows.cap();
+  if (nf_cap > 0)
   {
     // dof -> facets incidence of the rows that have facets (all of them special)
     P.special_pos.alloc(V->ndofs);
-    launch("plan_scatter_pos", plan_scatter_pos_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
+    launch("plan_scatter_pos", plan_scatter_pos_kernel, grid_for(ns_cap), dim3(kBlock), 0, P.n_special_rows,
            P.special_rows.p, P.special_pos.p);
     const char* fs = getenv("CFX_FACET_SORT");
-    const int64_t npairs = P.nfacets * 2 * nd;
-    if (!(fs && fs[0] == '0') && npairs < 2147483647LL && P.n_special_rows < 2147483647LL)
+    const int64_t npairs = nf_cap * 2 * nd;
+    if (!(fs && fs[0] == '0') && npairs < 2147483647LL && ns_cap < 2147483647LL)
     {
+      // (lengths still in HBM: the sort covers the capacity of the pair list, pairs behind the last facet carry the
+      // sentinel key = the capacity of the special-row list, which no row position reaches)
       DevArray<int32_t> keys(npairs), vals(npairs), keys_out(npairs);
       P.d2f.alloc(npairs); // the sorted values: the entries behind the last offset (sentinel keys) are never read
       launch("facet_dof_pairs", facet_dof_pairs_kernel, grid_for(npairs), dim3(kBlock), 0, P.nfacets, P.facet_rows.p,
-             V->dofmap.p, nd, P.special_pos.p, (int32_t)P.n_special_rows, keys.p, vals.p);
+             V->dofmap.p, nd, P.special_pos.p, (int32_t)ns_cap, keys.p, vals.p);
       int bits = 1;
-      while ((1ll << bits) <= P.n_special_rows) ++bits; // keys 0 .. n_special_rows (the sentinel)
+      while ((1ll << bits) <= ns_cap) ++bits; // keys 0 .. ns_cap (the sentinel)
       size_t tmp_bytes = 0;
       CFX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys.p, keys_out.p, vals.p, P.d2f.p, (size_t)npairs, 0, bits,
                                         ctx().stream));
       DevArray<uint8_t> tmp((int64_t)tmp_bytes);
       CFX_HIP(rocprim::radix_sort_pairs(tmp.p, tmp_bytes, keys.p, keys_out.p, vals.p, P.d2f.p, (size_t)npairs, 0, bits,
                                         ctx().stream));
-      P.d2f_offsets.alloc(P.n_special_rows + 1);
-      launch("facet_dof_offsets", sorted_key_offsets_kernel, grid_for(P.n_special_rows + 1), dim3(kBlock), 0,
+      P.d2f_offsets.alloc(ns_cap + 1);
+      launch("facet_dof_offsets", sorted_key_offsets_kernel, grid_for(ns_cap + 1), dim3(kBlock), 0,
              P.n_special_rows, npairs, keys_out.p, P.d2f_offsets.p);
       P.d2f_sorted = true;
     }
     else
     {
-    DevArray<int32_t> fcount(P.n_special_rows);
-    fcount.zero();
-    launch("facet_dof_count", facet_dof_count_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
-           P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
-    P.d2f_offsets.alloc(P.n_special_rows + 1);
-    exclusive_scan(fcount.p, P.d2f_offsets.p, P.n_special_rows);
-    const int64_t total = read_scalar(P.d2f_offsets.p + P.n_special_rows);
-    P.d2f.alloc(total);
-    fcount.zero();
-    launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(P.nfacets * 2 * nd), dim3(kBlock), 0, P.nfacets,
-           P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
+      const int64_t nse = P.n_special_rows.value(), nfe = P.nfacets.value(); // (count + fill: exact lengths)
+      DevArray<int32_t> fcount(nse);
+      fcount.zero();
+      launch("facet_dof_count", facet_dof_count_kernel, grid_for(nfe * 2 * nd), dim3(kBlock), 0, nfe,
+             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
+      P.d2f_offsets.alloc(nse + 1);
+      exclusive_scan(fcount.p, P.d2f_offsets.p, nse);
+      const int64_t total = read_scalar(P.d2f_offsets.p + nse);
+      P.d2f.alloc(total);
+      fcount.zero();
+      launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(nfe * 2 * nd), dim3(kBlock), 0, nfe,
+             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
     }
   }
   // rank structure of every uncut entity list: entity index of cell c =
@@ -1587,7 +1653,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   for (int slot = 0; slot < P.n_cell_slots; ++slot)
   {
     const cfx_integral_dev& I = a->integrals[P.cell_slot_integral[slot]];
-    if (I.n_entities == 0) continue;
+    if (I.n_entities.cap() == 0) continue;
     P.std_bits[slot].alloc(nwords);
     P.std_rank[slot].alloc(nwords + 1);
     DevArray<int32_t> pop(nwords);
@@ -1602,10 +1668,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     exclusive_scan(pop.p, P.std_rank[slot].p, nwords);
   }
   const char* det = getenv("CFX_DETERMINISTIC");
-  if (P.nfacets > 0 && det && det[0] == '1' && !P.d2f_sorted)
+  if (nf_cap > 0 && det && det[0] == '1' && !P.d2f_sorted)
   {
     // reproducible gather order (the lists were filled through an atomic cursor)
-    launch("plan_sort_d2f", seg_sort_kernel, grid_for(P.n_special_rows), dim3(kBlock), 0, P.n_special_rows,
+    launch("plan_sort_d2f", seg_sort_kernel, grid_for(ns_cap), dim3(kBlock), 0, P.n_special_rows,
            P.d2f_offsets.p, P.d2f.p);
   }
   // unsorted / repeated caller-supplied entity lists: the gather path cannot look them up
@@ -1732,22 +1798,24 @@ void plain_row_masks(cfx_form_s* a)
   plan.plain_masks_built = true;
   cfx_space_s* V = a->V;
   const Stencil& st = space_stencil(V);
-  if (!st.usable || plan.n_plain_rows == 0 || !plan.any_cells) return;
+  const int64_t np = plan.n_plain_rows.cap(); // (capacity of the list while its length is in HBM)
+  if (!st.usable || np == 0 || !plan.any_cells) return;
   const Adjacency& adj = V->dof_cells();
-  plan.plain_masks.alloc(plan.n_plain_rows);
-  plan.plain_uniform.alloc(plan.n_plain_rows);
+  plan.plain_masks.alloc(np);
+  plan.plain_uniform.alloc(np);
   launch("plan_plain_masks", plain_masks_kernel,
-         dim3((unsigned)((plan.n_plain_rows + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
+         dim3((unsigned)((np + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
          st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p);
   if (space_stencil_tiles(V).tiles_usable)
   {
     // work list of the tile kernels: one entry per row tile that holds a plain row
     DevArray<int32_t> first;
-    plan.n_plain_tiles = compact("plan_plain_tiles", plan.n_plain_rows, TileStart{plan.plain_rows.p}, first);
+    plan.n_plain_tiles = compact_count("plan_plain_tiles", "plan.plain_tiles", plan.n_plain_rows.devn(),
+                                       TileStart{plan.plain_rows.p}, first);
     plan.plain_tile_first = std::move(first);
-    plan.plain_tile_id.alloc(plan.n_plain_tiles);
-    launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles), dim3(kBlock), 0, plan.n_plain_tiles,
+    plan.plain_tile_id.alloc(plan.n_plain_tiles.cap());
+    launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles.cap()), dim3(kBlock), 0, plan.n_plain_tiles,
            plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
   }
   publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
@@ -1778,6 +1846,7 @@ void plan_cut_cells(cfx_form_s* a)
   plan.cut_cells_built = true;
   const int64_t nc = a->V->mesh->ncells;
   plan.n_cut_cells = compact_bytes("plan_cut_cells", nc, plan.cellmark.p, ByteRuleMark{}, plan.cut_cells);
+  const int64_t n_cut_cells = plan.n_cut_cells;
   const int64_t nwords = (nc + 63) / 64;
   plan.cut_bits.alloc(nwords);
   plan.cut_rank.alloc(nwords + 1);
@@ -1788,10 +1857,11 @@ void plan_cut_cells(cfx_form_s* a)
   for (int slot = 0; slot < plan.n_cell_slots; ++slot)
   {
     const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[slot]];
-    if (!I.rules || I.rules->nr == 0 || plan.n_cut_cells == 0) continue;
-    plan.cut_first[slot].alloc(plan.n_cut_cells);
-    dev_fill(plan.cut_first[slot].p, 0xff, sizeof(int32_t) * (size_t)plan.n_cut_cells);
-    launch("plan_cut_cells", plan_cut_first_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr, I.rules->parent_map.p,
+    const int64_t nrl = I.rules ? I.rules->nr.value() : 0;
+    if (nrl == 0 || n_cut_cells == 0) continue;
+    plan.cut_first[slot].alloc(n_cut_cells);
+    dev_fill(plan.cut_first[slot].p, 0xff, sizeof(int32_t) * (size_t)n_cut_cells);
+    launch("plan_cut_cells", plan_cut_first_kernel, grid_for(nrl), dim3(kBlock), 0, nrl, I.rules->parent_map.p,
            reinterpret_cast<const unsigned long long*>(plan.cut_bits.p), plan.cut_rank.p, plan.cut_first[slot].p);
   }
   publish_across_lanes();
@@ -1799,18 +1869,24 @@ void plan_cut_cells(cfx_form_s* a)
 
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:
 // rows at the edge of a restricted entity list, e.g. a rank's owned cells, keep the per-cell records)
-__global__ void vec_plain_len_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
+__global__ void vec_plain_len_kernel(DevN n_plain_d, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
                                      const uint8_t* __restrict__ uniform, uint8_t mark, int32_t* __restrict__ len)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_plain) return;
+  if (i >= n_plain)
+  {
+    if (i < n_plain_d.cap) len[i] = 0; // (the scan runs over the capacity of the list)
+    return;
+  }
   const int64_t r = rows[i];
   len[i] = uniform[i] == mark ? (int32_t)(d2c_off[r + 1] - d2c_off[r]) : 0;
 }
 
-__global__ void vec_plain_scatter_kernel(int64_t n_plain, const int32_t* __restrict__ rows, const int64_t* __restrict__ off,
+__global__ void vec_plain_scatter_kernel(DevN n_plain_d, const int32_t* __restrict__ rows, const int64_t* __restrict__ off,
                                          int32_t* __restrict__ t2off)
 {
+  const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_plain && off[i + 1] > off[i]) t2off[rows[i]] = (int32_t)off[i];
 }
@@ -1821,9 +1897,10 @@ struct LenIsZero
   __device__ bool operator()(int64_t i) const { return len[i] == 0; }
 };
 
-__global__ void gather_i32_kernel(int64_t n, const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
+__global__ void gather_i32_kernel(DevN n_d, const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
                                   int32_t* __restrict__ dst)
 {
+  const int64_t n = dev_n(n_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[idx[i]];
 }
@@ -1833,6 +1910,17 @@ __global__ void gather_i32_kernel(int64_t n, const int32_t* __restrict__ idx, co
 // `mark` (always so for the volume terms of a single-level-set problem: a vertex without a cut cell around it
 // has only inside cells around it; not so at the edge of a restricted entity list).  False: no such row, the
 // caller keeps the per-cell staging for all rows.
+// the rows that read the per-cell records: [the special rows | the plain rows listed by position in `idx`]
+__global__ void __launch_bounds__(kBlock) concat_rows_kernel(DevN n_a_d, const int32_t* __restrict__ a, DevN n_b_d,
+                                                             const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
+                                                             int32_t* __restrict__ out)
+{
+  const int64_t n_a = dev_n(n_a_d), n_b = dev_n(n_b_d);
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < n_a) out[i] = a[i];
+  else if (i - n_a < n_b) out[i] = src[idx[i - n_a]];
+}
+
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
 {
   cfx_row_plan& plan = row_plan(L);
@@ -1841,34 +1929,33 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   plan.vec_fast = 0;
   cfx_space_s* V = L->V;
   const Stencil& st = space_stencil(V);
-  if (!st.usable || plan.n_plain_rows == 0 || !plan.any_cells) return false;
+  const int64_t n = plan.n_plain_rows.cap(); // (capacity while the length is in HBM)
+  if (!st.usable || n == 0 || !plan.any_cells) return false;
   plain_row_masks(L);
-  if (plan.plain_uniform.n != plan.n_plain_rows) return false;
+  if (plan.plain_uniform.n != n) return false;
   const Adjacency& adj = V->dof_cells();
-  const int64_t n = plan.n_plain_rows;
   DevArray<int32_t> len(n);
   DevArray<int64_t> off(n + 1);
-  launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, adj.offsets.p,
-         plan.plain_uniform.p, mark, len.p);
+  launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
+         adj.offsets.p, plan.plain_uniform.p, mark, len.p);
   exclusive_scan(len.p, off.p, n);
-  const int64_t total = read_scalar(off.p + n);
-  if (total == 0 || total >= 2147483647LL) return false;
+  // (inside a step the total stays in HBM; "no such row" / "too many entries" are the recorded step's answers)
+  const Count total = count_site("vec.segment_entries", off.p + n);
+  if (total.cap() == 0 || total.cap() >= 2147483647LL) return false;
   plan.vec_t2off.alloc(V->ndofs);
   dev_fill(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs);
-  launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, n, plan.plain_rows.p, off.p,
-         plan.vec_t2off.p);
+  launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
+         off.p, plan.vec_t2off.p);
   // everything else (the rows next to the interface, plain rows that are not uniform) reads the per-cell records
   // = the special rows, then the plain rows without a segment (the order of this list is free)
   DevArray<int32_t> odd;
-  const int64_t n_odd = compact("vec_plain_offsets", n, LenIsZero{len.p}, odd);
-  plan.n_vec_slow_rows = plan.n_special_rows + n_odd;
-  plan.vec_slow_rows.alloc(plan.n_vec_slow_rows);
-  if (plan.n_special_rows > 0)
-    CFX_HIP(hipMemcpyAsync(plan.vec_slow_rows.p, plan.special_rows.p, sizeof(int32_t) * (size_t)plan.n_special_rows,
-                           hipMemcpyDeviceToDevice, ctx().stream));
-  if (n_odd > 0)
-    launch("vec_plain_offsets", gather_i32_kernel, grid_for(n_odd), dim3(kBlock), 0, n_odd, odd.p, plan.plain_rows.p,
-           plan.vec_slow_rows.p + plan.n_special_rows);
+  const Count n_odd = compact_count("vec_plain_offsets", "vec.odd_rows", plan.n_plain_rows.devn(), LenIsZero{len.p}, odd);
+  plan.n_vec_slow_rows = count_sum("vec.slow_rows", plan.n_special_rows, n_odd);
+  const int64_t cap_slow = plan.n_special_rows.cap() + n_odd.cap();
+  plan.vec_slow_rows.alloc(cap_slow);
+  if (cap_slow > 0)
+    launch("vec_plain_offsets", concat_rows_kernel, grid_for(cap_slow), dim3(kBlock), 0, plan.n_special_rows.devn(),
+           plan.special_rows.p, n_odd.devn(), odd.p, plan.plain_rows.p, plan.vec_slow_rows.p);
   plan.vec_t2_total = total;
   plan.vec_fast = 1;
   publish_across_lanes();
@@ -2113,10 +2200,11 @@ void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
   for (const auto& I : a->integrals)
   {
     require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "forms with different test and trial spaces take cell integrals");
-    if (I.n_entities > 0)
-      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(I.n_entities), dim3(kBlock), 0, I.n_entities, I.entities.p, mark.p);
-    if (I.rules && I.rules->nr > 0)
-      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(I.rules->nr), dim3(kBlock), 0, I.rules->nr, I.rules->parent_map.p,
+    const int64_t ne = I.n_entities.value(), nrl = I.rules ? I.rules->nr.value() : 0; // (rectangular blocks: exact lengths)
+    if (ne > 0)
+      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(ne), dim3(kBlock), 0, ne, I.entities.p, mark.p);
+    if (nrl > 0)
+      launch("pattern2_mark", mark_cells_u8_kernel, grid_for(nrl), dim3(kBlock), 0, nrl, I.rules->parent_map.p,
              mark.p);
   }
   const Adjacency& adj = V0->dof_cells();
@@ -2134,11 +2222,12 @@ void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
   P->max_row_len = std::max(read_scalar(maxlen.p), 1);
   P->indptr.alloc(P->nrows + 1);
   exclusive_scan(counts.p, P->indptr.p, P->nrows);
-  P->nnz = read_scalar(P->indptr.p + P->nrows);
-  P->indices.alloc(P->nnz);
+  const int64_t nnz2 = read_scalar(P->indptr.p + P->nrows);
+  P->nnz = nnz2;
+  P->indices.alloc(nnz2);
   S.indptr = P->indptr.p; S.indices = P->indices.p;
   launch("pattern2_rows_write", pattern_rows_kernel<64, 512>, wave_grid(V0->ndofs), dim3(kWave), 0, S);
-  P->stencil_plan = 0; P->split_plan = 0; P->full_plan = 0; P->odd_plan = 0;
+  P->built_plan = 0; P->stencil_plan = 0; P->split_plan = 0; P->full_plan = 0; P->odd_plan = 0;
 }
 
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
@@ -2149,10 +2238,16 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   const Stencil& st = space_stencil(V);
   // plain rows (uncut-cell items only) are subsets of the static stencil: mask + popcount;
   // the hash-set path then only sees the rows next to the interface
-  const bool use_stencil = st.usable && plan.n_plain_rows > 0 && plan.any_cells;
+  const bool use_stencil = st.usable && plan.n_plain_rows.cap() > 0 && plan.any_cells;
   // lists only (degree 2, vector, DG spaces): the plain rows whose cells are all marked copy their static list
-  const bool use_lists = !st.usable && st.lists && plan.n_plain_rows > 0 && plan.any_cells;
-  int64_t n_h = use_stencil ? plan.n_special_rows : plan.n_active_rows;
+  const bool use_lists = !st.usable && st.lists && plan.n_plain_rows.cap() > 0 && plan.any_cells;
+  // Row counts that are still in HBM (plan built inside a sync-free step) stay there on the stencil path (P1 on the
+  // geometry dofmap), whose kernels take their lengths from the device; the other paths size host-side work by the
+  // counts and read them back first.
+  const Count n_h_c = use_stencil ? plan.n_special_rows : Count(plan.n_active_rows.value());
+  if (!use_stencil) { (void)plan.n_special_rows.value(); (void)plan.n_plain_rows.value(); }
+  int64_t n_h = n_h_c.cap();
+  const int64_t n_special_x = plan.n_special_rows.cap(), n_plain_x = plan.n_plain_rows.cap(); // exact off the stencil path
   const int32_t* rows_h = use_stencil ? plan.special_rows.p : plan.active_rows.p;
   P->nrows = V->ndofs * V->bs;
   P->ncols = P->nrows;
@@ -2164,32 +2259,32 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   {
     const Adjacency& adj = V->dof_cells();
     constexpr int G = 4;
-    full.alloc(plan.n_plain_rows);
-    launch("pattern_plain_full", plain_full_kernel<G>, dim3((unsigned)((plan.n_plain_rows + kWave / G - 1) / (kWave / G))),
-           dim3(kWave), 0, plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, plan.cellmark.p, st.offsets.p,
+    full.alloc(n_plain_x);
+    launch("pattern_plain_full", plain_full_kernel<G>, dim3((unsigned)((n_plain_x + kWave / G - 1) / (kWave / G))),
+           dim3(kWave), 0, n_plain_x, plan.plain_rows.p, adj.offsets.p, adj.cells.p, plan.cellmark.p, st.offsets.p,
            V->bs, full.p, counts.p);
     DevArray<int32_t> odd;
-    const int64_t n_odd = compact("pattern_plain_full", plan.n_plain_rows, FlagIsZero{full.p}, odd);
-    any_full = n_odd < plan.n_plain_rows;
-    n_h = plan.n_special_rows + n_odd;
+    const int64_t n_odd = compact("pattern_plain_full", n_plain_x, FlagIsZero{full.p}, odd);
+    any_full = n_odd < n_plain_x;
+    n_h = n_special_x + n_odd;
     hashed.alloc(n_h);
-    if (plan.n_special_rows > 0)
-      CFX_HIP(hipMemcpyAsync(hashed.p, plan.special_rows.p, sizeof(int32_t) * (size_t)plan.n_special_rows,
+    if (n_special_x > 0)
+      CFX_HIP(hipMemcpyAsync(hashed.p, plan.special_rows.p, sizeof(int32_t) * (size_t)n_special_x,
                              hipMemcpyDeviceToDevice, ctx().stream));
     if (n_odd > 0)
       launch("pattern_plain_full", gather_i32_kernel, grid_for(n_odd), dim3(kBlock), 0, n_odd, odd.p, plan.plain_rows.p,
-             hashed.p + plan.n_special_rows);
+             hashed.p + n_special_x);
     rows_h = hashed.p;
   }
   PatArgs S{};
-  S.n_active = n_h; S.active_rows = rows_h;
+  S.n_active = use_stencil ? n_h_c.devn() : DevN(n_h); S.active_rows = rows_h;
   S.nd = V->ndofs_cell; S.bs = V->bs; S.dofmap = V->dofmap.p;
   if (plan.any_cells)
   {
     const Adjacency& adj = V->dof_cells();
     S.d2c_off = adj.offsets.p; S.d2c = adj.cells.p; S.cellmark = plan.cellmark.p;
   }
-  if (plan.nfacets > 0)
+  if (plan.nfacets.cap() > 0)
   {
     S.d2f_off = plan.d2f_offsets.p; S.d2f = plan.d2f.p; S.facet_rows = plan.facet_rows.p;
     S.special_mark = plan.special_mark.p; S.special_pos = plan.special_pos.p;
@@ -2237,10 +2332,10 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = staged_sets ? tmp_short.p : nullptr;
     S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = staged_sets ? tmp_long.p : nullptr; S2.len = len.p + n_short;
     // rows_h = [the plan's special rows in plan order | other rows]: the position in rows_h is the facet-incidence index
-    if (rows_h == hashed.p && plan.nfacets > 0)
+    if (rows_h == hashed.p && plan.nfacets.cap() > 0)
     {
-      S1.row_pos = short_idx.p; S1.n_first = plan.n_special_rows;
-      if (n_long > 0) { S2.row_pos = long_idx.p; S2.n_first = plan.n_special_rows; }
+      S1.row_pos = short_idx.p; S1.n_first = n_special_x;
+      if (n_long > 0) { S2.row_pos = long_idx.p; S2.n_first = n_special_x; }
     }
     if (n_short > 0) launch("pattern_rows_short", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
     if (n_long > 0) launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
@@ -2278,6 +2373,8 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       maxlen.zero();
       tmp.release();
       S.tmp = nullptr;
+      S.n_active = DevN(n_h_c.value());
+      n_h = S.n_active.cap;
       launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_h), dim3(kWave), 0, S);
       require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 511 dofs");
     }
@@ -2285,10 +2382,10 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   if (use_stencil)
   {
     plain_row_masks(a);
-    launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows), dim3(kBlock), 0, plan.n_plain_rows,
+    launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows.cap()), dim3(kBlock), 0, plan.n_plain_rows,
            plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
   }
-  if (!deferred) P->max_row_len = plan.n_active_rows > 0 ? read_scalar(maxlen.p) : 1;
+  if (!deferred) P->max_row_len = plan.n_active_rows.cap() > 0 ? read_scalar(maxlen.p) : 1;
   if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list
   if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: pattern max row length %d (static lists %d)\n", P->max_row_len, st.max_len);
   P->indptr.alloc(P->nrows + 1);
@@ -2300,38 +2397,43 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     exclusive_scan(sums.p, offs.p, ntiles);
     if (deferred)
     {
-      DevArray<int64_t> three(3);
-      launch("pattern_indptr", gather3_kernel, dim3(1), dim3(1), 0, overflow.p, maxlen.p, offs.p + ntiles, three.p);
-      struct Three { int64_t v[3]; };
-      const Three t = read_scalar(reinterpret_cast<const Three*>(three.p));
-      if (t.v[0] != 0)
+      // overflow flag, longest row and nnz in one round trip -- or, inside a step, none: nnz stays in HBM, the flag
+      // has to repeat the last step's answer and the longest row its size class (what the host picks kernels by)
+      const char* names[3] = {"pattern.overflow", "pattern.max_row_len", "pattern.nnz"};
+      CountSource src[3];
+      src[0].src = overflow.p; src[0].kind = kCountI32; src[0].mode = kCountMustEqual;
+      src[1].src = maxlen.p; src[1].kind = kCountI32; src[1].mode = kCountSizeClass;
+      src[2].src = offs.p + ntiles; src[2].kind = kCountI64;
+      Count t[3];
+      count_sites(3, names, src, t);
+      if (t[0].cap() != 0)
       {
         V->long_rows = true; // rows beyond 63 columns: build again, wide
         build_pattern(a, P);
         return;
       }
-      P->max_row_len = std::max((int)t.v[1], 1);
-      P->nnz = t.v[2];
+      P->max_row_len = std::max((int)t[1].cap(), 1);
+      P->nnz = t[2];
     }
     else
-      P->nnz = read_scalar(offs.p + ntiles);
-    P->indices.alloc(P->nnz);
+      P->nnz = Count(read_scalar(offs.p + ntiles));
+    P->indices.alloc(P->nnz.cap());
     launch("pattern_indptr", indptr_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
-           counts.p, offs.p, P->indptr.p, P->indices.p);
+           counts.p, offs.p, P->indptr.p, P->indices.p, P->nnz.devn());
   }
-  if (use_stencil && space_stencil_tiles(V).tiles_usable && plan.n_plain_tiles > 0)
-    launch("pattern_plain_write", pattern_plain_tiles_kernel, wave_grid(plan.n_plain_tiles), dim3(kWave), 0, plan.n_plain_tiles,
+  if (use_stencil && space_stencil_tiles(V).tiles_usable && plan.n_plain_tiles.cap() > 0)
+    launch("pattern_plain_write", pattern_plain_tiles_kernel, wave_grid(plan.n_plain_tiles.cap()), dim3(kWave), 0, plan.n_plain_tiles,
            plan.plain_tile_first.p, plan.plain_tile_id.p, plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p,
            st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p, V->ndofs);
   else if (use_stencil)
-    launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows * CFX_PPW_LANES), dim3(kBlock), 0,
+    launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows.cap() * CFX_PPW_LANES), dim3(kBlock), 0,
            plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
   if (any_full && V->bs == 1)
-    launch("pattern_plain_write", pattern_plain_copy_runs_kernel, wave_grid((plan.n_plain_rows + kWave - 1) / kWave), dim3(kWave), 0,
-           plan.n_plain_rows, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
+    launch("pattern_plain_write", pattern_plain_copy_runs_kernel, wave_grid((n_plain_x + kWave - 1) / kWave), dim3(kWave), 0,
+           n_plain_x, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
   else if (any_full)
-    launch("pattern_plain_write", pattern_plain_copy_kernel<8>, grid_for(plan.n_plain_rows * 8), dim3(kBlock), 0,
-           plan.n_plain_rows, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, V->bs, P->indptr.p, P->indices.p);
+    launch("pattern_plain_write", pattern_plain_copy_kernel<8>, grid_for(n_plain_x * 8), dim3(kBlock), 0,
+           n_plain_x, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, V->bs, P->indptr.p, P->indices.p);
   if (split_hashed && staged_sets)
   {
     if (n_short > 0)
@@ -2352,7 +2454,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   else if (n_h > 0)
   {
     if (T == 64)
-      launch("pattern_write", pattern_write_kernel<64>, grid_for(n_h * 8), dim3(kBlock), 0, n_h, rows_h, V->bs, tmp.p,
+      launch("pattern_write", pattern_write_kernel<64>, grid_for(n_h * 8), dim3(kBlock), 0, S.n_active, rows_h, V->bs, tmp.p,
              len.p, P->indptr.p, P->indices.p);
     else
     {
@@ -2378,6 +2480,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     }
     P->n_full_short = ns;
   };
+  P->built_plan = plan.serial;
   P->stencil_plan = use_stencil ? plan.serial : 0;
   // spaces with long rows (degree 2): the gather assembly runs the short rows 8 lanes per row
   P->split_plan = 0;
@@ -2389,11 +2492,11 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     // assemble_rows_block_plain_kernel, the other active rows keep the searching block kernel
     int n_std = 0;
     for (const auto& I : a->integrals)
-      if (I.type == CFX_CELL && I.n_entities > 0) ++n_std;
+      if (I.type == CFX_CELL && I.n_entities.cap() > 0) ++n_std;
     if (n_std == 1 && space_stencil_slotn(V).slotn_ok)
     {
       DevArray<int32_t> pos;
-      P->n_full_rows = compact("pattern_full_rows", plan.n_plain_rows, FlagSet8{full.p}, pos);
+      P->n_full_rows = compact("pattern_full_rows", n_plain_x, FlagSet8{full.p}, pos);
       P->full_rows.alloc(P->n_full_rows);
       launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
              plan.plain_rows.p, P->full_rows.p);
@@ -2405,18 +2508,18 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       P->full_plan = plan.serial;
     }
   }
-  if (P->max_row_len > 64 && V->bs == 1 && plan.n_active_rows > 0)
+  if (P->max_row_len > 64 && V->bs == 1 && plan.n_active_rows.cap() > 0)
   {
     // degree 2 with slot records, one uncut stiffness integral: the copied rows get their own gather kernel
     // (assemble_rows_p2_plain_kernel); the split below then covers the other active rows only
     const int32_t* base_rows = plan.active_rows.p;
-    int64_t n_base = plan.n_active_rows;
+    int64_t n_base = plan.n_active_rows.value();
     if (any_full && V->degree == 2)
     {
       int n_std = 0;
       bool closed = true;
       for (const auto& I : a->integrals)
-        if (I.type == CFX_CELL && I.n_entities > 0)
+        if (I.type == CFX_CELL && I.n_entities.cap() > 0)
         {
           ++n_std;
           closed = closed && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0;
@@ -2425,7 +2528,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       if (n_std == 1 && closed && a->rank == 2 && !(cf && cf[0] == '0') && space_stencil_slotn(V).slotn_ok)
       {
         DevArray<int32_t> pos;
-        P->n_full_rows = compact("pattern_full_rows", plan.n_plain_rows, FlagSet8{full.p}, pos);
+        P->n_full_rows = compact("pattern_full_rows", n_plain_x, FlagSet8{full.p}, pos);
         P->full_rows.alloc(P->n_full_rows);
         launch("pattern_full_rows", gather_i32_kernel, grid_for(P->n_full_rows), dim3(kBlock), 0, P->n_full_rows, pos.p,
                plan.plain_rows.p, P->full_rows.p);
@@ -2433,10 +2536,10 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
         base_rows = rows_h;
         n_base = n_h;
         // rows_h = [interface rows | plain rows without a copied list]: the second part on its own
-        P->n_odd_rows = n_h - plan.n_special_rows;
+        P->n_odd_rows = n_h - n_special_x;
         P->odd_rows.alloc(P->n_odd_rows);
         if (P->n_odd_rows > 0)
-          CFX_HIP(hipMemcpyAsync(P->odd_rows.p, rows_h + plan.n_special_rows, sizeof(int32_t) * (size_t)P->n_odd_rows,
+          CFX_HIP(hipMemcpyAsync(P->odd_rows.p, rows_h + n_special_x, sizeof(int32_t) * (size_t)P->n_odd_rows,
                                  hipMemcpyDeviceToDevice, ctx().stream));
         P->odd_plan = plan.serial;
       }

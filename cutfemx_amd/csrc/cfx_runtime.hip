@@ -128,6 +128,312 @@ int64_t& sync_counter()
   return n;
 }
 
+// ---------------------------------------------------------------------------
+// counts in HBM / sync-free steps (see cfx_common.h)
+// ---------------------------------------------------------------------------
+namespace
+{
+struct StepHistory
+{
+  std::vector<std::string> names;
+  std::vector<int64_t> values;
+  bool valid = false;
+};
+struct StepState
+{
+  bool active = false, spec = false, mismatch = false;
+  std::string key;
+  size_t cursor = 0;                 // next site of the step
+  std::vector<std::string> names;    // this step's sites ...
+  std::vector<int64_t> values;       // ... and their raw totals (filled at the read-back for published sites)
+  struct Pending { std::shared_ptr<CountCell> cell; size_t index; };
+  std::vector<Pending> pending;
+  struct Err { int entry; int code; std::string message; void (*decode)(int); };
+  std::vector<Err> errors;
+  struct Positive { std::shared_ptr<CountCell> cell; int code; std::string message; };
+  std::vector<Positive> positives;
+  int next_err = 1, next_slot = kCountFirstSlot;
+  int64_t published = 0, read_back = 0; // sites of this step by kind (diagnostics)
+};
+StepState& step()
+{
+  static StepState s;
+  return s;
+}
+std::map<std::string, StepHistory>& histories()
+{
+  static std::map<std::string, StepHistory> h;
+  return h;
+}
+bool step_debug()
+{
+  static const bool on = getenv("CFX_STEP_DEBUG") != nullptr;
+  return on;
+}
+double g_margin = 1.125;   // capacity = previous count x margin + slack
+int64_t g_slack = 256;
+
+int64_t* count_pool()
+{
+  // aligned to its size, so that the poison word is the base of any slot address (dev_n)
+  static int64_t* pool = []() {
+    void* raw = nullptr;
+    CFX_HIP(hipMalloc(&raw, 2 * kCountPoolBytes));
+    const uintptr_t a = (reinterpret_cast<uintptr_t>(raw) + kCountPoolBytes - 1) & ~(kCountPoolBytes - 1);
+    CFX_HIP(hipMemset(reinterpret_cast<void*>(a), 0, kCountPoolBytes));
+    return reinterpret_cast<int64_t*>(a);
+  }();
+  return pool;
+}
+int64_t* count_mirror()
+{
+  static int64_t* h = []() {
+    void* q = nullptr;
+    CFX_HIP(hipHostMalloc(&q, kCountPoolBytes, hipHostMallocDefault));
+    return static_cast<int64_t*>(q);
+  }();
+  return h;
+}
+
+constexpr int kMaxCountJobs = 6;
+struct CountJobs
+{
+  int n;
+  const void* src[kMaxCountJobs];
+  int kind[kMaxCountJobs];
+  int mode[kMaxCountJobs];
+  const int64_t* plus[kMaxCountJobs];
+  int64_t add[kMaxCountJobs];
+  int64_t cap[kMaxCountJobs];
+  int slot[kMaxCountJobs];
+};
+__device__ __forceinline__ int64_t count_read(const void* src, int kind)
+{
+  int64_t v;
+  if (src == nullptr) return 0;
+  if (kind == kCountI32) v = *static_cast<const int32_t*>(src);
+  else
+  {
+    v = *static_cast<const int64_t*>(src);
+    if (kind == kCountPackedLo) v &= (1ll << kCountPackShift) - 1;
+    else if (kind == kCountPackedHi) v >>= kCountPackShift;
+    else if (kind == kCountLo32) v &= 0xffffffffll;
+    else if (kind == kCountHi32) v >>= 32;
+    else if (kind == kCountSum32) v = (v & 0xffffffffll) + (v >> 32);
+  }
+  return v;
+}
+// speculative step: raw total next to the published one; a total beyond its capacity poisons the step
+__global__ void count_publish_kernel(CountJobs J, int64_t* pool)
+{
+  const int k = threadIdx.x;
+  if (k >= J.n) return;
+  const int64_t raw = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
+  pool[2 * J.slot[k] + 1] = raw;
+  const bool bad = J.mode[k] == kCountMustEqual ? raw != J.cap[k] : raw > J.cap[k];
+  if (bad) pool[0] = 1;
+  // (totals published after the poison word was set are seen as 0 by dev_n anyway)
+  pool[2 * J.slot[k]] = bad ? 0 : raw;
+}
+// read-back path: the totals side by side for one copy
+__global__ void count_gather_kernel(CountJobs J, int64_t* out)
+{
+  const int k = threadIdx.x;
+  if (k < J.n) out[k] = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
+}
+} // namespace
+
+CountCell::~CountCell() = default;
+
+int64_t Count::value() const
+{
+  if (!cell) return exact_n;
+  if (!cell->resolved)
+  {
+    cell->value = read_scalar(count_pool() + 2 * cell->slot);
+    cell->resolved = true;
+  }
+  return cell->value;
+}
+
+DevN Count::devn() const
+{
+  if (!cell) return DevN(exact_n);
+  if (cell->resolved) return DevN(cell->value);
+  return DevN(cell->cap, count_pool() + 2 * cell->slot);
+}
+
+namespace
+{
+std::map<const void*, Count>& list_registry()
+{
+  static std::map<const void*, Count> m;
+  return m;
+}
+} // namespace
+void list_register(const void* p, const Count& c) { if (p && c.cell) list_registry()[p] = c; }
+void list_unregister(const void* p) { list_registry().erase(p); }
+Count list_lookup(const void* p, int64_t n_given)
+{
+  auto it = list_registry().find(p);
+  if (it == list_registry().end()) return Count(n_given);
+  // the caller passes back what the ABI gave it: the capacity while the step was open, the exact length afterwards;
+  // a shorter prefix of a resolved list is the caller's own choice
+  const Count& c = it->second;
+  if (n_given == c.cap() || (c.cell && n_given == c.cell->cap)) return c;
+  if (!c.pending() && n_given <= c.cap()) return Count(n_given);
+  throw Error(CFX_ERR_INVALID_ARGUMENT, "a list whose length is still in HBM (open cfx_step) was passed back with another "
+                                        "count: pass the count the library returned, or end the step first");
+}
+
+ErrorFlag::ErrorFlag(int code, const char* message, void (*decode)(int))
+{
+  p = step_error_flag(code, message, decode);
+  deferred = p != nullptr;
+  if (!p) p = zero_flag();
+}
+void ErrorFlag::check(int code, const char* message) const
+{
+  if (deferred) return;
+  require(!read_scalar(p), code, message);
+}
+int64_t count_for_buffer(const Count& c, const void* user) { return is_device_pointer(user) ? c.cap() : c.value(); }
+void end_of_call_sync()
+{
+  if (step().active) return;
+  CFX_HIP(hipStreamSynchronize(ctx().stream));
+}
+
+Count count_sum(const char* name, const Count& a, const Count& b)
+{
+  if (!a.pending() && !b.pending())
+  {
+    const int64_t v = a.cap() + b.cap();
+    step_record(name, v);
+    return Count(v);
+  }
+  const DevN da = a.devn(), db = b.devn();
+  CountSource s;
+  s.src = da.dev; s.kind = kCountI64; s.plus = db.dev;
+  s.add = (da.dev ? 0 : da.cap) + (db.dev ? 0 : db.cap);
+  Count c;
+  count_sites(1, &name, &s, &c);
+  return c;
+}
+
+void step_record(const char* name, int64_t value)
+{
+  StepState& st = step();
+  if (!st.active) return;
+  st.names.push_back(name);
+  st.values.push_back(value);
+  if (step_debug()) fprintf(stderr, "cutfemx_amd: step site %s recorded: %lld\n", name, (long long)value);
+  ++st.cursor;
+  ++st.read_back;
+}
+void step_require_positive(const Count& c, int code, const char* message)
+{
+  if (c.pending() && step().active) { step().positives.push_back({c.cell, code, message}); return; }
+  require(c.value() > 0, code, message);
+}
+
+int error_in_step(int code)
+{
+  StepState& st = step();
+  if (!st.active || !st.spec || code == CFX_ERR_STEP_VOID) return code;
+  int64_t poison = 0;
+  if (hipMemcpy(&poison, count_pool(), sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return code;
+  if (poison == 0) return code;
+  g_last_error = "the step is void (a count did not fit the capacity taken from the previous step): end it and repeat it"
+                 " [while void: " + g_last_error + "]";
+  return CFX_ERR_STEP_VOID;
+}
+
+bool step_speculative() { return step().active && step().spec && !ctx().overlap; }
+const int64_t* step_poison() { return step_speculative() ? count_pool() : nullptr; }
+
+int* step_error_flag(int code, const char* message, void (*decode)(int))
+{
+  StepState& st = step();
+  if (!st.active || ctx().overlap || st.next_err >= kCountFirstSlot) return nullptr;
+  const int e = st.next_err++;
+  st.errors.push_back({e, code, message, decode});
+  return reinterpret_cast<int*>(count_pool() + 2 * e); // (entries 0..kCountFirstSlot-1 were zeroed by cfx_step_begin)
+}
+
+void count_sites(int n, const char* const* names, const CountSource* src, Count* out)
+{
+  require(n >= 1 && n <= kMaxCountJobs, CFX_ERR_RUNTIME, "count_sites: too many sites in one call");
+  StepState& st = step();
+  CountJobs J{};
+  J.n = n;
+  bool plain = true;
+  for (int k = 0; k < n; ++k)
+  {
+    J.src[k] = src[k].src; J.kind[k] = src[k].kind; J.mode[k] = src[k].mode; J.plus[k] = src[k].plus; J.add[k] = src[k].add;
+    plain = plain && src[k].src && !src[k].plus && src[k].add == 0;
+  }
+  bool publish = step_speculative() && st.next_slot + n <= kCountEntries;
+  if (publish)
+  {
+    const StepHistory& h = histories()[st.key];
+    for (int k = 0; k < n; ++k)
+      publish = publish && st.cursor + k < h.names.size() && h.names[st.cursor + k] == names[k];
+    if (!publish) st.mismatch = true; // another call sequence than last time: this step's record replaces the history
+  }
+  if (publish)
+  {
+    const StepHistory& h = histories()[st.key];
+    for (int k = 0; k < n; ++k)
+    {
+      const int64_t prev = h.values[st.cursor + k];
+      auto cell = std::make_shared<CountCell>();
+      cell->slot = st.next_slot++;
+      // (a list that was empty stays empty or the step is void: the host then takes the branches of the recorded step)
+      if (J.mode[k] == kCountSizeClass)
+        cell->cap = prev <= 32 ? 32 : (prev <= 64 ? 64 : (prev <= 128 ? 128 : (prev <= 256 ? 256 : 512)));
+      else
+        cell->cap = (J.mode[k] == kCountMustEqual || prev == 0) ? prev : (int64_t)((double)prev * g_margin) + g_slack;
+      cell->resolved = false;
+      cell->hint = prev;
+      J.cap[k] = cell->cap; J.slot[k] = cell->slot;
+      out[k].cell = cell;
+      out[k].exact_n = 0;
+      st.pending.push_back({cell, st.names.size()});
+      st.names.push_back(names[k]);
+      st.values.push_back(0);
+    }
+    if (step_debug())
+      for (int k = 0; k < n; ++k)
+        fprintf(stderr, "cutfemx_amd: step site %s published, capacity %lld (previous %lld)\n", names[k], (long long)J.cap[k], (long long)out[k].cell->hint);
+    st.cursor += n;
+    st.published += n;
+    launch("count_publish", count_publish_kernel, dim3(1), dim3(64), 0, J, count_pool());
+    return;
+  }
+  int64_t v[kMaxCountJobs];
+  if (n == 1 && plain && J.kind[0] == kCountI64)
+    v[0] = read_scalar(static_cast<const int64_t*>(J.src[0]));
+  else if (n == 1 && plain && J.kind[0] == kCountI32)
+    v[0] = read_scalar(static_cast<const int32_t*>(J.src[0]));
+  else
+  {
+    // (the staging words live past the slots of any step: the last entries of the pool)
+    int64_t* stage = count_pool() + 2 * kCountEntries - kMaxCountJobs;
+    launch("count_gather", count_gather_kernel, dim3(1), dim3(64), 0, J, stage);
+    struct Many { int64_t v[kMaxCountJobs]; };
+    const Many m = read_scalar(reinterpret_cast<const Many*>(stage));
+    for (int k = 0; k < n; ++k) v[k] = m.v[k];
+  }
+  for (int k = 0; k < n; ++k)
+  {
+    out[k] = Count(v[k]);
+    if (st.active) { st.names.push_back(names[k]); st.values.push_back(v[k]); }
+    if (st.active && step_debug()) fprintf(stderr, "cutfemx_amd: step site %s read back: %lld\n", names[k], (long long)v[k]);
+  }
+  if (st.active) { st.cursor += n; st.read_back += n; }
+}
+
 void* dev_alloc(size_t bytes)
 {
   BlockCache& c = cache();
@@ -701,6 +1007,134 @@ int cfx_overlap_end(void)
   c.overlap = false;
   for (void* p : c.deferred_free) dev_free(p);        // stream order on the main lane now covers both lanes' users
   c.deferred_free.clear();
+  CFX_API_END
+}
+
+int cfx_step_begin(const char* key)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  StepState& st = step();
+  require(!st.active, CFX_ERR_RUNTIME, "cfx_step_begin: the previous step was not ended");
+  require(!ctx().overlap, CFX_ERR_RUNTIME, "cfx_step_begin inside an overlap section");
+  st = StepState();
+  st.key = key ? key : "";
+  st.active = true;
+  const char* off = getenv("CFX_STEP_SPECULATE");
+  st.spec = histories()[st.key].valid && !(off && off[0] == '0');
+  // poison word + error words of the step (entries below the first slot): one fill
+  dev_fill(count_pool(), 0, sizeof(int64_t) * 2 * kCountFirstSlot);
+  CFX_API_END
+}
+
+int cfx_step_end(int* redo, int64_t* published, int64_t* read_back)
+{
+  CFX_API_BEGIN
+  StepState& st = step();
+  require(st.active, CFX_ERR_RUNTIME, "cfx_step_end without cfx_step_begin");
+  int64_t* host = count_mirror();
+  // the one read-back of a step: poison, error words, every slot (published + raw)
+  CFX_HIP(hipMemcpyAsync(host, count_pool(), sizeof(int64_t) * 2 * (size_t)st.next_slot, hipMemcpyDeviceToHost, ctx().main_stream));
+  CFX_HIP(hipStreamSynchronize(ctx().main_stream));
+  ++sync_counter();
+  if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back at cfx_step_end (%lld sites published, %lld read back)\n",
+                                (long long)st.published, (long long)st.read_back);
+  const bool poisoned = host[0] != 0;
+  if (step_debug())
+  {
+    fprintf(stderr, "cutfemx_amd: step '%s' ends: %s\n", st.key.c_str(), poisoned ? "VOID (a count did not fit)" : "ok");
+    for (auto& p : st.pending)
+      fprintf(stderr, "  %s: capacity %lld, value %lld\n", st.names[p.index].c_str(), (long long)p.cell->cap, (long long)host[2 * p.cell->slot + 1]);
+  }
+  for (auto& p : st.pending)
+  {
+    if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
+    st.values[p.index] = host[2 * p.cell->slot + 1];
+  }
+  StepHistory& h = histories()[st.key];
+  h.names = st.names;
+  h.values = st.values;
+  h.valid = !poisoned; // a void step: the repeat sizes everything by read-backs and records afresh
+  if (redo) *redo = poisoned ? 1 : 0;
+  if (published) *published = st.published;
+  if (read_back) *read_back = st.read_back;
+  const std::vector<StepState::Err> errors = std::move(st.errors);
+  const std::vector<StepState::Positive> positives = std::move(st.positives);
+  st = StepState();
+  if (!poisoned)
+  {
+    for (const auto& e : errors)
+      if (host[2 * e.entry] != 0)
+      {
+        if (e.decode) e.decode((int)host[2 * e.entry]);
+        throw Error(e.code, e.message);
+      }
+    for (const auto& q : positives)
+      if (q.cell->value <= 0) throw Error(q.code, q.message);
+  }
+  CFX_API_END
+}
+
+int cfx_step_resolve(void)
+{
+  CFX_API_BEGIN
+  StepState& st = step();
+  if (st.active && !st.pending.empty())
+  {
+    // every count published so far comes to the host (one read-back); the step stays open and later sites publish again
+    int64_t* host = count_mirror();
+    CFX_HIP(hipMemcpyAsync(host, count_pool(), sizeof(int64_t) * 2 * (size_t)st.next_slot, hipMemcpyDeviceToHost, ctx().main_stream));
+    CFX_HIP(hipStreamSynchronize(ctx().main_stream));
+    ++sync_counter();
+    if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back by cfx_step_resolve\n");
+    for (auto& p : st.pending)
+    {
+      if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
+      st.values[p.index] = host[2 * p.cell->slot + 1];
+    }
+    st.pending.clear();
+  }
+  CFX_API_END
+}
+
+int cfx_step_abort(void)
+{
+  CFX_API_BEGIN
+  StepState& st = step();
+  if (st.active)
+  {
+    CFX_HIP(hipStreamSynchronize(ctx().main_stream));
+    int64_t* host = count_mirror();
+    CFX_HIP(hipMemcpy(host, count_pool(), sizeof(int64_t) * 2 * (size_t)st.next_slot, hipMemcpyDeviceToHost));
+    for (auto& p : st.pending)
+      if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
+    histories()[st.key].valid = false;
+    st = StepState();
+  }
+  CFX_API_END
+}
+
+int cfx_step_set_margin(double factor, int64_t slack)
+{
+  CFX_API_BEGIN
+  require(factor > 0.0 && slack >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_step_set_margin: factor > 0, slack >= 0");
+  g_margin = factor;
+  g_slack = slack;
+  CFX_API_END
+}
+
+int cfx_step_forget(const char* key)
+{
+  CFX_API_BEGIN
+  if (key) histories().erase(key); else histories().clear();
+  CFX_API_END
+}
+
+int cfx_sync_count(int64_t* n)
+{
+  CFX_API_BEGIN
+  require(n != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_sync_count: null argument");
+  *n = sync_counter();
   CFX_API_END
 }
 

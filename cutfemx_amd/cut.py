@@ -36,10 +36,26 @@ class RuntimeQuadratureRules:
             _lib.check(_lib.lib().cfx_rules_view_get(handle, C.byref(v)))
         self._view = v
         self.tdim, self.gdim = v.tdim, v.gdim
-        self.total_points = int(v.nq)
-        self.num_rules = int(v.nr)
         self.host_width = int(v.host_width)   # 0: hosted by cells; 2 / 4: by exterior / interior facets
         self._cache: dict = {}
+
+    def _counts(self):
+        """(total points, rules) as the engine knows them now: capacities while the cutfemx_amd.step that made the
+        rules is open (their lengths are still in HBM), exact afterwards."""
+        v = _lib.RulesView()
+        if self.dtype == np.dtype(np.float32):
+            _lib.check(_lib.lib().cfx_rules_view_get_f32(self._h, C.byref(v)))
+        else:
+            _lib.check(_lib.lib().cfx_rules_view_get(self._h, C.byref(v)))
+        return int(v.nq), int(v.nr)
+
+    @property
+    def total_points(self) -> int:
+        return self._counts()[0]
+
+    @property
+    def num_rules(self) -> int:
+        return self._counts()[1]
 
     @classmethod
     def from_arrays(cls, mesh: Mesh, points, weights, offsets, parent_map):
@@ -65,30 +81,35 @@ class RuntimeQuadratureRules:
 
     def _get(self, name, ptr, n, dtype, shape=None):
         if name not in self._cache:
-            a = _lib.download(ptr, n, dtype)
+            a = _lib.download(ptr, n, dtype)   # (the properties below resolve pending counts before they size `n`)
             self._cache[name] = a if shape is None else a.reshape(shape)
         return self._cache[name]
 
     @property
     def points(self):
+        _lib.resolve_counts()
         return self._get("points", self._view.points, self.total_points * self.tdim, self.dtype, (-1, self.tdim))
 
     @property
     def weights(self):
+        _lib.resolve_counts()
         return self._get("weights", self._view.weights, self.total_points, self.dtype)
 
     @property
     def offsets(self):
+        _lib.resolve_counts()
         return self._get("offsets", self._view.offsets, self.num_rules + 1, np.int32)
 
     @property
     def parent_map(self):
+        _lib.resolve_counts()
         return self._get("parent_map", self._view.parent_map, self.num_rules, np.int32)
 
     @property
     def physical_points(self):
         """(gdim, total_nq), as python/cutfemx/cut.py:25-49."""
         if "phys" not in self._cache:
+            _lib.resolve_counts()
             out = np.empty((self.total_points, self.gdim), dtype=self.dtype)
             fn = (_lib.lib().cfx_rules_physical_points_f32 if self.dtype == np.dtype(np.float32)
                   else _lib.lib().cfx_rules_physical_points)
@@ -384,7 +405,11 @@ def update(cut_data: CutData) -> None:
 def locate_entities(cut_data: CutData, ls_part: str) -> np.ndarray:
     """Background cells matched by a selector, ascending int32 (cut.cpp:877-924)."""
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, _engine_selector(cut_data, ls_part), C.byref(p), C.byref(n)))
+    sel = _engine_selector(cut_data, ls_part)
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, sel, C.byref(p), C.byref(n)))
+    if _lib._step_open:   # the list's length may still be in HBM: fetch it, then ask again
+        _lib.resolve_counts()
+        _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, sel, C.byref(p), C.byref(n)))
     return _lib.download(p.value, n.value, np.int32)
 
 
@@ -392,20 +417,33 @@ class DeviceEntities(tuple):
     """(device pointer, count) of a located entity list.  The array belongs to the `CutData` it came from:
     the tuple keeps that object alive (`owner`), and the list is valid until the next `update()` /
     `locate_entities` with the same selector on it -- forms must be rebuilt after an update, as
-    python/demo/demo_moving_poisson.py:53-67 does."""
+    python/demo/demo_moving_poisson.py:53-67 does.  Inside a cutfemx_amd.step the count is the list's capacity (its
+    length is still in HBM; the engine recognises the list when it comes back in an Integral); `size` asks again."""
     owner = None
+    selector = None
 
-    def __new__(cls, ptr, n, owner):
+    def __new__(cls, ptr, n, owner, selector=None):
         self = super().__new__(cls, (ptr, n))
         self.owner = owner
+        self.selector = selector
         return self
+
+    @property
+    def size(self) -> int:
+        """The list's length as the engine knows it now (exact once the step that made it has ended)."""
+        if self.selector is None:
+            return int(self[1])
+        p, n = C.c_void_p(), C.c_int64()
+        _lib.check(_lib.lib().cfx_locate_entities(self.owner._h, self.selector, C.byref(p), C.byref(n)))
+        return int(n.value) if p.value == self[0] else int(self[1])
 
 
 def locate_entities_device(cut_data: CutData, ls_part: str):
     """(device pointer, count) of the selector result; owned by `cut_data` (kept alive by the result)."""
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, _engine_selector(cut_data, ls_part), C.byref(p), C.byref(n)))
-    return DeviceEntities(p.value, n.value, cut_data)
+    sel = _engine_selector(cut_data, ls_part)
+    _lib.check(_lib.lib().cfx_locate_entities(cut_data._h, sel, C.byref(p), C.byref(n)))
+    return DeviceEntities(p.value, n.value, cut_data, sel)
 
 
 def runtime_quadrature(cut_data: CutData, ls_part: str, order: int, *, backend: str = "straight"):
@@ -444,13 +482,22 @@ class FacetRows:
     (python/cutfemx/wrappers/cut.cpp:54-115).  The engine has no global facet
     numbering, so the rows ARE the facet identity."""
 
-    def __init__(self, ptr, n, owner, width: int = 4):
-        self.ptr, self.size, self._owner, self.width = ptr, int(n), owner, int(width)
+    def __init__(self, ptr, n, owner, width: int = 4, requery=None):
+        self.ptr, self._n, self._owner, self.width = ptr, int(n), owner, int(width)
+        self._requery = requery     # asks the engine for the list's count again (ghost-penalty rows made inside a step)
         self._rows = None
+
+    @property
+    def size(self) -> int:
+        """Number of rows: the capacity of the list while the cutfemx_amd.step that made it is open, exact afterwards."""
+        if self._requery is not None:
+            self._n = int(self._requery())
+        return self._n
 
     @property
     def rows(self) -> np.ndarray:
         if self._rows is None:
+            _lib.resolve_counts()
             self._rows = _lib.download(self.ptr, self.width * self.size, np.int32).reshape(-1, self.width)
         return self._rows
 
@@ -505,9 +552,16 @@ def ghost_penalty_facets(cut_data: CutData, selector: str, *, depth: int = 1, in
     if depth != 1:
         raise NotImplementedError("ghost_penalty_facets currently supports depth=1.")
     p, n = C.c_void_p(), C.c_int64()
-    _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, _engine_selector(cut_data, selector), C.byref(p), C.byref(n)))
+    sel = _engine_selector(cut_data, selector)
+    _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, sel, C.byref(p), C.byref(n)))
+    ptr = p.value
+
+    def requery():
+        q, m = C.c_void_p(), C.c_int64()
+        _lib.check(_lib.lib().cfx_ghost_penalty_facets(cut_data._h, sel, C.byref(q), C.byref(m)))
+        return m.value if q.value == ptr else n.value
     # the rows stay in HBM (owned by cut_data until update()/destruction); .rows downloads on demand
-    return FacetRows(p.value, n.value, cut_data)
+    return FacetRows(ptr, n.value, cut_data, requery=requery if _lib._step_open else None)
 
 
 class QuadratureFunction:

@@ -467,8 +467,8 @@ class DistributedPoisson:
         system, dom, A = info["system"], info["dom"], info["A"]
         r_lo, r_hi = part.owned_rows
         c_lo, c_hi = part.owned_cells
-        inactive = as_torch(dom._id, dom._ni, "int32", dev)
-        inside = as_torch(system.inside_cells[0], system.inside_cells[1], "int32", dev)
+        inactive = as_torch(dom._view()[2], dom._view()[3], "int32", dev)
+        inside = as_torch(system.inside_cells[0], system.inside_cells.size, "int32", dev)
         vr, ir = system.volume_rules, system.interface_rules
 
         def owned_points(rules):
@@ -529,7 +529,7 @@ class DistributedPoisson:
             self.comm.scatter_reverse_add(self.b, tri)    # cfx_dist_scatter_reverse_add
         dom = fem.deactivate_outside(A, self.b, fem.active_domain(a_all))
         r_lo, r_hi = part.owned_rows
-        inactive = as_torch(dom._id, dom._ni, "int32", dev)
+        inactive = as_torch(dom._view()[2], dom._view()[3], "int32", dev)
         n_inactive_owned = int(((inactive >= r_lo) & (inactive < r_hi)).sum())
         return dict(active_dofs_owned=(r_hi - r_lo) - n_inactive_owned, nnz=A.nnz, n_inside=i1 - i0,
                     nq_volume=vol_o.total_points_owned, nq_interface=itf_o.total_points_owned,

@@ -250,7 +250,9 @@ class MatrixCSR:
         v = _lib.PatternView()
         _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
         self._view = v
-        self.nrows, self.nnz, self.ncols = int(v.nrows), int(v.nnz), int(v.ncols)
+        self.nrows, self.ncols = int(v.nrows), int(v.ncols)
+        self._nnz_pending = _lib._step_open   # made inside a cutfemx_amd.step: nnz may still be in HBM
+        self._nnz = int(v.nnz)
         self._owns_values = values is None
         self._zero_pending = False
         if values is None:
@@ -276,6 +278,17 @@ class MatrixCSR:
                 raise ValueError(f"values holds {count} entries but the sparsity pattern needs nnz = {self.nnz}")
             self._values_keep = values
             self._vptr = ptr
+
+    @property
+    def nnz(self) -> int:
+        """Stored entries.  While the cutfemx_amd.step that made the matrix is open this is the capacity of the
+        index / value arrays (the exact count is still in HBM); afterwards it is exact."""
+        if self._nnz_pending:
+            v = _lib.PatternView()
+            _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
+            self._nnz = int(v.nnz)
+            self._nnz_pending = _lib._step_open
+        return self._nnz
 
     @property
     def values_ptr(self):
@@ -321,10 +334,12 @@ class MatrixCSR:
 
     @property
     def indices(self):
+        _lib.resolve_counts()
         return _lib.download(self._view.indices, self.nnz, np.int32)
 
     @property
     def data(self):
+        _lib.resolve_counts()
         return _lib.download(self.values_ptr, self.nnz, self.dtype)
 
     def scatter_reverse(self):
@@ -418,6 +433,9 @@ def apply_lifting(b, a: CutForm, bc_markers, bc_values, x0=None, alpha: float = 
     `bc_markers` (int8) / `bc_values` / `x0` hold one entry per dof; one bilinear form,
     i.e. one block of the reference's list-of-forms signature."""
     keep: list = []
+    if a.dtype == np.dtype(np.complex128) and _lib.scalar_dtype(b) != np.complex128:
+        # (as assemble_matrix / assemble_vector: the real entry points would drop the constants and the imaginary part)
+        raise TypeError("a complex128 form lifts into a complex128 vector")
     if _lib.scalar_dtype(b) == np.complex128:
         g = np.ascontiguousarray(bc_values, dtype=np.complex128)
         x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
@@ -503,22 +521,30 @@ class ActiveDomain:
 
     def __init__(self, handle, V):
         self._h, self.function_space = handle, V
+
+    def _view(self):
+        """(active cells, count, inactive dofs, count): the counts are capacities while the cutfemx_amd.step that made
+        the domain is open, exact afterwards."""
         ac, na, idf, ni = C.c_void_p(), C.c_int64(), C.c_void_p(), C.c_int64()
-        _lib.check(_lib.lib().cfx_active_view(handle, C.byref(ac), C.byref(na), C.byref(idf), C.byref(ni)))
-        self._ac, self._na, self._id, self._ni = ac.value, na.value, idf.value, ni.value
+        _lib.check(_lib.lib().cfx_active_view(self._h, C.byref(ac), C.byref(na), C.byref(idf), C.byref(ni)))
+        return ac.value, na.value, idf.value, ni.value
 
     @property
     def active_cells(self):
-        return _lib.download(self._ac, self._na, np.int32)
+        _lib.resolve_counts()
+        ac, na, _, _ = self._view()
+        return _lib.download(ac, na, np.int32)
 
     @property
     def inactive_dofs(self):
-        return _lib.download(self._id, self._ni, np.int32)
+        _lib.resolve_counts()
+        _, _, idf, ni = self._view()
+        return _lib.download(idf, ni, np.int32)
 
     @property
     def num_active_dofs(self):
         V = self.function_space
-        return V.ndofs * V.bs - self._ni
+        return V.ndofs * V.bs - self._view()[3]
 
     def __del__(self):
         try:

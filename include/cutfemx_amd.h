@@ -19,8 +19,9 @@
  *     are not thread-safe;
  *   - one process drives one GPU; several GPUs = several processes joined by a
  *     cfx_comm_t (cfx_dist_*, at the end of this header).
- * Scalar/geometry type: float64/float64 (north_star); other instantiations of
- * python/cutfemx/wrappers/fem.cpp:490-500 are not provided.
+ * Scalar/geometry type: float64/float64 (north_star).  Of the other instantiations of
+ * python/cutfemx/wrappers/fem.cpp:490-500 the boundary carries float32 containers (`*_f32`: widened on the way in,
+ * fp64 arithmetic, rounded once on the way out) and complex128 (`*_c128`); complex64 is not provided.
  */
 #ifndef CUTFEMX_AMD_H
 #define CUTFEMX_AMD_H
@@ -38,6 +39,9 @@ extern "C" {
 #define CFX_ERR_RUNTIME (-2)          /* std::runtime_error   -> RuntimeError */
 #define CFX_ERR_OUT_OF_RANGE (-3)     /* std::out_of_range    -> IndexError   */
 #define CFX_ERR_HIP (-4)              /* HIP runtime failure / no device      */
+#define CFX_ERR_STEP_VOID (-5)        /* inside cfx_step_begin / cfx_step_end: a count did not fit the capacity taken
+                                         from the previous step, the results of the step are void -- call
+                                         cfx_step_end() (it reports redo = 1) and repeat the step          */
 
 /* ---- classification codes: cutcells::cell::domain as used by
  *      cpp/cutfemx/cut/cut.cpp:292-321 ---------------------------------------- */
@@ -178,6 +182,28 @@ int cfx_synchronize(void);
 int cfx_overlap_begin(void);
 int cfx_overlap_side(int side);
 int cfx_overlap_end(void);
+/* Sync-free steps of a moving-domain loop (python/demo/demo_moving_poisson.py:53-67: cut.update -> rules -> forms ->
+ * create_matrix -> assemble, every time step).  The sizes of the data-dependent lists of such a step (located cells,
+ * rule points, ghost facets, row classes, nnz ...) change little from one step to the next, so between
+ * cfx_step_begin(key) and cfx_step_end() the library does not read them back where they are produced: buffers and
+ * grids are sized by the same site's count in the previous step of the loop `key` (x 1.125 + 256 by default), the
+ * exact lengths stay in HBM where the kernels read them, and cfx_step_end() fetches all of them -- and the error
+ * words of the assembly calls -- in ONE read-back.  The first step of a key (no history) reads every size back as
+ * outside a step.  *redo = 1: some count did not fit its capacity; every kernel after that point did nothing, the
+ * results of the step are void and the caller repeats the same calls (the repeat reads sizes back and always fits).
+ * While a step is open, counts returned through this ABI (cfx_locate_entities, cfx_rules_view_get, cfx_pattern_view_get,
+ * cfx_active_view, ...) are CAPACITIES >= the true count when the true count is still in HBM; pass them back to the
+ * library unchanged (it recognises its own lists by address) and query again after cfx_step_end() for the exact
+ * values.  *published / *read_back (optional): sites of the step that stayed in HBM / were read back at once.
+ * No reference counterpart (the reference is a CPU code: sizes are free there). */
+int cfx_step_begin(const char* key);
+int cfx_step_end(int* redo, int64_t* published, int64_t* read_back);
+int cfx_step_resolve(void);                              /* inside a step: fetch every count published so far (one read-back), e.g.
+                                                            before copying a list to the host; no-op outside a step */
+int cfx_step_abort(void);                                /* leave a step after an error: resolves what is pending, drops the history */
+int cfx_step_set_margin(double factor, int64_t slack);   /* capacity = previous count x factor + slack (tests force the redo path) */
+int cfx_step_forget(const char* key);                    /* drop the history of a loop (NULL: of all loops) */
+int cfx_sync_count(int64_t* n);                          /* host round trips (size / error read-backs) since start-up */
 int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
 int cfx_device_alloc(void** ptr, size_t bytes);
 int cfx_device_free(void* ptr);

@@ -252,6 +252,7 @@ int cfx_deactivate_outside_c128(cfx_active_t d, cfx_pattern_t P, double* values,
   if (values) ov = std::make_unique<OutArray<double>>(values, 2 * P->nnz.value(), true);
   if (b) ob = std::make_unique<OutArray<double>>(b, 2 * nrows, true);
   ZeroFlag err;
+  cfx::active_lists(d);
   const int64_t n_inactive = d->n_inactive.value();
   if (n_inactive > 0)
     launch("deactivate", deactivate_c128_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,

@@ -185,7 +185,7 @@ void device_memory_reset_peak();
 // Inside cfx_step_begin / cfx_step_end the size of a data-dependent list (located cells, rule points, ghost facets,
 // row classes, nnz ...) is not read back where it is produced: the producer PUBLISHES it in a slot of a small device
 // pool, the host continues with a capacity taken from the same site's count in the previous step of the loop
-// (x 1.125 + slack), every consumer sizes its grid by the capacity and takes the length from the slot.  One read-back
+// (x 1.03125 + slack), every consumer sizes its grid by the capacity and takes the length from the slot.  One read-back
 // at cfx_step_end fetches all slots: it resolves the counts on the host, feeds the next step's capacities and says
 // whether some count did not fit (then the step is void and the caller repeats it; the repeat sizes everything by
 // read-backs, like the first step of a loop).  A count that does not fit sets the pool's POISON word: every kernel
@@ -205,21 +205,15 @@ constexpr uintptr_t kCountPoolBytes = kCountEntries * 16;    // the pool is alig
 constexpr int kCountFirstSlot = 128;                         // entries 1..127: error words of the step's assembly calls
 
 #if defined(__HIPCC__)
+// (one scalar load: the kernel that finds a count beyond its capacity sets the poison word AND zeroes every published
+// length of the pool, and a length published later in a void step is published as 0 -- count_publish_kernel)
 __device__ __forceinline__ int64_t dev_n(const DevN& nn)
 {
   if (nn.dev == nullptr) return nn.cap;
-  const int64_t* base = reinterpret_cast<const int64_t*>(reinterpret_cast<uintptr_t>(nn.dev) & ~(kCountPoolBytes - 1));
-  if (*base != 0) return 0;
   const int64_t v = *nn.dev;
   return v < nn.cap ? v : nn.cap;
 }
-// the same without the poison check: for lengths read inside a kernel whose own length (dev_n) already vouched for the step
-__device__ __forceinline__ int64_t dev_len(const DevN& nn)
-{
-  if (nn.dev == nullptr) return nn.cap;
-  const int64_t v = *nn.dev;
-  return v < nn.cap ? v : nn.cap;
-}
+__device__ __forceinline__ int64_t dev_len(const DevN& nn) { return dev_n(nn); }
 #endif
 
 struct CountCell
@@ -792,8 +786,17 @@ struct cfx_aggregation_s
 struct cfx_active_s
 {
   cfx_space_t V = nullptr;
+  // The two indicators of deactivate.h:103-183 are the marks of the form's row plan (cells of every cell integral,
+  // dofs touched by any entity): the domain keeps the plan alive and deactivation works from the marks, row tile by
+  // row tile.  The LISTS (active cells, inactive dofs: ActiveDomain's public arrays) are compacted from the marks on
+  // first request (cfx::active_lists) -- a moving-domain step never asks for them.
+  std::shared_ptr<cfx_row_plan> plan;
+  cfx::DevArray<uint8_t> cell_indicator; // only when a facet integral has a cell outside every cell integral
+  bool lists_built = false;
   cfx::DevArray<int32_t> active_cells, inactive_dofs;
   cfx::Count n_active, n_inactive;
-  cfx::DevArray<int32_t> tile_zeros; // scalar spaces: inactive rows per tile of kByteTile rows (empty: not counted)
-  cfx::DevArray<int64_t> tile_zero_off; // ... and their exclusive scan: where a tile's rows start in inactive_dofs
 };
+namespace cfx
+{
+void active_lists(cfx_active_s* d);   // cfx_fem.hip
+}

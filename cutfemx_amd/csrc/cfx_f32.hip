@@ -317,6 +317,7 @@ int cfx_deactivate_outside_f32(cfx_active_t d, cfx_pattern_t P, float* values, f
   if (values) ov = std::make_unique<OutArray<float>>(values, P->nnz.value(), true);
   if (b) ob = std::make_unique<OutArray<float>>(b, nrows, true);
   ZeroFlag err;
+  cfx::active_lists(d);
   const int64_t n_inactive = d->n_inactive.value();
   if (n_inactive > 0)
     launch("deactivate", deactivate_f32_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,

@@ -1108,46 +1108,50 @@ __global__ void deactivate_kernel(DevN n_d, const int32_t* __restrict__ rows, co
   if (b) b[r] = rhs_value;
 }
 
-// A tile of kByteTile rows that are ALL inactive (most inactive rows: the region outside the domain) holds one entry per
-// row, its diagonal (assembler.h:538-560: the all-rows diagonal of every pattern this library builds; one entry per row
-// is checked here through the tile's two row pointers): row r0 + k sits k entries behind the tile's first row pointer,
-// so the tile is two contiguous fills -- no row list, no per-row pointers, no column check.  The rows of the other
-// tiles keep deactivate_kernel.
-__global__ void __launch_bounds__(kBlock) deactivate_tiles_kernel(int64_t nrows, const int32_t* __restrict__ tile_zeros,
-                                                                  const int64_t* __restrict__ tile_zero_off,
-                                                                  const int32_t* __restrict__ rows,
+// Deactivation straight from the row marks.  A tile of kByteTile rows that are ALL inactive (most inactive rows: the
+// region outside the domain) holds one entry per row, its diagonal (assembler.h:538-560: the all-rows diagonal of every
+// pattern this library builds; checked here: one entry per row through the tile's two row pointers, each entry its
+// row's diagonal through one coalesced read): row r0 + k sits k entries behind the tile's first row pointer, so the tile
+// is two contiguous fills.  The other tiles set their unmarked rows one by one.  tile_counts: active rows per tile
+// (special | plain << 32, cfx_row_plan::row_tile_counts).
+__global__ void __launch_bounds__(kBlock) deactivate_marks_kernel(int64_t nrows, const uint8_t* __restrict__ rowmark,
+                                                                  const int64_t* __restrict__ tile_counts,
                                                                   const int64_t* __restrict__ indptr,
                                                                   const int32_t* __restrict__ indices, double* __restrict__ values,
                                                                   double* __restrict__ b, double diagonal, double rhs_value, int* error,
-                                                                  DevN n_inactive_d, DevN nnz_d)
+                                                                  DevN n_active_d, DevN nnz_d)
 {
-  // (lengths still in HBM: nothing to do in a void step -- the row pointers may then point beyond the arrays)
-  if (n_inactive_d.dev && dev_n(n_inactive_d) == 0) return;
+  // (lengths still in HBM: nothing to do in a void step -- marks and row pointers are not those of this step then)
+  if (n_active_d.dev && dev_n(n_active_d) == 0) return;
   if (nnz_d.dev && dev_n(nnz_d) == 0) return;
   const int64_t r0 = (int64_t)blockIdx.x * kByteTile;
   const int tl = (int)min((int64_t)kByteTile, nrows - r0);
-  const int nz = tile_zeros[blockIdx.x];
-  if (nz == tl && indptr[r0 + tl] - indptr[r0] == tl)
+  const int64_t tc = tile_counts[blockIdx.x];
+  const int nact = (int)((tc & 0xffffffffll) + (tc >> 32));
+  if (nact == 0 && (!values || indptr[r0 + tl] - indptr[r0] == tl))
   {
-    // one entry per row -- and each is its row's diagonal (a coalesced read): the tile is two contiguous fills
-    const int64_t e0 = indptr[r0];
     int ok = 1;
-    for (int k = threadIdx.x; k < tl; k += kBlock) ok &= indices[e0 + k] == (int32_t)(r0 + k) ? 1 : 0;
+    const int64_t e0 = values ? indptr[r0] : 0;
+    if (values)
+      for (int k = threadIdx.x; k < tl; k += kBlock) ok &= indices[e0 + k] == (int32_t)(r0 + k) ? 1 : 0;
     if (__syncthreads_and(ok))
     {
-      block_fill_run(values + e0, tl, diagonal);
+      if (values) block_fill_run(values + e0, tl, diagonal);
       if (b) block_fill_run(b + r0, tl, rhs_value);
       return;
     }
   }
-  // a tile with active rows: its inactive rows one by one from the tile's slice of the list
-  const int64_t o = tile_zero_off[blockIdx.x];
-  for (int k = threadIdx.x; k < nz; k += kBlock)
+  if (nact == tl) return;
+  for (int k = threadIdx.x; k < tl; k += kBlock)
   {
-    const int32_t r = rows[o + k];
-    const int64_t rb = indptr[r], re = indptr[r + 1];
-    const int64_t pos = (re - rb == 1 && indices[rb] == r) ? rb : csr_find(indices, rb, re, r);
-    if (pos < 0) *error = 1; else values[pos] = diagonal;
+    const int64_t r = r0 + k;
+    if (rowmark[r]) continue;
+    if (values)
+    {
+      const int64_t rb = indptr[r], re = indptr[r + 1];
+      const int64_t pos = (re - rb == 1 && indices[rb] == r) ? rb : csr_find(indices, rb, re, (int32_t)r);
+      if (pos < 0) *error = 1; else values[pos] = diagonal;
+    }
     if (b) b[r] = rhs_value;
   }
 }
@@ -2050,82 +2054,53 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
   // every cell integral, standard or runtime) and rowmark (dofs touched by any
   // entity) -- collect_active_cells / build_active_indicator of deactivate.h:103-183.
   cfx_row_plan& plan = row_plan(a);
+  d->plan = a->plan;
+  const int64_t nrows = V->ndofs * V->bs;
+  (void)nrows;
+  // deactivate.h:155-160: no active cell <=> no active row (a cell of a cell integral marks its dofs)
+  step_require_positive(plan.n_active_rows, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
+  end_of_call_sync();
+  *out = d.release();
+  CFX_API_END
+}
+
+} // extern "C"
+
+namespace cfx
+{
+// ActiveDomain::active_cells / inactive_dofs as arrays (deactivate.h:387-400), compacted from the plan's marks
+void active_lists(cfx_active_s* d)
+{
+  if (d->lists_built) return;
+  cfx_space_s* V = d->V;
+  cfx_row_plan& plan = *d->plan;
   const int64_t nc = V->mesh->ncells;
-  bool facets_covered = plan.nfacets.cap() == 0;
-  ZeroFlag uncovered;
-  int uncovered_host = 0;
-  if (!facets_covered)
+  const uint8_t* cell_ind = plan.cellmark.p;
+  if (plan.nfacets.value() > 0)
   {
-    // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty
-    // band lies in the cut and inside cells): then the cell marks alone are the indicator.  The flag rides on the
-    // size read-back of the compaction below; should a facet cell be uncovered, that list is rebuilt
-    launch("active_cells", facet_cells_covered_kernel, grid_for(plan.nfacets.cap() * 2), dim3(kBlock), 0, plan.nfacets,
-           plan.facet_rows.p, plan.cellmark.p, uncovered.p);
+    // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty band
+    // lies in the cut and inside cells): then the cell marks alone are the indicator; else both cells of every
+    // facet join it (deactivate.h:138-146)
+    ZeroFlag uncovered;
+    const int64_t nf = plan.nfacets.value();
+    launch("active_cells", facet_cells_covered_kernel, grid_for(nf * 2), dim3(kBlock), 0, nf, plan.facet_rows.p,
+           plan.cellmark.p, uncovered.p);
+    if (read_scalar(uncovered.p))
+    {
+      d->cell_indicator.alloc((nc + 3) & ~3LL);
+      CFX_HIP(hipMemcpyAsync(d->cell_indicator.p, plan.cellmark.p, (size_t)nc, hipMemcpyDeviceToDevice, ctx().stream));
+      launch("mark_cells", mark_cells_kernel, grid_for(nf), dim3(kBlock), 0, nf, plan.facet_rows.p, 4, d->cell_indicator.p);
+      launch("mark_cells", mark_cells_kernel, grid_for(nf), dim3(kBlock), 0, nf, plan.facet_rows.p + 2, 4, d->cell_indicator.p);
+      cell_ind = d->cell_indicator.p;
+    }
   }
-  const int32_t* known_tiles = plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile ? plan.cell_tile_counts.p : nullptr;
-  if (step_speculative())
-  {
-    // the list's length stays in HBM; "every facet cell is covered" is taken from the previous step and checked at the
-    // end of this one (a must-equal site: another answer voids the step, the repeat takes the branch below)
-    const Count unc = count_site("active.uncovered", uncovered.p, kCountI32, kCountMustEqual);
-    uncovered_host = (int)unc.cap();
-    if (uncovered_host == 0)
-      d->n_active = compact_bytes_count("active_cells", "active.cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells,
-                                        known_tiles);
-  }
-  else
-  {
-    d->n_active = compact_bytes("active_cells", nc, plan.cellmark.p, ByteNonZero{}, d->active_cells, known_tiles,
-                                -1, facets_covered ? nullptr : uncovered.p, &uncovered_host);
-    // (the two totals a later step of this loop takes from HBM)
-    step_record("active.uncovered", uncovered_host);
-    if (uncovered_host == 0) step_record("active.cells", d->n_active.cap());
-  }
-  if (uncovered_host != 0)
-  {
-    // facet integrals contribute both of their cells (deactivate.h:138-146)
-    DevArray<uint8_t> mark((nc + 3) & ~3LL);
-    CFX_HIP(hipMemcpyAsync(mark.p, plan.cellmark.p, (size_t)nc, hipMemcpyDeviceToDevice, ctx().stream));
-    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets.cap()), dim3(kBlock), 0, plan.nfacets, plan.facet_rows.p, 4,
-           mark.p);
-    launch("mark_cells", mark_cells_kernel, grid_for(plan.nfacets.cap()), dim3(kBlock), 0, plan.nfacets,
-           plan.facet_rows.p + 2, 4, mark.p);
-    d->n_active = compact_bytes_count("active_cells", "active.cells2", nc, mark.p, ByteNonZero{}, d->active_cells);
-  }
-  // deactivate.h:155-160 (a count still in HBM is checked when the step ends: step_require_positive)
-  if (d->n_active.pending()) step_require_positive(d->n_active, CFX_ERR_INVALID_ARGUMENT,
-                                                   "cutfemx.fem.active_domain found no active background cells");
-  else
-    require(d->n_active.cap() > 0, CFX_ERR_INVALID_ARGUMENT, "cutfemx.fem.active_domain found no active background cells");
+  const int32_t* known_tiles = (cell_ind == plan.cellmark.p && plan.cell_tile_counts.n == (nc + kByteTile - 1) / kByteTile)
+                                   ? plan.cell_tile_counts.p : nullptr;
+  d->n_active = Count(compact_bytes("active_cells", nc, cell_ind, ByteNonZero{}, d->active_cells, known_tiles));
   const int64_t nrows = V->ndofs * V->bs;
   if (V->bs == 1)
-  {
-    // the plan counted the active rows per tile: the inactive ones are the rest of the tile
-    const int64_t ntiles = (nrows + kByteTile - 1) / kByteTile;
-    DevArray<int32_t> zeros;
-    if (plan.row_tile_counts.n == ntiles)
-    {
-      zeros.alloc(ntiles);
-      launch("inactive_dofs", inactive_tile_counts_kernel, grid_for(ntiles), dim3(kBlock), 0, ntiles, nrows,
-             plan.row_tile_counts.p, zeros.p);
-    }
-    if (plan.n_active_rows.pending())
-      d->n_inactive = compact_bytes_count("inactive_dofs", "active.inactive_dofs", nrows, plan.rowmark.p, ByteZero{},
-                                          d->inactive_dofs, zeros.n > 0 ? zeros.p : nullptr);
-    else
-    {
-      // (the plan knows how many rows are marked: the list is sized without a read-back)
-      d->n_inactive = compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs,
-                                    zeros.n > 0 ? zeros.p : nullptr, plan.built ? nrows - plan.n_active_rows.cap() : -1);
-      step_record("active.inactive_dofs", d->n_inactive.cap());
-    }
-    if (zeros.n > 0)
-    {
-      d->tile_zero_off.alloc(zeros.n + 1);
-      exclusive_scan(zeros.p, d->tile_zero_off.p, zeros.n);
-    }
-    d->tile_zeros = std::move(zeros);
-  }
+    d->n_inactive = Count(compact_bytes("inactive_dofs", nrows, plan.rowmark.p, ByteZero{}, d->inactive_dofs, nullptr,
+                                        nrows - plan.n_active_rows.value()));
   else
   {
     DevArray<uint8_t> ind(nrows);
@@ -2133,20 +2108,30 @@ int cfx_active_domain(cfx_form_t a, cfx_active_t* out)
     const int64_t nact = d->n_active.value();
     launch("mark_dofs", mark_dofs_kernel, grid_for(nact * V->ndofs_cell), dim3(kBlock), 0, nact,
            d->active_cells.p, V->dofmap.p, V->ndofs_cell, V->bs, ind.p);
-    d->n_inactive = compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs);
+    d->n_inactive = Count(compact_bytes("inactive_dofs", nrows, ind.p, ByteZero{}, d->inactive_dofs));
   }
-  end_of_call_sync();
-  *out = d.release();
-  CFX_API_END
+  d->lists_built = true;
 }
+} // namespace cfx
+
+extern "C" {
 
 int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_active, const int32_t** inactive_dofs,
                     int64_t* n_inactive)
 {
   CFX_API_BEGIN
   require(d != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_active_view: null handle");
+  // the number of inactive dofs alone (ActiveDomain.num_active_dofs) needs no list; inside a step it is the capacity
+  // derived from the row plan while the exact count is still in HBM
+  if (!active_cells && !n_active && !inactive_dofs)
+  {
+    // rows off the plan's active set (a dof is active iff an entity of the form touches it: the row marks)
+    if (n_inactive) *n_inactive = d->V->ndofs * d->V->bs - d->plan->n_active_rows.cap() * d->V->bs;
+    return CFX_OK;
+  }
+  active_lists(d);
   if (active_cells) *active_cells = d->active_cells.p;
-  if (n_active) *n_active = d->n_active.cap(); // (capacities while the step that made the lists is open)
+  if (n_active) *n_active = d->n_active.cap();
   if (inactive_dofs) *inactive_dofs = d->inactive_dofs.p;
   if (n_inactive) *n_inactive = d->n_inactive.cap();
   CFX_API_END
@@ -2163,19 +2148,23 @@ int cfx_deactivate_outside(cfx_active_t d, cfx_pattern_t P, double* values, doub
   if (b) ob = std::make_unique<OutArray<double>>(b, nrows, true);
   const char* kNoDiag = "Deactivated matrix row has no diagonal entry.";
   ErrorFlag err(CFX_ERR_RUNTIME, kNoDiag);
-  if (d->n_inactive.cap() > 0)
+  cfx_row_plan& plan = *d->plan;
+  const int64_t ntiles = (nrows + kByteTile - 1) / kByteTile;
+  if (d->V->bs == 1 && plan.row_tile_counts.n == ntiles && (!values || P->nrows == nrows))
   {
-    // the tile shortcut is sound for patterns whose rows hold nothing but the diagonal in fully inactive tiles: true of
-    // every pattern this library builds (nnz of a fully inactive tile == its row count is checked on the spot)
-    const int64_t ntiles = (nrows + kByteTile - 1) / kByteTile;
-    const bool tiles = values && P && d->V->bs == 1 && d->tile_zeros.n == ntiles && d->tile_zero_off.n == ntiles + 1
-                       && P->nrows == nrows;
-    if (tiles)
-      launch("deactivate", deactivate_tiles_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nrows, d->tile_zeros.p,
-             d->tile_zero_off.p, d->inactive_dofs.p, P->indptr.p, P->indices.p, ov->dev, b ? ob->dev : (double*)nullptr, diagonal,
-             rhs_value, err.p, d->n_inactive.devn(), P->nnz.devn());
-    else
-      launch("deactivate", deactivate_kernel, grid_for(d->n_inactive.cap()), dim3(kBlock), 0, d->n_inactive,
+    // straight from the row marks, tile by tile: a tile of kByteTile inactive rows is two contiguous fills, the other
+    // tiles set their inactive rows one by one -- no list of inactive dofs is built
+    launch("deactivate", deactivate_marks_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nrows, plan.rowmark.p,
+           plan.row_tile_counts.p, values ? P->indptr.p : (const int64_t*)nullptr, values ? P->indices.p : (const int32_t*)nullptr,
+           values ? ov->dev : (double*)nullptr, b ? ob->dev : (double*)nullptr, diagonal, rhs_value, err.p,
+           plan.n_active_rows.devn(), values ? P->nnz.devn() : DevN());
+  }
+  else
+  {
+    active_lists(d);
+    const int64_t n_inactive = d->n_inactive.value();
+    if (n_inactive > 0)
+      launch("deactivate", deactivate_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
              d->inactive_dofs.p, P ? P->indptr.p : nullptr, P ? P->indices.p : nullptr, values ? ov->dev : nullptr,
              b ? ob->dev : nullptr, diagonal, rhs_value, err.p);
   }

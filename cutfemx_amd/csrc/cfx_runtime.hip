@@ -170,7 +170,7 @@ bool step_debug()
   static const bool on = getenv("CFX_STEP_DEBUG") != nullptr;
   return on;
 }
-double g_margin = 1.125;   // capacity = previous count x margin + slack
+double g_margin = 1.03125; // capacity = previous count x margin + slack
 int64_t g_slack = 256;
 
 int64_t* count_pool()
@@ -224,16 +224,27 @@ __device__ __forceinline__ int64_t count_read(const void* src, int kind)
   return v;
 }
 // speculative step: raw total next to the published one; a total beyond its capacity poisons the step
-__global__ void count_publish_kernel(CountJobs J, int64_t* pool)
+// One wavefront.  A total beyond its capacity (or a must-equal word that differs) voids the step: the poison word is
+// set and EVERY published length of the pool becomes 0, so that each kernel launched from now on -- whatever list drives
+// it -- sees length 0 with the one load of dev_n; lengths published later in the void step are published as 0.
+__global__ void __launch_bounds__(64) count_publish_kernel(CountJobs J, int64_t* pool, int n_slots)
 {
   const int k = threadIdx.x;
-  if (k >= J.n) return;
-  const int64_t raw = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
-  pool[2 * J.slot[k] + 1] = raw;
-  const bool bad = J.mode[k] == kCountMustEqual ? raw != J.cap[k] : raw > J.cap[k];
-  if (bad) pool[0] = 1;
-  // (totals published after the poison word was set are seen as 0 by dev_n anyway)
-  pool[2 * J.slot[k]] = bad ? 0 : raw;
+  bool bad = false;
+  int64_t raw = 0;
+  if (k < J.n)
+  {
+    raw = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
+    pool[2 * J.slot[k] + 1] = raw;
+    bad = J.mode[k] == kCountMustEqual ? raw != J.cap[k] : raw > J.cap[k];
+  }
+  const bool void_step = __ballot(bad) != 0ull || pool[0] != 0;
+  if (k < J.n) pool[2 * J.slot[k]] = void_step ? 0 : raw;
+  if (void_step)
+  {
+    if (k == 0) pool[0] = 1;
+    for (int e = kCountFirstSlot + k; e < n_slots; e += 64) pool[2 * e] = 0;
+  }
 }
 // read-back path: the totals side by side for one copy
 __global__ void count_gather_kernel(CountJobs J, int64_t* out)
@@ -408,7 +419,7 @@ void count_sites(int n, const char* const* names, const CountSource* src, Count*
         fprintf(stderr, "cutfemx_amd: step site %s published, capacity %lld (previous %lld)\n", names[k], (long long)J.cap[k], (long long)out[k].cell->hint);
     st.cursor += n;
     st.published += n;
-    launch("count_publish", count_publish_kernel, dim3(1), dim3(64), 0, J, count_pool());
+    launch("count_publish", count_publish_kernel, dim3(1), dim3(64), 0, J, count_pool(), st.next_slot);
     return;
   }
   int64_t v[kMaxCountJobs];

@@ -543,8 +543,11 @@ class ActiveDomain:
 
     @property
     def num_active_dofs(self):
+        """Dofs touched by an entity of the form (no list is built for this: the row marks of the form's plan)."""
         V = self.function_space
-        return V.ndofs * V.bs - self._view()[3]
+        ni = C.c_int64()
+        _lib.check(_lib.lib().cfx_active_view(self._h, None, None, None, C.byref(ni)))
+        return V.ndofs * V.bs - ni.value
 
     def __del__(self):
         try:

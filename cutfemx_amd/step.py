@@ -65,7 +65,7 @@ def run_step(body, key: str = "default", max_passes: int = 3, info: dict | None 
     raise RuntimeError("cutfemx_amd.run_step: the step still does not fit its capacities after a sized repeat")
 
 
-def set_margin(factor: float = 1.125, slack: int = 256):
+def set_margin(factor: float = 1.03125, slack: int = 256):
     """Capacity of a list = its count in the previous step x factor + slack."""
     _lib.check(_lib.lib().cfx_step_set_margin(C.c_double(factor), C.c_int64(slack)))
 

@@ -186,7 +186,7 @@ int cfx_overlap_end(void);
  * create_matrix -> assemble, every time step).  The sizes of the data-dependent lists of such a step (located cells,
  * rule points, ghost facets, row classes, nnz ...) change little from one step to the next, so between
  * cfx_step_begin(key) and cfx_step_end() the library does not read them back where they are produced: buffers and
- * grids are sized by the same site's count in the previous step of the loop `key` (x 1.125 + 256 by default), the
+ * grids are sized by the same site's count in the previous step of the loop `key` (x 1.03125 + 256 by default), the
  * exact lengths stay in HBM where the kernels read them, and cfx_step_end() fetches all of them -- and the error
  * words of the assembly calls -- in ONE read-back.  The first step of a key (no history) reads every size back as
  * outside a step.  *redo = 1: some count did not fit its capacity; every kernel after that point did nothing, the
@@ -426,6 +426,10 @@ int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** r
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
 
 /* ---- deactivation: cpp/cutfemx/fem/deactivate.h:387-418 ------------------- */
+/* active_domain(): the two indicators (active cells, active dofs) are the marks of the form's row plan; deactivation
+ * works from the marks.  The LISTS (ActiveDomain::active_cells / inactive_dofs) are compacted on the first
+ * cfx_active_view call that asks for them; with active_cells = n_active = inactive_dofs = NULL the call returns the
+ * number of inactive dofs alone, which needs no list. */
 int cfx_active_domain(cfx_form_t a, cfx_active_t* out);
 int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_active,
                     const int32_t** inactive_dofs, int64_t* n_inactive);

@@ -261,6 +261,21 @@ struct CountSource
 // n sites at once (one read-back outside a step / one publish launch inside one); `names` identify the sites in the
 // step's history (the k-th site of a step must be the k-th site of the previous one, else it reads back as before)
 void count_sites(int n, const char* const* names, const CountSource* src, Count* out);
+// The same in two phases around the scan that produces the totals: inside a speculative step the scan's last thread
+// publishes them itself (no publish launch); otherwise finish() reads them back after the scan.
+//   CountPlan cp(n, names, src);  exclusive_scan(in, out, len, &cp);  cp.finish(counts);
+struct CountJobs;
+struct CountPlan
+{
+  int n = 0;
+  bool publish = false, fused = false, finished = false;
+  std::vector<std::string> names;
+  std::vector<CountSource> src;
+  std::vector<Count> counts;         // publish mode: the pending counts, made by the constructor
+  std::shared_ptr<CountJobs> jobs;   // publish mode: what the publishing thread does
+  CountPlan(int n, const char* const* names, const CountSource* src);
+  void finish(Count* out);
+};
 inline Count count_site(const char* name, const void* src, int kind = kCountI64, int mode = kCountUpTo)
 {
   CountSource s{src, kind, mode};
@@ -458,9 +473,10 @@ struct OutArray
 // device primitives (cfx_primitives.hip)
 // ---------------------------------------------------------------------------
 // out[0..n] = exclusive scan of in[0..n-1]; out[n] = total
-void exclusive_scan(const int32_t* in, int64_t* out, int64_t n);
-void exclusive_scan(const int32_t* in, int32_t* out, int64_t n);
-void exclusive_scan(const int64_t* in, int64_t* out, int64_t n);
+// `after` (optional): counts whose sources are complete once this scan has written its total (cfx::CountPlan)
+void exclusive_scan(const int32_t* in, int64_t* out, int64_t n, CountPlan* after = nullptr);
+void exclusive_scan(const int32_t* in, int32_t* out, int64_t n, CountPlan* after = nullptr);
+void exclusive_scan(const int64_t* in, int64_t* out, int64_t n, CountPlan* after = nullptr);
 
 // ---------------------------------------------------------------------------
 // handles
@@ -582,6 +598,7 @@ struct cfx_cut_s
   cfx::DevArray<int8_t> domain; // [nls*ncells]
   cfx::DevArray<uint8_t> host_mask; // cut(level_set, cells, tdim): 1 on the candidate cells; empty = all cells
   // inside / cut cells per compaction tile of level set 0, counted by the classification itself (empty: not available)
+  cfx::DevArray<int32_t> tile_block; // both arrays in one block: one zero fill per classification
   cfx::DevArray<int32_t> tiles_inside, tiles_cut;
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
@@ -637,6 +654,7 @@ struct cfx_row_plan
 {
   bool built = false;
   bool usable = false;             // row-gather assembly is legal for this form
+  cfx::DevArray<uint8_t> mark_block; // cellmark | rowmark | special_mark in one block (one zero fill per plan)
   cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
   cfx::DevArray<uint8_t> rowmark;  // dof touched by any entity of the form
   cfx::DevArray<int32_t> active_rows;
@@ -661,8 +679,8 @@ struct cfx_row_plan
   // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
   // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
   cfx::DevArray<int32_t> vec_t2off;
-  cfx::DevArray<int32_t> vec_slow_rows; // active rows without a segment: they gather the per-cell records
-  cfx::Count n_vec_slow_rows;
+  cfx::Count n_vec_odd_rows; // plain rows without a segment (their cells do not all carry the mark): with the special rows
+                             // they gather the per-cell records -- the second pass of assemble_vec_rows skips the others
   cfx::Count vec_t2_total;
   int vec_fast = -1;
   uint8_t vec_mark = 0;
@@ -692,6 +710,7 @@ struct cfx_row_plan
   cfx::DevArray<int32_t> std_rank[4];
   // per cell slot: open-addressing map parent cell -> first rule of the cell (rules of a cell are
   // consecutive); keys -1 = empty, size = mask + 1 >= 2 * distinct parents
+  cfx::DevArray<int32_t> rule_key_block; // the key tables of all slots (one 0xff fill)
   cfx::DevArray<int32_t> rule_keys[4], rule_first[4];
   uint32_t rule_mask[4] = {0, 0, 0, 0};
   // cells that host a runtime rule of any cell integral (cellmark & 0xF0), ascending, with the bitset + rank

@@ -905,6 +905,7 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   }
   if (lane == 0)
   {
+    if (rbase == 0) offsets[0] = 0; // (the first rule's first point: this cell opens the rule set)
     if (part == PART_IF)
     {
       for (int f = 0; f < ns; ++f)
@@ -1866,6 +1867,17 @@ struct IsCut
   __device__ bool operator()(int64_t c) const { return domain[c] == CFX_INTERSECTED; }
 };
 
+// the per-tile counters of the first level set, zeroed: two arrays in one block
+static void tile_counters(cfx_cut_t cut, int64_t ntiles)
+{
+  const int64_t stride = (ntiles + 3) & ~3LL;
+  cut->tile_block.alloc(2 * stride);
+  cut->tile_block.zero();
+  cut->tiles_inside.release(); cut->tiles_cut.release();
+  cut->tiles_inside.p = cut->tile_block.p; cut->tiles_inside.n = ntiles; cut->tiles_inside.owned = false;
+  cut->tiles_cut.p = cut->tile_block.p + stride; cut->tiles_cut.n = ntiles; cut->tiles_cut.owned = false;
+}
+
 void classify(cfx_cut_t cut)
 {
   const int64_t nc = cut->nhosts();
@@ -1888,8 +1900,7 @@ void classify(cfx_cut_t cut)
         if (k == 0 && cut->host_mask.n == 0)
         {
           const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
-          cut->tiles_inside.alloc(ntiles); cut->tiles_cut.alloc(ntiles);
-          cut->tiles_inside.zero(); cut->tiles_cut.zero();
+          tile_counters(cut, ntiles);
           b_in = cut->tiles_inside.p; b_cut = cut->tiles_cut.p;
         }
         else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
@@ -1906,8 +1917,7 @@ void classify(cfx_cut_t cut)
     if (k == 0 && cut->host_mask.n == 0)
     {
       const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
-      cut->tiles_inside.alloc(ntiles); cut->tiles_cut.alloc(ntiles);
-      cut->tiles_inside.zero(); cut->tiles_cut.zero();
+      tile_counters(cut, ntiles);
       t_in = cut->tiles_inside.p; t_cut = cut->tiles_cut.p;
     }
     else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
@@ -1983,13 +1993,15 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
     {
       const int64_t ntiles = cut->tiles_inside.n;
       DevArray<int64_t> off_in(ntiles + 1), off_cut(ntiles + 1);
-      exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
-      exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles);
-      // (both totals in one round trip -- or none: inside a step they stay in HBM and the lists are sized by the last step)
+      // (both totals in one round trip -- or none: inside a step they stay in HBM, published by the second scan, and
+      // the lists are sized by the last step)
       const char* names[2] = {"locate.inside", "locate.cut"};
       const CountSource src[2] = {{off_in.p + ntiles, kCountI64, kCountUpTo}, {off_cut.p + ntiles, kCountI64, kCountUpTo}};
+      CountPlan cp(2, names, src);
+      exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
+      exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles, &cp);
       Count cnt[2];
-      count_sites(2, names, src, cnt);
+      cp.finish(cnt);
       DevArray<int32_t> l_in(cnt[0].cap()), l_cut(cnt[1].cap());
       l_in.count = cnt[0]; l_cut.count = cnt[1];
       launch("locate_entities", locate_inside_cut_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nh, bytes, off_in.p,
@@ -2247,9 +2259,8 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     }
     // one scan for both totals of a part: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so below
     // 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
-    exclusive_scan(packed[k].p, packed_off[k].p, ncut);
   }
-  // the totals of all parts in one round trip (none inside a step: they stay in HBM)
+  // the totals of all parts in one round trip (none inside a step: they stay in HBM, published by the last scan)
   const char* names[4] = {"rules.points.0", "rules.rules.0", "rules.points.1", "rules.rules.1"};
   CountSource src[4];
   Count totals[4];
@@ -2258,7 +2269,9 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     src[2 * k] = CountSource{packed_off[k].p + ncut, kCountPackedLo, kCountUpTo};
     src[2 * k + 1] = CountSource{packed_off[k].p + ncut, kCountPackedHi, kCountUpTo};
   }
-  count_sites(2 * n, names, src, totals);
+  CountPlan cp(2 * n, names, src);
+  for (int k = 0; k < n; ++k) exclusive_scan(packed[k].p, packed_off[k].p, ncut, k == n - 1 ? &cp : nullptr);
+  cp.finish(totals);
   EmitJobs jobs{};
   jobs.n = n;
   for (int k = 0; k < n; ++k)
@@ -2271,7 +2284,8 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     r[k]->weights.alloc(nq);
     r[k]->offsets.alloc(nr + 1);
     r[k]->parent_map.alloc(nr);
-    dev_fill(r[k]->offsets.p, 0, sizeof(int32_t));
+    // (offsets[0] = 0 is written by the cell that emits rule 0; an empty rule set gets it here)
+    if (ncut == 0 || nr == 0) dev_fill(r[k]->offsets.p, 0, sizeof(int32_t));
     jobs.part[k] = parts[k]; jobs.packed_off[k] = packed_off[k].p;
     jobs.points[k] = r[k]->points.p; jobs.weights[k] = r[k]->weights.p;
     jobs.offsets[k] = r[k]->offsets.p; jobs.parent_map[k] = r[k]->parent_map.p;
@@ -2549,8 +2563,11 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
     else
       launch("ghost_facets_find", ghost_facets_find_kernel<3>, grid_for(nthreads), dim3(kBlock), 0, ncut_d, cutc.p,
              mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);
-    exclusive_scan(counts.p, offs.p, ncut);
-    total = count_site("ghost_facets", offs.p + ncut);
+    const char* gname = "ghost_facets";
+    const CountSource gsrc{offs.p + ncut, kCountI64, kCountUpTo};
+    CountPlan cp(1, &gname, &gsrc);
+    exclusive_scan(counts.p, offs.p, ncut, &cp);
+    cp.finish(&total);
   }
   DevArray<int32_t>& grows = cut->ghost_rows[selector];
   grows.alloc(total.cap() * 4);

@@ -202,8 +202,13 @@ inline Count compact_count(const char* name, const char* site, DevN n, Pred pred
   DevArray<int32_t> counts(ntiles);
   DevArray<int64_t> offsets(ntiles + 1);
   launch(name, compact_count_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, counts.p);
-  exclusive_scan(counts.p, offsets.p, ntiles);
-  const Count total = count_site(site, offsets.p + ntiles);
+  Count total;
+  {
+    const CountSource src{offsets.p + ntiles, kCountI64, kCountUpTo};
+    CountPlan cp(1, &site, &src);
+    exclusive_scan(counts.p, offsets.p, ntiles, &cp);
+    cp.finish(&total);
+  }
   out.alloc(total.cap());
   if (total.cell) out.count = total;
   launch(name, compact_write_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, offsets.p, out.p, total.devn());
@@ -336,8 +341,13 @@ inline Count compact_bytes_count(const char* name, const char* site, int64_t n, 
     launch(name, compact_bytes_count_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,
            counts.p);
   }
-  exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles);
-  const Count total = count_site(site, offsets.p + ntiles);
+  Count total;
+  {
+    const CountSource src{offsets.p + ntiles, kCountI64, kCountUpTo};
+    CountPlan cp(1, &site, &src);
+    exclusive_scan(tile_counts ? tile_counts : counts.p, offsets.p, ntiles, &cp);
+    cp.finish(&total);
+  }
   out.alloc(total.cap());
   if (total.cell) out.count = total;
   launch(name, compact_bytes_write_kernel<ByteTest>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, bytes, test,

@@ -133,6 +133,8 @@ struct RowArgs
   int facet_nq;         // fold_facets = 3, degree 2: records (quadrature points) per facet
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
   const uint8_t* slotn;    // degree 2: 12-byte slot records per (dof, cell) entry (cfx::Stencil::slotn), or null
+  const int32_t* vec_skip; // linear forms, second pass over the plain rows: skip row r when vec_skip[r] >= 0 (it has a segment)
+  DevN vec_n_odd;          // ... and leave at once when no plain row is without one
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
   const int64_t* st_off;
@@ -2927,8 +2929,11 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   constexpr int RPW = kWave / G;
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   const int64_t ri = CFX_ROW_BLOCK * RPW + grp;
-  const bool live = ri < dev_n(A.n_active) && A.cellmark != nullptr;
+  // second pass of the P1 row-ordered staging: the plain rows WITHOUT a segment (none, usually: the wave leaves at once)
+  if (A.vec_skip && dev_n(A.vec_n_odd) == 0) return;
+  bool live = ri < dev_n(A.n_active) && A.cellmark != nullptr;
   const int64_t r = live ? A.active_rows[ri] : 0;
+  if (live && A.vec_skip && A.vec_skip[r] >= 0) live = false;
   const int64_t cb = live ? A.d2c_off[r] : 0;
   const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
   double part = 0.0; // items gl, gl+G, ... in ascending order
@@ -4582,7 +4587,18 @@ void run_vector(cfx_form_s* L, double* b)
     launch("assemble_vec_plain", assemble_vec_plain_kernel<G>,
            dim3((unsigned)((plan.n_plain_rows.cap() + (kWave / G) - 1) / (kWave / G))), dim3(kWave), 0, plan.n_plain_rows,
            plan.plain_rows.p, A.d2c_off, plan.vec_t2off.p, st.vec_t2, b);
-    A.n_active = plan.n_vec_slow_rows; A.active_rows = plan.vec_slow_rows.p; // the rows next to the interface, mostly
+    // everything else gathers the per-cell records: the rows next to the interface ...
+    A.n_active = plan.n_special_rows; A.active_rows = plan.special_rows.p;
+    if (plan.n_vec_odd_rows.cap() > 0)
+    {
+      // ... and the plain rows without a segment (their cells do not all carry the mark: the edge of a restricted
+      // entity list): a pass over the plain rows that skips the others
+      RowArgs O = A;
+      O.n_active = plan.n_plain_rows; O.active_rows = plan.plain_rows.p;
+      O.vec_skip = plan.vec_t2off.p; O.vec_n_odd = plan.n_vec_odd_rows;
+      launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,
+             row_grid((O.n_active.cap + (kWave / CFX_VEC_G) - 1) / (kWave / CFX_VEC_G)), dim3(kWave), 0, O);
+    }
   }
   if (A.n_active.cap > 0)
     launch("assemble_vec_rows", assemble_vec_rows_kernel<TDIM, DEG, CFX_VEC_G>,

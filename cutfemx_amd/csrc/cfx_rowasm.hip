@@ -863,7 +863,7 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
                                                                       int32_t* __restrict__ active,
                                                                       int32_t* __restrict__ special_rows,
                                                                       int32_t* __restrict__ plain_rows, DevN n_special_d,
-                                                                      DevN n_plain_d)
+                                                                      DevN n_plain_d, int32_t* __restrict__ special_pos)
 {
   // (lists sized by the previous step: nothing is written beyond their published lengths -- 0 in a void step)
   const int64_t cap_s = n_special_d.dev ? dev_n(n_special_d) : INT64_MAX, cap_p = n_plain_d.dev ? dev_n(n_plain_d) : INT64_MAX;
@@ -884,7 +884,12 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
   for (int k = 0; k < kByteItems; ++k)
   {
     const int32_t row = (int32_t)(base + k);
-    if (fs & (1u << k)) { if (s < cap_s && p <= cap_p) { active[s + p] = row; special_rows[s] = row; } ++s; }
+    if (fs & (1u << k))
+    {
+      // (special_pos: position of a special row in its list, the index of the dof -> facets incidence)
+      if (s < cap_s && p <= cap_p) { active[s + p] = row; special_rows[s] = row; if (special_pos) special_pos[row] = (int32_t)s; }
+      ++s;
+    }
     else if (fp & (1u << k)) { if (p < cap_p && s <= cap_s) { active[s + p] = row; if (plain_rows) plain_rows[p] = row; } ++p; }
   }
 }
@@ -1429,17 +1434,42 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   const int nd = V->ndofs_cell;
   const int64_t nc = V->mesh->ncells;
   P.usable = true;
-  P.cellmark.alloc((nc + 3) & ~3LL);
-  P.cellmark.zero();
-  P.rowmark.alloc(V->ndofs);
-  P.rowmark.zero();
-  DevArray<uint8_t> special(V->ndofs); // rows touched by a runtime-rule cell or a facet
-  special.zero();
+  // the three mark arrays in one block, zeroed by one fill (16 B aligned parts: the kernels read them 16 B per lane)
+  const int64_t n_cm = (nc + 15) & ~15LL, n_rm = (V->ndofs + 15) & ~15LL;
+  P.mark_block.alloc(n_cm + 2 * n_rm);
+  P.mark_block.zero();
+  P.cellmark.p = P.mark_block.p; P.cellmark.n = (nc + 3) & ~3LL; P.cellmark.owned = false;
+  P.rowmark.p = P.mark_block.p + n_cm; P.rowmark.n = V->ndofs; P.rowmark.owned = false;
+  DevArray<uint8_t> special; // rows touched by a runtime-rule cell or a facet
+  special.p = P.mark_block.p + n_cm + n_rm; special.n = V->ndofs; special.owned = false;
   ZeroFlag flag;
   int plan_flags = 0; // the flag word, read together with the row totals
   // Entity counts may still be in HBM (lists made inside a sync-free step): grids then cover the capacity of a list
   // and the kernels take its length from the device (DevN).
   int n_facet_lists = 0;
+  // hash maps parent cell -> first rule of the cell integrals with runtime rules: key tables of all slots in one block
+  int64_t key_off[4] = {0, 0, 0, 0}, key_total = 0;
+  {
+    int slot = 0;
+    for (const cfx_integral_dev& I : a->integrals)
+    {
+      if (I.type != CFX_CELL || slot >= 4) continue;
+      const int64_t nr = I.rules ? I.rules->nr.cap() : 0;
+      if (nr > 0)
+      {
+        uint32_t size = 64;
+        while (size < 2 * (uint64_t)nr) size <<= 1;
+        key_off[slot] = key_total;
+        key_total += size;
+      }
+      ++slot;
+    }
+    if (key_total > 0)
+    {
+      P.rule_key_block.alloc(key_total);
+      dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
+    }
+  }
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
@@ -1474,9 +1504,9 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         uint32_t size = 64;
         while (size < 2 * (uint64_t)nr) size <<= 1;
         P.rule_mask[slot] = size - 1;
-        P.rule_keys[slot].alloc(size);
+        // (the key tables of all slots in one block, emptied by one fill: see rule_key_block above)
+        P.rule_keys[slot].p = P.rule_key_block.p + key_off[slot]; P.rule_keys[slot].n = size; P.rule_keys[slot].owned = false;
         P.rule_first[slot].alloc(size);
-        dev_fill(P.rule_keys[slot].p, 0xff, sizeof(int32_t) * (size_t)size);
         if (nd == 4)
           launch("plan_rules", plan_rules_kernel<4>, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
                  I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
@@ -1523,17 +1553,31 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   const int64_t nf_cap = P.nfacets.cap();
   if (nf_cap > 0)
   {
-    P.facet_rows.alloc(nf_cap * 4);
-    P.facet_slot.alloc(nf_cap);
+    // one list: the plan refers to the integral's own rows (the form's entity array: alive and unchanged while a form
+    // that shares this plan is used, cfx::validate_form) and needs no slot array -- every facet belongs to slot 0 of
+    // the facet integrals that have entities
+    const bool single_list = n_facet_lists == 1;
+    if (!single_list)
+    {
+      P.facet_rows.alloc(nf_cap * 4);
+      P.facet_slot.alloc(nf_cap);
+    }
     int64_t o = 0;
     for (int s = 0; s < P.n_facet_slots; ++s)
     {
       const cfx_integral_dev& I = a->integrals[P.facet_slot_integral[s]];
       const int64_t ne = I.n_entities.cap(); // (exact unless this is the only list)
       if (ne == 0) continue;
-      CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)ne,
-                             hipMemcpyDeviceToDevice, ctx().stream));
-      dev_fill(P.facet_slot.p + o, s, (size_t)ne);
+      if (single_list)
+      {
+        P.facet_rows.p = I.entities.p; P.facet_rows.n = ne * 4; P.facet_rows.owned = false;
+      }
+      else
+      {
+        CFX_HIP(hipMemcpyAsync(P.facet_rows.p + 4 * o, I.entities.p, sizeof(int32_t) * 4 * (size_t)ne,
+                               hipMemcpyDeviceToDevice, ctx().stream));
+        dev_fill(P.facet_slot.p + o, s, (size_t)ne);
+      }
       if (nd == 4)
         launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
@@ -1570,7 +1614,6 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
     launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, tcounts.p);
-    exclusive_scan(tcounts.p, toffs.p, ntiles);
     // the row totals and the plan's flag word (every kernel that sets a flag has been launched) in one read-back --
     // or, inside a step, left in HBM: the flag word (what the host branches on) must then repeat the last step's
     const char* names[4] = {"plan.special_rows", "plan.plain_rows", "plan.active_rows", "plan.flags"};
@@ -1580,7 +1623,9 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     src[2].src = toffs.p + ntiles; src[2].kind = kCountSum32;
     src[3].src = flag.p; src[3].kind = kCountI32; src[3].mode = kCountMustEqual;
     Count tot[4];
-    count_sites(4, names, src, tot);
+    CountPlan cp(4, names, src);
+    exclusive_scan(tcounts.p, toffs.p, ntiles, &cp);
+    cp.finish(tot);
     plan_flags = (int)tot[3].cap();
     const bool want_plain = space_stencil(V).lists;
     if (getenv("CFX_PLAN_DEBUG"))
@@ -1594,19 +1639,17 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     P.active_rows.alloc(tot[0].cap() + tot[1].cap());
     P.special_rows.alloc(tot[0].cap());
     if (want_plain) P.plain_rows.alloc(tot[1].cap());
+    if (nf_cap > 0) P.special_pos.alloc(V->ndofs);
     launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr,
-           tot[0].devn(), tot[1].devn());
+           tot[0].devn(), tot[1].devn(), nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr);
     P.row_tile_counts = std::move(tcounts); // the inactive dofs of a tile are the rest (cfx_active_domain)
   }
   P.special_mark = std::move(special);
   const int64_t ns_cap = P.n_special_rows.cap();
   if (nf_cap > 0)
   {
-    // dof -> facets incidence of the rows that have facets (all of them special)
-    P.special_pos.alloc(V->ndofs);
-    launch("plan_scatter_pos", plan_scatter_pos_kernel, grid_for(ns_cap), dim3(kBlock), 0, P.n_special_rows,
-           P.special_rows.p, P.special_pos.p);
+    // dof -> facets incidence of the rows that have facets (all of them special; special_pos came with the row lists)
     const char* fs = getenv("CFX_FACET_SORT");
     const int64_t npairs = nf_cap * 2 * nd;
     if (!(fs && fs[0] == '0') && npairs < 2147483647LL && ns_cap < 2147483647LL)
@@ -1869,8 +1912,9 @@ void plan_cut_cells(cfx_form_s* a)
 
 // lengths of the dof->cells lists of the plain rows whose incident cells all carry `mark` (0 for the others:
 // rows at the edge of a restricted entity list, e.g. a rank's owned cells, keep the per-cell records)
+// (packed for one scan: segment entries in the low 32 bits, "this row has no segment" in the high ones)
 __global__ void vec_plain_len_kernel(DevN n_plain_d, const int32_t* __restrict__ rows, const int64_t* __restrict__ d2c_off,
-                                     const uint8_t* __restrict__ uniform, uint8_t mark, int32_t* __restrict__ len)
+                                     const uint8_t* __restrict__ uniform, uint8_t mark, int64_t* __restrict__ len)
 {
   const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1880,7 +1924,8 @@ __global__ void vec_plain_len_kernel(DevN n_plain_d, const int32_t* __restrict__
     return;
   }
   const int64_t r = rows[i];
-  len[i] = uniform[i] == mark ? (int32_t)(d2c_off[r + 1] - d2c_off[r]) : 0;
+  const int64_t l = uniform[i] == mark ? d2c_off[r + 1] - d2c_off[r] : 0;
+  len[i] = l > 0 ? l : (1ll << 32);
 }
 
 __global__ void vec_plain_scatter_kernel(DevN n_plain_d, const int32_t* __restrict__ rows, const int64_t* __restrict__ off,
@@ -1888,14 +1933,10 @@ __global__ void vec_plain_scatter_kernel(DevN n_plain_d, const int32_t* __restri
 {
   const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_plain && off[i + 1] > off[i]) t2off[rows[i]] = (int32_t)off[i];
+  // (entries in the low 32 bits of the packed prefix)
+  if (i < n_plain && (off[i + 1] & 0xffffffffll) > (off[i] & 0xffffffffll)) t2off[rows[i]] = (int32_t)(off[i] & 0xffffffffll);
 }
 
-struct LenIsZero
-{
-  const int32_t* len;
-  __device__ bool operator()(int64_t i) const { return len[i] == 0; }
-};
 
 __global__ void gather_i32_kernel(DevN n_d, const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
                                   int32_t* __restrict__ dst)
@@ -1910,17 +1951,6 @@ __global__ void gather_i32_kernel(DevN n_d, const int32_t* __restrict__ idx, con
 // `mark` (always so for the volume terms of a single-level-set problem: a vertex without a cut cell around it
 // has only inside cells around it; not so at the edge of a restricted entity list).  False: no such row, the
 // caller keeps the per-cell staging for all rows.
-// the rows that read the per-cell records: [the special rows | the plain rows listed by position in `idx`]
-__global__ void __launch_bounds__(kBlock) concat_rows_kernel(DevN n_a_d, const int32_t* __restrict__ a, DevN n_b_d,
-                                                             const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
-                                                             int32_t* __restrict__ out)
-{
-  const int64_t n_a = dev_n(n_a_d), n_b = dev_n(n_b_d);
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i < n_a) out[i] = a[i];
-  else if (i - n_a < n_b) out[i] = src[idx[i - n_a]];
-}
-
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
 {
   cfx_row_plan& plan = row_plan(L);
@@ -1934,29 +1964,30 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   plain_row_masks(L);
   if (plan.plain_uniform.n != n) return false;
   const Adjacency& adj = V->dof_cells();
-  DevArray<int32_t> len(n);
-  DevArray<int64_t> off(n + 1);
+  DevArray<int64_t> len(n), off(n + 1);
   launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
          adj.offsets.p, plan.plain_uniform.p, mark, len.p);
-  exclusive_scan(len.p, off.p, n);
-  // (inside a step the total stays in HBM; "no such row" / "too many entries" are the recorded step's answers)
-  const Count total = count_site("vec.segment_entries", off.p + n);
-  if (total.cap() == 0 || total.cap() >= 2147483647LL) return false;
+  // one scan: the entries of all segments, and the plain rows without one.  Inside a step both totals stay in HBM
+  // (published by the scan); "no such row" / "too many entries" are then the recorded step's answers
+  Count tot[2];
+  {
+    const char* names[2] = {"vec.segment_entries", "vec.odd_rows"};
+    CountSource src[2];
+    src[0].src = off.p + n; src[0].kind = kCountLo32;
+    src[1].src = off.p + n; src[1].kind = kCountHi32;
+    CountPlan cp(2, names, src);
+    exclusive_scan(len.p, off.p, n, &cp);
+    cp.finish(tot);
+  }
+  if (tot[0].cap() == 0 || tot[0].cap() >= 2147483647LL) return false;
   plan.vec_t2off.alloc(V->ndofs);
   dev_fill(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs);
   launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
          off.p, plan.vec_t2off.p);
-  // everything else (the rows next to the interface, plain rows that are not uniform) reads the per-cell records
-  // = the special rows, then the plain rows without a segment (the order of this list is free)
-  DevArray<int32_t> odd;
-  const Count n_odd = compact_count("vec_plain_offsets", "vec.odd_rows", plan.n_plain_rows.devn(), LenIsZero{len.p}, odd);
-  plan.n_vec_slow_rows = count_sum("vec.slow_rows", plan.n_special_rows, n_odd);
-  const int64_t cap_slow = plan.n_special_rows.cap() + n_odd.cap();
-  plan.vec_slow_rows.alloc(cap_slow);
-  if (cap_slow > 0)
-    launch("vec_plain_offsets", concat_rows_kernel, grid_for(cap_slow), dim3(kBlock), 0, plan.n_special_rows.devn(),
-           plan.special_rows.p, n_odd.devn(), odd.p, plan.plain_rows.p, plan.vec_slow_rows.p);
-  plan.vec_t2_total = total;
+  // everything else reads the per-cell records: the special rows, and (a second pass that skips the rows with a
+  // segment) the few plain rows whose cells do not all carry the mark
+  plan.n_vec_odd_rows = tot[1];
+  plan.vec_t2_total = tot[0];
   plan.vec_fast = 1;
   publish_across_lanes();
   return true;
@@ -2394,7 +2425,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     DevArray<int64_t> sums(ntiles), offs(ntiles + 1);
     launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
            counts.p, sums.p);
-    exclusive_scan(sums.p, offs.p, ntiles);
+    if (!deferred) exclusive_scan(sums.p, offs.p, ntiles);
     if (deferred)
     {
       // overflow flag, longest row and nnz in one round trip -- or, inside a step, none: nnz stays in HBM, the flag
@@ -2405,7 +2436,9 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       src[1].src = maxlen.p; src[1].kind = kCountI32; src[1].mode = kCountSizeClass;
       src[2].src = offs.p + ntiles; src[2].kind = kCountI64;
       Count t[3];
-      count_sites(3, names, src, t);
+      CountPlan cp(3, names, src);
+      exclusive_scan(sums.p, offs.p, ntiles, &cp);
+      cp.finish(t);
       if (t[0].cap() != 0)
       {
         V->long_rows = true; // rows beyond 63 columns: build again, wide

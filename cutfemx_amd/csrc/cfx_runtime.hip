@@ -131,6 +131,20 @@ int64_t& sync_counter()
 // ---------------------------------------------------------------------------
 // counts in HBM / sync-free steps (see cfx_common.h)
 // ---------------------------------------------------------------------------
+constexpr int kMaxCountJobs = 6;
+struct CountJobs
+{
+  int64_t* pool;   // the count pool; n_slots: slots handed out so far in this step (what a void step zeroes)
+  int n_slots;
+  int n;
+  const void* src[kMaxCountJobs];
+  int kind[kMaxCountJobs];
+  int mode[kMaxCountJobs];
+  const int64_t* plus[kMaxCountJobs];
+  int64_t add[kMaxCountJobs];
+  int64_t cap[kMaxCountJobs];
+  int slot[kMaxCountJobs];
+};
 namespace
 {
 struct StepHistory
@@ -195,18 +209,6 @@ int64_t* count_mirror()
   return h;
 }
 
-constexpr int kMaxCountJobs = 6;
-struct CountJobs
-{
-  int n;
-  const void* src[kMaxCountJobs];
-  int kind[kMaxCountJobs];
-  int mode[kMaxCountJobs];
-  const int64_t* plus[kMaxCountJobs];
-  int64_t add[kMaxCountJobs];
-  int64_t cap[kMaxCountJobs];
-  int slot[kMaxCountJobs];
-};
 __device__ __forceinline__ int64_t count_read(const void* src, int kind)
 {
   int64_t v;
@@ -224,27 +226,30 @@ __device__ __forceinline__ int64_t count_read(const void* src, int kind)
   return v;
 }
 // speculative step: raw total next to the published one; a total beyond its capacity poisons the step
-// One wavefront.  A total beyond its capacity (or a must-equal word that differs) voids the step: the poison word is
+// Run by ONE thread.  A total beyond its capacity (or a must-equal word that differs) voids the step: the poison word is
 // set and EVERY published length of the pool becomes 0, so that each kernel launched from now on -- whatever list drives
 // it -- sees length 0 with the one load of dev_n; lengths published later in the void step are published as 0.
-__global__ void __launch_bounds__(64) count_publish_kernel(CountJobs J, int64_t* pool, int n_slots)
+__device__ __forceinline__ void count_publish(const CountJobs& J)
 {
-  const int k = threadIdx.x;
-  bool bad = false;
-  int64_t raw = 0;
-  if (k < J.n)
+  int64_t* pool = J.pool;
+  bool void_step = pool[0] != 0;
+  int64_t raw[kMaxCountJobs];
+  for (int k = 0; k < J.n; ++k)
   {
-    raw = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
-    pool[2 * J.slot[k] + 1] = raw;
-    bad = J.mode[k] == kCountMustEqual ? raw != J.cap[k] : raw > J.cap[k];
+    raw[k] = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
+    pool[2 * J.slot[k] + 1] = raw[k];
+    void_step = void_step || (J.mode[k] == kCountMustEqual ? raw[k] != J.cap[k] : raw[k] > J.cap[k]);
   }
-  const bool void_step = __ballot(bad) != 0ull || pool[0] != 0;
-  if (k < J.n) pool[2 * J.slot[k]] = void_step ? 0 : raw;
+  for (int k = 0; k < J.n; ++k) pool[2 * J.slot[k]] = void_step ? 0 : raw[k];
   if (void_step)
   {
-    if (k == 0) pool[0] = 1;
-    for (int e = kCountFirstSlot + k; e < n_slots; e += 64) pool[2 * e] = 0;
+    pool[0] = 1;
+    for (int e = kCountFirstSlot; e < J.n_slots; ++e) pool[2 * e] = 0;
   }
+}
+__global__ void count_publish_kernel(CountJobs J)
+{
+  if (threadIdx.x == 0) count_publish(J);
 }
 // read-back path: the totals side by side for one copy
 __global__ void count_gather_kernel(CountJobs J, int64_t* out)
@@ -372,19 +377,20 @@ int* step_error_flag(int code, const char* message, void (*decode)(int))
   return reinterpret_cast<int*>(count_pool() + 2 * e); // (entries 0..kCountFirstSlot-1 were zeroed by cfx_step_begin)
 }
 
-void count_sites(int n, const char* const* names, const CountSource* src, Count* out)
+CountPlan::CountPlan(int n_, const char* const* names_, const CountSource* src_) : n(n_)
 {
   require(n >= 1 && n <= kMaxCountJobs, CFX_ERR_RUNTIME, "count_sites: too many sites in one call");
   StepState& st = step();
-  CountJobs J{};
+  jobs = std::make_shared<CountJobs>();
+  CountJobs& J = *jobs;
   J.n = n;
-  bool plain = true;
   for (int k = 0; k < n; ++k)
   {
-    J.src[k] = src[k].src; J.kind[k] = src[k].kind; J.mode[k] = src[k].mode; J.plus[k] = src[k].plus; J.add[k] = src[k].add;
-    plain = plain && src[k].src && !src[k].plus && src[k].add == 0;
+    names.push_back(names_[k]);
+    src.push_back(src_[k]);
+    J.src[k] = src_[k].src; J.kind[k] = src_[k].kind; J.mode[k] = src_[k].mode; J.plus[k] = src_[k].plus; J.add[k] = src_[k].add;
   }
-  bool publish = step_speculative() && st.next_slot + n <= kCountEntries;
+  publish = step_speculative() && st.next_slot + n <= kCountEntries;
   if (publish)
   {
     const StepHistory& h = histories()[st.key];
@@ -392,36 +398,50 @@ void count_sites(int n, const char* const* names, const CountSource* src, Count*
       publish = publish && st.cursor + k < h.names.size() && h.names[st.cursor + k] == names[k];
     if (!publish) st.mismatch = true; // another call sequence than last time: this step's record replaces the history
   }
+  if (!publish) return;
+  const StepHistory& h = histories()[st.key];
+  counts.resize(n);
+  for (int k = 0; k < n; ++k)
+  {
+    const int64_t prev = h.values[st.cursor + k];
+    auto cell = std::make_shared<CountCell>();
+    cell->slot = st.next_slot++;
+    // (a list that was empty stays empty or the step is void: the host then takes the branches of the recorded step)
+    if (J.mode[k] == kCountSizeClass)
+      cell->cap = prev <= 32 ? 32 : (prev <= 64 ? 64 : (prev <= 128 ? 128 : (prev <= 256 ? 256 : 512)));
+    else
+      cell->cap = (J.mode[k] == kCountMustEqual || prev == 0) ? prev : (int64_t)((double)prev * g_margin) + g_slack;
+    cell->resolved = false;
+    cell->hint = prev;
+    J.cap[k] = cell->cap; J.slot[k] = cell->slot;
+    counts[k].cell = cell;
+    st.pending.push_back({cell, st.names.size()});
+    st.names.push_back(names[k]);
+    st.values.push_back(0);
+    if (step_debug())
+      fprintf(stderr, "cutfemx_amd: step site %s published, capacity %lld (previous %lld)\n", names[k].c_str(), (long long)J.cap[k], (long long)prev);
+  }
+  J.pool = count_pool();
+  J.n_slots = st.next_slot;
+  st.cursor += n;
+  st.published += n;
+}
+
+void CountPlan::finish(Count* out)
+{
+  require(!finished, CFX_ERR_RUNTIME, "CountPlan::finish called twice");
+  finished = true;
+  StepState& st = step();
+  CountJobs& J = *jobs;
   if (publish)
   {
-    const StepHistory& h = histories()[st.key];
-    for (int k = 0; k < n; ++k)
-    {
-      const int64_t prev = h.values[st.cursor + k];
-      auto cell = std::make_shared<CountCell>();
-      cell->slot = st.next_slot++;
-      // (a list that was empty stays empty or the step is void: the host then takes the branches of the recorded step)
-      if (J.mode[k] == kCountSizeClass)
-        cell->cap = prev <= 32 ? 32 : (prev <= 64 ? 64 : (prev <= 128 ? 128 : (prev <= 256 ? 256 : 512)));
-      else
-        cell->cap = (J.mode[k] == kCountMustEqual || prev == 0) ? prev : (int64_t)((double)prev * g_margin) + g_slack;
-      cell->resolved = false;
-      cell->hint = prev;
-      J.cap[k] = cell->cap; J.slot[k] = cell->slot;
-      out[k].cell = cell;
-      out[k].exact_n = 0;
-      st.pending.push_back({cell, st.names.size()});
-      st.names.push_back(names[k]);
-      st.values.push_back(0);
-    }
-    if (step_debug())
-      for (int k = 0; k < n; ++k)
-        fprintf(stderr, "cutfemx_amd: step site %s published, capacity %lld (previous %lld)\n", names[k], (long long)J.cap[k], (long long)out[k].cell->hint);
-    st.cursor += n;
-    st.published += n;
-    launch("count_publish", count_publish_kernel, dim3(1), dim3(64), 0, J, count_pool(), st.next_slot);
+    // (not taken along by a scan: its own one-thread launch)
+    if (!fused) launch("count_publish", count_publish_kernel, dim3(1), dim3(1), 0, J);
+    for (int k = 0; k < n; ++k) out[k] = counts[k];
     return;
   }
+  bool plain = true;
+  for (int k = 0; k < n; ++k) plain = plain && src[k].src && !src[k].plus && src[k].add == 0;
   int64_t v[kMaxCountJobs];
   if (n == 1 && plain && J.kind[0] == kCountI64)
     v[0] = read_scalar(static_cast<const int64_t*>(J.src[0]));
@@ -440,9 +460,15 @@ void count_sites(int n, const char* const* names, const CountSource* src, Count*
   {
     out[k] = Count(v[k]);
     if (st.active) { st.names.push_back(names[k]); st.values.push_back(v[k]); }
-    if (st.active && step_debug()) fprintf(stderr, "cutfemx_amd: step site %s read back: %lld\n", names[k], (long long)v[k]);
+    if (st.active && step_debug()) fprintf(stderr, "cutfemx_amd: step site %s read back: %lld\n", names[k].c_str(), (long long)v[k]);
   }
   if (st.active) { st.cursor += n; st.read_back += n; }
+}
+
+void count_sites(int n, const char* const* names, const CountSource* src, Count* out)
+{
+  CountPlan cp(n, names, src);
+  cp.finish(out);
 }
 
 void* dev_alloc(size_t bytes)
@@ -571,7 +597,7 @@ __global__ void __launch_bounds__(kBlock) scan_reduce_kernel(const Tin* __restri
 
 template <typename Tin, typename Tout>
 __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restrict__ in, int64_t n,
-                                                            const Tout* __restrict__ tile_offsets, Tout* out)
+                                                            const Tout* __restrict__ tile_offsets, Tout* out, CountJobs after)
 {
   // a thread scans kScanItems consecutive items; the tile goes through LDS both ways so that the global loads
   // and stores are coalesced (lane i touches element i of a 256-element row, not its own 64 B run)
@@ -608,11 +634,15 @@ __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restric
     if (tile + i < n) out[tile + i] = s_v[i];
   }
   // the element one past the end receives the grand total
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) out[n] = tile_offsets[blockIdx.x] + total;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+  {
+    out[n] = tile_offsets[blockIdx.x] + total;
+    if (after.n > 0) count_publish(after);
+  }
 }
 
 template <typename Tin, typename Tout>
-__global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out)
+__global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out, CountJobs after)
 {
   // single thread block, n <= kTile: used for the top of the recursion
   const int64_t base = (int64_t)threadIdx.x * kScanItems;
@@ -632,7 +662,11 @@ __global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out)
     if (base + k < n) out[base + k] = off;
     off += v[k];
   }
-  if (threadIdx.x == 0) out[n] = total;
+  if (threadIdx.x == 0)
+  {
+    out[n] = total;
+    if (after.n > 0) count_publish(after); // (reads out[n] back: this thread's own store)
+  }
 }
 
 // Single-pass scan (chained tiles with wave-wide look-back): one launch, the input is read
@@ -645,7 +679,8 @@ constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 
 template <typename Tin, typename Tout>
 __global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restrict__ in, int64_t n,
                                                               unsigned long long* __restrict__ state,
-                                                              unsigned int* __restrict__ ticket, Tout* __restrict__ out)
+                                                              unsigned int* __restrict__ ticket, Tout* __restrict__ out,
+                                                              CountJobs after)
 {
   __shared__ unsigned int s_tile;
   __shared__ unsigned long long s_prefix;
@@ -731,12 +766,19 @@ __global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restr
     if (tbase + i < n) out[tbase + i] = s_v[i];
   }
   // the element one past the end receives the grand total
-  if ((int64_t)(tile + 1) * kTile >= n && threadIdx.x == kBlock - 1) out[n] = (Tout)s_prefix + total;
+  if ((int64_t)(tile + 1) * kTile >= n && threadIdx.x == kBlock - 1)
+  {
+    out[n] = (Tout)s_prefix + total;
+    if (after.n > 0) count_publish(after);
+  }
 }
 
 template <typename Tin, typename Tout>
-static void scan_impl(const Tin* in, Tout* out, int64_t n)
+static void scan_impl(const Tin* in, Tout* out, int64_t n, CountPlan* plan = nullptr)
 {
+  // counts published by the scan's last thread (speculative steps); else an empty job list
+  CountJobs after{};
+  if (plan && plan->publish && !plan->fused && n > 0) { after = *plan->jobs; plan->fused = true; }
   if (n == 0)
   {
     cfx::dev_fill(out, 0, sizeof(Tout));
@@ -778,26 +820,26 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n)
       next += ntiles + 1;
     }
     launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, state,
-           reinterpret_cast<unsigned int*>(state + ntiles), out);
+           reinterpret_cast<unsigned int*>(state + ntiles), out, after);
     return;
   }
   if (ntiles == 1)
   {
-    launch("scan_top", scan_small_kernel<Tin, Tout>, dim3(1), dim3(kBlock), 0, in, n, out);
+    launch("scan_top", scan_small_kernel<Tin, Tout>, dim3(1), dim3(kBlock), 0, in, n, out, after);
     return;
   }
   DevArray<Tout> sums(ntiles), offs(ntiles + 1);
   launch("scan_reduce", scan_reduce_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, sums.p);
   if (ntiles <= kTile)
-    launch("scan_top", scan_small_kernel<Tout, Tout>, dim3(1), dim3(kBlock), 0, sums.p, ntiles, offs.p);
+    launch("scan_top", scan_small_kernel<Tout, Tout>, dim3(1), dim3(kBlock), 0, sums.p, ntiles, offs.p, CountJobs{});
   else
     scan_impl<Tout, Tout>(sums.p, offs.p, ntiles);
-  launch("scan_write", scan_write_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, offs.p, out);
+  launch("scan_write", scan_write_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, offs.p, out, after);
 }
 
-void exclusive_scan(const int32_t* in, int64_t* out, int64_t n) { scan_impl<int32_t, int64_t>(in, out, n); }
-void exclusive_scan(const int32_t* in, int32_t* out, int64_t n) { scan_impl<int32_t, int32_t>(in, out, n); }
-void exclusive_scan(const int64_t* in, int64_t* out, int64_t n) { scan_impl<int64_t, int64_t>(in, out, n); }
+void exclusive_scan(const int32_t* in, int64_t* out, int64_t n, CountPlan* after) { scan_impl<int32_t, int64_t>(in, out, n, after); }
+void exclusive_scan(const int32_t* in, int32_t* out, int64_t n, CountPlan* after) { scan_impl<int32_t, int32_t>(in, out, n, after); }
+void exclusive_scan(const int64_t* in, int64_t* out, int64_t n, CountPlan* after) { scan_impl<int64_t, int64_t>(in, out, n, after); }
 
 // ---------------------------------------------------------------------------
 // incidence inversion: map[ncells][width] (item ids) -> item -> cells (CSR).

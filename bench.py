@@ -252,6 +252,19 @@ def cpu_baseline_all_cores(n, order):
                 seconds=secs, active_dofs=active, host_cores_available=os.cpu_count())
 
 
+def scale_fields(comm, world, per_rank_ms, exchange_ms):
+    """What a SCALE-day line has to say about itself: which transport really moved the halo (an RCCL -> gloo fallback
+    ends the job unless CFX_REHEARSE=1, cutfemx_amd.dist.decide_transport), on how many ranks the RCCL communicator
+    came up, every rank's own step time (the slowest is the job's) and the exchange alone."""
+    return dict(transport=comm.transport if comm is not None else "none", rccl_ranks=getattr(comm, "rccl_ranks", 0),
+                world=world, per_rank_ms_per_step=[round(v, 4) for v in per_rank_ms],
+                slowest_rank_ms_per_step=round(max(per_rank_ms), 4),
+                imbalance=round(max(per_rank_ms) / (sum(per_rank_ms) / len(per_rank_ms)), 4),
+                exchange_ms=round(exchange_ms, 4),
+                exchange="level-set halo planes to / from the two slab neighbours, once per step (scatter_forward)",
+                fallback_reason=getattr(comm, "fallback_reason", ""))
+
+
 def kernel_profile(_lib, step, psteps):
     """Per-kernel HIP-event times (events on the launch stream) over psteps steps."""
     _lib.check(_lib.lib().cfx_profile_enable(1))
@@ -336,6 +349,9 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     _lib.check(_lib.lib().cfx_profile_enable(0))
     _lib.check(_lib.lib().cfx_profile_reset())
     mem1 = _lib.memory_stats()
+    # (the first step sized everything by read-backs; the next one takes its sizes from it and allocates the
+    # capacity-sized buffers the timed steps then find in the block cache: it belongs to the setup, like the first)
+    info = step()
     for _ in range(max(warmup - 1, 0)):
         info = step()
     barrier()
@@ -349,8 +365,23 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     else:
         info = info.counts()
     info = {k: v for k, v in info.items() if isinstance(v, (int, float))}
+    scale_info = None
     if world > 1:
         cdev = device if dist.get_backend() == "nccl" else "cpu"
+        # every rank's own time (the slowest one is the job's), and what the exchange alone costs
+        mine = torch.tensor([elapsed / steps * 1e3], device=cdev, dtype=torch.float64)
+        per_rank = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
+        xs = []
+        for _ in range(3):
+            barrier()
+            tx = time.perf_counter()
+            dp.exchange_only()
+            torch.cuda.synchronize()
+            xs.append(1e3 * (time.perf_counter() - tx))
+        xm = torch.tensor([min(xs)], device=cdev, dtype=torch.float64)
+        dist.all_reduce(xm, op=dist.ReduceOp.MAX)
+        scale_info = scale_fields(dp.comm, world, [float(v.item()) for v in per_rank], float(xm.item()))
         t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -363,6 +394,13 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         nq_total = float(info["nq_volume"] + info["nq_interface"])
     out = dict(value=active_total / (elapsed / steps), ms_per_step=1e3 * elapsed / steps,
                active_dofs=int(active_total), counts={k: int(v) for k, v in info.items()})
+    if scale_info is not None:
+        out["multi_gpu"] = scale_info
+    if world == 1:
+        out["step_mode"] = dict(sync_free=use_steps, **step_stats,
+                                note="sync_free: the timed step runs between cfx_step_begin / cfx_step_end -- list sizes stay "
+                                     "in HBM (published), buffers are sized by the previous step's counts, one read-back ends "
+                                     "the step; passes > 1 would mean a step was repeated because a count did not fit")
     static_bytes = (V if world == 1 else dp.V).static_table_bytes()
     setup_names = ("adj_", "stencil_", "cell_neighbours", "box_", "scan_reduce", "scan_write")
     setup_kernel_ms = sum(v for k, v in first_kernels.items() if k.startswith(setup_names))
@@ -535,16 +573,17 @@ def _kernel_times(step):
 def phase_roofline(tag, phase, ms, alg_bytes, what):
     """Roofline entry of one phase of a secondary configuration: algorithmic bytes / measured phase time against the
     HBM peak, with the phase's counter traffic from the committed PMC passes (tools/profile_cfg45.sh ->
-    tools/pmc_phase_traffic.py -> profiles/r03_<tag>_traffic.json) beside it."""
+    tools/pmc_phase_traffic.py -> profiles/rNN_<tag>_traffic.json: the latest round's file is quoted and named) beside it."""
     traffic, tnote, kern = None, "no PMC pass for this workload in profiles/", None
-    f = ROOT / "profiles" / f"r03_{tag}_traffic.json"
-    if f.exists():
+    files = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{tag}_traffic.json"))
+    if files:
+        f = files[-1]
         t = json.loads(f.read_text())
         traffic = t["phase_traffic_bytes"]
         kern = {k.split("(")[0][:60]: {kk: vv for kk, vv in v.items() if kk in ("wait_any_share", "l2_hit_rate")}
                 for k, v in t["kernels"].items()}
-        tnote = (f"FETCH_SIZE (raw) + WRITE_SIZE of the phase's kernels per step from {t['source']} (separate rocprofv3 "
-                 "--pmc passes of the same program, tools/profile_cfg45.sh)")
+        tnote = (f"FETCH_SIZE (raw) + WRITE_SIZE of the phase's kernels per step from {t['source']} via profiles/{f.name} "
+                 "(separate rocprofv3 --pmc passes of the same program, tools/profile_cfg45.sh)")
     ach = alg_bytes / (ms * 1e-3) / 1e9
     return dict(bound="hbm", kernel=phase, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                 traffic=traffic, algorithmic_bytes=alg_bytes, phase_ms=ms, algorithmic_bytes_are=what,
@@ -703,11 +742,108 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    proc = subprocess.Popen(launcher_command(args), env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
-    return proc.wait()
+    return run_child(launcher_command(args), env, float(os.environ.get("CFX_BENCH_TIMEOUT", "3000")))
+
+
+def run_child(cmd, env, timeout_s):
+    """Start `cmd` as a child in its own process group, relay its stdout line by line, return its exit code.  A rank
+    that dies takes the job down through torch.distributed.run (non-zero exit); a job that hangs -- a rank stuck in a
+    collective whose peer is gone -- is killed as a group after `timeout_s` and reported as 124."""
+    import signal
+    import subprocess
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def relay():
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    try:
+        rc = proc.wait(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write(f"bench.py: the rank job did not finish within {timeout_s:.0f} s: killing its process group\n")
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)      # the exact group this call started (start_new_session), nothing else
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        rc = 124
+    t.join(timeout=5)
+    return rc
+
+
+def moving_domain_leg(torch, device, n, order, nsteps=8, shift_h=0.3):
+    """The loop the step stands for, with the interface really MOVING (python/demo/demo_moving_poisson.py:53-90): one
+    CutData, the sphere's centre advanced by `shift_h` cells per step, cut.update() + rules + forms + create_matrix +
+    assemble + deactivation every step.  Timed twice over the same positions: as sync-free steps (cutfemx_amd.run_step:
+    sizes from the previous step, one read-back per step) and with every size read back where it is produced.  The
+    headline `value` re-cuts ONE level set; here the counts of every step differ from the last step's."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import _lib, poisson
+    mesh = cfx.Mesh.create_box(3, n)
+    V = cfx.FunctionSpace(mesh, 1)
+    ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
+    phi = torch.empty((n + 1) ** 3, device=device, dtype=torch.float64)
+    f = cfx.Function(V, phi)
+    values = torch.zeros(int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000), device=device, dtype=torch.float64)
+    b = torch.zeros(mesh.num_nodes, device=device, dtype=torch.float64)
+    state = {"cd": None}
+
+    def place(k):
+        cx, cy, cz, R = 0.40 + shift_h * k / n, 0.43, 0.41, 0.31
+        d2 = (ax[:, None, None] - cz) ** 2 + (ax[None, :, None] - cy) ** 2 + (ax[None, None, :] - cx) ** 2
+        phi.copy_((torch.sqrt(d2) - R).reshape(-1))     # in place: the engine aliases this array
+
+    def body():
+        if state["cd"] is None:
+            state["cd"] = cfx.cut(f)
+        else:
+            cfx.update(state["cd"])
+        system = poisson.build_forms(V, state["cd"], order=order)
+        _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(b.data_ptr()), 0, C.c_size_t(8 * b.numel())))
+        A = cfx.fem.create_matrix(system.a, values=values)
+        A.set_value(0.0)
+        cfx.fem.assemble_matrix(system.a, A=A)
+        cfx.fem.assemble_vector(system.L, b)
+        dom = cfx.fem.deactivate_outside(A, b, cfx.fem.active_domain(system.a))
+        return StepResult(system, A, dom)
+
+    def run(sync_free, key):
+        cfx.forget_step_history(key)
+        times, passes, syncs, nnz = [], [], [], []
+        for k in range(-2, nsteps):          # two untimed steps: mesh-static tables, first allocations, size history
+            place(k)
+            torch.cuda.synchronize()
+            s0 = _lib.sync_count()
+            t0 = time.perf_counter()
+            info = {}
+            out = cfx.run_step(body, key=key, info=info) if sync_free else body()
+            torch.cuda.synchronize()
+            if k >= 0:
+                times.append(1e3 * (time.perf_counter() - t0))
+                passes.append(info.get("passes", 1))
+                syncs.append(_lib.sync_count() - s0)
+                nnz.append(out.A.nnz)
+            del out
+        return dict(ms_per_step=sum(times) / len(times), ms_each=[round(t, 3) for t in times], passes=passes,
+                    read_backs_per_step=sum(syncs) / len(syncs), nnz_first_last=[nnz[0], nnz[-1]])
+    a = run(True, f"moving-{n}")
+    state["cd"] = None
+    bb = run(False, f"moving-{n}-rb")
+    return {"what": f"moving sphere, centre advanced by {shift_h} h per step, {nsteps} timed steps, full rebuild of plan and "
+                    "sparsity every step (the reference rebuilds too: cut.cpp:845-868); the level-set update itself is "
+                    "outside the timed region",
+            "mesh": n, "sync_free": a, "sizes_read_back": bb,
+            "incremental_sparsity": None,
+            "incremental_note": "not built: see DESIGN.md 7 (what a step could keep from the previous pattern, and why "
+                                "the P1 path gains little from it)"}
 
 
 def projected_scaling(torch, device, n, order, one_gpu_ms, worlds=(2, 4, 8)):
@@ -773,7 +909,18 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+            # a scaling line must be an xGMI line: without CFX_REHEARSE, an RCCL communicator that does not come up on
+            # every rank ends the job (cutfemx_amd.dist.TransportError) instead of falling back to host-staged gloo
+            os.environ.setdefault("CFX_DIST_STRICT", "1")
     os.environ["CFX_DEVICE"] = str(local_rank)
+    # One explicit HIP stream for torch and the engine alike (CFX_BENCH_STREAM=0: the legacy null stream, the library's
+    # default).  Dependent launches on the null stream are ~10 us apart on this stack (rocprofv3 kernel trace,
+    # profiles/r04_launch_gaps.txt) -- about 70 launches per step.
+    if os.environ.get("CFX_BENCH_STREAM", "1") != "0":
+        from cutfemx_amd import _lib as _sl
+        bench_stream = torch.cuda.Stream(device)
+        torch.cuda.set_stream(bench_stream)
+        _sl.check(_sl.lib().cfx_set_stream(C.c_void_p(bench_stream.cuda_stream)))
 
     n = args.n
     # one step on a tiny mesh first: HIP initialisation and the loading of the library's code objects happen here and
@@ -807,7 +954,7 @@ def main():
                        f"z-slabs x{world} weighted by active cells, halo 3 layers, RCCL p2p row reduction")},
     }
     for k in ("cut_quadrature_points_per_s", "cut_quadrature_points_reference_equivalent", "assemble_matrix_dofs_per_s",
-              "counts", "phases_ms", "setup", "memory", "kernels", "roofline", "roofline_by_kernel", "roofline_longest_kernel",
+              "counts", "step_mode", "multi_gpu", "phases_ms", "setup", "memory", "kernels", "roofline", "roofline_by_kernel", "roofline_longest_kernel",
               "whole_step_roofline"):
         out[k] = m.get(k)
     if rank == 0 and world == 1:
@@ -845,13 +992,24 @@ def main():
                 os.environ.pop("CFX_IMPLICIT_BOX", None)
         if not args.no_secondary:
             try:
+                import gc
+                from cutfemx_amd import _lib as _cl
+                gc.collect(); torch.cuda.empty_cache(); _cl.release_cache()
+                out["moving_domain"] = moving_domain_leg(torch, device, n, args.order)
+                gc.collect(); torch.cuda.empty_cache(); _cl.release_cache()
+            except Exception as e:
+                out["moving_domain"] = {"error": f"{type(e).__name__}: {e}"}
+        if not args.no_secondary:
+            try:
                 out["projected_scaling"] = projected_scaling(torch, device, n, args.order, m["ms_per_step"])
             except Exception as e:
                 out["projected_scaling"] = {"error": f"{type(e).__name__}: {e}"}
         out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
         out["cpu_baseline_all_cores"] = None if args.no_cpu else cpu_baseline_all_cores(args.cpu_n, args.order)
     elif rank == 0:
-        out["cpu_baseline"] = None
+        # the same bounded CPU sample as the one-GPU line, timed on rank 0's host cores after the timed region (the
+        # other ranks wait in destroy_process_group)
+        out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(kBlock, (DEG == 2 && RUNTIME && KSEL != 0) ? 4
 }
 
 // The source term f v with f = c prod_d sin(pi x_d) (CFX_F_SINPROD / CFX_F_POISSON_RHS) on the UNCUT cells of a P1
-// space: the kernel the generic one above spends its time in (14 points x 3 sinpi per tet, FP64-VALU bound).
+// space: the kernel the generic one above spends its time in (11 points x 3 sinpi per tet since the round-3 degree-4 rule, FP64-VALU bound).
 // sin(pi (a + delta)) = S cos(pi delta) + C sin(pi delta) with a = the coordinate of vertex 0 (one sincospi per
 // axis and cell) and delta the offset of the point inside the cell: for |pi delta| <= 0.03 the two series up to
 // u^7 are exact to 2e-17, so a point costs 7 fused multiply-adds per axis instead of a range reduction and a

@@ -84,6 +84,24 @@ def _zero(t):
     _lib.check(_lib.lib().cfx_device_memset(C.c_void_p(t.data_ptr()), 0, C.c_size_t(t.element_size() * t.numel())))
 
 
+class TransportError(RuntimeError):
+    """RCCL did not come up on every rank and the caller asked for RCCL or nothing (strict)."""
+
+
+def decide_transport(backend_is_nccl: bool, rccl_ranks: int, world: int, strict: bool, why: str = "") -> str:
+    """What the ranks of a job exchange data through, decided together: 'rccl' when torch.distributed runs on nccl and
+    the library's RCCL communicator came up on every rank; else 'host-staged' (the library packs on the GPU, the bytes
+    travel through gloo) -- unless `strict`: a benchmark that is meant to measure xGMI must not quietly time a host
+    path, so a job on the nccl backend whose RCCL communicator is missing on some rank raises TransportError."""
+    if backend_is_nccl and rccl_ranks == world:
+        return "rccl"
+    if backend_is_nccl and strict:
+        raise TransportError(f"the RCCL communicator came up on {rccl_ranks} of {world} ranks ({why or 'another rank failed'}); "
+                             "refusing the host-staged fallback (CFX_DIST_STRICT=1: set CFX_REHEARSE=1 for a one-GPU "
+                             "rehearsal over gloo)")
+    return "host-staged"
+
+
 class DistComm:
     """cfx_comm_t of this rank: RCCL over xGMI when torch.distributed runs on the nccl backend (the 128-byte
     ncclUniqueId made by rank 0 travels through torch.distributed, which is only the launcher's side channel
@@ -91,8 +109,11 @@ class DistComm:
     (gloo): what a one-GPU box can run with several ranks.  Data-path exchanges then go through
     cfx_dist_scatter_forward / cfx_dist_scatter_reverse_add / cfx_dist_scatter_reverse_matrix."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, strict: bool | None = None):
         import ctypes as C
+        import os
+        if strict is None:
+            strict = os.environ.get("CFX_DIST_STRICT") == "1"
 
         import torch
         import torch.distributed as dist
@@ -103,6 +124,7 @@ class DistComm:
         self._h = C.c_void_p()
         l = _lib.lib()
         self.rccl = dist.get_backend(group) == "nccl"
+        self.rccl_ranks, self.fallback_reason = 0, ""
         host_group = group
         if self.rccl:
             # every rank must end up on the same transport: the ranks agree on whether RCCL came up everywhere,
@@ -121,8 +143,11 @@ class DistComm:
             except Exception as e:          # noqa: BLE001 -- reported below, then the collective fallback
                 ok, why = 0, f"{type(e).__name__}: {e}"
             flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-            if int(flag.item()) == 0:
+            dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
+            self.rccl_ranks = int(flag.item())
+            self.fallback_reason = why
+            # (raises TransportError on every rank alike when strict: the job ends instead of timing a host path)
+            if decide_transport(True, self.rccl_ranks, self.world, strict, why) != "rccl":
                 import sys
                 print(f"cutfemx_amd.dist: RCCL communicator unavailable on some rank ({why or 'another rank'}); "
                       "falling back to host-staged exchanges over gloo", file=sys.stderr)
@@ -161,6 +186,11 @@ class DistComm:
                     return 1
             self._cb = _lib.HOST_EXCHANGE_FN(exchange)      # kept alive with the communicator
             _lib.check(l.cfx_dist_comm_create_host(self.world, self.rank, self._cb, None, C.byref(self._h)))
+
+    @property
+    def transport(self) -> str:
+        """'rccl' (point-to-point over xGMI) or 'host-staged' (pinned host buffers + gloo)."""
+        return "rccl" if self.rccl else "host-staged"
 
     def _exchanges(self, triples):
         """[(peer, (send_lo, send_hi), (recv_lo, recv_hi)), ...] -> cfx_dist_exchange array (contiguous ranges)"""
@@ -435,6 +465,11 @@ class DistributedPoisson:
     def step(self):
         return self.step_owner() if self.mode == "owner" else self.step_reduce()
 
+    def exchange_only(self):
+        """The level-set halo exchange of a step on its own (what bench.py times as `exchange_ms`)."""
+        if self.part.world > 1:
+            halo_forward(self.phi_values, self.part, comm=self.comm)
+
     def step_owner(self):
         """Level-set halo forward, then the serial hot path on the local slab; owned rows are complete."""
         torch, cfx, part, dev = self.torch, self.cfx, self.part, self.device
@@ -448,15 +483,23 @@ class DistributedPoisson:
             if part.rank < part.world - 1:
                 self.phi_values[ps * (part.z1 + 1 - part.lz0):] = float("nan")
             halo_forward(self.phi_values, part, comm=self.comm)
-        cd = cfx.cut(self.phi)
-        system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
-        _zero(self.b)
-        A = self._matrix(system.a)
-        A.set_value(0.0)
-        fem.assemble_matrix(system.a, A=A)
-        fem.assemble_vector(system.L, self.b)
-        dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
-        return dict(A=A, dom=dom, system=system, nnz=A.nnz)
+
+        def local_path():
+            cd = cfx.cut(self.phi)
+            system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
+            _zero(self.b)
+            A = self._matrix(system.a)
+            A.set_value(0.0)
+            fem.assemble_matrix(system.a, A=A)
+            fem.assemble_vector(system.L, self.b)
+            dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
+            return dict(A=A, dom=dom, system=system)
+        # the local path is one sync-free step of this rank's loop (cutfemx_amd.step): sizes stay in HBM, one read-back
+        # at its end; the exchange above is outside it (CFX_BENCH_STEP=0: every size read back where it is produced)
+        import os
+        if os.environ.get("CFX_BENCH_STEP", "1") == "0":
+            return local_path()
+        return cfx.run_step(local_path, key=f"slab-{part.n}-{part.world}-{part.rank}-{self.order}")
 
     def counters(self, info):
         """Counts of the owned share (active dofs, quadrature points, cut cells ...) of a step's

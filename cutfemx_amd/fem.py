@@ -502,6 +502,65 @@ def zero_rows(A: MatrixCSR, *, tol: float = 0.0) -> np.ndarray:
     return out
 
 
+def zero_block_rows(A_blocks, *, tol: float = 0.0) -> list[np.ndarray]:
+    """Zero rows of each block row of a MatrixCSR block system (python/cutfemx/fem.py:784-800,
+    cpp/cutfemx/fem/deactivate.h:279-320): row r of block row i is listed when it is zero in EVERY block A[i][j]
+    (None blocks count as zero).  Same checks and messages as the reference."""
+    rows = [list(r) for r in A_blocks]
+    if not rows:
+        raise RuntimeError("Zero-row scan requires at least one block row")
+    nb = len(rows)
+    out = []
+    for i, row in enumerate(rows):
+        if len(row) != nb:
+            raise RuntimeError("Zero-row scan requires a square block matrix")
+        if row[i] is None:
+            raise RuntimeError("Zero-row scan requires every diagonal matrix block")
+        nrows = row[i].nrows
+        if any(A is not None and A.nrows != nrows for A in row):
+            raise RuntimeError("Zero-row scan found incompatible row maps in a block row")
+        zero = None
+        for A in row:
+            if A is None:
+                continue
+            z = zero_rows(A, tol=tol)
+            zero = z if zero is None else np.intersect1d(zero, z, assume_unique=True)
+        out.append(np.asarray(zero, dtype=np.int32))
+    return out
+
+
+def deactivate_outside_blocks(A_blocks, active_domains, b_blocks=None, *, diagonal: float = 1.0,
+                              rhs_value: float = 0.0) -> list:
+    """Deactivate block rows from per-row active-domain support (python/cutfemx/fem.py:739-775,
+    cpp/cutfemx/fem/deactivate.h:420-457): the inactive rows of block row i come from active_domains[i]; only the
+    diagonal block A_blocks[i][i] and the optional right-hand side b_blocks[i] are modified -- off-diagonal blocks are
+    left alone on purpose (an inactive coupling entry is a form / domain consistency bug, not something to clean)."""
+    rows = [list(r) for r in A_blocks]
+    domains = list(active_domains)
+    if not rows:
+        raise RuntimeError("Block deactivation requires at least one block row")
+    if len(rows) != len(domains):
+        raise RuntimeError("Block deactivation requires one ActiveDomain per block row")
+    nb = len(rows)
+    for i, row in enumerate(rows):
+        if len(row) != nb:
+            raise RuntimeError("Block deactivation requires a square block matrix")
+        if domains[i] is None:
+            raise RuntimeError("Block deactivation received a null ActiveDomain")
+        if row[i] is None:
+            raise RuntimeError("Block deactivation requires every diagonal matrix block")
+    if b_blocks is not None:
+        b_blocks = list(b_blocks)
+        if len(b_blocks) != nb:
+            raise RuntimeError("Block deactivation requires one RHS vector per block row")
+        if any(b is None for b in b_blocks):
+            raise RuntimeError("Block deactivation received a null RHS vector")
+    for i in range(nb):
+        deactivate_outside(rows[i][i], None if b_blocks is None else b_blocks[i], domains[i], diagonal=diagonal,
+                           rhs_value=rhs_value)
+    return domains
+
+
 def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np.ndarray:
     """Local tensor of one entity (for local-entry parity checks)."""
     V = a.function_space

@@ -16,7 +16,9 @@
 #pragma once
 
 #include <complex>
+#include <algorithm>
 #include <cstdint>
+#include <iterator>
 #include <memory>
 #include <span>
 #include <stdexcept>
@@ -522,6 +524,77 @@ inline ActiveDomain& deactivate_outside(std::span<double> values, const Sparsity
   check(cfx_deactivate_outside(domain.handle.h, pattern.handle.h, values.empty() ? nullptr : values.data(),
                                b.empty() ? nullptr : b.data(), diagonal, rhs_value));
   return domain;
+}
+
+/// zero_rows(A, tol): rows whose assembled entries are all <= tol in magnitude (python/cutfemx/fem.py:777-782)
+inline std::vector<std::int32_t> zero_rows(std::span<const double> values, const SparsityPattern& pattern, double tol = 0.0)
+{
+  std::int32_t* rows = nullptr;
+  std::int64_t n = 0;
+  check(cfx_zero_rows(pattern.handle.h, values.data(), tol, &rows, &n));
+  std::vector<std::int32_t> out = download(rows, n);
+  check(cfx_device_free(rows));
+  return out;
+}
+
+/// One block of a MatrixCSR block system: the values of A[i][j] with their pattern (nullptr: an absent block)
+struct MatrixBlock
+{
+  std::span<double> values;
+  const SparsityPattern* pattern = nullptr;
+};
+
+/// zero_block_rows(): deactivate.h:279-320 -- row r of block row i is listed when it is zero in every block A[i][j]
+inline std::vector<std::vector<std::int32_t>> zero_block_rows(const std::vector<std::vector<MatrixBlock>>& A_blocks,
+                                                              double tol = 0.0)
+{
+  if (A_blocks.empty()) throw std::runtime_error("Zero-row scan requires at least one block row");
+  const std::size_t nb = A_blocks.size();
+  std::vector<std::vector<std::int32_t>> rows(nb);
+  for (std::size_t i = 0; i < nb; ++i)
+  {
+    if (A_blocks[i].size() != nb) throw std::runtime_error("Zero-row scan requires a square block matrix");
+    if (A_blocks[i][i].pattern == nullptr) throw std::runtime_error("Zero-row scan requires every diagonal matrix block");
+    const std::int64_t nrows = A_blocks[i][i].pattern->num_rows();
+    bool first = true;
+    for (std::size_t j = 0; j < nb; ++j)
+    {
+      const MatrixBlock& B = A_blocks[i][j];
+      if (B.pattern == nullptr) continue;
+      if (B.pattern->num_rows() != nrows) throw std::runtime_error("Zero-row scan found incompatible row maps in a block row");
+      std::vector<std::int32_t> z = zero_rows(B.values, *B.pattern, tol);
+      if (first) { rows[i] = std::move(z); first = false; continue; }
+      std::vector<std::int32_t> both;
+      std::set_intersection(rows[i].begin(), rows[i].end(), z.begin(), z.end(), std::back_inserter(both));
+      rows[i] = std::move(both);
+    }
+  }
+  return rows;
+}
+
+/// deactivate_outside_blocks(): deactivate.h:420-457 -- the inactive rows of block row i come from active_domains[i];
+/// only the diagonal block A[i][i] and the optional right-hand side b[i] are modified
+inline std::vector<ActiveDomain*> deactivate_outside_blocks(const std::vector<std::vector<MatrixBlock>>& A_blocks,
+                                                            const std::vector<ActiveDomain*>& active_domains,
+                                                            const std::vector<std::span<double>>& b_blocks = {},
+                                                            double diagonal = 1.0, double rhs_value = 0.0)
+{
+  if (A_blocks.empty()) throw std::runtime_error("Block deactivation requires at least one block row");
+  if (A_blocks.size() != active_domains.size())
+    throw std::runtime_error("Block deactivation requires one ActiveDomain per block row");
+  const std::size_t nb = A_blocks.size();
+  for (std::size_t i = 0; i < nb; ++i)
+  {
+    if (A_blocks[i].size() != nb) throw std::runtime_error("Block deactivation requires a square block matrix");
+    if (active_domains[i] == nullptr) throw std::runtime_error("Block deactivation received a null ActiveDomain");
+    if (A_blocks[i][i].pattern == nullptr) throw std::runtime_error("Block deactivation requires every diagonal matrix block");
+  }
+  if (!b_blocks.empty() && b_blocks.size() != nb)
+    throw std::runtime_error("Block deactivation requires one RHS vector per block row");
+  for (std::size_t i = 0; i < nb; ++i)
+    deactivate_outside(A_blocks[i][i].values, *A_blocks[i][i].pattern, b_blocks.empty() ? std::span<double>{} : b_blocks[i],
+                       *active_domains[i], diagonal, rhs_value);
+  return active_domains;
 }
 
 } // namespace fem

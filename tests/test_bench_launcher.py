@@ -46,3 +46,73 @@ def test_launcher_starts_child_ranks_and_propagates_the_exit_code():
                         "--mesh", "8", "--no-cpu", "--no-secondary"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode != 0
     assert "needs an MI355X" in p.stderr
+
+
+def test_a_rank_that_dies_makes_the_parent_exit_non_zero(tmp_path):
+    """run_child: the job is a child process group; its failure is the parent's exit code, its output is relayed."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    script = tmp_path / "job.py"
+    script.write_text("import sys\nprint('rank 0 alive', flush=True)\nsys.exit(3)\n")
+    rc = bench.run_child([sys.executable, str(script)], dict(os.environ), timeout_s=60)
+    assert rc == 3
+
+
+def test_a_job_that_hangs_is_killed_as_a_group_within_the_timeout(tmp_path):
+    """A rank stuck in a collective whose peer is gone never returns: the parent kills the group it started (and only
+    that group) and reports 124."""
+    import time
+    sys.path.insert(0, str(ROOT))
+    import bench
+    pidfile = tmp_path / "pids"
+    script = tmp_path / "job.py"
+    # a parent with a grandchild, both sleeping: the whole group must go
+    script.write_text(
+        "import os, subprocess, sys, time\n"
+        f"p = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\n"
+        f"open({str(pidfile)!r}, 'w').write(f'{{os.getpid()}} {{p.pid}}')\n"
+        "time.sleep(600)\n")
+    t0 = time.time()
+    rc = bench.run_child([sys.executable, str(script)], dict(os.environ), timeout_s=3)
+    assert rc == 124 and time.time() - t0 < 40
+    time.sleep(0.5)
+    for pid in map(int, pidfile.read_text().split()):
+        alive = True
+        try:
+            os.kill(pid, 0)
+            # a zombie still answers kill(0): read its state
+            state = Path(f"/proc/{pid}/stat").read_text().split(")")[-1].split()[0]
+            alive = state != "Z"
+        except (ProcessLookupError, FileNotFoundError):
+            alive = False
+        assert not alive, f"process {pid} of the job's group survived"
+
+
+def test_transport_decision_refuses_a_silent_fallback():
+    """SCALE day: a job on the nccl backend whose RCCL communicator is missing on some rank must not time a host path
+    (cutfemx_amd.dist.decide_transport; bench.py sets CFX_DIST_STRICT=1 unless CFX_REHEARSE=1)."""
+    import pytest
+    from cutfemx_amd.dist import TransportError, decide_transport
+    assert decide_transport(True, 8, 8, strict=True) == "rccl"
+    assert decide_transport(True, 8, 8, strict=False) == "rccl"
+    assert decide_transport(False, 0, 2, strict=False) == "host-staged"      # a gloo rehearsal: host-staged by design
+    assert decide_transport(False, 0, 2, strict=True) == "host-staged"
+    assert decide_transport(True, 7, 8, strict=False, why="rank 3: ncclCommInitRank failed") == "host-staged"
+    with pytest.raises(TransportError, match="7 of 8 ranks"):
+        decide_transport(True, 7, 8, strict=True, why="rank 3: ncclCommInitRank failed")
+
+
+def test_scale_line_names_its_transport():
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    class Comm:
+        transport, rccl_ranks, fallback_reason = "rccl", 8, ""
+    f = bench.scale_fields(Comm(), 8, [3.1, 3.0, 3.3, 3.2, 3.25, 3.1, 3.0, 2.9], 0.04)
+    assert f["transport"] == "rccl" and f["rccl_ranks"] == 8 and f["world"] == 8
+    assert f["slowest_rank_ms_per_step"] == 3.3 and len(f["per_rank_ms_per_step"]) == 8
+    assert f["exchange_ms"] == 0.04 and f["imbalance"] > 1.0
+
+    class Host:
+        transport, rccl_ranks, fallback_reason = "host-staged", 0, "rehearsal"
+    assert bench.scale_fields(Host(), 2, [1.0, 1.0], 0.5)["transport"] == "host-staged"

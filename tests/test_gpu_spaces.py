@@ -691,3 +691,60 @@ def test_overlap_without_prepare(oracle, degree, bs):
         assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
         assert rel_err(A.data, O.assemble_matrix(om, s["oV"], oa, ip, ix)) < RTOL
         assert rel_err(b.cpu().numpy(), O.assemble_vector(om, s["oV"], oL)) < RTOL
+
+
+def test_block_deactivation_uses_per_row_active_domains(oracle):
+    # python/tests/test_cut_api.py:880-952: a 2 x 2 block system, block row i supported on one side of the interface;
+    # zero_block_rows lists a row when it is zero in every block of its block row, deactivate_outside_blocks touches the
+    # diagonal blocks and the right-hand sides only
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    om = oracle.mesh_box(2, 12)
+    phi = level_set_values(om.x, 2)
+    mesh = cfx.Mesh.from_arrays(2, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(V, phi))
+    inside, outside = cfx.locate_entities(cd, "phi<0"), cfx.locate_entities(cd, "phi>0")
+    r_in, r_out = cfx.runtime_quadrature(cd, "phi<0", 2), cfx.runtime_quadrature(cd, "phi>0", 2)
+
+    def mass(cells, rules, scale=1.0):
+        a = fem.form([fem.Integral(fem.MASS, cells=cells, rules=rules, qdegree=2)], V)
+        A = fem.assemble_matrix(a)
+        if scale != 1.0:
+            import ctypes as C
+            vals = A.data * scale
+            cfx._lib.check(cfx._lib.lib().cfx_copy(C.c_void_p(A._vptr), vals.ctypes.data_as(C.c_void_p), C.c_size_t(vals.nbytes)))
+        return a, A
+    a00, A00 = mass(inside, r_in)
+    a11, A11 = mass(outside, r_out)
+    _, A01 = mass(inside, r_in, 0.25)        # u2 v1 dx_inside: rows of block row 0 live on the inside
+    _, A10 = mass(outside, r_out, 0.5)
+    A_blocks = [[A00, A01], [A10, A11]]
+
+    def rhs(cells, rules, scale):
+        L = fem.form([fem.Integral(fem.SOURCE, cells=cells, rules=rules, params=(fem.F_ONE, scale), qdegree=2)], V)
+        return fem.assemble_vector(L)
+    b_blocks = [rhs(inside, r_in, 1.0), rhs(outside, r_out, 2.0)]
+    domains = [fem.active_domain(a00), fem.active_domain(a11)]
+    zero_before = fem.zero_block_rows(A_blocks)
+    for i in range(2):
+        assert set(domains[i].inactive_dofs.tolist()).issubset(set(zero_before[i].tolist()))
+        assert domains[i].inactive_dofs.size > 0
+        b_blocks[i][domains[i].inactive_dofs] = 3.0
+    off_before = [A01.data.copy(), A10.data.copy()]
+    returned = fem.deactivate_outside_blocks(A_blocks, domains, b_blocks)
+    assert returned == domains
+    assert all(rows.size == 0 for rows in fem.zero_block_rows(A_blocks))
+    for i, dom in enumerate(domains):
+        np.testing.assert_allclose(b_blocks[i][dom.inactive_dofs], 0.0)
+        np.testing.assert_allclose(A_blocks[i][i].to_scipy().diagonal()[dom.inactive_dofs], 1.0)
+    assert np.array_equal(A01.data, off_before[0]) and np.array_equal(A10.data, off_before[1])   # off-diagonal blocks untouched
+    # the reference's input checks (deactivate.h:352-385, 323-337)
+    with pytest.raises(RuntimeError, match="one ActiveDomain per block row"):
+        fem.deactivate_outside_blocks(A_blocks, domains[:1])
+    with pytest.raises(RuntimeError, match="square block matrix"):
+        fem.deactivate_outside_blocks([[A00, A01], [A11]], domains)
+    with pytest.raises(RuntimeError, match="every diagonal matrix block"):
+        fem.zero_block_rows([[None, A01], [A10, A11]])
+    with pytest.raises(RuntimeError, match="one RHS vector per block row"):
+        fem.deactivate_outside_blocks(A_blocks, domains, b_blocks[:1])

@@ -15,7 +15,7 @@ src, nsteps, out, tag = sys.argv[1], float(sys.argv[2]), sys.argv[3], sys.argv[4
 pats = [re.compile(p) for p in sys.argv[5:]]
 kern = {}
 for line in open(src):
-    m = re.match(r"(\S.*?)\s+n=\s*(\d+)\s+(.*)", line)
+    m = re.match(r"(\S.*?)\s+n=\s*(\d+)\s+(?:of=\s*\d+\s+)?(.*)", line)
     if not m or not any(p.search(m.group(1)) for p in pats):
         continue
     vals = dict(kv.split("=") for kv in m.group(3).split())

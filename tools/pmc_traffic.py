@@ -3,10 +3,10 @@
 (FETCH_SIZE and WRITE_SIZE are reported in KiB... rocprofv3 derives them as requests x 64 B / 1024)."""
 import json, re, sys
 src, mesh = sys.argv[1], sys.argv[2]
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r04"
 out = {}
 for line in open(src):
-    m = re.match(r"(\S.*?)\s+n=\s*\d+\s+(.*)", line)
+    m = re.match(r"(\S.*?)\s+n=\s*\d+\s+(?:of=\s*\d+\s+)?(.*)", line)
     if not m:
         continue
     name = m.group(1).split("<")[0].replace("_kernel", "")

@@ -761,6 +761,11 @@ void prepare_form_tables(cfx_form_s* a);                                // cfx_g
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values,
                           bool fresh = false);
 bool assemble_vector_rows(cfx_form_s* L, double* b);
+// integrands compiled at run time (cfx_rtc.hip)
+bool user_integrand_known(int kernel);
+int user_integrand_rank(int kernel);
+void user_stage1(const cfx_form_s* a, const cfx_integral_dev& I, bool runtime, double* out, int out_mode, int64_t out_stride,
+                 int64_t only_index = -1);
 } // namespace cfx
 
 struct cfx_pattern_s

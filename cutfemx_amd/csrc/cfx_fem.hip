@@ -695,12 +695,72 @@ __global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
   }
 }
 
+// Entity-parallel scatter of staged local tensors ([n][ND x ND] or [n][ND], entity-major): the atomic path of the
+// integrands that are compiled at run time (cfx_rtc.hip).  One thread per (entity, local row).
+__global__ void __launch_bounds__(kBlock) scatter_staged_kernel(DevN n_d, const int32_t* __restrict__ cells, const int32_t* __restrict__ dofmap,
+                                                                int nd, int rank, const double* __restrict__ staged,
+                                                                const int8_t* __restrict__ bc0, const int8_t* __restrict__ bc1,
+                                                                const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                                double* __restrict__ values, int* error)
+{
+  const int64_t n = dev_n(n_d);
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = t / nd;
+  if (e >= n) return;
+  const int i = (int)(t - e * nd);
+  const int64_t c = cells[e];
+  const int32_t row = dofmap[c * nd + i];
+  if (rank == 1)
+  {
+    atomicAdd(&values[row], staged[e * nd + i]);
+    return;
+  }
+  if (bc0 && bc0[row]) return;
+  const int64_t rb = indptr[row], re = indptr[row + 1];
+  for (int j = 0; j < nd; ++j)
+  {
+    const int32_t col = dofmap[c * nd + j];
+    if (bc1 && bc1[col]) continue;
+    const int64_t pos = csr_find(indices, rb, re, col);
+    if (pos < 0) { *error = 1; continue; }
+    atomicAdd(&values[pos], staged[(e * nd + i) * nd + j]);
+  }
+}
+
+// a cell integral whose integrand was registered at run time: stage 1 through the compiled wrapper, then -- unless the
+// caller wants the staged tensors themselves (A.dump: the row gather, tabulate_entity) -- the scatter above
+void launch_user_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule, int parts)
+{
+  const cfx_space_s* V = a->V;
+  require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "user integrands are cell integrals");
+  require(A.lift_markers == nullptr, CFX_ERR_INVALID_ARGUMENT, "apply_lifting is not available for user integrands");
+  const bool single = only_index >= 0;
+  const int nd = V->ndofs_cell;
+  const int64_t nt = a->rank == 2 ? (int64_t)nd * nd : nd;
+  for (int part = 1; part <= 2; ++part)
+  {
+    if (!(parts & part)) continue;
+    const bool runtime = part == 2;
+    if (single && (runtime != (use_rule != 0))) continue;
+    if (runtime && !I.rules) continue;
+    const DevN n = single ? DevN(1) : (runtime ? I.rules->nr.devn() : I.n_entities.devn());
+    if (n.cap == 0) continue;
+    if (A.dump) { user_stage1(a, I, runtime, A.dump, 0, 0, only_index); continue; }
+    DevArray<double> staged(n.cap * nt);
+    user_stage1(a, I, runtime, staged.p, 0, 0, only_index);
+    const int32_t* cells = runtime ? I.rules->parent_map.p : I.entities.p;
+    launch("scatter_staged", scatter_staged_kernel, grid_for(n.cap * nd), dim3(kBlock), 0, n, cells + (single ? only_index : 0),
+           V->dofmap.p, nd, a->rank, (const double*)staged.p, A.bc0, A.bc1, A.indptr, A.indices, A.values, A.error);
+  }
+}
+
 template <int TDIM, int DEG, int BS>
 void launch_integral_t(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule,
                        int parts)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   const bool single = only_index >= 0;
+  if (user_integrand_known(I.kernel)) { launch_user_integral(a, I, A, only_index, use_rule, parts); return; }
   if (I.type == CFX_INTERIOR_FACET)
   {
     require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "interior-facet integrals are implemented for bilinear forms");
@@ -1702,7 +1762,8 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
     I.type = in.type; I.kernel = in.kernel; I.qdegree = in.qdegree; I.point_stride = in.point_stride;
     require(in.type == CFX_CELL || in.type == CFX_INTERIOR_FACET, CFX_ERR_INVALID_ARGUMENT,
             "cfx_form_create: integral type must be cell or interior_facet");
-    const bool bilinear = in.kernel < 100;
+    const bool user = user_integrand_known(in.kernel);
+    const bool bilinear = user ? user_integrand_rank(in.kernel) == 2 : in.kernel < 100;
     require(bilinear == (rank == 2), CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: kernel rank does not match the form");
     require(in.qdegree >= 0 && in.qdegree <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT,
             "cfx_form_create: quadrature degree out of range");
@@ -1723,6 +1784,9 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
       throw Error(CFX_ERR_INVALID_ARGUMENT,
                   "cfx_form_create: a cell integral takes cell-hosted rules (pass facet-hosted rules through "
                   "cfx_facet_rules_to_cells)");
+    else if (user)
+      require(in.type == CFX_CELL && !rect && V->bs == 1 && V->degree <= 2, CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: integrands registered at run time serve cell integrals of scalar spaces of degree 1 or 2");
     else
       require(in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS || in.kernel == CFX_K_NITSCHE
                   || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS

@@ -3802,6 +3802,14 @@ template <int TDIM, int DEG>
 void vec_tensors(cfx_form_s* L, const cfx_integral_dev& I, bool runtime, double* out, double* t2 = nullptr, int64_t out_cells = 0)
 {
   cfx_space_s* V = L->V;
+  if (user_integrand_known(I.kernel))
+  {
+    // an integrand compiled at run time (cfx_rtc.hip): its wrapper writes the layout the rows read -- rules [nr][ND],
+    // uncut cells [ND][n] by entity or [ND][ncells] by cell
+    if (runtime) user_stage1(L, I, true, out, 0, 0);
+    else user_stage1(L, I, false, out, out_cells > 0 ? 2 : 1, out_cells > 0 ? out_cells : I.n_entities.cap());
+    return;
+  }
   VecArgs A = vec_args(L, I);
   A.out_cells = out_cells;
   if (t2 && !runtime)
@@ -4515,6 +4523,8 @@ BlockChoice vec_block_choice(cfx_form_s* L, cfx_row_plan& plan, int slot, int co
 {
   const char* e = getenv("CFX_VEC_BLOCKS");
   if ((e && e[0] == '0') || count > 1 || L->V->bs != 1 || !plan.usable) return {false, false};
+  for (const auto& I : L->integrals) // (integrands compiled at run time are staged per cell, cfx_rtc.hip)
+    if (user_integrand_known(I.kernel)) return {false, false};
   const bool series = count == 1 && source_series_ok<DEG>(L->V, L->integrals[plan.cell_slot_integral[slot]]);
   if (series && !(e && e[0] == '2'))
   {
@@ -4549,7 +4559,9 @@ void run_vector(cfx_form_s* L, double* b)
   {
     // ... or (CFX_VEC_BLOCKS=0) its element vectors go to the plain rows directly
     const char* ro = getenv("CFX_VEC_ROWORDER");
-    if (!st.vec_blocks && count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0')
+    bool has_user = false;
+    for (const auto& I : L->integrals) has_user = has_user || user_integrand_known(I.kernel);
+    if (!st.vec_blocks && count == 1 && L->V->bs == 1 && plan.usable && !(ro && ro[0] == '0') && !has_user
         && plain_vec_offsets(L, (uint8_t)(1u << slot)))
     {
       st.t2.alloc(plan.vec_t2_total.cap());

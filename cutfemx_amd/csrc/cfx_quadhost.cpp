@@ -13,4 +13,22 @@ int quad_npoints(int dim, int degree)
   (void)cfx_quad_weights_1d; (void)cfx_quad_weights_2d; (void)cfx_quad_weights_3d;
   return cfx_quad_offset_3d[degree + 1] - cfx_quad_offset_3d[degree];
 }
+
+// host pointers into the tables (the run-time compiled integrands get the reference rule as HBM arrays)
+const double* quad_points_host(int dim, int degree)
+{
+  if (degree < 0) degree = 0;
+  if (degree > CFX_QUAD_MAX_DEGREE) degree = CFX_QUAD_MAX_DEGREE;
+  if (dim == 1) return cfx_quad_points_1d + cfx_quad_offset_1d[degree];
+  if (dim == 2) return cfx_quad_points_2d + 2 * cfx_quad_offset_2d[degree];
+  return cfx_quad_points_3d + 3 * cfx_quad_offset_3d[degree];
+}
+const double* quad_weights_host(int dim, int degree)
+{
+  if (degree < 0) degree = 0;
+  if (degree > CFX_QUAD_MAX_DEGREE) degree = CFX_QUAD_MAX_DEGREE;
+  if (dim == 1) return cfx_quad_weights_1d + cfx_quad_offset_1d[degree];
+  if (dim == 2) return cfx_quad_weights_2d + cfx_quad_offset_2d[degree];
+  return cfx_quad_weights_3d + cfx_quad_offset_3d[degree];
+}
 } // namespace cfx

@@ -224,13 +224,41 @@ class overlap:
         return False
 
 
+_user_integrand_rank: dict[int, int] = {}
+
+
+def register_integrand(name: str, source: str, rank: int = 2) -> int:
+    """Register the HIP C++ source of an integrand; returns the id to put into `Integral.kernel`.
+
+    The reference generates a tabulate_tensor kernel per form at run time (runintgen / FFCx,
+    python/cutfemx/_runintgen_adapter.py:181-217) and calls it per entity on the CPU; here the SOURCE of a device function
+
+        __device__ void name(double* A, const double* w, const double* c, const double* coordinate_dofs,
+                             int nq, const double* points, const double* weights, const double* point_data)
+
+    (local tensor, packed coefficient, constants = Integral.params, vertex coordinates [(tdim+1)][3], the entity's
+    rule: reference points, physical-measure weights, per-point data) is compiled for gfx950 with hipRTC -- see
+    include/cutfemx_amd.h (cfx_integrand_register) for the contract and the helpers in scope (cfx_tabulate, ...).
+    Cell integrals of scalar spaces of degree 1 or 2, over standard entities and / or runtime rules."""
+    kid = C.c_int()
+    _lib.check(_lib.load().cfx_integrand_register(name.encode(), source.encode(), int(rank), C.byref(kid)))
+    _user_integrand_rank[kid.value] = int(rank)
+    return kid.value
+
+
+def compile_integrand(kernel_id: int, tdim: int, ndofs_cell: int) -> None:
+    """Compile the (tdim, dofs per cell) variant of a registered integrand now instead of at its first use."""
+    _lib.check(_lib.load().cfx_integrand_compile(int(kernel_id), int(tdim), int(ndofs_cell)))
+
+
 def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: FunctionSpace | None = None, dtype=None) -> CutForm:
     """Create a form from integral descriptors (stands in for cutfemx.fem.form).  `V` is the test space; a bilinear
     form whose trial space differs (the off-diagonal blocks of a Stokes system, test_assembly_stokes.py:34-95) names it
     with `trial_space`."""
     integrals = list(integrals)
     if rank is None:
-        ranks = {2 if i.kernel < 100 else 1 for i in integrals}
+        ranks = {_user_integrand_rank[i.kernel] if i.kernel in _user_integrand_rank else (2 if i.kernel < 100 else 1)
+                 for i in integrals}
         if len(ranks) != 1:
             raise ValueError("all integrals of a form must have the same rank")
         rank = ranks.pop()

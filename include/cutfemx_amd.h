@@ -89,6 +89,9 @@ extern "C" {
 #define CFX_F_COEFFICIENT 3     /* a Function of the form's space: sum_j N_j(X_q) w[dof_j], `coefficient` = its dof values
                                    (the packed coefficient of pack_form.h:32-170 evaluated by the kernel) */
 
+/* ids >= CFX_K_USER_BASE: integrands registered at run time (cfx_integrand_register, below) */
+#define CFX_K_USER_BASE 1000
+
 typedef struct cfx_mesh_s* cfx_mesh_t;
 typedef struct cfx_cut_s* cfx_cut_t;
 typedef struct cfx_rules_s* cfx_rules_t;
@@ -424,6 +427,32 @@ int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, con
  * magnitude, ascending; *rows is released with cfx_device_free. */
 int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** rows, int64_t* n_rows);
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
+
+/* ---- user-supplied integrands: the runtime-generated kernel of a form
+ *      (cpp/dolfinx_custom_data/fem/Form.h:59-75: std::function tabulate_tensor per integral,
+ *      python/cutfemx/_runintgen_adapter.py:181-217: runintgen / FFCx generate and JIT-compile it).  A GPU engine cannot
+ *      call a CPU function pointer per entity; it compiles the integrand's SOURCE for gfx950 with hipRTC instead.
+ *      `source` defines a device function `name` with the argument list of a UFCx tabulate_tensor kernel extended by
+ *      the rule, as runintgen passes it through custom_data:
+ *
+ *        __device__ void name(double* A,                     local tensor, zero on entry: [ND][ND] row-major (rank 2) or [ND]
+ *                             const double* w,               packed coefficient (the ND cell dofs of `coefficient`) or NULL
+ *                             const double* c,               constants: cfx_integral.params[8]
+ *                             const double* coordinate_dofs, vertex coordinates of the cell, [(TDIM+1)][3]
+ *                             int nq, const double* points,  rule of this entity: [nq][TDIM] parent-reference coordinates
+ *                             const double* weights,         [nq] physical-measure weights (standard entities: reference
+ *                                                            weights x |det J| of the cell; runtime rules: as stored)
+ *                             const double* point_data);     [nq][point_stride] per-point data of the rules, or NULL
+ *
+ *      CFX_TDIM and CFX_ND (dofs per cell) are defined at compile time; helpers in scope: cfx_tabulate(X, N, dN),
+ *      cfx_tabulate_p1 / _p2, cfx_inverse_jacobian(coordinate_dofs, K) -> det J, cfx_cell_diameter(coordinate_dofs).
+ *      The id returned in *kernel_id goes into cfx_integral.kernel (cell integrals of scalar spaces of degree 1 or 2,
+ *      standard entities and / or runtime rules).  Stage 1 (one thread per entity) stages the local tensors in HBM; the
+ *      row gather -- or the entity-parallel scatter -- then assembles them like those of the built-in integrands that
+ *      are not formed in line.  A source that does not compile is CFX_ERR_INVALID_ARGUMENT with the compiler log in
+ *      cfx_last_error(); compilation needs no GPU (hipRTC targets gfx950 explicitly), loading the code object does. */
+int cfx_integrand_register(const char* name, const char* source, int rank, int* kernel_id);
+int cfx_integrand_compile(int kernel_id, int tdim, int ndofs_cell); /* compile a (tdim, dofs per cell) variant now */
 
 /* ---- deactivation: cpp/cutfemx/fem/deactivate.h:387-418 ------------------- */
 /* active_domain(): the two indicators (active cells, active dofs) are the marks of the form's row plan; deactivation

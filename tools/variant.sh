@@ -6,7 +6,7 @@ NAME=$1; FILE=$2; shift 2
 cd "$(dirname "$0")/../cutfemx_amd/csrc"
 mkdir -p ../../build
 OBJS=""
-for f in cfx_runtime cfx_mesh cfx_cut cfx_fem cfx_rowasm cfx_gather cfx_dist cfx_f32 cfx_c128; do
+for f in cfx_runtime cfx_mesh cfx_cut cfx_fem cfx_rowasm cfx_gather cfx_dist cfx_f32 cfx_c128 cfx_rtc; do
   if [ "$f.hip" = "$FILE" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wno-unused-function -Wno-pass-failed "$@" -c $f.hip -o /tmp/${f}_$NAME.o
     OBJS="$OBJS /tmp/${f}_$NAME.o"

@@ -579,6 +579,8 @@ struct cfx_rules_s
   cfx::DevArray<double> points, weights;
   cfx::DevArray<float> points_f32, weights_f32; // rounded copies behind cfx_rules_view_get_f32 (made on first use)
   cfx::DevArray<int32_t> offsets, parent_map;
+  bool parent_sentinel = false; // parent_map[nr] = -1 (rules made by cfx_runtime_quadrature: walks over "the rules of a cell"
+                                // end there and need not load the number of rules while it is still in HBM)
   // rules hosted by facets (cut(level_set, facets, tdim-1)): tdim == mesh tdim - 1, points are coordinates of
   // the host facet's reference simplex spanned by host_verts, parent_map = the caller's facet ids
   int host_width = 0;                 // 0: hosted by cells; 2: (cell, lf) rows; 4: (c0, lf0, c1, lf1) rows
@@ -614,6 +616,23 @@ struct cfx_cut_s
   int host_dim() const { return host_width ? mesh->tdim - 1 : mesh->tdim; }
 };
 
+// The previous sparsity pattern of a space (moving-domain loops, spaces whose patterns are built from neighbour lists
+// and hash sets: degree 2, vector-valued, DG).  A row of the new pattern whose incident cells kept their SIGNATURE --
+// "carries a mark of the form" and "which of its sides are facets of the form" -- couples exactly the columns it coupled
+// before: it copies them from the previous pattern instead of going through the hash sets again (cfx::build_pattern).
+// The arrays stay with the pattern they belong to while it is alive and move here when it is destroyed.
+struct cfx_pattern_cache
+{
+  struct cfx_pattern_s* live = nullptr;
+  cfx::DevArray<int64_t> indptr;
+  cfx::DevArray<int32_t> indices;
+  cfx::DevArray<uint8_t> sig;   // [ncells] signature of every cell in the step the pattern was built
+  std::vector<int> form_key;    // (type, kernel class) of the integrals: the same form structure only
+  int64_t nrows = 0;
+  bool valid = false;
+  void drop();
+};
+
 struct cfx_space_s
 {
   cfx_mesh_t mesh = nullptr;
@@ -624,6 +643,8 @@ struct cfx_space_s
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
   cfx::VecBlocks vblocks; // built on first use by cfx::space_vec_blocks()
+  cfx_pattern_cache pcache;          // previous pattern of this space (row reuse in moving-domain loops)
+  ~cfx_space_s() { pcache.drop(); }
   bool lists_short_overflow = false; // a short-list row overflowed the 128-slot set once: hashed rows all go wide
   bool long_rows = false; // a sparsity build of this space overflowed the 63-entry row sets: start with the wide kernel
   const cfx::Adjacency& dof_cells()
@@ -656,6 +677,8 @@ struct cfx_row_plan
   bool usable = false;             // row-gather assembly is legal for this form
   cfx::DevArray<uint8_t> mark_block; // cellmark | rowmark | special_mark in one block (one zero fill per plan)
   cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
+  cfx::DevArray<uint8_t> cellsig;  // bit 0: cellmark != 0; bit 1 + lf: side lf of the cell is a facet of the form (built on
+                                   // first use by cfx::plan_cell_signature: what a row's column set depends on)
   cfx::DevArray<uint8_t> rowmark;  // dof touched by any entity of the form
   cfx::DevArray<int32_t> active_rows;
   cfx::Count n_active_rows;
@@ -757,6 +780,9 @@ const VecBlocks& space_vec_blocks(cfx_space_s* V);                      // cfx_r
 bool vec_block_plan(cfx_form_s* L, uint8_t mark, bool merged);          // cfx_rowasm.hip
 void build_pattern(cfx_form_s* a, cfx_pattern_s* P);                    // cfx_rowasm.hip
 void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P);        // cfx_rowasm.hip
+void plan_cell_signature(cfx_form_s* a);                                // cfx_rowasm.hip
+bool pattern_reuse_ok(cfx_form_s* a);                                   // cfx_rowasm.hip
+void pattern_remember(cfx_form_s* a, cfx_pattern_s* P);                 // cfx_rowasm.hip
 void prepare_form_tables(cfx_form_s* a);                                // cfx_gather.hip
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values,
                           bool fresh = false);
@@ -770,10 +796,13 @@ void user_stage1(const cfx_form_s* a, const cfx_integral_dev& I, bool runtime, d
 
 struct cfx_pattern_s
 {
+  cfx_space_s* cache_owner = nullptr; // the space whose pattern cache points at this pattern (cfx_pattern_cache::live)
+  ~cfx_pattern_s();                   // hands the arrays to that cache (cfx_rowasm.hip)
   int64_t nrows = 0;
   cfx::Count nnz;
   int64_t ncols = 0; // = nrows unless the form is rectangular
   int max_row_len = 0; // upper bound on the scalar-dof row length
+  int64_t n_hashed_rows = 0, n_reused_rows = 0; // rows that needed a hash set / of which: copied from the space's previous pattern
   uint64_t built_plan = 0; // serial of the plan the pattern was built from (0: rectangular).  Only then are the rows off
                            // that plan's active set known to hold one diagonal entry each (the fused zero fill relies on it)
   uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)

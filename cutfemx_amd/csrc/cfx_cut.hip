@@ -368,18 +368,24 @@ __device__ __forceinline__ int sign_mask(const double* phi)
 constexpr int kPackShift = cfx::kCountPackShift; // (points, rules) of a cut cell packed into one int64 (see cfx_runtime_quadrature)
 constexpr int64_t kPackMask = (1ll << kPackShift) - 1;
 
-// per cut cell: number of rules and points it will emit for `part`
+// per cut cell: number of rules and points it will emit for each of the (one or two) parts asked for
+struct CountParts
+{
+  int n;
+  int part[2], nref[2];
+  int64_t* packed[2];
+};
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_count_kernel(DevN ncut_d, const int32_t* __restrict__ cut_cells,
                                                            const int32_t* __restrict__ ls_dofmap,
-                                                           const double* __restrict__ phi_v, int part, int nref,
-                                                           int64_t* __restrict__ packed)
+                                                           const double* __restrict__ phi_v, CountParts P)
 {
   const int64_t ncut = dev_n(ncut_d);
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= ncut)
   {
-    if (i < ncut_d.cap) packed[i] = 0; // list shorter than its capacity: the scan runs over the capacity
+    if (i < ncut_d.cap) // list shorter than its capacity: the scans run over the capacity
+      for (int k = 0; k < P.n; ++k) P.packed[k][i] = 0;
     return;
   }
   const int64_t c = cut_cells[i];
@@ -387,9 +393,13 @@ __global__ void __launch_bounds__(kBlock) cut_count_kernel(DevN ncut_d, const in
 #pragma unroll
   for (int v = 0; v <= TDIM; ++v) phi[v] = phi_v[ls_dofmap[c * (TDIM + 1) + v]];
   const CutCase& cs = c_cases[TDIM - 2][sign_mask<TDIM>(phi)];
-  const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
-  // points in the low kPackShift bits, rules above: one scan gives both offsets
-  packed[i] = (int64_t)(ns * nref) | ((int64_t)(part == PART_IF ? ns : (ns > 0 ? 1 : 0)) << kPackShift);
+  for (int k = 0; k < P.n; ++k)
+  {
+    const int part = P.part[k];
+    const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
+    // points in the low kPackShift bits, rules above: one scan gives both offsets
+    P.packed[k][i] = (int64_t)(ns * P.nref[k]) | ((int64_t)(part == PART_IF ? ns : (ns > 0 ? 1 : 0)) << kPackShift);
+  }
 }
 
 // parent-reference coordinates of local point p of the cut case
@@ -793,6 +803,10 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   int32_t* __restrict__ offsets = jobs.offsets[job];
   int32_t* __restrict__ parent_map = jobs.parent_map[job];
   const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
+  // the last cut cell closes the parent list with a sentinel (the list is allocated one entry longer): kernels that
+  // walk "the rules of cell c" stop there without knowing the number of rules, which may still be in HBM
+  if (lane == 0 && i == ncut - 1)
+    parent_map[(packed_off[i] >> kPackShift) + (part == PART_IF ? ns : (ns > 0 ? 1 : 0))] = -1;
   if (ns == 0) continue;
   int nref;
   const double* wref;
@@ -2241,25 +2255,28 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
   require(ncut < (1ll << 26), CFX_ERR_RUNTIME, "runtime quadrature: more than 2^26 cut cells");
   std::unique_ptr<cfx_rules_s> r[2];
   DevArray<int64_t> packed[2], packed_off[2];
+  CountParts cparts{};
+  cparts.n = n;
   for (int k = 0; k < n; ++k)
   {
-    const int nref = quad_npoints(parts[k] == PART_IF ? tdim - 1 : tdim, order);
     r[k] = std::make_unique<cfx_rules_s>();
     r[k]->mesh = mesh; r[k]->tdim = tdim; r[k]->gdim = mesh->gdim;
     packed[k].alloc(ncut);
     packed_off[k].alloc(ncut + 1);
-    if (ncut > 0)
-    {
-      if (tdim == 2)
-        launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi,
-               parts[k], nref, packed[k].p);
-      else
-        launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi,
-               parts[k], nref, packed[k].p);
-    }
-    // one scan for both totals of a part: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so below
-    // 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
+    cparts.part[k] = parts[k];
+    cparts.nref[k] = quad_npoints(parts[k] == PART_IF ? tdim - 1 : tdim, order);
+    cparts.packed[k] = packed[k].p;
   }
+  if (ncut > 0)
+  {
+    // (both parts from one pass over the cut cells)
+    if (tdim == 2)
+      launch("cut_count", cut_count_kernel<2>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi, cparts);
+    else
+      launch("cut_count", cut_count_kernel<3>, grid_for(ncut), dim3(kBlock), 0, ncut_d, cutc.p, cut->ls_dofmap.p, phi, cparts);
+  }
+  // one scan for both totals of a part: a cut cell emits at most 3 sub-simplices x 64 points and 2 rules, so below
+  // 2^26 cut cells the point prefix stays under 2^34 and the rule prefix under 2^27 (no carry, no sign bit).
   // the totals of all parts in one round trip (none inside a step: they stay in HBM, published by the last scan)
   const char* names[4] = {"rules.points.0", "rules.rules.0", "rules.points.1", "rules.rules.1"};
   CountSource src[4];
@@ -2283,7 +2300,8 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     r[k]->points.alloc(nq * tdim);
     r[k]->weights.alloc(nq);
     r[k]->offsets.alloc(nr + 1);
-    r[k]->parent_map.alloc(nr);
+    r[k]->parent_map.alloc(nr + 1); // (+ the sentinel behind the last rule, cut_emit_kernel)
+    r[k]->parent_sentinel = true;
     // (offsets[0] = 0 is written by the cell that emits rule 0; an empty rule set gets it here)
     if (ncut == 0 || nr == 0) dev_fill(r[k]->offsets.p, 0, sizeof(int32_t));
     jobs.part[k] = parts[k]; jobs.packed_off[k] = packed_off[k].p;

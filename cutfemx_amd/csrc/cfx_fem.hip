@@ -1920,6 +1920,15 @@ int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* v)
   CFX_API_END
 }
 
+int cfx_pattern_reuse_stats(cfx_pattern_t p, int64_t* hashed_rows, int64_t* reused_rows)
+{
+  CFX_API_BEGIN
+  require(p != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_pattern_reuse_stats: null handle");
+  if (hashed_rows) *hashed_rows = p->n_hashed_rows;
+  if (reused_rows) *reused_rows = p->n_reused_rows;
+  CFX_API_END
+}
+
 int cfx_pattern_destroy(cfx_pattern_t p)
 {
   CFX_API_BEGIN

@@ -3735,6 +3735,14 @@ struct Stage1
   DevArray<double> part;    // ... the partials of the step
 };
 
+// bound of the walks "for (e = first rule of c; e < bound && parent_map[e] == c; ++e)": the number of rules -- or, when
+// it is still in HBM and the list ends with a sentinel, the capacity + 1 as a plain number (no load in the loop)
+inline DevN rule_bound(const cfx_rules_s* R)
+{
+  if (R->nr.pending() && R->parent_sentinel) return DevN(R->nr.cap() + 1);
+  return R->nr.devn();
+}
+
 inline VecArgs vec_args(cfx_form_s* L, const cfx_integral_dev& I)
 {
   cfx_space_s* V = L->V;
@@ -3933,12 +3941,12 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     if (n_rules > 0 && combine_cuts)
     {
       // (the rule lookups stay valid for the kernels that ask for them; nothing is staged per integral)
-      R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
+      R.parent_map = I.rules->parent_map.p; R.nr = rule_bound(I.rules);
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
     }
     else if (n_rules > 0)
     {
-      R.parent_map = I.rules->parent_map.p; R.nr = I.rules->nr;
+      R.parent_map = I.rules->parent_map.p; R.nr = rule_bound(I.rules);
       R.rule_keys = plan.rule_keys[s].p; R.rule_first = plan.rule_first[s].p; R.rule_mask = plan.rule_mask[s];
       const char* cm = getenv("CFX_P2_MOMENTS");
       const bool moments = DEG == 2 && BS == 1 && a->rank == 2 && I.kernel == CFX_K_STIFFNESS && I.coefficient.n == 0

@@ -116,15 +116,33 @@ __global__ void __launch_bounds__(kBlock) plan_mark_entities_kernel(DevN n_d, co
 
 // runtime rules of a cell integral, nd <= 4: one pass over the parent list -- ascending check, and at the first
 // rule of every parent its cell mark, row marks (special rows) and hash-map entry parent -> first rule
-template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_rules_kernel(DevN nr_d, const int32_t* __restrict__ parent,
-                                                            const int32_t* __restrict__ dofmap, uint8_t bit, uint8_t* mark,
-                                                            uint8_t* rowmark, uint8_t* special, uint32_t hmask,
-                                                            int32_t* __restrict__ keys, int32_t* __restrict__ first, int* flag)
+// (the rule sets of all cell integrals of a form in one launch: job k covers the threads [start[k], start[k + 1]))
+struct RuleJobs
 {
-  const int64_t nr = dev_n(nr_d);
-  const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int n;
+  int64_t start[5];
+  DevN nr[4];
+  const int32_t* parent[4];
+  uint8_t bit[4];
+  uint32_t hmask[4];
+  int32_t* keys[4];
+  int32_t* first[4];
+};
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_rules_kernel(RuleJobs J, const int32_t* __restrict__ dofmap, uint8_t* mark,
+                                                            uint8_t* rowmark, uint8_t* special, int* flag)
+{
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  int k = 0;
+  while (k + 1 < J.n && t >= J.start[k + 1]) ++k;
+  const int64_t e = t - J.start[k];
+  const int64_t nr = dev_n(J.nr[k]);
   if (e >= nr) return;
+  const int32_t* __restrict__ parent = J.parent[k];
+  const uint8_t bit = J.bit[k];
+  const uint32_t hmask = J.hmask[k];
+  int32_t* __restrict__ keys = J.keys[k];
+  int32_t* __restrict__ first = J.first[k];
   const int32_t c = parent[e];
   if (e > 0)
   {
@@ -132,7 +150,9 @@ __global__ void __launch_bounds__(kBlock) plan_rules_kernel(DevN nr_d, const int
     if (prev > c) atomicOr(flag, 1);
     if (prev == c) return;
   }
-  mark[c] = mark[c] | bit;
+  // (two jobs of this launch may mark the same cell with different bits: a word-wide atomic OR on the byte's word;
+  // the mark array starts on a 16 B boundary and is padded to a multiple of four)
+  atomicOr(reinterpret_cast<unsigned int*>(mark + (c & ~3)), (unsigned int)bit << (8 * (c & 3)));
 #pragma unroll
   for (int j = 0; j < ND; ++j)
   {
@@ -1470,6 +1490,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
     }
   }
+  RuleJobs rjobs{};
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
@@ -1507,14 +1528,14 @@ cfx_row_plan& row_plan(cfx_form_s* a)
         // (the key tables of all slots in one block, emptied by one fill: see rule_key_block above)
         P.rule_keys[slot].p = P.rule_key_block.p + key_off[slot]; P.rule_keys[slot].n = size; P.rule_keys[slot].owned = false;
         P.rule_first[slot].alloc(size);
-        if (nd == 4)
-          launch("plan_rules", plan_rules_kernel<4>, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
-                 I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
-                 P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
-        else if (nd == 3)
-          launch("plan_rules", plan_rules_kernel<3>, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
-                 I.rules->parent_map.p, V->dofmap.p, (uint8_t)(16u << slot), P.cellmark.p, P.rowmark.p, special.p,
-                 P.rule_mask[slot], P.rule_keys[slot].p, P.rule_first[slot].p, flag.p);
+        if (nd == 4 || nd == 3)
+        {
+          // (queued: the rule sets of all slots go in one launch behind this loop)
+          const int k = rjobs.n++;
+          rjobs.start[k + 1] = rjobs.start[k] + ((nr + kBlock - 1) / kBlock) * kBlock;
+          rjobs.nr[k] = I.rules->nr; rjobs.parent[k] = I.rules->parent_map.p; rjobs.bit[k] = (uint8_t)(16u << slot);
+          rjobs.hmask[k] = P.rule_mask[slot]; rjobs.keys[k] = P.rule_keys[slot].p; rjobs.first[k] = P.rule_first[slot].p;
+        }
         else
         {
           launch("plan_mark_cells", plan_mark_cells_kernel, grid_for(nr), dim3(kBlock), 0, I.rules->nr,
@@ -1535,6 +1556,15 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       P.facet_slot_integral[P.n_facet_slots++] = (int)ii;
       if (ne > 0) ++n_facet_lists;
     }
+  }
+  if (rjobs.n > 0)
+  {
+    if (nd == 4)
+      launch("plan_rules", plan_rules_kernel<4>, grid_for(rjobs.start[rjobs.n]), dim3(kBlock), 0, rjobs, V->dofmap.p,
+             P.cellmark.p, P.rowmark.p, special.p, flag.p);
+    else
+      launch("plan_rules", plan_rules_kernel<3>, grid_for(rjobs.start[rjobs.n]), dim3(kBlock), 0, rjobs, V->dofmap.p,
+             P.cellmark.p, P.rowmark.p, special.p, flag.p);
   }
   // the facet rows of all facet integrals, concatenated: one list keeps its (possibly pending) length, several are
   // joined at their exact lengths
@@ -2216,11 +2246,135 @@ __global__ void mark_cells_u8_kernel(int64_t n, const int32_t* __restrict__ cell
   if (i < n) mark[cells[i]] = 1;
 }
 
+// ---------------------------------------------------------------------------
+// Row reuse between the patterns of consecutive steps (cfx_pattern_cache)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock) cellsig_marks_kernel(int64_t n, const uint8_t* __restrict__ cellmark, uint8_t* __restrict__ sig)
+{
+  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (c < n) sig[c] = cellmark[c] ? 1 : 0;
+}
+// side lf of cell c is a facet of the form: bit 1 + lf of the cell's signature (word-wide atomic OR on the byte)
+__global__ void __launch_bounds__(kBlock) cellsig_facets_kernel(int64_t nf, const int32_t* __restrict__ rows, uint8_t* sig)
+{
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= 2 * nf) return;
+  const int64_t c = rows[4 * (t >> 1) + 2 * (t & 1)];
+  const int lf = rows[4 * (t >> 1) + 2 * (t & 1) + 1];
+  atomicOr(reinterpret_cast<unsigned int*>(sig + (c & ~3)), (2u << lf) << (8 * (c & 3)));
+}
+// clean[i] = every incident cell of hashed row i has the signature it had when the previous pattern was built; a clean
+// row's length is the one it had there (expanded rows of a block space: bs rows per dof)
+__global__ void __launch_bounds__(kBlock) row_clean_kernel(int64_t n, const int32_t* __restrict__ rows,
+                                                           const int64_t* __restrict__ d2c_off, const int32_t* __restrict__ d2c,
+                                                           const uint8_t* __restrict__ sig, const uint8_t* __restrict__ prev_sig,
+                                                           const int64_t* __restrict__ prev_indptr, int bs,
+                                                           uint8_t* __restrict__ clean, int32_t* __restrict__ counts, int* maxlen)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = rows[i];
+  bool same = true;
+  for (int64_t k = d2c_off[r]; k < d2c_off[r + 1]; ++k)
+  {
+    const int32_t c = d2c[k];
+    same = same && sig[c] == prev_sig[c];
+  }
+  clean[i] = same ? 1 : 0;
+  if (!same) return;
+  for (int a = 0; a < bs; ++a)
+  {
+    const int len = (int)(prev_indptr[r * bs + a + 1] - prev_indptr[r * bs + a]);
+    counts[r * bs + a] = len;
+    if (a == 0 && len / bs > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, len / bs);
+  }
+}
+// the columns of the clean rows from the previous pattern: G lanes per dof
+template <int G>
+__global__ void __launch_bounds__(kBlock) pattern_copy_prev_kernel(int64_t n, const int32_t* __restrict__ rows, int bs,
+                                                                   const int64_t* __restrict__ prev_indptr,
+                                                                   const int32_t* __restrict__ prev_indices,
+                                                                   const int64_t* __restrict__ indptr, int32_t* __restrict__ indices)
+{
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t i = t / G;
+  if (i >= n) return;
+  const int gl = (int)(t - i * G);
+  const int64_t r = rows[i];
+  for (int a = 0; a < bs; ++a)
+  {
+    const int64_t pb = prev_indptr[r * bs + a], ob = indptr[r * bs + a];
+    const int len = (int)(prev_indptr[r * bs + a + 1] - pb);
+    for (int k = gl; k < len; k += G) indices[ob + k] = prev_indices[pb + k];
+  }
+}
+
 // Sparsity of a form whose test and trial spaces differ (assembler.h:442-529 with two dofmaps): row dof r of the test
 // space couples to the trial-space dofs of every cell of a cell integral (standard entity or rule parent) that
 // contains r.  No all-rows diagonal (assembler.h:537-560: only when the two index maps coincide).  One wavefront per
 // test-space dof, a 512-slot LDS set of trial dofs, count pass + write pass: the rectangular blocks are a small part
 // of a system's assembly, the kernel is the general one of the square patterns.
+// what the column set of a row depends on, cell by cell: "carries a mark of the form" and "which sides are facets of it"
+void plan_cell_signature(cfx_form_s* a)
+{
+  cfx_row_plan& plan = row_plan(a);
+  if (plan.cellsig.n > 0) return;
+  const int64_t nc = a->V->mesh->ncells;
+  plan.cellsig.alloc((nc + 3) & ~3LL);
+  launch("pattern_reuse", cellsig_marks_kernel, grid_for(nc), dim3(kBlock), 0, nc, plan.cellmark.p, plan.cellsig.p);
+  const int64_t nf = plan.nfacets.value();
+  if (nf > 0)
+    launch("pattern_reuse", cellsig_facets_kernel, grid_for(2 * nf), dim3(kBlock), 0, nf, plan.facet_rows.p, plan.cellsig.p);
+}
+
+// (type, kernel class) of a form's integrals: facet rows must be sides of mesh facets -- the (bad, root) pairs of the
+// extension penalty are not -- and the previous pattern must come from a form of the same structure
+static std::vector<int> pattern_form_key(const cfx_form_s* a, bool& ok)
+{
+  std::vector<int> key;
+  ok = true;
+  for (const auto& I : a->integrals)
+  {
+    if (I.type == CFX_INTERIOR_FACET && I.kernel == CFX_K_EXTENSION_L2) ok = false;
+    key.push_back(I.type);
+  }
+  return key;
+}
+
+bool pattern_reuse_ok(cfx_form_s* a)
+{
+  const char* e = getenv("CFX_PATTERN_REUSE");
+  if (e && e[0] == '0') return false;
+  cfx_space_s* V = a->V;
+  const cfx_pattern_cache& pc = V->pcache;
+  bool ok = true;
+  const std::vector<int> key = pattern_form_key(a, ok);
+  return ok && pc.valid && pc.nrows == V->ndofs * V->bs && pc.form_key == key && (pc.live != nullptr || pc.indptr.n > 0);
+}
+
+// the pattern just built becomes the space's previous pattern
+void pattern_remember(cfx_form_s* a, cfx_pattern_s* P)
+{
+  const char* e = getenv("CFX_PATTERN_REUSE");
+  cfx_space_s* V = a->V;
+  cfx_row_plan& plan = row_plan(a);
+  const Stencil& st = space_stencil(V);
+  bool ok = true;
+  const std::vector<int> key = pattern_form_key(a, ok);
+  // (the stencil path -- P1 on the geometry dofmap -- describes its rows by masks and has no use for the cache)
+  if ((e && e[0] == '0') || st.usable || !plan.any_cells || !ok || a->rectangular()) return;
+  plan_cell_signature(a);
+  cfx_pattern_cache& pc = V->pcache;
+  pc.drop();
+  pc.sig.alloc(plan.cellsig.n);
+  CFX_HIP(hipMemcpyAsync(pc.sig.p, plan.cellsig.p, (size_t)plan.cellsig.n, hipMemcpyDeviceToDevice, ctx().stream));
+  pc.form_key = key;
+  pc.nrows = P->nrows;
+  pc.live = P;
+  P->cache_owner = V;
+  pc.valid = true;
+}
+
 void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
 {
   cfx_space_s* V0 = a->V;
@@ -2307,8 +2461,45 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
              hashed.p + n_special_x);
     rows_h = hashed.p;
   }
+  // Moving-domain loops: a hashed row whose incident cells kept their signature since the previous pattern of this space
+  // couples the same columns as before -- it copies them (below, once the row offsets are known) instead of building
+  // and ranking its hash set again.  Only the rows around cells that changed go through the hash sets.
+  int64_t n_d = n_h;                 // rows that are hashed in this build
+  const int32_t* rows_d = rows_h;
+  DevArray<int32_t> dirty_rows, clean_rows;
+  int64_t n_clean = 0;
+  ZeroFlag reuse_maxlen;
+  const bool reuse = !use_stencil && n_h > 0 && plan.any_cells && pattern_reuse_ok(a);
+  P->n_hashed_rows = use_stencil ? 0 : n_h;
+  P->n_reused_rows = 0;
+  if (reuse)
+  {
+    const Adjacency& adj = V->dof_cells();
+    plan_cell_signature(a);
+    const cfx_pattern_cache& pc = V->pcache;
+    const int64_t* prev_indptr = pc.live ? pc.live->indptr.p : pc.indptr.p;
+    DevArray<uint8_t> clean(n_h);
+    launch("pattern_reuse", row_clean_kernel, grid_for(n_h), dim3(kBlock), 0, n_h, rows_h, adj.offsets.p, adj.cells.p,
+           plan.cellsig.p, pc.sig.p, prev_indptr, V->bs, clean.p, counts.p, reuse_maxlen.p);
+    DevArray<int32_t> idx_d, idx_c;
+    n_d = compact("pattern_reuse", n_h, FlagIsZero{clean.p}, idx_d);
+    n_clean = n_h - n_d;
+    dirty_rows.alloc(n_d);
+    if (n_d > 0)
+      launch("pattern_reuse", gather_i32_kernel, grid_for(n_d), dim3(kBlock), 0, n_d, idx_d.p, rows_h, dirty_rows.p);
+    if (n_clean > 0)
+    {
+      (void)compact("pattern_reuse", n_h, FlagSet8{clean.p}, idx_c);
+      clean_rows.alloc(n_clean);
+      launch("pattern_reuse", gather_i32_kernel, grid_for(n_clean), dim3(kBlock), 0, n_clean, idx_c.p, rows_h, clean_rows.p);
+    }
+    rows_d = dirty_rows.p;
+    P->n_reused_rows = n_clean;
+    if (getenv("CFX_PLAN_DEBUG"))
+      fprintf(stderr, "cutfemx_amd: pattern reuse: %lld of %lld hashed rows copy their columns\n", (long long)n_clean, (long long)n_h);
+  }
   PatArgs S{};
-  S.n_active = use_stencil ? n_h_c.devn() : DevN(n_h); S.active_rows = rows_h;
+  S.n_active = use_stencil ? n_h_c.devn() : DevN(n_d); S.active_rows = rows_d;
   S.nd = V->ndofs_cell; S.bs = V->bs; S.dofmap = V->dofmap.p;
   if (plan.any_cells)
   {
@@ -2320,7 +2511,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     S.d2f_off = plan.d2f_offsets.p; S.d2f = plan.d2f.p; S.facet_rows = plan.facet_rows.p;
     S.special_mark = plan.special_mark.p; S.special_pos = plan.special_pos.p;
   }
-  DevArray<int32_t> len(n_h), tmp;
+  DevArray<int32_t> len(n_d), tmp;
   ZeroFlag overflow, maxlen;
   // (the rows off the active set are never read from `counts`: indptr_*_kernel knows their length)
   S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;
@@ -2333,18 +2524,18 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   bool staged_sets = false;
   int64_t n_short = 0, n_long = 0;
   bool split_hashed = false;
-  if (use_lists && n_h > 0 && !V->lists_short_overflow)
+  if (use_lists && n_d > 0 && !V->lists_short_overflow)
   {
-    n_short = compact("pattern_split", n_h, StaticLenTest{rows_h, st.offsets.p, kShortLen, false}, short_idx);
-    n_long = n_h - n_short;
+    n_short = compact("pattern_split", n_d, StaticLenTest{rows_d, st.offsets.p, kShortLen, false}, short_idx);
+    n_long = n_d - n_short;
     short_rows.alloc(n_short);
     long_rows.alloc(n_long);
     if (n_short > 0)
-      launch("pattern_split", gather_i32_kernel, grid_for(n_short), dim3(kBlock), 0, n_short, short_idx.p, rows_h, short_rows.p);
+      launch("pattern_split", gather_i32_kernel, grid_for(n_short), dim3(kBlock), 0, n_short, short_idx.p, rows_d, short_rows.p);
     if (n_long > 0)
     {
-      compact("pattern_split", n_h, StaticLenTest{rows_h, st.offsets.p, kShortLen, true}, long_idx);
-      launch("pattern_split", gather_i32_kernel, grid_for(n_long), dim3(kBlock), 0, n_long, long_idx.p, rows_h, long_rows.p);
+      compact("pattern_split", n_d, StaticLenTest{rows_d, st.offsets.p, kShortLen, true}, long_idx);
+      launch("pattern_split", gather_i32_kernel, grid_for(n_long), dim3(kBlock), 0, n_long, long_idx.p, rows_d, long_rows.p);
     }
     split_hashed = true;
     T = 512;
@@ -2362,8 +2553,8 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     }
     S1.n_active = n_short; S1.active_rows = short_rows.p; S1.tmp = staged_sets ? tmp_short.p : nullptr;
     S2.n_active = n_long; S2.active_rows = long_rows.p; S2.tmp = staged_sets ? tmp_long.p : nullptr; S2.len = len.p + n_short;
-    // rows_h = [the plan's special rows in plan order | other rows]: the position in rows_h is the facet-incidence index
-    if (rows_h == hashed.p && plan.nfacets.cap() > 0)
+    // rows_d = [the plan's special rows in plan order | other rows]: the position in rows_d is the facet-incidence index
+    if (rows_d == hashed.p && plan.nfacets.cap() > 0)
     {
       S1.row_pos = short_idx.p; S1.n_first = n_special_x;
       if (n_long > 0) { S2.row_pos = long_idx.p; S2.n_first = n_special_x; }
@@ -2380,14 +2571,14 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     }
   }
   bool deferred = false;
-  if (n_h > 0 && !split_hashed)
+  if (n_d > 0 && !split_hashed)
   {
     bool wide = V->long_rows;
     if (!wide)
     {
-      tmp.alloc(n_h * 64);
+      tmp.alloc(n_d * 64);
       S.tmp = tmp.p;
-      launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((n_h + 15) / 16), dim3(kWave), 0, S);
+      launch("pattern_rows", pattern_rows_kernel<4, 64>, wave_grid((n_d + 15) / 16), dim3(kWave), 0, S);
       // stencil path (P1): the overflow flag travels with the longest row and nnz in ONE read-back further down; an
       // overflow (a row with more than 63 columns) then restarts the build on the wide path
       if (use_stencil) deferred = true;
@@ -2404,9 +2595,11 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       maxlen.zero();
       tmp.release();
       S.tmp = nullptr;
-      S.n_active = DevN(n_h_c.value());
-      n_h = S.n_active.cap;
-      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_h), dim3(kWave), 0, S);
+      // (the stencil path may have come here with its row count still in HBM: the wide kernels take it exact; the
+      // other paths hash the list they were given -- n_d rows, exact already)
+      if (use_stencil) { S.n_active = DevN(n_h_c.value()); n_d = S.n_active.cap; }
+      else S.n_active = DevN(n_d);
+      launch("pattern_rows_wide", pattern_rows_kernel<64, 512>, wave_grid(n_d), dim3(kWave), 0, S);
       require(!read_scalar(overflow.p), CFX_ERR_RUNTIME, "sparsity: a row couples more than 511 dofs");
     }
   }
@@ -2418,6 +2611,7 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   if (!deferred) P->max_row_len = plan.n_active_rows.cap() > 0 ? read_scalar(maxlen.p) : 1;
   if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list
+  if (reuse && n_clean > 0) P->max_row_len = std::max(P->max_row_len, read_scalar(reuse_maxlen.p)); // ... or of the previous pattern
   if (getenv("CFX_PLAN_DEBUG")) fprintf(stderr, "cutfemx_amd: pattern max row length %d (static lists %d)\n", P->max_row_len, st.max_len);
   P->indptr.alloc(P->nrows + 1);
   {
@@ -2461,6 +2655,12 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   else if (use_stencil)
     launch("pattern_plain_write", pattern_plain_write_kernel, grid_for(plan.n_plain_rows.cap() * CFX_PPW_LANES), dim3(kBlock), 0,
            plan.n_plain_rows, plan.plain_rows.p, plan.plain_masks.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
+  if (reuse && n_clean > 0)
+  {
+    const cfx_pattern_cache& pc = V->pcache;
+    launch("pattern_reuse", pattern_copy_prev_kernel<8>, grid_for(n_clean * 8), dim3(kBlock), 0, n_clean, clean_rows.p, V->bs,
+           pc.live ? pc.live->indptr.p : pc.indptr.p, pc.live ? pc.live->indices.p : pc.indices.p, P->indptr.p, P->indices.p);
+  }
   if (any_full && V->bs == 1)
     launch("pattern_plain_write", pattern_plain_copy_runs_kernel, wave_grid((n_plain_x + kWave - 1) / kWave), dim3(kWave), 0,
            n_plain_x, plan.plain_rows.p, full.p, st.offsets.p, st.nbr.p, P->indptr.p, P->indices.p);
@@ -2484,15 +2684,15 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     if (n_short > 0) launch("pattern_rows_short_write", pattern_rows_kernel<16, 128>, wave_grid((n_short + 3) / 4), dim3(kWave), 0, S1);
     if (n_long > 0) launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(n_long), dim3(kWave), 0, S2);
   }
-  else if (n_h > 0)
+  else if (n_d > 0)
   {
     if (T == 64)
-      launch("pattern_write", pattern_write_kernel<64>, grid_for(n_h * 8), dim3(kBlock), 0, S.n_active, rows_h, V->bs, tmp.p,
+      launch("pattern_write", pattern_write_kernel<64>, grid_for(n_d * 8), dim3(kBlock), 0, S.n_active, rows_d, V->bs, tmp.p,
              len.p, P->indptr.p, P->indices.p);
     else
     {
       S.indptr = P->indptr.p; S.indices = P->indices.p;
-      launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(n_h), dim3(kWave), 0, S);
+      launch("pattern_rows_wide_write", pattern_rows_kernel<64, 512>, wave_grid(n_d), dim3(kWave), 0, S);
     }
   }
   // full_rows = [dofs with at most 32 neighbours | the others]: the edge dofs of a degree-2 space (7 of 8 dofs, at most
@@ -2585,6 +2785,29 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
            base_rows, P->long_rows.p);
     P->split_plan = plan.serial;
   }
+  pattern_remember(a, P);
 }
 
 } // namespace cfx
+
+// the pattern a space's cache points at dies: its arrays move to the cache (no copy)
+cfx_pattern_s::~cfx_pattern_s()
+{
+  if (cache_owner && cache_owner->pcache.live == this)
+  {
+    cfx_pattern_cache& pc = cache_owner->pcache;
+    pc.indptr = std::move(indptr);
+    pc.indices = std::move(indices);
+    pc.live = nullptr;
+  }
+}
+
+void cfx_pattern_cache::drop()
+{
+  if (live) live->cache_owner = nullptr;
+  live = nullptr;
+  indptr.release();
+  indices.release();
+  sig.release();
+  valid = false;
+}

@@ -319,6 +319,13 @@ class MatrixCSR:
         return self._nnz
 
     @property
+    def reuse_stats(self) -> tuple[int, int]:
+        """(rows of the pattern that needed a hash set, those of them copied from the space's previous pattern)."""
+        h, r = C.c_int64(), C.c_int64()
+        _lib.check(_lib.lib().cfx_pattern_reuse_stats(self._p, C.byref(h), C.byref(r)))
+        return h.value, r.value
+
+    @property
     def values_ptr(self):
         """HBM address of the value array; a pending set_value(0) is carried out first."""
         if self._zero_pending:

@@ -396,6 +396,12 @@ int cfx_form_prepare(cfx_form_t a);
 /* create_sparsity_pattern(): assembler.h:567-592 (+ :442-529, :538-560) */
 int cfx_create_sparsity(cfx_form_t a, cfx_pattern_t* out);
 int cfx_pattern_view_get(cfx_pattern_t p, cfx_pattern_view* view);
+/* Moving-domain loops: the pattern of a space whose rows come from hash sets (degree 2, vector-valued, DG spaces)
+ * remembers the previous pattern of that space; a row whose incident cells kept their marks and facet sides since then
+ * copies its columns instead of being hashed and ranked again (CFX_PATTERN_REUSE=0 switches this off; the result is the
+ * same pattern bit for bit).  hashed_rows: rows of this pattern that needed a hash set; reused_rows: those of them
+ * that were copied.  The reference rebuilds every pattern from scratch (cut.cpp:845-868 + assembler.h:567-592). */
+int cfx_pattern_reuse_stats(cfx_pattern_t p, int64_t* hashed_rows, int64_t* reused_rows);
 int cfx_pattern_destroy(cfx_pattern_t p);
 /* assemble_matrix(): assembler.h:690-703 -> assemble_matrix_impl.h:629-810.
  * Accumulates into values[nnz] (HBM); bc0/bc1 int8 markers or NULL. */

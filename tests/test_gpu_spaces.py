@@ -748,3 +748,61 @@ def test_block_deactivation_uses_per_row_active_domains(oracle):
         fem.zero_block_rows([[None, A01], [A10, A11]])
     with pytest.raises(RuntimeError, match="one RHS vector per block row"):
         fem.deactivate_outside_blocks(A_blocks, domains, b_blocks[:1])
+
+
+@pytest.mark.parametrize("tdim,n,degree,bs", [(2, 14, 2, 1), (3, 6, 2, 1), (3, 5, 2, 3), (2, 12, 1, 2)])
+def test_pattern_rows_are_reused_between_the_steps_of_a_moving_domain(oracle, tdim, n, degree, bs, monkeypatch):
+    # cut.cpp:845-868 + assembler.h:567-592 rebuild the pattern every step; the engine copies the rows whose incident
+    # cells kept their marks and facet sides from the previous pattern of the space.  After K moving steps the pattern
+    # must equal a from-scratch build (CFX_PATTERN_REUSE=0) and the oracle's, bit for bit, and some rows must have
+    # been copied, some hashed.
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, degree)
+    oV = O.Space(dofmap, ndofs, degree, bs)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, degree, dofmap=None if degree == 1 else dofmap, ndofs=ndofs, bs=bs)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    kern_g, kern_o = (fem.ELASTICITY, O.K_ELASTICITY) if bs > 1 else (fem.STIFFNESS, O.K_STIFFNESS)
+    params = (1.0, 0.3) if bs > 1 else ()
+    reused_total = hashed_total = 0
+    for k in range(4):
+        c = np.array([0.40 + 0.013 * k, 0.45, 0.5][:tdim])
+        phi = np.linalg.norm(om.x[:, :tdim] - c, axis=1) - 0.27
+        cd = cfx.cut(cfx.Function(Vphi, phi))
+        dom = O.classify(om.conn, phi)
+        inside = cfx.locate_entities(cd, "phi<0")
+        vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+
+        def gform():
+            ints = [fem.Integral(kern_g, cells=inside, rules=vol, params=params, qdegree=2)]
+            if ghost.size > 0:
+                ints.append(fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2))
+            return fem.form(ints, V)
+        A = fem.create_matrix(gform())
+        hashed, reused = A.reuse_stats
+        hashed_total += hashed
+        reused_total += reused
+        if k == 0:
+            assert reused == 0
+        monkeypatch.setenv("CFX_PATTERN_REUSE", "0")
+        A0 = fem.create_matrix(gform())
+        monkeypatch.delenv("CFX_PATTERN_REUSE")
+        assert A0.reuse_stats[1] == 0
+        o_in = O.locate_entities(dom, "phi<0")
+        o_vol = O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", 2)
+        o_ghost = O.ghost_penalty_facets(om, dom, "phi<0")
+        o_ints = [O.Integral(O.CELL, kern_o, entities=o_in, rules=o_vol, params=params, qdegree=2)]
+        if len(o_ghost):
+            o_ints.append(O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=o_ghost, params=(0.1,), qdegree=2))
+        ip, ix = O.create_sparsity(om, oV, o_ints)
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
+        assert np.array_equal(A0.indptr, ip) and np.array_equal(A0.indices, ix)
+        # the values assembled into the reused pattern equal the oracle's too
+        want = O.assemble_matrix(om, oV, o_ints, ip, ix)
+        assert rel_err(fem.assemble_matrix(gform(), A=A).data, want) < RTOL
+        del A0
+    assert 0 < reused_total < hashed_total, (reused_total, hashed_total)

@@ -83,12 +83,13 @@ def test_moving_domain_loop_in_sync_free_steps(oracle, tdim, n):
         published.append(info["published"])
         assert info["passes"] == 1, info     # a slowly moving interface fits the previous step's capacities
         seen.append(check_against_oracle(oracle, om, phi, state["cd"], system, A, b, dom))
-    assert published[0] == 0 and all(p > 5 for p in published[1:]), published   # first step: sized by read-backs
     # the point of the exercise: from the second step on, at most two host round trips per step -- on the default path
-    # (a diagnostic switch such as CFX_STENCIL=0 selects kernels that read a pending count back on demand: same results)
+    # (a diagnostic switch such as CFX_STENCIL=0 selects kernels that read a pending count back on demand, and
+    # CFX_STEP_SPECULATE=0 publishes nothing at all: same results)
     import os
     switches = [k for k in os.environ if k.startswith("CFX_") and k not in ("CFX_STEP_DEBUG", "CFX_COUNT_SYNC", "CFX_DEVICE")]
     if not switches:
+        assert published[0] == 0 and all(p > 5 for p in published[1:]), published   # first step: sized by read-backs
         assert all(s <= 2 for s in syncs[1:]), syncs
     assert len(set(seen)) > 1   # the pattern really changed between steps
 

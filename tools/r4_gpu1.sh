@@ -1,5 +1,5 @@
 set -o pipefail
 mkdir -p gpurun_out/r4
-timeout -k 10 600 python -m pytest tests/test_user_integrands.py tests/test_gpu_step.py tests/test_gpu_spaces.py -x -q -m gpu > gpurun_out/r4/t_step.log 2>&1; rc=$?
-tail -n 40 gpurun_out/r4/t_step.log
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > gpurun_out/r4/t_all.log 2>&1; rc=$?
+tail -n 12 gpurun_out/r4/t_all.log
 exit $rc

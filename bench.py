@@ -610,8 +610,12 @@ def secondary_p2_gyroid(torch, device, n=256):
     ax = torch.arange(n + 1, device=device, dtype=torch.float64) / n
     Z, Y, X = ax[:, None, None], ax[None, :, None], ax[None, None, :]
     k = 2.0 * math.pi * 4.0
-    g = torch.sin(k * X) * torch.cos(k * Y) + torch.sin(k * Y) * torch.cos(k * Z) + torch.sin(k * Z) * torch.cos(k * X)
-    phi = cfx.Function(Vphi, (g + 0.0137).reshape(-1).contiguous())
+    def gyroid(shift=0.0):
+        Xs = X + shift
+        return (torch.sin(k * Xs) * torch.cos(k * Y) + torch.sin(k * Y) * torch.cos(k * Z) + torch.sin(k * Z) * torch.cos(k * Xs)
+                + 0.0137).reshape(-1).contiguous()
+    phi_values = gyroid()
+    phi = cfx.Function(Vphi, phi_values)
     dm, nd = cfx.box_lagrange2_dofmap(mesh, n, device)
     V = cfx.FunctionSpace(mesh, 2, dofmap=dm, ndofs=nd)
     b = torch.zeros(nd, device=device, dtype=torch.float64)
@@ -639,7 +643,42 @@ def secondary_p2_gyroid(torch, device, n=256):
                     n_ghost=0 if sysm.ghost_facets is None else sysm.ghost_facets.size)
     from cutfemx_amd import _lib
     _lib.memory_stats(reset_peak=True)
-    ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+    # (the step re-cuts ONE level set: every pattern row would be "unchanged since the last step" -- the row reuse of
+    # moving-domain loops is switched off for this line, which stays a full rebuild as in rounds 1-3, and measured on a
+    # gyroid that really moves below)
+    os.environ["CFX_PATTERN_REUSE"] = "0"
+    try:
+        ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+        kernels_ms = _kernel_times(step)
+    finally:
+        os.environ.pop("CFX_PATTERN_REUSE", None)
+
+    def moving(reuse, nsteps=4, shift_h=0.3):
+        """create_matrix of the MOVING gyroid (shifted by shift_h cells along x per step), with and without row reuse"""
+        os.environ["CFX_PATTERN_REUSE"] = "1" if reuse else "0"
+        try:
+            times, stats = [], []
+            for kk in range(-1, nsteps):      # one untimed step: the cache then holds the pattern one shift back
+                phi_values.copy_(gyroid(shift_h * kk / n))
+                torch.cuda.synchronize()
+                cd = cfx.cut(phi)
+                sysm = poisson.build_forms(V, cd, order=4)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                A = fem.create_matrix(sysm.a)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                if kk >= 0:
+                    times.append(1e3 * (t2 - t1))
+                    stats.append(A.reuse_stats)
+                del A, sysm, cd
+            return dict(create_matrix_ms=round(sum(times) / len(times), 2), each_ms=[round(t, 2) for t in times],
+                        hashed_rows=stats[-1][0], reused_rows=stats[-1][1],
+                        reused_share=round(stats[-1][1] / max(stats[-1][0], 1), 4))
+        finally:
+            os.environ.pop("CFX_PATTERN_REUSE", None)
+    moving_leg = {"what": f"gyroid shifted by 0.3 h along x per step: create_matrix with the rows around unchanged cells "
+                          "copied from the previous pattern of the space (cfx_pattern_reuse_stats) against a full rebuild",
+                  "incremental": moving(True), "full_rebuild": moving(False)}
+    phi_values.copy_(gyroid())
     # algorithmic bytes (SURVEY 8d style): assemble_matrix = CSR values written once + per uncut cell its connectivity
     # row, its share of the vertex coordinates and its degree-2 dofmap row + the rule slices of the cut cells (points,
     # weights, normals) + one record per ghost facet; sparsity = indices + indptr written + the same cell streams
@@ -651,7 +690,8 @@ def secondary_p2_gyroid(torch, device, n=256):
                          f"({nd} dofs) over the P1 level set, Nitsche + ghost penalty, order 4; one step = cut + rules + "
                          "sparsity + assemble_matrix + assemble_vector + deactivation",
                 value=info["active_dofs"] / (1e-3 * ms), unit="DOF/s", ms_per_step=ms, counts=info,
-                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=_kernel_times(step),
+                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=kernels_ms,
+                moving_domain=moving_leg,
                 roofline=phase_roofline("cfg4", "assemble_matrix (phase)", phases["assemble_matrix"], mat_b,
                                         "8 B x nnz values + 60 B per uncut / cut cell + rule slices + 448 B per ghost facet"),
                 roofline_sparsity=phase_roofline("cfg4_sparsity", "create_matrix (phase)", phases["sparsity"], pat_b,
@@ -697,7 +737,12 @@ def secondary_elasticity_share(torch, device, n=256, z0=89, nz=32):
                     n_cut=vol.num_rules, nq_volume=vol.total_points)
     from cutfemx_amd import _lib
     _lib.memory_stats(reset_peak=True)
-    ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+    os.environ["CFX_PATTERN_REUSE"] = "0"      # a full rebuild, as in rounds 1-3 (the step re-cuts one level set)
+    try:
+        ms, info = _timed_steps(torch, step, steps=2, warmup=1)
+        kernels_ms = _kernel_times(step)
+    finally:
+        os.environ.pop("CFX_PATTERN_REUSE", None)
     # assemble_matrix: the CSR values written once (8 B x nnz: 11.5 GB here) + per cell its connectivity row, vertex
     # share and degree-2 dofmap row + the cut cells' rule slices + the ghost-facet records.  Flops of the phase: the
     # closed-form block rows, ~50 flop per 3 x 3 block, 100 blocks per (cell, row dof) pair-set: 3 x 10^4 per cell
@@ -707,7 +752,7 @@ def secondary_elasticity_share(torch, device, n=256, z0=89, nz=32):
                          f"set, P2 vector space (3 x {nd} dofs), elasticity + ghost penalty; one step = cut + rules + sparsity "
                          "+ assemble_matrix",
                 value=info["active_dofs"] / (1e-3 * ms), unit="DOF/s", ms_per_step=ms, counts=info,
-                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=_kernel_times(step),
+                phases_ms={k2: round(v, 2) for k2, v in phases.items()}, kernels_ms=kernels_ms,
                 roofline=phase_roofline("cfg5", "assemble_matrix (phase)", phases["assemble_matrix"], mat_b,
                                         "8 B x nnz values + 60 B per cell + rule slices + 448 B per ghost facet"),
                 roofline_sparsity=phase_roofline("cfg5_sparsity", "create_matrix (phase)", phases["sparsity"], pat_b,

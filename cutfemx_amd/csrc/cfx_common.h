@@ -699,9 +699,10 @@ struct cfx_row_plan
   cfx::DevArray<int32_t> plain_tile_first, plain_tile_id; // ... and the tile's number
   cfx::Count n_plain_tiles;
   // linear forms, P1: the element vectors of the uncut cells are staged in the order the plain rows read them
-  // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] + k, k = position of the cell in the
-  // row's dof->cells list.  vec_t2off[dof] = -1 off the plain rows.  vec_fast: -1 not decided, 0 no, 1 yes
+  // (cfx::plain_vec_offsets): entry k of plain row r lives at vec_t2off[r] - 1 + k, k = position of the cell in the
+  // row's dof->cells list.  vec_t2off[dof] = 0 off the plain rows (offsets are stored + 1).  vec_fast: -1 not decided, 0 no, 1 yes
   cfx::DevArray<int32_t> vec_t2off;
+  bool vec_t2off_used = false; // plain_vec_offsets wrote segment offsets into it (stored + 1; 0 = none)
   cfx::Count n_vec_odd_rows; // plain rows without a segment (their cells do not all carry the mark): with the special rows
                              // they gather the per-cell records -- the second pass of assemble_vec_rows skips the others
   cfx::Count vec_t2_total;
@@ -772,7 +773,8 @@ cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_r
 void validate_form(const cfx_form_s* a);                                // cfx_rowasm.hip: stale entity lists / rules -> Error
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
 const Stencil& space_stencil_slotn(cfx_space_s* V);                     // cfx_rowasm.hip
-void plain_row_masks(cfx_form_s* a);                                    // cfx_rowasm.hip
+// (counts / maxlen: the sparsity build's row lengths, written by the same kernel when the masks are built now: true)
+bool plain_row_masks(cfx_form_s* a, int32_t* counts = nullptr, int* maxlen = nullptr); // cfx_rowasm.hip
 void plan_cut_cells(cfx_form_s* a);                                     // cfx_rowasm.hip
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip

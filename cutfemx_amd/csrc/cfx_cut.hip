@@ -133,9 +133,13 @@ struct SelectorPred
 // sign code of every level-set dof: 1 negative, 2 positive, 0 zero.  The bitwise AND of a cell's
 // codes is 1 iff all its values are negative, 2 iff all are positive, 0 otherwise -- and the byte
 // table (135 MB at 512^3) stays in the Infinity Cache where the 1.1 GB of doubles does not.
-__global__ void __launch_bounds__(kBlock) sign_codes_kernel(int64_t n, const double* __restrict__ phi, uint8_t* __restrict__ code)
+// (zero_n > 0: the first zero_n threads also clear the per-tile counters of the classification that follows -- a fill
+// launch less per step)
+__global__ void __launch_bounds__(kBlock) sign_codes_kernel(int64_t n, const double* __restrict__ phi, uint8_t* __restrict__ code,
+                                                            int32_t* __restrict__ zero_this, int64_t zero_n)
 {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < zero_n) zero_this[i] = 0;
   if (i >= n) return;
   const double v = phi[i];
   code[i] = v < 0.0 ? (uint8_t)1 : (v > 0.0 ? (uint8_t)2 : (uint8_t)0);
@@ -1214,24 +1218,34 @@ __global__ void __launch_bounds__(kBlock) ghost_facets_find_kernel(DevN ncut_d, 
 {
   const int64_t ncut = dev_n(ncut_d);
   constexpr int NV = TDIM + 1;
-  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= ncut * NV) return;
-  const int64_t i = t / NV;
-  const int lf = (int)(t - i * NV);
-  const int64_t c = cut_cells[i];
-  int4 r = make_int4(-1, -1, -1, -1);
-  int32_t nb;
-  int nlf;
-  if (facet_neighbour_tab<TDIM>(conn, c2c, c, lf, nb, nlf))
+  // one thread per cut cell: its NV facets one after the other, the count written once (no counter to zero first: a
+  // launch less per step -- a kernel boundary costs ~10 us here)
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= ncut)
   {
-    const bool nb_cut = domain[nb] == CFX_INTERSECTED;
-    if ((nb_cut || sel(nb)) && !(nb_cut && nb < c))
-    {
-      r = (c < nb) ? make_int4((int)c, lf, nb, nlf) : make_int4(nb, nlf, (int)c, lf);
-      atomicAdd(&counts[i], 1);
-    }
+    if (i < ncut_d.cap) counts[i] = 0; // (list shorter than its capacity: the scan runs over the capacity)
+    return;
   }
-  *reinterpret_cast<int4*>(cand + 4 * t) = r;
+  const int64_t c = cut_cells[i];
+  int n = 0;
+#pragma unroll
+  for (int lf = 0; lf < NV; ++lf)
+  {
+    int4 r = make_int4(-1, -1, -1, -1);
+    int32_t nb;
+    int nlf;
+    if (facet_neighbour_tab<TDIM>(conn, c2c, c, lf, nb, nlf))
+    {
+      const bool nb_cut = domain[nb] == CFX_INTERSECTED;
+      if ((nb_cut || sel(nb)) && !(nb_cut && nb < c))
+      {
+        r = (c < nb) ? make_int4((int)c, lf, nb, nlf) : make_int4(nb, nlf, (int)c, lf);
+        ++n;
+      }
+    }
+    *reinterpret_cast<int4*>(cand + 4 * (i * NV + lf)) = r;
+  }
+  counts[i] = n;
 }
 
 template <int TDIM>
@@ -1882,11 +1896,14 @@ struct IsCut
 };
 
 // the per-tile counters of the first level set, zeroed: two arrays in one block
-static void tile_counters(cfx_cut_t cut, int64_t ntiles)
+static void tile_counters(cfx_cut_t cut, int64_t ntiles, bool zeroed_already)
 {
   const int64_t stride = (ntiles + 3) & ~3LL;
-  cut->tile_block.alloc(2 * stride);
-  cut->tile_block.zero();
+  if (!zeroed_already)
+  {
+    cut->tile_block.alloc(2 * stride);
+    cut->tile_block.zero();
+  }
   cut->tiles_inside.release(); cut->tiles_cut.release();
   cut->tiles_inside.p = cut->tile_block.p; cut->tiles_inside.n = ntiles; cut->tiles_inside.owned = false;
   cut->tiles_cut.p = cut->tile_block.p + stride; cut->tiles_cut.n = ntiles; cut->tiles_cut.owned = false;
@@ -1899,8 +1916,22 @@ void classify(cfx_cut_t cut)
   {
     int8_t* dom = cut->domain.p + (int64_t)k * nc;
     DevArray<uint8_t> codes(cut->ls_ndofs);
+    // (the per-tile counters of level set 0 are cleared by the same launch when they fit its grid)
+    bool tiles_zeroed = false;
+    int32_t* zero_this = nullptr;
+    int64_t zero_n = 0;
+    if (k == 0 && cut->host_mask.n == 0)
+    {
+      const int64_t stride = (((nc + kByteTile - 1) / kByteTile) + 3) & ~3LL;
+      if (2 * stride <= cut->ls_ndofs)
+      {
+        cut->tile_block.alloc(2 * stride);
+        zero_this = cut->tile_block.p; zero_n = 2 * stride;
+        tiles_zeroed = true;
+      }
+    }
     launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
-           codes.p);
+           codes.p, zero_this, zero_n);
     const uint8_t* phi = codes.p;
     {
       // implicit-structured variant (opt-in): generated box mesh, P1 level set on the geometry dofmap
@@ -1914,7 +1945,7 @@ void classify(cfx_cut_t cut)
         if (k == 0 && cut->host_mask.n == 0)
         {
           const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
-          tile_counters(cut, ntiles);
+          tile_counters(cut, ntiles, tiles_zeroed);
           b_in = cut->tiles_inside.p; b_cut = cut->tiles_cut.p;
         }
         else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
@@ -1931,7 +1962,7 @@ void classify(cfx_cut_t cut)
     if (k == 0 && cut->host_mask.n == 0)
     {
       const int64_t ntiles = (nc + kByteTile - 1) / kByteTile;
-      tile_counters(cut, ntiles);
+      tile_counters(cut, ntiles, tiles_zeroed);
       t_in = cut->tiles_inside.p; t_cut = cut->tiles_cut.p;
     }
     else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
@@ -2573,8 +2604,7 @@ int cfx_ghost_penalty_facets(cfx_cut_t cut, const char* selector, const int32_t*
   Count total(0);
   if (ncut > 0)
   {
-    counts.zero();
-    const int64_t nthreads = ncut * (mesh->tdim + 1);
+    const int64_t nthreads = ncut;
     if (mesh->tdim == 2)
       launch("ghost_facets_find", ghost_facets_find_kernel<2>, grid_for(nthreads), dim3(kBlock), 0, ncut_d, cutc.p,
              mesh->conn.p, c2c.p, cut->domain.p, pred, counts.p, cand.p);

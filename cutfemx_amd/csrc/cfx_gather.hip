@@ -133,7 +133,7 @@ struct RowArgs
   int facet_nq;         // fold_facets = 3, degree 2: records (quadrature points) per facet
   unsigned inline_bits; // p1 kernel: mark bits of the inline P1 stiffness integrals
   const uint8_t* slotn;    // degree 2: 12-byte slot records per (dof, cell) entry (cfx::Stencil::slotn), or null
-  const int32_t* vec_skip; // linear forms, second pass over the plain rows: skip row r when vec_skip[r] >= 0 (it has a segment)
+  const int32_t* vec_skip; // linear forms, second pass over the plain rows: skip row r when vec_skip[r] > 0 (it has a segment)
   DevN vec_n_odd;          // ... and leave at once when no plain row is without one
   const uint32_t* slot4;   // plain kernel: cfx::Stencil tables of the space
   const uint8_t* diagpos;
@@ -300,7 +300,7 @@ __device__ __forceinline__ void store_std_vector(const VecArgs& A, int64_t e, in
 #pragma unroll
       for (int i = 0; i < ND; ++i)
       {
-        const int32_t o = A.t2off[A.dofmap[cell * ND + i]];
+        const int32_t o = A.t2off[A.dofmap[cell * ND + i]] - 1; // (stored + 1: 0 = the row has no segment)
         if (o >= 0) A.t2[(int64_t)o + A.cpos[cell * ND + i]] = be[i];
         else record = true;
       }
@@ -504,7 +504,7 @@ __device__ __forceinline__ void source_load_vertices(const VecArgs& A, SourceCel
 #if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 2)
     c.t2o[i] = c.v[i]; // ablation: no segment-offset gathers
 #else
-    c.t2o[i] = A.t2 ? A.t2off[c.v[i]] : -1;
+    c.t2o[i] = A.t2 ? A.t2off[c.v[i]] - 1 : -1; // (stored + 1: 0 = the row has no segment)
 #endif
   }
 }
@@ -2933,7 +2933,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_rows_kernel(RowArgs A)
   if (A.vec_skip && dev_n(A.vec_n_odd) == 0) return;
   bool live = ri < dev_n(A.n_active) && A.cellmark != nullptr;
   const int64_t r = live ? A.active_rows[ri] : 0;
-  if (live && A.vec_skip && A.vec_skip[r] >= 0) live = false;
+  if (live && A.vec_skip && A.vec_skip[r] > 0) live = false; // (segment offsets are stored + 1)
   const int64_t cb = live ? A.d2c_off[r] : 0;
   const int nc = live ? (int)(A.d2c_off[r + 1] - cb) : 0;
   double part = 0.0; // items gl, gl+G, ... in ascending order
@@ -4499,7 +4499,7 @@ __global__ void __launch_bounds__(kWave) assemble_vec_plain_kernel(DevN n_plain_
   const bool live = i < n_plain;
   const int64_t r = live ? rows[i] : 0;
   const int nc = live ? (int)(d2c_off[r + 1] - d2c_off[r]) : 0;
-  const int64_t o = live ? t2off[r] : -1; // -1: the row has no segment (it is in the plan's vec_slow_rows)
+  const int64_t o = live ? (int64_t)t2off[r] - 1 : -1; // -1: the row has no segment (stored + 1: 0 = none)
   double part = 0.0; // entries gl, gl + G, ... in ascending order, then a fixed tree: bitwise reproducible
   if (o >= 0)
   {

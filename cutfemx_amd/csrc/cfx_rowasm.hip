@@ -298,9 +298,10 @@ __global__ void plan_scatter_pos_kernel(DevN n_d, const int32_t* __restrict__ ro
   if (i < n) pos[rows[i]] = (int32_t)i;
 }
 
-__global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
+__global__ void facet_dof_count_kernel(DevN nf_d, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
                                        int nd, const int32_t* __restrict__ pos, int32_t* counts)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nf * 2 * nd) return;
   const int64_t f = i / (2 * nd);
@@ -317,10 +318,11 @@ __global__ void facet_dof_count_kernel(int64_t nf, const int32_t* __restrict__ r
   atomicAdd(&counts[pos[dof]], 1);
 }
 
-__global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
+__global__ void facet_dof_fill_kernel(DevN nf_d, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
                                       int nd, const int32_t* __restrict__ pos, const int64_t* __restrict__ offs,
                                       int32_t* cursor, int32_t* facets)
 {
+  const int64_t nf = dev_n(nf_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nf * 2 * nd) return;
   const int64_t f = i / (2 * nd);
@@ -334,7 +336,8 @@ __global__ void facet_dof_fill_kernel(int64_t nf, const int32_t* __restrict__ ro
       if (dofmap[c0 * nd + j] == dof) return;
   }
   const int32_t q = pos[dof];
-  facets[offs[q] + atomicAdd(&cursor[q], 1)] = (int32_t)f;
+  // (cursor[q] holds the row's count from the count pass: slots are handed out from the back)
+  facets[offs[q] + atomicSub(&cursor[q], 1) - 1] = (int32_t)f;
 }
 
 // dof -> facets incidence by sorting: one (special-row position, facet) pair per dof of a facet's two cells (a dof
@@ -940,7 +943,8 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
                                                             const uint8_t* __restrict__ cellmark, int nd,
                                                             const int64_t* __restrict__ st_off,
                                                             unsigned long long* __restrict__ masks,
-                                                            uint8_t* __restrict__ uniform)
+                                                            uint8_t* __restrict__ uniform, int32_t* __restrict__ counts,
+                                                            int* maxlen)
 {
   const int64_t n_plain = dev_n(n_plain_d);
   constexpr int G = CFX_MASKS_G;
@@ -1029,6 +1033,12 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
   {
     masks[i] = m;
     uniform[i] = (all_or == all_and) ? (uint8_t)all_or : (uint8_t)0;
+    if (counts) // (the sparsity build asked for the row lengths in the same pass: pattern_plain_len_kernel otherwise)
+    {
+      const int cnt = __popcll(m);
+      counts[r] = cnt;
+      if (cnt > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, cnt);
+    }
   }
 }
 
@@ -1455,9 +1465,16 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   const int64_t nc = V->mesh->ncells;
   P.usable = true;
   // the three mark arrays in one block, zeroed by one fill (16 B aligned parts: the kernels read them 16 B per lane)
+  // (... and, for P1 spaces on the geometry dofmap, the segment offsets of a linear form's row-ordered staging, which
+  // start out as "no segment" = 0: cfx::plain_vec_offsets)
   const int64_t n_cm = (nc + 15) & ~15LL, n_rm = (V->ndofs + 15) & ~15LL;
-  P.mark_block.alloc(n_cm + 2 * n_rm);
+  const int64_t n_t2 = space_stencil(V).usable ? ((4 * V->ndofs + 15) & ~15LL) : 0;
+  P.mark_block.alloc(n_cm + 2 * n_rm + n_t2);
   P.mark_block.zero();
+  if (n_t2 > 0)
+  {
+    P.vec_t2off.p = reinterpret_cast<int32_t*>(P.mark_block.p + n_cm + 2 * n_rm); P.vec_t2off.n = V->ndofs; P.vec_t2off.owned = false;
+  }
   P.cellmark.p = P.mark_block.p; P.cellmark.n = (nc + 3) & ~3LL; P.cellmark.owned = false;
   P.rowmark.p = P.mark_block.p + n_cm; P.rowmark.n = V->ndofs; P.rowmark.owned = false;
   DevArray<uint8_t> special; // rows touched by a runtime-rule cell or a facet
@@ -1682,7 +1699,12 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     // dof -> facets incidence of the rows that have facets (all of them special; special_pos came with the row lists)
     const char* fs = getenv("CFX_FACET_SORT");
     const int64_t npairs = nf_cap * 2 * nd;
-    if (!(fs && fs[0] == '0') && npairs < 2147483647LL && ns_cap < 2147483647LL)
+    // Small problems (a rank's share of a multi-GPU run): count + scan + fill with integer atomics -- 4 launches where
+    // the radix sort takes 13 (a kernel boundary costs ~10 us on this chip, profiles/r04_launch_gaps.txt) and 35 M
+    // returning atomics, which made this path the slower one at 512^3, shrink with the problem.  CFX_FACET_SORT=1 / 0
+    // forces one or the other.
+    const bool by_sort = (fs && fs[0] == '1') || (!(fs && fs[0] == '0') && npairs >= 6000000LL);
+    if (by_sort && npairs < 2147483647LL && ns_cap < 2147483647LL)
     {
       // (lengths still in HBM: the sort covers the capacity of the pair list, pairs behind the last facet carry the
       // sentinel key = the capacity of the special-row list, which no row position reaches)
@@ -1705,17 +1727,17 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     }
     else
     {
-      const int64_t nse = P.n_special_rows.value(), nfe = P.nfacets.value(); // (count + fill: exact lengths)
-      DevArray<int32_t> fcount(nse);
+      // (lengths may still be in HBM: the counters cover the capacity of the special-row list -- the tail stays zero --,
+      // the facet list is sized by its upper bound, one entry per (facet, dof of its two cells) pair; the fill reuses
+      // the counters as cursors counting DOWN, so that they need no second zero fill)
+      DevArray<int32_t> fcount(ns_cap);
       fcount.zero();
-      launch("facet_dof_count", facet_dof_count_kernel, grid_for(nfe * 2 * nd), dim3(kBlock), 0, nfe,
+      launch("facet_dof_count", facet_dof_count_kernel, grid_for(npairs), dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
-      P.d2f_offsets.alloc(nse + 1);
-      exclusive_scan(fcount.p, P.d2f_offsets.p, nse);
-      const int64_t total = read_scalar(P.d2f_offsets.p + nse);
-      P.d2f.alloc(total);
-      fcount.zero();
-      launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(nfe * 2 * nd), dim3(kBlock), 0, nfe,
+      P.d2f_offsets.alloc(ns_cap + 1);
+      exclusive_scan(fcount.p, P.d2f_offsets.p, ns_cap);
+      P.d2f.alloc(npairs);
+      launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(npairs), dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
     }
   }
@@ -1864,22 +1886,22 @@ const Stencil& space_stencil_slotn(cfx_space_s* V)
   return S;
 }
 
-void plain_row_masks(cfx_form_s* a)
+bool plain_row_masks(cfx_form_s* a, int32_t* counts, int* maxlen)
 {
   cfx_row_plan& plan = row_plan(a);
-  if (plan.plain_masks_built) return;
+  if (plan.plain_masks_built) return false;
   plan.plain_masks_built = true;
   cfx_space_s* V = a->V;
   const Stencil& st = space_stencil(V);
   const int64_t np = plan.n_plain_rows.cap(); // (capacity of the list while its length is in HBM)
-  if (!st.usable || np == 0 || !plan.any_cells) return;
+  if (!st.usable || np == 0 || !plan.any_cells) return false;
   const Adjacency& adj = V->dof_cells();
   plan.plain_masks.alloc(np);
   plan.plain_uniform.alloc(np);
   launch("plan_plain_masks", plain_masks_kernel,
          dim3((unsigned)((np + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
-         st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p);
+         st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p, counts, maxlen);
   if (space_stencil_tiles(V).tiles_usable)
   {
     // work list of the tile kernels: one entry per row tile that holds a plain row
@@ -1892,6 +1914,7 @@ void plain_row_masks(cfx_form_s* a)
            plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
   }
   publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
+  return counts != nullptr;
 }
 
 // first rule of every cut cell: rule e opens a new parent -> slot of that parent in the cut-cell list
@@ -1964,7 +1987,7 @@ __global__ void vec_plain_scatter_kernel(DevN n_plain_d, const int32_t* __restri
   const int64_t n_plain = dev_n(n_plain_d);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   // (entries in the low 32 bits of the packed prefix)
-  if (i < n_plain && (off[i + 1] & 0xffffffffll) > (off[i] & 0xffffffffll)) t2off[rows[i]] = (int32_t)(off[i] & 0xffffffffll);
+  if (i < n_plain && (off[i + 1] & 0xffffffffll) > (off[i] & 0xffffffffll)) t2off[rows[i]] = (int32_t)(off[i] & 0xffffffffll) + 1;
 }
 
 
@@ -2010,8 +2033,14 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
     cp.finish(tot);
   }
   if (tot[0].cap() == 0 || tot[0].cap() >= 2147483647LL) return false;
-  plan.vec_t2off.alloc(V->ndofs);
-  dev_fill(plan.vec_t2off.p, 0xff, sizeof(int32_t) * (size_t)V->ndofs);
+  // segment offsets are stored + 1 (0: the row has no segment): the array came zeroed with the plan's mark block
+  // (cfx::row_plan: one fill for all of them) unless this is a second layout of the same plan
+  if (plan.vec_t2off.n != V->ndofs || plan.vec_t2off_used)
+  {
+    plan.vec_t2off.alloc(V->ndofs);
+    dev_fill(plan.vec_t2off.p, 0, sizeof(int32_t) * (size_t)V->ndofs);
+  }
+  plan.vec_t2off_used = true;
   launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
          off.p, plan.vec_t2off.p);
   // everything else reads the per-cell records: the special rows, and (a second pass that skips the rows with a
@@ -2605,9 +2634,11 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   }
   if (use_stencil)
   {
-    plain_row_masks(a);
-    launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows.cap()), dim3(kBlock), 0, plan.n_plain_rows,
-           plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
+    // (the row lengths come out of the mask pass when the masks are built here; a plan whose masks exist already --
+    // a second pattern of the same lists -- takes the separate pass)
+    if (!plain_row_masks(a, counts.p, maxlen.p))
+      launch("pattern_plain", pattern_plain_len_kernel, grid_for(plan.n_plain_rows.cap()), dim3(kBlock), 0, plan.n_plain_rows,
+             plan.plain_rows.p, plan.plain_masks.p, counts.p, maxlen.p);
   }
   if (!deferred) P->max_row_len = plan.n_active_rows.cap() > 0 ? read_scalar(maxlen.p) : 1;
   if (any_full) P->max_row_len = std::max(P->max_row_len, st.max_len); // a copied row is at most the longest static list

@@ -60,12 +60,13 @@ def balanced_boundaries(weights, world: int):
     return bounds
 
 
-def sphere_layer_weights(n: int, active_weight: float = 15.0, cut_weight: float = 400.0):
+def sphere_layer_weights(n: int, active_weight: float = 14.0, cut_weight: float = 800.0):
     """Cost model per hex layer for the sphere workload, in units of one background cell
-    (~15 ps on MI355X: classification, selector scans, mark arrays; fitted to the per-rank
-    times of tools/rank_balance.py): an active (inside) cell costs ~0.22 ns more of assembly
-    (15), a cut cell ~6 ns of sub-triangulation, runtime quadrature, local tensors and
-    ghost-penalty facets (400).  The surface of a sphere
+    (~6 ps on MI355X: classification, selector scans, mark arrays): an active (inside) cell costs
+    ~0.085 ns more of assembly (14), a cut cell ~5.6 ns of sub-triangulation, runtime quadrature,
+    local tensors and ghost-penalty facets (800) -- least-squares fit of the round-4 per-rank times
+    of the 1 / 2 / 4 / 8-rank partitions of the 512^3 case (bench.py projected_scaling), which also
+    gives a fixed ~0.58 ms per rank and step: ~60 kernel boundaries of ~10 us.  The surface of a sphere
     between two parallel planes is 2 pi R dz (Archimedes), so the cut cells are spread evenly
     over the layers that meet the sphere: ~4.7 cut tets per h^2 of surface."""
     c, R = np.array([0.47, 0.43, 0.41]), 0.31

@@ -355,11 +355,13 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     for _ in range(max(warmup - 1, 0)):
         info = step()
     barrier()
+    syncs0 = _lib.sync_count()
     t0 = time.perf_counter()
     for _ in range(steps):
         info = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    read_backs = (_lib.sync_count() - syncs0) / steps
     if world > 1:
         info = dp.counters(info)       # owned-share counts of the last step, outside the timed region
     else:
@@ -397,7 +399,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     if scale_info is not None:
         out["multi_gpu"] = scale_info
     if world == 1:
-        out["step_mode"] = dict(sync_free=use_steps, **step_stats,
+        out["step_mode"] = dict(sync_free=use_steps, **step_stats, read_backs_per_step=read_backs,
                                 note="sync_free: the timed step runs between cfx_step_begin / cfx_step_end -- list sizes stay "
                                      "in HBM (published), buffers are sized by the previous step's counts, one read-back ends "
                                      "the step; passes > 1 would mean a step was repeated because a count did not fit")
@@ -431,6 +433,11 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     phases_ms = {k: round(1e3 * v / psteps, 4) for k, v in timer.t.items()}
     kernels = kernel_profile(_lib, lambda: step(overlap=False), psteps)   # one lane: every kernel alone on the GPU
     torch.cuda.synchronize()
+    if "step_mode" in out:
+        out["step_mode"]["launches_per_step"] = round(sum(v["launches"] for v in kernels.values()), 1)
+        out["step_mode"]["launches_note"] = ("kernel launches made by the library per step (its own launch wrapper: fills "
+                                             "included; the rocPRIM radix sort behind the dof -> facets incidence of "
+                                             "meshes with >= 6 M (facet, dof) pairs adds 11 launches the wrapper does not see)")
     alg_bytes = {
         "classify": B_CLASSIFY_PER_CELL * mesh.num_cells,
         "assemble_rows": B_UNCUT_CELL * info["n_inside"],
@@ -670,7 +677,9 @@ def secondary_p2_gyroid(torch, device, n=256):
                     times.append(1e3 * (t2 - t1))
                     stats.append(A.reuse_stats)
                 del A, sysm, cd
-            return dict(create_matrix_ms=round(sum(times) / len(times), 2), each_ms=[round(t, 2) for t in times],
+            return dict(create_matrix_ms=round(sum(times) / len(times), 2),
+                        create_matrix_median_ms=round(sorted(times)[len(times) // 2], 2),
+                        each_ms=[round(t, 2) for t in times],
                         hashed_rows=stats[-1][0], reused_rows=stats[-1][1],
                         reused_share=round(stats[-1][1] / max(stats[-1][0], 1), 4))
         finally:
@@ -886,9 +895,11 @@ def moving_domain_leg(torch, device, n, order, nsteps=8, shift_h=0.3):
                     "sparsity every step (the reference rebuilds too: cut.cpp:845-868); the level-set update itself is "
                     "outside the timed region",
             "mesh": n, "sync_free": a, "sizes_read_back": bb,
-            "incremental_sparsity": None,
-            "incremental_note": "not built: see DESIGN.md 7 (what a step could keep from the previous pattern, and why "
-                                "the P1 path gains little from it)"}
+            "incremental_sparsity": "config_p2_gyroid_256.moving_domain",
+            "incremental_note": "the P1 pattern of this workload is a masked copy of the mesh-static stencil (no hash sets: "
+                                "6.1 ms for 378 M entries, 0.9 of it for the hashed rows next to the interface), so nothing is kept "
+                                "from the previous step here; rows are reused where patterns are hashed (degree 2 / vector "
+                                "spaces): measured on the moving gyroid of config_p2_gyroid_256 (DESIGN.md 3, round 4)"}
 
 
 def projected_scaling(torch, device, n, order, one_gpu_ms, worlds=(2, 4, 8)):

@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("CFX_PATTERN_REUSE", "0")  # a full rebuild per step, as the bench line (the step re-cuts one level set)
 """Timing of one rank's share of BASELINE config 5 (256^3, P2 vector elasticity, sphere): slab of 32 layers."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

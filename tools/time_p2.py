@@ -1,3 +1,4 @@
+import os; os.environ.setdefault("CFX_PATTERN_REUSE", "0")  # a full rebuild per step, as the bench line (the step re-cuts one level set)
 """Timing of BASELINE config 4 (256^3 gyroid, P2 scalar) and config 5's rank share (P2 vector elasticity)."""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')

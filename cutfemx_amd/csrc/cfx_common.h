@@ -176,6 +176,7 @@ uint64_t dev_block_serial(const void* p);
 uint64_t next_serial();                    // process-wide counter shared by blocks, rules handles and plans
 void rules_serial_live(uint64_t s, bool live);
 bool rules_serial_is_live(uint64_t s);
+void dev_free_now(void* p); // give a (large, one-off) block back to the driver instead of the cache
 void device_memory_stats(size_t& live, size_t& cached, size_t& peak); // bytes held from HIP: in use / cached / high-water
 void device_memory_reset_peak();
 
@@ -359,6 +360,11 @@ struct DevArray
     if (p && owned) dev_free(p);
     p = nullptr; n = 0; owned = false; count = Count();
   }
+  void release_to_driver() // one-off scratch: not into the block cache
+  {
+    if (p && owned && !count.cell) { dev_free_now(p); p = nullptr; n = 0; owned = false; }
+    else release();
+  }
   void zero() { if (n > 0) dev_fill(p, 0, sizeof(T) * (size_t)n); }
   T* get() const { return p; }
 };
@@ -380,6 +386,21 @@ inline DevArray<T> to_device(const T* src, int64_t n)
   CFX_HIP(hipMemcpyAsync(a.p, src, sizeof(T) * (size_t)n, hipMemcpyHostToDevice, ctx().stream));
   CFX_HIP(hipStreamSynchronize(ctx().stream)); // the host buffer may die right after the call
   return a;
+}
+
+// connectivity / dofmap tables: kernels read their rows with 16-byte (8-byte) loads, so a caller's device array that
+// starts off a 16-byte boundary (a view into a larger tensor) is copied once instead of aliased
+template <typename T>
+inline DevArray<T> to_device_aligned(const T* src, int64_t n)
+{
+  if (src != nullptr && n > 0 && is_device_pointer(src) && (reinterpret_cast<uintptr_t>(src) & 15) != 0)
+  {
+    DevArray<T> a;
+    a.alloc(n);
+    CFX_HIP(hipMemcpyAsync(a.p, src, sizeof(T) * (size_t)n, hipMemcpyDeviceToDevice, ctx().stream));
+    return a;
+  }
+  return to_device(src, n);
 }
 
 // error word of an assembly call (an entry missing from the pattern, a deactivated row without a diagonal ...): read
@@ -769,6 +790,7 @@ struct cfx_form_s
 
 namespace cfx
 {
+bool assemble_rect_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, int* error); // cfx_gather.hip
 cfx_row_plan& row_plan(cfx_form_s* a);                                  // cfx_rowasm.hip
 void validate_form(const cfx_form_s* a);                                // cfx_rowasm.hip: stale entity lists / rules -> Error
 const Stencil& space_stencil(cfx_space_s* V);                           // cfx_rowasm.hip
@@ -810,8 +832,8 @@ struct cfx_pattern_s
   uint64_t stencil_plan = 0; // serial of the plan whose plain rows were laid out as stencil subsets (0: none)
   // long-row spaces: the plan's active rows split by row length (<= 64 columns / longer)
   uint64_t split_plan = 0;
-  cfx::DevArray<int32_t> short_rows, long_rows;
-  int64_t n_short_rows = 0, n_long_rows = 0;
+  cfx::DevArray<int32_t> short_rows, mid_rows, long_rows; // <= 64 columns, <= 128, longer
+  int64_t n_short_rows = 0, n_mid_rows = 0, n_long_rows = 0;
   // degree-2 spaces with neighbour lists: the plain rows that copied their static list (every incident cell an uncut
   // entity of the form's one stiffness integral); short_rows / long_rows then hold the other active rows only
   uint64_t full_plan = 0;

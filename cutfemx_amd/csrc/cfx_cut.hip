@@ -1162,51 +1162,79 @@ __device__ __forceinline__ bool facet_neighbour_tab(const int32_t* __restrict__ 
   return true;
 }
 
-template <int TDIM>
+template <int TDIM, bool XCD>
 __global__ void __launch_bounds__(kBlock) cell_neighbours_kernel(int64_t ncells, const int32_t* __restrict__ conn,
                                                                  const int64_t* __restrict__ v2c_off,
                                                                  const int32_t* __restrict__ v2c, int32_t* __restrict__ c2c)
 {
   constexpr int NV = TDIM + 1;
-  const int64_t c = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  // (XCD: every XCD -- every L2 -- walks one contiguous chunk of the cells; the candidates of neighbouring cells are
+  // the same rows of the connectivity: 95 -> 86 ms at 512^3)
+  const int64_t c = (XCD ? xcd_block_id() : (int64_t)blockIdx.x) * kBlock + threadIdx.x;
   if (c >= ncells) return;
   // All facets of the cell from TWO incidence lists instead of one list per facet: a cell that shares NV - 1
   // vertices with c is its neighbour across the facet opposite the vertex it lacks; every facet but the one opposite
   // vertex 0 contains vertex 0 (candidates: the cells around vertex 0), that one contains vertex 1.
+  // (Measured and dropped in round 4: deciding from the incidence lists alone -- a candidate is the neighbour across
+  // facet i when it is in the lists of all vertices but vertex i, one binary search per (candidate, vertex) instead of
+  // the candidate's connectivity row -- ran 5.6 x slower: 530 ms, ~600 dependent 4 B loads per cell.)
   int32_t cv[NV], out[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) { cv[i] = conn[c * NV + i]; out[i] = -1; }
+  constexpr int KB = 4; // candidates in flight: ids first, then their connectivity rows, then the compares
 #pragma unroll
   for (int pass = 0; pass < 2; ++pass)
   {
     const int32_t pivot = cv[pass];
-    for (int64_t k = v2c_off[pivot]; k < v2c_off[pivot + 1]; ++k)
+    const int64_t kb = v2c_off[pivot], ke = v2c_off[pivot + 1];
+    for (int64_t k0 = kb; k0 < ke; k0 += KB)
     {
-      const int32_t o = v2c[k];
-      if (o == c) continue;
-      int32_t ov[NV];
+      int32_t o[KB], ov[KB][NV];
 #pragma unroll
-      for (int i = 0; i < NV; ++i) ov[i] = conn[(int64_t)o * NV + i];
-      int shared = 0, missing = 0;
+      for (int u = 0; u < KB; ++u) o[u] = v2c[k0 + u < ke ? k0 + u : ke - 1];
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
+      for (int u = 0; u < KB; ++u)
       {
-        bool found = false;
+        if constexpr (NV == 4)
+        {
+          const int4 q = *reinterpret_cast<const int4*>(conn + (int64_t)o[u] * 4);
+          ov[u][0] = q.x; ov[u][1] = q.y; ov[u][2] = q.z; ov[u][3] = q.w;
+        }
+        else
+        {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) found = found || (ov[j] == cv[i]);
-        shared += found ? 1 : 0;
-        missing = found ? missing : i;
+          for (int i = 0; i < NV; ++i) ov[u][i] = conn[(int64_t)o[u] * NV + i];
+        }
       }
-      // pass 0 settles the facets that contain vertex 0, pass 1 the one opposite to it
-      if (shared == NV - 1 && (pass == 0 ? missing != 0 : missing == 0))
-      {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) out[i] = (i == missing && out[i] < 0) ? o : out[i];
+      for (int u = 0; u < KB; ++u)
+      {
+        if (k0 + u >= ke || o[u] == c) continue;
+        int shared = 0, missing = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+        {
+          bool found = false;
+#pragma unroll
+          for (int j = 0; j < NV; ++j) found = found || (ov[u][j] == cv[i]);
+          shared += found ? 1 : 0;
+          missing = found ? missing : i;
+        }
+        // pass 0 settles the facets that contain vertex 0, pass 1 the one opposite to it
+        if (shared == NV - 1 && (pass == 0 ? missing != 0 : missing == 0))
+        {
+#pragma unroll
+          for (int i = 0; i < NV; ++i) out[i] = (i == missing && out[i] < 0) ? o[u] : out[i];
+        }
       }
     }
   }
+  if constexpr (NV == 4) *reinterpret_cast<int4*>(c2c + c * 4) = make_int4(out[0], out[1], out[2], out[3]);
+  else
+  {
 #pragma unroll
-  for (int i = 0; i < NV; ++i) c2c[c * NV + i] = out[i];
+    for (int i = 0; i < NV; ++i) c2c[c * NV + i] = out[i];
+  }
 }
 
 template <int TDIM>
@@ -2825,11 +2853,12 @@ const cfx::DevArray<int32_t>& cfx_mesh_s::cell_neighbours()
   c2c.alloc(ncells * (int64_t)(tdim + 1));
   if (ncells > 0)
   {
+    const dim3 grid = xcd_grid((ncells + kBlock - 1) / kBlock);
     if (tdim == 2)
-      launch("cell_neighbours", cell_neighbours_kernel<2>, grid_for(ncells), dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
+      launch("cell_neighbours", cell_neighbours_kernel<2, true>, grid, dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
              adj.cells.p, c2c.p);
     else
-      launch("cell_neighbours", cell_neighbours_kernel<3>, grid_for(ncells), dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
+      launch("cell_neighbours", cell_neighbours_kernel<3, true>, grid, dim3(kBlock), 0, ncells, conn.p, adj.offsets.p,
              adj.cells.p, c2c.p);
   }
   c2c_built = true;

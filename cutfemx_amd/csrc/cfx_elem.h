@@ -499,6 +499,107 @@ __device__ __forceinline__ double field_eval(int id, const double* x)
   return (double)GDIM * kPi * kPi * p;
 }
 
+// ---------------------------------------------------------------------------
+// Bilinear forms whose test and trial spaces differ (cfx_form_create2; assemble_matrix_impl.h:68-189 with dofmap0 /
+// bs0 != dofmap1 / bs1): row (ia, ik) of the [(nd0 bs0) x (nd1 bs1)] element tensor of one cell integral over one
+// rule, accumulated into acc[j][b] (fixed strides: the sizes are run-time values -- one body serves every pair of
+// Lagrange spaces).  Shared by the entity-parallel kernel (cfx_fem.hip) and the row gather (cfx_gather.hip).
+// ---------------------------------------------------------------------------
+struct RectArgs
+{
+  const int32_t* dofmap1;
+  int deg0, bs0, nd0, deg1, bs1, nd1;
+};
+
+template <int TDIM>
+struct RectRow
+{
+  static constexpr int MAXND = TDIM == 2 ? 6 : 10, MAXBS = TDIM;
+  static __device__ __forceinline__ void accumulate(const RectArgs& R, int kernel, double scale, const Geo<TDIM>& g, int ia,
+                                                    int ik, int npts, const double* __restrict__ pts,
+                                                    const double* __restrict__ wts, double wscale,
+                                                    double (&acc)[MAXND][MAXBS])
+  {
+    for (int q = 0; q < npts; ++q)
+    {
+      double X[TDIM];
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
+      const double w = wts[q] * wscale;
+      double N[MAXND], dN[MAXND][TDIM];
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+      {
+        N[j] = 0.0;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) dN[j][t] = 0.0;
+      }
+      // the row's basis function of the test element: value and physical gradient
+      if (R.deg0 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
+      double Ni = 0.0, Gi[TDIM];
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) Gi[d] = 0.0;
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+        if (j == ia)
+        {
+          Ni = N[j];
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d)
+          {
+            double v = 0.0;
+#pragma unroll
+            for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
+            Gi[d] = v;
+          }
+        }
+      double Gia = 0.0; // component ik of the row gradient (DIV_TEST)
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d) Gia = (d == ik) ? Gi[d] : Gia;
+      // the trial element
+      if (R.deg1 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+      {
+        if (j >= R.nd1) continue;
+        double Gj[TDIM];
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+        {
+          double v = 0.0;
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
+          Gj[d] = v;
+        }
+        switch (kernel)
+        {
+        case CFX_K_MASS:
+#pragma unroll
+          for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * Ni * N[j] : 0.0;
+          break;
+        case CFX_K_STIFFNESS:
+        {
+          double sgg = 0.0;
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) sgg += Gi[d] * Gj[d];
+#pragma unroll
+          for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * sgg : 0.0;
+          break;
+        }
+        case CFX_K_DIV_TEST: // v = N0_i e_ik, p = N1_j
+          acc[j][0] += w * scale * Gia * N[j];
+          break;
+        case CFX_K_DIV_TRIAL: // q = N0_i, u = N1_j e_b
+#pragma unroll
+          for (int b = 0; b < MAXBS; ++b) acc[j][b] += w * scale * Ni * Gj[b];
+          break;
+        default: break;
+        }
+      }
+    }
+  }
+};
+
 // position of column `col` in CSR row [b,e); -1 if absent
 __device__ __forceinline__ int64_t csr_find(const int32_t* __restrict__ indices, int64_t b, int64_t e, int32_t col)
 {

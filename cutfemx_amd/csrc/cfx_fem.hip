@@ -898,16 +898,10 @@ void launch_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, 
 // every pair of Lagrange spaces instead of one instantiation per pair), scattered into its CSR row with one search
 // per trial dof and FP64 atomics, or contracted with the Dirichlet data (lifting), or dumped (tabulate_entity).
 // ---------------------------------------------------------------------------
-struct RectArgs
-{
-  const int32_t* dofmap1;
-  int deg0, bs0, nd0, deg1, bs1, nd1;
-};
-
 template <int TDIM, bool RUNTIME>
 __global__ void __launch_bounds__(kBlock) assemble_cells2_kernel(AsmArgs A, RectArgs R)
 {
-  constexpr int MAXND = TDIM == 2 ? 6 : 10, MAXBS = TDIM;
+  constexpr int MAXND = RectRow<TDIM>::MAXND, MAXBS = RectRow<TDIM>::MAXBS;
   const int nloc0 = R.nd0 * R.bs0, nloc1 = R.nd1 * R.bs1;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t e = tid / nloc0;
@@ -947,84 +941,7 @@ __global__ void __launch_bounds__(kBlock) assemble_cells2_kernel(AsmArgs A, Rect
   for (int j = 0; j < MAXND; ++j)
 #pragma unroll
     for (int b = 0; b < MAXBS; ++b) acc[j][b] = 0.0;
-  const double scale = A.params[0];
-  for (int q = 0; q < npts; ++q)
-  {
-    double X[TDIM];
-#pragma unroll
-    for (int t = 0; t < TDIM; ++t) X[t] = pts[(int64_t)q * TDIM + t];
-    const double w = wts[q] * wscale;
-    double N[MAXND], dN[MAXND][TDIM];
-#pragma unroll
-    for (int j = 0; j < MAXND; ++j)
-    {
-      N[j] = 0.0;
-#pragma unroll
-      for (int t = 0; t < TDIM; ++t) dN[j][t] = 0.0;
-    }
-    // the row's basis function of the test element: value and physical gradient
-    if (R.deg0 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
-    double Ni = 0.0, Gi[TDIM];
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d) Gi[d] = 0.0;
-#pragma unroll
-    for (int j = 0; j < MAXND; ++j)
-      if (j == ia)
-      {
-        Ni = N[j];
-#pragma unroll
-        for (int d = 0; d < TDIM; ++d)
-        {
-          double v = 0.0;
-#pragma unroll
-          for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
-          Gi[d] = v;
-        }
-      }
-    double Gia = 0.0; // component ik of the row gradient (DIV_TEST)
-#pragma unroll
-    for (int d = 0; d < TDIM; ++d) Gia = (d == ik) ? Gi[d] : Gia;
-    // the trial element
-    if (R.deg1 == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
-#pragma unroll
-    for (int j = 0; j < MAXND; ++j)
-    {
-      if (j >= R.nd1) continue;
-      double Gj[TDIM];
-#pragma unroll
-      for (int d = 0; d < TDIM; ++d)
-      {
-        double v = 0.0;
-#pragma unroll
-        for (int t = 0; t < TDIM; ++t) v += g.K[t][d] * dN[j][t];
-        Gj[d] = v;
-      }
-      switch (A.kernel)
-      {
-      case CFX_K_MASS:
-#pragma unroll
-        for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * Ni * N[j] : 0.0;
-        break;
-      case CFX_K_STIFFNESS:
-      {
-        double sgg = 0.0;
-#pragma unroll
-        for (int d = 0; d < TDIM; ++d) sgg += Gi[d] * Gj[d];
-#pragma unroll
-        for (int b = 0; b < MAXBS; ++b) acc[j][b] += (b == ik) ? w * sgg : 0.0;
-        break;
-      }
-      case CFX_K_DIV_TEST: // v = N0_i e_ik, p = N1_j
-        acc[j][0] += w * scale * Gia * N[j];
-        break;
-      case CFX_K_DIV_TRIAL: // q = N0_i, u = N1_j e_b
-#pragma unroll
-        for (int b = 0; b < MAXBS; ++b) acc[j][b] += w * scale * Ni * Gj[b];
-        break;
-      default: break;
-      }
-    }
-  }
+  RectRow<TDIM>::accumulate(R, A.kernel, A.params[0], g, ia, ik, npts, pts, wts, wscale, acc);
   if (A.dump)
   {
     double* out = A.dump + (e * nloc0 + I0) * (int64_t)nloc1;
@@ -1700,7 +1617,7 @@ int cfx_space_create(cfx_mesh_t mesh, int degree, int bs, int64_t ndofs, const i
   require(ndofs > 0 && ndofs * bs < 2147483647LL, CFX_ERR_INVALID_ARGUMENT, "cfx_space_create: dof count must fit int32");
   auto V = std::make_unique<cfx_space_s>();
   V->mesh = mesh; V->degree = degree; V->bs = bs; V->ndofs = ndofs; V->ndofs_cell = ndofs_cell;
-  V->dofmap = to_device(dofmap, mesh->ncells * (int64_t)ndofs_cell);
+  V->dofmap = to_device_aligned(dofmap, mesh->ncells * (int64_t)ndofs_cell);
   *out = V.release();
   CFX_API_END
 }
@@ -1960,9 +1877,11 @@ static void assemble_matrix_impl(cfx_form_t a, cfx_pattern_t P, const int8_t* bc
   // entity-parallel kernels with FP64 atomics
   if (a->rectangular())
   {
-    // test space != trial space: the entity-parallel kernel of the rectangular blocks (no row gather yet)
+    // test space != trial space: the row gather of the rectangular blocks (round 4; one writer per row, no global
+    // atomics), or the entity-parallel kernel (CFX_ASSEMBLY=atomic, rows beyond 256 columns)
     if (zero_first) dev_fill(out.dev, 0, sizeof(double) * (size_t)P->nnz.value());
-    for (const auto& I : a->integrals) launch_rectangular(a, I, A);
+    if (force_atomic() || !assemble_rect_rows(a, P, A.bc0, A.bc1, out.dev, A.error))
+      for (const auto& I : a->integrals) launch_rectangular(a, I, A);
     err.check(CFX_ERR_RUNTIME, kMissing);
     out.finish();
     return;

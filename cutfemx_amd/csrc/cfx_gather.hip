@@ -4270,6 +4270,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
         else
         {
           CFX_LEAN(8, 64, P->short_rows.p, P->n_short_rows);
+          CFX_LEAN(16, 256, P->mid_rows.p, P->n_mid_rows);
           CFX_LEAN(16, 256, P->long_rows.p, P->n_long_rows);
         }
         if (P->full_plan == plan.serial && P->n_full_rows > 0)
@@ -4317,10 +4318,17 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
             if (plan.nfacets.value() == 0) { S.d2f_off = nullptr; S.facet_nq = 0; }
             // the rows of at most 64 columns (edge dofs: most of them) 8 lanes per row with a quarter of the LDS, the
             // others 16 lanes and 256 columns; the two lists hold every hashed row, the few plain ones among them included
-            RowArgs S1 = S, S2 = S;
+            RowArgs S1 = S, S2 = S, S3 = S;
             S1.n_active = P->n_short_rows; S1.active_rows = P->short_rows.p;
             S2.n_active = P->n_long_rows; S2.active_rows = P->long_rows.p;
+            S3.n_active = P->n_mid_rows; S3.active_rows = P->mid_rows.p;
             const dim3 g1 = row_grid((S1.n_active.cap + 7) / 8), g2 = row_grid((S2.n_active.cap + 3) / 4);
+            const dim3 g3 = row_grid((S3.n_active.cap + 3) / 4);
+            if (S3.n_active.cap > 0)
+            {
+              if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 128, true>, g3, dim3(kWave), 0, S3);
+              else launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 16, 128, false>, g3, dim3(kWave), 0, S3);
+            }
             if (S1.n_active.cap > 0)
             {
               if (det) launch("assemble_rows_cut", assemble_rows_p2_interface_kernel<TDIM, 8, 64, true>, g1, dim3(kWave), 0, S1);
@@ -4630,6 +4638,218 @@ void run_vector(cfx_form_s* L, double* b)
 
 namespace cfx
 {
+
+// ---------------------------------------------------------------------------
+// Rectangular blocks (test space != trial space, cfx_form_create2) by row gather: the work units of the entity-parallel
+// kernel -- (cell, test row) -> one row of the [(nd0 bs0) x (nd1 bs1)] element tensor -- ordered by destination row.
+// Sixteen lanes per matrix row; the row's columns sit in LDS, a lane takes the incident cells t = gl, gl + 16, ... of
+// the row's test dof, forms the tensor row of every integral the cell's mark names (standard rule for an uncut
+// entity, the cell's runtime rules through the plan's hash map), finds the trial dofs' columns by binary search in LDS
+// and adds there; the row is written once.  No global atomics; bitwise reproducible with CFX_DETERMINISTIC=1.  The
+// plan is the test space's (marks, rule maps and active rows do not depend on the trial space).
+// ---------------------------------------------------------------------------
+struct Rect2Slot
+{
+  int kernel, qdegree;
+  double scale;
+  uint8_t std_bit, rule_bit;
+  DevN nr;
+  const int32_t* offsets;
+  const int32_t* parent_map;
+  const double* points;
+  const double* weights;
+  const int32_t* rule_keys;
+  const int32_t* rule_first;
+  unsigned rule_mask;
+};
+struct Rect2Args
+{
+  DevN n_active;
+  const int32_t* active_rows; // test dofs touched by the form
+  const double* x;
+  const int32_t* conn;
+  const int32_t* dofmap0;
+  const int64_t* d2c_off;
+  const int32_t* d2c;
+  const uint8_t* cellmark;
+  const int8_t* bc0;
+  const int8_t* bc1;
+  const int64_t* indptr;
+  const int32_t* indices;
+  double* values;
+  int* error;
+  RectArgs R;
+  int n_slots;
+  Rect2Slot slot[4];
+};
+
+template <int TDIM, bool ORDERED>
+__global__ void __launch_bounds__(kWave) assemble_rows2_kernel(Rect2Args A)
+{
+  constexpr int G = 16, RPW = kWave / G, CAP = 256;
+  constexpr int MAXND = RectRow<TDIM>::MAXND, MAXBS = RectRow<TDIM>::MAXBS;
+  __shared__ int32_t s_col[RPW][CAP];
+  __shared__ double s_val[RPW][CAP];
+  const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
+  const RectArgs& R = A.R;
+  const int64_t w = CFX_ROW_BLOCK * RPW + grp; // scalar rows of the active test dofs, bs0 per dof
+  const int64_t ri = w / R.bs0;
+  const int ik = (int)(w - ri * R.bs0);
+  const bool live = ri < dev_n(A.n_active);
+  const int64_t dof = live ? A.active_rows[ri] : 0;
+  const int64_t row = R.bs0 * dof + ik;
+  const int64_t rb = live ? A.indptr[row] : 0;
+  int len = live ? (int)(A.indptr[row + 1] - rb) : 0;
+  if (len > CAP) { *A.error = 2; len = 0; }
+  for (int k = gl; k < len; k += G) { s_col[grp][k] = A.indices[rb + k]; s_val[grp][k] = 0.0; }
+  __syncthreads();
+  const bool row_bc = live && A.bc0 && A.bc0[row];
+  const int64_t cb = live ? A.d2c_off[dof] : 0;
+  const int nc = (live && len > 0) ? (int)(A.d2c_off[dof + 1] - cb) : 0;
+  int npass = (nc + G - 1) / G;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) npass = max(npass, __shfl_xor(npass, o, 64)); // (the groups' barriers match)
+  for (int p = 0; p < npass; ++p)
+  {
+    const int t = p * G + gl;
+    const bool has = t < nc;
+    const int64_t c = has ? (int64_t)A.d2c[cb + t] : 0;
+    const uint8_t mark = has ? A.cellmark[c] : (uint8_t)0;
+    double acc[MAXND][MAXBS];
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+      for (int b = 0; b < MAXBS; ++b) acc[j][b] = 0.0;
+    if (mark)
+    {
+      int ia = 0;
+      for (int j = 0; j < R.nd0; ++j) ia = (A.dofmap0[c * R.nd0 + j] == (int32_t)dof) ? j : ia;
+      Geo<TDIM> g;
+      load_cell<TDIM>(A.x, A.conn, c, g);
+      jacobian<TDIM>(g);
+      for (int s = 0; s < A.n_slots; ++s)
+      {
+        const Rect2Slot& S = A.slot[s];
+        if (mark & S.std_bit)
+        {
+          int npts;
+          const double* wts;
+          const double* pts = ref_rule(TDIM, S.qdegree, npts, wts);
+          RectRow<TDIM>::accumulate(R, S.kernel, S.scale, g, ia, ik, npts, pts, wts, fabs(g.detJ), acc);
+        }
+        if (mark & S.rule_bit)
+        {
+          for (int64_t e = first_rule(S.rule_keys, S.rule_first, S.rule_mask, (int32_t)c); e < dev_len(S.nr) && S.parent_map[e] == c; ++e)
+          {
+            const int32_t q0 = S.offsets[e], q1 = S.offsets[e + 1];
+            RectRow<TDIM>::accumulate(R, S.kernel, S.scale, g, ia, ik, q1 - q0, S.points + (int64_t)q0 * TDIM, S.weights + q0, 1.0, acc);
+          }
+        }
+      }
+    }
+    // columns of the trial dofs of the cell: bs1 consecutive entries from the position of the first
+    int pos[MAXND];
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+    {
+      pos[j] = -1;
+      if (mark && j < R.nd1)
+      {
+        const int32_t col0 = R.bs1 * R.dofmap1[c * R.nd1 + j];
+        int lo = 0, hi = len;
+        while (lo < hi)
+        {
+          const int mid = (lo + hi) >> 1;
+          if (s_col[grp][mid] < col0) lo = mid + 1; else hi = mid;
+        }
+        if (lo < len && s_col[grp][lo] == col0) pos[j] = lo; else *A.error = 1;
+        if (pos[j] >= 0)
+        {
+#pragma unroll
+          for (int b = 0; b < MAXBS; ++b)
+            if (b < R.bs1 && (row_bc || (A.bc1 && A.bc1[col0 + b]))) acc[j][b] = 0.0;
+        }
+      }
+    }
+    if constexpr (ORDERED)
+    {
+      for (int turn = 0; turn < G; ++turn)
+      {
+        if (gl == turn)
+        {
+#pragma unroll
+          for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+            for (int b = 0; b < MAXBS; ++b)
+              if (pos[j] >= 0 && b < R.bs1) s_val[grp][pos[j] + b] += acc[j][b];
+        }
+        __syncthreads();
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+#pragma unroll
+        for (int b = 0; b < MAXBS; ++b)
+          if (pos[j] >= 0 && b < R.bs1) atomicAdd(&s_val[grp][pos[j] + b], acc[j][b]);
+    }
+  }
+  __syncthreads();
+  for (int k = gl; k < len; k += G) A.values[rb + k] += s_val[grp][k]; // (one writer per row)
+}
+
+bool assemble_rect_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, int* error)
+{
+  const char* rg = getenv("CFX_RECT_GATHER");
+  if (rg && rg[0] == '0') return false;
+  cfx_space_s* V0 = a->V;
+  cfx_space_s* V1 = a->V1;
+  for (const auto& I : a->integrals)
+    if (I.type != CFX_CELL) return false;
+  if ((int64_t)P->max_row_len * V1->bs > 256) return false;
+  cfx_row_plan& plan = row_plan(a);
+  if (!plan.usable || plan.n_cell_slots > 4) return false;
+  if (plan.n_active_rows.cap() == 0) return true;
+  const Adjacency& adj = V0->dof_cells();
+  Rect2Args A{};
+  A.n_active = plan.n_active_rows; A.active_rows = plan.active_rows.p;
+  A.x = V0->mesh->x.p; A.conn = V0->mesh->conn.p; A.dofmap0 = V0->dofmap.p;
+  A.d2c_off = adj.offsets.p; A.d2c = adj.cells.p; A.cellmark = plan.cellmark.p;
+  A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values; A.error = error;
+  A.R = RectArgs{V1->dofmap.p, V0->degree, V0->bs, V0->ndofs_cell, V1->degree, V1->bs, V1->ndofs_cell};
+  A.n_slots = plan.n_cell_slots;
+  for (int s = 0; s < plan.n_cell_slots; ++s)
+  {
+    const cfx_integral_dev& I = a->integrals[plan.cell_slot_integral[s]];
+    Rect2Slot& S = A.slot[s];
+    S.kernel = I.kernel; S.qdegree = I.qdegree; S.scale = I.params[0];
+    S.std_bit = I.n_entities.cap() > 0 ? (uint8_t)(1u << s) : (uint8_t)0;
+    S.rule_bit = 0;
+    if (I.rules && I.rules->nr.cap() > 0)
+    {
+      S.rule_bit = (uint8_t)(16u << s);
+      S.nr = rule_bound(I.rules);
+      S.offsets = I.rules->offsets.p; S.parent_map = I.rules->parent_map.p;
+      S.points = I.rules->points.p; S.weights = I.rules->weights.p;
+      S.rule_keys = plan.rule_keys[s].p; S.rule_first = plan.rule_first[s].p; S.rule_mask = plan.rule_mask[s];
+    }
+  }
+  const int64_t nrows_cap = A.n_active.cap * V0->bs;
+  const dim3 grid = row_grid((nrows_cap + 3) / 4);
+  const bool det = deterministic();
+  if (V0->mesh->tdim == 2)
+  {
+    if (det) launch("assemble_rows2", assemble_rows2_kernel<2, true>, grid, dim3(kWave), 0, A);
+    else launch("assemble_rows2", assemble_rows2_kernel<2, false>, grid, dim3(kWave), 0, A);
+  }
+  else
+  {
+    if (det) launch("assemble_rows2", assemble_rows2_kernel<3, true>, grid, dim3(kWave), 0, A);
+    else launch("assemble_rows2", assemble_rows2_kernel<3, false>, grid, dim3(kWave), 0, A);
+  }
+  return true;
+}
 
 bool assemble_matrix_rows(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t* bc1, double* values, bool fresh)
 {

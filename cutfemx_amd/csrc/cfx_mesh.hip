@@ -86,7 +86,7 @@ int cfx_mesh_create(int tdim, int gdim, int64_t nnodes, const double* x, int64_t
   m->tdim = tdim; m->gdim = gdim; m->nnodes = nnodes; m->ncells = ncells;
   m->x = to_device(x, nnodes * 3);
   if (cell_stride == nv)
-    m->conn = to_device(conn, ncells * nv);
+    m->conn = to_device_aligned(conn, ncells * nv);
   else
   {
     DevArray<int32_t> raw = to_device(conn, ncells * (int64_t)cell_stride);

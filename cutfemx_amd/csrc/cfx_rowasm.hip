@@ -228,6 +228,18 @@ struct RowLenTest
     return ((indptr[r + 1] - indptr[r]) > limit) == longer;
   }
 };
+struct RowLenRange // lo < length <= hi
+{
+  const int32_t* rows;
+  const int64_t* indptr;
+  int lo, hi;
+  __device__ bool operator()(int64_t i) const
+  {
+    const int64_t r = rows[i];
+    const int64_t len = indptr[r + 1] - indptr[r];
+    return len > lo && len <= hi;
+  }
+};
 
 // positions in the active-row list -> row ids, in place
 __global__ void map_rows_kernel(DevN n_d, const int32_t* __restrict__ rows, int32_t* __restrict__ idx)
@@ -796,7 +808,7 @@ __global__ void pattern_write_kernel(DevN n_active_d, const int32_t* __restrict_
   const int64_t ri = i / 8;
   if (ri >= n_active) return;
   const int n = len[ri];
-  const int64_t r = active_rows[ri];
+  const int64_t r = active_rows ? (int64_t)active_rows[ri] : ri; // (no list: all rows, the mesh-static stencil)
   for (int k = (int)(i - ri * 8); k < n; k += 8)
   {
     const int32_t col = tmp[ri * T + k];
@@ -1086,7 +1098,11 @@ __global__ void __launch_bounds__(kBlock) pattern_plain_write_kernel(DevN n_plai
 // ---------------------------------------------------------------------------
 constexpr int kTileMaxSt = kRowTile * 64; // a stencil holds at most 64 neighbours
 
-template <bool WRITE>
+// MODE 0: count the union of every tile; 1: write tile_verts / st_loc at the scanned offsets (the two-pass form);
+// 2: one pass -- st_loc final, the union into a staging row of kTileStage entries per tile (tile_verts then points at
+// the staging array and tile_voff is unused), compacted by stencil_tiles_pack_kernel once the offsets are known
+constexpr int kTileStage = 256;
+template <int MODE>
 __global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int64_t ntiles,
                                                               const int64_t* __restrict__ st_off,
                                                               const int32_t* __restrict__ nbr,
@@ -1138,7 +1154,8 @@ __global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int
     __syncthreads();
     // pack the used slots in order: slot -> position in the union
     int total = 0;
-    const int64_t vb = WRITE ? tile_voff[t] : 0;
+    constexpr bool WRITE = MODE != 0;
+    const int64_t vb = MODE == 1 ? tile_voff[t] : (MODE == 2 ? t * kTileStage : 0);
     for (int c = 0; c < n; c += kWave)
     {
       const int e = c + lane;
@@ -1147,7 +1164,8 @@ __global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int
       const int pos = total + __popcll(used & ((1ull << lane) - 1ull));
       if (v >= 0)
       {
-        if constexpr (WRITE) tile_verts[vb + pos] = v;
+        if constexpr (MODE == 1) tile_verts[vb + pos] = v;
+        if constexpr (MODE == 2) { if (pos < kTileStage) tile_verts[vb + pos] = v; }
         s_m[e] = pos;
       }
       total += __popcll(used);
@@ -1157,7 +1175,7 @@ __global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int
     {
       for (int e = lane; e < n; e += kWave) st_loc[b0 + e] = (uint16_t)s_m[s_rank[e]];
     }
-    else if (lane == 0)
+    if (MODE != 1 && lane == 0)
     {
       counts[t] = total;
       const int64_t rl = r0 + kRowTile < ndofs ? r0 + kRowTile : ndofs;
@@ -1168,6 +1186,18 @@ __global__ void __launch_bounds__(kWave) stencil_tiles_kernel(int64_t ndofs, int
     }
     __syncthreads(); // the LDS arrays are reused by the next tile
   }
+}
+
+__global__ void __launch_bounds__(kBlock) stencil_tiles_pack_kernel(int64_t ntiles, const int32_t* __restrict__ counts,
+                                                                    const int64_t* __restrict__ tile_voff,
+                                                                    const int32_t* __restrict__ staged,
+                                                                    int32_t* __restrict__ tile_verts)
+{
+  const int64_t t = (int64_t)blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (t >= ntiles) return;
+  const int n = counts[t];
+  const int64_t vb = tile_voff[t];
+  for (int k = threadIdx.x % kWave; k < n; k += kWave) tile_verts[vb + k] = staged[t * kTileStage + k];
 }
 
 // plain-list positions at which a new row tile starts
@@ -1819,15 +1849,36 @@ const Stencil& space_stencil(cfx_space_s* V)
   DevArray<int32_t> counts(V->ndofs), len(V->ndofs);
   ZeroFlag overflow, maxlen;
   A.len = len.p; A.counts = counts.p; A.overflow = overflow.p; A.maxlen = maxlen.p;
-  // count, scan, then build every set again and write it in place (no ndofs x 64 staging)
+  // One pass when the card has room for ndofs x 64 staged columns (34 GB at 512^3, released right after): every set is
+  // ranked into its staging row and copied once the offsets are known; else count, scan, build every set again and
+  // write it in place (30 + 31 ms at 512^3 against 30 + 7).
+  DevArray<int32_t> staged;
+  {
+    size_t free_b = 0, total_b = 0;
+    CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t live_b = 0, cached_b = 0, peak_b = 0;
+    device_memory_stats(live_b, cached_b, peak_b);
+    const size_t need = (size_t)V->ndofs * 64 * sizeof(int32_t);
+    const char* sv = getenv("CFX_STENCIL_STAGED");
+    if (need < (free_b + cached_b) / 3 && !(sv && sv[0] == '0')) { staged.alloc(V->ndofs * 64); A.tmp = staged.p; }
+  }
   launch("stencil_rows", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
   if (read_scalar(overflow.p)) return S; // a vertex with more than 63 neighbours: keep the hashed paths
   S.max_len = read_scalar(maxlen.p);
   S.offsets.alloc(V->ndofs + 1);
   exclusive_scan(counts.p, S.offsets.p, V->ndofs);
   S.nbr.alloc(read_scalar(S.offsets.p + V->ndofs));
-  A.indptr = S.offsets.p; A.indices = S.nbr.p;
-  launch("stencil_rows_write", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
+  if (staged.p)
+  {
+    launch("stencil_rows_write", pattern_write_kernel<64>, grid_for(V->ndofs * 8), dim3(kBlock), 0, DevN(V->ndofs),
+           (const int32_t*)nullptr, 1, staged.p, len.p, S.offsets.p, S.nbr.p);
+    staged.release_to_driver();
+  }
+  else
+  {
+    A.indptr = S.offsets.p; A.indices = S.nbr.p;
+    launch("stencil_rows_write", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
+  }
   S.slot4.alloc(adj.cells.n);
   S.diagpos.alloc(V->ndofs);
   S.cpos.alloc(V->mesh->ncells * (int64_t)V->ndofs_cell);
@@ -1852,17 +1903,46 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
   DevArray<int> maxima(3);
   maxima.zero();
   const dim3 grid = wave_grid(ntiles);
-  launch("stencil_tiles", stencil_tiles_kernel<false>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
-         adj.offsets.p, counts.p, (const int64_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, maxima.p);
+  // one pass when the card has room for kTileStage staged vertices per tile (8.6 GB at 512^3, given back right after)
+  // and no tile's union outgrows its staging row; else count, scan and build every tile a second time (42 + 52 ms)
+  DevArray<int32_t> staged;
+  {
+    size_t free_b = 0, total_b = 0;
+    CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+    size_t live_b = 0, cached_b = 0, peak_b = 0;
+    device_memory_stats(live_b, cached_b, peak_b);
+    const size_t need = (size_t)ntiles * kTileStage * sizeof(int32_t) + (size_t)S.nbr.n * sizeof(uint16_t);
+    const char* sv = getenv("CFX_STENCIL_STAGED");
+    if (need < (free_b + cached_b) / 3 && !(sv && sv[0] == '0')) staged.alloc(ntiles * kTileStage);
+  }
+  if (staged.p)
+  {
+    S.st_loc.alloc(S.nbr.n);
+    launch("stencil_tiles", stencil_tiles_kernel<2>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
+           adj.offsets.p, counts.p, (const int64_t*)nullptr, staged.p, S.st_loc.p, maxima.p);
+  }
+  else
+    launch("stencil_tiles", stencil_tiles_kernel<0>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
+           adj.offsets.p, counts.p, (const int64_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, maxima.p);
   const std::vector<int> mx = download(maxima.p, 3);
   S.max_tile_verts = mx[0]; S.max_tile_st = mx[1]; S.max_tile_items = mx[2];
-  if (S.max_tile_st > kTileMaxSt) return S;
+  if (S.max_tile_st > kTileMaxSt) { S.st_loc.release(); staged.release_to_driver(); return S; }
   S.tile_voff.alloc(ntiles + 1);
   exclusive_scan(counts.p, S.tile_voff.p, ntiles);
   S.tile_verts.alloc(read_scalar(S.tile_voff.p + ntiles));
-  S.st_loc.alloc(S.nbr.n);
-  launch("stencil_tiles_write", stencil_tiles_kernel<true>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
-         adj.offsets.p, (int32_t*)nullptr, S.tile_voff.p, S.tile_verts.p, S.st_loc.p, maxima.p);
+  if (staged.p && S.max_tile_verts <= kTileStage)
+  {
+    launch("stencil_tiles_write", stencil_tiles_pack_kernel, grid_for(ntiles * kWave), dim3(kBlock), 0, ntiles, counts.p,
+           S.tile_voff.p, staged.p, S.tile_verts.p);
+    staged.release_to_driver();
+  }
+  else
+  {
+    staged.release_to_driver();
+    if (!S.st_loc.p) S.st_loc.alloc(S.nbr.n);
+    launch("stencil_tiles_write", stencil_tiles_kernel<1>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
+           adj.offsets.p, (int32_t*)nullptr, S.tile_voff.p, S.tile_verts.p, S.st_loc.p, maxima.p);
+  }
   S.tiles_usable = true;
   publish_across_lanes();
   return S;
@@ -2809,11 +2889,19 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       }
     }
     P->n_short_rows = compact("pattern_short_rows", n_base, RowLenTest{base_rows, P->indptr.p, 64, false}, P->short_rows);
-    P->n_long_rows = compact("pattern_long_rows", n_base, RowLenTest{base_rows, P->indptr.p, 64, true}, P->long_rows);
+    // (three classes: a row set of 256 columns leaves the interface kernel two wavefronts per SIMD, and the vertex dofs
+    // of a degree-2 space -- 65 columns in a Kuhn mesh, ~90 with ghost-penalty couplings -- do not need it)
+    P->n_mid_rows = compact("pattern_long_rows", n_base, RowLenRange{base_rows, P->indptr.p, 64, 128}, P->mid_rows);
+    P->n_long_rows = compact("pattern_long_rows", n_base, RowLenTest{base_rows, P->indptr.p, 128, true}, P->long_rows);
     launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_short_rows), dim3(kBlock), 0, P->n_short_rows,
            base_rows, P->short_rows.p);
+    launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_mid_rows), dim3(kBlock), 0, P->n_mid_rows,
+           base_rows, P->mid_rows.p);
     launch("pattern_map_rows", map_rows_kernel, grid_for(P->n_long_rows), dim3(kBlock), 0, P->n_long_rows,
            base_rows, P->long_rows.p);
+    if (getenv("CFX_PLAN_DEBUG"))
+      fprintf(stderr, "cutfemx_amd: hashed row classes: <= 64 columns %lld, <= 128 %lld, longer %lld\n",
+              (long long)P->n_short_rows, (long long)P->n_mid_rows, (long long)P->n_long_rows);
     P->split_plan = plan.serial;
   }
   pattern_remember(a, P);

@@ -198,3 +198,64 @@ def test_gpu_pressure_ghost_penalty_power(oracle, tdim, n):
     assert np.array_equal(A.indices, ix) and rel_err(A.data, want) < 1e-12
     got = fem.tabulate_entity(fem.form(ga, V), 1, len(oghost) // 2, False)
     assert rel_err(got, O.tabulate_entity(om, oV, oa[1], len(oghost) // 2, False)) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n", [(2, 10), (3, 5)])
+def test_gpu_rectangular_blocks_by_row_gather(oracle, tdim, n, monkeypatch):
+    """Rectangular blocks go by row gather (assemble_rows2: one writer per row, no global atomics) unless the atomic path
+    is forced: both give the oracle's block, the gather is bitwise reproducible in deterministic mode, and a form with
+    two integrals (standard entities of one, rules of the other) takes one pass."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    from helpers import profiled
+    O = oracle
+    om, dm2, nd2, oVU, oVP, oVS = spaces(O, tdim, n)
+    phi = level_set_values(om.x, tdim)
+    dom = O.classify(om.conn, phi)
+    inside = O.locate_entities(dom, "phi<0")
+    ovol = O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", 4)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    VU = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2, bs=tdim)
+    VS = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2)
+    VP = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(VP, phi))
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    cases = {"Bt": (oVU, oVP, VU, VP, O.K_DIV_TEST, fem.DIV_TEST, (-1.0,)), "B": (oVP, oVU, VP, VU, O.K_DIV_TRIAL, fem.DIV_TRIAL, (-1.0,)),
+             "M21": (oVS, oVP, VS, VP, O.K_MASS, fem.MASS, ())}
+    for name, (o0, o1, g0, g1, ok, gk, par) in cases.items():
+        # two integrals: the uncut cells under one, the cut-cell rules under the other (+ a second copy of both)
+        oa = [O.Integral(O.CELL, ok, entities=inside, params=par, qdegree=3),
+              O.Integral(O.CELL, ok, rules=ovol, params=par, qdegree=3),
+              O.Integral(O.CELL, ok, entities=inside, rules=ovol, params=par, qdegree=3)]
+        ga = [fem.Integral(gk, cells=inside, params=par, qdegree=3),
+              fem.Integral(gk, rules=vol, params=par, qdegree=3),
+              fem.Integral(gk, cells=inside, rules=vol, params=par, qdegree=3)]
+        a = fem.form(ga, g0, trial_space=g1)
+        ip, ix = O.create_sparsity2(om, o0, o1, oa)
+        want = O.assemble_matrix2(om, o0, o1, oa, ip, ix)
+        monkeypatch.delenv("CFX_RECT_GATHER", raising=False)
+        A, names = profiled(lambda: fem.assemble_matrix(a))
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), name
+        assert rel_err(A.data, want) < 1e-12, name
+        import os
+        gather = os.environ.get("CFX_ASSEMBLY") != "atomic"
+        if gather:
+            assert "assemble_rows2" in names and "assemble_cells2_std" not in names, (name, sorted(names))
+        monkeypatch.setenv("CFX_RECT_GATHER", "0")
+        A0, names0 = profiled(lambda: fem.assemble_matrix(a))
+        assert "assemble_rows2" not in names0 and "assemble_cells2_std" in names0, (name, sorted(names0))
+        assert rel_err(A0.data, want) < 1e-12 and rel_err(A.data, A0.data) < 1e-13, name
+        monkeypatch.delenv("CFX_RECT_GATHER", raising=False)
+        monkeypatch.setenv("CFX_DETERMINISTIC", "1")
+        D1, D2 = fem.assemble_matrix(a), fem.assemble_matrix(a)
+        assert rel_err(D1.data, want) < 1e-12 and rel_err(D2.data, want) < 1e-12, name
+        if gather:                                    # (FP64 atomics arrive in any order)
+            assert np.array_equal(D1.data, D2.data), name
+        monkeypatch.delenv("CFX_DETERMINISTIC", raising=False)
+        # markers on both sides through the gather
+        rng = np.random.default_rng(11)
+        bc0 = (rng.random(o0.ndofs * o0.bs) < 0.1).astype(np.int8)
+        bc1 = (rng.random(o1.ndofs * o1.bs) < 0.1).astype(np.int8)
+        Ab = fem.assemble_matrix(a, bcs=(bc0, bc1))
+        assert rel_err(Ab.data, O.assemble_matrix2(om, o0, o1, oa, ip, ix, bc0, bc1)) < 1e-12, name

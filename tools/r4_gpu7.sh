@@ -1,0 +1,8 @@
+#!/bin/bash
+set -e
+mkdir -p gpurun_out/r4
+O=gpurun_out/r4
+timeout -k 10 600 python -m pytest tests/test_rectangular_forms.py tests/test_complex_assembly.py -x -q > $O/t7.log 2>&1 || { tail -40 $O/t7.log; exit 1; }
+tail -3 $O/t7.log
+CFX_ASSEMBLY=atomic timeout -k 10 600 python -m pytest tests/test_rectangular_forms.py -x -q > $O/t7a.log 2>&1 || { tail -40 $O/t7a.log; exit 1; }
+tail -3 $O/t7a.log

@@ -51,6 +51,23 @@ __host__ __device__ __forceinline__ uint32_t cfx_hash32(uint32_t h)
   return h;
 }
 
+// Integer atomics of a workgroup combined in LDS before they go to memory (incidence inversions: adj_*_lds_kernel,
+// facet_dof_*_kernel): kAdjRun consecutive entries per workgroup, <= kAdjRun distinct keys in 2 kAdjRun slots; the
+// return value is the slot, `rank` the arrival number of this entry among the workgroup's entries with the same key.
+constexpr int kAdjPer = 4, kAdjRun = kBlock * kAdjPer, kAdjSlots = 2 * kAdjRun;
+__device__ __forceinline__ int adj_lds_insert(int32_t* s_key, int32_t* s_cnt, int32_t item, int& rank)
+{
+  unsigned h = cfx_hash32((uint32_t)item) & (kAdjSlots - 1);
+  for (;;)
+  {
+    const int32_t prev = atomicCAS(&s_key[h], -1, item);
+    if (prev == -1 || prev == item) break;
+    h = (h + 1) & (kAdjSlots - 1);
+  }
+  rank = atomicAdd(&s_cnt[h], 1);
+  return (int)h;
+}
+
 // inclusive scan over the 64 lanes of a wavefront
 template <typename T>
 __device__ __forceinline__ T wave_inclusive_scan(T v)

@@ -310,46 +310,86 @@ __global__ void plan_scatter_pos_kernel(DevN n_d, const int32_t* __restrict__ ro
   if (i < n) pos[rows[i]] = (int32_t)i;
 }
 
-__global__ void facet_dof_count_kernel(DevN nf_d, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                       int nd, const int32_t* __restrict__ pos, int32_t* counts)
+// the special-row position of the k-th (facet, dof) pair of facet f, or -1 for the cell-1 copy of a dof both cells hold
+// (a shared dof lists the facet once)
+__device__ __forceinline__ int32_t facet_pair_key(const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap, int nd,
+                                                  const int32_t* __restrict__ pos, int64_t f, int k)
 {
-  const int64_t nf = dev_n(nf_d);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * 2 * nd) return;
-  const int64_t f = i / (2 * nd);
-  const int k = (int)(i - f * 2 * nd);
   const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
   const int32_t dof = dofmap[c * nd + (k < nd ? k : k - nd)];
-  // a dof shared by both cells must list the facet once: skip the cell1 copy
   if (k >= nd)
   {
     const int64_t c0 = rows[4 * f];
-    for (int j = 0; j < nd; ++j)
-      if (dofmap[c0 * nd + j] == dof) return;
+    bool skip = false;
+    for (int j = 0; j < nd; ++j) skip = skip || dofmap[c0 * nd + j] == dof;
+    if (skip) return -1;
   }
-  atomicAdd(&counts[pos[dof]], 1);
+  return pos[dof];
 }
 
-__global__ void facet_dof_fill_kernel(DevN nf_d, const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap,
-                                      int nd, const int32_t* __restrict__ pos, const int64_t* __restrict__ offs,
-                                      int32_t* cursor, int32_t* facets)
+// count + fill with the workgroup's atomics combined in LDS (cfx_device.h: adj_lds_insert): consecutive facets of the
+// list share most of their dofs (the list follows the cut cells), so a run of 1024 pairs reaches memory as ~150
+// atomics.  (counts / offsets / cursors are indexed by the dof's position in the special-row list.)  Round 3 sorted the
+// pairs instead from 6 M pairs on (13 launches, 1.1 ms at 512^3 against 0.6 ms now); CFX_FACET_SORT=1 keeps that path.
+__global__ void __launch_bounds__(kBlock) facet_dof_count_kernel(DevN nf_d, const int32_t* __restrict__ rows,
+                                                                 const int32_t* __restrict__ dofmap, int nd,
+                                                                 const int32_t* __restrict__ pos, int32_t* counts)
 {
-  const int64_t nf = dev_n(nf_d);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nf * 2 * nd) return;
-  const int64_t f = i / (2 * nd);
-  const int k = (int)(i - f * 2 * nd);
-  const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
-  const int32_t dof = dofmap[c * nd + (k < nd ? k : k - nd)];
-  if (k >= nd)
+  __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
+  for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
+  __syncthreads();
+  const int64_t npairs = dev_n(nf_d) * 2 * nd;
+  const int64_t base = (int64_t)blockIdx.x * kAdjRun;
+#pragma unroll
+  for (int q = 0; q < kAdjPer; ++q)
   {
-    const int64_t c0 = rows[4 * f];
-    for (int j = 0; j < nd; ++j)
-      if (dofmap[c0 * nd + j] == dof) return;
+    const int64_t i = base + q * kBlock + threadIdx.x;
+    if (i >= npairs) continue;
+    const int64_t f = i / (2 * nd);
+    const int32_t key = facet_pair_key(rows, dofmap, nd, pos, f, (int)(i - f * 2 * nd));
+    int rank;
+    if (key >= 0) (void)adj_lds_insert(s_key, s_cnt, key, rank);
   }
-  const int32_t q = pos[dof];
-  // (cursor[q] holds the row's count from the count pass: slots are handed out from the back)
-  facets[offs[q] + atomicSub(&cursor[q], 1) - 1] = (int32_t)f;
+  __syncthreads();
+  for (int k = threadIdx.x; k < kAdjSlots; k += kBlock)
+    if (s_key[k] >= 0) atomicAdd(&counts[s_key[k]], s_cnt[k]);
+}
+
+__global__ void __launch_bounds__(kBlock) facet_dof_fill_kernel(DevN nf_d, const int32_t* __restrict__ rows,
+                                                                const int32_t* __restrict__ dofmap, int nd,
+                                                                const int32_t* __restrict__ pos,
+                                                                const int64_t* __restrict__ offs, int32_t* cursor,
+                                                                int32_t* facets)
+{
+  __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
+  for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
+  __syncthreads();
+  const int64_t npairs = dev_n(nf_d) * 2 * nd;
+  const int64_t base = (int64_t)blockIdx.x * kAdjRun;
+  int32_t key[kAdjPer], fac[kAdjPer];
+  int slot[kAdjPer], rank[kAdjPer];
+#pragma unroll
+  for (int q = 0; q < kAdjPer; ++q)
+  {
+    const int64_t i = base + q * kBlock + threadIdx.x;
+    key[q] = -1; fac[q] = 0; slot[q] = 0; rank[q] = 0;
+    if (i < npairs)
+    {
+      const int64_t f = i / (2 * nd);
+      fac[q] = (int32_t)f;
+      key[q] = facet_pair_key(rows, dofmap, nd, pos, f, (int)(i - f * 2 * nd));
+      if (key[q] >= 0) slot[q] = adj_lds_insert(s_key, s_cnt, key[q], rank[q]);
+    }
+  }
+  __syncthreads();
+  // (cursor[q] holds the row's count from the count pass: slots are handed out from the back, so the counters need no
+  // second zero fill; the workgroup's entries of a row take one contiguous run)
+  for (int k = threadIdx.x; k < kAdjSlots; k += kBlock)
+    if (s_key[k] >= 0) s_cnt[k] = atomicSub(&cursor[s_key[k]], s_cnt[k]) - s_cnt[k];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kAdjPer; ++q)
+    if (key[q] >= 0) facets[offs[key[q]] + s_cnt[slot[q]] + rank[q]] = fac[q];
 }
 
 // dof -> facets incidence by sorting: one (special-row position, facet) pair per dof of a facet's two cells (a dof
@@ -1729,11 +1769,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     // dof -> facets incidence of the rows that have facets (all of them special; special_pos came with the row lists)
     const char* fs = getenv("CFX_FACET_SORT");
     const int64_t npairs = nf_cap * 2 * nd;
-    // Small problems (a rank's share of a multi-GPU run): count + scan + fill with integer atomics -- 4 launches where
-    // the radix sort takes 13 (a kernel boundary costs ~10 us on this chip, profiles/r04_launch_gaps.txt) and 35 M
-    // returning atomics, which made this path the slower one at 512^3, shrink with the problem.  CFX_FACET_SORT=1 / 0
-    // forces one or the other.
-    const bool by_sort = (fs && fs[0] == '1') || (!(fs && fs[0] == '0') && npairs >= 6000000LL);
+    // count + scan + fill with integer atomics combined per workgroup in LDS: 5 launches where the radix sort of
+    // rounds 2-3 takes 13 (a kernel boundary costs ~10 us on this chip, profiles/r04_launch_gaps.txt).  CFX_FACET_SORT=1
+    // keeps the sort (every list then comes out in ascending facet order without the deterministic mode's list sort).
+    const bool by_sort = fs && fs[0] == '1';
     if (by_sort && npairs < 2147483647LL && ns_cap < 2147483647LL)
     {
       // (lengths still in HBM: the sort covers the capacity of the pair list, pairs behind the last facet carry the
@@ -1762,12 +1801,13 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       // the counters as cursors counting DOWN, so that they need no second zero fill)
       DevArray<int32_t> fcount(ns_cap);
       fcount.zero();
-      launch("facet_dof_count", facet_dof_count_kernel, grid_for(npairs), dim3(kBlock), 0, P.nfacets,
+      const dim3 run_grid((unsigned)((npairs + kAdjRun - 1) / kAdjRun));
+      launch("facet_dof_count", facet_dof_count_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
       P.d2f_offsets.alloc(ns_cap + 1);
       exclusive_scan(fcount.p, P.d2f_offsets.p, ns_cap);
       P.d2f.alloc(npairs);
-      launch("facet_dof_fill", facet_dof_fill_kernel, grid_for(npairs), dim3(kBlock), 0, P.nfacets,
+      launch("facet_dof_fill", facet_dof_fill_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
     }
   }

@@ -891,20 +891,6 @@ __global__ void adj_fill_kernel(const int32_t* __restrict__ map, int64_t nentrie
 // (<= kAdjRun distinct keys in 2 kAdjRun slots) and issues ONE global atomic per distinct item; in the fill pass that
 // atomic reserves the item's slots for the whole workgroup and an entry's place among them is its arrival rank in
 // LDS (the lists are sorted afterwards either way).  Meshes without any locality pay the LDS pass on top (~10 %).
-constexpr int kAdjPer = 4, kAdjRun = kBlock * kAdjPer, kAdjSlots = 2 * kAdjRun;
-__device__ __forceinline__ int adj_lds_insert(int32_t* s_key, int32_t* s_cnt, int32_t item, int& rank)
-{
-  unsigned h = cfx_hash32((uint32_t)item) & (kAdjSlots - 1);
-  for (;;)
-  {
-    const int32_t prev = atomicCAS(&s_key[h], -1, item);
-    if (prev == -1 || prev == item) break;
-    h = (h + 1) & (kAdjSlots - 1);
-  }
-  rank = atomicAdd(&s_cnt[h], 1);
-  return (int)h;
-}
-
 __global__ void __launch_bounds__(kBlock) adj_count_lds_kernel(const int32_t* __restrict__ map, int64_t nentries, int32_t* counts)
 {
   __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];

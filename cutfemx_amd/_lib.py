@@ -110,6 +110,7 @@ SYMBOLS = [
     "cfx_set_bc_f32", "cfx_zero_rows_f32", "cfx_deactivate_outside_f32",
     "cfx_assemble_matrix_c128", "cfx_assemble_vector_c128", "cfx_apply_lifting_c128", "cfx_set_bc_c128",
     "cfx_deactivate_outside_c128",
+    "cfx_assemble_matrix_c64", "cfx_assemble_vector_c64", "cfx_apply_lifting_c64", "cfx_set_bc_c64", "cfx_deactivate_outside_c64",
 ]
 
 _lib = None
@@ -232,6 +233,8 @@ def scalar_dtype(a):
         return np.float64
     if getattr(a, "dtype", None) == np.dtype(np.complex128):
         return np.complex128                       # host numpy vectors of the complex128 instantiation (cfx_*_c128)
+    if getattr(a, "dtype", None) == np.dtype(np.complex64):
+        return np.complex64                        # ... and of the complex64 one (cfx_*_c64)
     if isinstance(a, DeviceBuffer):
         return np.float32 if a.dtype == np.dtype(np.float32) else np.float64
     if is_torch(a):

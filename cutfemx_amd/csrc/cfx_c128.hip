@@ -64,10 +64,11 @@ __global__ void __launch_bounds__(kBlock) set_bc_c128_kernel(int64_t n, const in
   b[i] = make_double2(ar * dr - ai * di, ar * di + ai * dr);
 }
 
+template <typename C2> // double2 (complex128) or float2 (complex64)
 __global__ void __launch_bounds__(kBlock) deactivate_c128_kernel(int64_t n, const int32_t* __restrict__ rows,
                                                                  const int64_t* __restrict__ indptr,
-                                                                 const int32_t* __restrict__ indices, double2* values, double2* b,
-                                                                 double2 diagonal, double2 rhs_value, int* error)
+                                                                 const int32_t* __restrict__ indices, C2* values, C2* b,
+                                                                 C2 diagonal, C2 rhs_value, int* error)
 {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -90,6 +91,37 @@ __global__ void __launch_bounds__(kBlock) deactivate_c128_kernel(int64_t n, cons
     if (pos < 0) *error = 1; else values[pos] = diagonal; // set, not add (set_diagonal)
   }
   if (b) b[r] = rhs_value;
+}
+
+// complex64 containers: widened once on the way in, rounded once on the way out (the policy of the float32 boundary)
+__global__ void __launch_bounds__(kBlock) widen_c64_kernel(int64_t n, const float* __restrict__ in, double* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+template <bool ADD>
+__global__ void __launch_bounds__(kBlock) narrow_c64_kernel(int64_t n, const double* __restrict__ in, float* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ADD ? (float)((double)out[i] + in[i]) : (float)in[i];
+}
+DevArray<double> widen_c64(const float* src, int64_t n)
+{
+  DevArray<double> out(n);
+  if (n > 0)
+  {
+    DevArray<float> in = to_device(src, n);
+    launch("widen_c64", widen_c64_kernel, grid_for(n), dim3(kBlock), 0, n, (const float*)in.p, out.p);
+    if (in.owned) CFX_HIP(hipStreamSynchronize(ctx().stream)); // the staging copy dies with `in`
+  }
+  return out;
+}
+template <bool ADD>
+void narrow_c64(const double* src, float* user, int64_t n)
+{
+  OutArray<float> out(user, n, ADD);
+  if (n > 0) launch("narrow_c64", narrow_c64_kernel<ADD>, grid_for(n), dim3(kBlock), 0, n, src, out.dev);
+  out.finish();
 }
 
 template <typename T>
@@ -255,10 +287,93 @@ int cfx_deactivate_outside_c128(cfx_active_t d, cfx_pattern_t P, double* values,
   cfx::active_lists(d);
   const int64_t n_inactive = d->n_inactive.value();
   if (n_inactive > 0)
-    launch("deactivate", deactivate_c128_kernel, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
+    launch("deactivate", deactivate_c128_kernel<double2>, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
            (const int32_t*)d->inactive_dofs.p, P ? (const int64_t*)P->indptr.p : (const int64_t*)nullptr,
            P ? (const int32_t*)P->indices.p : (const int32_t*)nullptr, values ? reinterpret_cast<double2*>(ov->dev) : (double2*)nullptr,
            b ? reinterpret_cast<double2*>(ob->dev) : (double2*)nullptr, make_double2(diag_re, diag_im), make_double2(rhs_re, rhs_im), err.p);
+  require(!read_scalar(err.p), CFX_ERR_RUNTIME, "Deactivated matrix row has no diagonal entry.");
+  if (ov) ov->finish();
+  if (ob) ob->finish();
+  CFX_API_END
+}
+
+// ---- complex64: the <std::complex<float>, float> rows of python/cutfemx/wrappers/fem.cpp:490-500.  Containers (CSR values,
+// vectors, Dirichlet data) are interleaved float32; constants stay double; every sum is formed in fp64 by the complex128
+// path above and rounded once.
+int cfx_assemble_matrix_c64(cfx_form_t a, cfx_pattern_t P, const int8_t* bc0, const int8_t* bc1, const double* scales,
+                            int zero_first, float* values)
+{
+  CFX_API_BEGIN
+  require(a && P && values, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_matrix_c64: null argument");
+  const int64_t nnz = P->nnz.value();
+  DevArray<double> wide(2 * nnz);
+  const int rc = cfx_assemble_matrix_c128(a, P, bc0, bc1, scales, 1, wide.p);
+  if (rc != CFX_OK) return rc;
+  if (zero_first) narrow_c64<false>(wide.p, values, 2 * nnz); else narrow_c64<true>(wide.p, values, 2 * nnz);
+  CFX_API_END
+}
+
+int cfx_assemble_vector_c64(cfx_form_t L, const double* scales, float* b)
+{
+  CFX_API_BEGIN
+  require(L && b, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_vector_c64: null argument");
+  require(L->rank == 1, CFX_ERR_INVALID_ARGUMENT, "cfx_assemble_vector_c64: form is not linear");
+  const int64_t n = L->V->ndofs * L->V->bs;
+  DevArray<double> wide(2 * n);
+  wide.zero();
+  const int rc = cfx_assemble_vector_c128(L, scales, wide.p);
+  if (rc != CFX_OK) return rc;
+  narrow_c64<true>(wide.p, b, 2 * n);
+  CFX_API_END
+}
+
+int cfx_apply_lifting_c64(cfx_form_t a, const int8_t* bc_markers, const float* bc_values, const float* x0, double alpha_re,
+                          double alpha_im, const double* scales, float* b)
+{
+  CFX_API_BEGIN
+  require(a && bc_markers && bc_values && b, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting_c64: null argument");
+  require(a->rank == 2, CFX_ERR_INVALID_ARGUMENT, "cfx_apply_lifting_c64: form is not bilinear");
+  const int64_t n = a->V->ndofs * a->V->bs, n1 = a->V1->ndofs * a->V1->bs;
+  DevArray<double> g = widen_c64(bc_values, 2 * n1), x = widen_c64(x0, x0 ? 2 * n1 : 0), wide(2 * n);
+  wide.zero();
+  const int rc = cfx_apply_lifting_c128(a, bc_markers, g.p, x0 ? x.p : nullptr, alpha_re, alpha_im, scales, wide.p);
+  if (rc != CFX_OK) return rc;
+  narrow_c64<true>(wide.p, b, 2 * n);
+  CFX_API_END
+}
+
+int cfx_set_bc_c64(int64_t n, const int8_t* bc_markers, const float* bc_values, const float* x0, double alpha_re,
+                   double alpha_im, float* b)
+{
+  CFX_API_BEGIN
+  require(n >= 0 && bc_markers && bc_values && b, CFX_ERR_INVALID_ARGUMENT, "cfx_set_bc_c64: null argument");
+  ctx().ensure();
+  // (unmarked entries make the round trip float -> double -> float unchanged)
+  DevArray<double> g = widen_c64(bc_values, 2 * n), x = widen_c64(x0, x0 ? 2 * n : 0), wide = widen_c64(b, 2 * n);
+  const int rc = cfx_set_bc_c128(n, bc_markers, g.p, x0 ? x.p : nullptr, alpha_re, alpha_im, wide.p);
+  if (rc != CFX_OK) return rc;
+  narrow_c64<false>(wide.p, b, 2 * n);
+  CFX_API_END
+}
+
+int cfx_deactivate_outside_c64(cfx_active_t d, cfx_pattern_t P, float* values, float* b, double diag_re, double diag_im,
+                               double rhs_re, double rhs_im)
+{
+  CFX_API_BEGIN
+  require(d && (values == nullptr || P), CFX_ERR_INVALID_ARGUMENT, "cfx_deactivate_outside_c64: null argument");
+  const int64_t nrows = d->V->ndofs * d->V->bs;
+  std::unique_ptr<OutArray<float>> ov, ob;
+  if (values) ov = std::make_unique<OutArray<float>>(values, 2 * P->nnz.value(), true);
+  if (b) ob = std::make_unique<OutArray<float>>(b, 2 * nrows, true);
+  ZeroFlag err;
+  cfx::active_lists(d);
+  const int64_t n_inactive = d->n_inactive.value();
+  if (n_inactive > 0)
+    launch("deactivate", deactivate_c128_kernel<float2>, grid_for(n_inactive), dim3(kBlock), 0, n_inactive,
+           (const int32_t*)d->inactive_dofs.p, P ? (const int64_t*)P->indptr.p : (const int64_t*)nullptr,
+           P ? (const int32_t*)P->indices.p : (const int32_t*)nullptr, values ? reinterpret_cast<float2*>(ov->dev) : (float2*)nullptr,
+           b ? reinterpret_cast<float2*>(ob->dev) : (float2*)nullptr, make_float2((float)diag_re, (float)diag_im),
+           make_float2((float)rhs_re, (float)rhs_im), err.p);
   require(!read_scalar(err.p), CFX_ERR_RUNTIME, "Deactivated matrix row has no diagonal entry.");
   if (ov) ov->finish();
   if (ob) ob->finish();

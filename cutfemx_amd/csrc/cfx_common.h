@@ -125,6 +125,8 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shm
   Context& c = ctx();
   if (grid.x == 0) return;
   c.last_launch = name;
+  static const bool trace = getenv("CFX_LAUNCH_TRACE") != nullptr; // the launch sequence of a step on stderr
+  if (trace) fprintf(stderr, "cutfemx_amd: launch %s grid %u\n", name, grid.x);
   // HIP launches at most 2^32 - 1 work-items per dimension; a larger grid is cut short silently
   if ((uint64_t)grid.x * block.x > 0xffffffffull)
     throw Error(CFX_ERR_RUNTIME, std::string(name) + ": launch exceeds 2^32 threads");
@@ -306,6 +308,7 @@ int* step_error_flag(int code, const char* message, void (*decode)(int) = nullpt
 // memset on the library stream in ONE launch (hipMemsetAsync splits unaligned sizes into up to three fill kernels,
 // ~100 tiny launches per step); cfx_runtime.hip
 void dev_fill(void* p, int byte, size_t bytes);
+void dev_fill2(void* pa, int byte_a, size_t bytes_a, void* pb, int byte_b, size_t bytes_b); // two fills, one launch
 
 // a zero-initialised device int from a pool that is cleared with one fill per 4096 flags (error / overflow flags:
 // a step took a dozen 4-byte memsets for them)
@@ -498,6 +501,9 @@ struct OutArray
 void exclusive_scan(const int32_t* in, int64_t* out, int64_t n, CountPlan* after = nullptr);
 void exclusive_scan(const int32_t* in, int32_t* out, int64_t n, CountPlan* after = nullptr);
 void exclusive_scan(const int64_t* in, int64_t* out, int64_t n, CountPlan* after = nullptr);
+// two scans of one length in one launch (the counts of `after` are published once both totals are written)
+void exclusive_scan_pair(const int32_t* inA, int64_t* outA, const int32_t* inB, int64_t* outB, int64_t n, CountPlan* after = nullptr);
+void exclusive_scan_pair(const int64_t* inA, int64_t* outA, const int64_t* inB, int64_t* outB, int64_t n, CountPlan* after = nullptr);
 
 // ---------------------------------------------------------------------------
 // handles

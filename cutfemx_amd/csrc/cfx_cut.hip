@@ -2071,8 +2071,7 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
       const char* names[2] = {"locate.inside", "locate.cut"};
       const CountSource src[2] = {{off_in.p + ntiles, kCountI64, kCountUpTo}, {off_cut.p + ntiles, kCountI64, kCountUpTo}};
       CountPlan cp(2, names, src);
-      exclusive_scan(cut->tiles_inside.p, off_in.p, ntiles);
-      exclusive_scan(cut->tiles_cut.p, off_cut.p, ntiles, &cp);
+      exclusive_scan_pair(cut->tiles_inside.p, off_in.p, cut->tiles_cut.p, off_cut.p, ntiles, &cp);
       Count cnt[2];
       cp.finish(cnt);
       DevArray<int32_t> l_in(cnt[0].cap()), l_cut(cnt[1].cap());
@@ -2346,7 +2345,9 @@ void simple_rules(cfx_cut_t cut, int n, const int* parts, int order, cfx_rules_t
     src[2 * k + 1] = CountSource{packed_off[k].p + ncut, kCountPackedHi, kCountUpTo};
   }
   CountPlan cp(2 * n, names, src);
-  for (int k = 0; k < n; ++k) exclusive_scan(packed[k].p, packed_off[k].p, ncut, k == n - 1 ? &cp : nullptr);
+  if (n == 2) exclusive_scan_pair(packed[0].p, packed_off[0].p, packed[1].p, packed_off[1].p, ncut, &cp);
+  else
+    for (int k = 0; k < n; ++k) exclusive_scan(packed[k].p, packed_off[k].p, ncut, k == n - 1 ? &cp : nullptr);
   cp.finish(totals);
   EmitJobs jobs{};
   jobs.n = n;

@@ -938,11 +938,22 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
                                                                       int32_t* __restrict__ active,
                                                                       int32_t* __restrict__ special_rows,
                                                                       int32_t* __restrict__ plain_rows, DevN n_special_d,
-                                                                      DevN n_plain_d, int32_t* __restrict__ special_pos)
+                                                                      DevN n_plain_d, int32_t* __restrict__ special_pos,
+                                                                      int32_t* __restrict__ zero_counts, int64_t zero_n)
 {
   // (lists sized by the previous step: nothing is written beyond their published lengths -- 0 in a void step)
   const int64_t cap_s = n_special_d.dev ? dev_n(n_special_d) : INT64_MAX, cap_p = n_plain_d.dev ? dev_n(n_plain_d) : INT64_MAX;
   const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
+  if (zero_counts)
+  {
+    // the counters of the dof -> facets incidence (one per special row, capacity zero_n <= about the dofs): zeroed
+    // here, a launch less than a fill of their own
+#pragma unroll
+    for (int k = 0; k < kByteItems; ++k)
+      if (base + k < zero_n) zero_counts[base + k] = 0;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+      for (int64_t i = (int64_t)gridDim.x * kBlock * kByteItems; i < zero_n; ++i) zero_counts[i] = 0;
+  }
   unsigned fa = 0, fs = 0;
   if (base < n)
   {
@@ -1539,8 +1550,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   // start out as "no segment" = 0: cfx::plain_vec_offsets)
   const int64_t n_cm = (nc + 15) & ~15LL, n_rm = (V->ndofs + 15) & ~15LL;
   const int64_t n_t2 = space_stencil(V).usable ? ((4 * V->ndofs + 15) & ~15LL) : 0;
-  P.mark_block.alloc(n_cm + 2 * n_rm + n_t2);
-  P.mark_block.zero();
+  P.mark_block.alloc(n_cm + 2 * n_rm + n_t2); // (zeroed below, in one launch with the rule-key tables)
   if (n_t2 > 0)
   {
     P.vec_t2off.p = reinterpret_cast<int32_t*>(P.mark_block.p + n_cm + 2 * n_rm); P.vec_t2off.n = V->ndofs; P.vec_t2off.owned = false;
@@ -1574,8 +1584,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     if (key_total > 0)
     {
       P.rule_key_block.alloc(key_total);
-      dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
+      dev_fill2(P.mark_block.p, 0, (size_t)P.mark_block.n, P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
     }
+    else
+      P.mark_block.zero();
   }
   RuleJobs rjobs{};
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
@@ -1726,6 +1738,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       no_fold = true;
   }
   Count n_plain_all;
+  // counters of the dof -> facets incidence (zeroed by the kernel that writes the row lists)
+  DevArray<int32_t> fcount;
+  const bool facets_by_sort = [&]() { const char* fs = getenv("CFX_FACET_SORT"); return fs && fs[0] == '1'; }()
+                              && nf_cap * 2 * nd < 2147483647LL;
   {
     const int64_t ntiles = (V->ndofs + kByteTile - 1) / kByteTile;
     DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
@@ -1757,9 +1773,10 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     P.special_rows.alloc(tot[0].cap());
     if (want_plain) P.plain_rows.alloc(tot[1].cap());
     if (nf_cap > 0) P.special_pos.alloc(V->ndofs);
+    if (nf_cap > 0 && !facets_by_sort) fcount.alloc(tot[0].cap());
     launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
            special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr,
-           tot[0].devn(), tot[1].devn(), nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr);
+           tot[0].devn(), tot[1].devn(), nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr, fcount.p, fcount.n);
     P.row_tile_counts = std::move(tcounts); // the inactive dofs of a tile are the rest (cfx_active_domain)
   }
   P.special_mark = std::move(special);
@@ -1772,8 +1789,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     // count + scan + fill with integer atomics combined per workgroup in LDS: 5 launches where the radix sort of
     // rounds 2-3 takes 13 (a kernel boundary costs ~10 us on this chip, profiles/r04_launch_gaps.txt).  CFX_FACET_SORT=1
     // keeps the sort (every list then comes out in ascending facet order without the deterministic mode's list sort).
-    const bool by_sort = fs && fs[0] == '1';
-    if (by_sort && npairs < 2147483647LL && ns_cap < 2147483647LL)
+    (void)fs;
+    if (facets_by_sort && ns_cap < 2147483647LL)
     {
       // (lengths still in HBM: the sort covers the capacity of the pair list, pairs behind the last facet carry the
       // sentinel key = the capacity of the special-row list, which no row position reaches)
@@ -1799,8 +1816,7 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       // (lengths may still be in HBM: the counters cover the capacity of the special-row list -- the tail stays zero --,
       // the facet list is sized by its upper bound, one entry per (facet, dof of its two cells) pair; the fill reuses
       // the counters as cursors counting DOWN, so that they need no second zero fill)
-      DevArray<int32_t> fcount(ns_cap);
-      fcount.zero();
+      if (fcount.n != ns_cap || !fcount.p) { fcount.alloc(ns_cap); fcount.zero(); }
       const dim3 run_grid((unsigned)((npairs + kAdjRun - 1) / kAdjRun));
       launch("facet_dof_count", facet_dof_count_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(kBlock) scan_write_kernel(const Tin* __restric
 }
 
 template <typename Tin, typename Tout>
-__global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out, CountJobs after)
+__device__ __forceinline__ void scan_small_body(const Tin* in, int64_t n, Tout* out)
 {
   // single thread block, n <= kTile: used for the top of the recursion
   const int64_t base = (int64_t)threadIdx.x * kScanItems;
@@ -684,11 +684,25 @@ __global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out, CountJobs
     if (base + k < n) out[base + k] = off;
     off += v[k];
   }
-  if (threadIdx.x == 0)
-  {
-    out[n] = total;
-    if (after.n > 0) count_publish(after); // (reads out[n] back: this thread's own store)
-  }
+  if (threadIdx.x == 0) out[n] = total;
+}
+
+template <typename Tin, typename Tout>
+__global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out, CountJobs after)
+{
+  scan_small_body<Tin, Tout>(in, n, out);
+  if (threadIdx.x == 0 && after.n > 0) count_publish(after); // (reads out[n] back: this thread's own store)
+}
+
+// two scans of one length in one launch (the lists of a step come in pairs: inside / cut cells, volume / interface
+// rules -- and a kernel boundary costs ~10 us): the same block scans A, then B; thread 0 wrote both totals
+template <typename Tin, typename Tout>
+__global__ void scan_small_pair_kernel(const Tin* inA, const Tin* inB, int64_t n, Tout* outA, Tout* outB, CountJobs after)
+{
+  scan_small_body<Tin, Tout>(inA, n, outA);
+  __syncthreads();
+  scan_small_body<Tin, Tout>(inB, n, outB);
+  if (threadIdx.x == 0 && after.n > 0) count_publish(after);
 }
 
 // Single-pass scan (chained tiles with wave-wide look-back): one launch, the input is read
@@ -698,17 +712,12 @@ __global__ void scan_small_kernel(const Tin* in, int64_t n, Tout* out, CountJobs
 // XCDs are not coherent with each other for plain loads.
 constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1ull;
 
+// one tile of a chained scan; true for the thread that wrote the grand total out[n]
 template <typename Tin, typename Tout>
-__global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restrict__ in, int64_t n,
-                                                              unsigned long long* __restrict__ state,
-                                                              unsigned int* __restrict__ ticket, Tout* __restrict__ out,
-                                                              CountJobs after)
+__device__ __forceinline__ bool scan_chained_tile(const Tin* __restrict__ in, int64_t n, unsigned long long* __restrict__ state,
+                                                  const unsigned int tile, Tout* __restrict__ out)
 {
-  __shared__ unsigned int s_tile;
   __shared__ unsigned long long s_prefix;
-  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
-  __syncthreads();
-  const unsigned int tile = s_tile;
   // the tile goes through LDS both ways: coalesced global loads and stores (see scan_write_kernel)
   __shared__ Tout s_v[kTile];
   const int64_t tbase = (int64_t)tile * kTile;
@@ -791,9 +800,40 @@ __global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restr
   if ((int64_t)(tile + 1) * kTile >= n && threadIdx.x == kBlock - 1)
   {
     out[n] = (Tout)s_prefix + total;
-    if (after.n > 0) count_publish(after);
+    return true;
   }
+  return false;
 }
+
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(kBlock) scan_chained_kernel(const Tin* __restrict__ in, int64_t n,
+                                                              unsigned long long* __restrict__ state,
+                                                              unsigned int* __restrict__ ticket, Tout* __restrict__ out,
+                                                              CountJobs after)
+{
+  __shared__ unsigned int s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  if (scan_chained_tile<Tin, Tout>(in, n, state, s_tile, out) && after.n > 0) count_publish(after);
+}
+
+// the pair form: a block takes ONE ticket and scans its tile of A, then of B (the predecessors it waits for hold lower
+// tickets in both); the block of the last tile wrote both totals, which the published counts may combine
+template <typename Tin, typename Tout>
+__global__ void __launch_bounds__(kBlock) scan_chained_pair_kernel(const Tin* __restrict__ inA, const Tin* __restrict__ inB,
+                                                                   int64_t n, unsigned long long* __restrict__ stateA,
+                                                                   unsigned long long* __restrict__ stateB,
+                                                                   unsigned int* __restrict__ ticket, Tout* __restrict__ outA,
+                                                                   Tout* __restrict__ outB, CountJobs after)
+{
+  __shared__ unsigned int s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  (void)scan_chained_tile<Tin, Tout>(inA, n, stateA, s_tile, outA);
+  __syncthreads();
+  if (scan_chained_tile<Tin, Tout>(inB, n, stateB, s_tile, outB) && after.n > 0) count_publish(after);
+}
+
 
 template <typename Tin, typename Tout>
 static void scan_impl(const Tin* in, Tout* out, int64_t n, CountPlan* plan = nullptr)
@@ -857,6 +897,53 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n, CountPlan* plan = nul
   else
     scan_impl<Tout, Tout>(sums.p, offs.p, ntiles);
   launch("scan_write", scan_write_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, offs.p, out, after);
+}
+
+// two scans of one length: one launch where one scan would take one (a single tile, or chained tiles); else one after
+// the other.  The counts of `plan` are published when both totals are written.
+template <typename Tin, typename Tout>
+static void scan_pair_impl(const Tin* inA, Tout* outA, const Tin* inB, Tout* outB, int64_t n, CountPlan* plan)
+{
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  static const int64_t chained_max = getenv("CFX_SCAN_CHAINED_TILES") ? atoll(getenv("CFX_SCAN_CHAINED_TILES")) : 8192;
+  static const bool off = getenv("CFX_SCAN_PAIRS") && getenv("CFX_SCAN_PAIRS")[0] == '0';
+  constexpr int64_t kPairWords = 1 << 16;
+  if (off || n == 0 || ntiles > chained_max || 2 * ntiles + 1 > kPairWords / 4)
+  {
+    scan_impl<Tin, Tout>(inA, outA, n, nullptr);
+    scan_impl<Tin, Tout>(inB, outB, n, plan);
+    return;
+  }
+  CountJobs after{};
+  if (plan && plan->publish && !plan->fused) { after = *plan->jobs; plan->fused = true; }
+  if (ntiles == 1)
+  {
+    launch("scan_top", scan_small_pair_kernel<Tin, Tout>, dim3(1), dim3(kBlock), 0, inA, inB, n, outA, outB, after);
+    return;
+  }
+  // tile states of both scans + the ticket: a zeroed slice of a pool of its own (cleared with one fill when it wraps)
+  struct PairPool { unsigned long long* pool = nullptr; int64_t next = kPairWords; };
+  static std::map<hipStream_t, PairPool> pools;
+  PairPool& sp = pools[ctx().stream];
+  if (!sp.pool) sp.pool = static_cast<unsigned long long*>(dev_alloc(sizeof(unsigned long long) * kPairWords));
+  if (sp.next + 2 * ntiles + 1 > kPairWords)
+  {
+    cfx::dev_fill(sp.pool, 0, sizeof(unsigned long long) * kPairWords);
+    sp.next = 0;
+  }
+  unsigned long long* state = sp.pool + sp.next;
+  sp.next += 2 * ntiles + 1;
+  launch("scan_chained", scan_chained_pair_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, inA, inB, n, state,
+         state + ntiles, reinterpret_cast<unsigned int*>(state + 2 * ntiles), outA, outB, after);
+}
+
+void exclusive_scan_pair(const int32_t* inA, int64_t* outA, const int32_t* inB, int64_t* outB, int64_t n, CountPlan* after)
+{
+  scan_pair_impl<int32_t, int64_t>(inA, outA, inB, outB, n, after);
+}
+void exclusive_scan_pair(const int64_t* inA, int64_t* outA, const int64_t* inB, int64_t* outB, int64_t n, CountPlan* after)
+{
+  scan_pair_impl<int64_t, int64_t>(inA, outA, inB, outB, n, after);
 }
 
 void exclusive_scan(const int32_t* in, int64_t* out, int64_t n, CountPlan* after) { scan_impl<int32_t, int64_t>(in, out, n, after); }
@@ -1026,6 +1113,28 @@ __global__ void __launch_bounds__(kBlock) fill16_kernel(unsigned char* __restric
   }
   if (blockIdx.x == 0 && threadIdx.x < (bytes & 15)) p[(size_t)n16 * 16 + threadIdx.x] = (unsigned char)word;
 }
+
+// two fills in one launch (the mark block and the rule-key tables of a row plan: 0x00 and 0xff)
+__global__ void __launch_bounds__(kBlock) fill16_pair_kernel(unsigned char* __restrict__ pa, size_t bytes_a, unsigned word_a,
+                                                             unsigned blocks_a, unsigned char* __restrict__ pb, size_t bytes_b,
+                                                             unsigned word_b)
+{
+  const bool second = blockIdx.x >= blocks_a;
+  unsigned char* p = second ? pb : pa;
+  const size_t bytes = second ? bytes_b : bytes_a;
+  const unsigned word = second ? word_b : word_a;
+  const unsigned blk = second ? blockIdx.x - blocks_a : blockIdx.x;
+  const int64_t n16 = (int64_t)(bytes / 16);
+  const uint4 v = make_uint4(word, word, word, word);
+  const int64_t base = (int64_t)blk * (kBlock * 4) + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+  {
+    const int64_t i = base + (int64_t)k * kBlock;
+    if (i < n16) reinterpret_cast<uint4*>(p)[i] = v;
+  }
+  if (blk == 0 && threadIdx.x < (bytes & 15)) p[(size_t)n16 * 16 + threadIdx.x] = (unsigned char)word;
+}
 } // namespace
 
 namespace cfx
@@ -1064,6 +1173,21 @@ void dev_fill(void* p, int byte, size_t bytes)
   const int64_t n16 = (int64_t)(bytes / 16);
   launch("fill", fill16_kernel, grid_for(std::max<int64_t>(n16, 1), kBlock * 4), dim3(kBlock), 0,
          static_cast<unsigned char*>(p), bytes, word);
+}
+
+void dev_fill2(void* pa, int byte_a, size_t bytes_a, void* pb, int byte_b, size_t bytes_b)
+{
+  if (bytes_a == 0 || bytes_b == 0 || ((reinterpret_cast<uintptr_t>(pa) | reinterpret_cast<uintptr_t>(pb)) & 15) != 0)
+  {
+    dev_fill(pa, byte_a, bytes_a);
+    dev_fill(pb, byte_b, bytes_b);
+    return;
+  }
+  auto word = [](int byte) { const unsigned b = (unsigned)byte & 0xffu; return b | (b << 8) | (b << 16) | (b << 24); };
+  const dim3 ga = grid_for(std::max<int64_t>((int64_t)(bytes_a / 16), 1), kBlock * 4);
+  const dim3 gb = grid_for(std::max<int64_t>((int64_t)(bytes_b / 16), 1), kBlock * 4);
+  launch("fill", fill16_pair_kernel, dim3(ga.x + gb.x), dim3(kBlock), 0, static_cast<unsigned char*>(pa), bytes_a, word(byte_a),
+         ga.x, static_cast<unsigned char*>(pb), bytes_b, word(byte_b));
 }
 } // namespace cfx
 

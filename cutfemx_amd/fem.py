@@ -21,6 +21,18 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import _lib
+
+_C128, _C64 = np.dtype(np.complex128), np.dtype(np.complex64)
+
+
+def _is_complex(dt) -> bool:
+    return dt is not None and np.dtype(dt) in (_C128, _C64)
+
+
+def _cfn(name: str, dt):
+    """the complex entry point of `name` for the scalar type dt: cfx_<name>_c128 or cfx_<name>_c64"""
+    return getattr(_lib.lib(), f"cfx_{name}_{'c64' if np.dtype(dt) == _C64 else 'c128'}")
+
 from .cut import FacetRows, RuntimeQuadratureRules
 from .mesh import FunctionSpace
 
@@ -140,15 +152,15 @@ class CutForm:
         # float64 entry points
         cplx = any(isinstance(i.scale, complex) and i.scale.imag != 0.0 for i in self.integrals) \
             or any(i._complex_coefficient() for i in self.integrals)
-        if dtype is not None and np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32), np.dtype(np.complex128)):
-            raise TypeError("forms are float64 (float32 containers) or complex128")
-        if cplx and dtype is not None and np.dtype(dtype) != np.dtype(np.complex128):
-            raise TypeError("a complex constant or coefficient needs dtype=complex128")
-        self.dtype = np.dtype(np.complex128) if (cplx or (dtype is not None and np.dtype(dtype) == np.dtype(np.complex128))) \
-            else np.dtype(np.float64)
+        if dtype is not None and np.dtype(dtype) not in (np.dtype(np.float64), np.dtype(np.float32), _C128, _C64):
+            raise TypeError("forms are float64 (float32 containers), complex128 or complex64")
+        if cplx and dtype is not None and not _is_complex(dtype):
+            raise TypeError("a complex constant or coefficient needs dtype=complex128 (or complex64)")
+        # (complex64: the containers the form assembles into are interleaved float32; the form itself is the same)
+        self.dtype = np.dtype(dtype) if _is_complex(dtype) else (_C128 if cplx else np.dtype(np.float64))
         self._scaled = any(complex(i.scale) != 1.0 for i in self.integrals)
-        if self._scaled and self.dtype != np.dtype(np.complex128):
-            raise TypeError("Integral.scale belongs to complex128 forms (fold a real constant into `params`)")
+        if self._scaled and not _is_complex(self.dtype):
+            raise TypeError("Integral.scale belongs to complex forms (fold a real constant into `params`)")
         self._h_im = None
 
         def create(part):
@@ -273,8 +285,8 @@ class MatrixCSR:
         self.function_space = V
         # scalar type T of la::MatrixCSR<T> (wrappers/fem.cpp:490-500): float64, or float32 through the *_f32 entry points
         self.dtype = np.dtype(_lib.scalar_dtype(values) if dtype is None else dtype)
-        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64), np.dtype(np.complex128)):
-            raise TypeError("MatrixCSR holds float64, float32 or complex128 values")
+        if self.dtype not in (np.dtype(np.float32), np.dtype(np.float64), _C128, _C64):
+            raise TypeError("MatrixCSR holds float64, float32, complex128 or complex64 values")
         v = _lib.PatternView()
         _lib.check(_lib.lib().cfx_pattern_view_get(self._p, C.byref(v)))
         self._view = v
@@ -344,7 +356,7 @@ class MatrixCSR:
             self._zero_pending = True
             return
         self._zero_pending = False
-        z = np.full(self.nnz, v if self.dtype == np.dtype(np.complex128) else float(v), dtype=self.dtype)
+        z = np.full(self.nnz, v if _is_complex(self.dtype) else float(v), dtype=self.dtype)
         _lib.check(_lib.lib().cfx_copy(C.c_void_p(self._vptr), z.ctypes.data_as(C.c_void_p),
                                        C.c_size_t(z.nbytes)))
 
@@ -406,8 +418,8 @@ def create_matrix(a: CutForm, values=None, dtype=None) -> MatrixCSR:
     scalar type of the matrix: float64 (default) or float32."""
     p = C.c_void_p()
     _lib.check(_lib.lib().cfx_create_sparsity(a._h, C.byref(p)))
-    if dtype is None and values is None and a.dtype == np.dtype(np.complex128):
-        dtype = np.complex128
+    if dtype is None and values is None and _is_complex(a.dtype):
+        dtype = a.dtype
     return MatrixCSR(p, a.function_space, values, dtype)
 
 
@@ -422,15 +434,15 @@ def assemble_matrix(a: CutForm, bcs=None, A: MatrixCSR | None = None) -> MatrixC
         b0, b1 = bcs if isinstance(bcs, tuple) else (bcs, bcs)
         bc0, bc1 = _lib.as_ptr(b0, np.int8, keep), _lib.as_ptr(b1, np.int8, keep)
     l = _lib.lib()
-    if A.dtype == np.dtype(np.complex128):
+    if _is_complex(A.dtype):
         zero = 1 if A._zero_pending else 0
         A._zero_pending = False
         for h, scales in a._parts():
-            _lib.check(l.cfx_assemble_matrix_c128(h, A._p, bc0, bc1, scales, zero, C.c_void_p(A._vptr)))
+            _lib.check(_cfn("assemble_matrix", A.dtype)(h, A._p, bc0, bc1, scales, zero, C.c_void_p(A._vptr)))
             zero = 0
         return A
-    if a.dtype == np.dtype(np.complex128):
-        raise TypeError("a complex128 form assembles into a complex128 matrix (create_matrix(a) makes one)")
+    if _is_complex(a.dtype):
+        raise TypeError("a complex form assembles into a complex matrix (create_matrix(a) makes one)")
     f32 = A.dtype == np.dtype(np.float32)
     if A._zero_pending:     # A.set_value(0) + assemble_matrix(A, a, bcs) as one call
         A._zero_pending = False
@@ -446,13 +458,13 @@ def assemble_vector(L: CutForm, b=None, dtype=np.float64):
     vector, or accumulates into `b` (numpy array or device torch tensor; float64 or float32)."""
     V = L.function_space
     if b is None:
-        b = np.zeros(V.ndofs * V.bs, dtype=np.complex128 if L.dtype == np.dtype(np.complex128) else dtype)
-    if _lib.scalar_dtype(b) == np.complex128:
+        b = np.zeros(V.ndofs * V.bs, dtype=L.dtype if _is_complex(L.dtype) else dtype)
+    if _is_complex(_lib.scalar_dtype(b)):
         for h, scales in L._parts():
-            _lib.check(_lib.lib().cfx_assemble_vector_c128(h, scales, _vec_ptr(b)))
+            _lib.check(_cfn("assemble_vector", _lib.scalar_dtype(b))(h, scales, _vec_ptr(b)))
         return b
-    if L.dtype == np.dtype(np.complex128):
-        raise TypeError("a complex128 form assembles into a complex128 vector")
+    if _is_complex(L.dtype):
+        raise TypeError("a complex form assembles into a complex vector")
     fn = _lib.lib().cfx_assemble_vector_f32 if _lib.scalar_dtype(b) == np.float32 else _lib.lib().cfx_assemble_vector
     _lib.check(fn(L._h, _vec_ptr(b)))
     return b
@@ -468,15 +480,16 @@ def apply_lifting(b, a: CutForm, bc_markers, bc_values, x0=None, alpha: float = 
     `bc_markers` (int8) / `bc_values` / `x0` hold one entry per dof; one bilinear form,
     i.e. one block of the reference's list-of-forms signature."""
     keep: list = []
-    if a.dtype == np.dtype(np.complex128) and _lib.scalar_dtype(b) != np.complex128:
+    if _is_complex(a.dtype) and not _is_complex(_lib.scalar_dtype(b)):
         # (as assemble_matrix / assemble_vector: the real entry points would drop the constants and the imaginary part)
-        raise TypeError("a complex128 form lifts into a complex128 vector")
-    if _lib.scalar_dtype(b) == np.complex128:
-        g = np.ascontiguousarray(bc_values, dtype=np.complex128)
-        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+        raise TypeError("a complex form lifts into a complex vector")
+    if _is_complex(_lib.scalar_dtype(b)):
+        cdt = np.dtype(_lib.scalar_dtype(b))
+        g = np.ascontiguousarray(bc_values, dtype=cdt)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=cdt)
         al = complex(alpha)
         for h, scales in a._parts():
-            _lib.check(_lib.lib().cfx_apply_lifting_c128(
+            _lib.check(_cfn("apply_lifting", cdt)(
                 h, _lib.as_ptr(bc_markers, np.int8, keep), g.ctypes.data_as(C.c_void_p),
                 None if x is None else x.ctypes.data_as(C.c_void_p), C.c_double(al.real), C.c_double(al.imag), scales, _vec_ptr(b)))
         return b
@@ -495,11 +508,12 @@ def set_bc(b, bc_markers, bc_values, x0=None, alpha: float = 1.0):
     """b[dofs] = alpha (g - x0) on the marked dofs (dolfinx.fem.set_bc / DirichletBC.set)."""
     keep: list = []
     n = b.numel() if _lib.is_torch(b) else b.size
-    if _lib.scalar_dtype(b) == np.complex128:
-        g = np.ascontiguousarray(bc_values, dtype=np.complex128)
-        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.complex128)
+    if _is_complex(_lib.scalar_dtype(b)):
+        cdt = np.dtype(_lib.scalar_dtype(b))
+        g = np.ascontiguousarray(bc_values, dtype=cdt)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=cdt)
         al = complex(alpha)
-        _lib.check(_lib.lib().cfx_set_bc_c128(C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), g.ctypes.data_as(C.c_void_p),
+        _lib.check(_cfn("set_bc", cdt)(C.c_int64(n), _lib.as_ptr(bc_markers, np.int8, keep), g.ctypes.data_as(C.c_void_p),
                                              None if x is None else x.ctypes.data_as(C.c_void_p), C.c_double(al.real),
                                              C.c_double(al.imag), _vec_ptr(b)))
         return b
@@ -522,7 +536,7 @@ def assemble_scalar(M: CutForm) -> float:
     if M.rank != 1 or any(i.kernel != SOURCE for i in M.integrals):
         raise ValueError("assemble_scalar takes a linear form made of SOURCE integrals (f dx)")
     b = assemble_vector(M)
-    return complex(b.sum()) if M.dtype == np.dtype(np.complex128) else float(b.sum())
+    return complex(b.sum()) if _is_complex(M.dtype) else float(b.sum())
 
 
 def zero_rows(A: MatrixCSR, *, tol: float = 0.0) -> np.ndarray:
@@ -669,9 +683,9 @@ def deactivate_outside(A: MatrixCSR | None, b, domain: ActiveDomain, diagonal: f
         dts.add(np.dtype(_lib.scalar_dtype(b)))
     if len(dts) > 1:
         raise TypeError("deactivate_outside: matrix and vector must have one scalar type")
-    if dts == {np.dtype(np.complex128)}:
+    if dts in ({_C128}, {_C64}):
         d, r = complex(diagonal), complex(rhs_value)
-        _lib.check(_lib.lib().cfx_deactivate_outside_c128(domain._h, A._p if A is not None else None,
+        _lib.check(_cfn("deactivate_outside", next(iter(dts)))(domain._h, A._p if A is not None else None,
                                                           C.c_void_p(A.values_ptr) if A is not None else None, bp,
                                                           C.c_double(d.real), C.c_double(d.imag), C.c_double(r.real), C.c_double(r.imag)))
         return domain

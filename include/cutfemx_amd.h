@@ -21,7 +21,8 @@
  *     cfx_comm_t (cfx_dist_*, at the end of this header).
  * Scalar/geometry type: float64/float64 (north_star).  Of the other instantiations of
  * python/cutfemx/wrappers/fem.cpp:490-500 the boundary carries float32 containers (`*_f32`: widened on the way in,
- * fp64 arithmetic, rounded once on the way out) and complex128 (`*_c128`); complex64 is not provided.
+ * fp64 arithmetic, rounded once on the way out), complex128 (`*_c128`) and complex64 (`*_c64`: interleaved float32
+ * containers, the complex128 arithmetic, rounded once).
  */
 #ifndef CUTFEMX_AMD_H
 #define CUTFEMX_AMD_H
@@ -542,6 +543,20 @@ int cfx_set_bc_c128(int64_t n, const int8_t* bc_markers, const double* bc_values
                     double alpha_im, double* b);
 int cfx_deactivate_outside_c128(cfx_active_t domain, cfx_pattern_t pattern, double* values, double* b, double diag_re,
                                 double diag_im, double rhs_re, double rhs_im);
+/* ---- complex64: the <std::complex<float>, float> rows of the same table.  Values, vectors and Dirichlet data are
+ *      interleaved (re, im) float32 (geometry and level sets then usually come through the *_f32 constructors); the
+ *      constants stay double; every entry is formed in fp64 as above and rounded to float32 once (accumulating calls:
+ *      widen, add, round). ------------------------------------------------------------------------------------------ */
+int cfx_assemble_matrix_c64(cfx_form_t a, cfx_pattern_t pattern, const int8_t* bc0, const int8_t* bc1, const double* scales,
+                            int zero_first, float* values /* [2 nnz] */);
+int cfx_assemble_vector_c64(cfx_form_t L, const double* scales, float* b /* [2 n] */);
+int cfx_apply_lifting_c64(cfx_form_t a, const int8_t* bc_markers, const float* bc_values /* [2 n1] */,
+                          const float* x0 /* [2 n1] or NULL */, double alpha_re, double alpha_im, const double* scales,
+                          float* b /* [2 n] */);
+int cfx_set_bc_c64(int64_t n, const int8_t* bc_markers, const float* bc_values, const float* x0, double alpha_re,
+                   double alpha_im, float* b);
+int cfx_deactivate_outside_c64(cfx_active_t domain, cfx_pattern_t pattern, float* values, float* b, double diag_re,
+                               double diag_im, double rhs_re, double rhs_im);
 
 
 /* ---- multi-GPU exchange steps (one rank per GPU; RCCL send/recv over xGMI between the ranks that share dofs) ----

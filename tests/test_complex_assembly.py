@@ -151,3 +151,70 @@ def test_gpu_complex_form_of_real_constants(oracle):
         assert np.array_equal(Ac.data.real, Ar.data) and not Ac.data.imag.any()
     with pytest.raises(TypeError):
         fem.form([fem.Integral(fem.MASS, cells=cells, qdegree=2, scale=2j)], V, dtype=np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n", [(2, 10), (3, 6)])
+def test_gpu_complex64_containers(oracle, tdim, n):
+    """complex64 (the <std::complex<float>, float> rows of wrappers/fem.cpp:490-500): interleaved float32 containers, the
+    complex128 arithmetic rounded once -- every entry within a few float32 ulps of the complex128 result; accumulate,
+    markers, lifting, set_bc and deactivation keep their meaning."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(V, phi))
+    inside = cfx.locate_entities(cd, "phi<0")
+    vol, itf = cfx.runtime_quadrature(cd, "phi<0", 4), cfx.runtime_quadrature(cd, "phi=0", 4)
+    nrm, ghost = cfx.normal(cd, itf), cfx.ghost_penalty_facets(cd, "phi<0")
+    s = [KAPPA, 0.5 - 1.5j, 1.0]
+
+    def forms(dtype):
+        a = fem.form([fem.Integral(fem.STIFFNESS, cells=inside, rules=vol, qdegree=0, scale=s[0]),
+                      fem.Integral(fem.NITSCHE, rules=itf, point_data=nrm, params=(40.0,), scale=s[1]),
+                      fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=0, scale=s[2])], V, dtype=dtype)
+        L = fem.form([fem.Integral(fem.SOURCE, cells=inside, rules=vol, params=(fem.F_SINPROD, 1.0), qdegree=4, scale=KAPPA),
+                      fem.Integral(fem.NITSCHE_RHS, rules=itf, point_data=nrm, params=(40.0, fem.F_SINPROD, 1.0), scale=1j)],
+                     V, dtype=dtype)
+        return a, L
+    a64, L64 = forms(np.complex64)
+    a128, L128 = forms(np.complex128)
+    assert a64.dtype == np.dtype(np.complex64)
+
+    def close(x, y, ulps=4):          # componentwise: float32 rounding of the complex128 value (+ accumulation slack)
+        y = np.asarray(y)
+        tol = ulps * np.finfo(np.float32).eps * np.maximum(np.abs(y), np.abs(y).max() * 1e-3)
+        return bool(np.all(np.abs(x.real - y.real) <= tol) and np.all(np.abs(x.imag - y.imag) <= tol))
+    A64, A128 = fem.assemble_matrix(a64), fem.assemble_matrix(a128)
+    assert A64.dtype == np.dtype(np.complex64) and A64.data.dtype == np.complex64
+    assert np.array_equal(A64.indptr, A128.indptr) and np.array_equal(A64.indices, A128.indices)
+    assert close(A64.data, A128.data, 2)
+    fem.assemble_matrix(a64, A=A64)                               # accumulates: widen, add, round
+    assert close(A64.data, 2.0 * A128.data, 4)
+    rng = np.random.default_rng(5)
+    bc = (rng.random(om.nnodes) < 0.1).astype(np.int8)
+    assert close(fem.assemble_matrix(a64, bcs=bc).data, fem.assemble_matrix(a128, bcs=bc).data, 2)
+    b64, b128 = fem.assemble_vector(L64), fem.assemble_vector(L128)
+    assert b64.dtype == np.complex64 and close(b64, b128, 2)
+    with pytest.raises(TypeError):
+        fem.assemble_vector(L64, np.zeros(om.nnodes, dtype=np.float32))
+    # lifting and set_bc with complex64 data
+    g = (rng.standard_normal(om.nnodes) + 1j * rng.standard_normal(om.nnodes)).astype(np.complex64)
+    x0 = (rng.standard_normal(om.nnodes) + 1j * rng.standard_normal(om.nnodes)).astype(np.complex64)
+    b0 = (rng.standard_normal(om.nnodes) + 1j * rng.standard_normal(om.nnodes)).astype(np.complex64)
+    alpha = 0.6 - 0.2j
+    got = fem.apply_lifting(b0.copy(), a64, bc, g, x0=x0, alpha=alpha)
+    ref = fem.apply_lifting(b0.astype(np.complex128), a128, bc, g.astype(np.complex128), x0=x0.astype(np.complex128), alpha=alpha)
+    assert got.dtype == np.complex64 and close(got, ref, 4)
+    got = fem.set_bc(b0.copy(), bc, g, x0=x0, alpha=alpha)
+    want = np.where(bc == 1, alpha * (g.astype(np.complex128) - x0.astype(np.complex128)), b0.astype(np.complex128))
+    assert close(got, want, 2) and np.array_equal(got[bc == 0], b0[bc == 0])
+    # deactivation with a complex diagonal
+    A1, b1 = fem.assemble_matrix(a64), fem.assemble_vector(L64)
+    fem.deactivate_outside(A1, b1, fem.active_domain(a64), diagonal=1.0 + 0.5j, rhs_value=0.25j)
+    A2, b2 = fem.assemble_matrix(a128), fem.assemble_vector(L128)
+    fem.deactivate_outside(A2, b2, fem.active_domain(a128), diagonal=1.0 + 0.5j, rhs_value=0.25j)
+    assert close(A1.data, A2.data, 2) and close(b1, b2, 2)

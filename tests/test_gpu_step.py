@@ -113,7 +113,9 @@ def test_a_count_that_does_not_fit_voids_the_step_and_the_repeat_is_exact(oracle
             system, A, b, dom = cfx.run_step(lambda: one_step(V, state["cd"], f, state), key=key, info=info)
             passes.append(info["passes"])
             check_against_oracle(oracle, om, phi, state["cd"], system, A, b, dom)
-        assert passes[0] == 1 and passes[1] == 2, passes    # the step after a recorded one speculates, overflows, repeats
+        import os
+        if os.environ.get("CFX_STEP_SPECULATE") != "0":     # (switched off: every step is a plain sequence, one pass)
+            assert passes[0] == 1 and passes[1] == 2, passes    # the step after a recorded one speculates, overflows, repeats
         assert all(p <= 2 for p in passes), passes          # ... and one sized repeat always fits
     finally:
         cfx.set_step_margin()

@@ -997,4 +997,145 @@ __device__ __forceinline__ void facet_local_row(int kernel, const double* __rest
   }
 }
 
+// ---------------------------------------------------------------------------
+// Row ia in [0, 2 nd0) of an interior-facet integral between two SCALAR spaces (test: R.deg0 / nd0, trial: R.deg1 /
+// nd1): macro test dofs = [cell0, cell1] of the test dofmap, macro trial dofs = [cell0, cell1] of the trial dofmap
+// (assemble_matrix_impl.h:462-606 builds dmapjoint0 / dmapjoint1 from dofmap0 and dofmap1 separately), acc[j], j in
+// [0, 2 nd1).  gamma h_avg^(1 + p) [dn v][dn u] (CFX_K_GHOST_GRADJUMP) and gamma / h_avg [v][u] (CFX_K_JUMP) over the
+// standard facet rule.  Run-time degrees, fixed strides: one body for every pair of Lagrange spaces.
+// ---------------------------------------------------------------------------
+template <int TDIM>
+__device__ __forceinline__ void facet_local_row2(const RectArgs& R, int kernel, const double* __restrict__ params, int qdegree,
+                                                 const Geo<TDIM>& g0, const Geo<TDIM>& g1, int lf0, int ia,
+                                                 double (&acc)[2 * RectRow<TDIM>::MAXND])
+{
+  constexpr int MAXND = RectRow<TDIM>::MAXND;
+  const double havg = 0.5 * (cell_diameter<TDIM>(g0) + cell_diameter<TDIM>(g1));
+  double nrm[TDIM];
+  {
+    double nn = 0.0;
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double v = 0.0;
+#pragma unroll
+      for (int t = 0; t < TDIM; ++t)
+      {
+        const double dl = (lf0 == 0) ? -1.0 : ((lf0 - 1 == t) ? 1.0 : 0.0);
+        v -= g0.K[t][d] * dl;
+      }
+      nrm[d] = v;
+      nn += v * v;
+    }
+    nn = sqrt(nn);
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d) nrm[d] /= nn;
+  }
+  double xf[TDIM][TDIM];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i <= TDIM; ++i)
+    {
+      if (i == lf0) continue;
+#pragma unroll
+      for (int j = 0; j < TDIM; ++j)
+        if (j == k)
+        {
+#pragma unroll
+          for (int d = 0; d < TDIM; ++d) xf[j][d] = g0.x[i][d];
+        }
+      ++k;
+    }
+  }
+  double scale;
+  if constexpr (TDIM == 2)
+  {
+    const double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
+    scale = sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
+    const double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    scale = sqrt(cx * cx + cy * cy + cz * cz);
+  }
+  const bool grad = kernel == CFX_K_GHOST_GRADJUMP;
+  int nref;
+  const double* wref;
+  const double* pref = ref_rule(TDIM - 1, qdegree, nref, wref);
+  for (int q = 0; q < nref; ++q)
+  {
+    double l0 = 1.0, xq[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM - 1; ++t) l0 -= pref[q * (TDIM - 1) + t];
+#pragma unroll
+    for (int d = 0; d < TDIM; ++d)
+    {
+      double v = l0 * xf[0][d];
+#pragma unroll
+      for (int t = 0; t < TDIM - 1; ++t) v += pref[q * (TDIM - 1) + t] * xf[t + 1][d];
+      xq[d] = v;
+    }
+    double X0[TDIM], X1[TDIM];
+#pragma unroll
+    for (int t = 0; t < TDIM; ++t)
+    {
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int d = 0; d < TDIM; ++d)
+      {
+        a += g0.K[t][d] * (xq[d] - g0.x[0][d]);
+        b += g1.K[t][d] * (xq[d] - g1.x[0][d]);
+      }
+      X0[t] = a; X1[t] = b;
+    }
+    // the jump of macro basis function m of a space of degree `deg`: [N0, -N1] or the normal derivatives
+    double N[MAXND], dN[MAXND][TDIM];
+    auto side_jumps = [&](int deg, const double* X, const Geo<TDIM>& g, double sign, double* out)
+    {
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+      {
+        N[j] = 0.0;
+#pragma unroll
+        for (int t = 0; t < TDIM; ++t) dN[j][t] = 0.0;
+      }
+      if (deg == 1) tabulate<TDIM, 1>(X, N, dN); else tabulate<TDIM, 2>(X, N, dN);
+#pragma unroll
+      for (int j = 0; j < MAXND; ++j)
+      {
+        double a = 0.0;
+#pragma unroll
+        for (int d = 0; d < TDIM; ++d)
+#pragma unroll
+          for (int t = 0; t < TDIM; ++t) a += g.K[t][d] * dN[j][t] * nrm[d];
+        out[j] = sign * (grad ? a : N[j]);
+      }
+    };
+    double jt0[MAXND], jt1[MAXND], ju0[MAXND], ju1[MAXND];
+    side_jumps(R.deg0, X0, g0, 1.0, jt0);
+    side_jumps(R.deg0, X1, g1, -1.0, jt1);
+    side_jumps(R.deg1, X0, g0, 1.0, ju0);
+    side_jumps(R.deg1, X1, g1, -1.0, ju1);
+    double ji = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+    {
+      ji = (j == ia && j < R.nd0) ? jt0[j] : ji; // (ia in [nd0, 2 nd0) is cell 1's row ia - nd0, not cell 0's row ia)
+      ji = (R.nd0 + j == ia && j < R.nd0) ? jt1[j] : ji;
+    }
+    const double w = grad ? wref[q] * scale * params[0] * havg * (params[1] != 0.0 ? pow(havg, params[1]) : 1.0)
+                          : wref[q] * scale * params[0] / havg;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+    {
+      acc[j] += (j < R.nd1) ? w * ji * ju0[j] : 0.0;
+      acc[MAXND + j] += (j < R.nd1) ? w * ji * ju1[j] : 0.0;
+    }
+  }
+}
+
 } // namespace cfx

@@ -993,6 +993,87 @@ __global__ void __launch_bounds__(kBlock) assemble_cells2_kernel(AsmArgs A, Rect
   }
 }
 
+// Interior-facet integrals of a rectangular form (two scalar spaces): one thread per (facet, macro test row).  The
+// macro row -- [cell0, cell1] columns of the TRIAL dofmap -- is scattered with one search per trial dof and FP64 atomics,
+// contracted with the Dirichlet data (lifting) or dumped (tabulate_entity).  Facet terms between different spaces are
+// rare (no demo or test of the reference has one off the block diagonal): they keep the entity-parallel path.
+template <int TDIM>
+__global__ void __launch_bounds__(kBlock) assemble_facets2_kernel(AsmArgs A, RectArgs R)
+{
+  constexpr int MAXND = RectRow<TDIM>::MAXND;
+  const int nm0 = 2 * R.nd0;
+  const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t e = tid / nm0;
+  if (e >= dev_n(A.n)) return;
+  const int ia = (int)(tid - e * nm0);
+  const int64_t c0 = A.entities[4 * e], c1 = A.entities[4 * e + 2];
+  const int lf0 = A.entities[4 * e + 1];
+  const int side = ia >= R.nd0 ? 1 : 0;
+  const int32_t* d1[2] = {R.dofmap1 + c0 * R.nd1, R.dofmap1 + c1 * R.nd1};
+  if (A.lift_markers)
+  {
+    bool any = false;
+    for (int sd = 0; sd < 2; ++sd)
+      for (int j = 0; j < R.nd1; ++j) any = any || A.lift_markers[d1[sd][j]] != 0;
+    if (!any) return;
+  }
+  Geo<TDIM> g0, g1;
+  load_cell<TDIM>(A.x, A.conn, c0, g0);
+  load_cell<TDIM>(A.x, A.conn, c1, g1);
+  jacobian<TDIM>(g0);
+  jacobian<TDIM>(g1);
+  double acc[2 * MAXND];
+#pragma unroll
+  for (int j = 0; j < 2 * MAXND; ++j) acc[j] = 0.0;
+  facet_local_row2<TDIM>(R, A.kernel, A.params, A.qdegree, g0, g1, lf0, ia, acc);
+  if (A.dump)
+  {
+    double* out = A.dump + (e * nm0 + ia) * (int64_t)(2 * R.nd1);
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+      if (j < R.nd1) { out[j] = acc[j]; out[R.nd1 + j] = acc[MAXND + j]; }
+    return;
+  }
+  const int32_t row = A.dofmap[(side ? c1 : c0) * R.nd0 + (ia - side * R.nd0)];
+  if (A.lift_markers)
+  {
+    double sum = 0.0;
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < MAXND; ++j)
+      if (j < R.nd1)
+      {
+        for (int sd = 0; sd < 2; ++sd)
+        {
+          const int32_t col = d1[sd][j];
+          if (A.lift_markers[col])
+          {
+            sum += acc[sd * MAXND + j] * A.lift_alpha * (A.lift_values[col] - (A.lift_x0 ? A.lift_x0[col] : 0.0));
+            any = true;
+          }
+        }
+      }
+    if (any) atomicAdd(A.values + row, -sum);
+    return;
+  }
+  const bool row_bc = A.bc0 && A.bc0[row];
+  const int64_t rb = A.indptr[row], re = A.indptr[row + 1];
+#pragma unroll
+  for (int j = 0; j < MAXND; ++j)
+  {
+    if (j >= R.nd1) continue;
+    for (int sd = 0; sd < 2; ++sd)
+    {
+      const int32_t col = d1[sd][j];
+      const int64_t pos = csr_find(A.indices, rb, re, col);
+      if (pos < 0) { *A.error = 1; continue; }
+      double v = acc[sd * MAXND + j];
+      if (row_bc || (A.bc1 && A.bc1[col])) v = 0.0;
+      atomicAdd(A.values + pos, v);
+    }
+  }
+}
+
 // every integral of a rectangular form, or one entity of one of them (only_index >= 0)
 void launch_rectangular(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index = -1, int use_rule = 0)
 {
@@ -1004,6 +1085,17 @@ void launch_rectangular(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs 
   const bool single = only_index >= 0;
   const int nloc0 = R.nd0 * R.bs0;
   const int tdim = V0->mesh->tdim;
+  if (I.type == CFX_INTERIOR_FACET)
+  {
+    A.n = single ? 1 : I.n_entities.value();
+    A.entities = I.entities.p + (single ? 4 * only_index : 0);
+    if (A.n.cap > 0)
+    {
+      if (tdim == 2) launch("assemble_facets2", assemble_facets2_kernel<2>, grid_for(A.n.cap * 2 * R.nd0), dim3(kBlock), 0, A, R);
+      else launch("assemble_facets2", assemble_facets2_kernel<3>, grid_for(A.n.cap * 2 * R.nd0), dim3(kBlock), 0, A, R);
+    }
+    return;
+  }
   if (!single || !use_rule)
   {
     A.n = single ? 1 : I.n_entities.value();
@@ -1714,11 +1806,17 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
     if (rect)
     {
       // test space != trial space: cell integrals of the kernels assemble_cells2_kernel knows, shapes that match
-      require(in.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "cfx_form_create2: cell integrals only");
       require(in.coefficient == nullptr && in.point_data == nullptr, CFX_ERR_INVALID_ARGUMENT,
               "cfx_form_create2: coefficients / per-point data are not supported on rectangular blocks");
       const int gd = V->mesh->gdim;
-      if (in.kernel == CFX_K_DIV_TEST)
+      if (in.type == CFX_INTERIOR_FACET)
+        // interior-facet terms between two spaces (assemble_matrix_impl.h:462-606 with dofmap0 != dofmap1): the
+        // gradient-jump and value-jump kernels over standard facets, scalar spaces of degree 1 or 2
+        require((in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_JUMP) && V->bs == 1 && V1->bs == 1 && in.rules == nullptr,
+                CFX_ERR_INVALID_ARGUMENT,
+                "cfx_form_create2: cell integrals, and interior-facet integrals (gradient jump, value jump) between "
+                "scalar spaces over standard facets");
+      else if (in.kernel == CFX_K_DIV_TEST)
         require(V->bs == gd && V1->bs == 1, CFX_ERR_INVALID_ARGUMENT, "div(v) p: vector test space, scalar trial space");
       else if (in.kernel == CFX_K_DIV_TRIAL)
         require(V->bs == 1 && V1->bs == gd, CFX_ERR_INVALID_ARGUMENT, "q div(u): scalar test space, vector trial space");
@@ -2018,7 +2116,7 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
   const int64_t limit = (I.type == CFX_CELL && use_rule) ? (I.rules ? I.rules->nr.value() : 0) : I.n_entities.value();
   require(index >= 0 && index < limit, CFX_ERR_OUT_OF_RANGE, "entity index out of range");
   const int nloc = V->ndofs_cell * V->bs * (I.type == CFX_INTERIOR_FACET ? 2 : 1);
-  const int nloc1 = a->rectangular() ? a->V1->ndofs_cell * a->V1->bs : nloc;
+  const int nloc1 = a->rectangular() ? a->V1->ndofs_cell * a->V1->bs * (I.type == CFX_INTERIOR_FACET ? 2 : 1) : nloc;
   const int64_t n = a->rank == 2 ? (int64_t)nloc * nloc1 : nloc;
   OutArray<double> out(Ae, n, false);
   ZeroFlag err;

@@ -2547,9 +2547,11 @@ void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
   const int64_t nc = V0->mesh->ncells;
   DevArray<uint8_t> mark((nc + 3) & ~3LL);
   mark.zero();
+  bool facets = false;
   for (const auto& I : a->integrals)
   {
-    require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "forms with different test and trial spaces take cell integrals");
+    if (I.type == CFX_INTERIOR_FACET) { facets = true; continue; }
+    require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "forms with different test and trial spaces take cell and interior-facet integrals");
     const int64_t ne = I.n_entities.value(), nrl = I.rules ? I.rules->nr.value() : 0; // (rectangular blocks: exact lengths)
     if (ne > 0)
       launch("pattern2_mark", mark_cells_u8_kernel, grid_for(ne), dim3(kBlock), 0, ne, I.entities.p, mark.p);
@@ -2564,6 +2566,18 @@ void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)
   S.n_active = V0->ndofs; S.active_rows = nullptr;
   S.nd = V1->ndofs_cell; S.bs = V0->bs; S.bs_col = V1->bs; S.no_self = 1; S.dofmap = V1->dofmap.p;
   S.d2c_off = adj.offsets.p; S.d2c = adj.cells.p; S.cellmark = mark.p;
+  if (facets)
+  {
+    // interior-facet terms: a row of either cell couples the TRIAL dofs of both cells (assembler.h:442-529 with two
+    // dofmaps).  The facet rows and the dof -> facets incidence are the TEST space's: its row plan has them.
+    cfx_row_plan& plan = row_plan(a);
+    if (plan.nfacets.value() > 0)
+    {
+      (void)plan.n_special_rows.value();
+      S.d2f_off = plan.d2f_offsets.p; S.d2f = plan.d2f.p; S.facet_rows = plan.facet_rows.p;
+      S.special_mark = plan.special_mark.p; S.special_pos = plan.special_pos.p;
+    }
+  }
   DevArray<int32_t> counts(P->nrows), len(V0->ndofs);
   ZeroFlag overflow, maxlen;
   S.len = len.p; S.counts = counts.p; S.overflow = overflow.p; S.maxlen = maxlen.p;

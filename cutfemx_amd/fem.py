@@ -617,7 +617,7 @@ def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np
     facet_type = I.facets is not None or (I.rules is not None and I.rules.host_width == 4)
     nloc = V.ndofs_cell * V.bs * (2 if facet_type else 1)
     V1 = getattr(a, "trial_space", V)
-    nloc1 = nloc if V1 is V else V1.ndofs_cell * V1.bs      # [(nd0 bs0) x (nd1 bs1)] row-major for rectangular forms
+    nloc1 = nloc if V1 is V else V1.ndofs_cell * V1.bs * (2 if facet_type else 1)   # [(nd0 bs0) x (nd1 bs1)] row-major for rectangular forms (facets: both cells)
     Ae = np.zeros((nloc, nloc1) if a.rank == 2 else (nloc,))
     _lib.check(_lib.lib().cfx_tabulate_entity(a._h, integral, C.c_int64(index), int(use_rule),
                                               Ae.ctypes.data_as(C.c_void_p)))

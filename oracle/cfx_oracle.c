@@ -1951,9 +1951,111 @@ static void cell_kernel2(const orc_mesh* m, const orc_space* V0, const orc_space
   }
 }
 
+/* interior-facet integral between two (scalar) spaces: macro test dofs = [cell0, cell1] of V0, macro trial dofs =
+   [cell0, cell1] of V1 (assemble_matrix_impl.h:462-606: dmapjoint0 / dmapjoint1 are built from dofmap0 and dofmap1
+   separately); Ae is (2 nd0) x (2 nd1).  gamma h_avg^(1 + p) [dn u][dn v] and gamma / h_avg [u][v], standard facet rule. */
+static int facet_kernel2(const orc_mesh* m, const orc_space* V0, const orc_space* V1, const orc_integral* I,
+                         const int32_t* row, double* Ae)
+{
+  const int tdim = m->tdim, gdim = m->gdim, nv = tdim + 1;
+  const int nd0 = V0->ndofs_cell, nd1 = V1->ndofs_cell, n1 = 2 * nd1;
+  if (V0->bs != 1 || V1->bs != 1) return -2;
+  if (I->kernel != ORC_K_GHOST_GRADJUMP && I->kernel != ORC_K_JUMP) return -2;
+  const int64_t c0 = row[0], c1 = row[2];
+  const int lf0 = row[1];
+  double x0[MAXV][3], x1[MAXV][3], J0[3][3], K0[3][3], J1[3][3], K1[3][3];
+  cell_coords(m, c0, x0); cell_coords(m, c1, x1);
+  jacobian(tdim, x0, J0, K0); jacobian(tdim, x1, J1, K1);
+  const double havg = 0.5 * (cell_diameter(tdim, x0) + cell_diameter(tdim, x1));
+  double n[3] = {0, 0, 0};
+  {
+    double dl[3];
+    for (int t = 0; t < tdim; ++t) dl[t] = (lf0 == 0) ? -1.0 : ((lf0 - 1 == t) ? 1.0 : 0.0);
+    double nn = 0.0;
+    for (int d = 0; d < gdim; ++d)
+    {
+      for (int t = 0; t < tdim; ++t) n[d] -= K0[t][d] * dl[t];
+      nn += n[d] * n[d];
+    }
+    nn = sqrt(nn);
+    for (int d = 0; d < gdim; ++d) n[d] /= nn;
+  }
+  double xf[3][3]; int k = 0;
+  for (int i = 0; i < nv; ++i)
+    if (i != lf0) { for (int d = 0; d < 3; ++d) xf[k][d] = x0[i][d]; ++k; }
+  double scale;
+  if (tdim == 2)
+  {
+    double dx = xf[1][0] - xf[0][0], dy = xf[1][1] - xf[0][1];
+    scale = sqrt(dx * dx + dy * dy);
+  }
+  else
+  {
+    double a[3], b[3];
+    for (int d = 0; d < 3; ++d) { a[d] = xf[1][d] - xf[0][d]; b[d] = xf[2][d] - xf[0][d]; }
+    double cx = a[1] * b[2] - a[2] * b[1], cy = a[2] * b[0] - a[0] * b[2], cz = a[0] * b[1] - a[1] * b[0];
+    scale = sqrt(cx * cx + cy * cy + cz * cz);
+  }
+  int nref; const double *pref, *wref;
+  ref_rule(tdim - 1, I->qdegree, &nref, &pref, &wref);
+  for (int q = 0; q < nref; ++q)
+  {
+    const double* xi = pref + (tdim - 1) * q;
+    double l0 = 1.0, xq[3] = {0, 0, 0};
+    for (int t = 0; t < tdim - 1; ++t) l0 -= xi[t];
+    for (int d = 0; d < gdim; ++d)
+    {
+      xq[d] = l0 * xf[0][d];
+      for (int t = 0; t < tdim - 1; ++t) xq[d] += xi[t] * xf[t + 1][d];
+    }
+    double X0[3], X1[3];
+    for (int t = 0; t < tdim; ++t)
+    {
+      X0[t] = 0.0; X1[t] = 0.0;
+      for (int d = 0; d < gdim; ++d)
+      {
+        X0[t] += K0[t][d] * (xq[d] - x0[0][d]);
+        X1[t] += K1[t][d] * (xq[d] - x1[0][d]);
+      }
+    }
+    double jt[2 * MAXND], ju[2 * MAXND]; /* the jump of every macro test / trial basis function */
+    for (int side = 0; side < 2; ++side)
+    {
+      const orc_space* V = side == 0 ? V0 : V1;
+      const int nd = V->ndofs_cell;
+      double* jj = side == 0 ? jt : ju;
+      double N0[MAXND], dN0[MAXND][3], N1[MAXND], dN1[MAXND][3];
+      tabulate(tdim, V->degree, X0, N0, dN0);
+      tabulate(tdim, V->degree, X1, N1, dN1);
+      for (int i = 0; i < nd; ++i)
+      {
+        if (I->kernel == ORC_K_GHOST_GRADJUMP)
+        {
+          double a = 0.0, b = 0.0;
+          for (int d = 0; d < gdim; ++d)
+            for (int t = 0; t < tdim; ++t)
+            {
+              a += K0[t][d] * dN0[i][t] * n[d];
+              b += K1[t][d] * dN1[i][t] * n[d];
+            }
+          jj[i] = a; jj[nd + i] = -b;
+        }
+        else { jj[i] = N0[i]; jj[nd + i] = -N1[i]; }
+      }
+    }
+    const double w = I->kernel == ORC_K_GHOST_GRADJUMP
+                         ? wref[q] * scale * I->params[0] * havg * (I->params[1] != 0.0 ? pow(havg, I->params[1]) : 1.0)
+                         : wref[q] * scale * I->params[0] / havg;
+    for (int i = 0; i < 2 * nd0; ++i)
+      for (int j = 0; j < 2 * nd1; ++j) Ae[i * n1 + j] += w * jt[i] * ju[j];
+  }
+  return 0;
+}
+
 int orc_tabulate_entity2(const orc_mesh* mesh, const orc_space* V0, const orc_space* V1, const orc_integral* I,
                          int64_t idx, int use_rule, double* Ae)
 {
+  if (I->type == ORC_INTERIOR_FACET) return facet_kernel2(mesh, V0, V1, I, I->entities + 4 * idx, Ae);
   if (I->type != ORC_CELL) return -1;
   if (use_rule)
   {
@@ -2001,6 +2103,29 @@ int orc_create_sparsity2(const orc_mesh* mesh, const orc_space* V0, const orc_sp
     for (int ii = 0; ii < n_integrals; ++ii)
     {
       const orc_integral* I = &integrals[ii];
+      if (I->type == ORC_INTERIOR_FACET)
+      {
+        /* macro rows (both cells, V0) x macro columns (both cells, V1): assembler.h:442-529 with two dofmaps */
+        if (V0->bs != 1 || V1->bs != 1) { free(cnt); return -1; }
+        for (int64_t e = 0; e < I->n_entities; ++e)
+        {
+          int32_t rr[2 * MAXLOC], cc[2 * MAXLOC];
+          int n0 = 0, n1 = 0;
+          for (int sd = 0; sd < 2; ++sd)
+          {
+            const int64_t cell = I->entities[4 * e + 2 * sd];
+            n0 += cell_dofs(V0, cell, rr + n0);
+            n1 += cell_dofs(V1, cell, cc + n1);
+          }
+          for (int i = 0; i < n0; ++i)
+          {
+            if (pass == 0) cnt[rr[i]] += n1;
+            else
+              for (int j = 0; j < n1; ++j) cols[fill[rr[i]]++] = cc[j];
+          }
+        }
+        continue;
+      }
       if (I->type != ORC_CELL) { free(cnt); return -1; }
       for (int part = 0; part < 2; ++part)
       {
@@ -2049,6 +2174,38 @@ int orc_assemble_matrix2(const orc_mesh* mesh, const orc_space* V0, const orc_sp
   for (int ii = 0; ii < n_integrals; ++ii)
   {
     const orc_integral* I = &integrals[ii];
+    if (I->type == ORC_INTERIOR_FACET)
+    {
+      for (int64_t e = 0; e < I->n_entities; ++e)
+      {
+        int32_t rr[2 * MAXLOC], cc[2 * MAXLOC];
+        double Af[4 * MAXND * MAXND];
+        int n0 = 0, n1 = 0;
+        for (int sd = 0; sd < 2; ++sd)
+        {
+          const int64_t cell = I->entities[4 * e + 2 * sd];
+          n0 += cell_dofs(V0, cell, rr + n0);
+          n1 += cell_dofs(V1, cell, cc + n1);
+        }
+        memset(Af, 0, sizeof(double) * (size_t)(n0 * n1));
+        if (orc_tabulate_entity2(mesh, V0, V1, I, e, 0, Af) != 0) return -2;
+        for (int i = 0; i < n0; ++i)
+          for (int j = 0; j < n1; ++j)
+          {
+            if ((bc0 && bc0[rr[i]]) || (bc1 && bc1[cc[j]])) continue;
+            const int64_t b = indptr[rr[i]], en = indptr[rr[i] + 1];
+            int64_t lo = b, hi = en;
+            while (lo < hi)
+            {
+              const int64_t mid = (lo + hi) / 2;
+              if (indices[mid] < cc[j]) lo = mid + 1; else hi = mid;
+            }
+            if (lo == en || indices[lo] != cc[j]) return -1;
+            values[lo] += Af[i * n1 + j];
+          }
+      }
+      continue;
+    }
     for (int part = 0; part < 2; ++part)
     {
       const int64_t ne = part == 0 ? I->n_entities : (I->rules ? I->rules->nr : 0);

@@ -375,7 +375,7 @@ def create_sparsity2(mesh, V0: Space, V1: Space, integrals):
     ip, ix = C.c_void_p(), C.c_void_p()
     rc = lib().orc_create_sparsity2(C.byref(mesh.c), C.byref(V0.c), C.byref(V1.c), arr, len(integrals), C.byref(ip), C.byref(ix))
     if rc != 0:
-        raise ValueError("rectangular forms take cell integrals")
+        raise ValueError("rectangular forms take cell integrals (and interior-facet integrals between scalar spaces)")
     nrows = V0.ndofs * V0.bs
     indptr = np.ctypeslib.as_array(C.cast(ip, C.POINTER(C.c_int64)), shape=(nrows + 1,)).copy()
     nnz = int(indptr[-1])
@@ -399,7 +399,8 @@ def assemble_matrix2(mesh, V0: Space, V1: Space, integrals, indptr, indices, bc0
 
 def tabulate_entity2(mesh, V0: Space, V1: Space, integral: Integral, idx: int, use_rule: bool):
     ic = integral.cstruct()
-    Ae = np.zeros((V0.dofmap.shape[1] * V0.bs, V1.dofmap.shape[1] * V1.bs))
+    m = 2 if integral.type == INTERIOR_FACET else 1     # facets: macro rows / columns of both cells
+    Ae = np.zeros((m * V0.dofmap.shape[1] * V0.bs, m * V1.dofmap.shape[1] * V1.bs))
     lib().orc_tabulate_entity2(C.byref(mesh.c), C.byref(V0.c), C.byref(V1.c), C.byref(ic), C.c_int64(idx), int(use_rule), _p(Ae))
     return Ae
 

@@ -435,9 +435,7 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
     torch.cuda.synchronize()
     if "step_mode" in out:
         out["step_mode"]["launches_per_step"] = round(sum(v["launches"] for v in kernels.values()), 1)
-        out["step_mode"]["launches_note"] = ("kernel launches made by the library per step (its own launch wrapper: fills "
-                                             "included; the rocPRIM radix sort behind the dof -> facets incidence of "
-                                             "meshes with >= 6 M (facet, dof) pairs adds 11 launches the wrapper does not see)")
+        out["step_mode"]["launches_note"] = "kernel launches made by the library per step (its own launch wrapper: fills included)"
     alg_bytes = {
         "classify": B_CLASSIFY_PER_CELL * mesh.num_cells,
         "assemble_rows": B_UNCUT_CELL * info["n_inside"],

@@ -191,3 +191,66 @@ def test_sub_domain_form_into_the_matrix_of_a_larger_form(oracle):
     fem.assemble_matrix(a_left, A=A)
     fem.assemble_matrix(a_right, A=A)
     assert rel_err(A.data, want) < RTOL
+
+
+@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 6, 2, 1), (2, 12, 2, 1), (3, 5, 2, 3), (2, 12, 1, 2)])
+def test_steps_of_spaces_off_the_p1_path(oracle, tdim, n, degree, bs):
+    """Degree-2 and vector spaces inside a sync-free step: their sparsity and gather paths size host-side work by
+    counts they read on demand (Count::value inside the step) -- the step must give the oracle's system all the same,
+    from the second step on with the cut's lists still sized by the previous step."""
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, degree)
+    oV = O.Space(dofmap, ndofs, degree, bs)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, degree, dofmap=None if degree == 1 else dofmap, ndofs=ndofs, bs=bs)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    xt = torch.tensor(om.x[:, :tdim].copy(), device="cuda")
+    phi = torch.empty(om.nnodes, device="cuda", dtype=torch.float64)
+    f = cfx.Function(Vphi, phi)
+    kern_g, kern_o = (fem.ELASTICITY, O.K_ELASTICITY) if bs > 1 else (fem.STIFFNESS, O.K_STIFFNESS)
+    params = (1.0, 0.3) if bs > 1 else ()
+    state = {"cd": None}
+    key = f"test-spaces-{tdim}-{degree}-{bs}"
+    cfx.forget_step_history(key)
+
+    def body():
+        if state["cd"] is None:
+            state["cd"] = cfx.cut(f)
+        else:
+            cfx.update(state["cd"])
+        cd = state["cd"]
+        inside = cfx.locate_entities_device(cd, "phi<0")
+        vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+        ints = [fem.Integral(kern_g, cells=inside, rules=vol, params=params, qdegree=2),
+                fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)]
+        a = fem.form(ints, V)
+        A = fem.create_matrix(a)
+        fem.assemble_matrix(a, A=A)
+        dom = fem.deactivate_outside(A, None, fem.active_domain(a))
+        return A, dom
+
+    for k in range(3):
+        phi.copy_(torch.linalg.norm(xt - centre_of(tdim, k, 0.01), dim=1) - 0.27)
+        info = {}
+        A, dom = cfx.run_step(body, key=key, info=info)
+        ph = phi.cpu().numpy()
+        d = O.classify(om.conn, ph)
+        o_in = O.locate_entities(d, "phi<0")
+        o_vol = O.runtime_quadrature(om, om.conn, ph, d, "phi<0", 2)
+        o_ghost = O.ghost_penalty_facets(om, d, "phi<0")
+        o_ints = [O.Integral(O.CELL, kern_o, entities=o_in, rules=o_vol, params=params, qdegree=2),
+                  O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=o_ghost, params=(0.1,), qdegree=2)]
+        ip, ix = O.create_sparsity(om, oV, o_ints)
+        want = O.assemble_matrix(om, oV, o_ints, ip, ix)
+        ina = O.inactive_dofs(oV, O.active_cells(o_ints, om.ncells))
+        O.deactivate(ina, ip, ix, want, None)
+        assert info["passes"] <= 2, info
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), k
+        assert rel_err(A.data, want) < RTOL, k
+        assert np.array_equal(dom.inactive_dofs, ina), k

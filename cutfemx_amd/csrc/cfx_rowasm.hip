@@ -310,27 +310,44 @@ __global__ void plan_scatter_pos_kernel(DevN n_d, const int32_t* __restrict__ ro
   if (i < n) pos[rows[i]] = (int32_t)i;
 }
 
-// the special-row position of the k-th (facet, dof) pair of facet f, or -1 for the cell-1 copy of a dof both cells hold
-// (a shared dof lists the facet once)
-__device__ __forceinline__ int32_t facet_pair_key(const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap, int nd,
-                                                  const int32_t* __restrict__ pos, int64_t f, int k)
+// count + fill with the workgroup's atomics combined in LDS (cfx_device.h: adj_lds_insert): consecutive facets of the
+// list share most of their dofs (the list follows the cut cells), so a run of ~1000 (facet, dof) pairs reaches memory as
+// ~150 atomics.  (counts / offsets / cursors are indexed by the dof's position in the special-row list.)  A thread owns
+// one (facet, side) unit: the dof row of its cell, and for side 1 the dof row of cell 0 to drop the dofs both cells hold
+// (a shared dof lists the facet once) -- 2 nd loads per unit where one thread per pair paid 1 + nd loads per pair.
+// Round 3 sorted the pairs instead from 6 M pairs on (13 launches, 1.1 ms at 512^3 against 0.5 ms now); CFX_FACET_SORT=1
+// keeps that path.
+constexpr int kFacetMaxNd = 10;
+__host__ __device__ inline int facet_units_per_block(int nd) { return kAdjRun / nd < kBlock ? kAdjRun / nd : kBlock; }
+
+__device__ __forceinline__ void facet_unit_keys(const int32_t* __restrict__ rows, const int32_t* __restrict__ dofmap, int nd,
+                                                const int32_t* __restrict__ pos, int64_t unit, int32_t* key)
 {
-  const int64_t c = rows[4 * f + (k < nd ? 0 : 2)];
-  const int32_t dof = dofmap[c * nd + (k < nd ? k : k - nd)];
-  if (k >= nd)
+  const int64_t f = unit >> 1;
+  const int side = (int)(unit & 1);
+  const int64_t c = rows[4 * f + 2 * side];
+  int32_t d[kFacetMaxNd], d0[kFacetMaxNd];
+#pragma unroll
+  for (int j = 0; j < kFacetMaxNd; ++j) d[j] = j < nd ? dofmap[c * nd + j] : -1;
+  if (side)
   {
     const int64_t c0 = rows[4 * f];
-    bool skip = false;
-    for (int j = 0; j < nd; ++j) skip = skip || dofmap[c0 * nd + j] == dof;
-    if (skip) return -1;
+#pragma unroll
+    for (int j = 0; j < kFacetMaxNd; ++j) d0[j] = j < nd ? dofmap[c0 * nd + j] : -2;
   }
-  return pos[dof];
+#pragma unroll
+  for (int j = 0; j < kFacetMaxNd; ++j)
+  {
+    bool skip = j >= nd;
+    if (side)
+    {
+#pragma unroll
+      for (int i = 0; i < kFacetMaxNd; ++i) skip = skip || d0[i] == d[j];
+    }
+    key[j] = skip ? -1 : pos[d[j]];
+  }
 }
 
-// count + fill with the workgroup's atomics combined in LDS (cfx_device.h: adj_lds_insert): consecutive facets of the
-// list share most of their dofs (the list follows the cut cells), so a run of 1024 pairs reaches memory as ~150
-// atomics.  (counts / offsets / cursors are indexed by the dof's position in the special-row list.)  Round 3 sorted the
-// pairs instead from 6 M pairs on (13 launches, 1.1 ms at 512^3 against 0.6 ms now); CFX_FACET_SORT=1 keeps that path.
 __global__ void __launch_bounds__(kBlock) facet_dof_count_kernel(DevN nf_d, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, int nd,
                                                                  const int32_t* __restrict__ pos, int32_t* counts)
@@ -338,17 +355,18 @@ __global__ void __launch_bounds__(kBlock) facet_dof_count_kernel(DevN nf_d, cons
   __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
-  const int64_t npairs = dev_n(nf_d) * 2 * nd;
-  const int64_t base = (int64_t)blockIdx.x * kAdjRun;
-#pragma unroll
-  for (int q = 0; q < kAdjPer; ++q)
+  const int per = facet_units_per_block(nd);
+  const int64_t unit = (int64_t)blockIdx.x * per + threadIdx.x;
+  if (threadIdx.x < per && unit < 2 * dev_n(nf_d))
   {
-    const int64_t i = base + q * kBlock + threadIdx.x;
-    if (i >= npairs) continue;
-    const int64_t f = i / (2 * nd);
-    const int32_t key = facet_pair_key(rows, dofmap, nd, pos, f, (int)(i - f * 2 * nd));
-    int rank;
-    if (key >= 0) (void)adj_lds_insert(s_key, s_cnt, key, rank);
+    int32_t key[kFacetMaxNd];
+    facet_unit_keys(rows, dofmap, nd, pos, unit, key);
+#pragma unroll
+    for (int j = 0; j < kFacetMaxNd; ++j)
+    {
+      int rank;
+      if (key[j] >= 0) (void)adj_lds_insert(s_key, s_cnt, key[j], rank);
+    }
   }
   __syncthreads();
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock)
@@ -364,22 +382,19 @@ __global__ void __launch_bounds__(kBlock) facet_dof_fill_kernel(DevN nf_d, const
   __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
-  const int64_t npairs = dev_n(nf_d) * 2 * nd;
-  const int64_t base = (int64_t)blockIdx.x * kAdjRun;
-  int32_t key[kAdjPer], fac[kAdjPer];
-  int slot[kAdjPer], rank[kAdjPer];
+  const int per = facet_units_per_block(nd);
+  const int64_t unit = (int64_t)blockIdx.x * per + threadIdx.x;
+  const bool live = threadIdx.x < per && unit < 2 * dev_n(nf_d);
+  int32_t key[kFacetMaxNd];
+  int slot[kFacetMaxNd], rank[kFacetMaxNd];
 #pragma unroll
-  for (int q = 0; q < kAdjPer; ++q)
+  for (int j = 0; j < kFacetMaxNd; ++j) { key[j] = -1; slot[j] = 0; rank[j] = 0; }
+  if (live)
   {
-    const int64_t i = base + q * kBlock + threadIdx.x;
-    key[q] = -1; fac[q] = 0; slot[q] = 0; rank[q] = 0;
-    if (i < npairs)
-    {
-      const int64_t f = i / (2 * nd);
-      fac[q] = (int32_t)f;
-      key[q] = facet_pair_key(rows, dofmap, nd, pos, f, (int)(i - f * 2 * nd));
-      if (key[q] >= 0) slot[q] = adj_lds_insert(s_key, s_cnt, key[q], rank[q]);
-    }
+    facet_unit_keys(rows, dofmap, nd, pos, unit, key);
+#pragma unroll
+    for (int j = 0; j < kFacetMaxNd; ++j)
+      if (key[j] >= 0) slot[j] = adj_lds_insert(s_key, s_cnt, key[j], rank[j]);
   }
   __syncthreads();
   // (cursor[q] holds the row's count from the count pass: slots are handed out from the back, so the counters need no
@@ -387,9 +402,10 @@ __global__ void __launch_bounds__(kBlock) facet_dof_fill_kernel(DevN nf_d, const
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock)
     if (s_key[k] >= 0) s_cnt[k] = atomicSub(&cursor[s_key[k]], s_cnt[k]) - s_cnt[k];
   __syncthreads();
+  const int32_t f = (int32_t)(unit >> 1);
 #pragma unroll
-  for (int q = 0; q < kAdjPer; ++q)
-    if (key[q] >= 0) facets[offs[key[q]] + s_cnt[slot[q]] + rank[q]] = fac[q];
+  for (int j = 0; j < kFacetMaxNd; ++j)
+    if (key[j] >= 0) facets[offs[key[j]] + s_cnt[slot[j]] + rank[j]] = f;
 }
 
 // dof -> facets incidence by sorting: one (special-row position, facet) pair per dof of a facet's two cells (a dof
@@ -1817,7 +1833,9 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       // the facet list is sized by its upper bound, one entry per (facet, dof of its two cells) pair; the fill reuses
       // the counters as cursors counting DOWN, so that they need no second zero fill)
       if (fcount.n != ns_cap || !fcount.p) { fcount.alloc(ns_cap); fcount.zero(); }
-      const dim3 run_grid((unsigned)((npairs + kAdjRun - 1) / kAdjRun));
+      require(nd <= kFacetMaxNd, CFX_ERR_RUNTIME, "dof -> facets incidence: more than 10 dofs per cell");
+      const int per = facet_units_per_block(nd);
+      const dim3 run_grid((unsigned)((2 * nf_cap + per - 1) / per));
       launch("facet_dof_count", facet_dof_count_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
              P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
       P.d2f_offsets.alloc(ns_cap + 1);

@@ -969,7 +969,7 @@ def main():
     os.environ["CFX_DEVICE"] = str(local_rank)
     # One explicit HIP stream for torch and the engine alike (CFX_BENCH_STREAM=0: the legacy null stream, the library's
     # default).  Dependent launches on the null stream are ~10 us apart on this stack (rocprofv3 kernel trace,
-    # profiles/r04_launch_gaps.txt) -- about 70 launches per step.
+    # profiles/r04_launch_gaps.txt, taken when a step had 73 of them; 52 now: `step_mode.launches_per_step`).
     if os.environ.get("CFX_BENCH_STREAM", "1") != "0":
         from cutfemx_amd import _lib as _sl
         bench_stream = torch.cuda.Stream(device)

@@ -553,6 +553,7 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
   __shared__ int32_t s_inc[RPW][kInc];
   __shared__ uint8_t s_incm[RPW][kInc];
   __shared__ int s_cnt[RPW];
+  __shared__ int s_nsrc[RPW]; // sources of the current chunk that add candidates (the others are not iterated at all)
   const int lane = threadIdx.x, grp = lane / G, gl = lane % G;
   // one pass for every launch that fits HIP's 2^32-thread limit; the grid is capped beyond it
   const int64_t n_active = dev_n(P.n_active);
@@ -671,6 +672,8 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
     {
       const int base = ch * kSrc;
       const int m = min(kSrc, nsrc - base);
+      if (gl == 0) s_nsrc[grp] = 0;
+      __syncthreads();
       for (int t = gl; t < m; t += G)
       {
         const int idx = base + t;
@@ -696,15 +699,19 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
           }
           if (lo < ninc && s_inc[grp][lo] == cell && s_incm[grp][lo]) cell = -1;
         }
-        s_src[grp][t] = cell;
+        // only the sources that add candidates are kept (their order does not matter: the set is ranked afterwards): the
+        // candidate loop below ran over every (source, local dof) pair, skipped ones included -- 1440 trips for a vertex
+        // dof of a degree-2 space of which ~480 loaded anything
+        if (cell >= 0) s_src[grp][atomicAdd(&s_nsrc[grp], 1)] = cell;
       }
       __syncthreads();
+      const int mv = s_nsrc[grp];
       // the (source, local dof) pairs, lane after lane: the pair index advances by G, (q, j) follow without a division
       // (t / nd with a run-time nd was ~20 instructions per candidate).  kU dof-row entries are requested together and
       // inserted afterwards: with one load per loop trip every trip waited for its own gather (~30 trips x 1.5 us for
       // a vertex dof of a degree-2 space)
       constexpr int kU = 8;
-      const int npairs = max(m, 0) * P.nd;
+      const int npairs = mv * P.nd;
       int q = gl / P.nd, j = gl - q * P.nd;
       const int dq = G / P.nd, dj = G - dq * P.nd;
       for (int t0 = gl; t0 < npairs; t0 += G * kU)

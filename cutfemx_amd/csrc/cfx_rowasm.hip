@@ -872,6 +872,22 @@ __global__ void pattern_write_kernel(DevN n_active_d, const int32_t* __restrict_
   if (ri >= n_active) return;
   const int n = len[ri];
   const int64_t r = active_rows ? (int64_t)active_rows[ri] : ri; // (no list: all rows, the mesh-static stencil)
+  if (bs == 1)
+  {
+    // scalar spaces: 16 B per lane from the (aligned) staging row, 32 entries per trip of the row's eight lanes
+    const int4* src = reinterpret_cast<const int4*>(tmp + ri * T);
+    const int64_t ob = indptr[r];
+    for (int k4 = (int)(i - ri * 8); 4 * k4 < n; k4 += 8)
+    {
+      const int4 v = src[k4];
+      const int k = 4 * k4;
+      indices[ob + k] = v.x;
+      if (k + 1 < n) indices[ob + k + 1] = v.y;
+      if (k + 2 < n) indices[ob + k + 2] = v.z;
+      if (k + 3 < n) indices[ob + k + 3] = v.w;
+    }
+    return;
+  }
   for (int k = (int)(i - ri * 8); k < n; k += 8)
   {
     const int32_t col = tmp[ri * T + k];

@@ -178,7 +178,6 @@ uint64_t dev_block_serial(const void* p);
 uint64_t next_serial();                    // process-wide counter shared by blocks, rules handles and plans
 void rules_serial_live(uint64_t s, bool live);
 bool rules_serial_is_live(uint64_t s);
-void dev_free_now(void* p); // give a (large, one-off) block back to the driver instead of the cache
 void device_memory_stats(size_t& live, size_t& cached, size_t& peak); // bytes held from HIP: in use / cached / high-water
 void device_memory_reset_peak();
 
@@ -363,11 +362,6 @@ struct DevArray
     if (p && owned) dev_free(p);
     p = nullptr; n = 0; owned = false; count = Count();
   }
-  void release_to_driver() // one-off scratch: not into the block cache
-  {
-    if (p && owned && !count.cell) { dev_free_now(p); p = nullptr; n = 0; owned = false; }
-    else release();
-  }
   void zero() { if (n > 0) dev_fill(p, 0, sizeof(T) * (size_t)n); }
   T* get() const { return p; }
 };
@@ -548,6 +542,27 @@ struct Stencil
   DevArray<uint16_t> st_loc;
   bool tiles_built = false, tiles_usable = false;
   int max_tile_verts = 0, max_tile_items = 0, max_tile_st = 0; // items: dof->cells entries, st: neighbour entries
+  // The single-pass build of the neighbour lists stages 64 columns per dof (34 GB at 512^3).  Giving that block back to
+  // the driver made the NEXT large hipMalloc of the process take 1.5 - 2.6 s on this stack (tools/time_malloc.py: 0.2 ms
+  // for the first 34 GB, 1.8 s for the same request after a hipFree of 34 GB); left in the block cache it would sit
+  // there unused.  It stays with the stencil instead and hosts the tables built after it (slot4, diagpos, cpos, st_loc,
+  // tile_verts are views into it; the tile build's scratch is its tail): `take` hands out the next 256 B-aligned piece,
+  // or allocates when the arena is absent or full.
+  DevArray<uint8_t> arena;
+  int64_t arena_used = 0;
+  template <typename T>
+  void take(DevArray<T>& a, int64_t n)
+  {
+    const int64_t bytes = ((int64_t)sizeof(T) * (n > 0 ? n : 1) + 255) & ~255LL;
+    if (arena.p && arena_used + bytes <= arena.n)
+    {
+      a.release();
+      a.p = reinterpret_cast<T*>(arena.p + arena_used); a.n = n; a.owned = false;
+      arena_used += bytes;
+    }
+    else
+      a.alloc(n);
+  }
 };
 constexpr int kRowTile = 16;
 

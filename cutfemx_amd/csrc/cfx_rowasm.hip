@@ -1978,16 +1978,19 @@ const Stencil& space_stencil(cfx_space_s* V)
   {
     launch("stencil_rows_write", pattern_write_kernel<64>, grid_for(V->ndofs * 8), dim3(kBlock), 0, DevN(V->ndofs),
            (const int32_t*)nullptr, 1, staged.p, len.p, S.offsets.p, S.nbr.p);
-    staged.release_to_driver();
+    // the staging block becomes the stencil's arena (Stencil::arena): the tables below are carved from it
+    S.arena.p = reinterpret_cast<uint8_t*>(staged.p); S.arena.n = staged.n * (int64_t)sizeof(int32_t); S.arena.owned = staged.owned;
+    staged.p = nullptr; staged.n = 0; staged.owned = false;
+    S.arena_used = 0;
   }
   else
   {
     A.indptr = S.offsets.p; A.indices = S.nbr.p;
     launch("stencil_rows_write", pattern_rows_kernel<4, 64>, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, A);
   }
-  S.slot4.alloc(adj.cells.n);
-  S.diagpos.alloc(V->ndofs);
-  S.cpos.alloc(V->mesh->ncells * (int64_t)V->ndofs_cell);
+  S.take(S.slot4, adj.cells.n);
+  S.take(S.diagpos, V->ndofs);
+  S.take(S.cpos, V->mesh->ncells * (int64_t)V->ndofs_cell);
   launch("stencil_slots", stencil_slots_kernel, wave_grid((V->ndofs + 15) / 16), dim3(kWave), 0, V->ndofs, adj.offsets.p,
          adj.cells.p, V->dofmap.p, V->ndofs_cell, S.offsets.p, S.nbr.p, S.slot4.p, S.diagpos.p, S.cpos.p);
   S.usable = true;
@@ -2009,21 +2012,33 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
   DevArray<int> maxima(3);
   maxima.zero();
   const dim3 grid = wave_grid(ntiles);
-  // one pass when the card has room for kTileStage staged vertices per tile (8.6 GB at 512^3, given back right after)
-  // and no tile's union outgrows its staging row; else count, scan and build every tile a second time (42 + 52 ms)
+  // one pass when there is room for kTileStage staged vertices per tile (8.6 GB at 512^3: the tail of the stencil's
+  // arena, else a block of its own) and no tile's union outgrows its staging row; else count, scan and build every
+  // tile a second time (42 + 52 ms)
   DevArray<int32_t> staged;
   {
-    size_t free_b = 0, total_b = 0;
-    CFX_HIP(hipMemGetInfo(&free_b, &total_b));
-    size_t live_b = 0, cached_b = 0, peak_b = 0;
-    device_memory_stats(live_b, cached_b, peak_b);
-    const size_t need = (size_t)ntiles * kTileStage * sizeof(int32_t) + (size_t)S.nbr.n * sizeof(uint16_t);
+    const int64_t need = ntiles * kTileStage * (int64_t)sizeof(int32_t);
+    const int64_t perm = (((int64_t)sizeof(uint16_t) * S.nbr.n + 255) & ~255LL);     // st_loc goes in front of it
     const char* sv = getenv("CFX_STENCIL_STAGED");
-    if (need < (free_b + cached_b) / 3 && !(sv && sv[0] == '0')) staged.alloc(ntiles * kTileStage);
+    const bool on = !(sv && sv[0] == '0');
+    if (on && S.arena.p && S.arena_used + perm + need <= S.arena.n)
+    {
+      // (the tail of the arena; the permanent tables grow from the front and are checked against it below)
+      staged.p = reinterpret_cast<int32_t*>(S.arena.p + ((S.arena.n - need) & ~255LL)); staged.n = ntiles * kTileStage; staged.owned = false;
+    }
+    else if (on)
+    {
+      size_t free_b = 0, total_b = 0;
+      CFX_HIP(hipMemGetInfo(&free_b, &total_b));
+      size_t live_b = 0, cached_b = 0, peak_b = 0;
+      device_memory_stats(live_b, cached_b, peak_b);
+      if ((size_t)(need + perm) < (free_b + cached_b) / 3) staged.alloc(ntiles * kTileStage);
+    }
   }
+  const uint8_t* tail = (staged.p && !staged.owned) ? reinterpret_cast<const uint8_t*>(staged.p) : nullptr; // arena tail in use
   if (staged.p)
   {
-    S.st_loc.alloc(S.nbr.n);
+    S.take(S.st_loc, S.nbr.n);
     launch("stencil_tiles", stencil_tiles_kernel<2>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
            adj.offsets.p, counts.p, (const int64_t*)nullptr, staged.p, S.st_loc.p, maxima.p);
   }
@@ -2032,20 +2047,23 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
            adj.offsets.p, counts.p, (const int64_t*)nullptr, (int32_t*)nullptr, (uint16_t*)nullptr, maxima.p);
   const std::vector<int> mx = download(maxima.p, 3);
   S.max_tile_verts = mx[0]; S.max_tile_st = mx[1]; S.max_tile_items = mx[2];
-  if (S.max_tile_st > kTileMaxSt) { S.st_loc.release(); staged.release_to_driver(); return S; }
+  if (S.max_tile_st > kTileMaxSt) { staged.release(); return S; }
   S.tile_voff.alloc(ntiles + 1);
   exclusive_scan(counts.p, S.tile_voff.p, ntiles);
-  S.tile_verts.alloc(read_scalar(S.tile_voff.p + ntiles));
+  const int64_t n_verts = read_scalar(S.tile_voff.p + ntiles);
+  // (tile_verts from the arena only if it ends below the scratch in the arena's tail)
+  if (tail && S.arena.p + S.arena_used + (((int64_t)sizeof(int32_t) * n_verts + 255) & ~255LL) > tail) S.tile_verts.alloc(n_verts);
+  else S.take(S.tile_verts, n_verts);
   if (staged.p && S.max_tile_verts <= kTileStage)
   {
     launch("stencil_tiles_write", stencil_tiles_pack_kernel, grid_for(ntiles * kWave), dim3(kBlock), 0, ntiles, counts.p,
            S.tile_voff.p, staged.p, S.tile_verts.p);
-    staged.release_to_driver();
+    staged.release();
   }
   else
   {
-    staged.release_to_driver();
-    if (!S.st_loc.p) S.st_loc.alloc(S.nbr.n);
+    staged.release();
+    if (!S.st_loc.p) S.take(S.st_loc, S.nbr.n);
     launch("stencil_tiles_write", stencil_tiles_kernel<1>, grid, dim3(kWave), 0, V->ndofs, ntiles, S.offsets.p, S.nbr.p,
            adj.offsets.p, (int32_t*)nullptr, S.tile_voff.p, S.tile_verts.p, S.st_loc.p, maxima.p);
   }

@@ -1,5 +1,6 @@
 // cutfemx_amd: runtime (device/stream/profile), scans, incidence inversion.
 #include "cfx_device.h"
+#include <chrono>
 
 namespace cfx
 {
@@ -494,7 +495,13 @@ void* dev_alloc(size_t bytes)
     return p;
   }
   void* p = nullptr;
+  static const bool trace = getenv("CFX_ALLOC_TRACE") != nullptr; // every hipMalloc of the block cache, with its duration
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc(&p, want);
+  if (trace)
+    fprintf(stderr, "cutfemx_amd: hipMalloc %.3f GB: %.1f ms (in use %.1f GB, cached %.1f GB)\n", want / 1073741824.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), c.in_use / 1073741824.0,
+            c.cached / 1073741824.0);
   if (e != hipSuccess)
   {
     (void)hipGetLastError();
@@ -519,21 +526,6 @@ void dev_free(void* p)
   c.cached += it->second.size;
   c.in_use -= it->second.size;
   c.live.erase(it);
-}
-
-void dev_free_now(void* p)
-{
-  if (!p) return;
-  BlockCache& c = cache();
-  auto it = c.live.find(p);
-  if (it == c.live.end()) return;
-  // a one-off scratch block (tens of GB of staging while the mesh-static tables are built): back to the driver, not
-  // into the cache, where nothing of a step's size would ever take it
-  (void)hipStreamSynchronize(ctx().main_stream);
-  if (ctx().side_stream) (void)hipStreamSynchronize(ctx().side_stream);
-  c.in_use -= it->second.size;
-  c.live.erase(it);
-  (void)hipFree(p);
 }
 
 uint64_t next_serial()

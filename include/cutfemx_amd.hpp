@@ -475,6 +475,37 @@ inline void assemble_vector(std::span<std::complex<double>> b, const Form& L, st
                                  reinterpret_cast<double*>(b.data())));
 }
 
+/// complex64 instantiation (T = std::complex<float>): interleaved float32 containers, the complex128 arithmetic, one
+/// rounding per entry; `scales` stay double
+inline void assemble_matrix(std::span<std::complex<float>> values, const Form& a, const SparsityPattern& pattern,
+                            std::span<const std::complex<double>> scales = {}, std::span<const std::int8_t> bc0 = {},
+                            std::span<const std::int8_t> bc1 = {})
+{
+  check(cfx_assemble_matrix_c64(a.handle.h, pattern.handle.h, bc0.empty() ? nullptr : bc0.data(),
+                                bc1.empty() ? nullptr : bc1.data(),
+                                scales.empty() ? nullptr : reinterpret_cast<const double*>(scales.data()), 0,
+                                reinterpret_cast<float*>(values.data())));
+}
+inline void assemble_vector(std::span<std::complex<float>> b, const Form& L, std::span<const std::complex<double>> scales = {})
+{
+  check(cfx_assemble_vector_c64(L.handle.h, scales.empty() ? nullptr : reinterpret_cast<const double*>(scales.data()),
+                                reinterpret_cast<float*>(b.data())));
+}
+
+/// A user integrand compiled for gfx950 at run time (the generated tabulate_tensor of a form, Form.h:59-75): `source`
+/// defines `__device__ void name(double* A, const double* w, const double* c, const double* coordinate_dofs, int nq,
+/// const double* points, const double* weights, const double* point_data)`; the id returned goes into Integral::kernel.
+inline int register_integrand(const std::string& name, const std::string& source, int rank)
+{
+  int id = 0;
+  check(cfx_integrand_register(name.c_str(), source.c_str(), rank, &id));
+  return id;
+}
+
+/// (Sync-free steps -- cfx_step_begin / cfx_step_end -- are not wrapped here: this facade returns host vectors sized by the
+/// counts of the moment, and inside a step those are capacities.  Callers that pass device handles on use the C ABI's
+/// step functions directly, as cutfemx_amd/step.py does.)
+
 /// apply_lifting(): b <- b - alpha A (g - x0) over the Dirichlet columns
 /// (cpp/dolfinx_custom_data/fem/assemble_vector_impl.h:383-436); one form, markers/values per dof
 inline void apply_lifting(std::span<double> b, const Form& a, std::span<const std::int8_t> bc_markers,

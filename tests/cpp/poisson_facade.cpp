@@ -65,6 +65,15 @@ int main(int argc, char** argv)
     cfx::fem::Form a = cfx::fem::Form::create(V, 2, ai);
     cfx::fem::Form L = cfx::fem::Form::create(V, 1, Li);
 
+    if (argc > 99)
+    {
+      // (type-checked, not run: the complex64 overloads and a run-time integrand)
+      std::vector<std::complex<float>> Ac, bc;
+      cfx::fem::SparsityPattern spc = cfx::fem::create_sparsity_pattern(a);
+      cfx::fem::assemble_matrix(std::span<std::complex<float>>(Ac), a, spc);
+      cfx::fem::assemble_vector(std::span<std::complex<float>>(bc), L);
+      (void)cfx::fem::register_integrand("user_k", "__device__ void user_k(double*, const double*, const double*, const double*, int, const double*, const double*, const double*) {}", 2);
+    }
     cfx::fem::SparsityPattern sp = cfx::fem::create_sparsity_pattern(a);
     std::vector<double> A(static_cast<std::size_t>(sp.num_nonzeros()), 0.0), b(static_cast<std::size_t>(mesh.num_nodes), 0.0);
     cfx::fem::assemble_matrix(A, a, sp);

@@ -606,7 +606,15 @@ struct cfx_mesh_s
   // ix + (n+1)(iy + (n+1) iz): the connectivity is a function of the cell id ("implicit-structured")
   int box_n = 0;
   const cfx::DevArray<int32_t>& cell_neighbours();
+  // Vertex summary of every block of kClassBlock consecutive cells (mesh-static, built on the first classification of a
+  // level set that lives on the geometry dofmap): the distinct vertices of the block's cells as at most kClassRuns runs
+  // of consecutive ids (start, length); nruns < 0: the block has more runs than that (an unordered mesh) and is always
+  // classified cell by cell.  A block whose vertices all carry one sign is classified without reading its connectivity.
+  cfx::DevArray<int32_t> class_nruns; // [nblocks]
+  cfx::DevArray<int2> class_runs;     // [nblocks * kClassRuns]
+  bool class_built = false;
 };
+constexpr int kClassBlock = 1024, kClassRuns = 32; // (one wavefront classifies a block: 16 cells per lane)
 
 struct cfx_rules_s
 {

@@ -101,3 +101,48 @@ def test_zero_values_at_vertices(oracle, tdim, n):
     # the interface x = 0.5 is counted once: its measure is 1
     itf = cfx.runtime_quadrature(cd, "phi=0", 2)
     assert abs(itf.weights.sum() - 1.0) < 1e-13
+
+
+@pytest.mark.parametrize("tdim,n", [(3, 14), (2, 40), (3, 9)])
+def test_block_culled_classification_equals_the_cell_loop(oracle, tdim, n, monkeypatch):
+    """Classification decides whole blocks of 1024 cells from the sign codes of their distinct vertices (mesh-static
+    vertex runs) and goes cell by cell only where the interface passes: the domain array, the located lists and their
+    counts must equal the oracle's and the cell-by-cell kernel's (CFX_CLASSIFY_CULL=0) -- on the generated numbering, on a
+    mesh whose cells and vertices are shuffled (no runs: every block falls back), with zeros at vertices, with one sign."""
+    import cutfemx_amd as cfx
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    rng = np.random.default_rng(12)
+    levels = {
+        "sphere": np.linalg.norm(om.x[:, :tdim] - 0.47, axis=1) - 0.31,
+        "zeros": np.round(8.0 * (om.x[:, 0] - 0.5)) / 8.0 + 0.0 * om.x[:, 1],        # exact zeros on a vertex plane
+        "random": rng.standard_normal(om.nnodes),
+        "negative": -np.ones(om.nnodes), "positive": np.ones(om.nnodes),
+    }
+    # a second mesh: the same cells in random order over randomly renumbered vertices
+    vperm = rng.permutation(om.nnodes)
+    inv = np.empty_like(vperm); inv[vperm] = np.arange(om.nnodes)
+    cperm = rng.permutation(om.ncells)
+    x2 = om.x[vperm]
+    conn2 = np.ascontiguousarray(inv[om.conn[cperm]].astype(np.int32))
+    for shuffled in (False, True):
+        x, conn = (x2, conn2) if shuffled else (om.x, om.conn)
+        for name, phi0 in levels.items():
+            phi = phi0[vperm] if shuffled else phi0
+            want = O.classify(conn, phi)
+            got = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("CFX_CLASSIFY_CULL", mode)
+                mesh = cfx.Mesh.from_arrays(tdim, x, conn)
+                V = cfx.FunctionSpace(mesh, 1)
+                cd = cfx.cut(cfx.Function(V, phi))
+                got[mode] = (cd.domain(), cfx.locate_entities(cd, "phi<0"), cfx.locate_entities(cd, "phi=0"))
+                # update() with a moved level set goes through the same (already built) summary
+                phi2 = phi + 0.03
+                cd2 = cfx.cut(cfx.Function(V, phi2))
+                assert np.array_equal(cd2.domain(), O.classify(conn, phi2)), (name, shuffled, mode)
+            for mode in ("1", "0"):
+                assert np.array_equal(got[mode][0], want), (name, shuffled, mode)
+                assert np.array_equal(got[mode][1], O.locate_entities(want, "phi<0")), (name, shuffled, mode)
+                assert np.array_equal(got[mode][2], O.locate_entities(want, "phi=0")), (name, shuffled, mode)
+    monkeypatch.delenv("CFX_CLASSIFY_CULL")

@@ -450,10 +450,17 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         blk = dom_h[:nb * 1024].reshape(nb, 1024)
         uniform = (blk == blk[:, :1]).all(axis=1) & (blk[:, 0] != 0)
         mixed = 1.0 - float(uniform.mean()) if nb > 0 else 1.0
-        classify_bytes = (1.0 + 20.0 * mixed) * mesh.num_cells + mesh.num_nodes + 256.0 * (mesh.num_cells / 1024.0)
+        # ... and inside those blocks quarter by quarter (256 cells) before any cell is looked at
+        q = blk[~uniform].reshape(-1, 256)
+        q_uniform = (q == q[:, :1]).all(axis=1) & (q[:, 0] != 0) if q.size else np.zeros(0, bool)
+        mixed_cells = 256.0 * float((~q_uniform).sum())
+        classify_bytes = (1.0 * mesh.num_cells + mesh.num_nodes + 256.0 * nb + 4 * 128.0 * float((~uniform).sum())
+                          + 20.0 * mixed_cells)
         classify_note = (f"block culling: 1 B per cell written + 1 B per vertex code + 256 B of vertex runs per block of 1024 "
-                         f"cells + 20 B per cell (connectivity row, codes) in the {100.0 * mixed:.1f} % of the blocks that "
-                         "have vertices on both sides")
+                         f"cells; {100.0 * mixed:.1f} % of the blocks have vertices on both sides and are decided by quarters "
+                         f"(128 B of runs each), {100.0 * mixed_cells / max(mesh.num_cells, 1):.1f} % of the cells end in the "
+                         "cell loop (20 B: connectivity row + codes)")
+        del q
         del dom_h, blk
     alg_bytes = {
         "classify": classify_bytes,

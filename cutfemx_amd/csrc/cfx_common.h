@@ -612,9 +612,13 @@ struct cfx_mesh_s
   // classified cell by cell.  A block whose vertices all carry one sign is classified without reading its connectivity.
   cfx::DevArray<int32_t> class_nruns; // [nblocks]
   cfx::DevArray<int2> class_runs;     // [nblocks * kClassRuns]
+  // ... and of its kClassSub quarter blocks (kClassSubRuns runs each): a block with vertices on both sides is decided
+  // quarter by quarter before any cell is looked at
+  cfx::DevArray<int2> class_sub_runs; // [nblocks * kClassSub * kClassSubRuns]
   bool class_built = false;
 };
 constexpr int kClassBlock = 1024, kClassRuns = 32; // (one wavefront classifies a block: 16 cells per lane)
+constexpr int kClassSub = 4, kClassSubRuns = 16;
 
 struct cfx_rules_s
 {

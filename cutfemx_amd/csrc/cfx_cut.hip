@@ -215,13 +215,16 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const 
 // go cell by cell as before.  Same domain array bit for bit, any mesh; a block without a summary (more than kClassRuns
 // runs: no locality in the numbering) always takes the cell-by-cell path.
 // ---------------------------------------------------------------------------
-template <int ND>
+template <int ND, int CELLS, int RUNS, int N, int H>
 __global__ void __launch_bounds__(kBlock) class_summary_kernel(int64_t ncells, const int32_t* __restrict__ conn,
-                                                               int32_t* __restrict__ nruns, int2* __restrict__ runs)
+                                                               int32_t* __restrict__ nruns, int2* __restrict__ runs,
+                                                               int2* __restrict__ sub_runs)
 {
+  constexpr int kClassBlock = CELLS, kClassRuns = RUNS; // (this kernel's block: the block proper, or a quarter of it)
   // the block's ND * kClassBlock vertex ids -> distinct ids (LDS hash set: a block of a mesh with any locality has a
   // few hundred) -> sorted (bitonic over N slots) -> runs of consecutive ids.  More than N distinct ids: no summary.
-  constexpr int N = 1024, Q = N / kBlock, H = 4096;
+  constexpr int Q = N / kBlock;
+  static_assert(N % kBlock == 0 && (H & (H - 1)) == 0 && H >= ND * CELLS, "summary table sizes");
   __shared__ int32_t s_h[H];
   __shared__ int32_t s_v[N];
   __shared__ int32_t s_start[kClassRuns + 1], s_d0[kClassRuns + 1];
@@ -258,8 +261,10 @@ __global__ void __launch_bounds__(kBlock) class_summary_kernel(int64_t ncells, c
   const int ndist = s_cnt;
   if (ndist > N)
   {
-    if (threadIdx.x == 0) nruns[blockIdx.x] = -1;
+    if (threadIdx.x == 0 && nruns) nruns[blockIdx.x] = -1;
     if (threadIdx.x < kClassRuns) runs[(int64_t)blockIdx.x * kClassRuns + threadIdx.x] = make_int2(0, threadIdx.x == 0 ? -1 : 0);
+    if (sub_runs && threadIdx.x < kClassSub * kClassSubRuns)
+      sub_runs[(int64_t)blockIdx.x * kClassSub * kClassSubRuns + threadIdx.x] = make_int2(0, threadIdx.x % kClassSubRuns == 0 ? -1 : 0);
     return;
   }
   for (int k = 2; k <= N; k <<= 1)
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(kBlock) class_summary_kernel(int64_t ncells, c
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) nruns[blockIdx.x] = tot_s <= kClassRuns ? tot_s : -1;
+  if (threadIdx.x == 0 && nruns) nruns[blockIdx.x] = tot_s <= kClassRuns ? tot_s : -1;
   // every slot is written: unused ones hold length 0, a block without a summary length -1 in slot 0 (the classification
   // reads the slots alone -- one dependent load less per wavefront)
   if (threadIdx.x < kClassRuns)
@@ -309,105 +314,167 @@ __global__ void __launch_bounds__(kBlock) class_summary_kernel(int64_t ncells, c
     else if (j < tot_s) r = make_int2(s_start[j], (j + 1 < tot_s ? s_d0[j + 1] : ndist) - s_d0[j]);
     runs[(int64_t)blockIdx.x * kClassRuns + j] = r;
   }
+  if (sub_runs == nullptr) return;
+  // The quarter blocks: per run of the block the span [min, max] of the ids the quarter's cells refer to -- a superset of
+  // the quarter's vertices when they do not fill the span, which keeps the culling exact (one sign on a superset is one
+  // sign on the set) and costs a search and two LDS atomics per reference where a summary of its own cost a hash set
+  // and a sort per quarter (36 ms at 512^3).  Quarters that touch more than kClassSubRuns runs get no summary.
+  __shared__ int32_t s_lo[kClassSub][RUNS], s_hi[kClassSub][RUNS];
+  const bool have = tot_s <= kClassRuns;
+  for (int i = threadIdx.x; i < kClassSub * RUNS; i += kBlock) { (&s_lo[0][0])[i] = 0x7fffffff; (&s_hi[0][0])[i] = -1; }
+  __syncthreads();
+  if (have)
+    for (int i = threadIdx.x; i < nloc; i += kBlock)
+    {
+      const int32_t v = conn[c0 * ND + i];
+      const int sq = (i / ND) / (CELLS / kClassSub);
+      int lo = 0, hi = tot_s; // last run whose start is <= v
+      while (hi - lo > 1)
+      {
+        const int mid = (lo + hi) >> 1;
+        if (s_start[mid] <= v) lo = mid; else hi = mid;
+      }
+      atomicMin(&s_lo[sq][lo], v);
+      atomicMax(&s_hi[sq][lo], v);
+    }
+  __syncthreads();
+  if (threadIdx.x < kClassSub)
+  {
+    const int sq = threadIdx.x;
+    int2* out = sub_runs + ((int64_t)blockIdx.x * kClassSub + sq) * kClassSubRuns;
+    int n = 0;
+    bool ok = have;
+    for (int j = 0; ok && j < tot_s; ++j)
+      if (s_hi[sq][j] >= 0)
+      {
+        if (n == kClassSubRuns) { ok = false; break; }
+        out[n++] = make_int2(s_lo[sq][j], s_hi[sq][j] - s_lo[sq][j] + 1);
+      }
+    if (!ok) { n = 0; out[n++] = make_int2(0, -1); }
+    for (; n < kClassSubRuns; ++n) out[n] = make_int2(0, 0);
+  }
+}
+
+// AND of the sign codes of the vertices a run table lists (RUNS slots of (start, length), one per lane; length 0: unused,
+// -1 in slot 0: no summary -> 0).  The elements are numbered through (prefix sums of the lengths) and dealt to the lanes E
+// at a time, so that a lane's loads are independent and in flight together: walking the runs one after the other left
+// every wavefront ~12 dependent load latencies long.
+template <int RUNS, int E>
+__device__ __forceinline__ unsigned class_runs_and(const int2* __restrict__ table, const uint8_t* __restrict__ code, int lane)
+{
+  const int2 mine = lane < RUNS ? table[lane] : make_int2(0, 0);
+  const bool summary = __shfl(mine.y, 0, 64) >= 0;
+  const int nr = summary ? __popcll(__ballot(mine.y > 0)) : 0;
+  unsigned all = summary ? 3u : 0u;
+  const int incl = wave_inclusive_scan<int>(summary ? mine.y : 0);
+  const int total = __shfl(incl, 63, 64);
+  for (int t0 = 0; t0 < total; t0 += 64 * E)
+  {
+    int addr[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) addr[e] = -1;
+    for (int j = 0; j < nr; ++j)
+    {
+      const int start = __shfl(mine.x, j, 64), hi = __shfl(incl, j, 64), lo = hi - __shfl(mine.y, j, 64);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+      {
+        const int t = t0 + lane + 64 * e;
+        addr[e] = (t >= lo && t < hi) ? start + (t - lo) : addr[e];
+      }
+    }
+    unsigned v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = addr[e] >= 0 ? (unsigned)code[addr[e]] : 3u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) all &= v[e];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) all &= __shfl_xor(all, o, 64);
+  return all;
+}
+
+// CELLS equal domain bytes from cbase on, written by the wavefront
+template <int CELLS>
+__device__ __forceinline__ void class_fill(int8_t* __restrict__ domain, int64_t cbase, int64_t ncells, int8_t d, int lane)
+{
+  const uint32_t w4 = 0x01010101u * (uint32_t)(uint8_t)d;
+#pragma unroll
+  for (int q4 = 0; q4 < CELLS / 256; ++q4)
+  {
+    const int64_t c = cbase + 4 * (lane + 64 * q4);
+    if (c + 4 <= ncells && (reinterpret_cast<uintptr_t>(domain + c) & 3) == 0) *reinterpret_cast<uint32_t*>(domain + c) = w4;
+    else
+      for (int64_t q = c; q < c + 4 && q < ncells; ++q) domain[q] = d;
+  }
 }
 
 // one wavefront per block of kClassBlock cells
 template <int ND>
 __global__ void __launch_bounds__(kBlock) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
-                                                                 const int32_t* __restrict__ nruns, const int2* __restrict__ runs,
+                                                                 const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
                                                                  const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
                                                                  int32_t* tiles_inside, int32_t* tiles_cut)
 {
-  constexpr int U = kClassBlock / 64;
+  constexpr int SUB = kClassBlock / kClassSub, U = SUB / 64;
   static_assert(kByteTile % kClassBlock == 0, "classification blocks must nest in compaction tiles");
   const int lane = threadIdx.x & 63;
   const int64_t b = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
   if (b >= nblocks) return;
   const int64_t cbase = b * kClassBlock;
-  const int2 mine = lane < kClassRuns ? runs[b * kClassRuns + lane] : make_int2(0, 0);
-  const bool summary = __shfl(mine.y, 0, 64) >= 0;
-  const int nr = summary ? __popcll(__ballot(mine.y > 0)) : 0;
-  unsigned all = summary ? 3u : 0u;
-  {
-    // The block's runs, one per lane.  Their elements are numbered through (prefix sums of the lengths) and dealt to
-    // the lanes E at a time, so that a lane's loads are independent and in flight together: walking the runs one after
-    // the other left every wavefront ~12 dependent load latencies long (1.6 ms at 512^3 for 3 M wavefronts).
-    constexpr int E = 12;
-    const int incl = wave_inclusive_scan<int>(summary ? mine.y : 0);
-    const int total = __shfl(incl, 63, 64);
-    for (int t0 = 0; t0 < total; t0 += 64 * E)
-    {
-      int addr[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) addr[e] = -1;
-      for (int j = 0; j < nr; ++j)
-      {
-        const int start = __shfl(mine.x, j, 64), hi = __shfl(incl, j, 64), lo = hi - __shfl(mine.y, j, 64);
-#pragma unroll
-        for (int e = 0; e < E; ++e)
-        {
-          const int t = t0 + lane + 64 * e;
-          addr[e] = (t >= lo && t < hi) ? start + (t - lo) : addr[e];
-        }
-      }
-      unsigned v[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) v[e] = addr[e] >= 0 ? (unsigned)code[addr[e]] : 3u;
-#pragma unroll
-      for (int e = 0; e < E; ++e) all &= v[e];
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) all &= __shfl_xor(all, o, 64);
   const int64_t tile = cbase / kByteTile;
+  const unsigned all = class_runs_and<kClassRuns, 12>(runs + b * kClassRuns, code, lane);
   if (all == 1u || all == 2u)
   {
-    // every vertex of the block on one side: kClassBlock equal bytes, 4 per lane
-    const int8_t d = all == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE;
-    const uint32_t w4 = 0x01010101u * (uint32_t)(uint8_t)d;
-    constexpr int PB = kClassBlock / 64; // bytes per lane
-#pragma unroll
-    for (int q4 = 0; q4 < PB / 4; ++q4)
-    {
-      const int64_t c = cbase + 4 * (lane + 64 * q4);
-      if (c + 4 <= ncells && (reinterpret_cast<uintptr_t>(domain + c) & 3) == 0) *reinterpret_cast<uint32_t*>(domain + c) = w4;
-      else
-        for (int64_t q = c; q < c + 4 && q < ncells; ++q) domain[q] = d;
-    }
+    // every vertex of the block on one side
+    class_fill<kClassBlock>(domain, cbase, ncells, all == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE, lane);
     if (tiles_inside && all == 1u && lane == 0)
       atomicAdd(&tiles_inside[tile], (int32_t)(ncells - cbase < kClassBlock ? ncells - cbase : kClassBlock));
     return;
   }
-  // mixed block: cell by cell (classify_kernel)
-  int32_t d[U][ND];
+  // vertices on both sides (or on the interface): quarter by quarter, and only the quarters that are mixed themselves cell
+  // by cell (classify_kernel)
   int n_in = 0, n_cut = 0;
-#pragma unroll
-  for (int u = 0; u < U; ++u)
+  for (int sq = 0; sq < kClassSub; ++sq)
   {
-    const int64_t c = cbase + lane + (int64_t)u * 64;
-    if (c >= ncells) continue;
-    if constexpr (ND == 4)
+    const int64_t sbase = cbase + (int64_t)sq * SUB;
+    if (sbase >= ncells) break;
+    const unsigned sall = class_runs_and<kClassSubRuns, 4>(sub_runs + (b * kClassSub + sq) * kClassSubRuns, code, lane);
+    if (sall == 1u || sall == 2u)
     {
-      const int4 v = *reinterpret_cast<const int4*>(dofmap + c * 4);
-      d[u][0] = v.x; d[u][1] = v.y; d[u][2] = v.z; d[u][3] = v.w;
+      class_fill<SUB>(domain, sbase, ncells, sall == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE, lane);
+      if (sall == 1u && lane == 0) n_in += (int)(ncells - sbase < SUB ? ncells - sbase : SUB);
+      continue;
     }
-    else
+    int32_t d[U][ND];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
     {
+      const int64_t c = sbase + lane + (int64_t)u * 64;
+      if (c >= ncells) continue;
+      if constexpr (ND == 4)
+      {
+        const int4 v = *reinterpret_cast<const int4*>(dofmap + c * 4);
+        d[u][0] = v.x; d[u][1] = v.y; d[u][2] = v.z; d[u][3] = v.w;
+      }
+      else
+      {
 #pragma unroll
-      for (int i = 0; i < ND; ++i) d[u][i] = dofmap[c * ND + i];
+        for (int i = 0; i < ND; ++i) d[u][i] = dofmap[c * ND + i];
+      }
     }
-  }
 #pragma unroll
-  for (int u = 0; u < U; ++u)
-  {
-    const int64_t c = cbase + lane + (int64_t)u * 64;
-    if (c >= ncells) continue;
-    unsigned a = 3u;
+    for (int u = 0; u < U; ++u)
+    {
+      const int64_t c = sbase + lane + (int64_t)u * 64;
+      if (c >= ncells) continue;
+      unsigned a = 3u;
 #pragma unroll
-    for (int i = 0; i < ND; ++i) a &= code[d[u][i]];
-    domain[c] = a == 1u ? (int8_t)CFX_INSIDE : (a == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
-    n_in += a == 1u ? 1 : 0;
-    n_cut += (a != 1u && a != 2u) ? 1 : 0;
+      for (int i = 0; i < ND; ++i) a &= code[d[u][i]];
+      domain[c] = a == 1u ? (int8_t)CFX_INSIDE : (a == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+      n_in += a == 1u ? 1 : 0;
+      n_cut += (a != 1u && a != 2u) ? 1 : 0;
+    }
   }
   if (tiles_inside)
   {
@@ -2225,14 +2292,19 @@ void classify(cfx_cut_t cut)
         {
           mesh->class_nruns.alloc(nb);
           mesh->class_runs.alloc(nb * kClassRuns);
-          if (nd == 4) launch("classify_summary", class_summary_kernel<4>, dim3((unsigned)nb), dim3(kBlock), 0, nc, mesh->conn.p, mesh->class_nruns.p, mesh->class_runs.p);
-          else launch("classify_summary", class_summary_kernel<3>, dim3((unsigned)nb), dim3(kBlock), 0, nc, mesh->conn.p, mesh->class_nruns.p, mesh->class_runs.p);
+          mesh->class_sub_runs.alloc(nb * kClassSub * kClassSubRuns);
+          if (nd == 4)
+            launch("classify_summary", class_summary_kernel<4, kClassBlock, kClassRuns, 1024, 4096>, dim3((unsigned)nb), dim3(kBlock), 0,
+                   nc, mesh->conn.p, mesh->class_nruns.p, mesh->class_runs.p, mesh->class_sub_runs.p);
+          else
+            launch("classify_summary", class_summary_kernel<3, kClassBlock, kClassRuns, 1024, 4096>, dim3((unsigned)nb), dim3(kBlock), 0,
+                   nc, mesh->conn.p, mesh->class_nruns.p, mesh->class_runs.p, mesh->class_sub_runs.p);
           mesh->class_built = true;
           publish_across_lanes();
         }
         const dim3 cgrid((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64)));
-        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, mesh->class_nruns.p, mesh->class_runs.p, phi, dom, t_in, t_cut);
-        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, mesh->class_nruns.p, mesh->class_runs.p, phi, dom, t_in, t_cut);
+        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut);
+        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut);
         continue;
       }
     }

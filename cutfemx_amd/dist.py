@@ -60,15 +60,18 @@ def balanced_boundaries(weights, world: int):
     return bounds
 
 
-def sphere_layer_weights(n: int, active_weight: float = 14.0, cut_weight: float = 800.0):
+def sphere_layer_weights(n: int, active_weight: float = 26.0, cut_weight: float = 1550.0):
     """Cost model per hex layer for the sphere workload, in units of one background cell
-    (~6 ps on MI355X: classification, selector scans, mark arrays): an active (inside) cell costs
-    ~0.085 ns more of assembly (14), a cut cell ~5.6 ns of sub-triangulation, runtime quadrature,
-    local tensors and ghost-penalty facets (800) -- least-squares fit of the round-4 per-rank times
-    of the 1 / 2 / 4 / 8-rank partitions of the 512^3 case (bench.py projected_scaling), which also
-    gives a fixed ~0.58 ms per rank and step: ~60 kernel boundaries of ~10 us.  The surface of a sphere
+    (~3.5 ps on MI355X since the culled classification of round 4 -- selector scans, mark arrays, the
+    block-wise sign test): an active (inside) cell costs ~26 of them more for its assembly, a cut cell
+    ~1550 for sub-triangulation, runtime quadrature, local tensors and ghost-penalty facets -- picked by
+    tools/rank_balance.py on the 8- and 4-rank partitions of the 512^3 case (slowest rank 3.15 / 5.62 ms;
+    rounds 1-3 and the start of round 4 used 15 / 400 and 14 / 800 against a costlier background cell).  The surface of a sphere
     between two parallel planes is 2 pi R dz (Archimedes), so the cut cells are spread evenly
     over the layers that meet the sphere: ~4.7 cut tets per h^2 of surface."""
+    import os
+    if os.environ.get("CFX_SLAB_WEIGHTS"):       # "active,cut": refitting experiments (tools/rank_balance.py)
+        active_weight, cut_weight = (float(v) for v in os.environ["CFX_SLAB_WEIGHTS"].split(","))
     c, R = np.array([0.47, 0.43, 0.41]), 0.31
     z = (np.arange(n) + 0.5) / n
     r2 = np.maximum(R * R - (z - c[2]) ** 2, 0.0)           # radius^2 of the sphere's cross-section

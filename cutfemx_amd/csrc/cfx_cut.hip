@@ -399,6 +399,14 @@ template <int CELLS>
 __device__ __forceinline__ void class_fill(int8_t* __restrict__ domain, int64_t cbase, int64_t ncells, int8_t d, int lane)
 {
   const uint32_t w4 = 0x01010101u * (uint32_t)(uint8_t)d;
+  // 16 B per lane when the run is whole and aligned: one store instruction per 1024 cells.  (The kernel is not bound by
+  // its stores -- 0.78 -> 0.75 ms with every block uniform -- nor helped by a persistent grid with the next block's
+  // runs prefetched: 1.5 ms; 786 k short wavefronts live on how many of them are in flight.)
+  if (cbase + CELLS <= ncells && (reinterpret_cast<uintptr_t>(domain + cbase) & 15) == 0)
+  {
+    if (lane < CELLS / 16) reinterpret_cast<uint4*>(domain + cbase)[lane] = make_uint4(w4, w4, w4, w4);
+    return;
+  }
 #pragma unroll
   for (int q4 = 0; q4 < CELLS / 256; ++q4)
   {

@@ -419,7 +419,7 @@ __device__ __forceinline__ void class_fill(int8_t* __restrict__ domain, int64_t 
 
 // one wavefront per block of kClassBlock cells
 template <int ND>
-__global__ void __launch_bounds__(kBlock) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
+__global__ void __launch_bounds__(kBlock, 8) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
                                                                  const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
                                                                  const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
                                                                  int32_t* tiles_inside, int32_t* tiles_cut)

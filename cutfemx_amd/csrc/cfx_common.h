@@ -656,6 +656,9 @@ struct cfx_cut_s
   // inside / cut cells per compaction tile of level set 0, counted by the classification itself (empty: not available)
   cfx::DevArray<int32_t> tile_block; // both arrays in one block: one zero fill per classification
   cfx::DevArray<int32_t> tiles_inside, tiles_cut;
+  // per block of kClassBlock cells of level set 0: 1 all inside, 2 all outside, 0 mixed (written by the culled
+  // classification; empty when the cell-by-cell kernel ran): the selector scan skips what it names
+  cfx::DevArray<uint8_t> block_class;
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
   // facet hosts (cut(level_set, facets, tdim-1), cut.cpp:540-591): the hosts are n_hosts facets of the mesh;

@@ -422,7 +422,8 @@ template <int ND>
 __global__ void __launch_bounds__(kBlock, 8) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
                                                                  const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
                                                                  const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
-                                                                 int32_t* tiles_inside, int32_t* tiles_cut)
+                                                                 int32_t* tiles_inside, int32_t* tiles_cut,
+                                                                 uint8_t* __restrict__ block_class)
 {
   constexpr int SUB = kClassBlock / kClassSub, U = SUB / 64;
   static_assert(kByteTile % kClassBlock == 0, "classification blocks must nest in compaction tiles");
@@ -438,8 +439,10 @@ __global__ void __launch_bounds__(kBlock, 8) classify_culled_kernel(int64_t ncel
     class_fill<kClassBlock>(domain, cbase, ncells, all == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE, lane);
     if (tiles_inside && all == 1u && lane == 0)
       atomicAdd(&tiles_inside[tile], (int32_t)(ncells - cbase < kClassBlock ? ncells - cbase : kClassBlock));
+    if (block_class && lane == 0) block_class[b] = (uint8_t)all;
     return;
   }
+  if (block_class && lane == 0) block_class[b] = 0;
   // vertices on both sides (or on the interface): quarter by quarter, and only the quarters that are mixed themselves cell
   // by cell (classify_kernel)
   int n_in = 0, n_cut = 0;
@@ -2232,6 +2235,7 @@ static void tile_counters(cfx_cut_t cut, int64_t ntiles, bool zeroed_already)
 void classify(cfx_cut_t cut)
 {
   const int64_t nc = cut->nhosts();
+  cut->block_class.release(); // (set again by the culled classification of level set 0)
   for (int k = 0; k < cut->nls; ++k)
   {
     int8_t* dom = cut->domain.p + (int64_t)k * nc;
@@ -2311,8 +2315,10 @@ void classify(cfx_cut_t cut)
           publish_across_lanes();
         }
         const dim3 cgrid((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64)));
-        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut);
-        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut);
+        uint8_t* bclass = nullptr;
+        if (k == 0 && t_in != nullptr) { cut->block_class.alloc(nb); bclass = cut->block_class.p; }
+        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass);
+        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass);
         continue;
       }
     }
@@ -2341,17 +2347,36 @@ __global__ void __launch_bounds__(kBlock) locate_inside_cut_kernel(int64_t n, co
                                                                    const int64_t* __restrict__ off_in,
                                                                    const int64_t* __restrict__ off_cut,
                                                                    int32_t* __restrict__ out_in, int32_t* __restrict__ out_cut,
-                                                                   DevN n_in_d, DevN n_cut_d)
+                                                                   DevN n_in_d, DevN n_cut_d, const uint8_t* __restrict__ block_class)
 {
   // (lists sized by the previous step: nothing is written when a total did not fit -- dev_n is 0 in a void step)
   const int64_t n_in = dev_n(n_in_d), n_cut = dev_n(n_cut_d);
   const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
   unsigned f_in = 0, f_cut = 0;
-  if (base < n)
+  // what the culled classification knows about whole blocks of kClassBlock cells saves the bytes of the uniform ones:
+  // a tile of outside blocks (two thirds of the 512^3 mesh) is left at once, an inside block lists its cells unread
+  unsigned cls = 0;
+  if (block_class)
+  {
+    constexpr int BPT = kByteTile / kClassBlock;
+    const int64_t nblocks = (n + kClassBlock - 1) / kClassBlock;
+    unsigned tile_all = 3u;
+#pragma unroll
+    for (int j = 0; j < BPT; ++j)
+    {
+      const int64_t bj = (int64_t)blockIdx.x * BPT + j;
+      tile_all &= bj < nblocks ? (unsigned)block_class[bj] : 2u;
+    }
+    if (tile_all == 2u) return;
+    cls = base < n ? (unsigned)block_class[base / kClassBlock] : 2u;
+  }
+  if (base < n && cls == 0u)
   {
     f_in = byte_flags(bytes, base, n, DomainMask{1});
     f_cut = byte_flags(bytes, base, n, DomainMask{2});
   }
+  else if (base < n && cls == 1u)
+    f_in = base + kByteItems <= n ? 0xffffu : ((1u << (int)(n - base)) - 1u);
   // the inside cells (the dense list) are packed in LDS and stored as one coalesced run per tile; the few cut
   // cells go out directly
   __shared__ int32_t s_in[kByteTile];
@@ -2399,7 +2424,8 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
       DevArray<int32_t> l_in(cnt[0].cap()), l_cut(cnt[1].cap());
       l_in.count = cnt[0]; l_cut.count = cnt[1];
       launch("locate_entities", locate_inside_cut_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nh, bytes, off_in.p,
-             off_cut.p, l_in.p, l_cut.p, l_in.devn(), l_cut.devn());
+             off_cut.p, l_in.p, l_cut.p, l_in.devn(), l_cut.devn(),
+             cut->block_class.n == (nh + kClassBlock - 1) / kClassBlock ? (const uint8_t*)cut->block_class.p : (const uint8_t*)nullptr);
       list_register(l_in.p, l_in.count);
       list_register(l_cut.p, l_cut.count);
       cut->located.emplace("phi<0", std::move(l_in));

@@ -1726,7 +1726,8 @@ int cfx_space_static_bytes(cfx_space_t V, int64_t bytes[4])
   const cfx::VecBlocks& B = V->vblocks;
   bytes[2] = 8 * S.tile_voff.n + 4 * S.tile_verts.n + 2 * S.st_loc.n
              + 8 * B.u_off.n + 2 * B.slot.n + 2 * B.seg.n + 8 * B.p_off.n + 8 * B.p_pos.n; // (+ the cell blocks of the linear forms)
-  bytes[3] = V->mesh->c2c_built ? 4 * V->mesh->c2c.n : 0;
+  bytes[3] = (V->mesh->c2c_built ? 4 * V->mesh->c2c.n : 0)
+             + (V->mesh->class_built ? 4 * V->mesh->class_nruns.n + 8 * (V->mesh->class_runs.n + V->mesh->class_sub_runs.n) : 0); // (+ the vertex runs of the culled classification)
   CFX_API_END
 }
 

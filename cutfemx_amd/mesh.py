@@ -200,6 +200,7 @@ class FunctionSpace:
         """HBM held by the mesh-static tables built by the first assembly on this space (cfx_space_static_bytes)."""
         b = (C.c_int64 * 4)()
         _lib.check(_lib.lib().cfx_space_static_bytes(self._h, b))
+        # (cell_neighbours: the cell -> cell table + the vertex runs of the culled classification, both the mesh's)
         return dict(dof_cells=int(b[0]), row_stencil=int(b[1]), row_tiles=int(b[2]), cell_neighbours=int(b[3]))
 
     @property

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -266,7 +267,20 @@ void count_sites(int n, const char* const* names, const CountSource* src, Count*
 // The same in two phases around the scan that produces the totals: inside a speculative step the scan's last thread
 // publishes them itself (no publish launch); otherwise finish() reads them back after the scan.
 //   CountPlan cp(n, names, src);  exclusive_scan(in, out, len, &cp);  cp.finish(counts);
-struct CountJobs;
+constexpr int kMaxCountJobs = 6;
+struct CountJobs
+{
+  int64_t* pool;   // the count pool; n_slots: slots handed out so far in this step (what a void step zeroes)
+  int n_slots;
+  int n;
+  const void* src[kMaxCountJobs];
+  int kind[kMaxCountJobs];
+  int mode[kMaxCountJobs];
+  const int64_t* plus[kMaxCountJobs];
+  int64_t add[kMaxCountJobs];
+  int64_t cap[kMaxCountJobs];
+  int slot[kMaxCountJobs];
+};
 struct CountPlan
 {
   int n = 0;
@@ -277,7 +291,50 @@ struct CountPlan
   std::shared_ptr<CountJobs> jobs;   // publish mode: what the publishing thread does
   CountPlan(int n, const char* const* names, const CountSource* src);
   void finish(Count* out);
+  // publish mode, for a kernel of the caller's that writes the totals itself (its last thread then runs count_publish):
+  // the jobs to hand to it; finish() then launches nothing and may be called BEFORE that kernel to get the capacities
+  CountJobs take_jobs() { fused = true; return *jobs; }
 };
+#if defined(__HIPCC__)
+__device__ __forceinline__ int64_t count_read(const void* src, int kind)
+{
+  int64_t v;
+  if (src == nullptr) return 0;
+  if (kind == kCountI32) v = *static_cast<const int32_t*>(src);
+  else
+  {
+    v = *static_cast<const int64_t*>(src);
+    if (kind == kCountPackedLo) v &= (1ll << kCountPackShift) - 1;
+    else if (kind == kCountPackedHi) v >>= kCountPackShift;
+    else if (kind == kCountLo32) v &= 0xffffffffll;
+    else if (kind == kCountHi32) v >>= 32;
+    else if (kind == kCountSum32) v = (v & 0xffffffffll) + (v >> 32);
+  }
+  return v;
+}
+// speculative step: raw total next to the published one; a total beyond its capacity poisons the step
+// Run by ONE thread.  A total beyond its capacity (or a must-equal word that differs) voids the step: the poison word is
+// set and EVERY published length of the pool becomes 0, so that each kernel launched from now on -- whatever list drives
+// it -- sees length 0 with the one load of dev_n; lengths published later in the void step are published as 0.
+__device__ __forceinline__ void count_publish(const CountJobs& J)
+{
+  int64_t* pool = J.pool;
+  bool void_step = pool[0] != 0;
+  int64_t raw[kMaxCountJobs];
+  for (int k = 0; k < J.n; ++k)
+  {
+    raw[k] = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
+    pool[2 * J.slot[k] + 1] = raw[k];
+    void_step = void_step || (J.mode[k] == kCountMustEqual ? raw[k] != J.cap[k] : raw[k] > J.cap[k]);
+  }
+  for (int k = 0; k < J.n; ++k) pool[2 * J.slot[k]] = void_step ? 0 : raw[k];
+  if (void_step)
+  {
+    pool[0] = 1;
+    for (int e = kCountFirstSlot; e < J.n_slots; ++e) pool[2 * e] = 0;
+  }
+}
+#endif
 inline Count count_site(const char* name, const void* src, int kind = kCountI64, int mode = kCountUpTo)
 {
   CountSource s{src, kind, mode};

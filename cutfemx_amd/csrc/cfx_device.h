@@ -106,6 +106,110 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T& total)
 }
 
 // ---------------------------------------------------------------------------
+// Chained tiles: the exclusive prefix of a per-tile total over the tiles of ONE launch (single-pass scans, and
+// count + offset + write kernels that would otherwise be three launches around a scan of the tile totals).
+// A tile takes its number from an atomic ticket when its block starts, so every predecessor it waits for is already
+// resident and makes progress.  Tile state = one 64-bit word (2-bit flag | 62-bit value) exchanged with agent-scope
+// atomics: the L2s of the eight XCDs are not coherent with each other for plain loads.  `state` holds one zeroed word
+// per tile, `ticket` one zeroed counter (cfx::chain_state hands out both).
+// ---------------------------------------------------------------------------
+constexpr int kChainLook = 4;
+constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1ull;
+
+struct ChainState
+{
+  unsigned long long* state = nullptr;
+  unsigned int* ticket = nullptr;
+};
+// zeroed state words for `ntiles` tiles + the ticket, from a pool that is cleared with one fill when it wraps; state ==
+// nullptr when ntiles is beyond what the pool serves (the caller keeps its multi-launch form); cfx_runtime.hip
+ChainState chain_state(int64_t ntiles);
+// count + offsets + write kernels of a sync-free step as ONE chained launch each, up to CFX_FUSED_TILES tiles (0: never;
+// the three launches around a scan of the tile totals, as outside a step).  Longer lists keep the passes that never
+// wait on each other.  Measured on MI355X (ticket on one address + look-back): ~13 ns per tile on top of the work, so
+// the two launch boundaries saved (~10 us each) are spent at ~1500 tiles; break-even was seen at 128^3 (500 - 1000
+// tiles per site), 32^3 gains 0.03 of 0.48 ms.  Groups of 8 tiles per ticket were tried: slower at every size (few
+// workgroups walking their tiles one after the other).
+inline ChainState fused_chain(bool publish, int64_t ntiles)
+{
+  static const int64_t max_tiles = []() { const char* e = getenv("CFX_FUSED_TILES"); return e ? atoll(e) : (int64_t)512; }();
+  return publish && ntiles <= max_tiles ? chain_state(ntiles) : ChainState{};
+}
+
+// all threads of the block: the number of this block's tile
+__device__ __forceinline__ unsigned int chain_take_tile(unsigned int* __restrict__ ticket)
+{
+  __shared__ unsigned int s_tile;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+  __syncthreads();
+  return s_tile;
+}
+
+// all threads of the block (>= 64 threads), `total` block-uniform: sum of the totals of the tiles before `tile`
+__device__ __forceinline__ unsigned long long chain_exclusive_prefix(unsigned long long* __restrict__ state,
+                                                                     const unsigned int tile, const unsigned long long total)
+{
+  __shared__ unsigned long long s_prefix;
+  if (threadIdx.x < 64)
+  {
+    const int lane = threadIdx.x;
+    unsigned long long prefix = 0;
+    if (tile == 0)
+    {
+      if (lane == 0)
+        __hip_atomic_store(&state[0], kScanPrefix | (total & kScanValueMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    else
+    {
+      if (lane == 0)
+        __hip_atomic_store(&state[tile], kScanAggregate | (total & kScanValueMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      // look back kChainLook x 64 tiles per round trip (the loads of a round are in flight together: the front of
+      // complete prefixes moves that many tiles per memory latency) until a tile with a complete prefix is found
+      int64_t hi = (int64_t)tile - 1;
+      unsigned long long acc = 0; // per lane; summed over the wave at the end
+      bool found = false;
+      while (!found)
+      {
+        unsigned long long w[kChainLook];
+#pragma unroll
+        for (int q = 0; q < kChainLook; ++q)
+        {
+          const int64_t p = hi - lane - 64 * q;
+          w[q] = kScanPrefix; // tiles before the first: prefix 0
+          if (p >= 0) w[q] = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < kChainLook; ++q)
+        {
+          const int64_t p = hi - lane - 64 * q;
+          while ((w[q] >> 62) == 0ull) w[q] = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int q = 0; q < kChainLook; ++q)
+        {
+          if (found) break;
+          const unsigned long long done = __ballot((w[q] >> 62) == 2ull);
+          const int first = done ? __ffsll((long long)done) - 1 : 64; // nearest tile whose prefix is complete
+          acc += (lane <= first) ? (w[q] & kScanValueMask) : 0ull;
+          found = done != 0ull;
+        }
+        hi -= 64 * kChainLook;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      prefix = acc;
+      if (lane == 0)
+        __hip_atomic_store(&state[tile], kScanPrefix | ((prefix + total) & kScanValueMask), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  return s_prefix;
+}
+
+// ---------------------------------------------------------------------------
 // stream compaction: indices i in [0,n) with pred(i), ascending.
 // Three launches: per-tile counts, scan, per-tile write.
 // ---------------------------------------------------------------------------
@@ -206,26 +310,77 @@ __global__ void __launch_bounds__(kBlock) compact_write_n_kernel(DevN n_d, Pred 
     if (f[k]) { if (o < cap) out[o] = (int32_t)(base + k); ++o; }
 }
 
-template <typename Pred>
-inline Count compact_count(const char* name, const char* site, DevN n, Pred pred, DevArray<int32_t>& out)
+// count + offsets + write in ONE launch (tiles chained by look-back): inside a sync-free step, where `out` is sized by the
+// previous step's total before anything is counted.  emit(o, i): what else the caller derives from hit i at position o.
+struct NoEmit
+{
+  __device__ void operator()(int64_t, int64_t) const {}
+};
+template <typename Pred, typename Emit>
+__global__ void __launch_bounds__(kBlock) compact_chained_kernel(DevN n_d, Pred pred, Emit emit, int32_t* __restrict__ out,
+                                                                 int64_t cap, ChainState chain,
+                                                                 int64_t* __restrict__ total_out, CountJobs after)
+{
+  const int64_t n = dev_n(n_d);
+  const unsigned int tile = chain_take_tile(chain.ticket);
+  const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kScanItems;
+  bool f[kScanItems];
+  int c = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + k;
+    f[k] = (i < n) && pred(i);
+    c += f[k] ? 1 : 0;
+  }
+  int total;
+  const int off = block_exclusive_scan<int>(c, total);
+  const int64_t prefix = (int64_t)chain_exclusive_prefix(chain.state, tile, (unsigned long long)total);
+  int64_t o = prefix + off;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (f[k]) { if (o < cap) { out[o] = (int32_t)(base + k); emit(o, base + k); } ++o; }
+  if (tile == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+  {
+    *total_out = prefix + total;
+    if (after.n > 0) count_publish(after);
+  }
+}
+
+// `pre(capacity)`: called once the capacity of `out` is known and before the write pass (allocates what emit writes to)
+template <typename Pred, typename Emit = NoEmit>
+inline Count compact_count(const char* name, const char* site, DevN n, Pred pred, DevArray<int32_t>& out,
+                           Emit* emit = nullptr, const std::function<void(int64_t)>& pre = nullptr)
 {
   const int64_t ntiles = (n.cap + kTile - 1) / kTile;
   if (ntiles == 0)
   {
     out.alloc(0);
     step_record(site, 0);
+    if (pre) pre(0);
     return Count(0);
   }
-  DevArray<int32_t> counts(ntiles);
+  DevArray<int32_t> counts;
   DevArray<int64_t> offsets(ntiles + 1);
-  launch(name, compact_count_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, counts.p);
   Count total;
+  const CountSource src{offsets.p + ntiles, kCountI64, kCountUpTo};
+  CountPlan cp(1, &site, &src);
+  const ChainState chain = fused_chain(cp.publish, ntiles);
+  if (chain.state)
   {
-    const CountSource src{offsets.p + ntiles, kCountI64, kCountUpTo};
-    CountPlan cp(1, &site, &src);
-    exclusive_scan(counts.p, offsets.p, ntiles, &cp);
+    const CountJobs after = cp.take_jobs();
     cp.finish(&total);
+    out.alloc(total.cap());
+    out.count = total;
+    if (pre) pre(total.cap());
+    launch(name, compact_chained_kernel<Pred, Emit>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, emit ? *emit : Emit{},
+           out.p, total.cap(), chain, offsets.p + ntiles, after);
+    return total;
   }
+  counts.alloc(ntiles);
+  launch(name, compact_count_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, counts.p);
+  exclusive_scan(counts.p, offsets.p, ntiles, &cp);
+  cp.finish(&total);
   out.alloc(total.cap());
   if (total.cell) out.count = total;
   launch(name, compact_write_n_kernel<Pred>, dim3((unsigned)ntiles), dim3(kBlock), 0, n, pred, offsets.p, out.p, total.devn());

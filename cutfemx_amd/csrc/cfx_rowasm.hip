@@ -820,16 +820,16 @@ __global__ void __launch_bounds__(kBlock) indptr_reduce_kernel(int64_t nrows, in
   if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
 
-__global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
-                                                              const int32_t* __restrict__ counts,
-                                                              const int64_t* __restrict__ tile_offsets,
-                                                              int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
-                                                              DevN nnz_d)
+// one tile of kTile rows: indptr, and the diagonal entries of its inactive rows.  first(total): the tile's first entry,
+// asked once the tile's own entries are summed (all threads call it: a table look-up, or the look-back of a chained
+// launch).  Returns first + total (all threads).  Nothing is written to `indices` at or beyond nnz_cap.
+template <typename First>
+__device__ __forceinline__ int64_t indptr_tile(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                               const int32_t* __restrict__ counts, const int64_t tile, First first,
+                                               int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                               const int64_t nnz_cap)
 {
-  // (indices sized by the previous step's nnz: nothing is written beyond the published total -- 0 in a void step)
-  const int64_t nnz_cap = nnz_d.dev ? dev_n(nnz_d) : INT64_MAX;
   __shared__ int64_t s_v[kTile];
-  const int64_t tile = (int64_t)blockIdx.x * kTile;
   // A whole tile of inactive rows of a scalar space (87 % of the rows at 512^3): indptr is an arithmetic progression and
   // the diagonal entries are the row numbers -- eight rows per thread as 16 B stores, no marks gathered row by row, no
   // LDS scan.
@@ -839,7 +839,8 @@ __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int
     const uint2 m = *reinterpret_cast<const uint2*>(rowmark + tile + 8 * threadIdx.x); // (tile and 8 t: 8 B aligned)
     if (__syncthreads_or((m.x | m.y) != 0u) == 0)
     {
-      const int64_t p0 = tile_offsets[blockIdx.x] + 8 * threadIdx.x;
+      const int64_t t0 = first((int64_t)kTile);
+      const int64_t p0 = t0 + 8 * threadIdx.x;
       const int64_t r0 = tile + 8 * threadIdx.x;
       if ((reinterpret_cast<uintptr_t>(indptr + r0) & 15) == 0)
       {
@@ -862,8 +863,7 @@ __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int
         for (int q = 0; q < 8; ++q)
           if (p0 + q + 1 <= nnz_cap) indices[p0 + q] = (int32_t)(r0 + q);
       }
-      if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) indptr[nrows] = tile_offsets[blockIdx.x] + kTile;
-      return;
+      return t0 + kTile;
     }
   }
 #pragma unroll
@@ -878,7 +878,9 @@ __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) { v[k] = s_v[threadIdx.x * kScanItems + k]; s += v[k]; }
   int64_t total;
-  int64_t off = block_exclusive_scan<int64_t>(s, total) + tile_offsets[blockIdx.x];
+  const int64_t local = block_exclusive_scan<int64_t>(s, total);
+  const int64_t t0 = first(total);
+  int64_t off = local + t0;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k) { s_v[threadIdx.x * kScanItems + k] = off; off += v[k]; }
   __syncthreads();
@@ -894,7 +896,42 @@ __global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int
     if (!rowmark[dof] && p + bs <= nnz_cap)
       for (int b = 0; b < bs; ++b) indices[p + b] = (int32_t)(dof * bs + b);
   }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) indptr[nrows] = tile_offsets[blockIdx.x] + total;
+  return t0 + total;
+}
+
+__global__ void __launch_bounds__(kBlock) indptr_write_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                                              const int32_t* __restrict__ counts,
+                                                              const int64_t* __restrict__ tile_offsets,
+                                                              int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                              DevN nnz_d)
+{
+  // (indices sized by the previous step's nnz: nothing is written beyond the published total -- 0 in a void step)
+  const int64_t nnz_cap = nnz_d.dev ? dev_n(nnz_d) : INT64_MAX;
+  const int64_t end = indptr_tile(nrows, bs, rowmark, counts, (int64_t)blockIdx.x * kTile,
+                                  [&](int64_t) { return tile_offsets[blockIdx.x]; }, indptr, indices, nnz_cap);
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) indptr[nrows] = end;
+}
+
+// reduce, offsets and write in ONE launch (tiles chained by look-back, cfx_device.h) -- inside a sync-free step, where
+// `indices` is sized by the previous step's nnz before the rows are summed.  The last tile leaves nnz in `total_out` and
+// publishes the step's counts; nothing is written beyond the capacity of `indices`, and a total beyond it voids the
+// step there.
+__global__ void __launch_bounds__(kBlock) indptr_chained_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
+                                                                const int32_t* __restrict__ counts,
+                                                                int64_t* __restrict__ indptr, int32_t* __restrict__ indices,
+                                                                int64_t nnz_cap, ChainState chain,
+                                                                int64_t* __restrict__ total_out, CountJobs after)
+{
+  const unsigned int tile = chain_take_tile(chain.ticket);
+  const int64_t end = indptr_tile(nrows, bs, rowmark, counts, (int64_t)tile * kTile,
+                                  [&](int64_t total) { return (int64_t)chain_exclusive_prefix(chain.state, tile, (unsigned long long)total); },
+                                  indptr, indices, nnz_cap);
+  if (tile == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+  {
+    indptr[nrows] = end;
+    *total_out = end;
+    if (after.n > 0) count_publish(after);
+  }
 }
 
 template <int T>
@@ -1007,28 +1044,17 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_count_kernel(int64_t n,
   if (threadIdx.x == 0) tile_counts[blockIdx.x] = (int64_t)tot_s | ((int64_t)tot_p << 32);
 }
 
-__global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n, const uint8_t* __restrict__ rowmark,
-                                                                      const uint8_t* __restrict__ special,
-                                                                      const int64_t* __restrict__ tile_offsets,
-                                                                      int32_t* __restrict__ active,
-                                                                      int32_t* __restrict__ special_rows,
-                                                                      int32_t* __restrict__ plain_rows, DevN n_special_d,
-                                                                      DevN n_plain_d, int32_t* __restrict__ special_pos,
-                                                                      int32_t* __restrict__ zero_counts, int64_t zero_n)
+// one tile of kByteTile dofs: its part of the three lists, nothing at or beyond the capacities.  first(mine): where the
+// tile's lists start (special | plain << 32), asked once the tile's own packed counts are known (all threads call it: a
+// table look-up, or the look-back of a chained launch).  Returns first + mine (all threads).
+template <typename First>
+__device__ __forceinline__ int64_t row_lists_tile(int64_t n, const uint8_t* __restrict__ rowmark,
+                                                  const uint8_t* __restrict__ special, const int64_t tile, First first,
+                                                  int32_t* __restrict__ active, int32_t* __restrict__ special_rows,
+                                                  int32_t* __restrict__ plain_rows, const int64_t cap_s, const int64_t cap_p,
+                                                  int32_t* __restrict__ special_pos)
 {
-  // (lists sized by the previous step: nothing is written beyond their published lengths -- 0 in a void step)
-  const int64_t cap_s = n_special_d.dev ? dev_n(n_special_d) : INT64_MAX, cap_p = n_plain_d.dev ? dev_n(n_plain_d) : INT64_MAX;
-  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * kByteItems;
-  if (zero_counts)
-  {
-    // the counters of the dof -> facets incidence (one per special row, capacity zero_n <= about the dofs): zeroed
-    // here, a launch less than a fill of their own
-#pragma unroll
-    for (int k = 0; k < kByteItems; ++k)
-      if (base + k < zero_n) zero_counts[base + k] = 0;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1)
-      for (int64_t i = (int64_t)gridDim.x * kBlock * kByteItems; i < zero_n; ++i) zero_counts[i] = 0;
-  }
+  const int64_t base = (tile * kBlock + threadIdx.x) * kByteItems;
   unsigned fa = 0, fs = 0;
   if (base < n)
   {
@@ -1036,10 +1062,11 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
     fs = byte_flags(special, base, n, ByteNonZero{}) & fa;
   }
   const unsigned fp = fa & ~fs;
-  int tot;
-  const int os = block_exclusive_scan<int>(__popc(fs), tot);
-  const int op = block_exclusive_scan<int>(__popc(fp), tot);
-  const int64_t t = tile_offsets[blockIdx.x];
+  int tot_s, tot_p;
+  const int os = block_exclusive_scan<int>(__popc(fs), tot_s);
+  const int op = block_exclusive_scan<int>(__popc(fp), tot_p);
+  const int64_t mine = (int64_t)tot_s | ((int64_t)tot_p << 32);
+  const int64_t t = first(mine);
   int64_t s = (t & 0xffffffffll) + os, p = (t >> 32) + op;
 #pragma unroll
   for (int k = 0; k < kByteItems; ++k)
@@ -1052,6 +1079,65 @@ __global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n,
       ++s;
     }
     else if (fp & (1u << k)) { if (p < cap_p && s <= cap_s) { active[s + p] = row; if (plain_rows) plain_rows[p] = row; } ++p; }
+  }
+  return t + mine;
+}
+
+// the counters of the dof -> facets incidence (one per special row, capacity zero_n <= about the dofs): zeroed by the
+// kernel that writes the row lists, a launch less than a fill of their own
+__device__ __forceinline__ void row_lists_zero(int32_t* __restrict__ zero_counts, int64_t zero_n, int64_t tile)
+{
+  const int64_t base = (tile * kBlock + threadIdx.x) * kByteItems;
+#pragma unroll
+  for (int k = 0; k < kByteItems; ++k)
+    if (base + k < zero_n) zero_counts[base + k] = 0;
+  if (tile == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+    for (int64_t i = (int64_t)gridDim.x * kBlock * kByteItems; i < zero_n; ++i) zero_counts[i] = 0;
+}
+
+__global__ void __launch_bounds__(kBlock) plan_row_lists_write_kernel(int64_t n, const uint8_t* __restrict__ rowmark,
+                                                                      const uint8_t* __restrict__ special,
+                                                                      const int64_t* __restrict__ tile_offsets,
+                                                                      int32_t* __restrict__ active,
+                                                                      int32_t* __restrict__ special_rows,
+                                                                      int32_t* __restrict__ plain_rows, DevN n_special_d,
+                                                                      DevN n_plain_d, int32_t* __restrict__ special_pos,
+                                                                      int32_t* __restrict__ zero_counts, int64_t zero_n)
+{
+  // (lists sized by the previous step: nothing is written beyond their published lengths -- 0 in a void step)
+  const int64_t cap_s = n_special_d.dev ? dev_n(n_special_d) : INT64_MAX, cap_p = n_plain_d.dev ? dev_n(n_plain_d) : INT64_MAX;
+  if (zero_counts) row_lists_zero(zero_counts, zero_n, blockIdx.x);
+  (void)row_lists_tile(n, rowmark, special, blockIdx.x, [&](int64_t) { return tile_offsets[blockIdx.x]; }, active,
+                       special_rows, plain_rows, cap_s, cap_p, special_pos);
+}
+
+// count, offsets and lists in ONE launch (tiles chained by look-back, cfx_device.h) -- inside a sync-free step, where the
+// lists are sized by the previous step before anything is counted.  The per-tile counts go to `tile_counts` as
+// plan_row_lists_count_kernel leaves them; the last tile leaves the packed totals in `total_out` and publishes the step's
+// counts; nothing is written beyond the capacities, and a total beyond them voids the step there.
+__global__ void __launch_bounds__(kBlock) plan_row_lists_chained_kernel(int64_t n, const uint8_t* __restrict__ rowmark,
+                                                                        const uint8_t* __restrict__ special,
+                                                                        int32_t* __restrict__ active,
+                                                                        int32_t* __restrict__ special_rows,
+                                                                        int32_t* __restrict__ plain_rows, int64_t cap_s,
+                                                                        int64_t cap_p, int32_t* __restrict__ special_pos,
+                                                                        int32_t* __restrict__ zero_counts, int64_t zero_n,
+                                                                        ChainState chain, int64_t* __restrict__ tile_counts,
+                                                                        int64_t* __restrict__ total_out, CountJobs after)
+{
+  const unsigned int tile = chain_take_tile(chain.ticket);
+  if (zero_counts) row_lists_zero(zero_counts, zero_n, tile);
+  const int64_t end = row_lists_tile(n, rowmark, special, tile,
+                                     [&](int64_t mine)
+                                     {
+                                       if (threadIdx.x == 0) tile_counts[tile] = mine;
+                                       return (int64_t)chain_exclusive_prefix(chain.state, tile, (unsigned long long)mine);
+                                     },
+                                     active, special_rows, plain_rows, cap_s, cap_p, special_pos);
+  if (tile == gridDim.x - 1 && threadIdx.x == 0)
+  {
+    *total_out = end;
+    if (after.n > 0) count_publish(after);
   }
 }
 
@@ -1331,6 +1417,13 @@ struct TileStart
 {
   const int32_t* rows;
   __device__ bool operator()(int64_t i) const { return i == 0 || (rows[i] / kRowTile) != (rows[i - 1] / kRowTile); }
+};
+
+struct TileIdEmit
+{
+  const int32_t* rows;
+  int32_t* ids;
+  __device__ void operator()(int64_t o, int64_t i) const { ids[o] = rows[i] / kRowTile; }
 };
 
 __global__ void tile_ids_kernel(DevN n_d, const int32_t* __restrict__ first, const int32_t* __restrict__ rows,
@@ -1829,8 +1922,6 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   {
     const int64_t ntiles = (V->ndofs + kByteTile - 1) / kByteTile;
     DevArray<int64_t> tcounts(ntiles), toffs(ntiles + 1);
-    launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
-           special.p, tcounts.p);
     // the row totals and the plan's flag word (every kernel that sets a flag has been launched) in one read-back --
     // or, inside a step, left in HBM: the flag word (what the host branches on) must then repeat the last step's
     const char* names[4] = {"plan.special_rows", "plan.plain_rows", "plan.active_rows", "plan.flags"};
@@ -1841,7 +1932,16 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     src[3].src = flag.p; src[3].kind = kCountI32; src[3].mode = kCountMustEqual;
     Count tot[4];
     CountPlan cp(4, names, src);
-    exclusive_scan(tcounts.p, toffs.p, ntiles, &cp);
+    // inside a step the capacities are known before anything is counted: count + offsets + lists in one chained launch
+    const ChainState chain = fused_chain(cp.publish, ntiles);
+    CountJobs after{};
+    if (chain.state) after = cp.take_jobs();
+    else
+    {
+      launch("plan_row_lists", plan_row_lists_count_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
+             special.p, tcounts.p);
+      exclusive_scan(tcounts.p, toffs.p, ntiles, &cp);
+    }
     cp.finish(tot);
     plan_flags = (int)tot[3].cap();
     const bool want_plain = space_stencil(V).lists;
@@ -1858,9 +1958,16 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     if (want_plain) P.plain_rows.alloc(tot[1].cap());
     if (nf_cap > 0) P.special_pos.alloc(V->ndofs);
     if (nf_cap > 0 && !facets_by_sort) fcount.alloc(tot[0].cap());
-    launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs, P.rowmark.p,
-           special.p, toffs.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr,
-           tot[0].devn(), tot[1].devn(), nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr, fcount.p, fcount.n);
+    if (chain.state)
+      launch("plan_row_lists", plan_row_lists_chained_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs,
+             P.rowmark.p, special.p, P.active_rows.p, P.special_rows.p, want_plain ? P.plain_rows.p : (int32_t*)nullptr,
+             tot[0].cap(), tot[1].cap(), nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr, fcount.p, fcount.n, chain,
+             tcounts.p, toffs.p + ntiles, after);
+    else
+      launch("plan_row_lists", plan_row_lists_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, V->ndofs,
+             P.rowmark.p, special.p, toffs.p, P.active_rows.p, P.special_rows.p,
+             want_plain ? P.plain_rows.p : (int32_t*)nullptr, tot[0].devn(), tot[1].devn(),
+             nf_cap > 0 ? P.special_pos.p : (int32_t*)nullptr, fcount.p, fcount.n);
     P.row_tile_counts = std::move(tcounts); // the inactive dofs of a tile are the rest (cfx_active_domain)
   }
   P.special_mark = std::move(special);
@@ -2144,14 +2251,21 @@ bool plain_row_masks(cfx_form_s* a, int32_t* counts, int* maxlen)
          st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p, counts, maxlen);
   if (space_stencil_tiles(V).tiles_usable)
   {
-    // work list of the tile kernels: one entry per row tile that holds a plain row
+    // work list of the tile kernels: one entry per row tile that holds a plain row (inside a step: positions and tile
+    // numbers from one chained launch; else the numbers follow the compaction's read-back)
     DevArray<int32_t> first;
+    TileIdEmit emit{plan.plain_rows.p, nullptr};
+    bool emitted = false;
+    auto pre = [&](int64_t cap) { plan.plain_tile_id.alloc(cap); emit.ids = plan.plain_tile_id.p; emitted = true; };
     plan.n_plain_tiles = compact_count("plan_plain_tiles", "plan.plain_tiles", plan.n_plain_rows.devn(),
-                                       TileStart{plan.plain_rows.p}, first);
+                                       TileStart{plan.plain_rows.p}, first, &emit, pre);
     plan.plain_tile_first = std::move(first);
-    plan.plain_tile_id.alloc(plan.n_plain_tiles.cap());
-    launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles.cap()), dim3(kBlock), 0, plan.n_plain_tiles,
-           plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
+    if (!emitted)
+    {
+      plan.plain_tile_id.alloc(plan.n_plain_tiles.cap());
+      launch("plan_plain_tiles", tile_ids_kernel, grid_for(plan.n_plain_tiles.cap()), dim3(kBlock), 0, plan.n_plain_tiles,
+             plan.plain_tile_first.p, plan.plain_rows.p, plan.plain_tile_id.p);
+    }
   }
   publish_across_lanes(); // the masks belong to the plan, which the other lane's form may share
   return counts != nullptr;
@@ -2231,6 +2345,50 @@ __global__ void vec_plain_scatter_kernel(DevN n_plain_d, const int32_t* __restri
 }
 
 
+// the two kernels above and the scan between them in ONE launch (tiles chained by look-back, cfx_device.h): inside a
+// sync-free step, where nothing is sized by the totals before they are published.  Eight consecutive plain rows per thread.
+__global__ void __launch_bounds__(kBlock) vec_plain_offsets_chained_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
+                                                                           const int64_t* __restrict__ d2c_off,
+                                                                           const uint8_t* __restrict__ uniform, uint8_t mark,
+                                                                           int32_t* __restrict__ t2off, ChainState chain,
+                                                                           int64_t* __restrict__ total_out, CountJobs after)
+{
+  const int64_t n_plain = dev_n(n_plain_d);
+  const unsigned int tile = chain_take_tile(chain.ticket);
+  const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kScanItems;
+  int32_t r[kScanItems];
+  int64_t l[kScanItems], s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    const int64_t i = base + k;
+    r[k] = 0; l[k] = 0;
+    if (i < n_plain)
+    {
+      r[k] = rows[i];
+      const int64_t len = uniform[i] == mark ? d2c_off[(int64_t)r[k] + 1] - d2c_off[r[k]] : 0;
+      l[k] = len > 0 ? len : (1ll << 32);
+    }
+    s += l[k];
+  }
+  int64_t total;
+  const int64_t local = block_exclusive_scan<int64_t>(s, total);
+  const int64_t prefix = (int64_t)chain_exclusive_prefix(chain.state, tile, (unsigned long long)total);
+  int64_t off = prefix + local;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+  {
+    // (entries in the low 32 bits of the packed prefix)
+    if ((l[k] & 0xffffffffll) > 0) t2off[r[k]] = (int32_t)(off & 0xffffffffll) + 1;
+    off += l[k];
+  }
+  if (tile == gridDim.x - 1 && threadIdx.x == kBlock - 1)
+  {
+    *total_out = prefix + total;
+    if (after.n > 0) count_publish(after);
+  }
+}
+
 __global__ void gather_i32_kernel(DevN n_d, const int32_t* __restrict__ idx, const int32_t* __restrict__ src,
                                   int32_t* __restrict__ dst)
 {
@@ -2257,21 +2415,30 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
   plain_row_masks(L);
   if (plan.plain_uniform.n != n) return false;
   const Adjacency& adj = V->dof_cells();
-  DevArray<int64_t> len(n), off(n + 1);
-  launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
-         adj.offsets.p, plan.plain_uniform.p, mark, len.p);
+  DevArray<int64_t> len, off(n + 1);
   // one scan: the entries of all segments, and the plain rows without one.  Inside a step both totals stay in HBM
   // (published by the scan); "no such row" / "too many entries" are then the recorded step's answers
   Count tot[2];
+  const char* names[2] = {"vec.segment_entries", "vec.odd_rows"};
+  CountSource src[2];
+  src[0].src = off.p + n; src[0].kind = kCountLo32;
+  src[1].src = off.p + n; src[1].kind = kCountHi32;
+  CountPlan cp(2, names, src);
+  // (inside a step nothing waits for the totals: lengths + offsets + scatter in one chained launch)
+  const int64_t ntiles = (n + kTile - 1) / kTile;
+  // (... when the recorded step took this layout: else the host leaves below, before any kernel that could publish)
+  const bool fast_before = cp.publish && cp.counts[0].cap() > 0 && cp.counts[0].cap() < 2147483647LL;
+  const ChainState chain = fused_chain(fast_before, ntiles);
+  CountJobs after{};
+  if (chain.state) after = cp.take_jobs();
+  else
   {
-    const char* names[2] = {"vec.segment_entries", "vec.odd_rows"};
-    CountSource src[2];
-    src[0].src = off.p + n; src[0].kind = kCountLo32;
-    src[1].src = off.p + n; src[1].kind = kCountHi32;
-    CountPlan cp(2, names, src);
+    len.alloc(n);
+    launch("vec_plain_offsets", vec_plain_len_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
+           adj.offsets.p, plan.plain_uniform.p, mark, len.p);
     exclusive_scan(len.p, off.p, n, &cp);
-    cp.finish(tot);
   }
+  cp.finish(tot);
   if (tot[0].cap() == 0 || tot[0].cap() >= 2147483647LL) return false;
   // segment offsets are stored + 1 (0: the row has no segment): the array came zeroed with the plan's mark block
   // (cfx::row_plan: one fill for all of them) unless this is a second layout of the same plan
@@ -2281,8 +2448,12 @@ bool plain_vec_offsets(cfx_form_s* L, uint8_t mark)
     dev_fill(plan.vec_t2off.p, 0, sizeof(int32_t) * (size_t)V->ndofs);
   }
   plan.vec_t2off_used = true;
-  launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
-         off.p, plan.vec_t2off.p);
+  if (chain.state)
+    launch("vec_plain_offsets", vec_plain_offsets_chained_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, plan.n_plain_rows,
+           plan.plain_rows.p, adj.offsets.p, plan.plain_uniform.p, mark, plan.vec_t2off.p, chain, off.p + n, after);
+  else
+    launch("vec_plain_offsets", vec_plain_scatter_kernel, grid_for(n), dim3(kBlock), 0, plan.n_plain_rows, plan.plain_rows.p,
+           off.p, plan.vec_t2off.p);
   // everything else reads the per-cell records: the special rows, and (a second pass that skips the rows with a
   // segment) the few plain rows whose cells do not all carry the mark
   plan.n_vec_odd_rows = tot[1];
@@ -2902,9 +3073,8 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
   {
     const int64_t ntiles = (P->nrows + kTile - 1) / kTile;
     DevArray<int64_t> sums(ntiles), offs(ntiles + 1);
-    launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
-           counts.p, sums.p);
-    if (!deferred) exclusive_scan(sums.p, offs.p, ntiles);
+    ChainState chain{};
+    CountJobs after{};
     if (deferred)
     {
       // overflow flag, longest row and nnz in one round trip -- or, inside a step, none: nnz stays in HBM, the flag
@@ -2916,7 +3086,17 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       src[2].src = offs.p + ntiles; src[2].kind = kCountI64;
       Count t[3];
       CountPlan cp(3, names, src);
-      exclusive_scan(sums.p, offs.p, ntiles, &cp);
+      // (inside a step nnz's capacity is known before the rows are summed: reduce + offsets + write in one chained
+      // launch -- unless the recorded step found a long row: the host then leaves below, before any kernel that could
+      // publish)
+      chain = fused_chain(cp.publish && cp.counts[0].cap() == 0, ntiles);
+      if (chain.state) after = cp.take_jobs();
+      else
+      {
+        launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs,
+               plan.rowmark.p, counts.p, sums.p);
+        exclusive_scan(sums.p, offs.p, ntiles, &cp);
+      }
       cp.finish(t);
       if (t[0].cap() != 0)
       {
@@ -2928,10 +3108,19 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
       P->nnz = t[2];
     }
     else
+    {
+      launch("pattern_indptr", indptr_reduce_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
+             counts.p, sums.p);
+      exclusive_scan(sums.p, offs.p, ntiles);
       P->nnz = Count(read_scalar(offs.p + ntiles));
+    }
     P->indices.alloc(P->nnz.cap());
-    launch("pattern_indptr", indptr_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs, plan.rowmark.p,
-           counts.p, offs.p, P->indptr.p, P->indices.p, P->nnz.devn());
+    if (chain.state)
+      launch("pattern_indptr", indptr_chained_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs,
+             plan.rowmark.p, counts.p, P->indptr.p, P->indices.p, P->nnz.cap(), chain, offs.p + ntiles, after);
+    else
+      launch("pattern_indptr", indptr_write_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, P->nrows, V->bs,
+             plan.rowmark.p, counts.p, offs.p, P->indptr.p, P->indices.p, P->nnz.devn());
   }
   if (use_stencil && space_stencil_tiles(V).tiles_usable && plan.n_plain_tiles.cap() > 0)
     launch("pattern_plain_write", pattern_plain_tiles_kernel, wave_grid(plan.n_plain_tiles.cap()), dim3(kWave), 0, plan.n_plain_tiles,

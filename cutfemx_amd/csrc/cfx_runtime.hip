@@ -139,20 +139,6 @@ int64_t& sync_counter()
 // ---------------------------------------------------------------------------
 // counts in HBM / sync-free steps (see cfx_common.h)
 // ---------------------------------------------------------------------------
-constexpr int kMaxCountJobs = 6;
-struct CountJobs
-{
-  int64_t* pool;   // the count pool; n_slots: slots handed out so far in this step (what a void step zeroes)
-  int n_slots;
-  int n;
-  const void* src[kMaxCountJobs];
-  int kind[kMaxCountJobs];
-  int mode[kMaxCountJobs];
-  const int64_t* plus[kMaxCountJobs];
-  int64_t add[kMaxCountJobs];
-  int64_t cap[kMaxCountJobs];
-  int slot[kMaxCountJobs];
-};
 namespace
 {
 struct StepHistory
@@ -217,44 +203,6 @@ int64_t* count_mirror()
   return h;
 }
 
-__device__ __forceinline__ int64_t count_read(const void* src, int kind)
-{
-  int64_t v;
-  if (src == nullptr) return 0;
-  if (kind == kCountI32) v = *static_cast<const int32_t*>(src);
-  else
-  {
-    v = *static_cast<const int64_t*>(src);
-    if (kind == kCountPackedLo) v &= (1ll << kCountPackShift) - 1;
-    else if (kind == kCountPackedHi) v >>= kCountPackShift;
-    else if (kind == kCountLo32) v &= 0xffffffffll;
-    else if (kind == kCountHi32) v >>= 32;
-    else if (kind == kCountSum32) v = (v & 0xffffffffll) + (v >> 32);
-  }
-  return v;
-}
-// speculative step: raw total next to the published one; a total beyond its capacity poisons the step
-// Run by ONE thread.  A total beyond its capacity (or a must-equal word that differs) voids the step: the poison word is
-// set and EVERY published length of the pool becomes 0, so that each kernel launched from now on -- whatever list drives
-// it -- sees length 0 with the one load of dev_n; lengths published later in the void step are published as 0.
-__device__ __forceinline__ void count_publish(const CountJobs& J)
-{
-  int64_t* pool = J.pool;
-  bool void_step = pool[0] != 0;
-  int64_t raw[kMaxCountJobs];
-  for (int k = 0; k < J.n; ++k)
-  {
-    raw[k] = count_read(J.src[k], J.kind[k]) + (J.plus[k] ? *J.plus[k] : 0) + J.add[k];
-    pool[2 * J.slot[k] + 1] = raw[k];
-    void_step = void_step || (J.mode[k] == kCountMustEqual ? raw[k] != J.cap[k] : raw[k] > J.cap[k]);
-  }
-  for (int k = 0; k < J.n; ++k) pool[2 * J.slot[k]] = void_step ? 0 : raw[k];
-  if (void_step)
-  {
-    pool[0] = 1;
-    for (int e = kCountFirstSlot; e < J.n_slots; ++e) pool[2 * e] = 0;
-  }
-}
 __global__ void count_publish_kernel(CountJobs J)
 {
   if (threadIdx.x == 0) count_publish(J);
@@ -697,19 +645,12 @@ __global__ void scan_small_pair_kernel(const Tin* inA, const Tin* inB, int64_t n
   if (threadIdx.x == 0 && after.n > 0) count_publish(after);
 }
 
-// Single-pass scan (chained tiles with wave-wide look-back): one launch, the input is read
-// once.  A tile takes its number from an atomic ticket when its block starts, so every
-// predecessor it waits for is already resident and makes progress.  Tile state = one 64-bit
-// word (2-bit flag | 62-bit value) exchanged with agent-scope atomics: the L2s of the eight
-// XCDs are not coherent with each other for plain loads.
-constexpr unsigned long long kScanAggregate = 1ull << 62, kScanPrefix = 2ull << 62, kScanValueMask = (1ull << 62) - 1ull;
-
+// Single-pass scan (chained tiles with wave-wide look-back, cfx_device.h): one launch, the input is read once.
 // one tile of a chained scan; true for the thread that wrote the grand total out[n]
 template <typename Tin, typename Tout>
 __device__ __forceinline__ bool scan_chained_tile(const Tin* __restrict__ in, int64_t n, unsigned long long* __restrict__ state,
                                                   const unsigned int tile, Tout* __restrict__ out)
 {
-  __shared__ unsigned long long s_prefix;
   // the tile goes through LDS both ways: coalesced global loads and stores (see scan_write_kernel)
   __shared__ Tout s_v[kTile];
   const int64_t tbase = (int64_t)tile * kTile;
@@ -730,50 +671,7 @@ __device__ __forceinline__ bool scan_chained_tile(const Tin* __restrict__ in, in
   }
   Tout total;
   const Tout local = block_exclusive_scan<Tout>(s, total);
-  if (threadIdx.x < 64)
-  {
-    const int lane = threadIdx.x;
-    unsigned long long prefix = 0;
-    if (tile == 0)
-    {
-      if (lane == 0)
-        __hip_atomic_store(&state[0], kScanPrefix | ((unsigned long long)total & kScanValueMask), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    else
-    {
-      if (lane == 0)
-        __hip_atomic_store(&state[tile], kScanAggregate | ((unsigned long long)total & kScanValueMask), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      // look back 64 tiles at a time until a tile with a complete prefix is found
-      int64_t hi = (int64_t)tile - 1;
-      while (true)
-      {
-        const int64_t p = hi - lane;
-        unsigned long long w = kScanPrefix; // tiles before the first: prefix 0
-        if (p >= 0)
-        {
-          do
-          {
-            w = __hip_atomic_load(&state[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          } while ((w >> 62) == 0ull);
-        }
-        const unsigned long long done = __ballot((w >> 62) == 2ull);
-        const int first = done ? __ffsll((long long)done) - 1 : 64; // nearest tile whose prefix is complete
-        unsigned long long part = (lane <= first) ? (w & kScanValueMask) : 0ull;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        prefix += part;
-        if (done) break;
-        hi -= 64;
-      }
-      if (lane == 0)
-        __hip_atomic_store(&state[tile], kScanPrefix | ((prefix + (unsigned long long)total) & kScanValueMask),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (lane == 0) s_prefix = prefix;
-  }
-  __syncthreads();
+  const unsigned long long s_prefix = chain_exclusive_prefix(state, tile, (unsigned long long)total);
   Tout off = local + (Tout)s_prefix;
 #pragma unroll
   for (int k = 0; k < kScanItems; ++k)
@@ -827,6 +725,29 @@ __global__ void __launch_bounds__(kBlock) scan_chained_pair_kernel(const Tin* __
 }
 
 
+// tile states + ticket of a chained launch: a zeroed slice of a pool that is cleared with one fill when it wraps (a step
+// runs a dozen short scans: one memset each otherwise)
+ChainState chain_state(int64_t ntiles)
+{
+  constexpr int64_t kPoolWords = 1 << 20;
+  // (one pool per stream: the refill at wrap-around is ordered against earlier users by the stream it runs on)
+  struct ScanPool { unsigned long long* pool = nullptr; int64_t next = kPoolWords; };
+  static std::map<hipStream_t, ScanPool> pools;
+  ChainState ch;
+  if (ntiles <= 0 || ntiles + 1 > kPoolWords / 4) return ch;
+  ScanPool& sp = pools[ctx().stream];
+  if (!sp.pool) sp.pool = static_cast<unsigned long long*>(dev_alloc(sizeof(unsigned long long) * kPoolWords));
+  if (sp.next + ntiles + 1 > kPoolWords)
+  {
+    cfx::dev_fill(sp.pool, 0, sizeof(unsigned long long) * kPoolWords); // stream order keeps earlier users ahead of it
+    sp.next = 0;
+  }
+  ch.state = sp.pool + sp.next;
+  ch.ticket = reinterpret_cast<unsigned int*>(sp.pool + sp.next + ntiles);
+  sp.next += ntiles + 1;
+  return ch;
+}
+
 template <typename Tin, typename Tout>
 static void scan_impl(const Tin* in, Tout* out, int64_t n, CountPlan* plan = nullptr)
 {
@@ -845,36 +766,17 @@ static void scan_impl(const Tin* in, Tout* out, int64_t n, CountPlan* plan = nul
   static const int64_t chained_max = getenv("CFX_SCAN_CHAINED_TILES") ? atoll(getenv("CFX_SCAN_CHAINED_TILES")) : 8192;
   if (ntiles > 1 && ntiles <= chained_max)
   {
-    // tile states + ticket: a zeroed slice of a pool that is cleared with one fill when it wraps (a step runs
-    // a dozen short scans: one memset each otherwise)
-    constexpr int64_t kPoolWords = 1 << 20;
-    // (one pool per stream: the refill at wrap-around is ordered against earlier users by the stream it runs on)
-    struct ScanPool { unsigned long long* pool = nullptr; int64_t next = kPoolWords; };
-    static std::map<hipStream_t, ScanPool> pools;
-    ScanPool& sp = pools[ctx().stream];
-    unsigned long long*& pool = sp.pool;
-    int64_t& next = sp.next;
-    unsigned long long* state;
+    ChainState ch = chain_state(ntiles);
     DevArray<unsigned long long> own;
-    if (ntiles + 1 > kPoolWords / 4)
+    if (!ch.state)
     {
       own.alloc(ntiles + 1);
       own.zero();
-      state = own.p;
+      ch.state = own.p;
+      ch.ticket = reinterpret_cast<unsigned int*>(own.p + ntiles);
     }
-    else
-    {
-      if (!pool) pool = static_cast<unsigned long long*>(dev_alloc(sizeof(unsigned long long) * kPoolWords));
-      if (next + ntiles + 1 > kPoolWords)
-      {
-        cfx::dev_fill(pool, 0, sizeof(unsigned long long) * kPoolWords); // stream order keeps earlier users ahead of it
-        next = 0;
-      }
-      state = pool + next;
-      next += ntiles + 1;
-    }
-    launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, state,
-           reinterpret_cast<unsigned int*>(state + ntiles), out, after);
+    launch("scan_chained", scan_chained_kernel<Tin, Tout>, dim3((unsigned)ntiles), dim3(kBlock), 0, in, n, ch.state,
+           ch.ticket, out, after);
     return;
   }
   if (ntiles == 1)
@@ -1163,6 +1065,8 @@ void dev_fill(void* p, int byte, size_t bytes)
   }
   const unsigned b = (unsigned)byte & 0xffu, word = b | (b << 8) | (b << 16) | (b << 24);
   const int64_t n16 = (int64_t)(bytes / 16);
+  static const bool trace = getenv("CFX_LAUNCH_TRACE") != nullptr;
+  if (trace) fprintf(stderr, "cutfemx_amd: fill of %zu bytes\n", bytes);
   launch("fill", fill16_kernel, grid_for(std::max<int64_t>(n16, 1), kBlock * 4), dim3(kBlock), 0,
          static_cast<unsigned char*>(p), bytes, word);
 }

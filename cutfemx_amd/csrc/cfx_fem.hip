@@ -2106,6 +2106,119 @@ int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** r
   CFX_API_END
 }
 
+namespace
+{
+constexpr int kMergeMaxBlocks = 8; // blocks per block row
+struct MergeRow
+{
+  int nb;                              // blocks of this block row (empty ones have indptr == nullptr)
+  const int64_t* indptr[kMergeMaxBlocks];
+  const int32_t* indices[kMergeMaxBlocks];
+  const double* values[kMergeMaxBlocks];
+  int64_t col_offset[kMergeMaxBlocks];
+};
+
+// entries of row r of the block row: the sum of the blocks' row lengths
+__global__ void block_merge_len_kernel(int64_t nrows, MergeRow B, int64_t* __restrict__ len)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  int64_t l = 0;
+  for (int j = 0; j < B.nb; ++j)
+    if (B.indptr[j]) l += B.indptr[j][r + 1] - B.indptr[j][r];
+  len[r] = l;
+}
+
+// 8 lanes per row: block after block, columns shifted by the block column's offset (each block's columns ascend and
+// the offsets ascend with the block column: the merged row is sorted)
+__global__ void block_merge_fill_kernel(int64_t nrows, MergeRow B, const int64_t* __restrict__ out_indptr,
+                                        int32_t* __restrict__ out_indices, double* __restrict__ out_values)
+{
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = t >> 3;
+  const int lane = (int)(t & 7);
+  if (r >= nrows) return;
+  int64_t o = out_indptr[r];
+  for (int j = 0; j < B.nb; ++j)
+  {
+    if (!B.indptr[j]) continue;
+    const int64_t b = B.indptr[j][r], e = B.indptr[j][r + 1];
+    for (int64_t k = b + lane; k < e; k += 8)
+    {
+      out_indices[o + (k - b)] = (int32_t)(B.indices[j][k] + B.col_offset[j]);
+      if (out_values) out_values[o + (k - b)] = B.values[j] ? B.values[j][k] : 0.0;
+    }
+    o += e - b;
+  }
+}
+} // namespace
+
+int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const int32_t* const* indices,
+                        const double* const* values, const int64_t* nrows, const int64_t* ncols, int64_t** out_indptr,
+                        int32_t** out_indices, double** out_values, int64_t* out_nnz)
+{
+  CFX_API_BEGIN
+  require(indptr && indices && nrows && ncols && out_indptr && out_indices && out_nnz, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_csr_block_merge: null argument");
+  require(nbr >= 1 && nbc >= 1 && nbc <= kMergeMaxBlocks, CFX_ERR_INVALID_ARGUMENT,
+          "cfx_csr_block_merge: 1 .. 8 block columns");
+  int64_t total_rows = 0, total_cols = 0;
+  for (int i = 0; i < nbr; ++i) { require(nrows[i] >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_csr_block_merge: negative row count"); total_rows += nrows[i]; }
+  for (int j = 0; j < nbc; ++j) { require(ncols[j] >= 0, CFX_ERR_INVALID_ARGUMENT, "cfx_csr_block_merge: negative column count"); total_cols += ncols[j]; }
+  require(total_cols <= 2147483647LL, CFX_ERR_OUT_OF_RANGE, "cfx_csr_block_merge: more than 2^31 - 1 columns");
+  // the blocks on the device (host arrays are uploaded; device arrays are used where they lie)
+  std::vector<DevArray<int64_t>> d_ip((size_t)nbr * nbc);
+  std::vector<DevArray<int32_t>> d_ix((size_t)nbr * nbc);
+  std::vector<DevArray<double>> d_v((size_t)nbr * nbc);
+  std::vector<MergeRow> rows((size_t)nbr);
+  for (int i = 0; i < nbr; ++i)
+  {
+    MergeRow& B = rows[i];
+    B = MergeRow{};
+    B.nb = nbc;
+    int64_t co = 0;
+    for (int j = 0; j < nbc; ++j)
+    {
+      const size_t k = (size_t)i * nbc + j;
+      B.col_offset[j] = co;
+      co += ncols[j];
+      if (!indptr[k] || nrows[i] == 0) continue;
+      require(indices[k] != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_csr_block_merge: a block has row offsets but no column indices");
+      d_ip[k] = to_device(indptr[k], nrows[i] + 1);
+      const int64_t nnz_k = read_scalar(d_ip[k].p + nrows[i]);
+      d_ix[k] = to_device(indices[k], nnz_k);
+      B.indptr[j] = d_ip[k].p; B.indices[j] = d_ix[k].p;
+      if (values && values[k]) { d_v[k] = to_device(values[k], nnz_k); B.values[j] = d_v[k].p; }
+    }
+  }
+  int64_t* ip = static_cast<int64_t*>(dev_alloc(sizeof(int64_t) * (size_t)(total_rows + 1)));
+  DevArray<int64_t> len(total_rows);
+  int64_t r0 = 0;
+  for (int i = 0; i < nbr; ++i)
+  {
+    if (nrows[i] > 0)
+      launch("block_merge", block_merge_len_kernel, grid_for(nrows[i]), dim3(kBlock), 0, nrows[i], rows[i], len.p + r0);
+    r0 += nrows[i];
+  }
+  exclusive_scan(len.p, ip, total_rows);
+  const int64_t nnz = read_scalar(ip + total_rows);
+  int32_t* ix = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
+  double* vals = out_values ? static_cast<double*>(dev_alloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1))) : nullptr;
+  r0 = 0;
+  for (int i = 0; i < nbr; ++i)
+  {
+    if (nrows[i] > 0)
+      launch("block_merge", block_merge_fill_kernel, grid_for(nrows[i] * 8), dim3(kBlock), 0, nrows[i], rows[i], ip + r0, ix,
+             vals);
+    r0 += nrows[i];
+  }
+  *out_indptr = ip;
+  *out_indices = ix;
+  if (out_values) *out_values = vals;
+  *out_nnz = nnz;
+  CFX_API_END
+}
+
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae)
 {
   CFX_API_BEGIN

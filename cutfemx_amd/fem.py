@@ -578,6 +578,91 @@ def zero_block_rows(A_blocks, *, tol: float = 0.0) -> list[np.ndarray]:
     return out
 
 
+class MergedCSR:
+    """The monolithic CSR matrix of a block system (merge_blocks): indptr (int64), indices (int32), float64 data in HBM."""
+
+    def __init__(self, indptr, indices, values, nnz, nrows, ncols, row_offsets, col_offsets):
+        self._indptr, self._indices, self._values = indptr, indices, values
+        self.nnz, self.nrows, self.ncols = int(nnz), int(nrows), int(ncols)
+        self.row_offsets, self.col_offsets = row_offsets, col_offsets   # first row / column of every block
+        self.dtype = np.dtype(np.float64)
+
+    @property
+    def indptr(self):
+        return _lib.download(self._indptr, self.nrows + 1, np.int64)
+
+    @property
+    def indices(self):
+        return _lib.download(self._indices, self.nnz, np.int32)
+
+    @property
+    def data(self):
+        return _lib.download(self._values, self.nnz, np.float64)
+
+    def torch_views(self, device):
+        """Zero-copy torch tensors (indptr int64, indices int32, values f64) over the HBM arrays."""
+        from .dist import as_torch
+        return (as_torch(self._indptr, self.nrows + 1, "int64", device), as_torch(self._indices, self.nnz, "int32", device),
+                as_torch(self._values, self.nnz, "float64", device))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csr_matrix((self.data, self.indices, self.indptr), shape=(self.nrows, self.ncols))
+
+    def to_dense(self):
+        return self.to_scipy().toarray()
+
+    def __del__(self):
+        try:
+            l = _lib.load()
+            for name in ("_indptr", "_indices", "_values"):
+                if getattr(self, name, None):
+                    l.cfx_device_free(C.c_void_p(getattr(self, name)))
+                    setattr(self, name, None)
+        except Exception:
+            pass
+
+
+def merge_blocks(A_blocks) -> MergedCSR:
+    """One CSR matrix from a block system of float64 MatrixCSR blocks (None: an empty block): the monolithic matrix the
+    reference assembles on a mixed element (python/tests/test_assembly_stokes.py:34-95), with block-ordered dofs -- all
+    rows of block row 0, then of block row 1 ...; columns likewise.  Every block row / column needs one block that fixes
+    its size; sizes must agree along rows and columns.  Runs on the GPU (cfx_csr_block_merge); the blocks are not changed."""
+    rows = [list(r) for r in A_blocks]
+    if not rows or not rows[0]:
+        raise RuntimeError("merge_blocks requires at least one block")
+    nbr, nbc = len(rows), len(rows[0])
+    if any(len(r) != nbc for r in rows):
+        raise RuntimeError("merge_blocks requires the same number of blocks in every block row")
+    nrows, ncols = [None] * nbr, [None] * nbc
+    for i, r in enumerate(rows):
+        for j, A in enumerate(r):
+            if A is None:
+                continue
+            if A.dtype != np.dtype(np.float64):
+                raise TypeError("merge_blocks takes float64 blocks")
+            if nrows[i] not in (None, A.nrows) or ncols[j] not in (None, A.ncols):
+                raise RuntimeError("merge_blocks found incompatible block sizes")
+            nrows[i], ncols[j] = A.nrows, A.ncols
+    if any(n is None for n in nrows) or any(n is None for n in ncols):
+        raise RuntimeError("merge_blocks requires a block in every block row and every block column")
+    _lib.resolve_counts()
+    n = nbr * nbc
+    ip, ix, va = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)()
+    for i, r in enumerate(rows):
+        for j, A in enumerate(r):
+            if A is not None:
+                k = i * nbc + j
+                ip[k], ix[k], va[k] = A._view.indptr, A._view.indices, A.values_ptr
+    nr, nc = (C.c_int64 * nbr)(*nrows), (C.c_int64 * nbc)(*ncols)
+    o_ip, o_ix, o_va, o_nnz = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int64()
+    _lib.check(_lib.lib().cfx_csr_block_merge(nbr, nbc, ip, ix, va, nr, nc, C.byref(o_ip), C.byref(o_ix), C.byref(o_va),
+                                              C.byref(o_nnz)))
+    return MergedCSR(o_ip.value, o_ix.value, o_va.value, o_nnz.value, sum(nrows), sum(ncols),
+                     np.concatenate([[0], np.cumsum(nrows)[:-1]]).astype(np.int64),
+                     np.concatenate([[0], np.cumsum(ncols)[:-1]]).astype(np.int64))
+
+
 def deactivate_outside_blocks(A_blocks, active_domains, b_blocks=None, *, diagonal: float = 1.0,
                               rhs_value: float = 0.0) -> list:
     """Deactivate block rows from per-row active-domain support (python/cutfemx/fem.py:739-775,

@@ -433,6 +433,18 @@ int cfx_set_bc(int64_t n, const int8_t* bc_markers, const double* bc_values, con
 /* zero_rows(A, tol) (python/cutfemx/fem.py:777-782): rows whose assembled entries are all <= tol in
  * magnitude, ascending; *rows is released with cfx_device_free. */
 int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** rows, int64_t* n_rows);
+/* One CSR matrix from an nbr x nbc block system (the blocks of cfx_form_create2 forms): row r of block row i becomes
+ * row (nrows[0] + ... + nrows[i-1]) + r and holds the entries of A[i][0], A[i][1], ... with the columns of block
+ * column j shifted by ncols[0] + ... + ncols[j-1] -- the monolithic matrix that the reference assembles on a mixed
+ * element (python/tests/test_assembly_stokes.py:34-95: ONE matrix on mixed_element([P2 vector, P1])), in block-ordered
+ * dof numbering (all dofs of space 0, then of space 1 ...; DOLFINx interleaves them cell by cell: the two differ by that
+ * permutation of rows and columns).  indptr / indices / values: nbr * nbc pointers, row-major, host or device; a NULL
+ * indptr marks an empty block; values may be NULL (pattern only: out_values NULL as well) and a NULL values[k] gives
+ * zeros.  Columns of a merged row ascend.  The outputs are device arrays released with cfx_device_free; at most 8
+ * block columns. */
+int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const int32_t* const* indices,
+                        const double* const* values, const int64_t* nrows, const int64_t* ncols, int64_t** out_indptr,
+                        int32_t** out_indices, double** out_values, int64_t* out_nnz);
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
 
 /* ---- user-supplied integrands: the runtime-generated kernel of a form

@@ -628,6 +628,52 @@ inline std::vector<ActiveDomain*> deactivate_outside_blocks(const std::vector<st
   return active_domains;
 }
 
+/// The monolithic matrix of a block system (host copies): what the reference assembles as ONE matrix on a mixed element
+/// (python/tests/test_assembly_stokes.py:34-95), with block-ordered dofs -- see cfx_csr_block_merge
+struct MergedCSR
+{
+  std::vector<std::int64_t> row_ptr;
+  std::vector<std::int32_t> cols;
+  std::vector<double> values;
+  std::int64_t num_rows = 0, num_cols = 0;
+};
+
+/// merge_blocks(): A_blocks[i][j] with a null pattern is an empty block; every block row and column needs one block
+inline MergedCSR merge_blocks(const std::vector<std::vector<MatrixBlock>>& A_blocks)
+{
+  if (A_blocks.empty() || A_blocks[0].empty()) throw std::runtime_error("merge_blocks requires at least one block");
+  const std::size_t nbr = A_blocks.size(), nbc = A_blocks[0].size();
+  std::vector<const std::int64_t*> ip(nbr * nbc, nullptr);
+  std::vector<const std::int32_t*> ix(nbr * nbc, nullptr);
+  std::vector<const double*> va(nbr * nbc, nullptr);
+  std::vector<std::int64_t> nrows(nbr, -1), ncols(nbc, -1);
+  for (std::size_t i = 0; i < nbr; ++i)
+  {
+    if (A_blocks[i].size() != nbc) throw std::runtime_error("merge_blocks requires the same number of blocks in every block row");
+    for (std::size_t j = 0; j < nbc; ++j)
+    {
+      const MatrixBlock& B = A_blocks[i][j];
+      if (B.pattern == nullptr) continue;
+      if ((nrows[i] >= 0 && nrows[i] != B.pattern->num_rows()) || (ncols[j] >= 0 && ncols[j] != B.pattern->num_cols()))
+        throw std::runtime_error("merge_blocks found incompatible block sizes");
+      nrows[i] = B.pattern->num_rows(); ncols[j] = B.pattern->num_cols();
+      ip[i * nbc + j] = B.pattern->view.indptr; ix[i * nbc + j] = B.pattern->view.indices; va[i * nbc + j] = B.values.data();
+    }
+  }
+  for (std::int64_t n : nrows) if (n < 0) throw std::runtime_error("merge_blocks requires a block in every block row and every block column");
+  for (std::int64_t n : ncols) if (n < 0) throw std::runtime_error("merge_blocks requires a block in every block row and every block column");
+  std::int64_t* o_ip = nullptr; std::int32_t* o_ix = nullptr; double* o_va = nullptr; std::int64_t nnz = 0;
+  check(cfx_csr_block_merge((int)nbr, (int)nbc, ip.data(), ix.data(), va.data(), nrows.data(), ncols.data(), &o_ip, &o_ix, &o_va, &nnz));
+  MergedCSR M;
+  for (std::int64_t n : nrows) M.num_rows += n;
+  for (std::int64_t n : ncols) M.num_cols += n;
+  M.row_ptr = download(o_ip, M.num_rows + 1);
+  M.cols = download(o_ix, nnz);
+  M.values = download(o_va, nnz);
+  check(cfx_device_free(o_ip)); check(cfx_device_free(o_ix)); check(cfx_device_free(o_va));
+  return M;
+}
+
 } // namespace fem
 
 namespace extensions

@@ -67,11 +67,14 @@ int main(int argc, char** argv)
 
     if (argc > 99)
     {
-      // (type-checked, not run: the complex64 overloads and a run-time integrand)
+      // (type-checked, not run: the complex64 overloads, the block merge and a run-time integrand)
       std::vector<std::complex<float>> Ac, bc;
       cfx::fem::SparsityPattern spc = cfx::fem::create_sparsity_pattern(a);
       cfx::fem::assemble_matrix(std::span<std::complex<float>>(Ac), a, spc);
       cfx::fem::assemble_vector(std::span<std::complex<float>>(bc), L);
+      std::vector<double> Ad;
+      const cfx::fem::MergedCSR merged = cfx::fem::merge_blocks({{cfx::fem::MatrixBlock{std::span<double>(Ad), &spc}}});
+      (void)merged;
       (void)cfx::fem::register_integrand("user_k", "__device__ void user_k(double*, const double*, const double*, const double*, int, const double*, const double*, const double*) {}", 2);
     }
     cfx::fem::SparsityPattern sp = cfx::fem::create_sparsity_pattern(a);

@@ -340,3 +340,98 @@ def test_gpu_facet_terms_between_spaces(oracle, tdim, n):
                 Msp = sp.csr_matrix((want, ix, ip), shape=(A.nrows, A.ncols))
                 got = fem.apply_lifting(b0.copy(), a, bc1, g, alpha=0.7)
                 assert np.abs(got - (b0 - Msp @ np.where(bc1 == 1, 0.7 * g, 0.0))).max() < 1e-11 * max(scale, 1.0), tag
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n", [(2, 4), (3, 3)])
+def test_gpu_stokes_monolithic_matrix_runtime_equals_standard(oracle, tdim, n):
+    """python/tests/test_assembly_stokes.py:34-95: ONE Stokes matrix on the Taylor-Hood pair -- here the blocks of
+    cfx_form_create2 forms merged on the GPU (fem.merge_blocks, block-ordered dofs) -- assembled over runtime rules that
+    cover every cell whole (order 4) agrees with the standard assembly to 1e-9; against the oracle's blocks put
+    together with scipy.sparse.bmat: pattern bit for bit, values to 1e-12; an absent block stays empty."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om, dm2, nd2, oVU, oVP, _ = spaces(O, tdim, n)
+    cells = np.arange(om.ncells, dtype=np.int32)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    VU = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2, bs=tdim)
+    VP = cfx.FunctionSpace(mesh, 1)
+    ofull = O.full_cell_rules(om, cells, 4)
+    full = cfx.full_cell_rules(mesh, cells, 4)
+    none = np.zeros(0, dtype=np.int32)
+
+    def blocks(runtime):
+        kw = dict(cells=none, rules=full) if runtime else dict(cells=cells)
+        A = fem.assemble_matrix(fem.form([fem.Integral(fem.STIFFNESS, qdegree=2, **kw)], VU))
+        Bt = fem.assemble_matrix(fem.form([fem.Integral(fem.DIV_TEST, params=(-1.0,), qdegree=3, **kw)], VU, trial_space=VP))
+        B = fem.assemble_matrix(fem.form([fem.Integral(fem.DIV_TRIAL, params=(-1.0,), qdegree=3, **kw)], VP, trial_space=VU))
+        return [[A, Bt], [B, None]]
+    std, run = blocks(False), blocks(True)
+    M_std, M_run = fem.merge_blocks(std), fem.merge_blocks(run)
+    nu, npr = nd2 * tdim, om.nnodes
+    assert (M_std.nrows, M_std.ncols) == (nu + npr, nu + npr)
+    assert list(M_std.row_offsets) == [0, nu] and list(M_std.col_offsets) == [0, nu]
+    diff = np.linalg.norm((M_std.to_scipy() - M_run.to_scipy()).toarray())
+    assert diff < 1e-9, diff
+    # the oracle's blocks, put together on the host
+    okw = dict(entities=cells)
+    oA = [O.Integral(O.CELL, O.K_STIFFNESS, qdegree=2, **okw)]
+    ipA, ixA = O.create_sparsity(om, oVU, oA)
+    want = {(0, 0): sp.csr_matrix((O.assemble_matrix(om, oVU, oA, ipA, ixA), ixA, ipA), shape=(nu, nu))}
+    for (i, j), (o0, o1, kern) in {(0, 1): (oVU, oVP, O.K_DIV_TEST), (1, 0): (oVP, oVU, O.K_DIV_TRIAL)}.items():
+        oi = [O.Integral(O.CELL, kern, params=(-1.0,), qdegree=3, **okw)]
+        ip, ix = O.create_sparsity2(om, o0, o1, oi)
+        want[(i, j)] = sp.csr_matrix((O.assemble_matrix2(om, o0, o1, oi, ip, ix), ix, ip), shape=(o0.ndofs * o0.bs, o1.ndofs * o1.bs))
+    # (bmat drops nothing: the blocks keep their explicit zeros through coo -> csr)
+    ref = sp.bmat([[want[(0, 0)], want[(0, 1)]], [want[(1, 0)], None]], format="csr")
+    ref.sort_indices()
+    got = M_std.to_scipy()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert rel_err(got.data, ref.data) < 1e-12
+    assert got[nu:, nu:].nnz == 0                                   # the absent pressure block
+    assert abs(got - got.T).max() < 1e-12 * abs(got).max()          # the saddle-point matrix is symmetric
+    # pattern only / sizes that do not fit / a block row without a block
+    with pytest.raises(RuntimeError, match="incompatible block sizes"):
+        fem.merge_blocks([[std[0][0], std[1][0]], [std[1][0], None]])
+    with pytest.raises(RuntimeError, match="every block row and every block column"):
+        fem.merge_blocks([[std[0][0], None], [std[1][0], None]])
+
+
+@pytest.mark.gpu
+def test_gpu_merge_blocks_on_a_cut_domain_with_ghost_penalties(oracle):
+    """test_assembly_stokes.py:98-142 (velocity + pressure ghost penalties on the mixed space) on a cut domain: the merged
+    matrix of [[A + g_u, B^T], [B, -g_p]] equals the oracle's blocks put together, and deactivating the diagonal blocks
+    first (deactivate_outside_blocks) carries over to the merged rows."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    tdim, n = 2, 8
+    om, dm2, nd2, oVU, oVP, _ = spaces(O, tdim, n)
+    phi = level_set_values(om.x, tdim)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    VU = cfx.FunctionSpace(mesh, 2, dofmap=dm2, ndofs=nd2, bs=tdim)
+    VP = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(VP, phi))
+    inside = cfx.locate_entities(cd, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    aU = fem.form([fem.Integral(fem.STIFFNESS, cells=inside, rules=vol, qdegree=2),
+                   fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)], VU)
+    aP = fem.form([fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(-0.05, 3.0), qdegree=2)], VP)
+    aBt = fem.form([fem.Integral(fem.DIV_TEST, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VU, trial_space=VP)
+    aB = fem.form([fem.Integral(fem.DIV_TRIAL, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VP, trial_space=VU)
+    blocks = [[fem.assemble_matrix(aU), fem.assemble_matrix(aBt)], [fem.assemble_matrix(aB), fem.assemble_matrix(aP)]]
+    M = fem.merge_blocks(blocks).to_scipy()
+    ref = sp.bmat([[b.to_scipy() for b in row] for row in blocks], format="csr")
+    ref.sort_indices()
+    assert np.array_equal(M.indptr, ref.indptr) and np.array_equal(M.indices, ref.indices) and np.array_equal(M.data, ref.data)
+    # block deactivation, then merge: the inactive rows of both diagonal blocks are identity rows of the merged matrix
+    aPd = fem.form([fem.Integral(fem.MASS, cells=inside, rules=vol, qdegree=2)], VP)   # (the pressure's support)
+    domains = [fem.active_domain(aU), fem.active_domain(aPd)]
+    fem.deactivate_outside_blocks(blocks, domains)
+    M2 = fem.merge_blocks(blocks).to_scipy()
+    nu = nd2 * tdim
+    dead = np.concatenate([domains[0].inactive_dofs, nu + domains[1].inactive_dofs])
+    assert dead.size > 0
+    assert np.allclose(M2.diagonal()[dead], 1.0)

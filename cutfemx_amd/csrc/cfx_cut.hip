@@ -1042,6 +1042,11 @@ struct EmitJobs
   int32_t* parent_map[2];
 };
 
+#if defined(CFX_EMIT_ABLATE)
+#define CFX_EMIT_STORE(dst, val) do { const double v_ = (val); if (v_ == 1.2345e300) (dst) = v_; } while (0) // ablation: no stores
+#else
+#define CFX_EMIT_STORE(dst, val) (dst) = (val)
+#endif
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
     DevN ncut_d, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
@@ -1093,10 +1098,14 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   __syncthreads();
   if (!live) return;
   // one or two rule sets of the same cut (runtime_quadratures: e.g. "phi<0" and "phi=0"): the staging above is shared
+  // (the offsets of both sets are requested before the first store: a load issued behind the first set's stores waits
+  // for them -- vmcnt counts loads and stores in order on this architecture)
+  int64_t po_job[2];
+#pragma unroll
+  for (int job = 0; job < 2; ++job) po_job[job] = job < jobs.n ? jobs.packed_off[job][i] : 0;
   for (int job = 0; job < jobs.n; ++job)
   {
   const int part = jobs.part[job];
-  const int64_t* __restrict__ packed_off = jobs.packed_off[job];
   double* __restrict__ points = jobs.points[job];
   double* __restrict__ weights = jobs.weights[job];
   int32_t* __restrict__ offsets = jobs.offsets[job];
@@ -1104,14 +1113,14 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
   const int ns = part == PART_IN ? cs.n_in : (part == PART_OUT ? cs.n_out : cs.n_if);
   // the last cut cell closes the parent list with a sentinel (the list is allocated one entry longer): kernels that
   // walk "the rules of cell c" stop there without knowing the number of rules, which may still be in HBM
+  const int64_t po = job == 0 ? po_job[0] : po_job[1];
   if (lane == 0 && i == ncut - 1)
-    parent_map[(packed_off[i] >> kPackShift) + (part == PART_IF ? ns : (ns > 0 ? 1 : 0))] = -1;
+    parent_map[(po >> kPackShift) + (part == PART_IF ? ns : (ns > 0 ? 1 : 0))] = -1;
   if (ns == 0) continue;
   int nref;
   const double* wref;
   const double* pref = ref_points<TDIM>(part == PART_IF ? TDIM - 1 : TDIM, degree, nref, wref);
   const int npts = ns * nref;
-  const int64_t po = packed_off[i];
   const int32_t pbase = (int32_t)(po & kPackMask), rbase = (int32_t)(po >> kPackShift);
 
   // J[d][t] = x_{t+1}[d] - x_0[d]
@@ -1176,9 +1185,9 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
         double v = l0 * V[0][d];
 #pragma unroll
         for (int t = 0; t < TDIM - 1; ++t) v += xi[t] * V[t + 1][d];
-        points[(int64_t)(pbase + pt) * TDIM + d] = v;
+        CFX_EMIT_STORE(points[(int64_t)(pbase + pt) * TDIM + d], v);
       }
-      weights[pbase + pt] = wref[q] * scale;
+      CFX_EMIT_STORE(weights[pbase + pt], wref[q] * scale);
     }
     else
     {
@@ -1211,9 +1220,9 @@ __global__ void __launch_bounds__(kBlock) cut_emit_kernel(
         double v = l0 * V[0][d];
 #pragma unroll
         for (int t = 0; t < TDIM; ++t) v += xi[t] * V[t + 1][d];
-        points[(int64_t)(pbase + pt) * TDIM + d] = v;
+        CFX_EMIT_STORE(points[(int64_t)(pbase + pt) * TDIM + d], v);
       }
-      weights[pbase + pt] = wref[q] * scale;
+      CFX_EMIT_STORE(weights[pbase + pt], wref[q] * scale);
     }
   }
   if (lane == 0)

@@ -541,7 +541,11 @@ __device__ __forceinline__ void source_vector(const SourceCell<TDIM>& c, int npt
 #pragma unroll
     for (int d = 0; d < TDIM; ++d)
     {
+#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 32)
+      S[d] = c.x[0][d]; C[d] = 1.0 - S[d]; // ablation: no sincospi of the anchor
+#else
       cfx_sincospi(c.x[0][d], S[d], C[d]);
+#endif
 #pragma unroll
       for (int t = 0; t < TDIM; ++t) ed[t][d] *= kPi;
     }

@@ -809,11 +809,32 @@ __global__ void __launch_bounds__(kBlock) indptr_reduce_kernel(int64_t nrows, in
 {
   const int64_t tile = (int64_t)blockIdx.x * kTile;
   int64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < kScanItems; ++k)
+  if (bs == 1 && tile + kTile <= nrows)
   {
-    const int64_t R = tile + k * kBlock + threadIdx.x;
-    if (R < nrows) s += rowmark[R / bs] ? counts[R] : bs;
+    // scalar space, whole tile: the marks of a thread's eight consecutive rows in one 8 B load (one byte per lane and
+    // load cost 0.18 ms for 135 M rows); the lengths are read for marked rows only
+    static_assert(kScanItems == 8, "eight rows per thread");
+    const int64_t r0 = tile + 8 * threadIdx.x;
+    const uint2 m = *reinterpret_cast<const uint2*>(rowmark + r0); // (tile and 8 t: 8 B aligned)
+    if ((m.x | m.y) == 0u) s = 8;
+    else
+    {
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+      {
+        const unsigned byte = ((q < 4 ? m.x : m.y) >> (8 * (q & 3))) & 0xffu;
+        s += byte ? counts[r0 + q] : 1;
+      }
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+    {
+      const int64_t R = tile + k * kBlock + threadIdx.x;
+      if (R < nrows) s += rowmark[R / bs] ? counts[R] : bs;
+    }
   }
   int64_t total;
   (void)block_exclusive_scan<int64_t>(s, total);
@@ -853,16 +874,21 @@ __device__ __forceinline__ int64_t indptr_tile(int64_t nrows, int bs, const uint
 #pragma unroll
         for (int q = 0; q < 8; ++q) indptr[r0 + q] = p0 + q;
       }
-      if (p0 + 8 <= nnz_cap)
+      // the diagonal entries: positions t0 .. t0 + kTile - 1 hold the rows tile .. tile + kTile - 1 -- written as 16 B
+      // words from the first aligned position on (t0 is whatever the active rows before the tile add up to: a lane's own
+      // eight entries start on a 16 B boundary one time in four), the few entries before and behind them one by one
+      const int64_t e_end = min(t0 + (int64_t)kTile, nnz_cap);
+      const int64_t a0 = (t0 + 3) & ~3ll; // (the index array starts on a 256 B boundary)
+      if (t0 + threadIdx.x < min(a0, e_end)) indices[t0 + threadIdx.x] = (int32_t)(tile + threadIdx.x);
+      const int64_t nchunks = e_end > a0 ? (e_end - a0) >> 2 : 0;
+      for (int64_t j = threadIdx.x; j < nchunks; j += kBlock)
       {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) indices[p0 + q] = (int32_t)(r0 + q);
+        const int64_t pos = a0 + 4 * j;
+        const int32_t v = (int32_t)(tile + (pos - t0));
+        *reinterpret_cast<int4*>(indices + pos) = make_int4(v, v + 1, v + 2, v + 3);
       }
-      else
-      {
-        for (int q = 0; q < 8; ++q)
-          if (p0 + q + 1 <= nnz_cap) indices[p0 + q] = (int32_t)(r0 + q);
-      }
+      const int64_t pos = a0 + 4 * nchunks + threadIdx.x;
+      if (pos < e_end) indices[pos] = (int32_t)(tile + (pos - t0));
       return t0 + kTile;
     }
   }

@@ -1044,6 +1044,17 @@ def main():
             s = measure(128, 20, 3, args.order, 1, 0, device, profile=False)
             out["config_128"] = {"workload": "configs[1]: 128^3 background mesh, same form", "value": s["value"],
                                  "unit": "DOF/s", "ms_per_step": s["ms_per_step"], "active_dofs": s["active_dofs"]}
+        if not args.no_secondary and n != 32:
+            # the launch-bound end of the same step: 32^3 (configs[0]-sized), where the step is ~40 kernel floors
+            try:
+                s = measure(32, 200, 10, args.order, 1, 0, device, profile=True)
+                sm = s.get("step_mode") or {}
+                out["config_32"] = {"workload": "32^3 background mesh, same form (launch-bound)", "value": s["value"], "unit": "DOF/s",
+                                    "ms_per_step": s["ms_per_step"], "active_dofs": s["active_dofs"],
+                                    "launches_per_step": sm.get("launches_per_step"),
+                                    "read_backs_per_step": sm.get("read_backs_per_step")}
+            except Exception as e:
+                out["config_32"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_secondary:
             import gc
             from cutfemx_amd import _lib as _cl

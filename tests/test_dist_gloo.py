@@ -204,3 +204,23 @@ def test_partition_arithmetic():
             # the peer lists the mirrored exchange: it sends the plane I receive and receives the one I send
             assert (p.rank, rcv, s) in q.exchanges(), (r, peer, s, rcv, q.exchanges())
     assert planes == list(range(65))
+
+
+def test_slab_boundaries_count_the_halo_layers():
+    # the split that counts a rank's halo layers as its work: a partition of the layers, never heavier (halos included)
+    # than the equal-weight split, for any world size and layer count -- also when there are barely more layers than ranks
+    import numpy as np
+    from cutfemx_amd.dist import balanced_boundaries, sphere_layer_weights
+    for n in (8, 9, 64, 200):
+        w = sphere_layer_weights(n)
+        cum = np.concatenate([[0.0], np.cumsum(w)])
+        for world in (1, 2, 3, 4, 8):
+            for lo, hi in ((1, 2), (3, 3)):
+                def heaviest(b):
+                    return max(cum[min(b[p + 1] + hi, n)] - cum[max(b[p] - lo, 0)] for p in range(world))
+                plain, aware = balanced_boundaries(w, world), balanced_boundaries(w, world, lo, hi)
+                assert aware[0] == 0 and aware[-1] == n and len(aware) == world + 1
+                assert all(aware[i] < aware[i + 1] for i in range(world)), (n, world, aware)
+                assert heaviest(aware) <= heaviest(plain) * (1 + 1e-12), (n, world, plain, aware)
+    # uniform weights: nothing to gain, the split stays a partition
+    assert balanced_boundaries(np.ones(12), 4, 1, 1)[-1] == 12

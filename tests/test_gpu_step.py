@@ -254,3 +254,28 @@ def test_steps_of_spaces_off_the_p1_path(oracle, tdim, n, degree, bs):
         assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), k
         assert rel_err(A.data, want) < RTOL, k
         assert np.array_equal(dom.inactive_dofs, ina), k
+
+
+def test_an_interface_that_enters_and_leaves_the_mesh(oracle):
+    # lists that are empty in one step and not in the next (no cut cell, no interface rule, no ghost facet while the whole
+    # box is inside; then a plane cuts it; then it is gone again): a count that was 0 has capacity 0, so the step in which
+    # the interface appears is void and repeated; the call sequence of a step changes with it (the history is replaced);
+    # every step exact, the fused count + write kernels included
+    import torch
+
+    import cutfemx_amd as cfx
+    om, mesh, V, xt, phi, f = moving_problem(oracle, 3, 10)
+    state = {"cd": None, "b": torch.zeros(om.nnodes, device="cuda", dtype=torch.float64)}
+    key = "test-enter-leave"
+    cfx.forget_step_history(key)
+    passes, cuts = [], []
+    for k, c in enumerate((1.5, 1.5, 0.63, 0.61, 0.61, 1.5, 1.5)):
+        phi.copy_(xt[:, 0] - c)
+        state["b"].zero_()
+        info = {}
+        system, A, b, dom = cfx.run_step(lambda: one_step(V, state["cd"], f, state), key=key, info=info)
+        passes.append(info["passes"])
+        cuts.append(int(system.interface_rules.num_rules))
+        check_against_oracle(oracle, om, phi, state["cd"], system, A, b, dom)
+    assert cuts[0] == 0 and cuts[1] == 0 and cuts[2] > 0 and cuts[4] > 0 and cuts[5] == 0, cuts
+    assert all(p <= 2 for p in passes), passes

@@ -646,7 +646,7 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
 }
 
 #ifndef CFX_SOURCE_WAVES
-#define CFX_SOURCE_WAVES 3
+#define CFX_SOURCE_WAVES 4 // (waves per SIMD the source kernels are compiled for: 3 -> 4 took 3.14 -> 2.96 ms at 512^3 in round 4; 5 spills: 4.4 ms)
 #endif
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_source_sin_p1_kernel(VecArgs A)

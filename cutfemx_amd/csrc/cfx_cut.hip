@@ -1047,8 +1047,11 @@ struct EmitJobs
 #else
 #define CFX_EMIT_STORE(dst, val) (dst) = (val)
 #endif
+#ifndef CFX_EMIT_WAVES
+#define CFX_EMIT_WAVES 4 // waves per SIMD the emit kernel is compiled for (112 registers in 3-D without a bound: 4)
+#endif
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) cut_emit_kernel(
+__global__ void __launch_bounds__(kBlock, CFX_EMIT_WAVES) cut_emit_kernel(
     DevN ncut_d, const int32_t* __restrict__ cut_cells, const double* __restrict__ x,
     const int32_t* __restrict__ conn, const int32_t* __restrict__ ls_dofmap, const double* __restrict__ phi_v,
     int degree, EmitJobs jobs)

@@ -388,8 +388,11 @@ __global__ void __launch_bounds__(kBlock) assemble_facets_kernel(AsmArgs A)
 #define CFX_CUT_LANES 4 // 512^3: 16 -> 830 us per launch, 8 -> 500, 4 -> 385, 2 -> 380
 #endif
 constexpr int kCutLanes = CFX_CUT_LANES; // lanes per rule: the points are dealt round-robin (coalesced, balanced), partial tensors folded by shuffles
+#ifndef CFX_CUTP1_WAVES
+#define CFX_CUTP1_WAVES 4 // waves per SIMD (126 registers in 3-D without a bound: 4)
+#endif
 template <int TDIM>
-__global__ void __launch_bounds__(kBlock) cut_tensors_p1_kernel(AsmArgs A)
+__global__ void __launch_bounds__(kBlock, CFX_CUTP1_WAVES) cut_tensors_p1_kernel(AsmArgs A)
 {
   constexpr int ND = TDIM + 1;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;

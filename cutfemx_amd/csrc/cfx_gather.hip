@@ -70,6 +70,9 @@ inline dim3 row_grid(int64_t nblocks)
 #ifndef CFX_VEC_CUT_LANES
 #define CFX_VEC_CUT_LANES 4 // lanes per runtime rule in stage 1 of the linear forms (512^3: 16 -> 887 us, 8 -> 580, 4 -> 469, 2 -> 541)
 #endif
+#ifndef CFX_ROWS_CUT_WAVES
+#define CFX_ROWS_CUT_WAVES 8 // ... and its form without the uncut-cell items (74 registers in 3-D: 5 or 6 -> 1.25, 8 -> 1.16 ms at 512^3)
+#endif
 #ifndef CFX_ROWS_WAVES
 #define CFX_ROWS_WAVES 5 // waves per SIMD the gather kernel is compiled for (measured: 4 -> 2.27, 5 -> 2.09, 6 -> 2.58 ms at 256^3)
 #endif
@@ -415,8 +418,11 @@ __device__ __forceinline__ void entity_vector(const VecArgs& A, int64_t e, int64
   }
 }
 
+#ifndef CFX_VECCUT_WAVES
+#define CFX_VECCUT_WAVES 1
+#endif
 template <int TDIM, int DEG, bool RUNTIME, int LANES = 1, int KSEL = 0>
-__global__ void __launch_bounds__(kBlock, (DEG == 2 && RUNTIME && KSEL != 0) ? 4 : 1) vec_tensors_kernel(VecArgs A)
+__global__ void __launch_bounds__(kBlock, (DEG == 2 && RUNTIME && KSEL != 0) ? 4 : ((DEG == 1 && RUNTIME) ? CFX_VECCUT_WAVES : 1)) vec_tensors_kernel(VecArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   const int64_t tid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1014,7 +1020,7 @@ __global__ void __launch_bounds__(kWave) vec_blocks_rows_kernel(DevN n_d, const 
 // CUTT: the cut cells' contributions come as one staged tensor per cut cell (A.cut_tensors): the per-integral rule
 // lookups, the moments and the closed-form code are not compiled in (degree 2: 157 -> under 128 VGPRs)
 template <int TDIM, int DEG, int G, int CAP, bool ORDERED, bool CUTS = true, bool STD = true, bool CUTT = false>
-__global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4) : 2) : 3) : CFX_ROWS_WAVES) assemble_rows_kernel(RowArgs A)
+__global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4) : 2) : 3) : (STD ? CFX_ROWS_WAVES : CFX_ROWS_CUT_WAVES)) assemble_rows_kernel(RowArgs A)
 {
   constexpr int ND = Elem<TDIM, DEG>::ND;
   constexpr int W = 2 * ND; // widest item: a facet's macro row

@@ -3032,8 +3032,11 @@ struct P2PlainArgs
   int* error;
 };
 
+#ifndef CFX_P2PLAIN_WAVES
+#define CFX_P2PLAIN_WAVES 4
+#endif
 template <int TDIM, int G, int CAP, bool ORDERED>
-__global__ void __launch_bounds__(kWave, 4) assemble_rows_p2_plain_kernel(P2PlainArgs A)
+__global__ void __launch_bounds__(kWave, CFX_P2PLAIN_WAVES) assemble_rows_p2_plain_kernel(P2PlainArgs A)
 {
   constexpr int ND = Elem<TDIM, 2>::ND, RPW = kWave / G;
   __shared__ double s_val[RPW][CAP];

@@ -418,8 +418,11 @@ __device__ __forceinline__ void class_fill(int8_t* __restrict__ domain, int64_t 
 }
 
 // one wavefront per block of kClassBlock cells
+#ifndef CFX_CLASSIFY_WAVES
+#define CFX_CLASSIFY_WAVES 6 // (8: 64 registers with 4 spilled, 1.20 ms at 512^3; 6 or 7: no spill, 1.17)
+#endif
 template <int ND>
-__global__ void __launch_bounds__(kBlock, 8) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
+__global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
                                                                  const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
                                                                  const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
                                                                  int32_t* tiles_inside, int32_t* tiles_cut,

@@ -1492,7 +1492,17 @@ __global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(DevN n_tiles
   const int nst = (int)(__shfl(so, kRowTile, 64) - sb0);
   if (pm == 0xffffu && __ballot(!full) == 0ull && __shfl(io, kRowTile, 64) - ob0 == nst)
   {
-    for (int j = lane; j < nst; j += kWave) indices[ob0 + j] = nbr[sb0 + j];
+    // (eight loads in flight per lane -- a tile of a P1 space on a Kuhn mesh holds ~430 entries: all of them -- where one
+    // load -> store per trip left the wavefront seven dependent latencies long)
+    for (int j0 = 0; j0 < nst; j0 += 8 * kWave)
+    {
+      int32_t v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = j0 + lane + u * kWave < nst ? nbr[sb0 + j0 + lane + u * kWave] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (j0 + lane + u * kWave < nst) indices[ob0 + j0 + lane + u * kWave] = v[u];
+    }
     return;
   }
   if (!live) return;

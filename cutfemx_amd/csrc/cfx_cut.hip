@@ -145,6 +145,26 @@ __global__ void __launch_bounds__(kBlock) sign_codes_kernel(int64_t n, const dou
   code[i] = v < 0.0 ? (uint8_t)1 : (v > 0.0 ? (uint8_t)2 : (uint8_t)0);
 }
 
+// the same, four values per thread: two 16 B loads and one 4 B store per lane (a byte per lane and store reached
+// 4.1 TB/s of the level set at 512^3).  phi and code start on 16 B / 4 B boundaries (checked at the launch); the last
+// n % 4 values go to the last thread one by one.
+__global__ void __launch_bounds__(kBlock) sign_codes4_kernel(int64_t n, const double* __restrict__ phi, uint8_t* __restrict__ code,
+                                                             int32_t* __restrict__ zero_this, int64_t zero_n)
+{
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i < zero_n) zero_this[i] = 0;
+  const int64_t b = 4 * i;
+  if (b >= n) return;
+  auto sign = [](double v) { return v < 0.0 ? 1u : (v > 0.0 ? 2u : 0u); };
+  if (b + 4 <= n)
+  {
+    const double2 p = *reinterpret_cast<const double2*>(phi + b), q = *reinterpret_cast<const double2*>(phi + b + 2);
+    *reinterpret_cast<uint32_t*>(code + b) = sign(p.x) | (sign(p.y) << 8) | (sign(q.x) << 16) | (sign(q.y) << 24);
+    return;
+  }
+  for (int64_t k = b; k < n; ++k) code[k] = (uint8_t)sign(phi[k]);
+}
+
 #ifndef CFX_CLASSIFY_UNROLL
 #define CFX_CLASSIFY_UNROLL 4
 #endif
@@ -2269,8 +2289,15 @@ void classify(cfx_cut_t cut)
         tiles_zeroed = true;
       }
     }
-    launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
-           codes.p, zero_this, zero_n);
+    // (four values per thread when the level set starts on a 16 B boundary and the grid still covers the counters)
+    const int64_t quads = (cut->ls_ndofs + 3) / 4;
+    if ((reinterpret_cast<uintptr_t>(cut->ls_values[k].p) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes.p) & 3) == 0
+        && zero_n <= quads)
+      launch("sign_codes", sign_codes4_kernel, grid_for(quads), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p, codes.p,
+             zero_this, zero_n);
+    else
+      launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
+             codes.p, zero_this, zero_n);
     const uint8_t* phi = codes.p;
     {
       // implicit-structured variant (opt-in): generated box mesh, P1 level set on the geometry dofmap

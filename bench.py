@@ -559,8 +559,18 @@ def measure(n, steps, warmup, order, world, rank, device, profile=True):
         vector=B_VECTOR_PER_ROW_CELL * 4 * info["n_inside"] + 8.0 * nrows,
         deactivate=B_DEACTIVATE_PER_ROW * (nrows - active))
     total_bytes = float(sum(step_bytes.values()))
-    whole_step = dict(algorithmic_bytes=total_bytes, achieved=total_bytes / (out["ms_per_step"] * 1e-3) / 1e9,
-                      peak=HBM_PEAK_GBS, unit="GB/s", frac=total_bytes / (out["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+    # ... and on the bytes of the algorithms the step actually runs: the culled classification does not stream the
+    # connectivity (its own price, `classify_bytes` above), everything else is priced as it is moved already
+    moved_bytes = total_bytes - step_bytes["classify"] + float(classify_bytes)
+    step_s = out["ms_per_step"] * 1e-3
+    whole_step = dict(algorithmic_bytes=total_bytes, achieved=total_bytes / step_s / 1e9,
+                      peak=HBM_PEAK_GBS, unit="GB/s", frac=total_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                      frac_survey_bytes=total_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                      frac_moved_bytes=moved_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                      moved_bytes=moved_bytes,
+                      fractions_are="frac_survey_bytes: SURVEY 8d's bytes per unit for every stage (18.3 B per cell for the "
+                                    "classification, which the block-culled kernel does not move); frac_moved_bytes: the same "
+                                    "sum with the classification priced as the culled algorithm moves it",
                       bytes_by_stage={k: float(v) for k, v in step_bytes.items()},
                       note="SURVEY 8d bytes per unit x units of this step (explicit connectivity), summed over the "
                            "stages, / measured step time; ghost facets and the zero fill priced as the engine moves them "
@@ -961,6 +971,136 @@ def projected_scaling(torch, device, n, order, one_gpu_ms, worlds=(2, 4, 8)):
                                       f"({2 * 8 * (n + 1) ** 2 / 1e6:.1f} MB), RCCL point-to-point over xGMI")
 
 
+LINE_LIMIT = 4096      # the driver's parser lost round 4's 20 kB line: the contract line stays far below that
+
+
+def _r(v, digits=4):
+    """Number rounded to `digits` significant digits (None stays None)."""
+    if v is None or isinstance(v, (bool, str)):
+        return v
+    return float(f"{float(v):.{digits}g}")
+
+
+def _phase_summary(leg):
+    """One-number summaries of a secondary configuration: step time and, per priced phase, the fraction of the HBM
+    roofline on algorithmic bytes and counter traffic / algorithmic bytes."""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": str(leg["error"])[:120]}
+    s = {"ms_per_step": _r(leg.get("ms_per_step"))}
+    for key, short in (("roofline", "matrix"), ("roofline_sparsity", "sparsity")):
+        r = leg.get(key)
+        if r:
+            s[short] = {"ms": _r(r.get("phase_ms")), "frac": _r(r.get("frac")),
+                        "traffic_ratio": _r(r["traffic"] / r["algorithmic_bytes"]) if r.get("traffic") else None}
+    md = leg.get("moving_domain")
+    if isinstance(md, dict) and "incremental" in md:
+        s["moving_create_matrix_ms"] = {"incremental": md["incremental"].get("create_matrix_ms"),
+                                        "full": md["full_rebuild"].get("create_matrix_ms"),
+                                        "reused_share": md["incremental"].get("reused_share")}
+    if "step_mode" in leg:
+        s["step_mode"] = leg["step_mode"]
+    return s
+
+
+def headline_line(out):
+    """The ONE stdout line of the contract: the driver's fields, `roofline`, `cpu_baseline` and one-number summaries of
+    the secondary legs, under LINE_LIMIT bytes.  Everything else is in bench_detail.json (`emit`)."""
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config")}
+    r = out.get("roofline")
+    if r:
+        line["roofline"] = {"bound": r["bound"], "achieved": _r(r.get("achieved")), "peak": r["peak"], "unit": r["unit"],
+                            "frac": _r(r.get("frac")), "traffic": r.get("traffic"), "kernel": r.get("kernel"),
+                            "avg_launch_us": _r(r.get("avg_launch_us")),
+                            "algorithmic_bytes_per_launch": r.get("algorithmic_bytes_per_launch")}
+    else:
+        line["roofline"] = None
+    c = out.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {"value": _r(c["value"]), "unit": c["unit"], "cores": c["cores"], "kind": c["kind"],
+                                "sample": str(c["sample"])[:300], "seconds": _r(c.get("seconds")),
+                                "extrapolated_to_workload_s": _r(c.get("seconds_at_512_extrapolated"))}
+    else:
+        line["cpu_baseline"] = None
+    ca = out.get("cpu_baseline_all_cores")
+    if ca:
+        line["cpu_baseline_all_cores"] = {"value": _r(ca["value"]), "cores": ca["cores"], "kind": ca["kind"]}
+    w = out.get("whole_step_roofline")
+    if w:
+        line["whole_step"] = {"frac_survey_bytes": _r(w.get("frac_survey_bytes")), "frac_moved_bytes": _r(w.get("frac_moved_bytes"))}
+    sm = out.get("step_mode")
+    if sm:
+        line["step_mode"] = {k: sm.get(k) for k in ("sync_free", "passes", "read_backs_per_step", "launches_per_step")}
+    if out.get("phases_ms"):
+        line["phases_ms"] = {k: _r(v) for k, v in out["phases_ms"].items()}
+    if out.get("cut_quadrature_points_per_s"):
+        line["cut_quadrature_points_per_s"] = _r(out["cut_quadrature_points_per_s"])
+    if out.get("multi_gpu"):
+        mg = out["multi_gpu"]
+        line["multi_gpu"] = {k: mg.get(k) for k in ("transport", "rccl_ranks", "world", "slowest_rank_ms_per_step",
+                                                    "imbalance", "exchange_ms", "per_rank_ms_per_step")}
+    sec = {}
+    for name in ("config_128", "config_32"):
+        if isinstance(out.get(name), dict):
+            sec[name] = {"ms_per_step": _r(out[name].get("ms_per_step"))} if "error" not in out[name] else {"error": out[name]["error"][:120]}
+    for name in ("config_p2_gyroid_256", "config_elasticity_share"):
+        if out.get(name) is not None:
+            sec[name] = _phase_summary(out[name])
+    if isinstance(out.get("implicit_structured"), dict):
+        sec["implicit_structured"] = {"ms_per_step": _r(out["implicit_structured"].get("ms_per_step"))}
+    md = out.get("moving_domain")
+    if isinstance(md, dict):
+        sec["moving_domain"] = ({"error": md["error"][:120]} if "error" in md else
+                                {"sync_free_ms": _r(md["sync_free"]["ms_per_step"]),
+                                 "sizes_read_back_ms": _r(md["sizes_read_back"]["ms_per_step"]),
+                                 "read_backs_per_step": md["sync_free"].get("read_backs_per_step")})
+    ps = out.get("projected_scaling")
+    if isinstance(ps, dict):
+        if "error" in ps:
+            sec["projected_scaling"] = {"error": ps["error"][:120]}
+        else:
+            w8 = ps["by_world"].get("8") or {}
+            sec["projected_scaling"] = {"kind": "projection from one GPU, NOT a measured curve",
+                                        "slowest_rank_ms_at_8": w8.get("slowest_rank_ms"),
+                                        "speedup_at_8_no_exchange": _r(w8.get("projected_speedup")),
+                                        "speedup_at_8_with_exchange": _r(w8.get("projected_speedup_with_exchange"))}
+    if sec:
+        line["secondary"] = sec
+    line["detail"] = out.get("detail_file")
+    text = json.dumps(line, separators=(",", ":"))
+    # never let an optional summary push the contract line over the limit
+    for drop in ("secondary", "phases_ms", "cpu_baseline_all_cores", "step_mode", "whole_step"):
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+def emit(out):
+    """Write the full record to bench_detail.json (gpurun_out/ when that directory can be made, next to bench.py
+    otherwise) and to stderr (`# bench_detail: ...`); print the contract line -- alone -- on stdout."""
+    target = None
+    name = os.environ.get("CFX_BENCH_DETAIL", "bench_detail.json")     # (profiling scripts name their own copy)
+    for d in (ROOT / "gpurun_out", ROOT):
+        try:
+            d.mkdir(exist_ok=True)
+            (d / name).write_text(json.dumps(out, indent=1))
+            target = str((d / name).relative_to(ROOT))
+            break
+        except OSError:
+            continue
+    out["detail_file"] = target
+    # (stdout carries the contract line and nothing else: whatever cut round 4's record short -- a cap on the head or
+    # on the tail of the captured stdout -- cannot reach a single line of ~2.5 kB.  The full record goes to stderr.)
+    if os.environ.get("CFX_BENCH_PRINT_DETAIL", "1") != "0":
+        sys.stderr.write("# bench_detail: " + json.dumps(out) + "\n")
+        sys.stderr.flush()
+    print(headline_line(out), flush=True)
+
+
 def main():
     args = parse()
     if args.cpu_worker:
@@ -1104,7 +1244,7 @@ def main():
         # other ranks wait in destroy_process_group)
         out["cpu_baseline"] = None if args.no_cpu else cpu_baseline(args.cpu_n, args.order)
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 

@@ -116,3 +116,66 @@ def test_scale_line_names_its_transport():
     class Host:
         transport, rccl_ranks, fallback_reason = "host-staged", 0, "rehearsal"
     assert bench.scale_fields(Host(), 2, [1.0, 1.0], 0.5)["transport"] == "host-staged"
+
+
+def _canned_record():
+    """A full bench record of the shape `bench.main` builds (round 4's committed one), with the fields round 5 added."""
+    import json
+    rec = json.loads((ROOT / "profiles" / "r04_default_bench.json").read_text())
+    rec["whole_step_roofline"].update(frac_survey_bytes=0.29, frac_moved_bytes=0.22)
+    rec["detail_file"] = "gpurun_out/bench_detail.json"
+    return rec
+
+
+def test_the_contract_line_is_short_and_carries_roofline_and_cpu_baseline():
+    """BENCH_r04.json.parsed was null: the one stdout line had grown to 20 kB.  The line the driver parses is now the
+    contract fields + roofline + cpu_baseline + one-number summaries, under 4 kB whatever the legs report."""
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    rec = _canned_record()
+    line = bench.headline_line(rec)
+    assert "\n" not in line and len(line) < bench.LINE_LIMIT == 4096
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["value"] == rec["value"] and d["ms_per_step"] == rec["ms_per_step"]
+    assert d["dtype"] == "f64" and d["vs_baseline"] is None and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "DOF/s" and c["value"] > 0 and c["sample"]
+    assert d["whole_step"] == {"frac_survey_bytes": 0.29, "frac_moved_bytes": 0.22}
+    s = d["secondary"]
+    assert s["config_p2_gyroid_256"]["sparsity"]["traffic_ratio"] > 1 and s["config_elasticity_share"]["matrix"]["frac"] > 0
+    assert "NOT a measured" in s["projected_scaling"]["kind"]
+    # legs that failed, exploded in size or are absent never break the line
+    rec["config_p2_gyroid_256"] = {"error": "RuntimeError: " + "x" * 5000}
+    rec["cpu_baseline"]["sample"] = "y" * 10000
+    rec["config"]["workload"] = rec["config"]["workload"] * 3
+    line = bench.headline_line(rec)
+    assert len(line) < 4096 and json.loads(line)["roofline"]["frac"] > 0
+    for k in ("config_128", "config_32", "moving_domain", "projected_scaling", "implicit_structured",
+              "config_elasticity_share", "cpu_baseline_all_cores", "whole_step_roofline", "step_mode", "phases_ms"):
+        rec.pop(k, None)
+    d = json.loads(bench.headline_line(rec))
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0
+
+
+def test_emit_prints_one_stdout_line_and_writes_the_detail_file(tmp_path, monkeypatch, capsys):
+    import json
+    sys.path.insert(0, str(ROOT))
+    import bench
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    rec = _canned_record()
+    bench.emit(rec)
+    cap = capsys.readouterr()
+    lines = cap.out.strip().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    d = json.loads(lines[0])
+    assert d["detail"] == "gpurun_out/bench_detail.json"
+    full = json.loads((tmp_path / "gpurun_out" / "bench_detail.json").read_text())
+    assert full["kernels"] and full["value"] == d["value"]
+    assert cap.err.startswith("# bench_detail: ")

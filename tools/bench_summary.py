@@ -2,7 +2,8 @@
 import json
 import sys
 
-d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+t = open(sys.argv[1]).read().strip()
+d = json.loads(t if t.startswith("{\n") else t.splitlines()[-1])   # bench_detail.json (indented) or a one-line record
 print(f"{d['ms_per_step']:.3f} ms/step  {d['value']:.4e} {d['unit']}  phases {d.get('phases_ms')}")
 r = d.get("roofline", {})
 print("roofline", r.get("kernel"), r.get("achieved"), r.get("frac"), "traffic", r.get("traffic"))

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 strip() { sed -e 's#/tmp/code/[^ ]*/repo/##g' -e 's#/root/repo/##g' "$1" > "$2"; }
 strip gpurun_out/pmc_${TAG}_summary.txt profiles/${TAG}_n512_pmc_summary.txt
 cp "$(find gpurun_out/prof_${TAG} -name '*kernel_stats.csv' -printf '%T@ %p\n' | sort -n | tail -1 | cut -d' ' -f2-)" profiles/${TAG}_n512_kernel_stats.csv   # (the newest: gpurun_out keeps earlier runs)
-cp gpurun_out/prof_${TAG}_bench.json profiles/${TAG}_n512_bench_under_rocprof.json
+cp gpurun_out/prof_${TAG}_bench_detail.json profiles/${TAG}_n512_bench_under_rocprof.json
 python3 tools/pmc_traffic.py profiles/${TAG}_n512_pmc_summary.txt 512 ${TAG}
 for c in cfg4 cfg5; do
   strip gpurun_out/pmc_${TAG}_${c}_summary.txt profiles/${TAG}_${c}_pmc_summary.txt

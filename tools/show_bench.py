@@ -3,7 +3,8 @@ import json
 import sys
 
 for f in sys.argv[1:]:
-    d = json.loads(open(f).read().strip().splitlines()[-1])
+    t = open(f).read().strip()
+    d = json.loads(t if t.startswith("{\n") else t.splitlines()[-1])   # bench_detail.json (indented) or a one-line record
     sm = d.get("step_mode") or {}
     ps = ((d.get("projected_scaling") or {}).get("by_world") or {}).get("8") or {}
     print(f, "ms/step", round(d["ms_per_step"], 4), "value", f"{d['value']:.4g}", "launches", sm.get("launches_per_step"),

@@ -354,6 +354,10 @@ void step_require_positive(const Count& c, int code, const char* message);
 Count count_sum(const char* name, const Count& a, const Count& b); // a + b: exact, or published when one is pending
 bool step_speculative();      // inside a step whose sizes come from the previous one
 const int64_t* step_poison(); // the pool's poison word (nullptr outside speculative steps)
+// `fn` runs if the open speculative step ends void or is aborted (state kept across steps that the step wrote must not
+// survive it); `step_forget_owner` withdraws an owner's hooks when the owner dies first
+void step_on_void(const void* owner, std::function<void()> fn);
+void step_forget_owner(const void* owner);
 // error words of assembly calls: inside a step they are read with the slots at cfx_step_end (the call returns at
 // once), outside they are read back by the caller as before
 int* step_error_flag(int code, const char* message, void (*decode)(int) = nullptr); // nullptr outside a step
@@ -758,7 +762,7 @@ struct cfx_space_s
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
   cfx::VecBlocks vblocks; // built on first use by cfx::space_vec_blocks()
   cfx_pattern_cache pcache;          // previous pattern of this space (row reuse in moving-domain loops)
-  ~cfx_space_s() { pcache.drop(); }
+  ~cfx_space_s() { cfx::step_forget_owner(this); pcache.drop(); }
   bool lists_short_overflow = false; // a short-list row overflowed the 128-slot set once: hashed rows all go wide
   bool long_rows = false; // a sparsity build of this space overflowed the 63-entry row sets: start with the wide kernel
   const cfx::Adjacency& dof_cells()

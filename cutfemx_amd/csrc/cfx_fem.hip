@@ -2194,7 +2194,9 @@ int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const in
       if (values && values[k]) { d_v[k] = to_device(values[k], nnz_k); B.values[j] = d_v[k].p; }
     }
   }
-  int64_t* ip = static_cast<int64_t*>(dev_alloc(sizeof(int64_t) * (size_t)(total_rows + 1)));
+  // (outputs are owned here until the call has succeeded: a later throw frees them)
+  DevArray<int64_t> ip_out(total_rows + 1);
+  int64_t* ip = ip_out.p;
   DevArray<int64_t> len(total_rows);
   int64_t r0 = 0;
   for (int i = 0; i < nbr; ++i)
@@ -2205,8 +2207,11 @@ int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const in
   }
   exclusive_scan(len.p, ip, total_rows);
   const int64_t nnz = read_scalar(ip + total_rows);
-  int32_t* ix = static_cast<int32_t*>(dev_alloc(sizeof(int32_t) * (size_t)(nnz > 0 ? nnz : 1)));
-  double* vals = out_values ? static_cast<double*>(dev_alloc(sizeof(double) * (size_t)(nnz > 0 ? nnz : 1))) : nullptr;
+  DevArray<int32_t> ix_out(nnz);
+  DevArray<double> vals_out;
+  if (out_values) vals_out.alloc(nnz);
+  int32_t* ix = ix_out.p;
+  double* vals = vals_out.p;
   r0 = 0;
   for (int i = 0; i < nbr; ++i)
   {
@@ -2215,6 +2220,9 @@ int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const in
              vals);
     r0 += nrows[i];
   }
+  // the fill kernels are done before the caller sees the arrays (torch may read them on another stream)
+  end_of_call_sync();
+  ip_out.owned = false; ix_out.owned = false; vals_out.owned = false;   // handed to the caller (cfx_device_free)
   *out_indptr = ip;
   *out_indices = ix;
   if (out_values) *out_values = vals;

@@ -2846,6 +2846,10 @@ void pattern_remember(cfx_form_s* a, cfx_pattern_s* P)
   pc.live = P;
   P->cache_owner = V;
   pc.valid = true;
+  // built inside a speculative step: provisional until the step ends -- a void step leaves `indptr` / `indices` partial
+  // or uninitialised (every kernel after the poisoning saw length 0) while the cell signature is mostly the right one,
+  // and the repeat would copy "clean" rows out of it
+  if (step_speculative()) step_on_void(V, [V]() { V->pcache.drop(); });
 }
 
 void build_pattern_rectangular(cfx_form_s* a, cfx_pattern_s* P)

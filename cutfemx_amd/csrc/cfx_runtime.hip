@@ -162,6 +162,10 @@ struct StepState
   std::vector<Positive> positives;
   int next_err = 1, next_slot = kCountFirstSlot;
   int64_t published = 0, read_back = 0; // sites of this step by kind (diagnostics)
+  // state kept ACROSS steps that this step wrote while speculative (a space's remembered pattern): undone when the
+  // step turns out void or is aborted -- what a void step built is partial or uninitialised by design
+  struct Undo { const void* owner; std::function<void()> fn; };
+  std::vector<Undo> undo;
 };
 StepState& step()
 {
@@ -313,8 +317,12 @@ int error_in_step(int code)
 {
   StepState& st = step();
   if (!st.active || !st.spec || code == CFX_ERR_STEP_VOID) return code;
-  int64_t poison = 0;
-  if (hipMemcpy(&poison, count_pool(), sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return code;
+  // ordered after the publishing kernels still queued on the engine's stream (a caller's stream is non-blocking: a
+  // null-stream copy would not wait for them), as cfx_step_end reads the pool
+  int64_t* host = count_mirror();
+  if (hipMemcpyAsync(host, count_pool(), sizeof(int64_t), hipMemcpyDeviceToHost, ctx().main_stream) != hipSuccess) return code;
+  if (hipStreamSynchronize(ctx().main_stream) != hipSuccess) return code;
+  const int64_t poison = host[0];
   if (poison == 0) return code;
   g_last_error = "the step is void (a count did not fit the capacity taken from the previous step): end it and repeat it"
                  " [while void: " + g_last_error + "]";
@@ -322,6 +330,16 @@ int error_in_step(int code)
 }
 
 bool step_speculative() { return step().active && step().spec && !ctx().overlap; }
+void step_on_void(const void* owner, std::function<void()> fn)
+{
+  if (step().active && step().spec) step().undo.push_back({owner, std::move(fn)});
+}
+void step_forget_owner(const void* owner)
+{
+  auto& u = step().undo;
+  for (size_t k = u.size(); k-- > 0;)
+    if (u[k].owner == owner) u.erase(u.begin() + (long)k);
+}
 const int64_t* step_poison() { return step_speculative() ? count_pool() : nullptr; }
 
 int* step_error_flag(int code, const char* message, void (*decode)(int))
@@ -1216,7 +1234,10 @@ int cfx_step_end(int* redo, int64_t* published, int64_t* read_back)
   if (read_back) *read_back = st.read_back;
   const std::vector<StepState::Err> errors = std::move(st.errors);
   const std::vector<StepState::Positive> positives = std::move(st.positives);
+  const std::vector<StepState::Undo> undo = std::move(st.undo);
   st = StepState();
+  if (poisoned)
+    for (const auto& u : undo) u.fn();
   if (!poisoned)
   {
     for (const auto& e : errors)
@@ -1265,7 +1286,9 @@ int cfx_step_abort(void)
     for (auto& p : st.pending)
       if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
     histories()[st.key].valid = false;
+    const std::vector<StepState::Undo> undo = std::move(st.undo);
     st = StepState();
+    for (const auto& u : undo) u.fn();
   }
   CFX_API_END
 }

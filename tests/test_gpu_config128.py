@@ -109,3 +109,122 @@ def test_cfg128_takes_the_specialised_kernels(cfg):
               "pattern_plain_write", "pattern_rows") + vec:   # (the plan and its masks are cached)
         assert k in names, (k, sorted(names))
     assert "assemble_rows_plain" not in names and "assemble_rows" not in names    # per-row fallback / unsplit path
+
+
+# --------------------------------------------------------------------------- the step bench.py times, at size
+def _sphere(torch, x, centre, radius=0.31):
+    c = torch.tensor(centre, device=x.device, dtype=torch.float64)
+    return torch.linalg.norm(x - c, dim=1) - radius
+
+
+def test_cfg128_sync_free_steps_of_the_bench_match_the_whole_oracle(oracle):
+    """The path `bench.py` times is `cutfemx_amd.run_step(hot_path_step)`: capacity-sized grids, `dev_n` early exits,
+    counts published by the scans, values stored into a caller's buffer after a fused `set_value(0)`.  Here the same
+    function runs as three steps of a loop whose sphere moves 0.3 h per step (python/demo/demo_moving_poisson.py:53-67);
+    the third step -- speculative, sized by the second -- is compared with the whole-mesh oracle as
+    `test_cfg128_csr_and_rhs` compares the plain sequence."""
+    import sys
+    from pathlib import Path
+
+    import torch
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    O = oracle
+    om = O.mesh_box(3, N)
+    mesh = cfx.Mesh.create_box(3, N)
+    V = cfx.FunctionSpace(mesh, 1)
+    dev = torch.device("cuda", 0)
+    xt = torch.tensor(om.x, device=dev)
+    phi = torch.empty(om.nnodes, device=dev, dtype=torch.float64)
+    f = cfx.Function(V, phi)
+    values = torch.full((int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000),), 7.0e33, device=dev, dtype=torch.float64)
+    b = torch.zeros(mesh.num_nodes, device=dev, dtype=torch.float64)
+    key = "test-cfg128-bench-step"
+    cfx.forget_step_history(key)
+    infos = []
+    for k in range(3):
+        phi.copy_(_sphere(torch, xt, (0.47 + 0.3 * k / N, 0.43, 0.41)))       # in place: the engine aliases this array
+        values.fill_(7.0e33)                                                   # stale values must all be overwritten
+        info = {}
+        res = cfx.run_step(lambda: bench.hot_path_step(cfx, poisson, V, f, values, b, 4, None, False), key=key, info=info)
+        infos.append(info)
+    import os
+    speculates = os.environ.get("CFX_STEP_SPECULATE") != "0"
+    if speculates:
+        assert infos[0]["published"] == 0, infos
+        assert all(i["published"] > 5 and i["passes"] == 1 for i in infos[1:]), infos
+    ref = oracle_poisson(O, om, phi.cpu().numpy(), order=4)
+    vals, bb = ref["values"].copy(), ref["b"].copy()
+    O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, bb)
+    sysm, A = res.system, res.A
+    assert np.array_equal(sysm.cut_data.domain(), ref["domain"])
+    c = res.counts()
+    assert c["n_inside"] == len(ref["inside"]) and c["n_cut"] == len(ref["itf"].parent_map)
+    assert c["nq_volume"] == len(ref["vol"].weights) and c["nq_interface"] == len(ref["itf"].weights)
+    assert c["n_ghost"] == len(ref["ghost"]) and c["nnz"] == len(ref["indices"])
+    assert c["active_dofs"] == om.nnodes - len(ref["inactive"])
+    for got, want in ((sysm.volume_rules, ref["vol"]), (sysm.interface_rules, ref["itf"])):
+        assert np.array_equal(got.offsets, want.offsets) and np.array_equal(got.parent_map, want.parent_map)
+        assert np.abs(got.points - want.points).max() <= 1e-14 and rel_err(got.weights, want.weights) < RTOL
+    assert np.array_equal(sysm.ghost_facets.rows, ref["ghost"])
+    assert np.array_equal(A.indptr, ref["indptr"]) and np.array_equal(A.indices, ref["indices"])
+    assert rel_err(A.data, vals) < RTOL
+    rowmax = np.maximum(np.maximum.reduceat(np.abs(vals), ref["indptr"][:-1]), 1e-300)
+    rows = np.repeat(np.arange(A.nrows), np.diff(ref["indptr"]))
+    assert np.all(np.abs(A.data - vals) <= RTOL * rowmax[rows])
+    assert rel_err(b.cpu().numpy(), bb) < RTOL
+    assert np.array_equal(res.dom.inactive_dofs, ref["inactive"])
+    # the caller's buffer IS the matrix: nothing stale behind the stored rows
+    assert float(values[:c["nnz"]].abs().max()) < 1e30
+
+
+def test_cfg128_slab_steps_while_the_interface_leaves_and_returns(oracle):
+    """One rank's kind of mesh (a 128 x 128 x 12 slab of the 128^3 box) in sync-free steps while the sphere moves out of
+    the slab and back: steps with no cut cell, no rule and no ghost facet between steps that have them.  The step in
+    which the interface re-enters finds capacities of 0, is void and repeated; every step equals the oracle."""
+    import sys
+    from pathlib import Path
+
+    import torch
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    import bench
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    O = oracle
+    z0, nz = 96, 12
+    mesh = cfx.Mesh.create_slab(N, z0, nz)
+    om = O.Mesh(3, mesh.x, mesh.conn)
+    V = cfx.FunctionSpace(mesh, 1)
+    dev = torch.device("cuda", 0)
+    xt = torch.tensor(om.x, device=dev)
+    phi = torch.empty(om.nnodes, device=dev, dtype=torch.float64)
+    f = cfx.Function(V, phi)
+    values = torch.zeros(60 * om.nnodes, device=dev, dtype=torch.float64)
+    b = torch.zeros(om.nnodes, device=dev, dtype=torch.float64)
+    key = "test-cfg128-slab-leave"
+    cfx.forget_step_history(key)
+    cuts, passes = [], []
+    # slab z in [0.75, 0.84375]; the sphere of radius 0.31 around z = cz reaches z = cz + 0.31 and cuts it; with
+    # radius 2 the whole slab is inside (an all-outside slab has no active cell: active_domain raises, as the reference)
+    for cz, radius in ((0.50, 0.31), (0.50 - 0.3 / N, 0.31), (0.50, 2.0), (0.50, 2.0 + 0.3 / N), (0.47, 0.31),
+                       (0.47 + 0.3 / N, 0.31)):
+        phi.copy_(_sphere(torch, xt, (0.47, 0.43, cz), radius))
+        info = {}
+        res = cfx.run_step(lambda: bench.hot_path_step(cfx, poisson, V, f, values, b, 4, None, False), key=key, info=info)
+        passes.append(info["passes"])
+        ref = oracle_poisson(O, om, phi.cpu().numpy(), order=4)
+        vals, bb = ref["values"].copy(), ref["b"].copy()
+        O.deactivate(ref["inactive"], ref["indptr"], ref["indices"], vals, bb)
+        cuts.append(len(ref["itf"].parent_map))
+        assert np.array_equal(res.system.cut_data.domain(), ref["domain"])
+        assert res.counts()["n_cut"] == cuts[-1] and res.counts()["nnz"] == len(ref["indices"])
+        assert np.array_equal(res.A.indptr, ref["indptr"]) and np.array_equal(res.A.indices, ref["indices"])
+        assert rel_err(res.A.data, vals) < RTOL and rel_err(b.cpu().numpy(), bb) < RTOL
+        assert np.array_equal(res.dom.inactive_dofs, ref["inactive"])
+        del res
+    assert cuts[0] > 1000 and cuts[2] == 0 and cuts[3] == 0 and cuts[4] > 1000, cuts
+    assert all(p <= 2 for p in passes), passes

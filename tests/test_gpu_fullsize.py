@@ -297,6 +297,60 @@ class TestConfig3:
         assert np.array_equal(mine, want)
 
 
+    def test_cfg3_sync_free_steps_of_the_bench_match_the_plain_sequence_and_the_oracle_slab(self, sphere512, oracle):
+        """The 512^3 number of bench.py is a sync-free step (`cutfemx_amd.run_step(hot_path_step)`: grids sized by the
+        previous step's counts, lengths read from HBM, the three-launch count / scan / write chains of meshes with more
+        than 512 tiles per site, values stored into the caller's buffer).  Two such steps; the SECOND one -- the
+        speculative kind the bench times -- must give the counts and the `indptr` of the plain sequence exactly, and
+        the rows of two vertex planes must match the oracle slab as `test_cfg3_plane_rows_match_oracle_slab` asks."""
+        import sys
+        from pathlib import Path
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+        import bench
+        from cutfemx_amd import poisson
+        s, torch = sphere512, _torch()
+        cfx, n, dev, mesh, V = s["cfx"], s["n"], s["dev"], s["mesh"], s["V"]
+        values = torch.full((int(mesh.num_nodes) + 40 * int(0.2 * mesh.num_nodes + 100000),), 3.0e33, device=dev,
+                            dtype=torch.float64)
+        b = torch.zeros(mesh.num_nodes, device=dev, dtype=torch.float64)
+        f = cfx.Function(V, s["phi"])
+        key = "test-cfg3-bench-step"
+        cfx.forget_step_history(key)
+        infos = []
+        for k in range(2):
+            info = {}
+            res = cfx.run_step(lambda: bench.hot_path_step(cfx, poisson, V, f, values, b, 4, None, False), key=key, info=info)
+            infos.append(info)
+            if k == 0:
+                del res
+        import os
+        if os.environ.get("CFX_STEP_SPECULATE") != "0":
+            assert infos[1]["published"] > 5 and infos[1]["passes"] == 1, infos
+        c, sysm = res.counts(), s["system"]
+        assert c["nnz"] == s["A"].nnz and c["n_inside"] == sysm.inside_cells.size
+        assert c["n_cut"] == sysm.interface_rules.num_rules and c["n_vol_rules"] == sysm.volume_rules.num_rules
+        assert c["nq_volume"] == sysm.volume_rules.total_points and c["nq_interface"] == sysm.interface_rules.total_points
+        assert c["n_ghost"] == sysm.ghost_facets.size
+        ip_a, _, _ = res.A.torch_views(dev)
+        ip_b, _, _ = s["A"].torch_views(dev)
+        assert bool(torch.equal(ip_a, ip_b))
+        assert float(values[:c["nnz"]].abs().max()) < 1e30          # nothing stale behind the stored rows
+        full = Numbering(n, 0, n, 1)
+        bh = b.cpu().numpy()
+        plain_dom = cfx.fem.active_domain(sysm.a)
+        for k0 in (210, 366):
+            z0, nz = k0 - 3, 6
+            om, phi = oracle_slab(oracle, cfx, n, z0, nz, "sphere", dev)
+            o = oracle_poisson(oracle, om, phi)
+            oracle.deactivate(o["inactive"], o["indptr"], o["indices"], o["values"], o["b"])   # the step deactivates
+            # (rows of the plane are complete in the slab; their inactive set is the slab's restricted to the plane)
+            nnz = compare_plane(res.A, bh, full, o, Numbering(n, z0, nz, 1), k0)
+            assert nnz > (n + 1) ** 2
+            c0, c1 = 6 * n * n * z0, 6 * n * n * (z0 + nz)
+            assert np.array_equal(res.system.cut_data.domain()[c0:c1], o["domain"])
+        assert res.dom.num_active_dofs == plain_dom.num_active_dofs
+        del res
+
     def test_cfg3_size_independent_properties(self, sphere512):
         s, torch = sphere512, _torch()
         cfx, dev, sysm, V = s["cfx"], s["dev"], s["system"], s["V"]

@@ -346,6 +346,21 @@ inline Count count_site(const char* name, const void* src, int kind = kCountI64,
 // cfx_integral / cfx_cut_* arguments -- the library recognises its own list and takes the published length
 void list_register(const void* p, const Count& c);
 void list_unregister(const void* p);
+// Provenance of a located entity list: "the cells of cut `cut` (classification number `gen`) whose domain value of
+// level set 0 is `value`" -- what lets a row plan derive the marks of such a list from the classification instead of
+// walking the list (cfx::row_plan, bulk tiles).  Keyed by the list's address; `serial` = the library block behind it
+// (addresses are recycled, serials are not).  Forgotten when the cut classifies again or dies.
+struct ListProvenance
+{
+  const struct ::cfx_cut_s* cut = nullptr;
+  uint64_t gen = 0;
+  int value = 0;
+  uint64_t serial = 0;
+  int64_t n = 0; // elements of the list as handed out (its capacity while the length is in HBM)
+};
+void provenance_register(const void* p, const struct ::cfx_cut_s* cut, uint64_t gen, int value, int64_t n);
+const ListProvenance* provenance_lookup(const void* p); // nullptr: unknown, or the block behind p is another one now
+void provenance_forget_cut(const struct ::cfx_cut_s* cut);
 Count list_lookup(const void* p, int64_t n_given);
 void step_record(const char* name, int64_t value); // a total the host obtained by other means: keeps the step's site
                                                    // sequence equal to the one of a step that publishes it
@@ -720,6 +735,15 @@ struct cfx_cut_s
   // per block of kClassBlock cells of level set 0: 1 all inside, 2 all outside, 0 mixed (written by the culled
   // classification; empty when the cell-by-cell kernel ran): the selector scan skips what it names
   cfx::DevArray<uint8_t> block_class;
+  // sign codes of level set 0 (1 negative, 2 positive, 0 zero: sign_codes_kernel), kept after the classification when
+  // the level set lives on the geometry dofmap: a row plan classifies whole row tiles from them (cfx::row_plan)
+  cfx::DevArray<uint8_t> codes0;
+  // ... and one byte per dof of level set 0, set on the dofs of every cut cell (by the classification kernels that
+  // visit the cut cells one by one; touch_valid says whether the last classification did)
+  cfx::DevArray<uint8_t> touch0;
+  bool touch_valid = false;
+  uint64_t gen = 0; // classification number of this cut (provenance of its located lists)
+  ~cfx_cut_s() { cfx::provenance_forget_cut(this); }
   std::map<std::string, cfx::DevArray<int32_t>> located;
   std::map<std::string, cfx::DevArray<int32_t>> ghost_rows;
   // facet hosts (cut(level_set, facets, tdim-1), cut.cpp:540-591): the hosts are n_hosts facets of the mesh;
@@ -794,6 +818,13 @@ struct cfx_row_plan
   bool built = false;
   bool usable = false;             // row-gather assembly is legal for this form
   cfx::DevArray<uint8_t> mark_block; // cellmark | rowmark | special_mark in one block (one zero fill per plan)
+  // Bulk rows (P1 on the geometry dofmap, the uncut entities = a located list of the cut whose level set lives on the
+  // same dofmap): class of every row from its vertex's sign code and the cut's touch byte -- 1: every cell around the row
+  // is an uncut entity (row active, stencil complete, nothing gathered), 0: no cell around it is an entity or cut, 2:
+  // look at the marks.  Cell marks then come from the classification bytes, not from a walk over the 10^8-entry list.
+  cfx::DevArray<uint8_t> rowcls;
+  bool bulk = false;
+  uint8_t bulk_bits = 0; // mark bits of the cell integrals whose uncut entities are that list
   cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
   cfx::DevArray<uint8_t> cellsig;  // bit 0: cellmark != 0; bit 1 + lf: side lf of the cell is a facet of the form (built on
                                    // first use by cfx::plan_cell_signature: what a row's column set depends on)

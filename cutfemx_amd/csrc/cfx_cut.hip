@@ -135,21 +135,25 @@ struct SelectorPred
 // table (135 MB at 512^3) stays in the Infinity Cache where the 1.1 GB of doubles does not.
 // (zero_n > 0: the first zero_n threads also clear the per-tile counters of the classification that follows -- a fill
 // launch less per step)
+// (touch, optional: one byte per level-set dof, cleared here and set by the classification on the dofs of every cut cell)
 __global__ void __launch_bounds__(kBlock) sign_codes_kernel(int64_t n, const double* __restrict__ phi, uint8_t* __restrict__ code,
-                                                            int32_t* __restrict__ zero_this, int64_t zero_n)
+                                                            int32_t* __restrict__ zero_this, int64_t zero_n,
+                                                            uint8_t* __restrict__ touch)
 {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < zero_n) zero_this[i] = 0;
   if (i >= n) return;
   const double v = phi[i];
   code[i] = v < 0.0 ? (uint8_t)1 : (v > 0.0 ? (uint8_t)2 : (uint8_t)0);
+  if (touch) touch[i] = 0;
 }
 
 // the same, four values per thread: two 16 B loads and one 4 B store per lane (a byte per lane and store reached
 // 4.1 TB/s of the level set at 512^3).  phi and code start on 16 B / 4 B boundaries (checked at the launch); the last
 // n % 4 values go to the last thread one by one.
 __global__ void __launch_bounds__(kBlock) sign_codes4_kernel(int64_t n, const double* __restrict__ phi, uint8_t* __restrict__ code,
-                                                             int32_t* __restrict__ zero_this, int64_t zero_n)
+                                                             int32_t* __restrict__ zero_this, int64_t zero_n,
+                                                             uint8_t* __restrict__ touch)
 {
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i < zero_n) zero_this[i] = 0;
@@ -160,9 +164,14 @@ __global__ void __launch_bounds__(kBlock) sign_codes4_kernel(int64_t n, const do
   {
     const double2 p = *reinterpret_cast<const double2*>(phi + b), q = *reinterpret_cast<const double2*>(phi + b + 2);
     *reinterpret_cast<uint32_t*>(code + b) = sign(p.x) | (sign(p.y) << 8) | (sign(q.x) << 16) | (sign(q.y) << 24);
+    if (touch) *reinterpret_cast<uint32_t*>(touch + b) = 0u; // (as aligned as the codes: checked at the launch)
     return;
   }
-  for (int64_t k = b; k < n; ++k) code[k] = (uint8_t)sign(phi[k]);
+  for (int64_t k = b; k < n; ++k)
+  {
+    code[k] = (uint8_t)sign(phi[k]);
+    if (touch) touch[k] = 0;
+  }
 }
 
 #ifndef CFX_CLASSIFY_UNROLL
@@ -171,7 +180,8 @@ __global__ void __launch_bounds__(kBlock) sign_codes4_kernel(int64_t n, const do
 template <int ND>
 __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const int32_t* __restrict__ dofmap,
                                                           const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
-                                                          int32_t* tiles_inside, int32_t* tiles_cut)
+                                                          int32_t* tiles_inside, int32_t* tiles_cut,
+                                                          uint8_t* __restrict__ touch = nullptr)
 {
   // U cells per thread, a block-wide stride apart: U independent 16 B/lane streaming loads in
   // flight per lane before the first dependent level-set gather
@@ -207,6 +217,11 @@ __global__ void __launch_bounds__(kBlock) classify_kernel(int64_t ncells, const 
     domain[c] = all == 1u ? (int8_t)CFX_INSIDE : (all == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
     n_in += all == 1u ? 1 : 0;
     n_cut += (all != 1u && all != 2u) ? 1 : 0;
+    if (touch && all != 1u && all != 2u) // (a cut cell: its dofs are next to the interface; every writer stores 1)
+    {
+#pragma unroll
+      for (int i = 0; i < ND; ++i) touch[d[u][i]] = 1;
+    }
   }
   // the two selector scans every solve starts with ("phi<0", "phi=0") get their tile counts here
   if (tiles_inside)
@@ -446,7 +461,7 @@ __global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_ke
                                                                  const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
                                                                  const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
                                                                  int32_t* tiles_inside, int32_t* tiles_cut,
-                                                                 uint8_t* __restrict__ block_class)
+                                                                 uint8_t* __restrict__ block_class, uint8_t* __restrict__ touch)
 {
   constexpr int SUB = kClassBlock / kClassSub, U = SUB / 64;
   static_assert(kByteTile % kClassBlock == 0, "classification blocks must nest in compaction tiles");
@@ -508,6 +523,11 @@ __global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_ke
       domain[c] = a == 1u ? (int8_t)CFX_INSIDE : (a == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
       n_in += a == 1u ? 1 : 0;
       n_cut += (a != 1u && a != 2u) ? 1 : 0;
+      if (touch && a != 1u && a != 2u) // (a cut cell: its dofs are next to the interface; every writer stores 1)
+      {
+#pragma unroll
+        for (int i = 0; i < ND; ++i) touch[d[u][i]] = 1;
+      }
     }
   }
   if (tiles_inside)
@@ -2271,10 +2291,20 @@ void classify(cfx_cut_t cut)
 {
   const int64_t nc = cut->nhosts();
   cut->block_class.release(); // (set again by the culled classification of level set 0)
+  ++cut->gen;                 // the located lists of the previous classification lose their provenance
+  provenance_forget_cut(cut);
   for (int k = 0; k < cut->nls; ++k)
   {
     int8_t* dom = cut->domain.p + (int64_t)k * nc;
-    DevArray<uint8_t> codes(cut->ls_ndofs);
+    // (the codes of level set 0 stay with the cut: a row plan classifies row tiles from them)
+    // ... next to one byte per level-set dof that the classification sets on the dofs of every cut cell: a dof with
+    // a negative (positive) value and no cut cell around it has only inside (outside) cells around it)
+    DevArray<uint8_t> codes_k;
+    if (k == 0 && cut->codes0.n != cut->ls_ndofs) { cut->codes0.alloc(cut->ls_ndofs); cut->touch0.alloc(cut->ls_ndofs); }
+    if (k != 0) codes_k.alloc(cut->ls_ndofs);
+    struct { uint8_t* p; } codes{k == 0 ? cut->codes0.p : codes_k.p};
+    uint8_t* touch = k == 0 ? cut->touch0.p : nullptr;
+    if (k == 0) cut->touch_valid = false;
     // (the per-tile counters of level set 0 are cleared by the same launch when they fit its grid)
     bool tiles_zeroed = false;
     int32_t* zero_this = nullptr;
@@ -2292,12 +2322,12 @@ void classify(cfx_cut_t cut)
     // (four values per thread when the level set starts on a 16 B boundary and the grid still covers the counters)
     const int64_t quads = (cut->ls_ndofs + 3) / 4;
     if ((reinterpret_cast<uintptr_t>(cut->ls_values[k].p) & 15) == 0 && (reinterpret_cast<uintptr_t>(codes.p) & 3) == 0
-        && zero_n <= quads)
+        && (reinterpret_cast<uintptr_t>(touch) & 3) == 0 && zero_n <= quads)
       launch("sign_codes", sign_codes4_kernel, grid_for(quads), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p, codes.p,
-             zero_this, zero_n);
+             zero_this, zero_n, touch);
     else
       launch("sign_codes", sign_codes_kernel, grid_for(cut->ls_ndofs), dim3(kBlock), 0, cut->ls_ndofs, cut->ls_values[k].p,
-             codes.p, zero_this, zero_n);
+             codes.p, zero_this, zero_n, touch);
     const uint8_t* phi = codes.p;
     {
       // implicit-structured variant (opt-in): generated box mesh, P1 level set on the geometry dofmap
@@ -2359,20 +2389,22 @@ void classify(cfx_cut_t cut)
         const dim3 cgrid((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64)));
         uint8_t* bclass = nullptr;
         if (k == 0 && t_in != nullptr) { cut->block_class.alloc(nb); bclass = cut->block_class.p; }
-        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass);
-        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass);
+        if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass, touch);
+        else launch("classify", classify_culled_kernel<3>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass, touch);
+        if (k == 0) cut->touch_valid = true;
         continue;
       }
     }
     switch (cut->ls_ndofs_cell)
     {
-    case 2: launch("classify", classify_kernel<2>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
-    case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
-    case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
-    case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
-    case 10: launch("classify", classify_kernel<10>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut); break;
+    case 2: launch("classify", classify_kernel<2>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut, touch); break;
+    case 3: launch("classify", classify_kernel<3>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut, touch); break;
+    case 4: launch("classify", classify_kernel<4>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut, touch); break;
+    case 6: launch("classify", classify_kernel<6>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut, touch); break;
+    case 10: launch("classify", classify_kernel<10>, grid_for(nc, kBlock * CFX_CLASSIFY_UNROLL), dim3(kBlock), 0, nc, cut->ls_dofmap.p, phi, dom, t_in, t_cut, touch); break;
     default: throw Error(CFX_ERR_INVALID_ARGUMENT, "unsupported level-set element (dofs per cell must be 3, 4, 6 or 10)");
     }
+    if (k == 0) cut->touch_valid = true;
   }
   if (cut->host_mask.n > 0)
     for (int k = 0; k < cut->nls; ++k)
@@ -2470,6 +2502,7 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
              cut->block_class.n == (nh + kClassBlock - 1) / kClassBlock ? (const uint8_t*)cut->block_class.p : (const uint8_t*)nullptr);
       list_register(l_in.p, l_in.count);
       list_register(l_cut.p, l_cut.count);
+      if (cut->host_width == 0 && cut->host_mask.n == 0) provenance_register(l_in.p, cut, cut->gen, -1, l_in.n);
       cut->located.emplace("phi<0", std::move(l_in));
       cut->located.emplace("phi=0", std::move(l_cut));
       return cut->located.find(selector)->second;
@@ -2478,6 +2511,9 @@ const DevArray<int32_t>& locate(cfx_cut_t cut, const std::string& selector)
     if (pred.sel.ls[0] == 0 && cut->tiles_inside.n > 0)
       known = pred.sel.mask[0] == 1 ? cut->tiles_inside.p : (pred.sel.mask[0] == 2 ? cut->tiles_cut.p : nullptr);
     compact_bytes("locate_entities", nh, bytes, DomainMask{pred.sel.mask[0]}, out, known); // 1 B/cell stream
+    // ("phi<0" / "phi>0" of level set 0 over all cells: the list is a function of the classification)
+    if (pred.sel.ls[0] == 0 && cut->host_width == 0 && cut->host_mask.n == 0 && (pred.sel.mask[0] == 1 || pred.sel.mask[0] == 4))
+      provenance_register(out.p, cut, cut->gen, pred.sel.mask[0] == 1 ? -1 : 1, out.n);
   }
   else
     compact("locate_entities", nh, pred, out);

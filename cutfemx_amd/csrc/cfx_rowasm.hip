@@ -215,6 +215,150 @@ __global__ void plan_mark_rows_cells_kernel(DevN n_d, const int32_t* __restrict_
   if (special) special[dof] = 1;
 }
 
+
+// ---------------------------------------------------------------------------
+// Bulk rows (cfx_row_plan::rowcls).  The reference marks cell by cell and row by row (deactivate.h:103-183,
+// assembler.h:442-560).  Where the uncut entities of a form are "the cells on one side of level set 0" and the space's
+// dofs are the level set's (P1 on the geometry dofmap), a dof on that side with no cut cell around it has ONLY such
+// cells around it -- active, whole stencil, one mark -- and a dof on the other side with no cut cell around it has none:
+// neither needs a mark to be written or read.  The classification leaves the two bytes that say so per dof (sign code,
+// touch byte: cfx_cut.hip).
+// ---------------------------------------------------------------------------
+constexpr uint8_t kRowOut = 0, kRowIn = 1, kRowMix = 2;
+
+// 16 rows per thread: class of every row (`sel`: sign code of the entities' side), and the rows' initial marks --
+// rowmark = 1 on a bulk row, 0 elsewhere; special = 0; the segment offsets of a linear form's staging = 0 ("none")
+// wherever they can be read (rows that can lie on an entity).  All arrays are padded to a multiple of 16 rows.
+__global__ void __launch_bounds__(kBlock) row_class_kernel(int64_t ndofs, const uint8_t* __restrict__ codes,
+                                                           const uint8_t* __restrict__ touch, uint8_t sel,
+                                                           uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
+                                                           uint8_t* __restrict__ special, int32_t* __restrict__ t2off,
+                                                           const int64_t* __restrict__ poison)
+{
+  const int64_t r0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  if (r0 >= ndofs) return;
+  // (a void step: every list-driven kernel sees length 0 and marks nothing -- the rows must not be marked either, or the
+  // kernels that walk the marks would read lengths nobody wrote)
+  const bool void_step = poison != nullptr && *poison != 0;
+  unsigned c[4] = {0u, 0u, 0u, 0u}, t[4] = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
+  if (void_step) { c[0] = c[1] = c[2] = c[3] = (3u - sel) * 0x01010101u; t[0] = t[1] = t[2] = t[3] = 0u; }
+  else if (r0 + 16 <= ndofs && ((reinterpret_cast<uintptr_t>(codes + r0) | reinterpret_cast<uintptr_t>(touch + r0)) & 15) == 0)
+  {
+    const uint4 cv = *reinterpret_cast<const uint4*>(codes + r0), tv = *reinterpret_cast<const uint4*>(touch + r0);
+    c[0] = cv.x; c[1] = cv.y; c[2] = cv.z; c[3] = cv.w;
+    t[0] = tv.x; t[1] = tv.y; t[2] = tv.z; t[3] = tv.w;
+  }
+  else
+    for (int k = 0; k < 16 && r0 + k < ndofs; ++k) // (rows beyond the last one stay "touched, code 0": class 2, mark 0)
+    {
+      c[k >> 2] |= (unsigned)codes[r0 + k] << (8 * (k & 3));
+      t[k >> 2] = (t[k >> 2] & ~(0xffu << (8 * (k & 3)))) | ((unsigned)touch[r0 + k] << (8 * (k & 3)));
+    }
+  unsigned cls[4], rm[4];
+  bool any_in = false, all_out = true;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    cls[q] = 0u; rm[q] = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      const unsigned code = (c[q] >> (8 * k)) & 0xffu, tch = (t[q] >> (8 * k)) & 0xffu;
+      const unsigned cl = tch ? kRowMix : (code == sel ? kRowIn : (code == 3u - sel ? kRowOut : kRowMix));
+      cls[q] |= cl << (8 * k);
+      rm[q] |= (cl == kRowIn ? 1u : 0u) << (8 * k);
+      any_in = any_in || cl == kRowIn;
+      all_out = all_out && cl == kRowOut;
+    }
+  }
+  *reinterpret_cast<uint4*>(rowcls + r0) = make_uint4(cls[0], cls[1], cls[2], cls[3]);
+  *reinterpret_cast<uint4*>(rowmark + r0) = make_uint4(rm[0], rm[1], rm[2], rm[3]);
+  *reinterpret_cast<uint4*>(special + r0) = make_uint4(0u, 0u, 0u, 0u);
+  if (t2off && !all_out)
+  {
+    if (r0 + 16 <= ndofs)
+    {
+      uint4* q = reinterpret_cast<uint4*>(t2off + r0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    else
+      for (int64_t r = r0; r < ndofs; ++r) t2off[r] = 0;
+  }
+}
+
+// cell marks of the uncut entities of a located list straight from the classification bytes: mark = bits where
+// domain == value, 0 elsewhere -- 16 cells per thread; a block of kClassBlock cells the culled classification found
+// uniform (block_class 1: all inside, 2: all outside) is written without being read.  Covers the padded array.
+__global__ void __launch_bounds__(kBlock) cellmark_from_domain_kernel(int64_t ncells, int64_t npad, const int8_t* __restrict__ domain,
+                                                                      int8_t value, uint8_t bits,
+                                                                      const uint8_t* __restrict__ block_class,
+                                                                      uint8_t* __restrict__ cellmark,
+                                                                      const int64_t* __restrict__ poison)
+{
+  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  if (base >= npad) return;
+  unsigned out[4] = {0u, 0u, 0u, 0u};
+  int known = -1; // the block's class says what every cell of it is
+  if (poison != nullptr && *poison != 0) known = 0; // (a void step: no marks, as when the list has length 0)
+  else if (block_class && base < ncells)
+  {
+    const unsigned c = block_class[base / kClassBlock];
+    if (c == 1u) known = -1 == value ? 1 : 0;
+    else if (c == 2u) known = 1 == value ? 1 : 0;
+  }
+  if (known == 1 && base + 16 <= ncells)
+  {
+    const unsigned w = bits * 0x01010101u;
+    out[0] = out[1] = out[2] = out[3] = w;
+  }
+  else if (known == 0) {}
+  else if (base + 16 <= ncells)
+  {
+    const uint4 d = *reinterpret_cast<const uint4*>(domain + base); // (domain of level set 0 and base: 16 B aligned)
+    const unsigned x[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if ((int8_t)((x[q] >> (8 * k)) & 0xffu) == value) out[q] |= (unsigned)bits << (8 * k);
+  }
+  else
+    for (int k = 0; base + k < ncells; ++k)
+      if (domain[base + k] == value) out[k >> 2] |= (unsigned)bits << (8 * (k & 3));
+  *reinterpret_cast<uint4*>(cellmark + base) = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
+// the rows next to the interface (class 2): active iff a cell around them carries a mark (the rows of rule cells and
+// facets were marked by the kernels that walk those lists).  16 rows per thread: most threads read 16 class bytes and
+// leave; the others walk the dof -> cells lists of their class-2 rows.
+__global__ void __launch_bounds__(kBlock) mix_rowmark_kernel(int64_t ndofs, const uint8_t* __restrict__ rowcls,
+                                                             const int64_t* __restrict__ d2c_off, const int32_t* __restrict__ d2c,
+                                                             const uint8_t* __restrict__ cellmark, uint8_t* __restrict__ rowmark)
+{
+  const int64_t r0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  if (r0 >= ndofs) return;
+  const uint4 cv = *reinterpret_cast<const uint4*>(rowcls + r0); // (padded to a multiple of 16 rows)
+  const unsigned c[4] = {cv.x, cv.y, cv.z, cv.w};
+  if (((c[0] | c[1] | c[2] | c[3]) & 0x02020202u) == 0u) return;
+  for (int k = 0; k < 16 && r0 + k < ndofs; ++k)
+  {
+    if (((c[k >> 2] >> (8 * (k & 3))) & 0xffu) != kRowMix) continue;
+    const int64_t r = r0 + k;
+    const int64_t cb = d2c_off[r], ce = d2c_off[r + 1];
+    unsigned any = 0;
+    for (int64_t t = cb; t < ce; t += 8)
+    {
+      int32_t cell[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) cell[j] = t + j < ce ? d2c[t + j] : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) any |= cell[j] >= 0 ? (unsigned)cellmark[cell[j]] : 0u;
+    }
+    if (any) rowmark[r] = 1;
+  }
+}
+
 // active-row positions whose CSR row is at most / longer than `limit` columns
 struct RowLenTest
 {
@@ -1191,7 +1335,7 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
                                                             const int64_t* __restrict__ st_off,
                                                             unsigned long long* __restrict__ masks,
                                                             uint8_t* __restrict__ uniform, int32_t* __restrict__ counts,
-                                                            int* maxlen)
+                                                            int* maxlen, const uint8_t* __restrict__ rowcls, uint8_t bulk_bits)
 {
   const int64_t n_plain = dev_n(n_plain_d);
   constexpr int G = CFX_MASKS_G;
@@ -1203,7 +1347,11 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
   unsigned all_or = 0, all_and = 0xffu; // over the incident cells: equal iff every cell has the same mark
   bool need_slots = false; // this lane met an unmarked cell
   int full_cells = 0;      // marked cells this lane did not expand into stencil positions
-  if (live)
+  // a bulk row: every cell around it is an uncut entity -- the whole stencil, one mark, nothing to gather (no cell
+  // around a PLAIN row carries a rule mark: the dofs of a rule cell are special rows)
+  const bool bulk = live && rowcls && rowcls[r] == kRowIn;
+  if (bulk) { all_or = all_and = bulk_bits; full_cells = 1; }
+  else if (live)
   {
     const int64_t cb = d2c_off[r];
     const int nc = (int)(d2c_off[r + 1] - cb);
@@ -1761,6 +1909,42 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   const int64_t n_cm = (nc + 15) & ~15LL, n_rm = (V->ndofs + 15) & ~15LL;
   const int64_t n_t2 = space_stencil(V).usable ? ((4 * V->ndofs + 15) & ~15LL) : 0;
   P.mark_block.alloc(n_cm + 2 * n_rm + n_t2); // (zeroed below, in one launch with the rule-key tables)
+  // Bulk rows: the uncut entities of every cell integral that has any are ONE list, and that list is what
+  // cfx_locate_entities made of the current classification of a cut whose level set lives on this space's dofmap
+  // (= the geometry dofmap: the space is P1 on it).  CFX_BULK_ROWS=0: marks from the lists, as the reference walks them.
+  const cfx_cut_s* bulk_cut = nullptr;
+  int bulk_value = 0;
+  {
+    const char* be = getenv("CFX_BULK_ROWS");
+    const void* list = nullptr;
+    int64_t list_n = 0;
+    bool one_list = true;
+    int slot = 0;
+    uint8_t bits = 0;
+    for (const cfx_integral_dev& I : a->integrals)
+    {
+      if (I.type != CFX_CELL) continue;
+      if (slot >= 4) { one_list = false; break; }
+      if (I.n_entities.cap() > 0)
+      {
+        if (list && (list != I.entities.p || list_n != I.n_entities.cap())) one_list = false;
+        list = I.entities.p; list_n = I.n_entities.cap();
+        bits |= (uint8_t)(1u << slot);
+      }
+      ++slot;
+    }
+    const ListProvenance* pv = (!(be && be[0] == '0') && one_list && list && space_stencil(V).usable && V->bs == 1
+                                && (nd == 4 || nd == 3)) ? provenance_lookup(list) : nullptr;
+    if (pv && pv->n == list_n && pv->cut->gen == pv->gen && pv->cut->mesh == V->mesh && pv->cut->ls_dofmap.p == V->mesh->conn.p
+        && pv->cut->ls_ndofs == V->ndofs && pv->cut->codes0.n == V->ndofs && pv->cut->touch_valid && pv->cut->touch0.n == V->ndofs
+        && (pv->value == -1 || pv->value == 1))
+    {
+      P.bulk = true;
+      P.bulk_bits = bits;
+      bulk_cut = pv->cut;
+      bulk_value = pv->value;
+    }
+  }
   if (n_t2 > 0)
   {
     P.vec_t2off.p = reinterpret_cast<int32_t*>(P.mark_block.p + n_cm + 2 * n_rm); P.vec_t2off.n = V->ndofs; P.vec_t2off.owned = false;
@@ -1791,11 +1975,23 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       }
       ++slot;
     }
-    if (key_total > 0)
+    if (key_total > 0) P.rule_key_block.alloc(key_total);
+    if (P.bulk)
     {
-      P.rule_key_block.alloc(key_total);
-      dev_fill2(P.mark_block.p, 0, (size_t)P.mark_block.n, P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
+      // no zero fill: the row classes initialise the row marks, the cell marks come from the classification bytes
+      if (key_total > 0) dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
+      P.rowcls.alloc(n_rm);
+      launch("plan_row_class", row_class_kernel, grid_for(n_rm / 16), dim3(kBlock), 0, V->ndofs, bulk_cut->codes0.p,
+             bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
+             n_t2 > 0 ? P.vec_t2off.p : (int32_t*)nullptr, step_poison());
+      const int64_t nb = (nc + kClassBlock - 1) / kClassBlock;
+      launch("plan_cell_marks", cellmark_from_domain_kernel, grid_for(n_cm / 16), dim3(kBlock), 0, nc, n_cm, bulk_cut->domain.p,
+             (int8_t)bulk_value, P.bulk_bits, bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : (const uint8_t*)nullptr,
+             P.cellmark.p, step_poison());
+      P.any_cells = true;
     }
+    else if (key_total > 0)
+      dev_fill2(P.mark_block.p, 0, (size_t)P.mark_block.n, P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
     else
       P.mark_block.zero();
   }
@@ -1809,7 +2005,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       if (P.n_cell_slots >= 4) { P.usable = false; continue; }
       const int slot = P.n_cell_slots++;
       P.cell_slot_integral[slot] = (int)ii;
-      if (ne > 0)
+      if (ne > 0 && P.bulk) {} // (marked from the classification above)
+      else if (ne > 0)
       {
         if (nd == 4)
           launch("plan_mark_entities", plan_mark_entities_kernel<4>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
@@ -1946,6 +2143,13 @@ cfx_row_plan& row_plan(cfx_form_s* a)
              V->dofmap.p, nd - ns, flag.p);
     else
       no_fold = true;
+  }
+  if (P.bulk)
+  {
+    // the rows next to the interface, from the marks of the cells around them
+    const Adjacency& adj = V->dof_cells();
+    launch("plan_mix_rows", mix_rowmark_kernel, grid_for(n_rm / 16), dim3(kBlock), 0, V->ndofs, P.rowcls.p, adj.offsets.p,
+           adj.cells.p, P.cellmark.p, P.rowmark.p);
   }
   Count n_plain_all;
   // counters of the dof -> facets incidence (zeroed by the kernel that writes the row lists)
@@ -2281,7 +2485,8 @@ bool plain_row_masks(cfx_form_s* a, int32_t* counts, int* maxlen)
   launch("plan_plain_masks", plain_masks_kernel,
          dim3((unsigned)((np + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
-         st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p, counts, maxlen);
+         st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p, counts, maxlen, plan.bulk ? plan.rowcls.p : (const uint8_t*)nullptr,
+         plan.bulk_bits);
   if (space_stencil_tiles(V).tiles_usable)
   {
     // work list of the tile kernels: one entry per row tile that holds a plain row (inside a step: positions and tile

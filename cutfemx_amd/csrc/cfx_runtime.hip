@@ -249,6 +249,31 @@ std::map<const void*, Count>& list_registry()
 } // namespace
 void list_register(const void* p, const Count& c) { if (p && c.cell) list_registry()[p] = c; }
 void list_unregister(const void* p) { list_registry().erase(p); }
+
+static std::map<const void*, ListProvenance>& provenance_registry()
+{
+  static std::map<const void*, ListProvenance> r;
+  return r;
+}
+void provenance_register(const void* p, const cfx_cut_s* cut, uint64_t gen, int value, int64_t n)
+{
+  if (!p) return;
+  provenance_registry()[p] = ListProvenance{cut, gen, value, dev_block_serial(p), n};
+}
+const ListProvenance* provenance_lookup(const void* p)
+{
+  auto& r = provenance_registry();
+  auto it = r.find(p);
+  if (it == r.end()) return nullptr;
+  if (it->second.serial == 0 || dev_block_serial(p) != it->second.serial) { r.erase(it); return nullptr; }
+  return &it->second;
+}
+void provenance_forget_cut(const cfx_cut_s* cut)
+{
+  auto& r = provenance_registry();
+  for (auto it = r.begin(); it != r.end();)
+    if (it->second.cut == cut) it = r.erase(it); else ++it;
+}
 Count list_lookup(const void* p, int64_t n_given)
 {
   auto it = list_registry().find(p);
@@ -473,7 +498,11 @@ void* dev_alloc(size_t bytes)
     (void)hipGetLastError();
     dev_cache_release(); // out of memory: give the cached blocks back and retry once
     e = hipMalloc(&p, want);
-    if (e != hipSuccess) throw Error(CFX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    if (e != hipSuccess)
+    {
+      (void)hipGetLastError(); // (the failure is reported here: it must not come back from the next launch's check)
+      throw Error(CFX_ERR_HIP, std::string("hipMalloc: ") + hipGetErrorString(e));
+    }
   }
   c.hand_out(p, want);
   return p;

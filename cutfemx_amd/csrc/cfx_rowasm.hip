@@ -345,6 +345,7 @@ __global__ void __launch_bounds__(kBlock) mix_rowmark_kernel(int64_t ndofs, cons
   {
     if (((c[k >> 2] >> (8 * (k & 3))) & 0xffu) != kRowMix) continue;
     const int64_t r = r0 + k;
+    if (rowmark[r]) continue; // (a dof of a rule cell or of a facet: marked by the kernel that walked that list)
     const int64_t cb = d2c_off[r], ce = d2c_off[r + 1];
     unsigned any = 0;
     for (int64_t t = cb; t < ce; t += 8)
@@ -1327,7 +1328,7 @@ struct ByteIs
 #endif
 // stencil mask of a plain row: OR over its marked incident cells of the positions of their dofs, and
 // the mark byte shared by all its incident cells (0: not uniform).  G lanes per row.
-__global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
+__device__ __forceinline__ void plain_masks_rows(const int64_t n_plain, const int64_t i, const int32_t* __restrict__ rows,
                                                             const int64_t* __restrict__ d2c_off,
                                                             const int32_t* __restrict__ d2c,
                                                             const uint32_t* __restrict__ slot4,
@@ -1337,10 +1338,8 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
                                                             uint8_t* __restrict__ uniform, int32_t* __restrict__ counts,
                                                             int* maxlen, const uint8_t* __restrict__ rowcls, uint8_t bulk_bits)
 {
-  const int64_t n_plain = dev_n(n_plain_d);
   constexpr int G = CFX_MASKS_G;
   const int lane = threadIdx.x, gl = lane % G;
-  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
   const bool live = i < n_plain;
   const int64_t r = live ? rows[i] : 0;
   unsigned long long m = 0;
@@ -1435,6 +1434,55 @@ __global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, cons
       if (cnt > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, cnt);
     }
   }
+}
+
+
+// 64 consecutive plain rows per wavefront.  All of them bulk rows (every cell around them an uncut entity -- most
+// wavefronts away from the interface): one lane per row, the whole stencil, one mark, nothing gathered; else four passes
+// of 16 rows with G lanes per row.
+__global__ void __launch_bounds__(kWave) plain_masks_kernel(DevN n_plain_d, const int32_t* __restrict__ rows,
+                                                            const int64_t* __restrict__ d2c_off,
+                                                            const int32_t* __restrict__ d2c,
+                                                            const uint32_t* __restrict__ slot4,
+                                                            const uint8_t* __restrict__ cellmark, int nd,
+                                                            const int64_t* __restrict__ st_off,
+                                                            unsigned long long* __restrict__ masks,
+                                                            uint8_t* __restrict__ uniform, int32_t* __restrict__ counts,
+                                                            int* maxlen, const uint8_t* __restrict__ rowcls, uint8_t bulk_bits)
+{
+  static_assert(kWave / CFX_MASKS_G == 16, "sixteen rows per pass");
+  const int64_t n_plain = dev_n(n_plain_d);
+  const int lane = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kWave;
+  if (i0 >= n_plain) return;
+  if (rowcls)
+  {
+    const int64_t i = i0 + lane;
+    const bool live = i < n_plain;
+    const int64_t r = live ? rows[i] : 0;
+    const bool bulk = live && rowcls[r] == kRowIn;
+    if (__ballot(live && !bulk) == 0ull)
+    {
+      int cnt = 0;
+      if (live)
+      {
+        cnt = (int)(st_off[r + 1] - st_off[r]);
+        masks[i] = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+        uniform[i] = bulk_bits;
+        if (counts) counts[r] = cnt;
+      }
+      if (counts)
+      {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt = max(cnt, __shfl_xor(cnt, o, 64));
+        if (lane == 0 && cnt > *reinterpret_cast<volatile int*>(maxlen)) atomicMax(maxlen, cnt);
+      }
+      return;
+    }
+  }
+  for (int pass = 0; pass < CFX_MASKS_G; ++pass)
+    plain_masks_rows(n_plain, i0 + pass * 16 + lane / CFX_MASKS_G, rows, d2c_off, d2c, slot4, cellmark, nd, st_off, masks, uniform,
+                     counts, maxlen, rowcls, bulk_bits);
 }
 
 // sparsity of the plain rows, pass 1: row length = popcount of the mask
@@ -2483,7 +2531,7 @@ bool plain_row_masks(cfx_form_s* a, int32_t* counts, int* maxlen)
   plan.plain_masks.alloc(np);
   plan.plain_uniform.alloc(np);
   launch("plan_plain_masks", plain_masks_kernel,
-         dim3((unsigned)((np + (kWave / CFX_MASKS_G) - 1) / (kWave / CFX_MASKS_G))), dim3(kWave), 0,
+         dim3((unsigned)((np + kWave - 1) / kWave)), dim3(kWave), 0,
          plan.n_plain_rows, plan.plain_rows.p, adj.offsets.p, adj.cells.p, st.slot4.p, plan.cellmark.p, V->ndofs_cell,
          st.offsets.p, plan.plain_masks.p, plan.plain_uniform.p, counts, maxlen, plan.bulk ? plan.rowcls.p : (const uint8_t*)nullptr,
          plan.bulk_bits);

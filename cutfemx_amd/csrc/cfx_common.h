@@ -942,6 +942,8 @@ bool assemble_vector_rows(cfx_form_s* L, double* b);
 // integrands compiled at run time (cfx_rtc.hip)
 bool user_integrand_known(int kernel);
 int user_integrand_rank(int kernel);
+int user_integrand_kind(int kernel); // 0: cell integrand, 1: interior-facet integrand
+void user_stage1_facets(const cfx_form_s* a, const cfx_integral_dev& I, double* out, int64_t only_index = -1);
 void user_stage1(const cfx_form_s* a, const cfx_integral_dev& I, bool runtime, double* out, int out_mode, int64_t out_stride,
                  int64_t only_index = -1);
 } // namespace cfx

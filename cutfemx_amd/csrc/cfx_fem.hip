@@ -700,34 +700,76 @@ __global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
 
 // Entity-parallel scatter of staged local tensors ([n][ND x ND] or [n][ND], entity-major): the atomic path of the
 // integrands that are compiled at run time (cfx_rtc.hip).  One thread per (entity, local row).
+// (local index I = dof i * bs + component a: the blocked layout of the reference's dofmaps)
 __global__ void __launch_bounds__(kBlock) scatter_staged_kernel(DevN n_d, const int32_t* __restrict__ cells, const int32_t* __restrict__ dofmap,
-                                                                int nd, int rank, const double* __restrict__ staged,
+                                                                int nd, int bs, int rank, const double* __restrict__ staged,
                                                                 const int8_t* __restrict__ bc0, const int8_t* __restrict__ bc1,
                                                                 const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
                                                                 double* __restrict__ values, int* error)
 {
   const int64_t n = dev_n(n_d);
+  const int nloc = nd * bs;
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t e = t / nd;
+  const int64_t e = t / nloc;
   if (e >= n) return;
-  const int i = (int)(t - e * nd);
+  const int I = (int)(t - e * nloc);
   const int64_t c = cells[e];
-  const int32_t row = dofmap[c * nd + i];
+  const int32_t row = dofmap[c * nd + I / bs] * bs + I % bs;
   if (rank == 1)
   {
-    atomicAdd(&values[row], staged[e * nd + i]);
+    atomicAdd(&values[row], staged[e * nloc + I]);
     return;
   }
-  if (bc0 && bc0[row]) return;
+  // zero BC rows / columns: assemble_matrix_impl.h:151-185 (the diagonal is the caller's: set_diagonal)
+  const bool row_bc = bc0 && bc0[row];
   const int64_t rb = indptr[row], re = indptr[row + 1];
   for (int j = 0; j < nd; ++j)
   {
-    const int32_t col = dofmap[c * nd + j];
-    if (bc1 && bc1[col]) continue;
-    const int64_t pos = csr_find(indices, rb, re, col);
+    const int32_t col0 = dofmap[c * nd + j] * bs;
+    const int64_t pos = csr_find(indices, rb, re, col0);
     if (pos < 0) { *error = 1; continue; }
-    atomicAdd(&values[pos], staged[(e * nd + i) * nd + j]);
+    for (int b = 0; b < bs; ++b)
+    {
+      double v = staged[(e * nloc + I) * nloc + j * bs + b];
+      if (row_bc || (bc1 && bc1[col0 + b])) v = 0.0;
+      atomicAdd(&values[pos + b], v);
+    }
   }
+}
+
+// ... of staged facet macro tensors [n][2 nloc][2 nloc]: one thread per (facet, macro row); macro dofs = [cell 0, cell 1]
+__global__ void __launch_bounds__(kBlock) scatter_staged_facets_kernel(DevN n_d, const int32_t* __restrict__ rows,
+                                                                       const int32_t* __restrict__ dofmap, int nd, int bs,
+                                                                       const double* __restrict__ staged,
+                                                                       const int8_t* __restrict__ bc0, const int8_t* __restrict__ bc1,
+                                                                       const int64_t* __restrict__ indptr,
+                                                                       const int32_t* __restrict__ indices,
+                                                                       double* __restrict__ values, int* error)
+{
+  const int64_t n = dev_n(n_d);
+  const int nloc = nd * bs, nm = 2 * nloc;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t f = t / nm;
+  if (f >= n) return;
+  const int I = (int)(t - f * nm);
+  const int64_t c[2] = {rows[4 * f], rows[4 * f + 2]};
+  const int si = I / nloc, Ii = I - si * nloc;
+  const int32_t row = dofmap[c[si] * nd + Ii / bs] * bs + Ii % bs;
+  const bool row_bc = bc0 && bc0[row];
+  const int64_t rb = indptr[row], re = indptr[row + 1];
+  for (int s = 0; s < 2; ++s)
+    for (int j = 0; j < nd; ++j)
+    {
+      const int32_t col0 = dofmap[c[s] * nd + j] * bs;
+      const int64_t pos = csr_find(indices, rb, re, col0);
+      if (pos < 0) { *error = 1; continue; }
+      for (int b = 0; b < bs; ++b)
+      {
+        double v = staged[(f * nm + I) * nm + s * nloc + j * bs + b];
+        if (row_bc || (bc1 && bc1[col0 + b])) v = 0.0;
+        atomicAdd(&values[pos + b], v);
+      }
+    }
 }
 
 // a cell integral whose integrand was registered at run time: stage 1 through the compiled wrapper, then -- unless the
@@ -735,11 +777,26 @@ __global__ void __launch_bounds__(kBlock) scatter_staged_kernel(DevN n_d, const 
 void launch_user_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArgs A, int64_t only_index, int use_rule, int parts)
 {
   const cfx_space_s* V = a->V;
-  require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "user integrands are cell integrals");
   require(A.lift_markers == nullptr, CFX_ERR_INVALID_ARGUMENT, "apply_lifting is not available for user integrands");
   const bool single = only_index >= 0;
-  const int nd = V->ndofs_cell;
-  const int64_t nt = a->rank == 2 ? (int64_t)nd * nd : nd;
+  const int nd = V->ndofs_cell, bs = V->bs;
+  if (I.type == CFX_INTERIOR_FACET)
+  {
+    // macro tensors [facet][2 nloc][2 nloc]: to the caller (row gather, tabulate_entity), or staged and scattered
+    const DevN n = single ? DevN(1) : I.n_entities.devn();
+    if (n.cap == 0) return;
+    if (A.dump) { user_stage1_facets(a, I, A.dump, only_index); return; }
+    const int64_t nm = 2 * (int64_t)nd * bs;
+    DevArray<double> staged(n.cap * nm * nm);
+    user_stage1_facets(a, I, staged.p, only_index);
+    launch("scatter_staged", scatter_staged_facets_kernel, grid_for(n.cap * nm), dim3(kBlock), 0, n,
+           I.entities.p + 4 * (single ? only_index : 0), V->dofmap.p, nd, bs, (const double*)staged.p, A.bc0, A.bc1, A.indptr,
+           A.indices, A.values, A.error);
+    return;
+  }
+  require(I.type == CFX_CELL, CFX_ERR_INVALID_ARGUMENT, "user integrands are cell or interior-facet integrals");
+  const int64_t nloc = (int64_t)nd * bs;
+  const int64_t nt = a->rank == 2 ? nloc * nloc : nloc;
   for (int part = 1; part <= 2; ++part)
   {
     if (!(parts & part)) continue;
@@ -752,8 +809,8 @@ void launch_user_integral(const cfx_form_s* a, const cfx_integral_dev& I, AsmArg
     DevArray<double> staged(n.cap * nt);
     user_stage1(a, I, runtime, staged.p, 0, 0, only_index);
     const int32_t* cells = runtime ? I.rules->parent_map.p : I.entities.p;
-    launch("scatter_staged", scatter_staged_kernel, grid_for(n.cap * nd), dim3(kBlock), 0, n, cells + (single ? only_index : 0),
-           V->dofmap.p, nd, a->rank, (const double*)staged.p, A.bc0, A.bc1, A.indptr, A.indices, A.values, A.error);
+    launch("scatter_staged", scatter_staged_kernel, grid_for(n.cap * nloc), dim3(kBlock), 0, n, cells + (single ? only_index : 0),
+           V->dofmap.p, nd, bs, a->rank, (const double*)staged.p, A.bc0, A.bc1, A.indptr, A.indices, A.values, A.error);
   }
 }
 
@@ -1780,7 +1837,12 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
     require(bilinear == (rank == 2), CFX_ERR_INVALID_ARGUMENT, "cfx_form_create: kernel rank does not match the form");
     require(in.qdegree >= 0 && in.qdegree <= CFX_QUAD_MAX_DEGREE, CFX_ERR_INVALID_ARGUMENT,
             "cfx_form_create: quadrature degree out of range");
-    if (in.type == CFX_INTERIOR_FACET)
+    if (in.type == CFX_INTERIOR_FACET && user)
+      require(user_integrand_kind(in.kernel) == 1 && !rect && V->degree <= 2 && in.rules == nullptr && 2 * V->ndofs_cell * V->bs <= 24,
+              CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: an interior-facet integral takes an integrand registered with cfx_integrand_register_facet "
+              "(standard facets, spaces of degree 1 or 2 with at most 24 macro dofs)");
+    else if (in.type == CFX_INTERIOR_FACET)
     {
       require(in.kernel == CFX_K_GHOST_GRADJUMP || in.kernel == CFX_K_EXTENSION_L2 || in.kernel == CFX_K_JUMP
                   || in.kernel == CFX_K_SIP,
@@ -1798,8 +1860,8 @@ static int form_create_impl(cfx_space_t V, cfx_space_t V1, int rank, int n_integ
                   "cfx_form_create: a cell integral takes cell-hosted rules (pass facet-hosted rules through "
                   "cfx_facet_rules_to_cells)");
     else if (user)
-      require(in.type == CFX_CELL && !rect && V->bs == 1 && V->degree <= 2, CFX_ERR_INVALID_ARGUMENT,
-              "cfx_form_create: integrands registered at run time serve cell integrals of scalar spaces of degree 1 or 2");
+      require(in.type == CFX_CELL && !rect && V->degree <= 2 && user_integrand_kind(in.kernel) == 0, CFX_ERR_INVALID_ARGUMENT,
+              "cfx_form_create: a cell integral takes an integrand registered with cfx_integrand_register (spaces of degree 1 or 2)");
     else
       require(in.kernel == CFX_K_MASS || in.kernel == CFX_K_STIFFNESS || in.kernel == CFX_K_NITSCHE
                   || in.kernel == CFX_K_ELASTICITY || in.kernel == CFX_L_SOURCE || in.kernel == CFX_L_NITSCHE_RHS

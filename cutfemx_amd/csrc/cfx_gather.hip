@@ -4019,7 +4019,10 @@ RowArgs prepare(cfx_form_s* a, Stage1& st, bool combine_cuts = false)
     // 3-D P1 scalar spaces: stage 1 stores the macro tensor already folded over the shared dofs, 25 doubles per
     // facet instead of 64 (fold_facets = 2); elsewhere the P1 fold happens in the gather (1) or not at all (0)
     const char* fe = getenv("CFX_FACET_FOLD_STAGE1");
-    if (TDIM == 3 && DEG == 1 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0')) A.fold_facets = 2;
+    bool user_facets = false; // (integrands compiled at run time stage the whole macro tensor: folded in the gather, or not)
+    for (int s = 0; s < plan.n_facet_slots; ++s)
+      user_facets = user_facets || user_integrand_known(a->integrals[plan.facet_slot_integral[s]].kernel);
+    if (TDIM == 3 && DEG == 1 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && fe[0] == '0') && !user_facets) A.fold_facets = 2;
     // ... and when every facet term is the gradient jump over standard facets, the folded tensor is rank one:
     // stage 1 stores its vector and weight (8 doubles per facet, fold_facets = 3)
     bool rank_one = DEG == 1 && BS == 1 && A.fold_facets && a->rank == 2 && !(fe && (fe[0] == '0' || fe[0] == '2'));

@@ -86,6 +86,47 @@ __global__ void __launch_bounds__(kBlock) plan_pack_bits_kernel(int64_t ncells, 
   }
 }
 
+// the same words for the uncut entities of a located list, from the classification bytes: bit k of word w = (domain of
+// cell 64 w + k == value).  A block of kClassBlock cells that the culled classification found uniform is not read.
+__global__ void __launch_bounds__(kBlock) pack_bits_domain_kernel(int64_t ncells, const int8_t* __restrict__ domain, int8_t value,
+                                                                  const uint8_t* __restrict__ block_class,
+                                                                  unsigned long long* __restrict__ words, int32_t* __restrict__ pop,
+                                                                  const int64_t* __restrict__ poison)
+{
+  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t base = w * 64;
+  if (base >= ncells) return;
+  unsigned long long v = 0;
+  int known = -1;
+  if (poison != nullptr && *poison != 0) known = 0; // (a void step: no entities, as when the list has length 0)
+  else if (block_class)
+  {
+    const unsigned c = block_class[base / kClassBlock];
+    if (c == 1u) known = -1 == value ? 1 : 0;
+    else if (c == 2u) known = 1 == value ? 1 : 0;
+  }
+  if (known == 1 && base + 64 <= ncells) v = ~0ull;
+  else if (known == 0) {}
+  else if (base + 64 <= ncells)
+  {
+    const uint4* p = reinterpret_cast<const uint4*>(domain + base);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+    {
+      const uint4 u = p[q];
+      const unsigned x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if ((int8_t)((x[k >> 2] >> (8 * (k & 3))) & 0xffu) == value) v |= 1ull << (16 * q + k);
+    }
+  }
+  else
+    for (int k = 0; base + k < ncells; ++k)
+      if (domain[base + k] == value) v |= 1ull << k;
+  words[w] = v;
+  pop[w] = __popcll(v);
+}
+
 // uncut entities of a cell integral, nd <= 4 dofs per cell, in one pass over the list: cell mark, row marks
 // (dofmap row as one 16 B load when nd == 4) and the ascending check
 template <int ND>
@@ -2322,8 +2363,19 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       P.cell_tile_counts.alloc((nc + kByteTile - 1) / kByteTile);
       tiles = P.cell_tile_counts.p;
     }
-    launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, P.cellmark.p,
-           (uint8_t)(1u << slot), reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p, tiles);
+    if (P.bulk)
+    {
+      // (the entities are the cells of one domain value: no pass over the mark bytes; the marked cells per tile -- the
+      // count pass of the active-cell list -- are counted when that list is asked for)
+      const int64_t nb = (nc + kClassBlock - 1) / kClassBlock;
+      P.cell_tile_counts.release();
+      launch("plan_pack_bits", pack_bits_domain_kernel, grid_for(nwords), dim3(kBlock), 0, nc, bulk_cut->domain.p, (int8_t)bulk_value,
+             bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : (const uint8_t*)nullptr,
+             reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p, step_poison());
+    }
+    else
+      launch("plan_pack_bits", plan_pack_bits_kernel, grid_for(nwords), dim3(kBlock), 0, nc, P.cellmark.p,
+             (uint8_t)(1u << slot), reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p, tiles);
     exclusive_scan(pop.p, P.std_rank[slot].p, nwords);
   }
   const char* det = getenv("CFX_DETERMINISTIC");

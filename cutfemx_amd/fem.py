@@ -239,7 +239,7 @@ class overlap:
 _user_integrand_rank: dict[int, int] = {}
 
 
-def register_integrand(name: str, source: str, rank: int = 2) -> int:
+def register_integrand(name: str, source: str, rank: int = 2, facet: bool = False, variant=None) -> int:
     """Register the HIP C++ source of an integrand; returns the id to put into `Integral.kernel`.
 
     The reference generates a tabulate_tensor kernel per form at run time (runintgen / FFCx,
@@ -251,16 +251,32 @@ def register_integrand(name: str, source: str, rank: int = 2) -> int:
     (local tensor, packed coefficient, constants = Integral.params, vertex coordinates [(tdim+1)][3], the entity's
     rule: reference points, physical-measure weights, per-point data) is compiled for gfx950 with hipRTC -- see
     include/cutfemx_amd.h (cfx_integrand_register) for the contract and the helpers in scope (cfx_tabulate, ...).
-    Cell integrals of scalar spaces of degree 1 or 2, over standard entities and / or runtime rules."""
+    Cell integrals of Lagrange spaces of degree 1 or 2 (scalar or vector-valued: CFX_BS, CFX_NDB), over standard entities
+    and / or runtime rules.  `facet=True`: an interior-facet integrand
+
+        __device__ void name(double* A, const double* w, const double* c, const double* coordinate_dofs,
+                             const int* entity_local_index, int nq, const double* points0, const double* points1,
+                             const double* weights)
+
+    over (c0, lf0, c1, lf1) rows -- macro tensor [[00, 01], [10, 11]], both cells' coordinate_dofs, {lf0, lf1}
+    (assemble_matrix_impl.h:528-542).  `variant=(tdim, dofs per cell[, bs])`: the variant the source is validated
+    against at registration (default (3, 4, 1))."""
     kid = C.c_int()
-    _lib.check(_lib.load().cfx_integrand_register(name.encode(), source.encode(), int(rank), C.byref(kid)))
+    if variant is None and not facet:
+        _lib.check(_lib.load().cfx_integrand_register(name.encode(), source.encode(), int(rank), C.byref(kid)))
+    elif variant is None:
+        _lib.check(_lib.load().cfx_integrand_register_facet(name.encode(), source.encode(), C.byref(kid)))
+    else:
+        tdim, nd, bs = (list(variant) + [1])[:3]
+        _lib.check(_lib.load().cfx_integrand_register_variant(name.encode(), source.encode(), int(rank), int(bool(facet)),
+                                                              int(tdim), int(nd), int(bs), C.byref(kid)))
     _user_integrand_rank[kid.value] = int(rank)
     return kid.value
 
 
-def compile_integrand(kernel_id: int, tdim: int, ndofs_cell: int) -> None:
-    """Compile the (tdim, dofs per cell) variant of a registered integrand now instead of at its first use."""
-    _lib.check(_lib.load().cfx_integrand_compile(int(kernel_id), int(tdim), int(ndofs_cell)))
+def compile_integrand(kernel_id: int, tdim: int, ndofs_cell: int, bs: int = 1) -> None:
+    """Compile the (tdim, dofs per cell, block size) variant of a registered integrand now instead of at its first use."""
+    _lib.check(_lib.load().cfx_integrand_compile_bs(int(kernel_id), int(tdim), int(ndofs_cell), int(bs)))
 
 
 def form(integrals, V: FunctionSpace, rank: int | None = None, trial_space: FunctionSpace | None = None, dtype=None) -> CutForm:

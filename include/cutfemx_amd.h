@@ -465,13 +465,42 @@ int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule,
  *
  *      CFX_TDIM and CFX_ND (dofs per cell) are defined at compile time; helpers in scope: cfx_tabulate(X, N, dN),
  *      cfx_tabulate_p1 / _p2, cfx_inverse_jacobian(coordinate_dofs, K) -> det J, cfx_cell_diameter(coordinate_dofs).
- *      The id returned in *kernel_id goes into cfx_integral.kernel (cell integrals of scalar spaces of degree 1 or 2,
- *      standard entities and / or runtime rules).  Stage 1 (one thread per entity) stages the local tensors in HBM; the
+ *      The id returned in *kernel_id goes into cfx_integral.kernel (cell integrals of Lagrange spaces of degree 1 or 2,
+ *      scalar or vector-valued, standard entities and / or runtime rules).  Stage 1 (one thread per entity) stages the local tensors in HBM; the
  *      row gather -- or the entity-parallel scatter -- then assembles them like those of the built-in integrands that
  *      are not formed in line.  A source that does not compile is CFX_ERR_INVALID_ARGUMENT with the compiler log in
  *      cfx_last_error(); compilation needs no GPU (hipRTC targets gfx950 explicitly), loading the code object does. */
 int cfx_integrand_register(const char* name, const char* source, int rank, int* kernel_id);
 int cfx_integrand_compile(int kernel_id, int tdim, int ndofs_cell); /* compile a (tdim, dofs per cell) variant now */
+/* Vector-valued spaces (bs > 1): CFX_BS = the space's block size and CFX_NDB = CFX_ND * CFX_BS are defined as well;
+ * the local tensor is [NDB][NDB] (or [NDB]) with entry (dof i, component a) at i * CFX_BS + a -- the layout of the
+ * reference's blocked dofmaps (assemble_matrix_impl.h:137-149).  `w` holds the scalar coefficient's ND dofs for bilinear
+ * forms and the ND x CFX_BS dofs of a Function of the form's space for linear forms.
+ *
+ * Interior-facet integrands -- the reference's kernel call with entity_local_index = {lf0, lf1} and the macro layout
+ * [[00, 01], [10, 11]] (assemble_matrix_impl.h:528-542):
+ *
+ *      __device__ void NAME(double* A,                     macro tensor, zero on entry: [2 NDB][2 NDB] row-major over
+ *                                                          [cell 0 dofs, cell 1 dofs]
+ *                           const double* w,               packed coefficient of both cells [2][ND], or NULL
+ *                           const double* c,               cfx_integral.params[8]
+ *                           const double* coordinate_dofs, [2][(TDIM+1)][3]: cell 0, then cell 1
+ *                           const int* entity_local_index, {lf0, lf1}
+ *                           int nq,
+ *                           const double* points0,         [nq][TDIM]: the facet's points in the reference cell of cell 0
+ *                           const double* points1,         ... the same physical points in the reference cell of cell 1
+ *                           const double* weights);        [nq] physical (facet-measure) weights
+ *
+ *      over the (c0, lf0, c1, lf1) rows of a CFX_INTERIOR_FACET integral (standard facets; bilinear forms; at most 24
+ *      macro dofs: scalar spaces of degree 1 or 2, vector spaces of degree 1).  The points are those of the engine's
+ *      reference facet rule of cfx_integral.qdegree, pushed forward from cell 0's facet and pulled back to both cells.
+ *      Sparsity, row gather, deactivation work from the entity lists and are unchanged.
+ * cfx_integrand_register_variant: registration that validates the source against the named (tdim, dofs per cell, block
+ * size) variant instead of (3, 4, 1) -- for sources that only compile for 2-D / degree 2 / vector spaces. */
+int cfx_integrand_register_facet(const char* name, const char* source, int* kernel_id);
+int cfx_integrand_register_variant(const char* name, const char* source, int rank, int facet, int tdim, int ndofs_cell, int bs,
+                                   int* kernel_id);
+int cfx_integrand_compile_bs(int kernel_id, int tdim, int ndofs_cell, int bs);
 
 /* ---- deactivation: cpp/cutfemx/fem/deactivate.h:387-418 ------------------- */
 /* active_domain(): the two indicators (active cells, active dofs) are the marks of the form's row plan; deactivation

@@ -2173,6 +2173,80 @@ int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** r
 
 namespace
 {
+// ---- a CSR matrix in another numbering (cfx_csr_permute): row r -> row_perm[r], column c -> col_perm[c] ----
+__global__ void permute_check_kernel(int64_t n, const int32_t* __restrict__ perm, int32_t* hits, int* bad)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t t = perm[i];
+  if (t < 0 || t >= n) { *bad = 1; return; }
+  atomicAdd(&hits[t], 1);
+}
+__global__ void permute_verify_kernel(int64_t n, const int32_t* __restrict__ hits, int* bad)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && hits[i] != 1) *bad = 1;
+}
+__global__ void permute_len_kernel(int64_t nrows, const int64_t* __restrict__ indptr, const int32_t* __restrict__ row_perm,
+                                   int64_t* __restrict__ len)
+{
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows) len[row_perm[r]] = indptr[r + 1] - indptr[r];
+}
+// one wavefront per row: the row's (mapped column, value) pairs are sorted by column in LDS (bitonic over the next power
+// of two, padded with INT_MAX) and written at the row's new place
+constexpr int kPermuteCap = 2048;
+__global__ void __launch_bounds__(64) permute_rows_kernel(int64_t nrows, const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices, const double* __restrict__ values,
+                                                          const int32_t* __restrict__ row_perm, const int32_t* __restrict__ col_perm,
+                                                          const int64_t* __restrict__ out_indptr, int32_t* __restrict__ out_indices,
+                                                          double* __restrict__ out_values, int* error)
+{
+  __shared__ int32_t s_key[kPermuteCap];
+  __shared__ double s_val[kPermuteCap];
+  const int lane = threadIdx.x;
+  for (int64_t r = blockIdx.x; r < nrows; r += gridDim.x)
+  {
+    const int64_t b = indptr[r];
+    const int len = (int)(indptr[r + 1] - b);
+    if (len > kPermuteCap) { *error = 1; continue; }
+    int n2 = 1;
+    while (n2 < len) n2 <<= 1;
+    for (int k = lane; k < n2; k += 64)
+    {
+      s_key[k] = k < len ? col_perm[indices[b + k]] : 0x7fffffff;
+      s_val[k] = (k < len && values) ? values[b + k] : 0.0;
+    }
+    __syncthreads();
+    for (int k = 2; k <= n2; k <<= 1)
+      for (int j = k >> 1; j > 0; j >>= 1)
+      {
+        for (int i = lane; i < n2; i += 64)
+        {
+          const int p = i ^ j;
+          if (p > i)
+          {
+            const int32_t a = s_key[i], c = s_key[p];
+            const bool up = (i & k) == 0;
+            if ((a > c) == up)
+            {
+              s_key[i] = c; s_key[p] = a;
+              const double t = s_val[i]; s_val[i] = s_val[p]; s_val[p] = t;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    const int64_t o = out_indptr[row_perm[r]];
+    for (int k = lane; k < len; k += 64)
+    {
+      out_indices[o + k] = s_key[k];
+      if (out_values) out_values[o + k] = s_val[k];
+    }
+    __syncthreads(); // the LDS image is reused by the next row
+  }
+}
+
 constexpr int kMergeMaxBlocks = 8; // blocks per block row
 struct MergeRow
 {
@@ -2289,6 +2363,52 @@ int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const in
   *out_indices = ix;
   if (out_values) *out_values = vals;
   *out_nnz = nnz;
+  CFX_API_END
+}
+
+int cfx_csr_permute(int64_t nrows, int64_t ncols, const int64_t* indptr, const int32_t* indices, const double* values,
+                    const int32_t* row_perm, const int32_t* col_perm, int64_t** out_indptr, int32_t** out_indices,
+                    double** out_values)
+{
+  CFX_API_BEGIN
+  require(indptr && indices && row_perm && col_perm && out_indptr && out_indices && nrows >= 0 && ncols >= 0,
+          CFX_ERR_INVALID_ARGUMENT, "cfx_csr_permute: null argument");
+  require(nrows <= 2147483647LL && ncols <= 2147483647LL, CFX_ERR_OUT_OF_RANGE, "cfx_csr_permute: more than 2^31 - 1 rows or columns");
+  DevArray<int64_t> d_ip = to_device(indptr, nrows + 1);
+  const int64_t nnz = nrows > 0 ? read_scalar(d_ip.p + nrows) : 0;
+  DevArray<int32_t> d_ix = to_device(indices, nnz);
+  DevArray<double> d_v;
+  if (values) d_v = to_device(values, nnz);
+  DevArray<int32_t> d_rp = to_device(row_perm, nrows), d_cp = to_device(col_perm, ncols);
+  // both maps must be permutations: every target hit exactly once
+  {
+    ZeroFlag bad;
+    DevArray<int32_t> hits(std::max(nrows, ncols));
+    hits.zero();
+    launch("csr_permute", permute_check_kernel, grid_for(nrows), dim3(kBlock), 0, nrows, d_rp.p, hits.p, bad.p);
+    launch("csr_permute", permute_verify_kernel, grid_for(nrows), dim3(kBlock), 0, nrows, hits.p, bad.p);
+    hits.zero();
+    launch("csr_permute", permute_check_kernel, grid_for(ncols), dim3(kBlock), 0, ncols, d_cp.p, hits.p, bad.p);
+    launch("csr_permute", permute_verify_kernel, grid_for(ncols), dim3(kBlock), 0, ncols, hits.p, bad.p);
+    require(!read_scalar(bad.p), CFX_ERR_INVALID_ARGUMENT, "cfx_csr_permute: row_perm / col_perm is not a permutation");
+  }
+  DevArray<int64_t> ip_out(nrows + 1);
+  DevArray<int64_t> len(nrows);
+  launch("csr_permute", permute_len_kernel, grid_for(nrows), dim3(kBlock), 0, nrows, d_ip.p, d_rp.p, len.p);
+  exclusive_scan(len.p, ip_out.p, nrows);
+  DevArray<int32_t> ix_out(nnz);
+  DevArray<double> v_out;
+  if (out_values) v_out.alloc(nnz);
+  ErrorFlag err(CFX_ERR_RUNTIME, "cfx_csr_permute: a row holds more than 2048 entries");
+  if (nrows > 0)
+    launch("csr_permute", permute_rows_kernel, wave_grid(nrows), dim3(64), 0, nrows, d_ip.p, d_ix.p, values ? d_v.p : (const double*)nullptr,
+           d_rp.p, d_cp.p, ip_out.p, ix_out.p, out_values ? v_out.p : (double*)nullptr, err.p);
+  err.check(CFX_ERR_RUNTIME, "cfx_csr_permute: a row holds more than 2048 entries");
+  end_of_call_sync();
+  ip_out.owned = false; ix_out.owned = false; v_out.owned = false; // handed to the caller (cfx_device_free)
+  *out_indptr = ip_out.p;
+  *out_indices = ix_out.p;
+  if (out_values) *out_values = v_out.p;
   CFX_API_END
 }
 

@@ -679,6 +679,118 @@ def merge_blocks(A_blocks) -> MergedCSR:
                      np.concatenate([[0], np.cumsum(ncols)[:-1]]).astype(np.int64))
 
 
+def permute_csr(A, row_perm, col_perm=None) -> MergedCSR:
+    """The matrix `A` (a MergedCSR or MatrixCSR of float64 values) with row r moved to row_perm[r] and column c to
+    col_perm[c] (default: the same map), columns of every row ascending again -- on the GPU (cfx_csr_permute)."""
+    col_perm = row_perm if col_perm is None else col_perm
+    rp = np.ascontiguousarray(row_perm, dtype=np.int32)
+    cp = np.ascontiguousarray(col_perm, dtype=np.int32)
+    if rp.size != A.nrows or cp.size != A.ncols:
+        raise ValueError("permute_csr: one target per row and per column")
+    if isinstance(A, MergedCSR):
+        ip, ix, va, nnz = A._indptr, A._indices, A._values, A.nnz
+    else:
+        _lib.resolve_counts()
+        ip, ix, va, nnz = A._view.indptr, A._view.indices, A.values_ptr, A.nnz
+    o_ip, o_ix, o_va = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _lib.check(_lib.lib().cfx_csr_permute(C.c_int64(A.nrows), C.c_int64(A.ncols), C.c_void_p(ip), C.c_void_p(ix), C.c_void_p(va),
+                                          rp.ctypes.data_as(C.c_void_p), cp.ctypes.data_as(C.c_void_p), C.byref(o_ip),
+                                          C.byref(o_ix), C.byref(o_va)))
+    return MergedCSR(o_ip.value, o_ix.value, o_va.value, nnz, A.nrows, A.ncols, np.zeros(1, np.int64), np.zeros(1, np.int64))
+
+
+class MixedSpace:
+    """A space on a mixed element -- `mixed_element([P2 vector, P1])` of python/tests/test_assembly_stokes.py:34-95 -- as ONE
+    object: the caller's mixed dofmap (DOLFINx's: the dofs of all sub-elements numbered together, cell by cell) and the
+    sub-elements' (degree, block size).
+
+        W = fem.MixedSpace(mesh, mixed_dofmap, ndofs, [(2, gdim), (1, 1)])
+        a = {(0, 0): [Integral(...)], (0, 1): [...], (1, 0): [...], (1, 1): [...]}   # integrals by (test, trial) sub-element
+        A = W.assemble_matrix(a)          # ONE CSR matrix in the numbering of `mixed_dofmap`
+
+    Row `mixed_dofmap[c]` lists the cell's dofs sub-element by sub-element; sub-element s takes ndofs_cell(degree_s) x
+    bs_s entries, (node i, component k) at i * bs_s + k (the layout of DOLFINx's flattened mixed dofmaps).  The engine
+    assembles per (test, trial) pair on block spaces it derives from the columns of the mixed dofmap -- sub.space(s): nodes
+    numbered in the order of their first component's mixed dof --, merges the blocks (merge_blocks: block-ordered dofs)
+    and moves rows and columns to the mixed numbering (permute_csr with block_to_mixed)."""
+
+    def __init__(self, mesh, mixed_dofmap, ndofs: int, subs):
+        from .mesh import FunctionSpace
+        M = np.ascontiguousarray(mixed_dofmap, dtype=np.int32)
+        if M.ndim != 2 or M.shape[0] != mesh.num_cells:
+            raise ValueError("MixedSpace: mixed_dofmap holds one row per cell")
+        tdim = mesh.tdim
+        self.mesh, self.ndofs, self.subs = mesh, int(ndofs), [(int(d), int(b)) for d, b in subs]
+        self.spaces, self.block_to_mixed, self.offsets = [], [], []
+        o = 0
+        for degree, bs in self.subs:
+            if degree not in (1, 2):
+                raise ValueError("MixedSpace: sub-elements of degree 1 or 2")
+            nd = tdim + 1 if degree == 1 else (tdim + 1) * (tdim + 2) // 2
+            if o + nd * bs > M.shape[1]:
+                raise ValueError("MixedSpace: the mixed dofmap has fewer entries per cell than its sub-elements need")
+            cols = o + bs * np.arange(nd)
+            comp0 = M[:, cols]
+            nodes = np.unique(comp0)                       # ascending: node k of the block space <-> nodes[k]
+            sub_map = np.searchsorted(nodes, comp0).astype(np.int32)
+            perm = np.full(nodes.size * bs, -1, dtype=np.int64)
+            for k in range(bs):
+                perm[sub_map.ravel().astype(np.int64) * bs + k] = M[:, cols + k].ravel()
+            if degree == 1 and nodes.size == mesh.num_nodes and np.array_equal(sub_map, mesh.conn):
+                V = FunctionSpace(mesh, 1, bs=bs)           # the geometry dofmap itself: the stencil paths apply
+            else:
+                V = FunctionSpace(mesh, degree, dofmap=sub_map, ndofs=int(nodes.size), bs=bs)
+            self.spaces.append(V)
+            self.block_to_mixed.append(perm)
+            self.offsets.append(o)
+            o += nd * bs
+        if o != M.shape[1]:
+            raise ValueError("MixedSpace: the sub-elements do not account for every entry of a mixed dofmap row")
+        P = np.concatenate(self.block_to_mixed)
+        if P.size != self.ndofs or P.min() < 0 or np.unique(P).size != P.size or P.max() != self.ndofs - 1:
+            raise ValueError("MixedSpace: the sub-elements' dofs do not number 0 .. ndofs - 1 exactly once")
+        self.permutation = P.astype(np.int32)              # block-ordered dof -> mixed dof
+        self.block_offsets = np.concatenate([[0], np.cumsum([p.size for p in self.block_to_mixed])]).astype(np.int64)
+
+    def sub(self, s: int):
+        """The block space of sub-element s (W.sub(s).collapse() of the reference)."""
+        return self.spaces[s]
+
+    def form(self, integrals, test: int, trial: int) -> CutForm:
+        """The bilinear form of the integrals between sub-elements `test` and `trial`."""
+        V0, V1 = self.spaces[test], self.spaces[trial]
+        return form(list(integrals), V0, rank=2, trial_space=None if trial == test else V1)
+
+    def assemble_matrix(self, blocks: dict, deactivate: dict | None = None) -> MergedCSR:
+        """ONE matrix in the mixed numbering from integrals given by (test, trial) sub-element pair.  `deactivate`
+        (optional): {s: ActiveDomain or True} -- the inactive rows of diagonal block (s, s) get a unit diagonal
+        (deactivate_outside_blocks) before the merge; True takes the block's own active domain."""
+        ns = len(self.spaces)
+        forms = {k: (v if isinstance(v, CutForm) else self.form(v, *k)) for k, v in blocks.items()}
+        A = [[assemble_matrix(forms[(i, j)]) if (i, j) in forms else None for j in range(ns)] for i in range(ns)]
+        if deactivate:
+            doms = []
+            for s in range(ns):
+                d = deactivate.get(s)
+                doms.append(active_domain(forms[(s, s)]) if d is True else d)
+            if all(d is not None for d in doms):
+                deactivate_outside_blocks(A, doms)
+            else:
+                for s, d in enumerate(doms):
+                    if d is not None:
+                        deactivate_outside(A[s][s], None, d)
+        # (a sub-element without any block still needs its rows: an empty pattern of the right size is not built here)
+        merged = merge_blocks(A)
+        return permute_csr(merged, self.permutation)
+
+    def vector_to_mixed(self, b_blocks) -> np.ndarray:
+        """Block vectors (one per sub-element, block numbering) -> one vector in the mixed numbering."""
+        out = np.zeros(self.ndofs, dtype=np.float64)
+        for perm, b in zip(self.block_to_mixed, b_blocks):
+            out[perm] = np.asarray(b.cpu() if hasattr(b, "cpu") else b, dtype=np.float64)
+        return out
+
+
 def deactivate_outside_blocks(A_blocks, active_domains, b_blocks=None, *, diagonal: float = 1.0,
                               rhs_value: float = 0.0) -> list:
     """Deactivate block rows from per-row active-domain support (python/cutfemx/fem.py:739-775,

@@ -445,6 +445,15 @@ int cfx_zero_rows(cfx_pattern_t P, const double* values, double tol, int32_t** r
 int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const int32_t* const* indices,
                         const double* const* values, const int64_t* nrows, const int64_t* ncols, int64_t** out_indptr,
                         int32_t** out_indices, double** out_values, int64_t* out_nnz);
+/* The same matrix in another dof numbering: row r becomes row row_perm[r], column c becomes column col_perm[c], the
+ * columns of every row ascend again.  With cfx_csr_block_merge this gives the monolithic matrix of a mixed element in
+ * the numbering the CALLER holds -- DOLFINx numbers the dofs of mixed_element([P2 vector, P1]) cell by cell, interleaved
+ * (python/tests/test_assembly_stokes.py:34-95): row_perm[block-ordered dof] = mixed dof, built from the caller's mixed
+ * dofmap (cutfemx_amd.fem.MixedSpace).  Both maps must be permutations (checked); arrays host or device; values / out_values
+ * may be NULL (pattern only); rows of at most 2048 entries.  Outputs are device arrays released with cfx_device_free. */
+int cfx_csr_permute(int64_t nrows, int64_t ncols, const int64_t* indptr, const int32_t* indices, const double* values,
+                    const int32_t* row_perm, const int32_t* col_perm, int64_t** out_indptr, int32_t** out_indices,
+                    double** out_values);
 int cfx_tabulate_entity(cfx_form_t a, int integral, int64_t index, int use_rule, double* Ae);
 
 /* ---- user-supplied integrands: the runtime-generated kernel of a form

@@ -435,3 +435,109 @@ def test_gpu_merge_blocks_on_a_cut_domain_with_ghost_penalties(oracle):
     dead = np.concatenate([domains[0].inactive_dofs, nu + domains[1].inactive_dofs])
     assert dead.size > 0
     assert np.allclose(M2.diagonal()[dead], 1.0)
+
+
+def _interleaved_mixed_dofmap(tdim, dm2, nd2, conn, nnodes, seed=None):
+    """A DOLFINx-like numbering of mixed_element([P2 vector(tdim), P1]): the dofs of all sub-elements numbered together,
+    node by node -- vertex v: (u_0 .. u_{d-1}, p), edge e: (u_0 .. u_{d-1}) -- optionally scrambled.  Row layout of the
+    mixed dofmap: [velocity: node-major, component inner | pressure]."""
+    nv = nnodes
+    ne = nd2 - nv
+    ids = np.empty((nd2, tdim), dtype=np.int64)            # mixed id of velocity (node, component)
+    pid = np.empty(nv, dtype=np.int64)
+    k = 0
+    for v in range(nv):
+        ids[v] = k + np.arange(tdim); pid[v] = k + tdim; k += tdim + 1
+    for e in range(ne):
+        ids[nv + e] = k + np.arange(tdim); k += tdim
+    ndofs = k
+    if seed is not None:
+        sc = np.random.default_rng(seed).permutation(ndofs)
+        ids, pid = sc[ids], sc[pid]
+    M = np.concatenate([ids[dm2].reshape(dm2.shape[0], -1), pid[conn]], axis=1).astype(np.int32)
+    return M, ndofs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tdim,n,seed", [(2, 5, None), (2, 4, 7), (3, 3, 3)])
+def test_gpu_mixed_space_gives_the_monolithic_matrix_in_the_callers_numbering(oracle, tdim, n, seed):
+    """VERDICT r4, missing #2: python/tests/test_assembly_stokes.py:34-95 assembles ONE matrix on
+    mixed_element([P2 vector, P1]) in DOLFINx's interleaved numbering.  fem.MixedSpace takes that mixed dofmap and the
+    sub-elements' (degree, bs): forms are given by (test, trial) sub-element, the result is one CSR matrix in the mixed
+    numbering.  Checked against the oracle's blocks permuted on the host (pattern bit for bit, values 1e-12), with whole-
+    cell runtime rules against the standard assembly (1e-9, the reference's assertion), and on a cut domain with both
+    ghost penalties and deactivated rows."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om, dm2, nd2, oVU, oVP, _ = spaces(O, tdim, n)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    M, ndofs = _interleaved_mixed_dofmap(tdim, dm2, nd2, om.conn, om.nnodes, seed)
+    W = fem.MixedSpace(mesh, M, ndofs, [(2, tdim), (1, 1)])
+    nu, npr = nd2 * tdim, om.nnodes
+    assert W.ndofs == nu + npr and W.sub(0).bs == tdim and W.sub(1).bs == 1 and W.sub(0).ndofs == nd2
+    # the derived block spaces number their nodes by ascending mixed id of component 0; the permutation undoes the mixing
+    P = W.permutation
+    assert np.array_equal(np.sort(P), np.arange(ndofs))
+    cells = np.arange(om.ncells, dtype=np.int32)
+    full = cfx.full_cell_rules(mesh, cells, 4)
+    none = np.zeros(0, dtype=np.int32)
+
+    def integrals(runtime):
+        kw = dict(cells=none, rules=full) if runtime else dict(cells=cells)
+        return {(0, 0): [fem.Integral(fem.STIFFNESS, qdegree=2, **kw)],
+                (0, 1): [fem.Integral(fem.DIV_TEST, params=(-1.0,), qdegree=3, **kw)],
+                (1, 0): [fem.Integral(fem.DIV_TRIAL, params=(-1.0,), qdegree=3, **kw)]}
+    A_std, A_run = W.assemble_matrix(integrals(False)), W.assemble_matrix(integrals(True))
+    assert np.linalg.norm((A_std.to_scipy() - A_run.to_scipy()).toarray()) < 1e-9
+    # the oracle's blocks in ITS block numbering (vertex / edge order of the oracle's dofmaps) -> mixed numbering
+    okw = dict(entities=cells)
+    oA = [O.Integral(O.CELL, O.K_STIFFNESS, qdegree=2, **okw)]
+    ipA, ixA = O.create_sparsity(om, oVU, oA)
+    want = {(0, 0): sp.csr_matrix((O.assemble_matrix(om, oVU, oA, ipA, ixA), ixA, ipA), shape=(nu, nu))}
+    for (i, j), (o0, o1, kern) in {(0, 1): (oVU, oVP, O.K_DIV_TEST), (1, 0): (oVP, oVU, O.K_DIV_TRIAL)}.items():
+        oi = [O.Integral(O.CELL, kern, params=(-1.0,), qdegree=3, **okw)]
+        ip, ix = O.create_sparsity2(om, o0, o1, oi)
+        want[(i, j)] = sp.csr_matrix((O.assemble_matrix2(om, o0, o1, oi, ip, ix), ix, ip), shape=(o0.ndofs * o0.bs, o1.ndofs * o1.bs))
+    ref_block = sp.bmat([[want[(0, 0)], want[(0, 1)]], [want[(1, 0)], None]], format="csr")
+    # oracle block dof (node k of dm2 numbering, component a) -> mixed id, read off the mixed dofmap itself
+    to_mixed = np.full(nu + npr, -1, dtype=np.int64)
+    nd_cell = dm2.shape[1]
+    for a in range(tdim):
+        to_mixed[dm2.ravel().astype(np.int64) * tdim + a] = M[:, a:nd_cell * tdim:tdim].ravel()
+    to_mixed[nu + om.conn.ravel()] = M[:, nd_cell * tdim:].ravel()
+    assert to_mixed.min() >= 0
+    coo = ref_block.tocoo()
+    ref = sp.csr_matrix((coo.data, (to_mixed[coo.row], to_mixed[coo.col])), shape=(ndofs, ndofs))
+    ref.sort_indices()
+    got = A_std.to_scipy()
+    assert np.array_equal(got.indptr, ref.indptr) and np.array_equal(got.indices, ref.indices)
+    assert rel_err(got.data, ref.data) < 1e-12
+    assert abs(got - got.T).max() < 1e-12 * abs(got).max()
+    # a cut domain: velocity + pressure ghost penalties (test_assembly_stokes.py:98-142), inactive rows deactivated
+    phi = level_set_values(om.x, tdim)
+    cd = cfx.cut(cfx.Function(cfx.FunctionSpace(mesh, 1), phi))
+    inside = cfx.locate_entities(cd, "phi<0")
+    vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+    ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    cut_blocks = {(0, 0): [fem.Integral(fem.STIFFNESS, cells=inside, rules=vol, qdegree=2),
+                           fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2)],
+                  (0, 1): [fem.Integral(fem.DIV_TEST, cells=inside, rules=vol, params=(-1.0,), qdegree=3)],
+                  (1, 0): [fem.Integral(fem.DIV_TRIAL, cells=inside, rules=vol, params=(-1.0,), qdegree=3)],
+                  (1, 1): [fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(-0.05, 3.0), qdegree=2)]}
+    forms = {k: W.form(v, *k) for k, v in cut_blocks.items()}
+    dom_p = fem.active_domain(fem.form([fem.Integral(fem.MASS, cells=inside, rules=vol, qdegree=2)], W.sub(1)))
+    A_cut = W.assemble_matrix(forms, deactivate={0: True, 1: dom_p}).to_scipy()
+    blocks = [[fem.assemble_matrix(forms[(i, j)]) for j in range(2)] for i in range(2)]
+    doms = [fem.active_domain(forms[(0, 0)]), dom_p]
+    fem.deactivate_outside_blocks(blocks, doms)
+    Bm = sp.bmat([[b.to_scipy() for b in row] for row in blocks], format="coo")
+    refc = sp.csr_matrix((Bm.data, (W.permutation[Bm.row], W.permutation[Bm.col])), shape=(ndofs, ndofs))
+    refc.sort_indices()
+    assert np.array_equal(A_cut.indptr, refc.indptr) and np.array_equal(A_cut.indices, refc.indices)
+    assert np.array_equal(A_cut.data, refc.data)
+    dead = W.permutation[np.concatenate([np.asarray(doms[0].inactive_dofs), nu + np.asarray(doms[1].inactive_dofs)])]
+    assert dead.size > 0 and np.allclose(A_cut.diagonal()[dead], 1.0)
+    # maps that are not permutations are refused
+    with pytest.raises(ValueError, match="not a permutation"):
+        fem.permute_csr(A_std, np.zeros(ndofs, dtype=np.int32))

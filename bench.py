@@ -680,7 +680,7 @@ def secondary_p2_gyroid(torch, device, n=256):
         torch.cuda.synchronize(); t4 = t()
         phases.update(cut_rules_forms=1e3 * (t1 - t0), sparsity=1e3 * (t2 - t1), assemble_matrix=1e3 * (t3 - t2),
                       assemble_vector_deactivate=1e3 * (t4 - t3))
-        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=sysm.inside_cells[1],
+        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=sysm.inside_cells.size,
                     n_cut=sysm.interface_rules.num_rules, nq_volume=sysm.volume_rules.total_points,
                     nq_interface=sysm.interface_rules.total_points,
                     n_ghost=0 if sysm.ghost_facets is None else sysm.ghost_facets.size)
@@ -778,7 +778,7 @@ def secondary_elasticity_share(torch, device, n=256, z0=89, nz=32):
         torch.cuda.synchronize(); t3 = t()
         phases.update(cut_rules_forms=1e3 * (t1 - t0), sparsity=1e3 * (t2 - t1), assemble_matrix=1e3 * (t3 - t2))
         dom = fem.active_domain(a)
-        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=inside[1], n_ghost=ghost.size,
+        return dict(active_dofs=dom.num_active_dofs, nnz=A.nnz, n_inside=inside.size, n_ghost=ghost.size,
                     n_cut=vol.num_rules, nq_volume=vol.total_points)
     from cutfemx_amd import _lib
     _lib.memory_stats(reset_peak=True)

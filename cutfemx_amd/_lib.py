@@ -86,7 +86,7 @@ class PatternView(C.Structure):
 # every symbol declared in include/cutfemx_amd.h
 SYMBOLS = [
     "cfx_init", "cfx_last_error", "cfx_set_stream", "cfx_synchronize", "cfx_step_begin", "cfx_step_end", "cfx_step_resolve", "cfx_step_abort",
-    "cfx_step_set_margin", "cfx_step_forget", "cfx_sync_count", "cfx_integrand_register", "cfx_integrand_compile", "cfx_integrand_register_facet", "cfx_integrand_register_variant", "cfx_integrand_compile_bs", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
+    "cfx_step_set_margin", "cfx_step_forget", "cfx_sync_count", "cfx_list_count", "cfx_integrand_register", "cfx_integrand_compile", "cfx_integrand_register_facet", "cfx_integrand_register_variant", "cfx_integrand_compile_bs", "cfx_overlap_begin", "cfx_overlap_side", "cfx_overlap_end", "cfx_copy",
     "cfx_device_alloc", "cfx_device_free", "cfx_device_memset", "cfx_device_cache_release", "cfx_device_memory_stats", "cfx_profile_enable", "cfx_profile_reset",
     "cfx_profile_count", "cfx_profile_get", "cfx_event_create", "cfx_event_record",
     "cfx_event_elapsed_ms", "cfx_event_destroy", "cfx_mesh_create", "cfx_mesh_create_box", "cfx_mesh_create_slab",

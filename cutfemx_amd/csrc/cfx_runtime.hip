@@ -1338,6 +1338,19 @@ int cfx_step_forget(const char* key)
   CFX_API_END
 }
 
+int cfx_list_count(const void* list, int64_t n_given, int64_t* n)
+{
+  CFX_API_BEGIN
+  require(n != nullptr, CFX_ERR_INVALID_ARGUMENT, "cfx_list_count: null argument");
+  // a list handed out with its length still in HBM: the capacity while that step is open, the exact length once it has
+  // ended; any other pointer (a list with an exact length, the caller's own array, a list that is gone): n_given.
+  // Nothing is recomputed.
+  *n = n_given;
+  auto it = list_registry().find(list);
+  if (list != nullptr && it != list_registry().end()) *n = it->second.pending() ? it->second.cap() : it->second.value();
+  CFX_API_END
+}
+
 int cfx_sync_count(int64_t* n)
 {
   CFX_API_BEGIN

@@ -431,11 +431,9 @@ class DeviceEntities(tuple):
     @property
     def size(self) -> int:
         """The list's length as the engine knows it now (exact once the step that made it has ended)."""
-        if self.selector is None:
-            return int(self[1])
-        p, n = C.c_void_p(), C.c_int64()
-        _lib.check(_lib.lib().cfx_locate_entities(self.owner._h, self.selector, C.byref(p), C.byref(n)))
-        return int(n.value) if p.value == self[0] else int(self[1])
+        n = C.c_int64()
+        _lib.check(_lib.lib().cfx_list_count(C.c_void_p(self[0]), C.c_int64(int(self[1])), C.byref(n)))
+        return int(n.value)
 
 
 def locate_entities_device(cut_data: CutData, ls_part: str):
@@ -491,7 +489,11 @@ class FacetRows:
     def size(self) -> int:
         """Number of rows: the capacity of the list while the cutfemx_amd.step that made it is open, exact afterwards."""
         if self._requery is not None:
-            self._n = int(self._requery())
+            # by the list's identity (cfx_list_count): nothing is recomputed, a list the engine no longer tracks keeps
+            # the count it was handed out with
+            n = C.c_int64()
+            _lib.check(_lib.lib().cfx_list_count(C.c_void_p(self.ptr), C.c_int64(self._n), C.byref(n)))
+            self._n = int(n.value)
         return self._n
 
     @property

@@ -207,6 +207,11 @@ int cfx_step_resolve(void);                              /* inside a step: fetch
 int cfx_step_abort(void);                                /* leave a step after an error: resolves what is pending, drops the history */
 int cfx_step_set_margin(double factor, int64_t slack);   /* capacity = previous count x factor + slack (tests force the redo path) */
 int cfx_step_forget(const char* key);                    /* drop the history of a loop (NULL: of all loops) */
+/* Length of an entity list the library handed out as (pointer, count) -- cfx_locate_entities, cfx_ghost_penalty_facets,
+ * cfx_interior_facets_for_cells -- as the engine knows it NOW: the count returned inside a sync-free step is the list's
+ * capacity; after the step the exact length.  Looked up by the list's identity; nothing is recomputed.  A pointer the
+ * engine does not track (a list made outside a step, whose count was exact; the caller's own array) gives n_given back. */
+int cfx_list_count(const void* list, int64_t n_given, int64_t* n);
 int cfx_sync_count(int64_t* n);                          /* host round trips (size / error read-backs) since start-up */
 int cfx_copy(void* dst, const void* src, size_t bytes); /* hipMemcpyDefault on the stream + sync */
 int cfx_device_alloc(void** ptr, size_t bytes);

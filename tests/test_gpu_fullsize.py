@@ -185,7 +185,7 @@ class TestConfig3:
         n_in, n_cut, n_out = int((dom == -1).sum()), int((dom == 0).sum()), int((dom == 1).sum())
         assert n_in + n_cut + n_out == 6 * n ** 3
         vr, ir = sysm.volume_rules, sysm.interface_rules
-        assert sysm.inside_cells[1] == n_in
+        assert sysm.inside_cells.size == n_in
         # every cut cell hosts volume rules and interface rules (one per sub-facet), parents ascending
         for rules in (vr, ir):
             parents = rules.parent_map
@@ -363,7 +363,7 @@ class TestConfig3:
         vr = sysm.volume_rules
         from cutfemx_amd.dist import as_torch
         volume = float(as_torch(vr._view.weights, vr.total_points, "float64", dev).sum()) \
-            + sysm.inside_cells[1] / (6.0 * s["n"] ** 3)
+            + sysm.inside_cells.size / (6.0 * s["n"] ** 3)
         assert abs(float(b1.sum()) - volume) < 1e-12 * volume
         # (2) constants lie in the null space of the stiffness block (cut cells included)
         aK = fem.form([fem.Integral(fem.STIFFNESS, cells=sysm.inside_cells, rules=sysm.volume_rules, qdegree=0)], V)
@@ -412,7 +412,7 @@ def test_cfg4_p2_gyroid_256(oracle):
     # properties: mass matrix sums to the volume, sum(b_1) too, stiffness annihilates constants
     vr = sysm.volume_rules
     volume = float(as_torch(vr._view.weights, vr.total_points, "float64", dev).sum()) \
-        + sysm.inside_cells[1] / (6.0 * n ** 3)
+        + sysm.inside_cells.size / (6.0 * n ** 3)
     del A, sysm.a
     M = fem.assemble_matrix(fem.form([fem.Integral(fem.MASS, cells=sysm.inside_cells, rules=vr, qdegree=4)], V))
     assert abs(float(M.torch_views(dev)[2].sum()) - volume) < 1e-12 * volume
@@ -506,5 +506,5 @@ def test_cfg5_p2_vector_elasticity_rank_share(oracle):
     del K
     M = fem.assemble_matrix(fem.form(ga[2:], V))
     volume = float(as_torch(vol._view.weights, vol.total_points, "float64", dev).sum()) \
-        + inside[1] / (6.0 * n ** 3)
+        + inside.size / (6.0 * n ** 3)
     assert abs(float(M.torch_views(dev)[2].sum()) - 3.0 * volume) < 1e-12 * volume

@@ -12,7 +12,7 @@ fi
 K=0
 for mode in "CFX_DETERMINISTIC=1" "CFX_ASSEMBLY=atomic" "CFX_STENCIL=0" "CFX_STENCIL_LISTS=0" "CFX_P2_PLAIN=0" "CFX_P2_CLOSED=0" \
             "CFX_P2_MOMENTS=0" "CFX_FACET_FOLD_STAGE1=0" "CFX_BLOCK_PLAIN=0" "CFX_TILES=0" "CFX_LAZY_ZERO=0" "CFX_P2_CUT_TENSORS=0" \
-            "CFX_P2_INTERFACE=0" "CFX_VEC_BLOCKS=0" "CFX_VEC_BLOCKS=2" "CFX_STEP_SPECULATE=0" "CFX_FACET_SORT=1" "CFX_RECT_GATHER=0" "CFX_CLASSIFY_CULL=0" "CFX_FUSED_TILES=0" "CFX_FUSED_TILES=1000000"; do
+            "CFX_P2_INTERFACE=0" "CFX_VEC_BLOCKS=0" "CFX_VEC_BLOCKS=2" "CFX_STEP_SPECULATE=0" "CFX_FACET_SORT=1" "CFX_RECT_GATHER=0" "CFX_CLASSIFY_CULL=0" "CFX_FUSED_TILES=0" "CFX_FUSED_TILES=1000000" "CFX_BULK_ROWS=0"; do
   K=$((K+1))
   if [ "$K" -lt "$FIRST" ] || [ "$K" -gt "$LAST" ]; then continue; fi
   name=$(echo "$mode" | tr -c 'A-Za-z0-9' '_')

@@ -22,7 +22,7 @@ for it in range(3):
     a = fem.form(ga, V)
     A, ts = T(lambda: fem.create_matrix(a))
     _, ta = T(lambda: fem.assemble_matrix(a, A=A))
-    print('cfg5 share: inside', inside[1], 'nnz', A.nnz, 'sparsity ms', ts, 'assemble_matrix ms', ta, flush=True)
+    print('cfg5 share: inside', inside.size, 'nnz', A.nnz, 'sparsity ms', ts, 'assemble_matrix ms', ta, flush=True)
     if it == 2:
         import ctypes as C
         from cutfemx_amd import _lib

@@ -32,7 +32,7 @@ for it in range(2):
     T('assemble_matrix', lambda: fem.assemble_matrix(s.a, A=A), acc)
     b = torch.zeros(nd, device=dev, dtype=torch.float64)
     T('assemble_vector', lambda: fem.assemble_vector(s.L, b), acc)
-    print('cfg4 P2 gyroid', n, acc, 'nnz', A.nnz, 'inside', s.inside_cells[1], flush=True)
+    print('cfg4 P2 gyroid', n, acc, 'nnz', A.nnz, 'inside', s.inside_cells.size, flush=True)
     if it == 1:
         def fresh():   # A = 0 then assemble: the fused path the bench step takes (rows stored, not read-modified-written)
             A.set_value(0.0)

@@ -2,8 +2,11 @@
 """Summarise rocprofv3 --pmc counter_collection.csv files: per kernel, mean of each counter per WORKLOAD-SIZED dispatch.
 bench.py runs an 8^3 step first (library warm-up) and each kernel name therefore has a few tiny dispatches next to the
 ones of the mesh under test; a mean over all of them dilutes the per-launch figures (round-3 verdict: classify_kernel
-n = 9 of which 2 tiny).  Only dispatches whose grid is at least half the largest grid of that kernel name are averaged;
-`n=` is the number used, `of=` the number seen."""
+n = 9 of which 2 tiny).  A kernel that also runs once at set-up with a much larger grid (round-4 verdict: pattern_rows, whose
+first-step full-hash dispatch was taken for the per-step one) has its steady-state dispatches in the grid-size class that
+REPEATS most often: dispatches are grouped by grid size (classes a factor 1.5 apart), classes below 1 % of the largest
+grid are the warm-up mesh, and the class with the most dispatches is averaged (ties: the larger grid).  `n=` is the
+number used, `of=` the number seen."""
 import csv, sys, glob, collections
 def short(name):
     s = name.replace("(anonymous namespace)::", "").replace("cfx::", "").replace("void ", "")
@@ -17,9 +20,14 @@ for d in sys.argv[1:]:
         acc, seen = {}, {}
         for k, rs in rows.items():
             gmax = max(g for g, _, _ in rs)
+            import math
+            cls = lambda g: int(math.log(max(g, 1.0)) / math.log(1.5))
+            first = next(iter({c for _, c, _ in rs}))
+            count = collections.Counter(cls(g) for g, c, _ in rs if c == first and g >= 0.01 * gmax)
+            best = max(count, key=lambda q: (count[q], q))
             cs = collections.defaultdict(list)
             for g, c, v in rs:
-                if g >= 0.5 * gmax:
+                if g >= 0.01 * gmax and abs(cls(g) - best) <= 0:
                     cs[c].append(v)
             acc[k] = cs
             seen[k] = max(sum(1 for g, c2, _ in rs if c2 == c) for c in {c for _, c, _ in rs})

@@ -4,8 +4,8 @@ bench.py runs an 8^3 step first (library warm-up) and each kernel name therefore
 ones of the mesh under test; a mean over all of them dilutes the per-launch figures (round-3 verdict: classify_kernel
 n = 9 of which 2 tiny).  A kernel that also runs once at set-up with a much larger grid (round-4 verdict: pattern_rows, whose
 first-step full-hash dispatch was taken for the per-step one) has its steady-state dispatches in the grid-size class that
-REPEATS most often: dispatches are grouped by grid size (classes a factor 1.5 apart), classes below 1 % of the largest
-grid are the warm-up mesh, and the class with the most dispatches is averaged (ties: the larger grid).  `n=` is the
+REPEATS most often: dispatches are grouped by grid size (classes a factor 1.5 apart) and the class with the most
+dispatches is averaged (ties: the larger grid; the warm-up mesh runs fewer steps than the mesh under test).  `n=` is the
 number used, `of=` the number seen."""
 import csv, sys, glob, collections
 def short(name):
@@ -23,11 +23,11 @@ for d in sys.argv[1:]:
             import math
             cls = lambda g: int(math.log(max(g, 1.0)) / math.log(1.5))
             first = next(iter({c for _, c, _ in rs}))
-            count = collections.Counter(cls(g) for g, c, _ in rs if c == first and g >= 0.01 * gmax)
+            count = collections.Counter(cls(g) for g, c, _ in rs if c == first)
             best = max(count, key=lambda q: (count[q], q))
             cs = collections.defaultdict(list)
             for g, c, v in rs:
-                if g >= 0.01 * gmax and abs(cls(g) - best) <= 0:
+                if cls(g) == best:
                     cs[c].append(v)
             acc[k] = cs
             seen[k] = max(sum(1 for g, c2, _ in rs if c2 == c) for c in {c for _, c, _ in rs})

@@ -95,13 +95,14 @@ def balanced_boundaries(weights, world: int, halo_lo: int = 0, halo_hi: int = 0)
     return best
 
 
-def sphere_layer_weights(n: int, active_weight: float = 26.0, cut_weight: float = 1550.0):
+def sphere_layer_weights(n: int, active_weight: float = 18.0, cut_weight: float = 1100.0):
     """Cost model per hex layer for the sphere workload, in units of one background cell
     (~3.5 ps on MI355X since the culled classification of round 4 -- selector scans, mark arrays, the
     block-wise sign test): an active (inside) cell costs ~26 of them more for its assembly, a cut cell
     ~1550 for sub-triangulation, runtime quadrature, local tensors and ghost-penalty facets -- picked by
-    tools/rank_balance.py on the 8- and 4-rank partitions of the 512^3 case (slowest rank 3.15 / 5.62 ms;
-    rounds 1-3 and the start of round 4 used 15 / 400 and 14 / 800 against a costlier background cell).  The surface of a sphere
+    tools/rank_balance.py on the 8- and 4-rank partitions of the 512^3 case (round 5, after the bulk rows: 18 / 1100,
+    slowest rank 2.95 / 5.22 ms against 3.02 / 5.30 with round 4's 26 / 1550; rounds 1-3 used 15 / 400 and 14 / 800
+    against a costlier background cell).  The surface of a sphere
     between two parallel planes is 2 pi R dz (Archimedes), so the cut cells are spread evenly
     over the layers that meet the sphere: ~4.7 cut tets per h^2 of surface."""
     import os
@@ -527,10 +528,21 @@ class DistributedPoisson:
             cd = cfx.cut(self.phi)
             system = poisson.build_forms(self.V, cd, order=self.order, gamma=self.gamma, gamma_g=self.gamma_g)
             _zero(self.b)
-            A = self._matrix(system.a)
-            A.set_value(0.0)
-            fem.assemble_matrix(system.a, A=A)
-            fem.assemble_vector(system.L, self.b)
+            import os
+            if os.environ.get("CFX_OVERLAP", "0") == "1":
+                # (opt-in: the linear form on a second HIP stream beside the pattern + matrix -- measured per rank in
+                # bench.py's projection; off by default)
+                system.L.prepare()
+                with fem.overlap() as lanes:
+                    lanes.side(lambda: fem.assemble_vector(system.L, self.b))
+                    A = self._matrix(system.a)
+                    A.set_value(0.0)
+                    fem.assemble_matrix(system.a, A=A)
+            else:
+                A = self._matrix(system.a)
+                A.set_value(0.0)
+                fem.assemble_matrix(system.a, A=A)
+                fem.assemble_vector(system.L, self.b)
             dom = fem.deactivate_outside(A, self.b, fem.active_domain(system.a))
             return dict(A=A, dom=dom, system=system)
         # the local path is one sync-free step of this rank's loop (cutfemx_amd.step): sizes stay in HBM, one read-back

@@ -55,7 +55,10 @@ def test_the_bulk_path_is_taken_and_equals_the_list_walk_and_the_oracle(oracle, 
     (s2, A2, b2, dom2), names2 = profiled(lambda: poisson_system(cfx, V, cd2))
     assert "plan_row_class" not in names2 and ("plan_mark_entities" in names2 or switched_off)
     assert np.array_equal(A.indptr, A2.indptr) and np.array_equal(A.indices, A2.indices)
-    assert np.array_equal(A.data, A2.data) and np.array_equal(b, b2)
+    if os.environ.get("CFX_ASSEMBLY") == "atomic":      # (FP64 atomics: the order of the sums is the schedule's)
+        assert rel_err(A.data, A2.data) < 1e-13 and rel_err(b, b2) < 1e-13
+    else:
+        assert np.array_equal(A.data, A2.data) and np.array_equal(b, b2)
     assert np.array_equal(dom.inactive_dofs, dom2.inactive_dofs)
 
 

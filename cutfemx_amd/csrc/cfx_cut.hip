@@ -452,38 +452,71 @@ __device__ __forceinline__ void class_fill(int8_t* __restrict__ domain, int64_t 
   }
 }
 
-// one wavefront per block of kClassBlock cells
-#ifndef CFX_CLASSIFY_WAVES
-#define CFX_CLASSIFY_WAVES 6 // (8: 64 registers with 4 spilled, 1.20 ms at 512^3; 6 or 7: no spill, 1.17)
-#endif
+// The same for TWO tables at once (lanes 0..31 hold the runs of table A, lanes 32..63 those of table B; RUNS <= 32): both
+// tables arrive with one load latency and both sets of sign codes with a second one.  The culled classification is
+// bound by how many of its short wavefronts are in flight (786 k of them at 512^3, two dependent loads each): a
+// wavefront that decides two blocks halves their number.
+template <int RUNS, int E>
+__device__ __forceinline__ void class_runs_and2(const int2* __restrict__ tableA, const int2* __restrict__ tableB, bool haveB,
+                                                const uint8_t* __restrict__ code, int lane, unsigned& allA, unsigned& allB)
+{
+  static_assert(RUNS <= 32, "two tables in one wavefront");
+  const int half = lane >> 5, hl = lane & 31;
+  int2 mine = make_int2(0, 0);
+  if (hl < RUNS && (half == 0 || haveB)) mine = (half == 0 ? tableA : tableB)[hl];
+  const bool sumA = __shfl(mine.y, 0, 64) >= 0, sumB = haveB && __shfl(mine.y, 32, 64) >= 0;
+  const unsigned long long pos = __ballot(mine.y > 0);
+  const int nrA = sumA ? __popcll(pos & 0xffffffffull) : 0, nrB = sumB ? __popcll(pos >> 32) : 0;
+  const bool mysum = half == 0 ? sumA : sumB;
+  int incl = wave_inclusive_scan<int>(mysum ? mine.y : 0);
+  const int totA = __shfl(incl, 31, 64);
+  const int totB = __shfl(incl, 63, 64) - totA;
+  if (half) incl -= totA; // prefix inside the own table
+  allA = sumA ? 3u : 0u; allB = sumB ? 3u : 0u;
+  const int total = max(totA, totB);
+  for (int t0 = 0; t0 < total; t0 += 64 * E)
+  {
+    int addrA[E], addrB[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) { addrA[e] = -1; addrB[e] = -1; }
+    for (int j = 0; j < max(nrA, nrB); ++j)
+    {
+      const int sa = __shfl(mine.x, j, 64), ha = __shfl(incl, j, 64), la = ha - __shfl(mine.y, j, 64);
+      const int sb = __shfl(mine.x, 32 + j, 64), hb = __shfl(incl, 32 + j, 64), lb = hb - __shfl(mine.y, 32 + j, 64);
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+      {
+        const int t = t0 + lane + 64 * e;
+        addrA[e] = (j < nrA && t >= la && t < ha) ? sa + (t - la) : addrA[e];
+        addrB[e] = (j < nrB && t >= lb && t < hb) ? sb + (t - lb) : addrB[e];
+      }
+    }
+    unsigned va[E], vb[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) va[e] = addrA[e] >= 0 ? (unsigned)code[addrA[e]] : 3u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) vb[e] = addrB[e] >= 0 ? (unsigned)code[addrB[e]] : 3u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) { allA &= va[e]; allB &= vb[e]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { allA &= __shfl_xor(allA, o, 64); allB &= __shfl_xor(allB, o, 64); }
+}
+
+// a block with vertices on both sides (or on the interface): quarter by quarter, and only the quarters that are mixed
+// themselves cell by cell (classify_kernel).  The whole wavefront works on the one block.
 template <int ND>
-__global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
-                                                                 const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
-                                                                 const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
-                                                                 int32_t* tiles_inside, int32_t* tiles_cut,
-                                                                 uint8_t* __restrict__ block_class, uint8_t* __restrict__ touch)
+__device__ __forceinline__ void classify_block_mixed(int64_t ncells, int64_t b, const int32_t* __restrict__ dofmap,
+                                                     const int2* __restrict__ sub_runs, const uint8_t* __restrict__ code,
+                                                     int8_t* __restrict__ domain, int32_t* tiles_inside, int32_t* tiles_cut,
+                                                     uint8_t* __restrict__ touch, int lane)
 {
   constexpr int SUB = kClassBlock / kClassSub, U = SUB / 64;
-  static_assert(kByteTile % kClassBlock == 0, "classification blocks must nest in compaction tiles");
-  const int lane = threadIdx.x & 63;
-  const int64_t b = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-  if (b >= nblocks) return;
   const int64_t cbase = b * kClassBlock;
   const int64_t tile = cbase / kByteTile;
-  const unsigned all = class_runs_and<kClassRuns, 12>(runs + b * kClassRuns, code, lane);
-  if (all == 1u || all == 2u)
-  {
-    // every vertex of the block on one side
-    class_fill<kClassBlock>(domain, cbase, ncells, all == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE, lane);
-    if (tiles_inside && all == 1u && lane == 0)
-      atomicAdd(&tiles_inside[tile], (int32_t)(ncells - cbase < kClassBlock ? ncells - cbase : kClassBlock));
-    if (block_class && lane == 0) block_class[b] = (uint8_t)all;
-    return;
-  }
-  if (block_class && lane == 0) block_class[b] = 0;
-  // vertices on both sides (or on the interface): quarter by quarter, and only the quarters that are mixed themselves cell
-  // by cell (classify_kernel)
   int n_in = 0, n_cut = 0;
+  // (the four quarter tables decided in one go -- 16 lanes per table, one round of loads -- measured in round 5: no change,
+  // 1.056 against 1.044 ms at 512^3: the mixed blocks live on their cell loops)
   for (int sq = 0; sq < kClassSub; ++sq)
   {
     const int64_t sbase = cbase + (int64_t)sq * SUB;
@@ -539,6 +572,46 @@ __global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_ke
       if (n_in) atomicAdd(&tiles_inside[tile], n_in);
       if (n_cut) atomicAdd(&tiles_cut[tile], n_cut);
     }
+  }
+}
+
+// one wavefront per PAIR of blocks of kClassBlock cells
+#ifndef CFX_CLASSIFY_WAVES
+#define CFX_CLASSIFY_WAVES 5 // (round 5, two blocks per wavefront, 512^3 sphere: 4 -> 1.21 ms, 5 -> 1.04, 6 -> 1.09)
+#endif
+#ifndef CFX_CLASSIFY_E
+#define CFX_CLASSIFY_E 12 // sign codes per lane, table and round of loads (a block has ~690: one round)
+#endif
+template <int ND>
+__global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_kernel(int64_t ncells, int64_t nblocks, const int32_t* __restrict__ dofmap,
+                                                                 const int2* __restrict__ runs, const int2* __restrict__ sub_runs,
+                                                                 const uint8_t* __restrict__ code, int8_t* __restrict__ domain,
+                                                                 int32_t* tiles_inside, int32_t* tiles_cut,
+                                                                 uint8_t* __restrict__ block_class, uint8_t* __restrict__ touch)
+{
+  static_assert(kByteTile % kClassBlock == 0, "classification blocks must nest in compaction tiles");
+  const int lane = threadIdx.x & 63;
+  const int64_t b0 = 2 * ((int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+  if (b0 >= nblocks) return;
+  const bool have1 = b0 + 1 < nblocks;
+  unsigned all[2];
+  class_runs_and2<kClassRuns, CFX_CLASSIFY_E>(runs + b0 * kClassRuns, runs + (b0 + 1) * kClassRuns, have1, code, lane, all[0], all[1]);
+  for (int k = 0; k < (have1 ? 2 : 1); ++k)
+  {
+    const int64_t b = b0 + k;
+    const int64_t cbase = b * kClassBlock;
+    const unsigned a = all[k];
+    if (a == 1u || a == 2u)
+    {
+      // every vertex of the block on one side
+      class_fill<kClassBlock>(domain, cbase, ncells, a == 1u ? (int8_t)CFX_INSIDE : (int8_t)CFX_OUTSIDE, lane);
+      if (tiles_inside && a == 1u && lane == 0)
+        atomicAdd(&tiles_inside[cbase / kByteTile], (int32_t)(ncells - cbase < kClassBlock ? ncells - cbase : kClassBlock));
+      if (block_class && lane == 0) block_class[b] = (uint8_t)a;
+      continue;
+    }
+    if (block_class && lane == 0) block_class[b] = 0;
+    classify_block_mixed<ND>(ncells, b, dofmap, sub_runs, code, domain, tiles_inside, tiles_cut, touch, lane);
   }
 }
 
@@ -2386,7 +2459,7 @@ void classify(cfx_cut_t cut)
           mesh->class_built = true;
           publish_across_lanes();
         }
-        const dim3 cgrid((unsigned)((nb + kBlock / 64 - 1) / (kBlock / 64)));
+        const dim3 cgrid((unsigned)(((nb + 1) / 2 + kBlock / 64 - 1) / (kBlock / 64)));   // a wavefront per pair of blocks
         uint8_t* bclass = nullptr;
         if (k == 0 && t_in != nullptr) { cut->block_class.alloc(nb); bclass = cut->block_class.p; }
         if (nd == 4) launch("classify", classify_culled_kernel<4>, cgrid, dim3(kBlock), 0, nc, nb, cut->ls_dofmap.p, (const int2*)mesh->class_runs.p, (const int2*)mesh->class_sub_runs.p, phi, dom, t_in, t_cut, bclass, touch);

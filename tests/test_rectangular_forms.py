@@ -535,7 +535,7 @@ def test_gpu_mixed_space_gives_the_monolithic_matrix_in_the_callers_numbering(or
     refc = sp.csr_matrix((Bm.data, (W.permutation[Bm.row], W.permutation[Bm.col])), shape=(ndofs, ndofs))
     refc.sort_indices()
     assert np.array_equal(A_cut.indptr, refc.indptr) and np.array_equal(A_cut.indices, refc.indices)
-    assert np.array_equal(A_cut.data, refc.data)
+    assert rel_err(A_cut.data, refc.data) < 1e-13      # (two assemblies: the atomic paths sum in schedule order)
     dead = W.permutation[np.concatenate([np.asarray(doms[0].inactive_dofs), nu + np.asarray(doms[1].inactive_dofs)])]
     assert dead.size > 0 and np.allclose(A_cut.diagonal()[dead], 1.0)
     # maps that are not permutations are refused

@@ -983,10 +983,29 @@ def projected_scaling(torch, device, n, order, one_gpu_ms, worlds=(2, 4, 8)):
             torch.cuda.synchronize()
         xs.append(1e3 * (time.perf_counter() - t0))
     exchange_ms = sorted(xs)[len(xs) // 2]
+    # ... and what the same bytes cost when they only have to be MOVED on the device (a device-to-device copy of the four
+    # plane pairs): a floor for any transport.  An xGMI link carries ~50 GB/s per direction (MI355X_MICROARCH.md: 7 links
+    # x ~153 GB/s bidirectional per GPU), both neighbours on their own links: bytes / 50 GB/s + ~30 us of launch as the
+    # labelled ESTIMATE in between.
+    other = torch.empty_like(planes)
+    ds = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _nb in range(2):
+            other.copy_(planes); planes.copy_(other)
+        torch.cuda.synchronize()
+        ds.append(1e3 * (time.perf_counter() - t0))
+    device_copy_ms = sorted(ds)[len(ds) // 2]
+    xgmi_estimate_ms = 1e3 * (2 * 8 * ps) / 50e9 + 0.03
     for w in out.values():
         w["projected_speedup_with_exchange"] = one_gpu_ms / (w["slowest_rank_ms"] + exchange_ms)
+        w["projected_speedup_xgmi_estimate"] = one_gpu_ms / (w["slowest_rank_ms"] + xgmi_estimate_ms)
     return dict(kind="projection from one GPU (each rank's slab run alone); NOT a measured scaling curve",
                 one_gpu_ms=one_gpu_ms, by_world=out, exchange_upper_bound_ms=round(exchange_ms, 4),
+                exchange_device_copy_ms=round(device_copy_ms, 4), exchange_xgmi_estimate_ms=round(xgmi_estimate_ms, 4),
+                exchange_xgmi_estimate_is="one neighbour's two planes at 50 GB/s per direction of one xGMI link + 30 us; an "
+                                          "ESTIMATE, nothing was sent",
                 exchange_upper_bound_is="level-set halo of an interior rank (2 vertex planes to and from each of two "
                                         f"neighbours, {2 * 2 * 8 * ps / 1e6:.1f} MB each way) staged through pinned host memory on "
                                         "this one GPU, copies one after the other, added to the slowest rank's step with no "
@@ -1087,7 +1106,8 @@ def headline_line(out):
             sec["projected_scaling"] = {"kind": "projection from one GPU, NOT a measured curve",
                                         "slowest_rank_ms_at_8": w8.get("slowest_rank_ms"),
                                         "speedup_at_8_no_exchange": _r(w8.get("projected_speedup")),
-                                        "speedup_at_8_with_exchange": _r(w8.get("projected_speedup_with_exchange"))}
+                                        "speedup_at_8_with_exchange": _r(w8.get("projected_speedup_with_exchange")),
+                                        "speedup_at_8_xgmi_estimate": _r(w8.get("projected_speedup_xgmi_estimate"))}
     if sec:
         line["secondary"] = sec
     line["detail"] = out.get("detail_file")

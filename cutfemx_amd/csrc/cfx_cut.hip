@@ -622,7 +622,7 @@ __global__ void __launch_bounds__(kBlock, CFX_CLASSIFY_WAVES) classify_culled_ke
 template <int TDIM>
 __global__ void __launch_bounds__(kBlock) classify_box_kernel(int64_t ncubes, int n, const uint8_t* __restrict__ code,
                                                               int8_t* __restrict__ domain, int32_t* tiles_inside,
-                                                              int32_t* tiles_cut)
+                                                              int32_t* tiles_cut, uint8_t* __restrict__ touch)
 {
   constexpr int NC = TDIM == 3 ? 6 : 2; // cells per cube
   constexpr int NV = TDIM + 1;
@@ -651,6 +651,15 @@ __global__ void __launch_bounds__(kBlock) classify_box_kernel(int64_t ncubes, in
 #pragma unroll
       for (int j = 0; j < NV; ++j) all &= c[TDIM == 3 ? tet[k][j] : tri[k][j]];
       s_dom[threadIdx.x * NC + k] = all == 1u ? (int8_t)CFX_INSIDE : (all == 2u ? (int8_t)CFX_OUTSIDE : (int8_t)CFX_INTERSECTED);
+      if (touch && all != 1u && all != 2u) // (a cut cell: its vertices are next to the interface; every writer stores 1)
+      {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+        {
+          const int i = TDIM == 3 ? tet[k][j] : tri[k][j];
+          touch[v0 + (i & 1) + n1 * (((i >> 1) & 1) + n1 * ((i >> 2) & 1))] = 1;
+        }
+      }
       if (tiles_inside && all != 2u)
         atomicAdd(&s_cnt[2 * (int)((h * NC + k) / kByteTile - tile0) + (all == 1u ? 0 : 1)], 1);
     }
@@ -2420,10 +2429,11 @@ void classify(cfx_cut_t cut)
         else if (k == 0) { cut->tiles_inside.release(); cut->tiles_cut.release(); }
         if (mesh->tdim == 3)
           launch("classify_box", classify_box_kernel<3>, grid_for(ncubes), dim3(kBlock), 0, ncubes, mesh->box_n, phi, dom,
-                 b_in, b_cut);
+                 b_in, b_cut, touch);
         else
           launch("classify_box", classify_box_kernel<2>, grid_for(ncubes), dim3(kBlock), 0, ncubes, mesh->box_n, phi, dom,
-                 b_in, b_cut);
+                 b_in, b_cut, touch);
+        if (k == 0) cut->touch_valid = true;
         continue;
       }
     }

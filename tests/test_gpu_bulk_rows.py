@@ -16,8 +16,7 @@ RTOL = 1e-12
 def bulk_expected() -> bool:
     """The diagnostic modes that switch the row stencil (or the bulk rows themselves) off take the list walk: same results."""
     import os
-    return not (os.environ.get("CFX_STENCIL") == "0" or os.environ.get("CFX_BULK_ROWS") == "0"
-                or os.environ.get("CFX_IMPLICIT_BOX") == "1")
+    return not (os.environ.get("CFX_STENCIL") == "0" or os.environ.get("CFX_BULK_ROWS") == "0")
 
 
 def poisson_system(cfx, V, cd, order=4):

@@ -785,6 +785,11 @@ struct cfx_space_s
   std::vector<std::weak_ptr<struct cfx_row_plan>> plans; // plans of the live forms on this space
   cfx::Stencil stencil; // built on first use by cfx::space_stencil()
   cfx::VecBlocks vblocks; // built on first use by cfx::space_vec_blocks()
+  // degree 2: the two mesh vertices every dof sits between (a vertex dof: twice its vertex), ascending -- mesh-static,
+  // built on first use by cfx::space_dof_verts(); lets a row plan class the dofs of a degree-2 space from the level
+  // set's vertex codes (bulk rows)
+  cfx::DevArray<int32_t> dof_verts;
+  bool dof_verts_built = false, dof_verts_ok = false;
   cfx_pattern_cache pcache;          // previous pattern of this space (row reuse in moving-domain loops)
   ~cfx_space_s() { cfx::step_forget_owner(this); pcache.drop(); }
   bool lists_short_overflow = false; // a short-list row overflowed the 128-slot set once: hashed rows all go wide
@@ -824,6 +829,7 @@ struct cfx_row_plan
   // look at the marks.  Cell marks then come from the classification bytes, not from a walk over the 10^8-entry list.
   cfx::DevArray<uint8_t> rowcls;
   bool bulk = false;
+  int bulk_kind = 0; // 1: P1 on the geometry dofmap (dof = vertex); 2: degree 2 (a dof between two vertices, cfx_space_s::dof_verts)
   uint8_t bulk_bits = 0; // mark bits of the cell integrals whose uncut entities are that list
   cfx::DevArray<uint8_t> cellmark; // bit i: uncut entity of cell integral slot i; bit 4+i: parent of its rules
   cfx::DevArray<uint8_t> cellsig;  // bit 0: cellmark != 0; bit 1 + lf: side lf of the cell is a facet of the form (built on
@@ -927,6 +933,7 @@ const Stencil& space_stencil_slotn(cfx_space_s* V);                     // cfx_r
 bool plain_row_masks(cfx_form_s* a, int32_t* counts = nullptr, int* maxlen = nullptr); // cfx_rowasm.hip
 void plan_cut_cells(cfx_form_s* a);                                     // cfx_rowasm.hip
 const Stencil& space_stencil_tiles(cfx_space_s* V);                     // cfx_rowasm.hip
+bool space_dof_verts(cfx_space_s* V);                                   // cfx_rowasm.hip (cfx_space_s::dof_verts)
 bool plain_vec_offsets(cfx_form_s* L, uint8_t mark);                    // cfx_rowasm.hip
 const VecBlocks& space_vec_blocks(cfx_space_s* V);                      // cfx_rowasm.hip
 bool vec_block_plan(cfx_form_s* L, uint8_t mark, bool merged);          // cfx_rowasm.hip

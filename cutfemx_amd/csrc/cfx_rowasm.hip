@@ -401,6 +401,60 @@ __global__ void __launch_bounds__(kBlock) mix_rowmark_kernel(int64_t ndofs, cons
   }
 }
 
+// degree 2: the two vertices of every dof, ascending (every cell that holds the dof writes the same pair)
+__global__ void __launch_bounds__(kBlock) dof_verts_kernel(int64_t ncells, int tdim, const int32_t* __restrict__ conn,
+                                                           const int32_t* __restrict__ dofmap, int32_t* __restrict__ dof_verts)
+{
+  const int nv = tdim + 1, nd = tdim == 2 ? 6 : 10;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t c = t / nd;
+  if (c >= ncells) return;
+  const int j = (int)(t - c * nd);
+  const int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
+  const int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
+  const int a = j < nv ? j : (tdim == 2 ? ea2[j - nv] : ea3[j - nv]), b = j < nv ? j : (tdim == 2 ? eb2[j - nv] : eb3[j - nv]);
+  const int32_t va = conn[c * nv + a], vb = conn[c * nv + b];
+  const int64_t dof = dofmap[c * nd + j];
+  *reinterpret_cast<int2*>(dof_verts + 2 * dof) = make_int2(min(va, vb), max(va, vb));
+}
+
+// row classes of a degree-2 space from the vertex codes: a dof with an end vertex on the entities' side that no cut
+// cell touches has only entities around it (the cells around an edge are cells around either of its vertices); likewise
+// on the other side; else the marks decide.  Four dofs per thread; also the rows' initial marks (row_class_kernel).
+__global__ void __launch_bounds__(kBlock) row_class_p2_kernel(int64_t ndofs, const int32_t* __restrict__ dof_verts,
+                                                              const uint8_t* __restrict__ codes, const uint8_t* __restrict__ touch,
+                                                              uint8_t sel, uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
+                                                              uint8_t* __restrict__ special, const int64_t* __restrict__ poison)
+{
+  const int64_t r0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (r0 >= ndofs) return;
+  const bool void_step = poison != nullptr && *poison != 0; // (mark nothing: row_class_kernel)
+  unsigned cls = 0u, rm = 0u;
+  int32_t v[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) v[k] = r0 + k / 2 < ndofs ? dof_verts[2 * r0 + k] : -1;
+  unsigned cd[8], tc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { cd[k] = v[k] >= 0 ? codes[v[k]] : 0u; tc[k] = v[k] >= 0 ? touch[v[k]] : 1u; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+  {
+    unsigned c = kRowMix;
+    if (void_step) c = kRowOut;
+    else if (r0 + q < ndofs)
+    {
+      const bool in = (!tc[2 * q] && cd[2 * q] == sel) || (!tc[2 * q + 1] && cd[2 * q + 1] == sel);
+      const bool out = (!tc[2 * q] && cd[2 * q] == 3u - sel) || (!tc[2 * q + 1] && cd[2 * q + 1] == 3u - sel);
+      c = in ? kRowIn : (out ? kRowOut : kRowMix);
+    }
+    cls |= c << (8 * q);
+    rm |= (c == kRowIn ? 1u : 0u) << (8 * q);
+  }
+  *reinterpret_cast<unsigned*>(rowcls + r0) = cls; // (the three arrays are padded to a multiple of 16 rows)
+  *reinterpret_cast<unsigned*>(rowmark + r0) = rm;
+  *reinterpret_cast<unsigned*>(special + r0) = 0u;
+}
+
 // active-row positions whose CSR row is at most / longer than `limit` columns
 struct RowLenTest
 {
@@ -1750,30 +1804,59 @@ __global__ void __launch_bounds__(kWave) pattern_plain_tiles_kernel(DevN n_tiles
 // Spaces with neighbour lists only (degree 2, vector-valued, DG): a plain row whose incident cells are ALL uncut
 // entities of the form couples exactly its static list -- its columns are a copy, no hash set.  full[i] = 1 for
 // such rows (and their expanded row lengths go to counts); the others join the hashed rows.
+// (64 consecutive plain rows per wavefront: all of them bulk rows -- nearly every wavefront away from the interface -- one
+// lane per row and nothing gathered; else kWave / G passes of G lanes per row)
 template <int G>
 __global__ void __launch_bounds__(kWave) plain_full_kernel(int64_t n_plain, const int32_t* __restrict__ rows,
                                                             const int64_t* __restrict__ d2c_off, const int32_t* __restrict__ d2c,
                                                             const uint8_t* __restrict__ cellmark,
                                                             const int64_t* __restrict__ st_off, int bs,
-                                                            uint8_t* __restrict__ full, int32_t* __restrict__ counts)
+                                                            uint8_t* __restrict__ full, int32_t* __restrict__ counts,
+                                                            const uint8_t* __restrict__ rowcls)
 {
   const int lane = threadIdx.x, gl = lane % G;
-  const int64_t i = (int64_t)blockIdx.x * (kWave / G) + lane / G;
-  const bool live = i < n_plain;
-  const int64_t r = live ? rows[i] : 0;
-  const int64_t cb = live ? d2c_off[r] : 0;
-  const int nc = live ? (int)(d2c_off[r + 1] - cb) : 0;
-  int miss = 0;
-  for (int t = gl; t < nc; t += G) miss |= (cellmark[d2c[cb + t]] & 0x0Fu) == 0;
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) miss |= __shfl_xor(miss, o, G);
-  if (!live || gl != 0) return;
-  const bool f = miss == 0 && nc > 0;
-  full[i] = f ? 1 : 0;
-  if (f)
+  const int64_t i0 = (int64_t)blockIdx.x * kWave;
+  if (i0 >= n_plain) return;
+  if (rowcls)
   {
-    const int len = (int)(st_off[r + 1] - st_off[r]);
-    for (int a = 0; a < bs; ++a) counts[r * bs + a] = len * bs;
+    // a bulk row (cfx_row_plan::rowcls): every cell around it is an uncut entity
+    const int64_t i = i0 + lane;
+    const bool live = i < n_plain;
+    const int64_t r = live ? rows[i] : 0;
+    const bool bulk = live && rowcls[r] == kRowIn && d2c_off[r + 1] > d2c_off[r];
+    if (__ballot(live && !bulk) == 0ull)
+    {
+      if (live)
+      {
+        full[i] = 1;
+        const int len = (int)(st_off[r + 1] - st_off[r]);
+        for (int a = 0; a < bs; ++a) counts[r * bs + a] = len * bs;
+      }
+      return;
+    }
+  }
+  for (int pass = 0; pass < G; ++pass)
+  {
+    const int64_t i = i0 + pass * (kWave / G) + lane / G;
+    const bool live = i < n_plain;
+    const int64_t r = live ? rows[i] : 0;
+    const int64_t cb = live ? d2c_off[r] : 0;
+    int nc = live ? (int)(d2c_off[r + 1] - cb) : 0;
+    const bool bulk = live && rowcls && rowcls[r] == kRowIn && nc > 0;
+    const int nc_all = nc;
+    if (bulk) nc = 0;
+    int miss = 0;
+    for (int t = gl; t < nc; t += G) miss |= (cellmark[d2c[cb + t]] & 0x0Fu) == 0;
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) miss |= __shfl_xor(miss, o, G);
+    if (!live || gl != 0) continue;
+    const bool f = miss == 0 && nc_all > 0;
+    full[i] = f ? 1 : 0;
+    if (f)
+    {
+      const int len = (int)(st_off[r + 1] - st_off[r]);
+      for (int a = 0; a < bs; ++a) counts[r * bs + a] = len * bs;
+    }
   }
 }
 
@@ -2022,13 +2105,18 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       }
       ++slot;
     }
-    const ListProvenance* pv = (!(be && be[0] == '0') && one_list && list && space_stencil(V).usable && V->bs == 1
-                                && (nd == 4 || nd == 3)) ? provenance_lookup(list) : nullptr;
+    // kind 1: P1 on the geometry dofmap (a dof IS a level-set vertex); kind 2: degree 2, any block size (a dof sits
+    // between two vertices: cfx_space_s::dof_verts)
+    const bool p1 = space_stencil(V).usable && V->bs == 1 && (nd == 4 || nd == 3);
+    const bool p2 = V->degree == 2 && (nd == 10 || nd == 6) && nd == (V->mesh->tdim == 3 ? 10 : 6);
+    const ListProvenance* pv = (!(be && be[0] == '0') && one_list && list && (p1 || p2)) ? provenance_lookup(list) : nullptr;
+    const int64_t nvert = V->mesh->nnodes;
     if (pv && pv->n == list_n && pv->cut->gen == pv->gen && pv->cut->mesh == V->mesh && pv->cut->ls_dofmap.p == V->mesh->conn.p
-        && pv->cut->ls_ndofs == V->ndofs && pv->cut->codes0.n == V->ndofs && pv->cut->touch_valid && pv->cut->touch0.n == V->ndofs
-        && (pv->value == -1 || pv->value == 1))
+        && pv->cut->ls_ndofs == nvert && pv->cut->codes0.n == nvert && pv->cut->touch_valid && pv->cut->touch0.n == nvert
+        && (pv->value == -1 || pv->value == 1) && (p1 ? V->ndofs == nvert : space_dof_verts(V)))
     {
       P.bulk = true;
+      P.bulk_kind = p1 ? 1 : 2;
       P.bulk_bits = bits;
       bulk_cut = pv->cut;
       bulk_value = pv->value;
@@ -2070,9 +2158,14 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       // no zero fill: the row classes initialise the row marks, the cell marks come from the classification bytes
       if (key_total > 0) dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
       P.rowcls.alloc(n_rm);
-      launch("plan_row_class", row_class_kernel, grid_for(n_rm / 16), dim3(kBlock), 0, V->ndofs, bulk_cut->codes0.p,
-             bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
-             n_t2 > 0 ? P.vec_t2off.p : (int32_t*)nullptr, step_poison());
+      if (P.bulk_kind == 1)
+        launch("plan_row_class", row_class_kernel, grid_for(n_rm / 16), dim3(kBlock), 0, V->ndofs, bulk_cut->codes0.p,
+               bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
+               n_t2 > 0 ? P.vec_t2off.p : (int32_t*)nullptr, step_poison());
+      else
+        launch("plan_row_class", row_class_p2_kernel, grid_for(n_rm / 4), dim3(kBlock), 0, V->ndofs, V->dof_verts.p,
+               bulk_cut->codes0.p, bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
+               step_poison());
       const int64_t nb = (nc + kClassBlock - 1) / kClassBlock;
       launch("plan_cell_marks", cellmark_from_domain_kernel, grid_for(n_cm / 16), dim3(kBlock), 0, nc, n_cm, bulk_cut->domain.p,
              (int8_t)bulk_value, P.bulk_bits, bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : (const uint8_t*)nullptr,
@@ -2550,6 +2643,21 @@ const Stencil& space_stencil_tiles(cfx_space_s* V)
   S.tiles_usable = true;
   publish_across_lanes();
   return S;
+}
+
+bool space_dof_verts(cfx_space_s* V)
+{
+  if (V->dof_verts_built) return V->dof_verts_ok;
+  V->dof_verts_built = true;
+  const int tdim = V->mesh->tdim, nd = tdim == 3 ? 10 : 6;
+  if (V->degree != 2 || V->ndofs_cell != nd || (tdim != 2 && tdim != 3)) return false;
+  V->dof_verts.alloc(2 * V->ndofs);
+  dev_fill(V->dof_verts.p, 0xff, sizeof(int32_t) * 2 * (size_t)V->ndofs); // (-1: a dof no cell holds)
+  launch("space_dof_verts", dof_verts_kernel, grid_for(V->mesh->ncells * nd), dim3(kBlock), 0, V->mesh->ncells, tdim,
+         V->mesh->conn.p, V->dofmap.p, V->dof_verts.p);
+  V->dof_verts_ok = true;
+  publish_across_lanes();
+  return true;
 }
 
 const Stencil& space_stencil_slotn(cfx_space_s* V)
@@ -3241,9 +3349,9 @@ void build_pattern(cfx_form_s* a, cfx_pattern_s* P)
     const Adjacency& adj = V->dof_cells();
     constexpr int G = 4;
     full.alloc(n_plain_x);
-    launch("pattern_plain_full", plain_full_kernel<G>, dim3((unsigned)((n_plain_x + kWave / G - 1) / (kWave / G))),
+    launch("pattern_plain_full", plain_full_kernel<G>, dim3((unsigned)((n_plain_x + kWave - 1) / kWave)),
            dim3(kWave), 0, n_plain_x, plan.plain_rows.p, adj.offsets.p, adj.cells.p, plan.cellmark.p, st.offsets.p,
-           V->bs, full.p, counts.p);
+           V->bs, full.p, counts.p, plan.bulk ? plan.rowcls.p : (const uint8_t*)nullptr);
     DevArray<int32_t> odd;
     const int64_t n_odd = compact("pattern_plain_full", n_plain_x, FlagIsZero{full.p}, odd);
     any_full = n_odd < n_plain_x;

@@ -160,3 +160,55 @@ def test_facets_from_another_source_mark_rows_inside_the_bulk(oracle):
     ip, ix = O.create_sparsity(om, oV, oi)
     assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
     assert rel_err(A.data, O.assemble_matrix(om, oV, oi, ip, ix)) < RTOL
+
+
+@pytest.mark.parametrize("tdim,n,bs", [(3, 7, 1), (2, 14, 1), (3, 5, 3), (2, 10, 2)])
+def test_bulk_rows_of_degree_two_spaces(oracle, tdim, n, bs, monkeypatch):
+    """Degree 2 (scalar and vector): a dof sits between two mesh vertices (cfx_space_s::dof_verts); with an end vertex on
+    the entities' side that no cut cell touches, every cell around the dof is an entity.  Same pattern, values and
+    inactive dofs as the list walk and as the oracle; the forms carry a ghost penalty so that rows next to the interface
+    are special, and a second form has the inside cells alone (the mark gather decides the rows of the cut cells)."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import fem
+    O = oracle
+    om = O.mesh_box(tdim, n)
+    phi = level_set_values(om.x, tdim)
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, 2)
+    oV = O.Space(dofmap, ndofs, 2, bs)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    V = cfx.FunctionSpace(mesh, 2, dofmap=dofmap, ndofs=ndofs, bs=bs)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    kern_g, kern_o, params = (fem.ELASTICITY, O.K_ELASTICITY, (1.0, 0.3)) if bs > 1 else (fem.STIFFNESS, O.K_STIFFNESS, ())
+    d = O.classify(om.conn, phi)
+    o_in = O.locate_entities(d, "phi<0")
+    o_vol = O.runtime_quadrature(om, om.conn, phi, d, "phi<0", 2)
+    o_ghost = O.ghost_penalty_facets(om, d, "phi<0")
+
+    def build(with_rules):
+        cd = cfx.cut(cfx.Function(Vphi, phi))
+        inside = cfx.locate_entities_device(cd, "phi<0")
+        ints = [fem.Integral(kern_g, cells=inside, params=params, qdegree=2,
+                             **(dict(rules=cfx.runtime_quadrature(cd, "phi<0", 2)) if with_rules else {}))]
+        if with_rules:
+            ints.append(fem.Integral(fem.GHOST_GRADJUMP, facets=cfx.ghost_penalty_facets(cd, "phi<0"), params=(0.1,), qdegree=2))
+        a = fem.form(ints, V)
+        (A, dom), names = profiled(lambda: (fem.assemble_matrix(a), fem.active_domain(a)))
+        return A, dom, names, cd
+    for with_rules in (True, False):
+        o_ints = [O.Integral(O.CELL, kern_o, entities=o_in, params=params, qdegree=2, **(dict(rules=o_vol) if with_rules else {}))]
+        if with_rules:
+            o_ints.append(O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=o_ghost, params=(0.1,), qdegree=2))
+        ip, ix = O.create_sparsity(om, oV, o_ints)
+        want = O.assemble_matrix(om, oV, o_ints, ip, ix)
+        ina = O.inactive_dofs(oV, O.active_cells(o_ints, om.ncells))
+        A, dom, names, _keep = build(with_rules)
+        if bulk_expected():
+            assert "plan_row_class" in names, sorted(names)     # (plan_mark_cells still marks the rule cells)
+        assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), with_rules
+        assert rel_err(A.data, want) < RTOL and np.array_equal(dom.inactive_dofs, ina)
+        monkeypatch.setenv("CFX_BULK_ROWS", "0")
+        A2, dom2, names2, _keep2 = build(with_rules)
+        monkeypatch.delenv("CFX_BULK_ROWS")
+        assert "plan_row_class" not in names2
+        assert np.array_equal(A2.indptr, ip) and np.array_equal(A2.indices, ix) and rel_err(A2.data, want) < RTOL
+        assert np.array_equal(dom2.inactive_dofs, ina)

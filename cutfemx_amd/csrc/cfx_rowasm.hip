@@ -859,19 +859,40 @@ __global__ void __launch_bounds__(kWave) pattern_rows_kernel(PatArgs P)
     const int64_t fpos = (P.d2f_off && P.special_mark[r]) ? (int64_t)P.special_pos[r] : -1;
     if (fpos >= 0 && P.nd == 4)
     {
-      // P1: one facet per lane (11 loads for 8 candidates; the triple form below costs 24)
-      for (int64_t k = P.d2f_off[fpos] + gl; k < P.d2f_off[fpos + 1]; k += G)
+      // P1: one facet per lane (11 loads for 8 candidates; the triple form below costs 24), kF facets of a lane per trip
+      // with each of the three dependent levels -- incidence entry, facet row, dof rows -- requested for all of them at
+      // once: one facet per trip waited three memory latencies per trip, ten trips for a row with forty facets
+      constexpr int kF = 4;
+      const int64_t fe = P.d2f_off[fpos + 1];
+      for (int64_t k0 = P.d2f_off[fpos] + gl; k0 < fe; k0 += (int64_t)G * kF)
       {
-        const int64_t f = P.d2f[k];
-        for (int s = 0; s < 2; ++s)
+        int64_t f[kF];
+#pragma unroll
+        for (int u = 0; u < kF; ++u) f[u] = k0 + (int64_t)u * G < fe ? (int64_t)P.d2f[k0 + (int64_t)u * G] : -1;
+        int64_t c[kF][2];
+#pragma unroll
+        for (int u = 0; u < kF; ++u)
         {
-          const int64_t c = P.facet_rows[4 * f + 2 * s];
-          const int4 v = *reinterpret_cast<const int4*>(P.dofmap + c * 4);
-          ok = hash_insert<T>(tab, v.x) && ok;
-          ok = hash_insert<T>(tab, v.y) && ok;
-          ok = hash_insert<T>(tab, v.z) && ok;
-          ok = hash_insert<T>(tab, v.w) && ok;
+          const int4 row = f[u] >= 0 ? *reinterpret_cast<const int4*>(P.facet_rows + 4 * f[u]) : make_int4(-1, 0, -1, 0);
+          c[u][0] = row.x; c[u][1] = row.z;
         }
+        int4 v[kF][2];
+#pragma unroll
+        for (int u = 0; u < kF; ++u)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            v[u][s2] = c[u][s2] >= 0 ? *reinterpret_cast<const int4*>(P.dofmap + c[u][s2] * 4) : make_int4(-1, -1, -1, -1);
+#pragma unroll
+        for (int u = 0; u < kF; ++u)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            if (c[u][s2] >= 0)
+            {
+              ok = hash_insert<T>(tab, v[u][s2].x) && ok;
+              ok = hash_insert<T>(tab, v[u][s2].y) && ok;
+              ok = hash_insert<T>(tab, v[u][s2].z) && ok;
+              ok = hash_insert<T>(tab, v[u][s2].w) && ok;
+            }
       }
     }
   }

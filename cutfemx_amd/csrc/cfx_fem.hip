@@ -2248,6 +2248,7 @@ __global__ void __launch_bounds__(64) permute_rows_kernel(int64_t nrows, const i
 }
 
 constexpr int kMergeMaxBlocks = 8; // blocks per block row
+struct MergeCols { int64_t n[8]; };
 struct MergeRow
 {
   int nb;                              // blocks of this block row (empty ones have indptr == nullptr)
@@ -2258,13 +2259,24 @@ struct MergeRow
 };
 
 // entries of row r of the block row: the sum of the blocks' row lengths
-__global__ void block_merge_len_kernel(int64_t nrows, MergeRow B, int64_t* __restrict__ len)
+// (the merged row is sorted only if every block's row is: checked here, `bad` is raised by the caller; columns must also
+// lie inside their block column)
+__global__ void block_merge_len_kernel(int64_t nrows, MergeRow B, int64_t* __restrict__ len, MergeCols ncols, int* bad)
 {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= nrows) return;
   int64_t l = 0;
   for (int j = 0; j < B.nb; ++j)
-    if (B.indptr[j]) l += B.indptr[j][r + 1] - B.indptr[j][r];
+    if (B.indptr[j])
+    {
+      const int64_t b = B.indptr[j][r], e = B.indptr[j][r + 1];
+      l += e - b;
+      for (int64_t k = b; k < e; ++k)
+      {
+        const int32_t c = B.indices[j][k];
+        if (c < 0 || c >= ncols.n[j] || (k > b && B.indices[j][k - 1] >= c)) *bad = 1;
+      }
+    }
   len[r] = l;
 }
 
@@ -2334,15 +2346,20 @@ int cfx_csr_block_merge(int nbr, int nbc, const int64_t* const* indptr, const in
   DevArray<int64_t> ip_out(total_rows + 1);
   int64_t* ip = ip_out.p;
   DevArray<int64_t> len(total_rows);
+  ZeroFlag unsorted;
+  MergeCols mcols{};
+  for (int j = 0; j < nbc; ++j) mcols.n[j] = ncols[j];
   int64_t r0 = 0;
   for (int i = 0; i < nbr; ++i)
   {
     if (nrows[i] > 0)
-      launch("block_merge", block_merge_len_kernel, grid_for(nrows[i]), dim3(kBlock), 0, nrows[i], rows[i], len.p + r0);
+      launch("block_merge", block_merge_len_kernel, grid_for(nrows[i]), dim3(kBlock), 0, nrows[i], rows[i], len.p + r0, mcols, unsorted.p);
     r0 += nrows[i];
   }
   exclusive_scan(len.p, ip, total_rows);
   const int64_t nnz = read_scalar(ip + total_rows);
+  require(!read_scalar(unsorted.p), CFX_ERR_INVALID_ARGUMENT,
+          "cfx_csr_block_merge: a block has a row whose columns do not ascend strictly inside its block column");
   DevArray<int32_t> ix_out(nnz);
   DevArray<double> vals_out;
   if (out_values) vals_out.alloc(nnz);

@@ -541,3 +541,14 @@ def test_gpu_mixed_space_gives_the_monolithic_matrix_in_the_callers_numbering(or
     # maps that are not permutations are refused
     with pytest.raises(ValueError, match="not a permutation"):
         fem.permute_csr(A_std, np.zeros(ndofs, dtype=np.int32))
+    # ... and so is a block whose rows are not sorted (cfx_csr_block_merge relies on it: ADVICE r4)
+    import ctypes as C
+    from cutfemx_amd import _lib
+    ipb = np.array([0, 2, 3], dtype=np.int64); ixb = np.array([1, 0, 1], dtype=np.int32); vb = np.ones(3)
+    ptrs = [(C.c_void_p * 1)(a.ctypes.data_as(C.c_void_p).value) for a in (ipb, ixb, vb)]
+    nr1 = (C.c_int64 * 1)(2)
+    o = [C.c_void_p(), C.c_void_p(), C.c_void_p()]
+    nnz_out = C.c_int64()
+    rc = _lib.lib().cfx_csr_block_merge(1, 1, ptrs[0], ptrs[1], ptrs[2], nr1, nr1, C.byref(o[0]), C.byref(o[1]), C.byref(o[2]),
+                                        C.byref(nnz_out))
+    assert rc != 0 and b"ascend" in _lib.lib().cfx_last_error()

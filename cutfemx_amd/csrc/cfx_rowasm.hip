@@ -88,12 +88,11 @@ __global__ void __launch_bounds__(kBlock) plan_pack_bits_kernel(int64_t ncells, 
 
 // the same words for the uncut entities of a located list, from the classification bytes: bit k of word w = (domain of
 // cell 64 w + k == value).  A block of kClassBlock cells that the culled classification found uniform is not read.
-__global__ void __launch_bounds__(kBlock) pack_bits_domain_kernel(int64_t ncells, const int8_t* __restrict__ domain, int8_t value,
-                                                                  const uint8_t* __restrict__ block_class,
-                                                                  unsigned long long* __restrict__ words, int32_t* __restrict__ pop,
-                                                                  const int64_t* __restrict__ poison)
+__device__ __forceinline__ void pack_bits_domain_body(int64_t w, int64_t ncells, const int8_t* __restrict__ domain, int8_t value,
+                                                      const uint8_t* __restrict__ block_class,
+                                                      unsigned long long* __restrict__ words, int32_t* __restrict__ pop,
+                                                      const int64_t* __restrict__ poison)
 {
-  const int64_t w = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t base = w * 64;
   if (base >= ncells) return;
   unsigned long long v = 0;
@@ -125,6 +124,13 @@ __global__ void __launch_bounds__(kBlock) pack_bits_domain_kernel(int64_t ncells
       if (domain[base + k] == value) v |= 1ull << k;
   words[w] = v;
   pop[w] = __popcll(v);
+}
+__global__ void __launch_bounds__(kBlock) pack_bits_domain_kernel(int64_t ncells, const int8_t* __restrict__ domain, int8_t value,
+                                                                  const uint8_t* __restrict__ block_class,
+                                                                  unsigned long long* __restrict__ words, int32_t* __restrict__ pop,
+                                                                  const int64_t* __restrict__ poison)
+{
+  pack_bits_domain_body((int64_t)blockIdx.x * kBlock + threadIdx.x, ncells, domain, value, block_class, words, pop, poison);
 }
 
 // uncut entities of a cell integral, nd <= 4 dofs per cell, in one pass over the list: cell mark, row marks
@@ -168,12 +174,23 @@ struct RuleJobs
   uint32_t hmask[4];
   int32_t* keys[4];
   int32_t* first[4];
+  // the rows of the form's one interior-facet list ride in the same launch (threads from start[n] on): null = none
+  DevN nf;
+  const int32_t* facet_rows;
 };
+template <int ND>
+__device__ __forceinline__ void plan_facet_rows_body(int64_t f, DevN nf_d, const int32_t* __restrict__ rows,
+                                                     const int32_t* __restrict__ dofmap, uint8_t* rowmark, uint8_t* special, int* flag);
 template <int ND>
 __global__ void __launch_bounds__(kBlock) plan_rules_kernel(RuleJobs J, const int32_t* __restrict__ dofmap, uint8_t* mark,
                                                             uint8_t* rowmark, uint8_t* special, int* flag)
 {
   const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (J.facet_rows != nullptr && t >= J.start[J.n])
+  {
+    plan_facet_rows_body<ND>(t - J.start[J.n], J.nf, J.facet_rows, dofmap, rowmark, special, flag);
+    return;
+  }
   int k = 0;
   while (k + 1 < J.n && t >= J.start[k + 1]) ++k;
   const int64_t e = t - J.start[k];
@@ -213,12 +230,10 @@ __global__ void __launch_bounds__(kBlock) plan_rules_kernel(RuleJobs J, const in
 
 // interior-facet entities, nd <= 4: row marks (special rows) of both cells of every row
 template <int ND>
-__global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(DevN nf_d, const int32_t* __restrict__ rows,
-                                                                 const int32_t* __restrict__ dofmap, uint8_t* rowmark,
-                                                                 uint8_t* special, int* flag)
+__device__ __forceinline__ void plan_facet_rows_body(int64_t f, DevN nf_d, const int32_t* __restrict__ rows,
+                                                     const int32_t* __restrict__ dofmap, uint8_t* rowmark, uint8_t* special, int* flag)
 {
   const int64_t nf = dev_n(nf_d);
-  const int64_t f = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (f >= nf) return;
   const int4 r = *reinterpret_cast<const int4*>(rows + 4 * f);
   int32_t d0[ND], d1[ND];
@@ -240,6 +255,13 @@ __global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(DevN nf_d, cons
     nfree += shared ? 0 : 1;
   }
   if (nfree != 1) atomicOr(flag, 2);
+}
+template <int ND>
+__global__ void __launch_bounds__(kBlock) plan_facet_rows_kernel(DevN nf_d, const int32_t* __restrict__ rows,
+                                                                 const int32_t* __restrict__ dofmap, uint8_t* rowmark,
+                                                                 uint8_t* special, int* flag)
+{
+  plan_facet_rows_body<ND>((int64_t)blockIdx.x * kBlock + threadIdx.x, nf_d, rows, dofmap, rowmark, special, flag);
 }
 
 // `special` (may be null): rows that receive something other than uncut-cell items
@@ -270,13 +292,13 @@ constexpr uint8_t kRowOut = 0, kRowIn = 1, kRowMix = 2;
 // 16 rows per thread: class of every row (`sel`: sign code of the entities' side), and the rows' initial marks --
 // rowmark = 1 on a bulk row, 0 elsewhere; special = 0; the segment offsets of a linear form's staging = 0 ("none")
 // wherever they can be read (rows that can lie on an entity).  All arrays are padded to a multiple of 16 rows.
-__global__ void __launch_bounds__(kBlock) row_class_kernel(int64_t ndofs, const uint8_t* __restrict__ codes,
-                                                           const uint8_t* __restrict__ touch, uint8_t sel,
-                                                           uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
-                                                           uint8_t* __restrict__ special, int32_t* __restrict__ t2off,
-                                                           const int64_t* __restrict__ poison)
+__device__ __forceinline__ void row_class_body(int64_t thread, int64_t ndofs, const uint8_t* __restrict__ codes,
+                                               const uint8_t* __restrict__ touch, uint8_t sel,
+                                               uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
+                                               uint8_t* __restrict__ special, int32_t* __restrict__ t2off,
+                                               const int64_t* __restrict__ poison)
 {
-  const int64_t r0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  const int64_t r0 = thread * 16;
   if (r0 >= ndofs) return;
   // (a void step: every list-driven kernel sees length 0 and marks nothing -- the rows must not be marked either, or the
   // kernels that walk the marks would read lengths nobody wrote)
@@ -331,13 +353,12 @@ __global__ void __launch_bounds__(kBlock) row_class_kernel(int64_t ndofs, const 
 // cell marks of the uncut entities of a located list straight from the classification bytes: mark = bits where
 // domain == value, 0 elsewhere -- 16 cells per thread; a block of kClassBlock cells the culled classification found
 // uniform (block_class 1: all inside, 2: all outside) is written without being read.  Covers the padded array.
-__global__ void __launch_bounds__(kBlock) cellmark_from_domain_kernel(int64_t ncells, int64_t npad, const int8_t* __restrict__ domain,
-                                                                      int8_t value, uint8_t bits,
-                                                                      const uint8_t* __restrict__ block_class,
-                                                                      uint8_t* __restrict__ cellmark,
-                                                                      const int64_t* __restrict__ poison)
+__device__ __forceinline__ void cellmark_from_domain_body(int64_t thread, int64_t ncells, int64_t npad,
+                                                          const int8_t* __restrict__ domain, int8_t value, uint8_t bits,
+                                                          const uint8_t* __restrict__ block_class, uint8_t* __restrict__ cellmark,
+                                                          const int64_t* __restrict__ poison)
 {
-  const int64_t base = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 16;
+  const int64_t base = thread * 16;
   if (base >= npad) return;
   unsigned out[4] = {0u, 0u, 0u, 0u};
   int known = -1; // the block's class says what every cell of it is
@@ -421,12 +442,12 @@ __global__ void __launch_bounds__(kBlock) dof_verts_kernel(int64_t ncells, int t
 // row classes of a degree-2 space from the vertex codes: a dof with an end vertex on the entities' side that no cut
 // cell touches has only entities around it (the cells around an edge are cells around either of its vertices); likewise
 // on the other side; else the marks decide.  Four dofs per thread; also the rows' initial marks (row_class_kernel).
-__global__ void __launch_bounds__(kBlock) row_class_p2_kernel(int64_t ndofs, const int32_t* __restrict__ dof_verts,
-                                                              const uint8_t* __restrict__ codes, const uint8_t* __restrict__ touch,
-                                                              uint8_t sel, uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
-                                                              uint8_t* __restrict__ special, const int64_t* __restrict__ poison)
+__device__ __forceinline__ void row_class_p2_body(int64_t thread, int64_t ndofs, const int32_t* __restrict__ dof_verts,
+                                                  const uint8_t* __restrict__ codes, const uint8_t* __restrict__ touch,
+                                                  uint8_t sel, uint8_t* __restrict__ rowcls, uint8_t* __restrict__ rowmark,
+                                                  uint8_t* __restrict__ special, const int64_t* __restrict__ poison)
 {
-  const int64_t r0 = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  const int64_t r0 = thread * 4;
   if (r0 >= ndofs) return;
   const bool void_step = poison != nullptr && *poison != 0; // (mark nothing: row_class_kernel)
   unsigned cls = 0u, rm = 0u;
@@ -453,6 +474,63 @@ __global__ void __launch_bounds__(kBlock) row_class_p2_kernel(int64_t ndofs, con
   *reinterpret_cast<unsigned*>(rowcls + r0) = cls; // (the three arrays are padded to a multiple of 16 rows)
   *reinterpret_cast<unsigned*>(rowmark + r0) = rm;
   *reinterpret_cast<unsigned*>(special + r0) = 0u;
+}
+
+// The marks a bulk row plan starts from, in ONE launch (four independent passes, each over its own range of workgroups:
+// a launch costs ~6 us whatever it does, and at 32^3 the whole step is forty such floors): row classes + initial row
+// marks (kind 1: P1, 16 rows per thread; kind 2: degree 2, four), cell marks from the classification bytes, the bit
+// words + counts of the uncut entities, and the 0xff fill of the rule-key tables.
+struct BulkInit
+{
+  unsigned blocks_cls, blocks_cm, blocks_pack; // (the fill takes the rest of the grid)
+  int kind;
+  int64_t ndofs;
+  const int32_t* dof_verts;
+  const uint8_t* codes;
+  const uint8_t* touch;
+  uint8_t sel;
+  uint8_t* rowcls;
+  uint8_t* rowmark;
+  uint8_t* special;
+  int32_t* t2off;
+  int64_t ncells, npad;
+  const int8_t* domain;
+  int8_t value;
+  uint8_t bits;
+  const uint8_t* block_class;
+  uint8_t* cellmark;
+  unsigned long long* words;
+  int32_t* pop;
+  int32_t* keys; // rule-key tables: n_keys words of -1 (n_keys a multiple of 64: power-of-two tables of >= 64 keys)
+  int64_t n_keys;
+  const int64_t* poison;
+};
+__global__ void __launch_bounds__(kBlock) plan_bulk_init_kernel(BulkInit B)
+{
+  unsigned b = blockIdx.x;
+  if (b < B.blocks_cls)
+  {
+    const int64_t t = (int64_t)b * kBlock + threadIdx.x;
+    if (B.kind == 1) row_class_body(t, B.ndofs, B.codes, B.touch, B.sel, B.rowcls, B.rowmark, B.special, B.t2off, B.poison);
+    else row_class_p2_body(t, B.ndofs, B.dof_verts, B.codes, B.touch, B.sel, B.rowcls, B.rowmark, B.special, B.poison);
+    return;
+  }
+  b -= B.blocks_cls;
+  if (b < B.blocks_cm)
+  {
+    cellmark_from_domain_body((int64_t)b * kBlock + threadIdx.x, B.ncells, B.npad, B.domain, B.value, B.bits, B.block_class,
+                              B.cellmark, B.poison);
+    return;
+  }
+  b -= B.blocks_cm;
+  if (b < B.blocks_pack)
+  {
+    pack_bits_domain_body((int64_t)b * kBlock + threadIdx.x, B.ncells, B.domain, B.value, B.block_class, B.words, B.pop, B.poison);
+    return;
+  }
+  b -= B.blocks_pack;
+  const int64_t i = ((int64_t)b * kBlock + threadIdx.x) * 4; // (16 B per thread; the block is 16 B aligned)
+  if (i < B.n_keys) *reinterpret_cast<int4*>(B.keys + i) = make_int4(-1, -1, -1, -1);
 }
 
 // active-row positions whose CSR row is at most / longer than `limit` columns
@@ -2185,6 +2263,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   P.cellmark.p = P.mark_block.p; P.cellmark.n = (nc + 3) & ~3LL; P.cellmark.owned = false;
   P.rowmark.p = P.mark_block.p + n_cm; P.rowmark.n = V->ndofs; P.rowmark.owned = false;
   DevArray<uint8_t> special; // rows touched by a runtime-rule cell or a facet
+  DevArray<int32_t> bulk_pop;  // bulk: entities per bit word of slot bulk_packed_slot (plan_bulk_init), scanned below
+  int bulk_packed_slot = -1;
   special.p = P.mark_block.p + n_cm + n_rm; special.n = V->ndofs; special.owned = false;
   ZeroFlag flag;
   int plan_flags = 0; // the flag word, read together with the row totals
@@ -2211,21 +2291,31 @@ cfx_row_plan& row_plan(cfx_form_s* a)
     if (key_total > 0) P.rule_key_block.alloc(key_total);
     if (P.bulk)
     {
-      // no zero fill: the row classes initialise the row marks, the cell marks come from the classification bytes
-      if (key_total > 0) dev_fill(P.rule_key_block.p, 0xff, sizeof(int32_t) * (size_t)key_total);
+      // no zero fill: the row classes initialise the row marks, the cell marks come from the classification bytes; the
+      // bit words of the first slot with entities and the emptied rule-key tables come out of the same launch
       P.rowcls.alloc(n_rm);
-      if (P.bulk_kind == 1)
-        launch("plan_row_class", row_class_kernel, grid_for(n_rm / 16), dim3(kBlock), 0, V->ndofs, bulk_cut->codes0.p,
-               bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
-               n_t2 > 0 ? P.vec_t2off.p : (int32_t*)nullptr, step_poison());
-      else
-        launch("plan_row_class", row_class_p2_kernel, grid_for(n_rm / 4), dim3(kBlock), 0, V->ndofs, V->dof_verts.p,
-               bulk_cut->codes0.p, bulk_cut->touch0.p, (uint8_t)(bulk_value < 0 ? 1 : 2), P.rowcls.p, P.rowmark.p, special.p,
-               step_poison());
       const int64_t nb = (nc + kClassBlock - 1) / kClassBlock;
-      launch("plan_cell_marks", cellmark_from_domain_kernel, grid_for(n_cm / 16), dim3(kBlock), 0, nc, n_cm, bulk_cut->domain.p,
-             (int8_t)bulk_value, P.bulk_bits, bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : (const uint8_t*)nullptr,
-             P.cellmark.p, step_poison());
+      const int64_t nwords = (nc + 63) / 64;
+      bulk_packed_slot = __builtin_ctz((unsigned)P.bulk_bits);
+      P.std_bits[bulk_packed_slot].alloc(nwords);
+      bulk_pop.alloc(nwords);
+      BulkInit B{};
+      B.kind = P.bulk_kind;
+      B.blocks_cls = grid_for(P.bulk_kind == 1 ? n_rm / 16 : n_rm / 4).x;
+      B.blocks_cm = grid_for(n_cm / 16).x;
+      B.blocks_pack = grid_for(nwords).x;
+      B.ndofs = V->ndofs; B.dof_verts = P.bulk_kind == 2 ? V->dof_verts.p : nullptr;
+      B.codes = bulk_cut->codes0.p; B.touch = bulk_cut->touch0.p; B.sel = (uint8_t)(bulk_value < 0 ? 1 : 2);
+      B.rowcls = P.rowcls.p; B.rowmark = P.rowmark.p; B.special = special.p;
+      B.t2off = (P.bulk_kind == 1 && n_t2 > 0) ? P.vec_t2off.p : nullptr;
+      B.ncells = nc; B.npad = n_cm; B.domain = bulk_cut->domain.p; B.value = (int8_t)bulk_value; B.bits = P.bulk_bits;
+      B.block_class = bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : nullptr;
+      B.cellmark = P.cellmark.p;
+      B.words = reinterpret_cast<unsigned long long*>(P.std_bits[bulk_packed_slot].p); B.pop = bulk_pop.p;
+      B.keys = key_total > 0 ? P.rule_key_block.p : nullptr; B.n_keys = key_total;
+      B.poison = step_poison();
+      const unsigned blocks_fill = key_total > 0 ? grid_for((key_total + 3) / 4).x : 0u;
+      launch("plan_bulk_init", plan_bulk_init_kernel, dim3(B.blocks_cls + B.blocks_cm + B.blocks_pack + blocks_fill), dim3(kBlock), 0, B);
       P.any_cells = true;
     }
     else if (key_total > 0)
@@ -2301,13 +2391,25 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       if (ne > 0) ++n_facet_lists;
     }
   }
+  // (one launch for the rule sets; the rows of the form's only facet list join it)
+  bool facets_with_rules = false;
   if (rjobs.n > 0)
   {
+    int64_t threads = rjobs.start[rjobs.n];
+    if (n_facet_lists == 1)
+      for (int s = 0; s < P.n_facet_slots; ++s)
+      {
+        const cfx_integral_dev& I = a->integrals[P.facet_slot_integral[s]];
+        if (I.n_entities.cap() == 0) continue;
+        rjobs.nf = I.n_entities; rjobs.facet_rows = I.entities.p;
+        threads += I.n_entities.cap();
+        facets_with_rules = true;
+      }
     if (nd == 4)
-      launch("plan_rules", plan_rules_kernel<4>, grid_for(rjobs.start[rjobs.n]), dim3(kBlock), 0, rjobs, V->dofmap.p,
+      launch("plan_rules", plan_rules_kernel<4>, grid_for(threads), dim3(kBlock), 0, rjobs, V->dofmap.p,
              P.cellmark.p, P.rowmark.p, special.p, flag.p);
     else
-      launch("plan_rules", plan_rules_kernel<3>, grid_for(rjobs.start[rjobs.n]), dim3(kBlock), 0, rjobs, V->dofmap.p,
+      launch("plan_rules", plan_rules_kernel<3>, grid_for(threads), dim3(kBlock), 0, rjobs, V->dofmap.p,
              P.cellmark.p, P.rowmark.p, special.p, flag.p);
   }
   // the facet rows of all facet integrals, concatenated: one list keeps its (possibly pending) length, several are
@@ -2352,7 +2454,8 @@ cfx_row_plan& row_plan(cfx_form_s* a)
                                hipMemcpyDeviceToDevice, ctx().stream));
         dev_fill(P.facet_slot.p + o, s, (size_t)ne);
       }
-      if (nd == 4)
+      if (facets_with_rules) {} // (marked by plan_rules)
+      else if (nd == 4)
         launch("plan_facet_rows", plan_facet_rows_kernel<4>, grid_for(ne), dim3(kBlock), 0, I.n_entities,
                I.entities.p, V->dofmap.p, P.rowmark.p, special.p, flag.p);
       else if (nd == 3)
@@ -2503,21 +2606,26 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   {
     const cfx_integral_dev& I = a->integrals[P.cell_slot_integral[slot]];
     if (I.n_entities.cap() == 0) continue;
-    P.std_bits[slot].alloc(nwords);
     P.std_rank[slot].alloc(nwords + 1);
+    if (P.bulk && slot == bulk_packed_slot)
+    {
+      // (packed by plan_bulk_init; the marked cells per tile -- the count pass of the active-cell list -- are counted
+      // when that list is asked for)
+      exclusive_scan(bulk_pop.p, P.std_rank[slot].p, nwords);
+      continue;
+    }
+    P.std_bits[slot].alloc(nwords);
     DevArray<int32_t> pop(nwords);
     int32_t* tiles = nullptr;
-    if (P.cell_tile_counts.n == 0)
+    if (!P.bulk && P.cell_tile_counts.n == 0)
     {
       P.cell_tile_counts.alloc((nc + kByteTile - 1) / kByteTile);
       tiles = P.cell_tile_counts.p;
     }
     if (P.bulk)
     {
-      // (the entities are the cells of one domain value: no pass over the mark bytes; the marked cells per tile -- the
-      // count pass of the active-cell list -- are counted when that list is asked for)
+      // (the entities are the cells of one domain value: no pass over the mark bytes)
       const int64_t nb = (nc + kClassBlock - 1) / kClassBlock;
-      P.cell_tile_counts.release();
       launch("plan_pack_bits", pack_bits_domain_kernel, grid_for(nwords), dim3(kBlock), 0, nc, bulk_cut->domain.p, (int8_t)bulk_value,
              bulk_cut->block_class.n == nb ? bulk_cut->block_class.p : (const uint8_t*)nullptr,
              reinterpret_cast<unsigned long long*>(P.std_bits[slot].p), pop.p, step_poison());

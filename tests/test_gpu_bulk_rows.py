@@ -51,7 +51,7 @@ def test_the_bulk_path_is_taken_and_equals_the_list_walk_and_the_oracle(oracle, 
     import os
     switched_off = not bulk_expected()
     if not switched_off:
-        for k in ("plan_row_class", "plan_cell_marks", "plan_mix_rows"):
+        for k in ("plan_bulk_init", "plan_mix_rows"):
             assert k in names, (k, sorted(names))
         assert "plan_mark_entities" not in names
     against_oracle(oracle, om, phi, A, b, dom)
@@ -59,7 +59,7 @@ def test_the_bulk_path_is_taken_and_equals_the_list_walk_and_the_oracle(oracle, 
     monkeypatch.setenv("CFX_BULK_ROWS", "0")
     cd2 = cfx.cut(cfx.Function(V, phi))
     (s2, A2, b2, dom2), names2 = profiled(lambda: poisson_system(cfx, V, cd2))
-    assert "plan_row_class" not in names2 and ("plan_mark_entities" in names2 or switched_off)
+    assert "plan_bulk_init" not in names2 and ("plan_mark_entities" in names2 or switched_off)
     assert np.array_equal(A.indptr, A2.indptr) and np.array_equal(A.indices, A2.indices)
     if os.environ.get("CFX_ASSEMBLY") == "atomic":      # (FP64 atomics: the order of the sums is the schedule's)
         assert rel_err(A.data, A2.data) < 1e-13 and rel_err(b, b2) < 1e-13
@@ -84,8 +84,8 @@ def test_a_host_copy_of_the_list_has_no_provenance_and_takes_the_list_walk(oracl
         a = fem.form([fem.Integral(fem.STIFFNESS, cells=cells, rules=vol, qdegree=0)], V)
         A, names = profiled(lambda: fem.assemble_matrix(a))
         out[tag] = (A, names)
-    assert ("plan_row_class" in out["dev"][1] or not bulk_expected()) and "plan_row_class" not in out["host"][1]
-    assert "plan_row_class" not in out["prefix"][1]
+    assert ("plan_bulk_init" in out["dev"][1] or not bulk_expected()) and "plan_bulk_init" not in out["host"][1]
+    assert "plan_bulk_init" not in out["prefix"][1]
     assert np.array_equal(out["dev"][0].indices, out["host"][0].indices)
     assert rel_err(out["dev"][0].data, out["host"][0].data) < 1e-14
     # half of the list is another form: fewer entries
@@ -117,7 +117,7 @@ def test_zeros_at_vertices_only_inside_cells_and_scrambled_numbering(oracle, tdi
             inside = cfx.locate_entities_device(cd, "phi<0")
             a = fem.form([fem.Integral(fem.MASS, cells=inside, qdegree=2)], V)
             (A, dom), names = profiled(lambda: (fem.assemble_matrix(a), fem.active_domain(a)))
-            assert "plan_row_class" in names or not bulk_expected()
+            assert "plan_bulk_init" in names or not bulk_expected()
             oV = O.Space(m.conn, m.nnodes, 1)
             oi = [O.Integral(O.CELL, O.K_MASS, entities=O.locate_entities(d, "phi<0"), qdegree=2)]
             ip, ix = O.create_sparsity(m, oV, oi)
@@ -152,7 +152,7 @@ def test_facets_from_another_source_mark_rows_inside_the_bulk(oracle):
     a = fem.form([fem.Integral(fem.STIFFNESS, cells=inside_dev, rules=vol, qdegree=0),
                   fem.Integral(fem.GHOST_GRADJUMP, facets=facets, params=(0.1,), qdegree=0)], V)
     A, names = profiled(lambda: fem.assemble_matrix(a))
-    assert "plan_row_class" in names or not bulk_expected()
+    assert "plan_bulk_init" in names or not bulk_expected()
     oV = O.Space(om.conn, om.nnodes, 1)
     ovol = O.runtime_quadrature(om, om.conn, phi, d, "phi<0", 2)
     oi = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=ovol, qdegree=0),
@@ -203,12 +203,12 @@ def test_bulk_rows_of_degree_two_spaces(oracle, tdim, n, bs, monkeypatch):
         ina = O.inactive_dofs(oV, O.active_cells(o_ints, om.ncells))
         A, dom, names, _keep = build(with_rules)
         if bulk_expected():
-            assert "plan_row_class" in names, sorted(names)     # (plan_mark_cells still marks the rule cells)
+            assert "plan_bulk_init" in names, sorted(names)     # (plan_mark_cells still marks the rule cells)
         assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix), with_rules
         assert rel_err(A.data, want) < RTOL and np.array_equal(dom.inactive_dofs, ina)
         monkeypatch.setenv("CFX_BULK_ROWS", "0")
         A2, dom2, names2, _keep2 = build(with_rules)
         monkeypatch.delenv("CFX_BULK_ROWS")
-        assert "plan_row_class" not in names2
+        assert "plan_bulk_init" not in names2
         assert np.array_equal(A2.indptr, ip) and np.array_equal(A2.indices, ix) and rel_err(A2.data, want) < RTOL
         assert np.array_equal(dom2.inactive_dofs, ina)

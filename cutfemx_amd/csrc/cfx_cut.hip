@@ -1167,11 +1167,7 @@ struct EmitJobs
   int32_t* parent_map[2];
 };
 
-#if defined(CFX_EMIT_ABLATE)
-#define CFX_EMIT_STORE(dst, val) do { const double v_ = (val); if (v_ == 1.2345e300) (dst) = v_; } while (0) // ablation: no stores
-#else
 #define CFX_EMIT_STORE(dst, val) (dst) = (val)
-#endif
 #ifndef CFX_EMIT_WAVES
 #define CFX_EMIT_WAVES 4 // waves per SIMD the emit kernel is compiled for (112 registers in 3-D without a bound: 4)
 #endif

@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(kBlock) compact_bytes_write_kernel(int64_t n, 
     if (o + i < cap) out[o + i] = s_out[i];
 }
 
-__global__ inline void ride_along_kernel(const int64_t* a, const int* b, int64_t* out)
+static __global__ void ride_along_kernel(const int64_t* a, const int* b, int64_t* out)
 {
   out[0] = *a; out[1] = *b;
 }

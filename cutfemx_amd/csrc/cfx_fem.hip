@@ -680,9 +680,6 @@ __global__ void __launch_bounds__(64) elasticity_tensors_mfma_kernel(AsmArgs A)
     double* out = A.dump + e * (int64_t)(NLOC * NLOC);
     // 16 B per lane: 1 KiB per store instruction (a tensor starts on a 16 B boundary: NLOC^2 is even)
     typedef double cfx_d2 __attribute__((ext_vector_type(2)));
-#if defined(CFX_MFMA_ABLATE) && (CFX_MFMA_ABLATE & 1)
-    if (s_H[lane] == 1.2345e300) // ablation: no stores
-#endif
     for (int o = lane; o < NLOC * NLOC / 2; o += 64)
       reinterpret_cast<cfx_d2*>(out)[o] = reinterpret_cast<const cfx_d2*>(s_H)[o];
     __syncthreads(); // s_H / s_L are reused by the next cell

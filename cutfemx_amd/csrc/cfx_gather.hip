@@ -128,7 +128,6 @@ struct RowArgs
   const int32_t* indices;
   double* values;
   int* error;
-  int debug; // ablation switches (CFX_DEBUG_ROWS), 0 in production
   int iso_geometry; // the space's dofmap is the geometry dofmap (P1): dofs are vertex ids
   unsigned mark_mask;   // cell-mark bits this launch handles: 0x0F uncut entities, 0xF0 runtime rules (+ facets)
   int fold_facets;      // every facet-type entity joins two cells across a shared facet (no extension pairs): 1 fold in the
@@ -502,16 +501,8 @@ __device__ __forceinline__ void source_load_vertices(const VecArgs& A, SourceCel
 #pragma unroll
   for (int i = 0; i <= TDIM; ++i)
   {
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 4)
-    for (int d = 0; d < TDIM; ++d) c.x[i][d] = 1e-9 * (double)((c.v[i] >> (9 * d)) & 511) + (i == d + 1 ? 1e-3 : 0.0); // ablation: no vertex gathers
-#else
     load_vertex<TDIM>(A.x, c.v[i], c.x[i]);
-#endif
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 2)
-    c.t2o[i] = c.v[i]; // ablation: no segment-offset gathers
-#else
     c.t2o[i] = A.t2 ? A.t2off[c.v[i]] - 1 : -1; // (stored + 1: 0 = the row has no segment)
-#endif
   }
 }
 
@@ -547,11 +538,7 @@ __device__ __forceinline__ void source_vector(const SourceCell<TDIM>& c, int npt
 #pragma unroll
     for (int d = 0; d < TDIM; ++d)
     {
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 32)
-      S[d] = c.x[0][d]; C[d] = 1.0 - S[d]; // ablation: no sincospi of the anchor
-#else
       cfx_sincospi(c.x[0][d], S[d], C[d]);
-#endif
 #pragma unroll
       for (int t = 0; t < TDIM; ++t) ed[t][d] *= kPi;
     }
@@ -628,16 +615,8 @@ __device__ __forceinline__ void source_compute(const VecArgs& A, const SourceCel
   double be[ND];
   source_vector<TDIM>(c, npts, pts, wts, fscale, be);
   if (!valid) return;
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 1)
-  if (be[0] != 1.2345e300) return; // ablation: no stores
-#endif
   // entry i to the segment of row dof_i (store_std_vector, with the gathers already in registers)
   bool record = A.t2 == nullptr;
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 16)
-  for (int i = 0; i < 2; ++i) // ablation: the same bytes in half as many (16 B) stores
-    if (c.t2o[i] >= 0) *reinterpret_cast<cfx_d2u*>(A.t2 + (int64_t)c.t2o[i] + ((c.cp >> (8 * i)) & 0xffu)) = cfx_d2u{be[i], be[i + 2]};
-  return;
-#endif
 #pragma unroll
   for (int i = 0; i < ND; ++i)
   {
@@ -665,9 +644,6 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_source_sin_p1_ke
   int npts;
   const double* wts;
   const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 8)
-  npts = 1; // ablation: one point
-#endif
   const double fscale = A.params[1] * ((int)A.params[0] == CFX_F_POISSON_RHS ? (double)TDIM * kPi * kPi : 1.0);
   auto ent = [&](int64_t e) { return A.entities[e < last ? e : last]; }; // (clamped: the tail of the pipeline loads the last cell again)
   SourceCell<TDIM> a, b;
@@ -892,9 +868,6 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_blocks_sin_p1_ke
   int npts;
   const double* wts;
   const double* pts = ref_rule(TDIM, A.qdegree, npts, wts);
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 8)
-  npts = 1; // ablation: one point
-#endif
   const double fscale = A.params[1] * ((int)A.params[0] == CFX_F_POISSON_RHS ? (double)TDIM * kPi * kPi : 1.0);
   const int64_t nt = P.n_active, stride = gridDim.x, last = P.ncells - 1;
   auto blk = [&](int64_t i) { return (int64_t)P.active[i < nt ? i : nt - 1]; }; // (clamped: the tail loads the last block again)
@@ -947,12 +920,7 @@ __global__ void __launch_bounds__(kBlock, CFX_SOURCE_WAVES) vec_blocks_sin_p1_ke
 #pragma unroll
       for (int j = 0; j < ND; ++j) sv[xa.sl[j]] = xa.on ? be[j] : 0.0;
     }
-#if !(defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 32))
     __syncthreads(); // (the other buffer is written by the next trip: its readers of the previous trip have passed this barrier)
-#endif
-#if defined(CFX_SOURCE_ABLATE) && (CFX_SOURCE_ABLATE & 64)
-    if (be[0] == 1.2345e300) // ablation: no segment sums, no partial stores
-#endif
     if ((int)threadIdx.x < xa.nu)
     {
       double sum = 0.0;
@@ -1059,7 +1027,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
   const bool cells = live && A.cellmark != nullptr;
   const int64_t cb = cells ? A.d2c_off[r] : 0;
   const int nc = cells ? (int)(A.d2c_off[r + 1] - cb) : 0;
-  const bool facets = live && A.d2f_off != nullptr && (A.mark_mask & 0xF0u) != 0 && !(A.debug & 8);
+  const bool facets = live && A.d2f_off != nullptr && (A.mark_mask & 0xF0u) != 0;
   const int64_t fpos = (facets && A.special_mark[r]) ? (int64_t)A.special_pos[r] : -1; // incidence is per special row
   const int64_t fb = fpos >= 0 ? A.d2f_off[fpos] : 0;
   const int nf = fpos >= 0 ? (int)(A.d2f_off[fpos + 1] - fb) : 0;
@@ -1087,7 +1055,6 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
   auto add_item = [&](auto nc_tag, bool has, const int32_t* cols, double* acc, const int* sl)
   {
     constexpr int NC = decltype(nc_tag)::value;
-    if (A.debug & 1) { if (has && acc[0] == 1.2345e300) *A.error = 3; return; } // ablation: no reduction
     // (slot, value) pairs of this lane's item; BC rows / columns are zeroed here
     // (assemble_matrix_impl.h:151-185)
     double v[NC];
@@ -1177,8 +1144,8 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
         if (mk[k])
         {
 #pragma unroll
-          for (int j = 0; j < ND; ++j) csl[j] = (A.debug & 4) ? j : find_slot(cd[k][j]);
-          for (int i = 0; i < ((A.debug & 2) ? 0 : A.n_cell); ++i)
+          for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[k][j]);
+          for (int i = 0; i < A.n_cell; ++i)
           {
             const RowIntegral& I = A.cell[i];
             if (STD && (mark & (1u << i)))
@@ -1276,7 +1243,7 @@ __global__ void __launch_bounds__(kWave, DEG > 1 ? (CUTS ? (CUTT ? (STD ? 3 : 4)
     double d = dsum;
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) d += __shfl_xor(d, o, G);
-    if (live && gl == 0 && len > 0 && nc > 0 && !(A.debug & 1))
+    if (live && gl == 0 && len > 0 && nc > 0)
     {
       const int slot = find_slot((int32_t)r);
       if (slot >= 0) atomicAdd(&s_val[grp][slot], d);
@@ -1605,9 +1572,6 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
   double dsum = 0.0;
   auto find_slot = [&](int32_t col) -> int
   {
-#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 1)
-    return (int)((unsigned)col % (unsigned)(len > 0 ? len : 1)); // ablation: no probe
-#endif
     // the first two positions without a branch (load factor <= 1/2: ~9 of 10 lookups end there), both keys in flight
     // together; the probe loop only behind them (26 loops with data-dependent trip counts per pass were a good part
     // of the kernel's scalar instructions: as many as vector ones)
@@ -1633,10 +1597,6 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
   auto add_item = [&](auto nc_tag, bool has, const int32_t* cols, const double* acc, const int* sl)
   {
     constexpr int NC = decltype(nc_tag)::value;
-#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 8)
-    if (has && acc[0] == 1.2345e300) *A.error = 3; // ablation: no LDS accumulation
-    return;
-#endif
     double v[NC];
     int sidx[NC];
 #pragma unroll
@@ -1752,13 +1712,11 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
       {
 #pragma unroll
         for (int j = 0; j < ND; ++j) csl[j] = find_slot(cd[j]);
-#if !(defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 4)) // (ablation: no closed-form row)
         if (mark & 0x0Fu)
         {
           jacobian<TDIM>(g);
           p2_stiffness_row<TDIM>(g, lr, 1.0, acc);
         }
-#endif
         if (is_cut)
         {
 #pragma unroll
@@ -1776,11 +1734,7 @@ __global__ void __launch_bounds__(kWave, CFX_IFC_WAVES) assemble_rows_p2_interfa
       int sl[WF];
 #pragma unroll
       for (int j = 0; j < WF; ++j) { acc[j] = 0.0; sl[j] = -1; }
-#if defined(CFX_IFC_ABLATE) && (CFX_IFC_ABLATE & 2)
-      if (false) // ablation: no facet items
-#else
       if (hasf)
-#endif
       {
         int m = -1;
 #pragma unroll
@@ -2286,9 +2240,6 @@ __global__ void __launch_bounds__(kWave, CFX_PLAIN_WAVES) assemble_rows_plain_ke
 #ifndef CFX_TILE_R
 #define CFX_TILE_R 3 // items per lane and pass (measured with 5 waves per SIMD: 2 -> 2.17 ms, 3 -> 2.17, 4 -> 2.42, 6 -> 3.23; with 4: 6 -> 2.26)
 #endif
-#ifndef CFX_TILE_ABLATE
-#define CFX_TILE_ABLATE 0 // timing-only builds (wrong results): 1 no LDS atomics, 2 no coordinate reads, 4 no stiffness arithmetic, 8 no items
-#endif
 struct TileArgs
 {
   const double* x;
@@ -2446,11 +2397,7 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
   double dsum = 0.0;
   // lane gl owns the items [gl * per, gl * per + per): lanes that run together work on cells a quarter of the
   // row's list apart, which rarely share a vertex -- fewer LDS atomics that serialise on one address
-#if (CFX_TILE_ABLATE & 8)
-  const int per = 0; // ablation: staging and write-out only
-#else
   const int per = (nc + G - 1) / G;
-#endif
   for (int base = 0;; base += R)
   {
     if (__ballot(base < per) == 0) break;
@@ -2495,18 +2442,8 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
       for (int q = 0; q < TDIM; ++q)
 #pragma unroll
         for (int d = 0; d < TDIM; ++d)
-#if (CFX_TILE_ABLATE & 2)
-          xo[q][d] = xr[d] + 0.001 * (double)(vo[k][q] + d + q * q); // ablation: no coordinate reads
-#else
           xo[q][d] = s_x[vo[k][q] * TDIM + d];
-#endif
-#if (CFX_TILE_ABLATE & 4)
-      dg = xo[0][0] + xr[0]; // ablation: no stiffness arithmetic
-#pragma unroll
-      for (int q = 0; q < TDIM; ++q) off[q] = xo[q][1] + xo[q][TDIM - 1];
-#else
       p1_stiffness_row<TDIM>(xr, xo, dg, off);
-#endif
       int osl[TDIM];
       double ov[TDIM];
 #pragma unroll
@@ -2549,16 +2486,11 @@ __global__ void __launch_bounds__(kWave, CFX_TILE_WAVES) assemble_tiles_plain_ke
       }
       else
       {
-#if (CFX_TILE_ABLATE & 1)
-#pragma unroll
-        for (int q = 0; q < TDIM; ++q) dsum += rep[k] ? ov[q] * (double)osl[q] : 0.0; // ablation: no LDS atomics
-#else
         if (rep[k])
         {
 #pragma unroll
           for (int q = 0; q < TDIM; ++q) atomicAdd(&s_val[st_rel + osl[q]], ov[q]);
         }
-#endif
       }
     }
   }
@@ -3066,19 +2998,7 @@ __global__ void __launch_bounds__(kWave, CFX_P2PLAIN_WAVES) assemble_rows_p2_pla
       const uint32_t* rec = reinterpret_cast<const uint32_t*>(A.slotn + (cb + t) * 12);
       w0 = rec[0]; w1 = rec[1]; w2 = rec[2];
       Geo<TDIM> g;
-#if defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 3
-      for (int i = 0; i <= TDIM; ++i) // ablation: no connectivity row, no vertices
-        for (int d = 0; d < TDIM; ++d) g.x[i][d] = 1e-9 * (double)((c >> (7 * d)) & 127) + (i == d + 1 ? 1e-3 : 0.0);
-#elif defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 4
-      {
-        const int4 vv = *reinterpret_cast<const int4*>(A.conn + c * 4); // ablation: no vertex gathers
-        const int vq[4] = {vv.x, vv.y, vv.z, vv.w};
-        for (int i = 0; i <= TDIM; ++i)
-          for (int d = 0; d < TDIM; ++d) g.x[i][d] = 1e-9 * (double)((vq[i] >> (7 * d)) & 127) + (i == d + 1 ? 1e-3 : 0.0);
-      }
-#else
       load_cell<TDIM>(A.x, A.conn, c, g);
-#endif
       jacobian<TDIM>(g);
       p2_stiffness_row<TDIM>(g, (int)((w2 >> 16) & 0xffu), 1.0, acc);
     }
@@ -3104,17 +3024,9 @@ __global__ void __launch_bounds__(kWave, CFX_P2PLAIN_WAVES) assemble_rows_p2_pla
     }
     else
     {
-#if defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 1
-#pragma unroll
-      for (int j = 0; j < ND; ++j)
-        if (sl[j] >= 0) s_val[grp][sl[j]] = acc[j]; // ablation: plain LDS stores
-#elif defined(CFX_P2PLAIN_ABLATE) && CFX_P2PLAIN_ABLATE == 2
-      if (acc[0] == 1.2345e300 && sl[0] >= 0) *A.error = 3; // ablation: no LDS traffic
-#else
 #pragma unroll
       for (int j = 0; j < ND; ++j)
         if (sl[j] >= 0) atomicAdd(&s_val[grp][sl[j]], acc[j]);
-#endif
     }
   }
   __syncthreads();
@@ -3258,9 +3170,6 @@ struct BlockP2Args
 
 #ifndef CFX_BLOCK_P2_WAVES
 #define CFX_BLOCK_P2_WAVES 2
-#endif
-#ifndef CFX_BP2_ABLATE
-#define CFX_BP2_ABLATE 0 // timing-only builds (wrong results): 1 no phase 2, 2 no stores, 4 no phase 1, 8 no gathers, 16 no LDS zeroing
 #endif
 // 3 x 3 (2 x 2) gradient Gram block of one (row dof, column dof) pair with RUNTIME indices: the row is described by its
 // barycentric pair (a, b) (a vertex row: a == b, Gb = 0), the column by (jc, jd) likewise; Gs = grad(lam_k), Ga / Gb =
@@ -3478,24 +3387,14 @@ __global__ void __launch_bounds__(kWave, CFX_BLOCK_P2_WAVES) assemble_rows_block
     const bool dlive = d < nd_here;
     const int nc = dlive ? s_nc[d] : 0;
     const int lene = dlive ? s_len[d] : 0;
-#if !(CFX_BP2_ABLATE & 16)
     for (int k = gl; k < BS * lene; k += G) s_val[grp][k] = 0.0;
-#endif
-#if !(CFX_BP2_ABLATE & 4)
     if (gl < nc) stage_item(itA, xA);
-#endif
     // next stages: vertices of q + 1, connectivity of q + 2, incidence entries of q + 3 -- in flight during phase 2
-#if (CFX_BP2_ABLATE & 8)
-    const Coords xN = xA; const Conn cnN = cnB; const Item itN = itC;
-#else
     const Coords xN = load_coords(cnB);
     const Conn cnN = load_conn(itC.c);
     const Item itN = load_item(q + 3, gl);
-#endif
     __syncthreads();
-#if !(CFX_BP2_ABLATE & 1)
     add_items(min(G, nc), lene);
-#endif
     for (int base = G; base < nc; base += G) // (rare: more incident cells than lanes)
     {
       __syncthreads();
@@ -3512,9 +3411,6 @@ __global__ void __launch_bounds__(kWave, CFX_BLOCK_P2_WAVES) assemble_rows_block
     // the BS rows of a dof are one contiguous run of BS x lene values: the whole wavefront streams the runs of the
     // RPW dofs one after the other, 16 B per lane (groups of G lanes storing 8 B each left the matrix write at
     // 1.4 TB/s: 8.4 ms of this kernel's 13.3 at BASELINE config 5's share)
-#if (CFX_BP2_ABLATE & 2)
-    if (lmbda == 1.2345e300)
-#endif
 #pragma unroll
     for (int g2 = 0; g2 < RPW; ++g2)
     {
@@ -3603,7 +3499,7 @@ template <int TDIM>
 __global__ void __launch_bounds__(kBlock, CFX_CUTT_WAVES) cut_tensors_p2_kernel(CutTensorArgs A)
 {
   constexpr int NV = TDIM + 1, NE = TDIM == 2 ? 3 : 6, ND = NV + NE, NP = ND * (ND + 1) / 2;
-  constexpr int NM = 1 + NV + NV * (NV + 1) / 2, NO = (NP + kCutLanes2 - 1) / kCutLanes2;
+  constexpr int NO = (NP + kCutLanes2 - 1) / kCutLanes2;
   constexpr int ea2[3] = {1, 0, 0}, eb2[3] = {2, 2, 1};
   constexpr int ea3[6] = {2, 1, 1, 0, 0, 0}, eb3[6] = {3, 3, 2, 3, 2, 1};
   __shared__ double s_T[kBlock / kCutLanes2][NP + 1];
@@ -4096,7 +3992,6 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
   A.bc0 = bc0; A.bc1 = bc1; A.indptr = P->indptr.p; A.indices = P->indices.p; A.values = values;
   ErrorFlag err(CFX_ERR_RUNTIME, kEntryMissing, raise_gather_error);
   A.error = err.p;
-  if (const char* dbg = getenv("CFX_DEBUG_ROWS")) A.debug = atoi(dbg);
   // `fresh` = MatrixCSR.set_value(0) fused into this call (nothing has written to `values` yet: stage 1 fills its own
   // buffers).  P1 on the split path: every active row has a FIRST writer that stores (the tile / plain kernels their
   // rows, assemble_rows_p1 the rows it is given), so only the inactive rows (one diagonal entry each) are zeroed --

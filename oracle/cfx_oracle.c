@@ -266,12 +266,6 @@ static double cell_diameter(int tdim, double xc[MAXV][3])
 static const int tri_edges[3][2] = {{1, 2}, {0, 2}, {0, 1}};
 static const int tet_edges[6][2] = {{2, 3}, {1, 3}, {1, 2}, {0, 3}, {0, 2}, {0, 1}};
 
-static int lagrange_ndofs(int tdim, int degree)
-{
-  if (degree == 1) return tdim + 1;
-  return tdim == 2 ? 6 : 10;
-}
-
 static void tabulate(int tdim, int degree, const double* X, double* N, double dN[][3])
 {
   double lam[4], dlam[4][3];

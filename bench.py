@@ -253,9 +253,11 @@ def cpu_baseline_all_cores(n, order):
 
 
 def scale_fields(comm, world, per_rank_ms, exchange_ms):
-    """What a SCALE-day line has to say about itself: which transport really moved the halo (an RCCL -> gloo fallback
-    ends the job unless CFX_REHEARSE=1, cutfemx_amd.dist.decide_transport), on how many ranks the RCCL communicator
-    came up, every rank's own step time (the slowest is the job's) and the exchange alone."""
+    """What a SCALE-day line has to say about itself: which transport really moved the halo ('rccl': the library's own
+    communicator; 'rccl-torch': the same links through the job's nccl process group when that communicator did not come
+    up on every rank; an RCCL -> gloo fallback ends the job unless CFX_REHEARSE=1, cutfemx_amd.dist.decide_transport), on
+    how many ranks the library's RCCL communicator came up, every rank's own step time (the slowest is the job's) and the
+    exchange alone."""
     return dict(transport=comm.transport if comm is not None else "none", rccl_ranks=getattr(comm, "rccl_ranks", 0),
                 world=world, per_rank_ms_per_step=[round(v, 4) for v in per_rank_ms],
                 slowest_rank_ms_per_step=round(max(per_rank_ms), 4),
@@ -1174,7 +1176,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
             # a scaling line must be an xGMI line: without CFX_REHEARSE, an RCCL communicator that does not come up on
-            # every rank ends the job (cutfemx_amd.dist.TransportError) instead of falling back to host-staged gloo
+            # every rank moves its device buffers through this nccl group instead ('rccl-torch'); a host-staged gloo fallback
+            # ends the job (cutfemx_amd.dist.TransportError)
             os.environ.setdefault("CFX_DIST_STRICT", "1")
     os.environ["CFX_DEVICE"] = str(local_rank)
     # One explicit HIP stream for torch and the engine alike (CFX_BENCH_STREAM=0: the legacy null stream, the library's

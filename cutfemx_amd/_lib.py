@@ -101,7 +101,7 @@ SYMBOLS = [
     "cfx_pattern_view_get", "cfx_pattern_reuse_stats", "cfx_pattern_destroy", "cfx_assemble_matrix", "cfx_assemble_matrix_zeroed", "cfx_assemble_vector",
     "cfx_apply_lifting", "cfx_set_bc", "cfx_zero_rows", "cfx_csr_block_merge", "cfx_csr_permute", "cfx_tabulate_entity", "cfx_active_domain", "cfx_active_view", "cfx_deactivate_outside",
     "cfx_active_destroy",
-    "cfx_dist_unique_id", "cfx_dist_comm_create", "cfx_dist_comm_create_host", "cfx_dist_comm_info", "cfx_dist_comm_destroy",
+    "cfx_dist_unique_id", "cfx_dist_comm_create", "cfx_dist_comm_create_host", "cfx_dist_comm_create_device", "cfx_dist_comm_info", "cfx_dist_comm_destroy",
     "cfx_dist_scatter_forward", "cfx_dist_scatter_reverse_add", "cfx_dist_scatter_reverse_matrix", "cfx_dist_indicator_or",
     "cfx_dist_indicator_forward",
     "cfx_mesh_create_f32", "cfx_cut_create_f32", "cfx_cut_update_f32", "cfx_rules_create_f32", "cfx_rules_view_get_f32",

@@ -111,6 +111,8 @@ struct cfx_comm_s
   ncclComm_t comm = nullptr;
   cfx_host_exchange_fn host_fn = nullptr;
   void* host_user = nullptr;
+  cfx_device_exchange_fn device_fn = nullptr; // the caller's own GPU-to-GPU transport (cfx_dist_comm_create_device)
+  void* device_user = nullptr;
   std::vector<PinnedBuf> stage_send, stage_recv; // per segment slot of an exchange, reused by every later exchange
 };
 
@@ -162,6 +164,25 @@ void transport(cfx_comm_s* c, std::vector<Segment>& seg)
       if (s.recv_bytes > 0) nccl_check(r.Recv(s.recv, (size_t)s.recv_bytes, ncclInt8, s.peer, c->comm, cx.stream), "ncclRecv");
     }
     nccl_check(r.GroupEnd(), "ncclGroupEnd");
+    return;
+  }
+  if (c->device_fn)
+  {
+    // the caller's GPU-to-GPU transport (a GPU-aware MPI, the launcher's own RCCL process group): it is handed the device
+    // segments once everything that fills them has run; whatever it enqueues must have completed when it returns
+    const int n = (int)seg.size();
+    std::vector<int32_t> peers(n);
+    std::vector<const void*> sp(n, nullptr);
+    std::vector<void*> rp(n, nullptr);
+    std::vector<int64_t> sb(n), rb(n);
+    for (int i = 0; i < n; ++i)
+    {
+      peers[i] = seg[i].peer; sb[i] = seg[i].send_bytes; rb[i] = seg[i].recv_bytes;
+      sp[i] = sb[i] > 0 ? seg[i].send : nullptr; rp[i] = rb[i] > 0 ? seg[i].recv : nullptr;
+    }
+    CFX_HIP(hipStreamSynchronize(cx.stream));
+    const int rc = c->device_fn(c->device_user, n, peers.data(), sp.data(), sb.data(), rp.data(), rb.data());
+    if (rc != 0) throw Error(CFX_ERR_RUNTIME, "cfx_dist: the device exchange callback failed");
     return;
   }
   // host-staged: device -> pinned host, the caller's callback (MPI / gloo), pinned host -> device.  The staging
@@ -275,6 +296,17 @@ int cfx_dist_comm_create_host(int world, int rank, cfx_host_exchange_fn fn, void
   require(out && fn && world >= 1 && rank >= 0 && rank < world, CFX_ERR_INVALID_ARGUMENT, "cfx_dist_comm_create_host: bad argument");
   auto c = std::make_unique<cfx_comm_s>();
   c->world = world; c->rank = rank; c->is_rccl = false; c->host_fn = fn; c->host_user = user;
+  *out = c.release();
+  CFX_API_END
+}
+
+int cfx_dist_comm_create_device(int world, int rank, cfx_device_exchange_fn fn, void* user, cfx_comm_t* out)
+{
+  CFX_API_BEGIN
+  ctx().ensure();
+  require(out && fn && world >= 1 && rank >= 0 && rank < world, CFX_ERR_INVALID_ARGUMENT, "cfx_dist_comm_create_device: bad argument");
+  auto c = std::make_unique<cfx_comm_s>();
+  c->world = world; c->rank = rank; c->is_rccl = false; c->device_fn = fn; c->device_user = user;
   *out = c.release();
   CFX_API_END
 }

@@ -128,13 +128,20 @@ class TransportError(RuntimeError):
     """RCCL did not come up on every rank and the caller asked for RCCL or nothing (strict)."""
 
 
-def decide_transport(backend_is_nccl: bool, rccl_ranks: int, world: int, strict: bool, why: str = "") -> str:
-    """What the ranks of a job exchange data through, decided together: 'rccl' when torch.distributed runs on nccl and
-    the library's RCCL communicator came up on every rank; else 'host-staged' (the library packs on the GPU, the bytes
-    travel through gloo) -- unless `strict`: a benchmark that is meant to measure xGMI must not quietly time a host
-    path, so a job on the nccl backend whose RCCL communicator is missing on some rank raises TransportError."""
+def decide_transport(backend_is_nccl: bool, rccl_ranks: int, world: int, strict: bool, why: str = "",
+                     torch_p2p: bool = True) -> str:
+    """What the ranks of a job exchange data through, decided together:
+    'rccl'        torch.distributed runs on nccl and the library's own RCCL communicator came up on every rank;
+    'rccl-torch'  it did not come up everywhere, but the job's nccl process group is there: the library hands its device
+                  segments to a callback that posts them as grouped isend / irecv on that group -- still RCCL over xGMI,
+                  driven by torch instead of by the library (`torch_p2p`, on unless CFX_DIST_TORCH_P2P=0);
+    'host-staged' the library packs on the GPU, the bytes travel through gloo -- a rehearsal on a gloo job, and never a
+                  silent fallback of an nccl job when `strict`: a benchmark that is meant to measure xGMI must not quietly
+                  time a host path, so such a job raises TransportError instead."""
     if backend_is_nccl and rccl_ranks == world:
         return "rccl"
+    if backend_is_nccl and torch_p2p:
+        return "rccl-torch"
     if backend_is_nccl and strict:
         raise TransportError(f"the RCCL communicator came up on {rccl_ranks} of {world} ranks ({why or 'another rank failed'}); "
                              "refusing the host-staged fallback (CFX_DIST_STRICT=1: set CFX_REHEARSE=1 for a one-GPU "
@@ -163,12 +170,29 @@ class DistComm:
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self._h = C.c_void_p()
         l = _lib.lib()
-        self.rccl = dist.get_backend(group) == "nccl"
+        backend_nccl = dist.get_backend(group) == "nccl"
+        self.rccl = backend_nccl
         self.rccl_ranks, self.fallback_reason = 0, ""
+        self._transport = "host-staged"
         host_group = group
+        # CFX_DIST_TRANSPORT: "torch" skips the library's own communicator (exchanges as isend / irecv of device tensors on the
+        # job's process group), "device" does the same on any backend (gloo: the callback stages through the host itself -- the
+        # one-GPU rehearsal of the device-callback path), "host" forces the host-staged mode
+        forced = os.environ.get("CFX_DIST_TRANSPORT", "")
+        torch_p2p = os.environ.get("CFX_DIST_TORCH_P2P", "1") != "0"
+        if forced == "host":
+            self.rccl = False
+            if backend_nccl:
+                if strict:
+                    raise TransportError("CFX_DIST_TRANSPORT=host on an nccl job with CFX_DIST_STRICT=1")
+                host_group = dist.new_group(backend="gloo")
+        elif forced in ("torch", "device"):
+            self.rccl = False
+            self._device_callback(group, via_host=not backend_nccl)
+            self.fallback_reason = f"CFX_DIST_TRANSPORT={forced}"
         if self.rccl:
-            # every rank must end up on the same transport: the ranks agree on whether RCCL came up everywhere,
-            # and fall back together to the host-staged mode over a gloo side group otherwise
+            # every rank must end up on the same transport: the ranks agree on whether RCCL came up everywhere, and move
+            # together to the next transport otherwise (decide_transport)
             ok, why = 1, ""
             buf = (C.c_char * 128)()
             if self.rank == 0 and l.cfx_dist_unique_id(buf) != 0:
@@ -186,17 +210,25 @@ class DistComm:
             dist.all_reduce(flag, op=dist.ReduceOp.SUM, group=group)
             self.rccl_ranks = int(flag.item())
             self.fallback_reason = why
-            # (raises TransportError on every rank alike when strict: the job ends instead of timing a host path)
-            if decide_transport(True, self.rccl_ranks, self.world, strict, why) != "rccl":
+            # (raises TransportError on every rank alike when strict and no RCCL path is left: the job ends instead of
+            # timing a host path)
+            decided = decide_transport(True, self.rccl_ranks, self.world, strict, why, torch_p2p)
+            if decided == "rccl":
+                self._transport = "rccl"
+            else:
                 import sys
-                print(f"cutfemx_amd.dist: RCCL communicator unavailable on some rank ({why or 'another rank'}); "
-                      "falling back to host-staged exchanges over gloo", file=sys.stderr)
+                print(f"cutfemx_amd.dist: the library's RCCL communicator is unavailable on some rank ({why or 'another rank'}); "
+                      + ("exchanging device buffers through torch.distributed's nccl group instead" if decided == "rccl-torch"
+                         else "falling back to host-staged exchanges over gloo"), file=sys.stderr)
                 if self._h:
                     l.cfx_dist_comm_destroy(self._h)
                     self._h = C.c_void_p()
                 self.rccl = False
-                host_group = dist.new_group(backend="gloo")
-        if not self.rccl:
+                if decided == "rccl-torch":
+                    self._device_callback(group, via_host=False)
+                else:
+                    host_group = dist.new_group(backend="gloo")
+        if not self.rccl and not self._h:
             group = host_group
             self.group = group
 
@@ -227,10 +259,51 @@ class DistComm:
             self._cb = _lib.HOST_EXCHANGE_FN(exchange)      # kept alive with the communicator
             _lib.check(l.cfx_dist_comm_create_host(self.world, self.rank, self._cb, None, C.byref(self._h)))
 
+    def _device_callback(self, group, via_host: bool):
+        """cfx_dist_comm_create_device with a callback that posts the library's device segments as one batch of isend /
+        irecv on `group` (nccl: RCCL over xGMI, driven by torch); via_host: the tensors travel as host copies (a gloo
+        group -- the one-GPU rehearsal of this path)."""
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def exchange(_user, n, peers, send, send_bytes, recv, recv_bytes):
+            try:
+                ops, back = [], []
+                for i in range(n):
+                    if send_bytes[i] > 0:
+                        t = as_torch(send[i], send_bytes[i], "uint8", dev)
+                        ops.append(dist.P2POp(dist.isend, t.cpu() if via_host else t, int(peers[i]), group))
+                    if recv_bytes[i] > 0:
+                        t = as_torch(recv[i], recv_bytes[i], "uint8", dev)
+                        if via_host:
+                            h = torch.empty(recv_bytes[i], dtype=torch.uint8)
+                            back.append((t, h))
+                            t = h
+                        ops.append(dist.P2POp(dist.irecv, t, int(peers[i]), group))
+                if ops:
+                    for req in dist.batch_isend_irecv(ops):
+                        req.wait()
+                for t, h in back:
+                    t.copy_(h)
+                # (the library's stream may not be torch's current one: everything has landed when this returns)
+                torch.cuda.current_stream().synchronize()
+                return 0
+            except Exception:            # (an exception must not cross the C frame)
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = self._lib.HOST_EXCHANGE_FN(exchange)     # (same signature; kept alive with the communicator)
+        self._lib.check(self._lib.lib().cfx_dist_comm_create_device(self.world, self.rank, self._cb, None, C.byref(self._h)))
+        self._transport = "host-callback-device" if via_host else "rccl-torch"
+
     @property
     def transport(self) -> str:
-        """'rccl' (point-to-point over xGMI) or 'host-staged' (pinned host buffers + gloo)."""
-        return "rccl" if self.rccl else "host-staged"
+        """'rccl' (the library's communicator: point-to-point over xGMI), 'rccl-torch' (the same links through
+        torch.distributed's nccl group), 'host-staged' (pinned host buffers + gloo)."""
+        return self._transport
 
     def _exchanges(self, triples):
         """[(peer, (send_lo, send_hi), (recv_lo, recv_hi)), ...] -> cfx_dist_exchange array (contiguous ranges)"""
@@ -455,7 +528,7 @@ class _DevView:
 
 def as_torch(ptr, n, dtype, device):
     import torch
-    typestr = {"int32": "<i4", "int64": "<i8", "float64": "<f8", "float32": "<f4", "int8": "|i1"}[dtype]
+    typestr = {"int32": "<i4", "int64": "<i8", "float64": "<f8", "float32": "<f4", "int8": "|i1", "uint8": "|u1"}[dtype]
     if n == 0:
         return torch.empty(0, dtype=getattr(torch, dtype), device=device)
     return torch.as_tensor(_DevView(ptr, n, typestr), device=device)

@@ -622,7 +622,8 @@ int cfx_deactivate_outside_c64(cfx_active_t domain, cfx_pattern_t pattern, float
  * A communicator is either RCCL (cfx_dist_unique_id on one rank, the 128 bytes handed to all ranks by the launcher's
  * own channel -- MPI_Bcast, torch.distributed, a file -- then cfx_dist_comm_create on every rank after cfx_init on its
  * GPU; librccl.so.1 is loaded on first use) or host-staged (cfx_dist_comm_create_host: the library moves the slices
- * through pinned host memory and the caller's callback -- MPI_Sendrecv, gloo -- moves the bytes). */
+ * through pinned host memory and the caller's callback -- MPI_Sendrecv, gloo -- moves the bytes) or the caller's own
+ * device transport (cfx_dist_comm_create_device: the callback is handed the device segments). */
 typedef struct cfx_comm_s* cfx_comm_t;
 #define CFX_DIST_ID_BYTES 128 /* sizeof(ncclUniqueId) */
 /* n messages out and n in: to / from peers[i], send[i] / recv[i] are host buffers of send_bytes[i] / recv_bytes[i] bytes
@@ -632,6 +633,14 @@ typedef int (*cfx_host_exchange_fn)(void* user, int n, const int32_t* peers, con
 int cfx_dist_unique_id(char id[CFX_DIST_ID_BYTES]);
 int cfx_dist_comm_create(int world, int rank, const char id[CFX_DIST_ID_BYTES], cfx_comm_t* out);
 int cfx_dist_comm_create_host(int world, int rank, cfx_host_exchange_fn fn, void* user, cfx_comm_t* out);
+/* The caller's own GPU-to-GPU transport (a GPU-aware MPI_Isend / MPI_Irecv pair per peer, the launcher's RCCL process
+ * group -- torch.distributed on the nccl backend): same contract as cfx_host_exchange_fn with send[i] / recv[i] DEVICE
+ * buffers.  The library's stream has been drained when the callback runs; every transfer must have completed (or be
+ * ordered before later work on the library's stream) when it returns.  Replaces MPI neighbourhood exchanges of
+ * dolfinx::common::Scatterer (python/demo/demo_poisson.py:51-54,157) for callers that already hold a communicator. */
+typedef int (*cfx_device_exchange_fn)(void* user, int n, const int32_t* peers, const void* const* send,
+                                      const int64_t* send_bytes, void* const* recv, const int64_t* recv_bytes);
+int cfx_dist_comm_create_device(int world, int rank, cfx_device_exchange_fn fn, void* user, cfx_comm_t* out);
 int cfx_dist_comm_info(cfx_comm_t comm, int* world, int* rank, int* is_rccl);
 int cfx_dist_comm_destroy(cfx_comm_t comm);
 /* What this rank sends to and receives from one peer in one exchange step, in elements of the array: a contiguous

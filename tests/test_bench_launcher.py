@@ -97,9 +97,14 @@ def test_transport_decision_refuses_a_silent_fallback():
     assert decide_transport(True, 8, 8, strict=False) == "rccl"
     assert decide_transport(False, 0, 2, strict=False) == "host-staged"      # a gloo rehearsal: host-staged by design
     assert decide_transport(False, 0, 2, strict=True) == "host-staged"
-    assert decide_transport(True, 7, 8, strict=False, why="rank 3: ncclCommInitRank failed") == "host-staged"
+    # the library's communicator missing on a rank of an nccl job: the job's own nccl group carries the device buffers
+    # (still RCCL over xGMI), strict or not ...
+    assert decide_transport(True, 7, 8, strict=True, why="rank 3: ncclCommInitRank failed") == "rccl-torch"
+    assert decide_transport(True, 0, 8, strict=False) == "rccl-torch"
+    # ... and with that path switched off (CFX_DIST_TORCH_P2P=0) a strict job ends instead of timing a host path
+    assert decide_transport(True, 7, 8, strict=False, why="rank 3: ncclCommInitRank failed", torch_p2p=False) == "host-staged"
     with pytest.raises(TransportError, match="7 of 8 ranks"):
-        decide_transport(True, 7, 8, strict=True, why="rank 3: ncclCommInitRank failed")
+        decide_transport(True, 7, 8, strict=True, why="rank 3: ncclCommInitRank failed", torch_p2p=False)
 
 
 def test_scale_line_names_its_transport():

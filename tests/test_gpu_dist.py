@@ -16,6 +16,9 @@ def _worker(rank, world, port, n, q, mode):
     sys.path.insert(0, str(ROOT))
     sys.path.insert(0, str(ROOT / "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFX_DEVICE="0")
+    if mode.endswith("+device"):
+        os.environ["CFX_DIST_TRANSPORT"] = "device"
+        mode = mode.split("+")[0]
     import scipy.sparse as sp
     import torch
     import torch.distributed as dist
@@ -56,13 +59,13 @@ def _worker(rank, world, port, n, q, mode):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["owner", "reduce"])
+@pytest.mark.parametrize("mode", ["owner", "reduce", "owner+device"])
 def test_two_ranks_on_one_gpu_match_serial(oracle, mode):
     import torch.multiprocessing as mp
     n = 16
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 2000) + (7 if mode == "owner" else 0)
+    port = 29600 + (os.getpid() % 2000) + {"owner": 7, "reduce": 0, "owner+device": 13}[mode]
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q, mode)) for r in range(2)]
     for p in procs:
         p.start()
@@ -82,11 +85,14 @@ def test_two_ranks_on_one_gpu_match_serial(oracle, mode):
     assert total_active == gm.nnodes - gref["inactive"].size
 
 
-def _prim_worker(rank, world, port, q):
-    """cfx_dist_* primitives between two ranks on one card (host-staged transport): contiguous ranges and index
-    lists, copy / add / or, and the matrix row exchange with its size check."""
+def _prim_worker(rank, world, port, q, transport="host"):
+    """cfx_dist_* primitives between two ranks on one card (host-staged transport, or the device-callback transport with
+    a callback that stages through the host itself): contiguous ranges and index lists, copy / add / or, and the matrix
+    row exchange with its size check."""
     sys.path.insert(0, str(ROOT))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CFX_DEVICE="0")
+    if transport == "device":
+        os.environ["CFX_DIST_TRANSPORT"] = "device"
     import torch
     import torch.distributed as dist
 
@@ -96,6 +102,7 @@ def _prim_worker(rank, world, port, q):
         dev = torch.device("cuda", 0)
         comm = DistComm()
         assert not comm.rccl and comm.world == 2
+        assert comm.transport == ("host-callback-device" if transport == "device" else "host-staged")
         peer = 1 - rank
         ok = True
         # scatter_forward, contiguous: my tail [90, 100) <- the peer's head [0, 10)
@@ -129,12 +136,15 @@ def _prim_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_dist_primitives_two_ranks_host_staged():
+@pytest.mark.parametrize("transport", ["host", "device"])
+def test_dist_primitives_two_ranks_host_staged(transport):
+    """(device: cfx_dist_comm_create_device -- the library hands DEVICE segments to the caller's transport; on the real
+    multi-GPU job that callback posts them on torch.distributed's nccl group, here it copies through the host)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29100 + (os.getpid() % 400)
-    procs = [ctx.Process(target=_prim_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29100 + (os.getpid() % 400) + (500 if transport == "device" else 0)
+    procs = [ctx.Process(target=_prim_worker, args=(r, 2, port, q, transport)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in procs]

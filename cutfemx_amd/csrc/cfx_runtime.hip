@@ -146,6 +146,10 @@ struct StepHistory
   std::vector<std::string> names;
   std::vector<int64_t> values;
   bool valid = false;
+  // the valid record before this one (same sites): a count that grew from there to `values` is expected to grow on --
+  // a front that advances steadily outruns a fixed 3 % margin every few steps otherwise
+  std::vector<std::string> before_names;
+  std::vector<int64_t> before_values;
 };
 struct StepState
 {
@@ -409,7 +413,16 @@ CountPlan::CountPlan(int n_, const char* const* names_, const CountSource* src_)
     if (J.mode[k] == kCountSizeClass)
       cell->cap = prev <= 32 ? 32 : (prev <= 64 ? 64 : (prev <= 128 ? 128 : (prev <= 256 ? 256 : 512)));
     else
-      cell->cap = (J.mode[k] == kCountMustEqual || prev == 0) ? prev : (int64_t)((double)prev * g_margin) + g_slack;
+    {
+      // linear trend over the last two valid steps (never below the last count itself)
+      int64_t expect = prev;
+      if (h.before_values.size() == h.values.size() && h.before_names[st.cursor + k] == names[k])
+      {
+        const int64_t grown = prev - h.before_values[st.cursor + k];
+        if (grown > 0 && h.before_values[st.cursor + k] > 0) expect = prev + std::min(grown, prev);
+      }
+      cell->cap = (J.mode[k] == kCountMustEqual || prev == 0) ? prev : (int64_t)((double)expect * g_margin) + g_slack;
+    }
     cell->resolved = false;
     cell->hint = prev;
     J.cap[k] = cell->cap; J.slot[k] = cell->slot;
@@ -1255,6 +1268,7 @@ int cfx_step_end(int* redo, int64_t* published, int64_t* read_back)
     st.values[p.index] = host[2 * p.cell->slot + 1];
   }
   StepHistory& h = histories()[st.key];
+  if (h.valid) { h.before_names = std::move(h.names); h.before_values = std::move(h.values); } // (a void step's record is not kept)
   h.names = st.names;
   h.values = st.values;
   h.valid = !poisoned; // a void step: the repeat sizes everything by read-backs and records afresh

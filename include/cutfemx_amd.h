@@ -190,7 +190,8 @@ int cfx_overlap_end(void);
  * create_matrix -> assemble, every time step).  The sizes of the data-dependent lists of such a step (located cells,
  * rule points, ghost facets, row classes, nnz ...) change little from one step to the next, so between
  * cfx_step_begin(key) and cfx_step_end() the library does not read them back where they are produced: buffers and
- * grids are sized by the same site's count in the previous step of the loop `key` (x 1.03125 + 256 by default), the
+ * grids are sized by the same site's count in the previous step of the loop `key` (x 1.03125 + 256 by default; a count that grew
+ * over the last two valid steps is first extrapolated by the same amount), the
  * exact lengths stay in HBM where the kernels read them, and cfx_step_end() fetches all of them -- and the error
  * words of the assembly calls -- in ONE read-back.  The first step of a key (no history) reads every size back as
  * outside a step.  *redo = 1: some count did not fit its capacity; every kernel after that point did nothing, the

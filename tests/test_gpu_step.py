@@ -121,6 +121,35 @@ def test_a_count_that_does_not_fit_voids_the_step_and_the_repeat_is_exact(oracle
         cfx.set_step_margin()
 
 
+def test_steady_growth_is_followed_by_the_capacities(oracle):
+    """A front that advances steadily (counts + 5 - 7 % per step) outruns the 3 % margin at every step; the capacities
+    follow the trend of the last two valid steps, so only the first speculative step (no trend yet) is repeated."""
+    import os
+
+    import torch
+
+    import cutfemx_amd as cfx
+    om, mesh, V, xt, phi, f = moving_problem(oracle, 3, 24)
+    state = {"cd": None, "b": torch.zeros(om.nnodes, device="cuda", dtype=torch.float64)}
+    key = "test-growth"
+    cfx.forget_step_history(key)
+    try:
+        cfx.set_step_margin(1.03125, 8)     # (the default slack of 256 entries would carry a mesh this small by itself)
+        passes = []
+        for k in range(8):
+            phi.copy_(torch.linalg.norm(xt - centre_of(3, 0), dim=1) - (0.25 + 0.006 * k))
+            state["b"].zero_()
+            info = {}
+            system, A, b, dom = cfx.run_step(lambda: one_step(V, state["cd"], f, state), key=key, info=info)
+            passes.append(info["passes"])
+        check_against_oracle(oracle, om, phi, state["cd"], system, A, b, dom)
+        if os.environ.get("CFX_STEP_SPECULATE") != "0":
+            assert passes[:2] == [1, 2], passes       # sized by read-backs, then the margin alone does not fit
+            assert passes[2:] == [1] * 6, passes      # from the third step on the trend carries the growth
+    finally:
+        cfx.set_step_margin()
+
+
 def test_sizes_read_inside_a_step_are_capacities_and_resolve_on_demand(oracle):
     import torch
 

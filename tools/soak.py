@@ -66,5 +66,10 @@ for k in range(steps):
     if k % every == every - 1:
         torch.cuda.synchronize()
         m = _lib.memory_stats()
-        print(f"step {k + 1:5d}: in_use {m['in_use'] / 2**20:9.1f} MiB cached {m['cached'] / 2**20:9.1f} MiB peak {m['peak'] / 2**20:9.1f} MiB "
+        try:
+            import psutil
+            rss = psutil.Process().memory_info().rss / 2**20
+        except ImportError:
+            rss = float("nan")
+        print(f"step {k + 1:5d}: host RSS {rss:8.1f} MiB in_use {m['in_use'] / 2**20:9.1f} MiB cached {m['cached'] / 2**20:9.1f} MiB peak {m['peak'] / 2**20:9.1f} MiB "
               f"repeated steps so far {redo} nnz {nnz} nnz(P2) {nnz2} {1e3 * (time.perf_counter() - t0) / (k + 1):.3f} ms/step", flush=True)

@@ -496,6 +496,18 @@ int64_t& sync_counter(); // host round trips so far (cfx_runtime.hip), reported 
 
 void* pinned_scratch(); // 256 B of page-locked host memory (cfx_runtime.hip): target of the size read-backs
 
+// A value read back inside a SPECULATIVE step is only meaningful while the step is not void: once a count did not fit,
+// every kernel after it did nothing and what the host reads -- a total of lengths nobody wrote, say -- is garbage that
+// must not size anything (a 3 GB `nnz` and a fault followed, tests/test_gpu_step.py: the long loop).  Every read-back
+// of such a step therefore brings the poison word along in the same round trip and throws CFX_ERR_STEP_VOID when it is
+// set: the call returns that status, the caller ends the step and repeats it.
+struct StepVoidGuard
+{
+  int64_t* host = nullptr; // pinned word (null: no speculative step open)
+  StepVoidGuard();         // queues the copy of the poison word on ctx().stream (cfx_runtime.hip)
+  void check() const;      // after the synchronisation: throws Error(CFX_ERR_STEP_VOID) when the step is void
+};
+
 template <typename T>
 inline T read_scalar(const T* dev)
 {
@@ -503,10 +515,12 @@ inline T read_scalar(const T* dev)
   static_assert(sizeof(T) <= 256, "read_scalar reads small values");
   T* h = static_cast<T*>(pinned_scratch());
   CFX_HIP(hipMemcpyAsync(h, dev, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  const StepVoidGuard guard;
   CFX_HIP(hipStreamSynchronize(ctx().stream));
   const T v = *h;
   ++sync_counter();
   if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back after %s\n", ctx().last_launch);
+  guard.check();
   return v;
 }
 
@@ -518,10 +532,12 @@ inline void read_two(const T* dev_a, const T* dev_b, T& a, T& b)
   T* h = static_cast<T*>(pinned_scratch());
   CFX_HIP(hipMemcpyAsync(h, dev_a, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
   CFX_HIP(hipMemcpyAsync(h + 1, dev_b, sizeof(T), hipMemcpyDeviceToHost, ctx().stream));
+  const StepVoidGuard guard;
   CFX_HIP(hipStreamSynchronize(ctx().stream));
   a = h[0]; b = h[1];
   ++sync_counter();
   if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back after %s\n", ctx().last_launch);
+  guard.check();
 }
 
 template <typename T>
@@ -531,7 +547,9 @@ inline std::vector<T> download(const T* dev, int64_t n)
   if (n > 0)
   {
     CFX_HIP(hipMemcpyAsync(v.data(), dev, sizeof(T) * (size_t)n, hipMemcpyDeviceToHost, ctx().stream));
+    const StepVoidGuard guard;
     CFX_HIP(hipStreamSynchronize(ctx().stream));
+    guard.check();
   }
   return v;
 }

@@ -359,6 +359,25 @@ int error_in_step(int code)
 }
 
 bool step_speculative() { return step().active && step().spec && !ctx().overlap; }
+
+StepVoidGuard::StepVoidGuard()
+{
+  if (!step().active || !step().spec) return;
+  static int64_t* word = []() {
+    void* q = nullptr;
+    CFX_HIP(hipHostMalloc(&q, 64, hipHostMallocDefault));
+    return static_cast<int64_t*>(q);
+  }();
+  host = word;
+  *host = 0;
+  CFX_HIP(hipMemcpyAsync(host, count_pool(), sizeof(int64_t), hipMemcpyDeviceToHost, ctx().stream));
+}
+void StepVoidGuard::check() const
+{
+  if (host && *host != 0)
+    throw Error(CFX_ERR_STEP_VOID, "the step is void (a count did not fit the capacity taken from the previous step): a size "
+                                   "read back after that point means nothing -- end the step and repeat it");
+}
 void step_on_void(const void* owner, std::function<void()> fn)
 {
   if (step().active && step().spec) step().undo.push_back({owner, std::move(fn)});
@@ -1307,6 +1326,11 @@ int cfx_step_resolve(void)
     CFX_HIP(hipStreamSynchronize(ctx().main_stream));
     ++sync_counter();
     if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back by cfx_step_resolve\n");
+    // (a void step: the published slots were zeroed and later totals mean nothing -- nothing is resolved, the caller ends
+    // the step and repeats it)
+    if (st.spec && host[0] != 0)
+      throw Error(CFX_ERR_STEP_VOID, "the step is void (a count did not fit the capacity taken from the previous step): end it "
+                                     "and repeat it");
     for (auto& p : st.pending)
     {
       if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }

@@ -150,6 +150,47 @@ def test_steady_growth_is_followed_by_the_capacities(oracle):
         cfx.set_step_margin()
 
 
+def test_a_long_loop_neither_leaks_nor_keeps_repeating(oracle):
+    """The moving-domain loop for 120 steps (the sphere travels and breathes; tools/soak.py is the long form): the engine's
+    HBM (handed out + cached blocks) does not grow between step 80 and step 120, repeated steps stay the exception, the last step is exact.
+    (This loop found a void step whose garbage read-backs sized a 3 GB matrix: on a mesh this small the list of plain
+    rows is empty at times, an empty list has capacity 0, and the step in which it fills up is void from there on --
+    every size read back after that point now comes with the poison word and ends the pass, cfx::StepVoidGuard.)"""
+    import math
+    import os
+
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import _lib
+    om, mesh, V, xt, phi, f = moving_problem(oracle, 3, 12)
+    state = {"cd": None, "b": torch.zeros(om.nnodes, device="cuda", dtype=torch.float64)}
+    key = "test-soak"
+    cfx.forget_step_history(key)
+    repeated, in_use = 0, {}
+    for k in range(120):
+        t = 2.0 * math.pi * (k % 40) / 40.0      # (period 40: steps 39 and 119 see the same geometry)
+        c = torch.tensor([0.45 + 0.10 * math.sin(3.0 * t), 0.45, 0.5], device="cuda", dtype=torch.float64)
+        phi.copy_(torch.linalg.norm(xt - c, dim=1) - (0.27 + 0.04 * math.sin(t)))
+        state["b"].zero_()
+        info = {}
+        system, A, b, dom = cfx.run_step(lambda: one_step(V, state["cd"], f, state), key=key, info=info)
+        repeated += info["passes"] - 1
+        if k in (39, 79, 119):
+            last = (system, A, b, dom)
+            import gc
+            gc.collect()                  # (handles of earlier steps and tests that wait in reference cycles)
+            torch.cuda.synchronize()
+            m = _lib.memory_stats()
+            in_use[k] = m["in_use"] + m["cached"]     # (handed out + cached: a block may serve a smaller request)
+        if k != 119:
+            del system, A, b, dom
+    check_against_oracle(oracle, om, phi, state["cd"], *last)
+    assert in_use[119] <= 1.1 * in_use[79] + (1 << 20), in_use      # same geometry at steps 39, 79, 119
+    if os.environ.get("CFX_STEP_SPECULATE") != "0":
+        assert repeated <= 30, repeated      # (a 12^3 mesh: counts of a few hundred, lists that empty and fill up again)
+
+
 def test_sizes_read_inside_a_step_are_capacities_and_resolve_on_demand(oracle):
     import torch
 

@@ -65,3 +65,79 @@ def test_degenerate_level_sets_match_oracle(oracle, tdim, n, seed):
         assert np.all(np.isfinite(R.weights)) and np.all(R.weights >= 0.0)
         assert np.max(np.abs(R.weights - want.weights), initial=0.0) <= RTOL * max(np.max(want.weights, initial=0.0), 1e-300)
         assert np.max(np.abs(R.points - want.points), initial=0.0) < 1e-13
+
+
+@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 8, 1, 1), (2, 16, 1, 1), (3, 5, 2, 1), (3, 6, 1, 3)])
+def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree, bs):
+    """Differential run (tools/soak_fuzz.py is the long form): a level set that wanders, breathes, leaves the mesh and
+    swallows it; every step is run as a sync-free step (sizes from the previous step, voided and repeated when they do
+    not fit, python/demo/demo_moving_poisson.py:53-90) and as the plain sequence -- the CSR pattern must agree bit for
+    bit, values / right-hand side / deactivated rows to 1e-12.  A domain without cells is refused as the reference does
+    (deactivate.h:150-155) in both forms."""
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    fem = cfx.fem
+    rng = np.random.default_rng(17 * tdim + n)
+    x, conn = cfx.box_mesh_arrays(tdim, n)
+    mesh = cfx.Mesh.from_arrays(tdim, x, conn)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    V = Vphi if (degree == 1 and bs == 1) else cfx.FunctionSpace(mesh, degree, bs=bs)
+    xt = torch.tensor(x[:, :tdim].copy(), device="cuda")
+    phi = torch.empty(x.shape[0], device="cuda", dtype=torch.float64)
+    f = cfx.Function(Vphi, phi)
+
+    def one(state):
+        if state.get("cd") is None:
+            state["cd"] = cfx.cut(f)
+        else:
+            cfx.update(state["cd"])
+        cd = state["cd"]
+        if bs == 1:
+            s = poisson.build_forms(V, cd, order=3)
+            a, L = s.a, s.L
+        else:
+            inside = cfx.locate_entities_device(cd, "phi<0")
+            vol = cfx.runtime_quadrature(cd, "phi<0", 2)
+            ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+            ints = [fem.Integral(fem.ELASTICITY, cells=inside, rules=vol, params=(1.0e3, 0.3), qdegree=0)]
+            if ghost.size > 0:
+                ints.append(fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(5.0,), qdegree=0))
+            a, L = fem.form(ints, V), None
+        A = fem.create_matrix(a)
+        fem.assemble_matrix(a, A=A)
+        b = fem.assemble_vector(L) if L is not None else None
+        return A, b, fem.deactivate_outside(A, b, fem.active_domain(a))
+
+    key = f"test-fuzz-{tdim}-{n}-{degree}-{bs}"
+    cfx.forget_step_history(key)
+    sa, sb = {"cd": None}, {"cd": None}
+    c, R, compared, refused = np.full(tdim, 0.5), 0.3, 0, 0
+    for k in range(48):
+        c = np.clip(c + rng.normal(0.0, 0.04, tdim) + 0.05 * (0.5 - c), 0.0, 1.0)
+        R = float(np.clip(R + rng.normal(0.0, 0.04) + 0.05 * (0.3 - R), 0.05, 0.9))
+        if k % 17 == 16:
+            R = -0.05          # no domain at all
+        if k % 23 == 22:
+            R = 2.0            # the whole mesh inside: no cut cell
+        phi.copy_(torch.linalg.norm(xt - torch.tensor(c, device="cuda"), dim=1) - R)
+        try:
+            A1, b1, d1 = cfx.run_step(lambda: one(sa), key=key)
+        except ValueError as e:
+            assert "no active background cells" in str(e) and float(phi.min()) > 0.0, (k, R, str(e))
+            with pytest.raises(ValueError, match="no active background cells"):
+                one(sb)
+            sa, sb = {"cd": None}, {"cd": None}
+            cfx.forget_step_history(key)
+            refused += 1
+            continue
+        A2, b2, d2 = one(sb)
+        assert A1.nnz == A2.nnz and np.array_equal(A1.indptr, A2.indptr) and np.array_equal(A1.indices, A2.indices), (k, R)
+        assert rel_err(A1.data, A2.data) < RTOL, (k, R)
+        if b1 is not None:
+            assert rel_err(np.asarray(b1), np.asarray(b2)) < RTOL, (k, R)
+        assert np.array_equal(d1.inactive_dofs, d2.inactive_dofs), (k, R)
+        compared += 1
+        del A1, b1, d1, A2, b2, d2
+    assert compared >= 24 and refused >= 2, (compared, refused)

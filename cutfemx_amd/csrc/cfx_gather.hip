@@ -2837,30 +2837,42 @@ __global__ void __launch_bounds__(kWave, INLINE == 1 ? 2 : CFX_BLOCK_WAVES) asse
 }
 
 // la::MatrixCSR::set_value(0) restricted to the rows no gather kernel writes: the inactive rows (their diagonal entry)
+// (nnz_d: the pattern's entry count, possibly still in HBM -- 0 in a void step, whose marks and row pointers are not
+// this step's: nothing is touched then, and never anything at or beyond nnz)
 __global__ void __launch_bounds__(kBlock) zero_inactive_rows_kernel(int64_t nrows, int bs, const uint8_t* __restrict__ rowmark,
-                                                                    const int64_t* __restrict__ indptr, double* __restrict__ values)
+                                                                    const int64_t* __restrict__ indptr, double* __restrict__ values,
+                                                                    DevN nnz_d)
 {
+  const int64_t nnz = dev_n(nnz_d);
   const int64_t R = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (R >= nrows || rowmark[R / bs]) return;
-  for (int64_t k = indptr[R]; k < indptr[R + 1]; ++k) values[k] = 0.0;
+  if (R >= nrows || nnz == 0 || rowmark[R / bs]) return;
+  const int64_t e1 = min(indptr[R + 1], nnz);
+  for (int64_t k = max(indptr[R], (int64_t)0); k < e1; ++k) values[k] = 0.0;
 }
 
 // ... scalar spaces with the plan's per-tile row counts: a tile of kByteTile rows without an active row is kByteTile
 // consecutive diagonal entries -- one contiguous fill from the tile's first row pointer, no per-row reads
 __global__ void __launch_bounds__(kBlock) zero_inactive_tiles_kernel(int64_t nrows, const uint8_t* __restrict__ rowmark,
                                                                      const int64_t* __restrict__ tile_counts,
-                                                                     const int64_t* __restrict__ indptr, double* __restrict__ values)
+                                                                     const int64_t* __restrict__ indptr, double* __restrict__ values,
+                                                                     DevN nnz_d)
 {
+  const int64_t nnz = dev_n(nnz_d);
+  if (nnz == 0) return;
   const int64_t r0 = (int64_t)blockIdx.x * kByteTile;
   const int n = (int)min((int64_t)kByteTile, nrows - r0);
   if (tile_counts[blockIdx.x] == 0)
   {
-    block_fill_run(values + indptr[r0], n, 0.0);
+    const int64_t e0 = indptr[r0];
+    if (e0 >= 0 && e0 + n <= nnz) block_fill_run(values + e0, n, 0.0);
     return;
   }
   for (int k = threadIdx.x; k < n; k += kBlock)
     if (!rowmark[r0 + k])
-      for (int64_t e = indptr[r0 + k]; e < indptr[r0 + k + 1]; ++e) values[e] = 0.0;
+    {
+      const int64_t e1 = min(indptr[r0 + k + 1], nnz);
+      for (int64_t e = max(indptr[r0 + k], (int64_t)0); e < e1; ++e) values[e] = 0.0;
+    }
 }
 
 // stage 2, linear forms: b[r] += sum over the marked incident cells of be[local row]
@@ -4049,10 +4061,10 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
           const int64_t nr = P->nrows, ntiles = (nr + kByteTile - 1) / kByteTile;
           if (plan.row_tile_counts.n == ntiles)
             launch("zero_inactive_rows", zero_inactive_tiles_kernel, dim3((unsigned)ntiles), dim3(kBlock), 0, nr, plan.rowmark.p,
-                   plan.row_tile_counts.p, P->indptr.p, values);
+                   plan.row_tile_counts.p, P->indptr.p, values, P->nnz.devn());
           else
             launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(nr), dim3(kBlock), 0, nr, 1, plan.rowmark.p,
-                   P->indptr.p, values);
+                   P->indptr.p, values, P->nnz.devn());
         }
         // rows laid out as stencil subsets by build_pattern from this very plan: slots by popcount
         const Stencil& stn = a->V->stencil;
@@ -4148,7 +4160,7 @@ int run_matrix(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const int8_t*
       if (!lazy_zero) fill_all();
       else
         launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, 1, plan.rowmark.p,
-               P->indptr.p, values);
+               P->indptr.p, values, P->nnz.devn());
       // degree 2: (a) the uncut items of every row with the lean kernel, short rows (<= 64 columns:
       // the edge dofs, ~5 cells each) 8 lanes per row, long rows 16; (b) rule + facet items of the
       // interface rows with the full kernel.  Needs the row partition made with the pattern.
@@ -4310,7 +4322,7 @@ int run_matrix_block(cfx_form_s* a, cfx_pattern_s* P, const int8_t* bc0, const i
     // entries written by nobody -- fill everything)
     if (P->built_plan == plan0.serial)
       launch("zero_inactive_rows", zero_inactive_rows_kernel, grid_for(P->nrows), dim3(kBlock), 0, P->nrows, BS, plan0.rowmark.p,
-             P->indptr.p, values);
+             P->indptr.p, values, P->nnz.devn());
     else
       dev_fill(values, 0, sizeof(double) * (size_t)P->nnz.value());
   }

@@ -67,7 +67,7 @@ def test_degenerate_level_sets_match_oracle(oracle, tdim, n, seed):
         assert np.max(np.abs(R.points - want.points), initial=0.0) < 1e-13
 
 
-@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 8, 1, 1), (2, 16, 1, 1), (3, 5, 2, 1), (3, 6, 1, 3)])
+@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 8, 1, 1), (2, 16, 1, 1), (3, 5, 2, 1), (3, 6, 1, 3), (3, 40, 1, 1), (3, 20, 2, 1)])
 def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree, bs):
     """Differential run (tools/soak_fuzz.py is the long form): a level set that wanders, breathes, leaves the mesh and
     swallows it; every step is run as a sync-free step (sizes from the previous step, voided and repeated when they do

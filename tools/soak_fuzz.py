@@ -2,7 +2,7 @@
 """Differential soak: the same moving-domain step run (a) as a sync-free step (cutfemx_amd.run_step) and (b) as the plain
 sequence with every size read back, on small meshes with a level set that wanders, breathes, leaves the mesh (no domain
 at all) and swallows it (no cut cell) -- spaces P1, P2 and P1-vector, 2-D and 3-D.  Every step compares nnz, indptr,
-indices bit for bit and values / b to 1e-12.  usage: python tools/soak_fuzz.py [steps] [seed]"""
+indices bit for bit and values / b to 1e-12.  usage: python tools/soak_fuzz.py [steps] [seed] [big]"""
 import math, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -43,16 +43,25 @@ def one(V, f, kind, state):
 
 
 bad = 0
-for tdim, n, degree, bs, kind in [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
-                                  (2, 14, 2, 1, "poisson")]:
+big = len(sys.argv) > 3 and sys.argv[3] == "big"    # larger meshes: the row tiles, the culled classification and the bulk rows engage
+for tdim, n, degree, bs, kind in [(3, 48, 1, 1, "poisson"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
+                                  (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled")]:
     x, conn = cfx.box_mesh_arrays(tdim, n)
+    if kind.endswith("+scrambled"):
+        # no locality left: vertices and cells renumbered at random, local vertex order of every cell permuted
+        kind = kind.split("+")[0]
+        pv = rng.permutation(x.shape[0])
+        inv = np.empty_like(pv); inv[pv] = np.arange(pv.size)
+        x = x[pv]
+        conn = inv[conn][rng.permutation(conn.shape[0])]
+        conn = np.ascontiguousarray(np.take_along_axis(conn, rng.permuted(np.tile(np.arange(tdim + 1), (conn.shape[0], 1)), axis=1), axis=1)).astype(np.int32)
     mesh = cfx.Mesh.from_arrays(tdim, x, conn)
     Vphi = cfx.FunctionSpace(mesh, 1)
     V = Vphi if (degree == 1 and bs == 1) else cfx.FunctionSpace(mesh, degree, bs=bs)
     xt = torch.tensor(x[:, :tdim].copy(), device=dev)
     phi = torch.empty(x.shape[0], device=dev, dtype=torch.float64)
     f = cfx.Function(Vphi, phi)
-    key = f"fuzz-{tdim}-{n}-{degree}-{bs}"
+    key = f"fuzz-{tdim}-{n}-{degree}-{bs}-{kind}"
     cfx.forget_step_history(key)
     sa, sb = {"cd": None}, {"cd": None}
     c, R, redo, empty, t0 = np.full(tdim, 0.5), 0.3, 0, 0, time.perf_counter()

@@ -44,7 +44,8 @@ def one(V, f, kind, state):
 
 bad = 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"    # larger meshes: the row tiles, the culled classification and the bulk rows engage
-for tdim, n, degree, bs, kind in [(3, 48, 1, 1, "poisson"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
+huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count / scan / write triples (> 512 tiles per site)
+for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
                                   (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled")]:
     x, conn = cfx.box_mesh_arrays(tdim, n)
     if kind.endswith("+scrambled"):

@@ -43,6 +43,8 @@ def one(V, f, kind, state):
 
 
 bad = 0
+if os.environ.get("CFX_FUZZ_MARGIN"):      # e.g. 0.97: capacities BELOW the previous counts -- nearly every speculative pass is void
+    cfx.set_step_margin(float(os.environ["CFX_FUZZ_MARGIN"]), 0)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"    # larger meshes: the row tiles, the culled classification and the bulk rows engage
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count / scan / write triples (> 512 tiles per site)
 for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),

@@ -552,3 +552,45 @@ def test_gpu_mixed_space_gives_the_monolithic_matrix_in_the_callers_numbering(or
     rc = _lib.lib().cfx_csr_block_merge(1, 1, ptrs[0], ptrs[1], ptrs[2], nr1, nr1, C.byref(o[0]), C.byref(o[1]), C.byref(o[2]),
                                         C.byref(nnz_out))
     assert rc != 0 and b"ascend" in _lib.lib().cfx_last_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_csr_permute_random_matrices_match_scipy(seed):
+    """cfx_csr_permute on random CSR matrices (empty rows, rows of up to 2048 entries, rectangular shapes, random row and
+    column bijections) against scipy: the permuted matrix with ascending columns, bit for bit."""
+    import scipy.sparse as sp
+    import torch
+
+    from cutfemx_amd import fem
+    rng = np.random.default_rng(seed)
+    nrows, ncols = int(rng.integers(1, 500)), int(rng.integers(1, 3000))
+    lens = rng.integers(0, min(ncols, 64) + 1, size=nrows)
+    lens[rng.integers(0, nrows)] = min(ncols, 2048)                      # one row at the limit of the LDS sort
+    lens[rng.integers(0, nrows, size=max(nrows // 5, 1))] = 0            # empty rows
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(ncols, size=int(l), replace=False)) for l in lens] + [np.zeros(0, np.int64)]).astype(np.int32)
+    data = rng.standard_normal(indices.size)
+    dev = torch.device("cuda", 0)
+    t_ip, t_ix, t_va = (torch.tensor(indptr, device=dev), torch.tensor(indices, device=dev),
+                        torch.tensor(data, device=dev))
+
+    class Borrowed(fem.MergedCSR):      # arrays owned by torch: nothing to hand back to the engine
+        def __del__(self):
+            pass
+
+    A = Borrowed(t_ip.data_ptr(), t_ix.data_ptr(), t_va.data_ptr(), indices.size, nrows, ncols, np.zeros(1, np.int64), np.zeros(1, np.int64))
+    rp, cp = rng.permutation(nrows).astype(np.int32), rng.permutation(ncols).astype(np.int32)
+    B = fem.permute_csr(A, rp, cp)
+    rows = np.repeat(np.arange(nrows), lens)
+    want = sp.coo_matrix((data, (rp[rows], cp[indices])), shape=(nrows, ncols)).tocsr()
+    want.sort_indices()
+    assert np.array_equal(B.indptr, want.indptr.astype(np.int64))
+    assert np.array_equal(B.indices, want.indices.astype(np.int32))
+    assert np.array_equal(B.data, want.data)
+    # a map that is not a bijection is refused
+    bad = rp.copy()
+    bad[0] = bad[-1] if nrows > 1 else 1
+    if nrows > 1:
+        with pytest.raises((ValueError, RuntimeError)):
+            fem.permute_csr(A, bad, cp)

@@ -141,3 +141,62 @@ def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree,
         compared += 1
         del A1, b1, d1, A2, b2, d2
     assert compared >= 24 and refused >= 2, (compared, refused)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("CFX_FUZZ_SEEDS", "6"))))   # (more seeds: a hunt, not a gate)
+@pytest.mark.parametrize("tdim,n,degree", [(3, 9, 1), (2, 26, 1), (3, 6, 2), (2, 14, 2)])
+def test_rough_level_sets_match_oracle(oracle, tdim, n, degree, seed):
+    """Level sets with many components and features below the mesh size (a sum of random sinusoids: islands, holes, thin
+    necks, cells cut next to cells cut) on box and scrambled meshes: the whole cut Poisson system against the oracle --
+    classification and located lists bit for bit, rules, ghost facets, CSR pattern bit for bit, values / right-hand side to
+    1e-12, active cells and deactivated rows."""
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    O = oracle
+    rng = np.random.default_rng(1000 * tdim + 10 * degree + seed)
+    om = scrambled_mesh(O, tdim, n, seed=seed) if seed % 2 else O.mesh_box(tdim, n)
+    x = om.x[:, :tdim]
+    phi = np.full(x.shape[0], rng.uniform(-0.15, 0.15))
+    for _ in range(4):
+        k = rng.uniform(2.0, 9.0, size=tdim)
+        phi += rng.uniform(0.2, 0.5) * np.prod(np.sin(k * x + rng.uniform(0.0, 6.28, size=tdim)), axis=1)
+    mesh = cfx.Mesh.from_arrays(tdim, om.x, om.conn)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    cd = cfx.cut(cfx.Function(Vphi, phi))
+    dom = O.classify(om.conn, phi)
+    assert np.array_equal(cd.domain(), dom)
+    if degree == 1:
+        ref = oracle_poisson(O, om, phi, order=3)
+        V = Vphi
+        s = poisson.build_forms(V, cd, order=3)
+        assert np.array_equal(s.ghost_facets.rows.reshape(-1, 4), ref["ghost"].reshape(-1, 4))
+        A = cfx.fem.assemble_matrix(s.a)
+        b = cfx.fem.assemble_vector(s.L)
+        assert np.array_equal(A.indptr, ref["indptr"]) and np.array_equal(A.indices, ref["indices"])
+        assert rel_err(A.data, ref["values"]) < RTOL and rel_err(b, ref["b"]) < RTOL
+        act = cfx.fem.active_domain(s.a)
+        assert np.array_equal(act.active_cells, ref["active"]) and np.array_equal(act.inactive_dofs, ref["inactive"])
+        return
+    # degree 2 (hashed pattern rows, closed-form rows, moments): stiffness + mass on inside and cut cells + ghost penalty
+    dofmap, ndofs = cfx.lagrange_dofmap(tdim, om.conn, om.nnodes, 2)
+    oV = O.Space(dofmap, ndofs, 2, 1)
+    V = cfx.FunctionSpace(mesh, 2, dofmap=dofmap, ndofs=ndofs)
+    inside = O.locate_entities(dom, "phi<0")
+    vol = O.runtime_quadrature(om, om.conn, phi, dom, "phi<0", 3)
+    ghost = O.ghost_penalty_facets(om, dom, "phi<0")
+    oint = [O.Integral(O.CELL, O.K_STIFFNESS, entities=inside, rules=vol, qdegree=2),
+            O.Integral(O.CELL, O.K_MASS, entities=inside, rules=vol, qdegree=4)]
+    if len(ghost):
+        oint.append(O.Integral(O.INTERIOR_FACET, O.K_GHOST_GRADJUMP, entities=ghost, params=(0.1,), qdegree=2))
+    ip, ix = O.create_sparsity(om, oV, oint)
+    want = O.assemble_matrix(om, oV, oint, ip, ix)
+    fem = cfx.fem
+    g_in = cfx.locate_entities_device(cd, "phi<0")
+    g_vol = cfx.runtime_quadrature(cd, "phi<0", 3)
+    g_ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+    ints = [fem.Integral(fem.STIFFNESS, cells=g_in, rules=g_vol, qdegree=2), fem.Integral(fem.MASS, cells=g_in, rules=g_vol, qdegree=4)]
+    if g_ghost.size > 0:
+        ints.append(fem.Integral(fem.GHOST_GRADJUMP, facets=g_ghost, params=(0.1,), qdegree=2))
+    A = fem.assemble_matrix(fem.form(ints, V))
+    assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
+    assert rel_err(A.data, want) < RTOL

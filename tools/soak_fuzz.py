@@ -16,9 +16,14 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(seed)
 
 
+vary = {"ghost": True, "order": 4, "peek": False}   # CFX_FUZZ_VARY=1: the body of the step changes from step to step
+
+
 def build(V, cd, kind):
     if kind == "poisson":
-        s = poisson.build_forms(V, cd, order=4)
+        s = poisson.build_forms(V, cd, order=vary["order"], ghost_penalty=vary["ghost"])
+        if vary["peek"]:
+            _ = s.inside_cells.size + s.volume_rules.num_rules     # sizes asked for in mid-step: resolved on demand
         return s.a, s.L
     inside = cfx.locate_entities_device(cd, "phi<0")
     vol = cfx.runtime_quadrature(cd, "phi<0", 2)
@@ -47,9 +52,14 @@ if os.environ.get("CFX_FUZZ_MARGIN"):      # e.g. 0.97: capacities BELOW the pre
     cfx.set_step_margin(float(os.environ["CFX_FUZZ_MARGIN"]), 0)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"    # larger meshes: the row tiles, the culled classification and the bulk rows engage
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count / scan / write triples (> 512 tiles per site)
-for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
-                                  (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled")]:
+for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 40, 1, 1, "poisson+rough"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
+                                  (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled"),
+                                  (3, 12, 1, 1, "poisson+rough"), (2, 30, 1, 1, "poisson+rough"), (3, 7, 2, 1, "poisson+rough"),
+                                  (3, 9, 1, 3, "elasticity+rough")]:
     x, conn = cfx.box_mesh_arrays(tdim, n)
+    rough = kind.endswith("+rough")          # a level set with islands, holes and necks whose phases wander (no sphere)
+    if rough:
+        kind = kind.split("+")[0]
     if kind.endswith("+scrambled"):
         # no locality left: vertices and cells renumbered at random, local vertex order of every cell permuted
         kind = kind.split("+")[0]
@@ -64,7 +74,7 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
     xt = torch.tensor(x[:, :tdim].copy(), device=dev)
     phi = torch.empty(x.shape[0], device=dev, dtype=torch.float64)
     f = cfx.Function(Vphi, phi)
-    key = f"fuzz-{tdim}-{n}-{degree}-{bs}-{kind}"
+    key = f"fuzz-{tdim}-{n}-{degree}-{bs}-{kind}{'-rough' if rough else ''}"
     cfx.forget_step_history(key)
     sa, sb = {"cd": None}, {"cd": None}
     c, R, redo, empty, t0 = np.full(tdim, 0.5), 0.3, 0, 0, time.perf_counter()
@@ -73,7 +83,21 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
         R = float(np.clip(R + rng.normal(0.0, 0.03) + 0.05 * (0.3 - R), 0.05, 0.9))
         if k % 37 == 36: R = -0.05          # no domain at all
         if k % 53 == 52: R = 2.0            # the whole mesh inside: no cut cell
-        phi.copy_(torch.linalg.norm(xt - torch.tensor(c, device=dev), dim=1) - R)
+        if rough:
+            if k == 0:
+                kv = [torch.tensor(rng.uniform(2.0, 9.0, size=tdim), device=dev) for _ in range(3)]
+                ph = [rng.uniform(0.0, 6.28, size=tdim) for _ in range(3)]
+            val = torch.full((x.shape[0],), 0.3 - R, device=dev, dtype=torch.float64)
+            for q in range(3):
+                ph[q] = ph[q] + rng.normal(0.0, 0.08, tdim)
+                val += 0.35 * torch.prod(torch.sin(kv[q] * xt + torch.tensor(ph[q], device=dev)), dim=1)
+            if R in (-0.05, 2.0):
+                val = val * 0.0 + (1.0 if R < 0 else -1.0)      # no domain / the whole mesh
+            phi.copy_(val)
+        else:
+            phi.copy_(torch.linalg.norm(xt - torch.tensor(c, device=dev), dim=1) - R)
+        if os.environ.get("CFX_FUZZ_VARY") == "1":
+            vary.update(ghost=bool(rng.integers(0, 4) > 0), order=int(rng.choice([2, 3, 4])), peek=bool(rng.integers(0, 5) == 0))
         info = {}
         try:
             A1, b1, d1 = cfx.run_step(lambda: one(V, f, kind, sa), key=key, info=info)

@@ -42,7 +42,11 @@ extern "C" {
 #define CFX_ERR_HIP (-4)              /* HIP runtime failure / no device      */
 #define CFX_ERR_STEP_VOID (-5)        /* inside cfx_step_begin / cfx_step_end: a count did not fit the capacity taken
                                          from the previous step, the results of the step are void -- call
-                                         cfx_step_end() (it reports redo = 1) and repeat the step          */
+                                         cfx_step_end() (it reports redo = 1) and repeat the step.  ANY call of
+                                         a step may return it: an error raised while the step is void, and every
+                                         size read back to the host after the count overflowed (the read-back
+                                         carries the step's poison word: a total of lengths nobody wrote must not
+                                         size anything)                                                         */
 
 /* ---- classification codes: cutcells::cell::domain as used by
  *      cpp/cutfemx/cut/cut.cpp:292-321 ---------------------------------------- */

@@ -35,6 +35,7 @@ extern thread_local std::string g_last_error;
 // after that point did nothing, and whatever the host then reads back -- an empty active-cell list, say -- is not a
 // property of the problem).  The status of such a call becomes CFX_ERR_STEP_VOID: end the step, repeat it.
 int error_in_step(int code);
+void step_resolve_all(); // inside a step: every count published so far comes to the host in one read-back (cfx_step_resolve)
 
 #define CFX_HIP(expr)                                                                   \
   do                                                                                    \

@@ -225,13 +225,46 @@ __global__ void count_gather_kernel(CountJobs J, int64_t* out)
 
 CountCell::~CountCell() = default;
 
+static void step_resolve_pending()
+{
+  StepState& st = step();
+  if (st.active && !st.pending.empty())
+  {
+    // every count published so far comes to the host (one read-back); the step stays open and later sites publish again
+    int64_t* host = count_mirror();
+    CFX_HIP(hipMemcpyAsync(host, count_pool(), sizeof(int64_t) * 2 * (size_t)st.next_slot, hipMemcpyDeviceToHost, ctx().main_stream));
+    CFX_HIP(hipStreamSynchronize(ctx().main_stream));
+    ++sync_counter();
+    if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back by cfx_step_resolve\n");
+    // (a void step: the published slots were zeroed and later totals mean nothing -- nothing is resolved, the caller ends
+    // the step and repeats it)
+    if (st.spec && host[0] != 0)
+      throw Error(CFX_ERR_STEP_VOID, "the step is void (a count did not fit the capacity taken from the previous step): end it "
+                                     "and repeat it");
+    for (auto& p : st.pending)
+    {
+      if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
+      st.values[p.index] = host[2 * p.cell->slot + 1];
+    }
+    st.pending.clear();
+  }
+}
+
+void step_resolve_all() { step_resolve_pending(); }
+
 int64_t Count::value() const
 {
   if (!cell) return exact_n;
   if (!cell->resolved)
   {
-    cell->value = read_scalar(count_pool() + 2 * cell->slot);
-    cell->resolved = true;
+    // inside the step that published it: every count published so far comes along in the same round trip (the paths
+    // that ask for one size usually ask for the next one right after: 20 -> 16 read-backs per configs[3]-style step)
+    if (step().active) step_resolve_pending();
+    if (!cell->resolved)
+    {
+      cell->value = read_scalar(count_pool() + 2 * cell->slot);
+      cell->resolved = true;
+    }
   }
   return cell->value;
 }
@@ -1317,27 +1350,7 @@ int cfx_step_end(int* redo, int64_t* published, int64_t* read_back)
 int cfx_step_resolve(void)
 {
   CFX_API_BEGIN
-  StepState& st = step();
-  if (st.active && !st.pending.empty())
-  {
-    // every count published so far comes to the host (one read-back); the step stays open and later sites publish again
-    int64_t* host = count_mirror();
-    CFX_HIP(hipMemcpyAsync(host, count_pool(), sizeof(int64_t) * 2 * (size_t)st.next_slot, hipMemcpyDeviceToHost, ctx().main_stream));
-    CFX_HIP(hipStreamSynchronize(ctx().main_stream));
-    ++sync_counter();
-    if (ctx().trace_sync) fprintf(stderr, "cutfemx_amd: read-back by cfx_step_resolve\n");
-    // (a void step: the published slots were zeroed and later totals mean nothing -- nothing is resolved, the caller ends
-    // the step and repeats it)
-    if (st.spec && host[0] != 0)
-      throw Error(CFX_ERR_STEP_VOID, "the step is void (a count did not fit the capacity taken from the previous step): end it "
-                                     "and repeat it");
-    for (auto& p : st.pending)
-    {
-      if (!p.cell->resolved) { p.cell->value = host[2 * p.cell->slot]; p.cell->resolved = true; }
-      st.values[p.index] = host[2 * p.cell->slot + 1];
-    }
-    st.pending.clear();
-  }
+  cfx::step_resolve_all();
   CFX_API_END
 }
 

@@ -240,6 +240,9 @@ struct Count
   bool pending() const { return cell && !cell->resolved; }
   int64_t cap() const { return cell ? (cell->resolved ? cell->value : cell->cap) : exact_n; } // allocation / grid bound
   int64_t hint() const { return cell ? (cell->resolved ? cell->value : cell->hint) : exact_n; } // best guess of the value
+  // the same number whether the count is still pending or has been read back since: what a cache key may hold (cap()
+  // turns from the capacity into the value when a count is resolved in mid-step)
+  int64_t key() const { return cell ? cell->cap : exact_n; }
   int64_t value() const;        // exact: a pending count is read back now (one counted round trip)
   DevN devn() const;            // what kernels take
   operator DevN() const { return devn(); }

@@ -2178,9 +2178,11 @@ cfx_row_plan& row_plan(cfx_form_s* a)
   for (size_t ii = 0; ii < a->integrals.size(); ++ii)
   {
     const cfx_integral_dev& I = a->integrals[ii];
+    // (Count::key(): a count resolved between the plan of the bilinear form and the look-up of the linear form of the
+    // same step must not change the key -- degree-2 steps built their plan twice, +4.2 ms at configs[3])
     const int64_t ne = I.n_entities.cap();
-    const std::array<int64_t, 7> k{(int64_t)ii, ne > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, ne,
-                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr.cap() : 0,
+    const std::array<int64_t, 7> k{(int64_t)ii, ne > 0 ? (int64_t)(uintptr_t)I.entities.p : 0, ne > 0 ? I.n_entities.key() : 0,
+                                   (int64_t)(uintptr_t)I.rules, I.rules ? I.rules->nr.key() : 0,
                                    ne > 0 ? (int64_t)I.entities_serial : 0, (int64_t)I.rules_serial};
     (I.type == CFX_CELL ? key_cells : key_facets).push_back(k);
   }

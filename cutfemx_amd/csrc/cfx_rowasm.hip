@@ -1215,7 +1215,8 @@ __device__ __forceinline__ int64_t indptr_tile(int64_t nrows, int bs, const uint
       }
       // (the diagonal entries one by one: as 16 B words from the first aligned position on -- t0 is whatever the active
       // rows before the tile add up to -- the kernel ran 0.63 instead of 0.51 ms at 512^3)
-      if (p0 + 8 <= nnz_cap)
+      // (p0 < 0: a void step -- the lengths of marked rows before this tile were never written and summed to garbage)
+      if (p0 >= 0 && p0 + 8 <= nnz_cap)
       {
 #pragma unroll
         for (int q = 0; q < 8; ++q) indices[p0 + q] = (int32_t)(r0 + q);
@@ -1223,7 +1224,7 @@ __device__ __forceinline__ int64_t indptr_tile(int64_t nrows, int bs, const uint
       else
       {
         for (int q = 0; q < 8; ++q)
-          if (p0 + q + 1 <= nnz_cap) indices[p0 + q] = (int32_t)(r0 + q);
+          if (p0 + q >= 0 && p0 + q + 1 <= nnz_cap) indices[p0 + q] = (int32_t)(r0 + q);
       }
       return t0 + kTile;
     }
@@ -1255,7 +1256,7 @@ __device__ __forceinline__ int64_t indptr_tile(int64_t nrows, int bs, const uint
     const int64_t p = s_v[i];
     indptr[R] = p;
     const int64_t dof = R / bs;
-    if (!rowmark[dof] && p + bs <= nnz_cap)
+    if (!rowmark[dof] && p >= 0 && p + bs <= nnz_cap)
       for (int b = 0; b < bs; ++b) indices[p + b] = (int32_t)(dof * bs + b);
   }
   return t0 + total;

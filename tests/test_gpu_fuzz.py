@@ -67,8 +67,10 @@ def test_degenerate_level_sets_match_oracle(oracle, tdim, n, seed):
         assert np.max(np.abs(R.points - want.points), initial=0.0) < 1e-13
 
 
-@pytest.mark.parametrize("tdim,n,degree,bs", [(3, 8, 1, 1), (2, 16, 1, 1), (3, 5, 2, 1), (3, 6, 1, 3), (3, 40, 1, 1), (3, 20, 2, 1)])
-def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree, bs):
+@pytest.mark.parametrize("tdim,n,degree,bs,margin", [(3, 8, 1, 1, None), (2, 16, 1, 1, None), (3, 5, 2, 1, None), (3, 6, 1, 3, None),
+                                                     (3, 40, 1, 1, None), (3, 20, 2, 1, None),
+                                                     (3, 8, 1, 1, 0.98), (3, 24, 1, 1, 0.97), (3, 6, 2, 1, 0.98)])
+def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree, bs, margin):
     """Differential run (tools/soak_fuzz.py is the long form): a level set that wanders, breathes, leaves the mesh and
     swallows it; every step is run as a sync-free step (sizes from the previous step, voided and repeated when they do
     not fit, python/demo/demo_moving_poisson.py:53-90) and as the plain sequence -- the CSR pattern must agree bit for
@@ -81,6 +83,14 @@ def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree,
     fem = cfx.fem
     rng = np.random.default_rng(17 * tdim + n)
     x, conn = cfx.box_mesh_arrays(tdim, n)
+    if margin is not None:
+        # capacities BELOW the previous counts (nearly every speculative pass is void) on a mesh without locality: vertices
+        # and cells renumbered at random (tools/soak_fuzz.py seed 31 faulted here: a row-pointer pass over garbage lengths)
+        pv = rng.permutation(x.shape[0])
+        inv = np.empty_like(pv)
+        inv[pv] = np.arange(pv.size)
+        x = x[pv]
+        conn = np.ascontiguousarray(inv[conn][rng.permutation(conn.shape[0])]).astype(np.int32)
     mesh = cfx.Mesh.from_arrays(tdim, x, conn)
     Vphi = cfx.FunctionSpace(mesh, 1)
     V = Vphi if (degree == 1 and bs == 1) else cfx.FunctionSpace(mesh, degree, bs=bs)
@@ -110,10 +120,21 @@ def test_wandering_level_set_in_steps_equals_the_plain_sequence(tdim, n, degree,
         b = fem.assemble_vector(L) if L is not None else None
         return A, b, fem.deactivate_outside(A, b, fem.active_domain(a))
 
-    key = f"test-fuzz-{tdim}-{n}-{degree}-{bs}"
+    key = f"test-fuzz-{tdim}-{n}-{degree}-{bs}-{margin}"
     cfx.forget_step_history(key)
+    if margin is not None:
+        cfx.set_step_margin(margin, 0)
     sa, sb = {"cd": None}, {"cd": None}
     c, R, compared, refused = np.full(tdim, 0.5), 0.3, 0, 0
+    try:
+        _wander(cfx, rng, tdim, xt, phi, one, sa, sb, key, c, R)
+    finally:
+        cfx.set_step_margin()
+
+
+def _wander(cfx, rng, tdim, xt, phi, one, sa, sb, key, c, R):
+    import torch
+    compared = refused = 0
     for k in range(48):
         c = np.clip(c + rng.normal(0.0, 0.04, tdim) + 0.05 * (0.5 - c), 0.0, 1.0)
         R = float(np.clip(R + rng.normal(0.0, 0.04) + 0.05 * (0.3 - R), 0.05, 0.9))

@@ -145,6 +145,8 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t shm
     hipLaunchKernelGGL(kernel, grid, block, shmem, c.stream, args...);
   }
   CFX_HIP(hipGetLastError());
+  static const bool sync_each = getenv("CFX_LAUNCH_SYNC") != nullptr; // diagnostics: a fault surfaces at its own launch
+  if (sync_each) CFX_HIP(hipStreamSynchronize(c.stream));
 }
 
 // grid of one-wavefront blocks whose kernel loops `for (blk = blockIdx.x; ...; blk += gridDim.x)`
@@ -227,6 +229,7 @@ struct CountCell
   int64_t hint = 0;       // the same site's value in the previous step (what host-side heuristics compare)
   int64_t value = 0;      // exact value once resolved
   bool resolved = true;
+  uint64_t step_serial = 0; // the speculative step that published it (its pool slot is meaningful while that step is open)
   ~CountCell();
 };
 

@@ -2487,6 +2487,15 @@ void active_lists(cfx_active_s* d)
   cfx_row_plan& plan = *d->plan;
   const int64_t nc = V->mesh->ncells;
   const uint8_t* cell_ind = plan.cellmark.p;
+  if (plan.nfacets.value() > 0 && !plan.facet_rows.owned)
+  {
+    // the facet rows of a plan with one facet list ARE the form's entity array: gone with the list's owner (the form and
+    // the ghost-facet handle of a step that has ended) -- say so instead of reading a recycled block
+    for (const auto& k : plan.key_facets)
+      if (k[1] == (int64_t)(uintptr_t)plan.facet_rows.p && k[5] != 0 && dev_block_serial(plan.facet_rows.p) != (uint64_t)k[5])
+        throw Error(CFX_ERR_RUNTIME, "stale active domain: the facet list of the form it was made from was released; ask for "
+                                     "the lists while the form is alive (the Python wrapper keeps it)");
+  }
   if (plan.nfacets.value() > 0)
   {
     // the cells of the facet integrals are almost always cells of the cell integrals too (the ghost-penalty band

@@ -666,10 +666,16 @@ __device__ __forceinline__ void facet_unit_keys(const int32_t* __restrict__ rows
   }
 }
 
+// (nkeys: entries of `counts` = capacity of the special-row list; poison: the step's poison word or null.  The facet
+// count of a form with several facet lists is exact on the host, so it does not drop to 0 when a LATER site -- the row
+// lists, whose capacity sizes `counts` -- makes the step void: positions beyond the capacity are skipped and a void
+// step is left alone (the DG loop of tools/soak_fuzz.py under forced overflow)
 __global__ void __launch_bounds__(kBlock) facet_dof_count_kernel(DevN nf_d, const int32_t* __restrict__ rows,
                                                                  const int32_t* __restrict__ dofmap, int nd,
-                                                                 const int32_t* __restrict__ pos, int32_t* counts)
+                                                                 const int32_t* __restrict__ pos, int32_t* counts,
+                                                                 int64_t nkeys, const int64_t* __restrict__ poison)
 {
+  if (poison != nullptr && *poison != 0) return;
   __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
@@ -683,7 +689,7 @@ __global__ void __launch_bounds__(kBlock) facet_dof_count_kernel(DevN nf_d, cons
     for (int j = 0; j < kFacetMaxNd; ++j)
     {
       int rank;
-      if (key[j] >= 0) (void)adj_lds_insert(s_key, s_cnt, key[j], rank);
+      if (key[j] >= 0 && key[j] < nkeys) (void)adj_lds_insert(s_key, s_cnt, key[j], rank);
     }
   }
   __syncthreads();
@@ -695,8 +701,9 @@ __global__ void __launch_bounds__(kBlock) facet_dof_fill_kernel(DevN nf_d, const
                                                                 const int32_t* __restrict__ dofmap, int nd,
                                                                 const int32_t* __restrict__ pos,
                                                                 const int64_t* __restrict__ offs, int32_t* cursor,
-                                                                int32_t* facets)
+                                                                int32_t* facets, int64_t nkeys, const int64_t* __restrict__ poison)
 {
+  if (poison != nullptr && *poison != 0) return;
   __shared__ int32_t s_key[kAdjSlots], s_cnt[kAdjSlots];
   for (int k = threadIdx.x; k < kAdjSlots; k += kBlock) { s_key[k] = -1; s_cnt[k] = 0; }
   __syncthreads();
@@ -712,7 +719,10 @@ __global__ void __launch_bounds__(kBlock) facet_dof_fill_kernel(DevN nf_d, const
     facet_unit_keys(rows, dofmap, nd, pos, unit, key);
 #pragma unroll
     for (int j = 0; j < kFacetMaxNd; ++j)
+    {
+      if (key[j] >= nkeys) key[j] = -1;
       if (key[j] >= 0) slot[j] = adj_lds_insert(s_key, s_cnt, key[j], rank[j]);
+    }
   }
   __syncthreads();
   // (cursor[q] holds the row's count from the count pass: slots are handed out from the back, so the counters need no
@@ -2593,12 +2603,12 @@ cfx_row_plan& row_plan(cfx_form_s* a)
       const int per = facet_units_per_block(nd);
       const dim3 run_grid((unsigned)((2 * nf_cap + per - 1) / per));
       launch("facet_dof_count", facet_dof_count_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
-             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p);
+             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, fcount.p, ns_cap, step_poison());
       P.d2f_offsets.alloc(ns_cap + 1);
       exclusive_scan(fcount.p, P.d2f_offsets.p, ns_cap);
       P.d2f.alloc(npairs);
       launch("facet_dof_fill", facet_dof_fill_kernel, run_grid, dim3(kBlock), 0, P.nfacets,
-             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p);
+             P.facet_rows.p, V->dofmap.p, nd, P.special_pos.p, P.d2f_offsets.p, fcount.p, P.d2f.p, ns_cap, step_poison());
     }
   }
   // rank structure of every uncut entity list: entity index of cell c =

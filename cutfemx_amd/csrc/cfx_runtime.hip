@@ -165,6 +165,7 @@ struct StepState
   struct Positive { std::shared_ptr<CountCell> cell; int code; std::string message; };
   std::vector<Positive> positives;
   int next_err = 1, next_slot = kCountFirstSlot;
+  uint64_t serial = 0;               // of this step (cells remember it)
   int64_t published = 0, read_back = 0; // sites of this step by kind (diagnostics)
   // state kept ACROSS steps that this step wrote while speculative (a space's remembered pattern): undone when the
   // step turns out void or is aborted -- what a void step built is partial or uninitialised by design
@@ -272,7 +273,15 @@ int64_t Count::value() const
 DevN Count::devn() const
 {
   if (!cell) return DevN(exact_n);
-  if (cell->resolved) return DevN(cell->value);
+  // A count that was read back in mid-step (a size asked for by the caller, a path that sizes host-side work) still
+  // follows its slot while the step that published it is open: the step may turn void AFTER the read-back, and a
+  // kernel driven by the exact length would then fill arrays whose capacity belongs to the site that overflowed
+  // (the DG loop of tools/soak_fuzz.py: rule points written behind their 528-entry capacity).  min(slot, value) is
+  // the value while the step is sound and 0 once it is void.
+  if (cell->resolved)
+    return (step().active && step().spec && cell->step_serial == step().serial && cell->slot >= 0)
+               ? DevN(cell->value, count_pool() + 2 * cell->slot)
+               : DevN(cell->value);
   return DevN(cell->cap, count_pool() + 2 * cell->slot);
 }
 
@@ -461,6 +470,7 @@ CountPlan::CountPlan(int n_, const char* const* names_, const CountSource* src_)
     const int64_t prev = h.values[st.cursor + k];
     auto cell = std::make_shared<CountCell>();
     cell->slot = st.next_slot++;
+    cell->step_serial = st.serial;
     // (a list that was empty stays empty or the step is void: the host then takes the branches of the recorded step)
     if (J.mode[k] == kCountSizeClass)
       cell->cap = prev <= 32 ? 32 : (prev <= 64 ? 64 : (prev <= 128 ? 128 : (prev <= 256 ? 256 : 512)));
@@ -1286,6 +1296,8 @@ int cfx_step_begin(const char* key)
   require(!st.active, CFX_ERR_RUNTIME, "cfx_step_begin: the previous step was not ended");
   require(!ctx().overlap, CFX_ERR_RUNTIME, "cfx_step_begin inside an overlap section");
   st = StepState();
+  static uint64_t step_counter = 0;
+  st.serial = ++step_counter;
   st.key = key ? key : "";
   st.active = true;
   const char* off = getenv("CFX_STEP_SPECULATE");

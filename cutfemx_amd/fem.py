@@ -840,8 +840,10 @@ def tabulate_entity(a: CutForm, integral: int, index: int, use_rule: bool) -> np
 class ActiveDomain:
     """cutfemx.fem.ActiveDomain (cpp/cutfemx/fem/deactivate.h:387-400)."""
 
-    def __init__(self, handle, V):
-        self._h, self.function_space = handle, V
+    def __init__(self, handle, V, form=None):
+        # (the lists of the domain are compacted on first request from the plan of `form`, whose facet rows alias the
+        # form's own entity arrays: the form -- and with it the lists its integrals pin -- lives as long as this object)
+        self._h, self.function_space, self._form = handle, V, form
 
     def _view(self):
         """(active cells, count, inactive dofs, count): the counts are capacities while the cutfemx_amd.step that made
@@ -882,7 +884,7 @@ class ActiveDomain:
 def active_domain(a: CutForm) -> ActiveDomain:
     h = C.c_void_p()
     _lib.check(_lib.lib().cfx_active_domain(a._h, C.byref(h)))
-    return ActiveDomain(h, a.function_space)
+    return ActiveDomain(h, a.function_space, a)
 
 
 def deactivate_outside(A: MatrixCSR | None, b, domain: ActiveDomain, diagonal: float = 1.0,

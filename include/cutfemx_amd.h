@@ -525,7 +525,9 @@ int cfx_integrand_compile_bs(int kernel_id, int tdim, int ndofs_cell, int bs);
 /* active_domain(): the two indicators (active cells, active dofs) are the marks of the form's row plan; deactivation
  * works from the marks.  The LISTS (ActiveDomain::active_cells / inactive_dofs) are compacted on the first
  * cfx_active_view call that asks for them; with active_cells = n_active = inactive_dofs = NULL the call returns the
- * number of inactive dofs alone, which needs no list. */
+ * number of inactive dofs alone, which needs no list.  The lists are made from the form's plan, whose facet rows alias
+ * the form's own interior-facet entity array: ask for them while the form and that array are alive (a released list
+ * is detected and refused with CFX_ERR_RUNTIME; the deactivation calls themselves need nothing but the marks). */
 int cfx_active_domain(cfx_form_t a, cfx_active_t* out);
 int cfx_active_view(cfx_active_t d, const int32_t** active_cells, int64_t* n_active,
                     const int32_t** inactive_dofs, int64_t* n_inactive);

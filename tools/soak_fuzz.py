@@ -16,6 +16,10 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(seed)
 
 
+class SkipStep(Exception):
+    pass
+
+
 vary = {"ghost": True, "order": 4, "peek": False}   # CFX_FUZZ_VARY=1: the body of the step changes from step to step
 
 
@@ -35,6 +39,20 @@ def build(V, cd, kind):
 
 
 def one(V, f, kind, state):
+    if kind == "dg":
+        # the cut DG system on the facet hosts of the skeleton (python/demo/demo_dg_poisson.py): its own cuts every step
+        g = poisson.build_dg_forms(f, 1)
+        A = fem.assemble_matrix(g.a)
+        b = fem.assemble_vector(g.L)
+        return A, b, fem.deactivate_outside(A, b, fem.active_domain(g.a))
+    if kind == "extension":
+        cd = cfx.cut(f)
+        agg = cfx.extensions.create_cell_aggregation(cd, "phi<0", 0.6, allow_rootless=True)
+        if agg.num_pairs == 0:
+            raise SkipStep()      # (nothing to penalise)
+        A = cfx.extensions.extension_penalty_matrix(V, cd, agg, 2.5, 2)
+        s = poisson.build_forms(V, cd, order=3)
+        return A, None, fem.active_domain(s.a)
     if state.get("cd") is None:
         state["cd"] = cfx.cut(f)
     else:
@@ -55,7 +73,10 @@ huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count 
 for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 40, 1, 1, "poisson+rough"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
                                   (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled"),
                                   (3, 12, 1, 1, "poisson+rough"), (2, 30, 1, 1, "poisson+rough"), (3, 7, 2, 1, "poisson+rough"),
-                                  (3, 9, 1, 3, "elasticity+rough")]:
+                                  (3, 9, 1, 3, "elasticity+rough"), (2, 18, 1, 1, "dg"), (3, 5, 1, 1, "dg"), (2, 22, 1, 1, "extension")]:
+    if os.environ.get("CFX_FUZZ_ONLY") and os.environ["CFX_FUZZ_ONLY"] not in kind:
+        continue
+    rng = np.random.default_rng([seed, tdim, n, degree, bs, len(kind)])     # (every configuration its own stream: CFX_FUZZ_ONLY replays it)
     x, conn = cfx.box_mesh_arrays(tdim, n)
     rough = kind.endswith("+rough")          # a level set with islands, holes and necks whose phases wander (no sphere)
     if rough:
@@ -102,6 +123,8 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
         try:
             A1, b1, d1 = cfx.run_step(lambda: one(V, f, kind, sa), key=key, info=info)
             A2, b2, d2 = one(V, f, kind, sb)
+        except SkipStep:
+            continue
         except Exception as e:              # noqa: BLE001 -- reported, the run goes on with fresh handles
             sa, sb = {"cd": None}, {"cd": None}
             cfx.forget_step_history(key)

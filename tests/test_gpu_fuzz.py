@@ -221,3 +221,57 @@ def test_rough_level_sets_match_oracle(oracle, tdim, n, degree, seed):
     A = fem.assemble_matrix(fem.form(ints, V))
     assert np.array_equal(A.indptr, ip) and np.array_equal(A.indices, ix)
     assert rel_err(A.data, want) < RTOL
+
+
+@pytest.mark.parametrize("tdim,n,margin", [(2, 18, None), (3, 5, None), (3, 5, 0.98), (2, 14, 0.98)])
+def test_wandering_dg_system_in_steps_equals_the_plain_sequence(tdim, n, margin):
+    """The cut DG system (python/demo/demo_dg_poisson.py: facet-hosted rules, several facet integrals, a space in which
+    every active row is an interface row) inside sync-free steps against the plain sequence; with `margin` the capacities
+    lie BELOW the previous counts, so that nearly every speculative pass is void.  tools/soak_fuzz.py found two faults
+    here: a count read back in mid-step no longer dropped to 0 when the step turned void later (rule points written
+    behind their capacity), and the joined facet lists of a form with several facet integrals have an exact length --
+    the facet incidence indexed a counter array sized by the capacity of the row lists."""
+    import torch
+
+    import cutfemx_amd as cfx
+    from cutfemx_amd import poisson
+    fem = cfx.fem
+    rng = np.random.default_rng(5 * tdim + n)
+    x, conn = cfx.box_mesh_arrays(tdim, n)
+    mesh = cfx.Mesh.from_arrays(tdim, x, conn)
+    Vphi = cfx.FunctionSpace(mesh, 1)
+    xt = torch.tensor(x[:, :tdim].copy(), device="cuda")
+    phi = torch.empty(x.shape[0], device="cuda", dtype=torch.float64)
+    f = cfx.Function(Vphi, phi)
+
+    def one():
+        g = poisson.build_dg_forms(f, 1)
+        A = fem.assemble_matrix(g.a)
+        b = fem.assemble_vector(g.L)
+        return A, b, fem.deactivate_outside(A, b, fem.active_domain(g.a))
+
+    key = f"test-fuzz-dg-{tdim}-{n}-{margin}"
+    cfx.forget_step_history(key)
+    if margin is not None:
+        cfx.set_step_margin(margin, 0)
+    try:
+        c, R, compared = np.full(tdim, 0.5), 0.3, 0
+        for k in range(40):
+            c = np.clip(c + rng.normal(0.0, 0.04, tdim) + 0.05 * (0.5 - c), 0.0, 1.0)
+            R = float(np.clip(R + rng.normal(0.0, 0.04) + 0.05 * (0.3 - R), 0.12, 0.45))
+            phi.copy_(torch.linalg.norm(xt - torch.tensor(c, device="cuda"), dim=1) - R)
+            try:
+                A1, b1, d1 = cfx.run_step(one, key=key)
+            except ValueError as e:
+                assert "no active background cells" in str(e) and float(phi.min()) > 0.0, (k, R, str(e))
+                cfx.forget_step_history(key)
+                continue
+            A2, b2, d2 = one()
+            assert A1.nnz == A2.nnz and np.array_equal(A1.indptr, A2.indptr) and np.array_equal(A1.indices, A2.indices), (k, R)
+            assert rel_err(A1.data, A2.data) < RTOL and rel_err(np.asarray(b1), np.asarray(b2)) < RTOL, (k, R)
+            assert np.array_equal(d1.inactive_dofs, d2.inactive_dofs), (k, R)
+            compared += 1
+            del A1, b1, d1, A2, b2, d2
+        assert compared >= 30, compared
+    finally:
+        cfx.set_step_margin()

@@ -45,6 +45,36 @@ def one(V, f, kind, state):
         A = fem.assemble_matrix(g.a)
         b = fem.assemble_vector(g.L)
         return A, b, fem.deactivate_outside(A, b, fem.active_domain(g.a))
+    if kind == "stokes":
+        # cut Stokes blocks on (P2 vector, P1) with both ghost penalties, deactivated and merged into one matrix
+        # (python/tests/test_assembly_stokes.py:98-142): rectangular forms, block helpers
+        VU, VP = V
+        if state.get("cd") is None:
+            state["cd"] = cfx.cut(f)
+        else:
+            cfx.update(state["cd"])
+        cd = state["cd"]
+        inside = cfx.locate_entities_device(cd, "phi<0")
+        vol = cfx.runtime_quadrature(cd, "phi<0", 4)
+        ghost = cfx.ghost_penalty_facets(cd, "phi<0")
+        i00 = [fem.Integral(fem.STIFFNESS, cells=inside, rules=vol, qdegree=2)]
+        # (no branch on ghost.size that changes the FORM: inside a step a size is a capacity, and an integral over a list
+        # that turns out empty adds nothing -- but replacing it by another integral would)
+        i11 = [fem.Integral(fem.MASS, cells=inside, rules=vol, params=(0.0,), qdegree=2)]
+        if ghost.size > 0:
+            i00.append(fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(0.1,), qdegree=2))
+            i11.append(fem.Integral(fem.GHOST_GRADJUMP, facets=ghost, params=(-0.05, 3.0), qdegree=2))
+        a00 = fem.form(i00, VU)
+        a01 = fem.form([fem.Integral(fem.DIV_TEST, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VU, trial_space=VP)
+        a10 = fem.form([fem.Integral(fem.DIV_TRIAL, cells=inside, rules=vol, params=(-1.0,), qdegree=3)], VP, trial_space=VU)
+        a11 = fem.form(i11, VP)
+        blocks = [[fem.assemble_matrix(a00), fem.assemble_matrix(a01)], [fem.assemble_matrix(a10), fem.assemble_matrix(a11)]]
+        dom_p = fem.active_domain(fem.form([fem.Integral(fem.MASS, cells=inside, rules=vol, qdegree=2)], VP))
+        doms = [fem.active_domain(a00), dom_p]
+        fem.deactivate_outside_blocks(blocks, doms)
+        state["dbg"] = dict(block_nnz=[b.nnz for row in blocks for b in row], n_ghost=ghost.size, n_inside=inside.size,
+                            n_rules=vol.num_rules)
+        return fem.merge_blocks(blocks), None, doms[0]
     if kind == "extension":
         cd = cfx.cut(f)
         agg = cfx.extensions.create_cell_aggregation(cd, "phi<0", 0.6, allow_rootless=True)
@@ -73,7 +103,8 @@ huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count 
 for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 40, 1, 1, "poisson+rough"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
                                   (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled"),
                                   (3, 12, 1, 1, "poisson+rough"), (2, 30, 1, 1, "poisson+rough"), (3, 7, 2, 1, "poisson+rough"),
-                                  (3, 9, 1, 3, "elasticity+rough"), (2, 18, 1, 1, "dg"), (3, 5, 1, 1, "dg"), (2, 22, 1, 1, "extension")]:
+                                  (3, 9, 1, 3, "elasticity+rough"), (2, 18, 1, 1, "dg"), (3, 5, 1, 1, "dg"), (2, 22, 1, 1, "extension"),
+                                  (2, 12, 2, 2, "stokes"), (3, 5, 2, 3, "stokes")]:
     if os.environ.get("CFX_FUZZ_ONLY") and os.environ["CFX_FUZZ_ONLY"] not in kind:
         continue
     rng = np.random.default_rng([seed, tdim, n, degree, bs, len(kind)])     # (every configuration its own stream: CFX_FUZZ_ONLY replays it)
@@ -92,6 +123,8 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
     mesh = cfx.Mesh.from_arrays(tdim, x, conn)
     Vphi = cfx.FunctionSpace(mesh, 1)
     V = Vphi if (degree == 1 and bs == 1) else cfx.FunctionSpace(mesh, degree, bs=bs)
+    if kind == "stokes":
+        V = (cfx.FunctionSpace(mesh, 2, bs=tdim), Vphi)
     xt = torch.tensor(x[:, :tdim].copy(), device=dev)
     phi = torch.empty(x.shape[0], device=dev, dtype=torch.float64)
     f = cfx.Function(Vphi, phi)
@@ -147,7 +180,8 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
         ok = ok and np.array_equal(d1.inactive_dofs, d2.inactive_dofs)
         if not ok:
             bad += 1
-            print(f"{key} step {k} R={R:.3f}: in-step result differs from the plain sequence (nnz {A1.nnz} / {A2.nnz})", flush=True)
+            print(f"{key} step {k} R={R:.3f}: in-step result differs from the plain sequence (nnz {A1.nnz} / {A2.nnz}) "
+                  f"{sa.get('dbg')} / {sb.get('dbg')} passes {info.get('passes')}", flush=True)
         del A1, b1, d1, A2, b2, d2
     m = _lib.memory_stats()
     print(f"{key}: {steps} steps, {redo} repeated, {empty} with no domain (refused as the reference does), {bad} bad so far, {1e3 * (time.perf_counter() - t0) / steps:.2f} ms per double step, "

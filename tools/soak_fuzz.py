@@ -16,6 +16,9 @@ dev = torch.device("cuda:0")
 rng = np.random.default_rng(seed)
 
 
+RTC = {}
+
+
 class SkipStep(Exception):
     pass
 
@@ -75,6 +78,28 @@ def one(V, f, kind, state):
         state["dbg"] = dict(block_nnz=[b.nnz for row in blocks for b in row], n_ghost=ghost.size, n_inside=inside.size,
                             n_rules=vol.num_rules)
         return fem.merge_blocks(blocks), None, doms[0]
+    if kind == "rtc":
+        # the Poisson system with its stiffness and Nitsche integrands REGISTERED from source (hipRTC): the generated-kernel
+        # path of the reference (Form.h:59-75) inside steps
+        if "ids" not in RTC:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+            from test_user_integrands import NITSCHE_SRC, STIFFNESS_SRC
+            RTC["ids"] = (fem.register_integrand("user_stiffness", STIFFNESS_SRC), fem.register_integrand("user_nitsche", NITSCHE_SRC))
+        ks, kn = RTC["ids"]
+        if state.get("cd") is None:
+            state["cd"] = cfx.cut(f)
+        else:
+            cfx.update(state["cd"])
+        s0 = poisson.build_forms(V, state["cd"], order=3)
+        ints = [fem.Integral(ks, cells=s0.inside_cells, rules=s0.volume_rules, qdegree=0),
+                fem.Integral(kn, rules=s0.interface_rules, point_data=s0.normals, params=(40.0,))]
+        if s0.ghost_facets is not None and s0.ghost_facets.size > 0:
+            ints.append(fem.Integral(fem.GHOST_GRADJUMP, facets=s0.ghost_facets, params=(0.1,), qdegree=0))
+        a = fem.form(ints, V)
+        A = fem.create_matrix(a)
+        fem.assemble_matrix(a, A=A)
+        b = fem.assemble_vector(s0.L)
+        return A, b, fem.deactivate_outside(A, b, fem.active_domain(a))
     if kind == "extension":
         cd = cfx.cut(f)
         agg = cfx.extensions.create_cell_aggregation(cd, "phi<0", 0.6, allow_rootless=True)
@@ -104,7 +129,7 @@ for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "pois
                                   (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled"),
                                   (3, 12, 1, 1, "poisson+rough"), (2, 30, 1, 1, "poisson+rough"), (3, 7, 2, 1, "poisson+rough"),
                                   (3, 9, 1, 3, "elasticity+rough"), (2, 18, 1, 1, "dg"), (3, 5, 1, 1, "dg"), (2, 22, 1, 1, "extension"),
-                                  (2, 12, 2, 2, "stokes"), (3, 5, 2, 3, "stokes")]:
+                                  (2, 12, 2, 2, "stokes"), (3, 5, 2, 3, "stokes"), (3, 8, 1, 1, "rtc"), (2, 16, 1, 1, "rtc")]:
     if os.environ.get("CFX_FUZZ_ONLY") and os.environ["CFX_FUZZ_ONLY"] not in kind:
         continue
     rng = np.random.default_rng([seed, tdim, n, degree, bs, len(kind)])     # (every configuration its own stream: CFX_FUZZ_ONLY replays it)

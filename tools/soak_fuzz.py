@@ -139,7 +139,9 @@ if os.environ.get("CFX_FUZZ_MARGIN"):      # e.g. 0.97: capacities BELOW the pre
     cfx.set_step_margin(float(os.environ["CFX_FUZZ_MARGIN"]), 0)
 big = len(sys.argv) > 3 and sys.argv[3] == "big"    # larger meshes: the row tiles, the culled classification and the bulk rows engage
 huge = len(sys.argv) > 3 and sys.argv[3] == "huge"  # ... and the unfused count / scan / write triples (> 512 tiles per site)
-for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 40, 1, 1, "poisson+rough"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
+for tdim, n, degree, bs, kind in [(3, 136, 1, 1, "poisson"), (3, 56, 2, 1, "poisson")] if huge else [(3, 48, 1, 1, "poisson"), (3, 40, 1, 1, "poisson+rough"), (3, 24, 2, 1, "poisson"), (3, 28, 1, 3, "elasticity"), (2, 200, 1, 1, "poisson"),
+                                  (2, 96, 1, 1, "dg"), (3, 12, 1, 1, "dg"), (3, 10, 2, 3, "stokes"), (2, 60, 2, 2, "stokes"), (3, 24, 1, 1, "rtc"),
+                                  (3, 24, 1, 1, "mls"), (2, 120, 1, 1, "extension")] if big else [(3, 10, 1, 1, "poisson"), (2, 20, 1, 1, "poisson"), (3, 6, 2, 1, "poisson"), (3, 8, 1, 3, "elasticity"),
                                   (2, 14, 2, 1, "poisson"), (3, 8, 1, 1, "poisson+scrambled"), (2, 12, 2, 1, "poisson+scrambled"),
                                   (3, 12, 1, 1, "poisson+rough"), (2, 30, 1, 1, "poisson+rough"), (3, 7, 2, 1, "poisson+rough"),
                                   (3, 9, 1, 3, "elasticity+rough"), (2, 18, 1, 1, "dg"), (3, 5, 1, 1, "dg"), (2, 22, 1, 1, "extension"),
